@@ -1,0 +1,116 @@
+/*
+ * wsnark.h -- C ABI of libwsnark.so: the MI355X-native replacement for the BN128
+ * Groth16 prove hot path of iden3/wasmsnark.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference root, /root/reference in the build container).  The seam is the one the
+ * reference itself has: the three worker commands G1_MULTIEXP / G2_MULTIEXP / CALC_H
+ * (src/bn128.js:102-166), their host wrappers Bn128.g1_multiexp / g2_multiexp / calcH
+ * (src/bn128.js:353-415, 569-578) and Bn128.groth16GenProof (src/bn128.js:580-720).
+ * INTEGRATION.md shows the N-API / ctypes bindings over this header.
+ *
+ * Byte layouts are the reference's (tools/buildpkey.js:57-77, tools/buildwitness.js:36-41):
+ *   field element  32 B little-endian; Montgomery form (R = 2^256) unless stated "plain"
+ *   G1 affine      64 B  (x, y)                x == 0  => point at infinity
+ *   G2 affine      128 B (x.c0, x.c1, y.c0, y.c1)
+ *   G1 Jacobian    96 B  (x, y, z)             z == 0  => infinity; canonical (0, 1, 0)
+ *   G2 Jacobian    192 B
+ *   scalars        32 B raw 256-bit little-endian, NOT required to be < r
+ *
+ * All functions return 0 on success or a WSNARK_ERR_* code; none throws or aborts.
+ * wsnark_last_error() gives a thread-local human-readable message.
+ * Input pointers are borrowed for the duration of the call only.
+ * "_dev" variants take DEVICE pointers (hipMalloc / torch tensor data_ptr) and a
+ * hipStream_t (as void*; NULL = the library's own stream); results that are a single
+ * group element are still written to HOST memory.
+ */
+#ifndef WSNARK_H
+#define WSNARK_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WSNARK_OK 0
+#define WSNARK_ERR_SIZE 1    /* n not a power of two, > 2^28, or inconsistent lengths */
+#define WSNARK_ERR_FORMAT 2  /* malformed proving key / pols records / offsets out of range */
+#define WSNARK_ERR_HIP 3     /* HIP runtime error, see wsnark_last_error() */
+#define WSNARK_ERR_ARG 4     /* NULL pointer or bad handle */
+#define WSNARK_ERR_NOINIT 5  /* wsnark_init() not called */
+
+typedef struct wsnark_pkey wsnark_pkey_t;
+
+/* Replaces build() / worker INIT (src/bn128.js:173-265, 55-66): selects the GPU, creates
+ * the library stream.  device < 0 => use $LOCAL_RANK or 0.  Idempotent. */
+int wsnark_init(int device);
+/* Replaces Bn128.terminate() / worker TERMINATE (src/bn128.js:562-566, 167-169). */
+void wsnark_shutdown(void);
+const char* wsnark_last_error(void);
+/* "<device name> <gcn arch> CUs=<n>" of the device in use */
+const char* wsnark_device_info(void);
+
+/* Worker command G1_MULTIEXP + Bn128.g1_multiexp (src/bn128.js:102-113, 353-383;
+ * kernel g1m_multiexp2, src/build_multiexp.js:651-744).  Host pointers.
+ * out96 = sum_i scalars[i]*points[i] as Jacobian-Montgomery, affine-normalised
+ * ((x, y, 1) or (0, 1, 0)); n == 0 => infinity. */
+int wsnark_g1_msm(const void* scalars, const void* points_affine, uint64_t n, void* out96);
+/* Worker command G2_MULTIEXP + Bn128.g2_multiexp (src/bn128.js:114-125, 385-415;
+ * kernel g2m_multiexp, src/build_multiexp.js:498-580). */
+int wsnark_g2_msm(const void* scalars, const void* points_affine, uint64_t n, void* out192);
+int wsnark_g1_msm_dev(const void* d_scalars, const void* d_points_affine, uint64_t n, void* out96_host, void* stream);
+int wsnark_g2_msm_dev(const void* d_scalars, const void* d_points_affine, uint64_t n, void* out192_host, void* stream);
+
+/* fft_fft / fft_ifft (src/build_fft.js:159-221), in place on n Montgomery Fr elements.
+ * n must be a power of two <= 2^28 (the reference traps otherwise, :137-154);
+ * inverse with n == 1 is rejected (the reference never returns, :575-583). */
+int wsnark_fr_ntt(void* buf, uint64_t n, int odd, int inverse);
+int wsnark_fr_ntt_dev(void* d_buf, uint64_t n, int odd, int inverse, void* stream);
+/* fft_toMontgomeryN / fft_fromMontgomeryN (src/build_fft.js:418-458, 507-547) */
+int wsnark_fr_to_montgomery(const void* in, void* out, uint64_t n);
+int wsnark_fr_from_montgomery(const void* in, void* out, uint64_t n);
+
+/* Worker command CALC_H + Bn128.calcH (src/bn128.js:126-166, 569-578).
+ * signals: n_signals x 32 B plain; polsA/polsB: the key's record streams
+ * (u32 ncoefs, then ncoefs x (u32 idx, 32 B coef)) per signal (src/build_pol.js:62-144);
+ * out_h: domain x 32 B plain. */
+int wsnark_calc_h(const void* signals, const void* polsA, size_t lenA, const void* polsB, size_t lenB,
+                  uint32_t n_signals, uint32_t domain, void* out_h);
+
+/* Parses proving_key.bin (tools/buildpkey.js:124-240; header read at src/bn128.js:581-604)
+ * and makes it device-resident (points as-is, pols transposed to row-major CSR). */
+int wsnark_pkey_load(const void* pkey, size_t len, wsnark_pkey_t** out_handle);
+void wsnark_pkey_free(wsnark_pkey_t* handle);
+int wsnark_pkey_info(const wsnark_pkey_t* handle, uint32_t* n_vars, uint32_t* n_public, uint32_t* domain);
+
+/* Bn128.groth16GenProof (src/bn128.js:580-720).  witness: nVars x 32 B plain
+ * (tools/buildwitness.js:36-41).  r32 / s32: the two 32-byte blinding values the reference
+ * draws from crypto.randomBytes (src/bn128.js:642-661); NULL => drawn from the OS CSPRNG.
+ * out384 = pi_a (x, y, z) 96 B | pi_b (x.c0, x.c1, y.c0, y.c1, z.c0, z.c1) 192 B |
+ * pi_c 96 B: affine, PLAIN (non-Montgomery) little-endian, i.e. exactly the integers
+ * bin2g1/bin2g2 print (src/bn128.js:329-351, 706-718); infinity = (0, 1, 0). */
+int wsnark_groth16_prove(wsnark_pkey_t* handle, const void* witness, size_t witness_len, const void* r32,
+                         const void* s32, void* out384);
+/* same, witness already on the device */
+int wsnark_groth16_prove_dev(wsnark_pkey_t* handle, const void* d_witness, size_t witness_len, const void* r32,
+                             const void* s32, void* out384_host, void* stream);
+
+/* ---- synthetic-input helpers: NO reference counterpart ----
+ * out[i] = scalars[i] * base (affine Montgomery in and out; infinity written as all-zero bytes).
+ * The reference ships no proving key (its test/data/proving_key.bin is absent), so benches and
+ * tests build valid synthetic keys from known toxic waste with these (wasmsnark_amd/synth.py). */
+int wsnark_g1_mul_base_batch(const void* base64, const void* scalars, uint64_t n, void* out_affine);
+int wsnark_g2_mul_base_batch(const void* base128, const void* scalars, uint64_t n, void* out_affine);
+
+/* ---- measurement hooks (bench.py) ---- */
+/* enable/disable per-kernel HIP-event timing on the stream kernels are launched on */
+void wsnark_timing_enable(int on);
+void wsnark_timing_reset(void);
+/* writes "name total_ms launches\n" lines; returns bytes needed (excluding NUL) */
+size_t wsnark_timing_report(char* buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,118 @@
+// hip_emul.h -- a tiny CPU stand-in for the parts of the HIP runtime and device
+// language that wasmsnark_amd/csrc uses.  TEST INFRASTRUCTURE ONLY.
+//
+// Purpose: this build container has no GPU.  To exercise kernel INDEX MATH before
+// spending GPU minutes, the CPU test-suite compiles the very same .hip sources with
+// g++ and -DWSNARK_EMUL against this header into tests/emul/libwsnark_emul.so.  Each
+// workgroup runs its threads as cooperative coroutines (ucontext); __syncthreads()
+// yields until every live thread of the block has arrived.  Blocks run one after the
+// other.  Nothing here is built into, shipped with, or loaded by the product library
+// (wasmsnark_amd/libwsnark.so), and GPU parity tests never use it.
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <functional>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+#define __align__(n) __attribute__((aligned(n)))
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint3_emul { unsigned x, y, z; };
+
+namespace hip_emul {
+extern thread_local uint3_emul t_threadIdx, t_blockIdx;
+extern thread_local dim3 t_blockDim, t_gridDim;
+void* dyn_smem();
+void sync_threads();
+uint32_t shfl_exchange(uint32_t v, int src_lane, int width);
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+}  // namespace hip_emul
+
+#define threadIdx (::hip_emul::t_threadIdx)
+#define blockIdx (::hip_emul::t_blockIdx)
+#define blockDim (::hip_emul::t_blockDim)
+#define gridDim (::hip_emul::t_gridDim)
+
+static inline void __syncthreads() { ::hip_emul::sync_threads(); }
+static inline unsigned __brev(unsigned v) {
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+    v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+    return (v >> 16) | (v << 16);
+}
+static inline int __clz(unsigned v) { return v ? __builtin_clz(v) : 32; }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+
+// wave-level exchange (64 lanes): every lane of the wave must call it
+static inline uint32_t __shfl(uint32_t v, int src, int width = 64) { return ::hip_emul::shfl_exchange(v, src, width); }
+static inline uint32_t __shfl_down(uint32_t v, unsigned d, int width = 64) {
+    int lane = (int)(threadIdx.x & 63);
+    int src = lane + (int)d;
+    if ((src & ~(width - 1)) != (lane & ~(width - 1))) src = lane;
+    return ::hip_emul::shfl_exchange(v, src, 64);
+}
+static inline uint32_t __shfl_xor(uint32_t v, int m, int width = 64) {
+    (void)width;
+    return ::hip_emul::shfl_exchange(v, (int)(threadIdx.x & 63) ^ m, 64);
+}
+
+template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
+
+// ---- host runtime ----
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+typedef struct emul_stream* hipStream_t;
+typedef struct emul_event* hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+struct hipDeviceProp_t { int multiProcessorCount; char name[64]; char gcnArchName[64]; };
+
+static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "emulated failure"; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+    p->multiProcessorCount = 4; strcpy(p->name, "cpu-emulator"); strcpy(p->gcnArchName, "emul"); return hipSuccess;
+}
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(64, (n + 63) & ~(size_t)63); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+template <class F> static inline hipError_t hipFuncSetAttribute(F, int, int) { return hipSuccess; }
+#define hipStreamNonBlocking 1
+
+namespace hip_emul {
+template <class K, class... Args>
+static inline void emul_launch(K kernel, dim3 g, dim3 b, size_t sh, Args... args) {
+    launch(g, b, sh, [=]() { kernel(args...); });
+}
+}  // namespace hip_emul
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    ::hip_emul::emul_launch(kernel, (grid), (block), (shmem), __VA_ARGS__)

@@ -1,0 +1,20 @@
+"""Builds / loads tests/emul/libwsnark_emul.so: the product's kernel SOURCES compiled by g++
+against a CPU thread emulator (tests/emul/hip_emul.h).  CPU tests use it to check kernel index
+math without a GPU; it is not the product and GPU tests never touch it."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "wasmsnark_amd", "csrc")
+SO = os.path.join(ROOT, "tests", "emul", "libwsnark_emul.so")
+
+_bn = None
+
+
+def emul_bn128():
+    global _bn
+    if _bn is None:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-j8", "emul"])
+        from wasmsnark_amd import _lib, bn128
+        _bn = bn128.Bn128(lib=_lib.load(SO))
+    return _bn

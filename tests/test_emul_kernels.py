@@ -1,0 +1,119 @@
+"""CPU-only checks of the HIP kernel sources (run under the thread emulator in tests/emul)
+against the pinned oracle and the reference-generated golden vectors.  These do NOT replace the
+GPU parity tests (tests/test_gpu_parity.py); they exist so index-math bugs are caught here."""
+import base64
+import random
+
+import pytest
+
+from conftest import load_golden
+from emul_util import emul_bn128
+
+H = bytes.fromhex
+B64 = base64.b64decode
+
+
+@pytest.fixture(scope="module")
+def bn():
+    return emul_bn128()
+
+
+def test_to_from_montgomery(bn, orc):
+    rnd = random.Random(1)
+    x = b"".join(rnd.randrange(orc.R).to_bytes(32, "little") for _ in range(300))
+    assert bn.toMontgomeryN(x) == orc.to_mont_n(x)
+    assert bn.fromMontgomeryN(x) == orc.from_mont_n(x)
+
+
+def test_fft_golden(bn):
+    for c in load_golden("fft.json")["cases"]:
+        x = B64(c["input_mont"])
+        if c["n"] == 1:
+            assert bn.fft(x, 0) == B64(c["fft0"])
+            with pytest.raises(Exception):
+                bn.ifft(x, 0)
+            continue
+        assert bn.fft(x, 0) == B64(c["fft0"]), c["n"]
+        assert bn.fft(x, 1) == B64(c["fft1"]), c["n"]
+        assert bn.ifft(x, 0) == B64(c["ifft0"]), c["n"]
+        assert bn.ifft(x, 1) == B64(c["ifft1"]), c["n"]
+
+
+@pytest.mark.parametrize("bits", [1, 2, 3, 5, 10, 11, 12, 13])
+def test_fft_vs_oracle_multi_pass(bn, orc, bits):
+    # bits <= 10: single LDS pass; 11..16: two passes (exercises twiddles + digit reversal)
+    n = 1 << bits
+    rnd = random.Random(bits)
+    x = orc.to_mont_n(b"".join(rnd.randrange(orc.R).to_bytes(32, "little") for _ in range(n)))
+    for odd in (0, 1):
+        assert bn.fft(x, odd) == orc.fft(x, n, odd), (bits, odd)
+        assert bn.ifft(x, odd) == orc.fft(x, n, odd, inverse=True), (bits, odd)
+
+
+def test_fft_three_pass(bn, orc):
+    n = 1 << 17
+    rnd = random.Random(17)
+    x = orc.to_mont_n(b"".join(rnd.randrange(orc.R).to_bytes(32, "little") for _ in range(n)))
+    assert bn.fft(x, 1) == orc.fft(x, n, 1)
+    assert bn.ifft(x, 0) == orc.fft(x, n, 0, inverse=True)
+
+
+def test_fft_rejects_bad_sizes(bn):
+    for n in (0, 3, 6, 1000):
+        with pytest.raises(Exception):
+            bn.fft(b"\0" * (32 * n), 0)
+
+
+@pytest.mark.parametrize("g", [1, 2])
+def test_msm_golden(bn, orc, g):
+    for c in load_golden("msm.json")["g%d" % g]:
+        if c["flavour"] == "accumulate_into_3G":
+            continue
+        s, p = B64(c["scalars"]), B64(c["points"])
+        out = bn.g1_multiexp(s, p) if g == 1 else bn.g2_multiexp(s, p)
+        want = H(c["multiexp_affine"])
+        # affine-normalised Jacobian-Montgomery triple is unique
+        assert out == want, (g, c["n"], c["flavour"])
+
+
+def _points(orc, g, ks):
+    gen = H(load_golden("groups.json")["g%d" % g]["gen"])
+    sz = 64 if g == 1 else 128
+    return b"".join(orc.g_affine(g, orc.g_times_scalar(g, gen, k.to_bytes(32, "little")))[:sz] for k in ks)
+
+
+@pytest.mark.parametrize("g,n", [(1, 700), (2, 200)])
+def test_msm_vs_oracle_skewed(bn, orc, g, n):
+    # circuit-like scalars: zeros, ones, small values, hot buckets
+    rnd = random.Random(100 + g)
+    ks = [rnd.randrange(1, orc.R) for _ in range(n)]
+    pts = _points(orc, g, ks)
+    sc = []
+    for i in range(n):
+        u = rnd.random()
+        if u < 0.07: v = 0
+        elif u < 0.40: v = 1            # hot bucket -> hot-task path
+        elif u < 0.55: v = rnd.randrange(1 << 32)
+        elif u < 0.60: v = (1 << 256) - 1 - rnd.randrange(1 << 20)
+        else: v = rnd.randrange(orc.R)
+        sc.append(v.to_bytes(32, "little"))
+    sc = b"".join(sc)
+    out = bn.g1_multiexp(sc, pts) if g == 1 else bn.g2_multiexp(sc, pts)
+    want = orc.g_affine(g, orc.multiexp(g, "multiexp2" if g == 1 else "multiexp", sc, pts, n))
+    assert out == want
+
+
+def test_msm_same_point_many_times(bn, orc):
+    # every pair identical: exercises the doubling branch of the mixed add and hot buckets
+    n = 257
+    pts = _points(orc, 1, [5]) * n
+    sc = (3).to_bytes(32, "little") * n
+    out = bn.g1_multiexp(sc, pts)
+    want = orc.g_affine(1, orc.multiexp(1, "multiexp2", sc, pts, n))
+    assert out == want
+
+
+def test_calc_h_golden(bn):
+    for c in load_golden("calch.json"):
+        h = bn.calcH(B64(c["signals"]), B64(c["polsA"]), B64(c["polsB"]), c["nSignals"], c["domain"])
+        assert h == B64(c["h"]), (c["nSignals"], c["domain"])

@@ -1,0 +1,103 @@
+"""ctypes loader for libwsnark.so (the hand-written HIP library behind include/wsnark.h).
+
+There is deliberately NO fallback: if the shared library is missing, or no GPU is visible,
+loading / init fails loudly.  (tests/emul builds a CPU thread-emulator of the same kernel
+sources for index-math tests; it is only ever loaded through `load(path=...)` by tests.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_SO = os.path.join(_HERE, "libwsnark.so")
+
+ERRORS = {1: "WSNARK_ERR_SIZE", 2: "WSNARK_ERR_FORMAT", 3: "WSNARK_ERR_HIP", 4: "WSNARK_ERR_ARG", 5: "WSNARK_ERR_NOINIT"}
+
+# every symbol include/wsnark.h declares
+SYMBOLS = [
+    "wsnark_init", "wsnark_shutdown", "wsnark_last_error", "wsnark_device_info",
+    "wsnark_g1_msm", "wsnark_g2_msm", "wsnark_g1_msm_dev", "wsnark_g2_msm_dev",
+    "wsnark_fr_ntt", "wsnark_fr_ntt_dev", "wsnark_fr_to_montgomery", "wsnark_fr_from_montgomery",
+    "wsnark_calc_h", "wsnark_pkey_load", "wsnark_pkey_free", "wsnark_pkey_info",
+    "wsnark_groth16_prove", "wsnark_groth16_prove_dev",
+    "wsnark_g1_mul_base_batch", "wsnark_g2_mul_base_batch",
+    "wsnark_timing_enable", "wsnark_timing_reset", "wsnark_timing_report",
+]
+
+
+class WsnarkError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (ERRORS.get(code, "?"), code, msg))
+        self.code = code
+
+
+class Lib:
+    def __init__(self, path=None):
+        path = path or os.environ.get("WSNARK_LIB") or DEFAULT_SO
+        if not os.path.exists(path):
+            raise ImportError(
+                "libwsnark.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+        self.path = path
+        self.c = C.CDLL(path)
+        for s in SYMBOLS:
+            getattr(self.c, s)  # AttributeError if the ABI is incomplete
+        c = self.c
+        c.wsnark_last_error.restype = C.c_char_p
+        c.wsnark_device_info.restype = C.c_char_p
+        c.wsnark_timing_report.restype = C.c_size_t
+        c.wsnark_timing_report.argtypes = [C.c_void_p, C.c_size_t]
+        u64, vp, sz, u32 = C.c_uint64, C.c_void_p, C.c_size_t, C.c_uint32
+        c.wsnark_g1_msm.argtypes = [vp, vp, u64, vp]
+        c.wsnark_g2_msm.argtypes = [vp, vp, u64, vp]
+        c.wsnark_g1_msm_dev.argtypes = [vp, vp, u64, vp, vp]
+        c.wsnark_g2_msm_dev.argtypes = [vp, vp, u64, vp, vp]
+        c.wsnark_fr_ntt.argtypes = [vp, u64, C.c_int, C.c_int]
+        c.wsnark_fr_ntt_dev.argtypes = [vp, u64, C.c_int, C.c_int, vp]
+        c.wsnark_fr_to_montgomery.argtypes = [vp, vp, u64]
+        c.wsnark_fr_from_montgomery.argtypes = [vp, vp, u64]
+        c.wsnark_calc_h.argtypes = [vp, vp, sz, vp, sz, u32, u32, vp]
+        c.wsnark_pkey_load.argtypes = [vp, sz, C.POINTER(vp)]
+        c.wsnark_pkey_free.argtypes = [vp]
+        c.wsnark_pkey_free.restype = None
+        c.wsnark_pkey_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+        c.wsnark_groth16_prove.argtypes = [vp, vp, sz, vp, vp, vp]
+        c.wsnark_groth16_prove_dev.argtypes = [vp, vp, sz, vp, vp, vp, vp]
+        c.wsnark_g1_mul_base_batch.argtypes = [vp, vp, u64, vp]
+        c.wsnark_g2_mul_base_batch.argtypes = [vp, vp, u64, vp]
+        self.initialised = False
+
+    def check(self, rc):
+        if rc != 0:
+            raise WsnarkError(rc, (self.c.wsnark_last_error() or b"").decode())
+
+    def init(self, device=-1):
+        self.check(self.c.wsnark_init(device))
+        self.initialised = True
+        return (self.c.wsnark_device_info() or b"").decode()
+
+    def shutdown(self):
+        self.c.wsnark_shutdown()
+        self.initialised = False
+
+    def timing_report(self):
+        n = self.c.wsnark_timing_report(None, 0)
+        buf = C.create_string_buffer(n + 1)
+        self.c.wsnark_timing_report(buf, n + 1)
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, ms, cnt = line.split()
+            out[name] = (float(ms), int(cnt))
+        return out
+
+
+_default = None
+
+
+def load(path=None):
+    """Returns the process-wide Lib for `path` (default: wasmsnark_amd/libwsnark.so)."""
+    global _default
+    if path is not None:
+        return Lib(path)
+    if _default is None:
+        _default = Lib()
+    return _default

@@ -1,0 +1,181 @@
+"""Host-side mirror of the reference's JS API for the prove path, over the C ABI.
+
+Mirrors /root/reference src/bn128.js (class Bn128, `build()`), main_bn128.js
+(window.groth16GenProof) and README.md:28-30 (genZKSnarkProof): same names, same argument
+meaning (byte buffers in the reference's layouts), same return shapes (Jacobian-Montgomery
+byte strings for the multiexps, plain-form h for calcH, an object of decimal strings for
+proofs).  The Node.js drop-in (wasmsnark_amd/js) binds the same C ABI through N-API; this
+Python mirror exists so the parity tests read like the reference's own tests.
+"""
+import ctypes as C
+
+from . import _lib
+
+
+_Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+
+
+def _mont(v):
+    return ((v << 256) % _Q).to_bytes(32, "little")
+
+
+# generators (src/bn128/build_bn128.js:59-90), affine Montgomery
+G1_GEN = _mont(1) + _mont(2)
+G2_GEN = (_mont(10857046999023057135944570762232829481370756359578518086990519993285655852781)
+          + _mont(11559732032986387107991004021392285783925812861821192530917403151452391805634)
+          + _mont(8495653923123431417604973247489272438418190587263600148770280649306958101930)
+          + _mont(4082367875863433681332203403145435568316851327593401208105741076214120093531))
+
+
+def _buf(b):
+    if isinstance(b, (bytes, bytearray, memoryview)):
+        b = bytes(b)
+        return (C.c_uint8 * max(len(b), 1)).from_buffer_copy(b if len(b) else b"\0"), len(b)
+    raise TypeError("expected a bytes-like object (the reference takes ArrayBuffers)")
+
+
+class ProvingKey:
+    """Device-resident proving key (wsnark_pkey_load)."""
+
+    def __init__(self, lib, data):
+        self._lib = lib
+        self._h = C.c_void_p()
+        b, n = _buf(data)
+        lib.check(lib.c.wsnark_pkey_load(b, n, C.byref(self._h)))
+        nv, npub, dom = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        lib.check(lib.c.wsnark_pkey_info(self._h, C.byref(nv), C.byref(npub), C.byref(dom)))
+        self.n_vars, self.n_public, self.domain = nv.value, npub.value, dom.value
+
+    def free(self):
+        if self._h:
+            self._lib.c.wsnark_pkey_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Bn128:
+    """`await buildBn128()` of the reference -> `build()` here (src/bn128.js:173-265)."""
+
+    def __init__(self, lib=None, device=-1):
+        self.lib = lib or _lib.load()
+        self.device_info = self.lib.init(device)
+        self._keys = {}
+
+    # --- src/bn128.js:353-383 ---
+    def g1_multiexp(self, scalars, points):
+        s, ns = _buf(scalars)
+        p, np_ = _buf(points)
+        n = ns // 32
+        if np_ < n * 64:
+            raise ValueError("points buffer shorter than n*64 bytes")
+        out = (C.c_uint8 * 96)()
+        self.lib.check(self.lib.c.wsnark_g1_msm(s, p, n, out))
+        return bytes(out)
+
+    # --- src/bn128.js:385-415 ---
+    def g2_multiexp(self, scalars, points):
+        s, ns = _buf(scalars)
+        p, np_ = _buf(points)
+        n = ns // 32
+        if np_ < n * 128:
+            raise ValueError("points buffer shorter than n*128 bytes")
+        out = (C.c_uint8 * 192)()
+        self.lib.check(self.lib.c.wsnark_g2_msm(s, p, n, out))
+        return bytes(out)
+
+    # --- src/bn128.js:569-578 (worker CALC_H :126-166) ---
+    def calcH(self, signals, polsA, polsB, nSignals, domainSize):
+        s, _ = _buf(signals)
+        a, la = _buf(polsA)
+        b, lb = _buf(polsB)
+        out = (C.c_uint8 * (domainSize * 32))()
+        self.lib.check(self.lib.c.wsnark_calc_h(s, a, la, b, lb, nSignals, domainSize, out))
+        return bytes(out)
+
+    # --- fft_fft / fft_ifft (src/build_fft.js:159-221) on Montgomery Fr elements ---
+    def fft(self, data, odd=0, inverse=False):
+        b, n = _buf(data)
+        self.lib.check(self.lib.c.wsnark_fr_ntt(b, n // 32, int(odd), 1 if inverse else 0))
+        return bytes(b)[:n]
+
+    def ifft(self, data, odd=0):
+        return self.fft(data, odd, True)
+
+    def toMontgomeryN(self, data):
+        b, n = _buf(data)
+        self.lib.check(self.lib.c.wsnark_fr_to_montgomery(b, b, n // 32))
+        return bytes(b)[:n]
+
+    def fromMontgomeryN(self, data):
+        b, n = _buf(data)
+        self.lib.check(self.lib.c.wsnark_fr_from_montgomery(b, b, n // 32))
+        return bytes(b)[:n]
+
+    # --- synthetic-input helper (no reference counterpart): scalars[i] * generator, affine ---
+    def mul_base(self, g, scalars, base=None):
+        s, ns = _buf(scalars)
+        n = ns // 32
+        sz = 64 if g == 1 else 128
+        b, _ = _buf(base if base is not None else (G1_GEN if g == 1 else G2_GEN))
+        out = (C.c_uint8 * max(n * sz, 1))()
+        fn = self.lib.c.wsnark_g1_mul_base_batch if g == 1 else self.lib.c.wsnark_g2_mul_base_batch
+        self.lib.check(fn(b, s, n, out))
+        return bytes(out)[: n * sz]
+
+    def load_key(self, pkey):
+        return ProvingKey(self.lib, pkey)
+
+    # --- src/bn128.js:580-720 ---
+    def groth16GenProof(self, signals, pkey, r=None, s=None):
+        """signals: witness.bin bytes; pkey: proving_key.bin bytes or a ProvingKey.
+        r, s: optional 32-byte blinding values (the reference draws them with
+        crypto.randomBytes, src/bn128.js:642-661). Returns {pi_a, pi_b, pi_c} of decimal strings."""
+        key = pkey if isinstance(pkey, ProvingKey) else ProvingKey(self.lib, pkey)
+        w, nw = _buf(signals)
+        out = (C.c_uint8 * 384)()
+        rb = _buf(r)[0] if r is not None else None
+        sb = _buf(s)[0] if s is not None else None
+        if (r is not None and len(r) != 32) or (s is not None and len(s) != 32):
+            raise ValueError("r and s must be 32 bytes")
+        self.lib.check(self.lib.c.wsnark_groth16_prove(key._h, w, nw, rb, sb, out))
+        if key is not pkey:
+            key.free()
+        return proof_from_bytes(bytes(out))
+
+    def terminate(self):  # src/bn128.js:562-566
+        self.lib.shutdown()
+
+
+def proof_from_bytes(b):
+    """bin2g1 / bin2g2 of the reference (src/bn128.js:319-351, 714-718)."""
+    v = [str(int.from_bytes(b[i:i + 32], "little")) for i in range(0, 384, 32)]
+    return {"pi_a": v[0:3], "pi_b": [v[3:5], v[5:7], v[7:9]], "pi_c": v[9:12]}
+
+
+def build(lib=None, device=-1):
+    return Bn128(lib, device)
+
+
+_singleton = None
+
+
+def groth16GenProof(witness, provingKey, cb=None):
+    """main_bn128.js:26-39 (window.groth16GenProof): optional node-style callback."""
+    global _singleton
+    try:
+        if _singleton is None:
+            _singleton = build()
+        proof = _singleton.groth16GenProof(witness, provingKey)
+    except Exception as e:  # noqa: BLE001 - mirrors cb(err)
+        if cb:
+            return cb(e, None)
+        raise
+    return cb(None, proof) if cb else proof
+
+
+genZKSnarkProof = groth16GenProof  # README.md:28-30 name

@@ -1,0 +1,213 @@
+// cabi.hip -- the extern "C" surface declared in include/wsnark.h.
+#include <string.h>
+
+#include "../../include/wsnark.h"
+#include "internal.h"
+
+namespace wsnark {
+int context_init(int device);
+void context_shutdown();
+const std::string& get_last_error();
+const std::string& device_info();
+struct ProvingKey;
+int pkey_load(const uint8_t* buf, size_t len, ProvingKey** out);
+void pkey_free(ProvingKey* K);
+void pkey_info(const ProvingKey* K, uint32_t* nv, uint32_t* np, uint32_t* dom);
+int groth16_prove_host_witness(ProvingKey* K, const uint8_t* witness, size_t witness_len, const uint8_t* r32,
+                               const uint8_t* s32, uint8_t* out384);
+int groth16_prove_dev_witness(ProvingKey* K, const Fe* d_witness, size_t witness_len, const uint8_t* r32,
+                              const uint8_t* s32, uint8_t* out384, hipStream_t s);
+int g1_mul_base_batch(const void* base, const void* scalars, uint64_t n, void* out);
+int g2_mul_base_batch(const void* base, const void* scalars, uint64_t n, void* out);
+}  // namespace wsnark
+
+using namespace wsnark;
+
+static_assert(sizeof(Fe) == 32, "field element must be 32 bytes");
+static_assert(sizeof(Affine<Fq>) == 64 && sizeof(Affine<Fq2>) == 128, "affine layouts");
+static_assert(sizeof(Jac<Fq>) == 96 && sizeof(Jac<Fq2>) == 192, "jacobian layouts");
+static_assert(sizeof(XYZZ<Fq>) == 128 && sizeof(XYZZ<Fq2>) == 256, "xyzz layouts");
+
+#define REQUIRE_CTX()                                                        \
+    Context* C = ctx();                                                      \
+    if (!C) { set_last_error("wsnark_init() has not been called"); return WSNARK_ERR_NOINIT; }
+
+template <class AffT, class JacT, int (*FN)(const Fe*, const AffT*, uint64_t, JacT*, hipStream_t)>
+static int msm_host(const void* scalars, const void* points, uint64_t n, void* out) {
+    REQUIRE_CTX();
+    if (!out || (n && (!scalars || !points))) return WSNARK_ERR_ARG;
+    if (n > ((uint64_t)1 << 28)) return WSNARK_ERR_SIZE;
+    DevBuf ds, dp;
+    if (n) {
+        WS_HIP_CHECK(ds.alloc(n * 32));
+        WS_HIP_CHECK(dp.alloc(n * sizeof(AffT)));
+        WS_HIP_CHECK(hipMemcpyAsync(ds.p, scalars, n * 32, hipMemcpyHostToDevice, C->stream));
+        WS_HIP_CHECK(hipMemcpyAsync(dp.p, points, n * sizeof(AffT), hipMemcpyHostToDevice, C->stream));
+    }
+    JacT r;
+    int rc = FN(ds.as<Fe>(), dp.as<AffT>(), n, &r, C->stream);
+    if (rc) return rc;
+    memcpy(out, &r, sizeof r);
+    return WSNARK_OK;
+}
+
+extern "C" {
+
+int wsnark_init(int device) { return context_init(device); }
+void wsnark_shutdown(void) { context_shutdown(); }
+const char* wsnark_last_error(void) { return get_last_error().c_str(); }
+const char* wsnark_device_info(void) { return device_info().c_str(); }
+
+// ---- MSM ----
+int wsnark_g1_msm(const void* scalars, const void* points, uint64_t n, void* out96) {
+    return msm_host<Affine<Fq>, Jac<Fq>, msm_g1_dev>(scalars, points, n, out96);
+}
+int wsnark_g2_msm(const void* scalars, const void* points, uint64_t n, void* out192) {
+    return msm_host<Affine<Fq2>, Jac<Fq2>, msm_g2_dev>(scalars, points, n, out192);
+}
+int wsnark_g1_msm_dev(const void* d_scalars, const void* d_points, uint64_t n, void* out96_host, void* stream) {
+    REQUIRE_CTX();
+    if (!out96_host) return WSNARK_ERR_ARG;
+    Jac<Fq> r;
+    int rc = msm_g1_dev((const Fe*)d_scalars, (const Affine<Fq>*)d_points, n, &r, (hipStream_t)stream);
+    if (rc) return rc;
+    memcpy(out96_host, &r, sizeof r);
+    return WSNARK_OK;
+}
+int wsnark_g2_msm_dev(const void* d_scalars, const void* d_points, uint64_t n, void* out192_host, void* stream) {
+    REQUIRE_CTX();
+    if (!out192_host) return WSNARK_ERR_ARG;
+    Jac<Fq2> r;
+    int rc = msm_g2_dev((const Fe*)d_scalars, (const Affine<Fq2>*)d_points, n, &r, (hipStream_t)stream);
+    if (rc) return rc;
+    memcpy(out192_host, &r, sizeof r);
+    return WSNARK_OK;
+}
+
+// ---- NTT ----
+int wsnark_fr_ntt_dev(void* d_buf, uint64_t n, int odd, int inverse, void* stream) {
+    REQUIRE_CTX();
+    return ntt_dev((Fe*)d_buf, n, odd, inverse, (hipStream_t)stream);
+}
+int wsnark_fr_ntt(void* buf, uint64_t n, int odd, int inverse) {
+    REQUIRE_CTX();
+    if (!buf) return WSNARK_ERR_ARG;
+    if (n == 0 || (n & (n - 1)) || n > ((uint64_t)1 << 28)) return WSNARK_ERR_SIZE;
+    DevBuf d;
+    WS_HIP_CHECK(d.alloc(n * 32));
+    WS_HIP_CHECK(hipMemcpyAsync(d.p, buf, n * 32, hipMemcpyHostToDevice, C->stream));
+    int rc = ntt_dev(d.as<Fe>(), n, odd, inverse, C->stream);
+    if (rc) return rc;
+    WS_HIP_CHECK(hipMemcpyAsync(buf, d.p, n * 32, hipMemcpyDeviceToHost, C->stream));
+    WS_HIP_CHECK(hipStreamSynchronize(C->stream));
+    return WSNARK_OK;
+}
+static int fr_map_host(const void* in, void* out, uint64_t n, int to_mont) {
+    REQUIRE_CTX();
+    if (n == 0) return WSNARK_OK;
+    if (!in || !out) return WSNARK_ERR_ARG;
+    DevBuf d;
+    WS_HIP_CHECK(d.alloc(n * 32));
+    WS_HIP_CHECK(hipMemcpyAsync(d.p, in, n * 32, hipMemcpyHostToDevice, C->stream));
+    int rc = fr_map_dev(d.as<Fe>(), d.as<Fe>(), n, to_mont, C->stream);
+    if (rc) return rc;
+    WS_HIP_CHECK(hipMemcpyAsync(out, d.p, n * 32, hipMemcpyDeviceToHost, C->stream));
+    WS_HIP_CHECK(hipStreamSynchronize(C->stream));
+    return WSNARK_OK;
+}
+int wsnark_fr_to_montgomery(const void* in, void* out, uint64_t n) { return fr_map_host(in, out, n, 1); }
+int wsnark_fr_from_montgomery(const void* in, void* out, uint64_t n) { return fr_map_host(in, out, n, 0); }
+
+// ---- CALC_H ----
+int wsnark_calc_h(const void* signals, const void* polsA, size_t lenA, const void* polsB, size_t lenB,
+                  uint32_t n_signals, uint32_t domain, void* out_h) {
+    REQUIRE_CTX();
+    if (!signals || !polsA || !polsB || !out_h) return WSNARK_ERR_ARG;
+    if (domain < 2 || (domain & (domain - 1)) || domain > (1u << 27)) return WSNARK_ERR_SIZE;
+    CsrMatrix A, B;
+    size_t used = 0;
+    int rc = pols_to_csr((const uint8_t*)polsA, lenA, n_signals, domain, &A, &used, C->stream);
+    if (rc) return rc;
+    rc = pols_to_csr((const uint8_t*)polsB, lenB, n_signals, domain, &B, &used, C->stream);
+    if (rc) return rc;
+    DevBuf dsig, dh;
+    WS_HIP_CHECK(dsig.alloc((size_t)n_signals * 32));
+    WS_HIP_CHECK(dh.alloc((size_t)domain * 32));
+    WS_HIP_CHECK(hipMemcpyAsync(dsig.p, signals, (size_t)n_signals * 32, hipMemcpyHostToDevice, C->stream));
+    rc = calc_h_dev(dsig.as<Fe>(), n_signals, A, B, domain, dh.as<Fe>(), C->stream);
+    if (rc) return rc;
+    WS_HIP_CHECK(hipMemcpyAsync(out_h, dh.p, (size_t)domain * 32, hipMemcpyDeviceToHost, C->stream));
+    WS_HIP_CHECK(hipStreamSynchronize(C->stream));
+    return WSNARK_OK;
+}
+
+// ---- proving key / prove ----
+int wsnark_pkey_load(const void* pkey, size_t len, wsnark_pkey_t** out_handle) {
+    REQUIRE_CTX();
+    if (!out_handle) return WSNARK_ERR_ARG;
+    ProvingKey* K = nullptr;
+    int rc = pkey_load((const uint8_t*)pkey, len, &K);
+    if (rc) return rc;
+    *out_handle = reinterpret_cast<wsnark_pkey_t*>(K);
+    return WSNARK_OK;
+}
+void wsnark_pkey_free(wsnark_pkey_t* h) {
+    if (h) pkey_free(reinterpret_cast<ProvingKey*>(h));
+}
+int wsnark_pkey_info(const wsnark_pkey_t* h, uint32_t* nv, uint32_t* np, uint32_t* dom) {
+    if (!h) return WSNARK_ERR_ARG;
+    pkey_info(reinterpret_cast<const ProvingKey*>(h), nv, np, dom);
+    return WSNARK_OK;
+}
+int wsnark_groth16_prove(wsnark_pkey_t* h, const void* witness, size_t witness_len, const void* r32, const void* s32,
+                         void* out384) {
+    REQUIRE_CTX();
+    if (!h || !witness || !out384) return WSNARK_ERR_ARG;
+    return groth16_prove_host_witness(reinterpret_cast<ProvingKey*>(h), (const uint8_t*)witness, witness_len,
+                                      (const uint8_t*)r32, (const uint8_t*)s32, (uint8_t*)out384);
+}
+int wsnark_groth16_prove_dev(wsnark_pkey_t* h, const void* d_witness, size_t witness_len, const void* r32,
+                             const void* s32, void* out384_host, void* stream) {
+    REQUIRE_CTX();
+    if (!h || !d_witness || !out384_host) return WSNARK_ERR_ARG;
+    return groth16_prove_dev_witness(reinterpret_cast<ProvingKey*>(h), (const Fe*)d_witness, witness_len,
+                                     (const uint8_t*)r32, (const uint8_t*)s32, (uint8_t*)out384_host, (hipStream_t)stream);
+}
+
+// ---- synthetic-input helpers (no reference counterpart) ----
+int wsnark_g1_mul_base_batch(const void* base64, const void* scalars, uint64_t n, void* out_affine) {
+    return g1_mul_base_batch(base64, scalars, n, out_affine);
+}
+int wsnark_g2_mul_base_batch(const void* base128, const void* scalars, uint64_t n, void* out_affine) {
+    return g2_mul_base_batch(base128, scalars, n, out_affine);
+}
+
+// ---- timing ----
+void wsnark_timing_enable(int on) {
+    Context* C = ctx();
+    if (C) C->timer.enabled = on != 0;
+}
+void wsnark_timing_reset(void) {
+    Context* C = ctx();
+    if (C) C->timer.reset();
+}
+size_t wsnark_timing_report(char* buf, size_t cap) {
+    Context* C = ctx();
+    if (!C) return 0;
+    (void)hipStreamSynchronize(C->stream);
+    C->timer.collect();
+    std::string s;
+    for (auto& kv : C->timer.acc) {
+        char line[256];
+        snprintf(line, sizeof line, "%s %.6f %llu\n", kv.first.c_str(), kv.second.first, (unsigned long long)kv.second.second);
+        s += line;
+    }
+    if (buf && cap) {
+        size_t k = s.size() < cap - 1 ? s.size() : cap - 1;
+        memcpy(buf, s.data(), k);
+        buf[k] = 0;
+    }
+    return s.size();
+}
+
+}  // extern "C"

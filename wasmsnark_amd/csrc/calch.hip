@@ -1,0 +1,178 @@
+// calch.hip -- the CALC_H worker command on the GPU: h = upper half of the coefficients of
+// A(x)*B(x), where A, B are the witness-weighted Lagrange combinations of the key's polsA/polsB.
+//
+// Replaces SURVEY.md section 8a rows a17-a19 (/root/reference src/bn128.js:126-166 CALC_H;
+// src/build_pol.js:62-144 pol_constructLC; src/build_fft.js:374-547 copyNInterleaved / mulN /
+// to/fromMontgomeryN).
+//
+// Differences from the reference's sequence (all exact field arithmetic => identical h):
+//  * pol_constructLC walks a column-major record stream and scatter-adds; here the stream is
+//    transposed ONCE at key load into row-major CSR and each output row is one lane's dot product
+//    (modular sums are order independent).
+//  * the reference interleaves evaluations on the n-domain and on its odd coset into a 2n array
+//    and runs one size-2n inverse transform, keeping the upper half.  With E = A.B on the domain,
+//    O = A.B on the coset, e = iNTT_n(E), o = iNTT_n(O):
+//        c[t] = (e[t mod n] + w_2n^-t o[t mod n]) / 2   for t in [0, 2n)
+//    so h[t] = c[n + t] = (e[t] - w_2n^-t o[t]) / 2: two size-n transforms, no 2n buffer.
+#include <string.h>
+
+#include "internal.h"
+
+namespace wsnark {
+
+__global__ __launch_bounds__(256) void fr_map_kernel(const Fe* __restrict__ in, Fe* __restrict__ out, uint64_t n, int to_mont) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = to_mont ? Fr::to_mont(in[i]) : Fr::from_mont(in[i]);
+}
+
+// res[row] = sum_k coef[k] * sig[col[k]]   (pol_constructLC, row-major)
+__global__ __launch_bounds__(256) void lc_spmv_kernel(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+                                                        const Fe* __restrict__ coef, const Fe* __restrict__ sig,
+                                                        uint32_t n_rows, Fe* __restrict__ res) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    Fe acc = Fr::zero();
+    const uint32_t e = row_ptr[r + 1];
+    for (uint32_t k = row_ptr[r]; k < e; k++) acc = Fr::add(acc, Fr::mul(coef[k], sig[col[k]]));
+    res[r] = acc;
+}
+
+__global__ __launch_bounds__(256) void fr_mul_kernel(const Fe* __restrict__ a, const Fe* __restrict__ b, Fe* __restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = Fr::mul(a[i], b[i]);
+}
+
+// h[t] = fromMontgomery( (e[t] - w_2n^-t * o[t]) / 2 ),  w_2n^-t = -w_2n^(n-t) for t >= 1
+__global__ __launch_bounds__(256) void calch_combine_kernel(const Fe* __restrict__ e, const Fe* __restrict__ o,
+                                                              const Fe* __restrict__ cs_lo, const Fe* __restrict__ cs_hi,
+                                                              uint32_t hc, uint32_t n, Fe half, Fe* __restrict__ h) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    Fe ot = o[t], v;
+    if (t == 0) {
+        v = Fr::sub(e[0], ot);
+    } else {
+        const uint32_t x = n - t;
+        Fe f = Fr::mul(cs_hi[x >> hc], cs_lo[x & ((1u << hc) - 1)]);
+        v = Fr::add(e[t], Fr::mul(f, ot));
+    }
+    h[t] = Fr::from_mont(Fr::mul(v, half));
+}
+
+int fr_map_dev(const Fe* d_in, Fe* d_out, uint64_t n, int to_mont, hipStream_t s) {
+    Context* C = ctx();
+    if (!C) return WS_ERR_NOINIT;
+    if (n == 0) return WS_OK;
+    if (!s) s = C->stream;
+    hipLaunchKernelGGL(fr_map_kernel, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s, d_in, d_out, n, to_mont);
+    WS_HIP_CHECK(hipGetLastError());
+    return WS_OK;
+}
+
+int pols_to_csr(const uint8_t* pols, size_t len, uint32_t n_signals, uint32_t domain, CsrMatrix* out,
+                size_t* consumed, hipStream_t s) {
+    // pass 1: validate + count per row
+    std::vector<uint32_t> row_ptr((size_t)domain + 1, 0);
+    size_t pp = 0;
+    uint64_t nnz = 0;
+    for (uint32_t i = 0; i < n_signals; i++) {
+        if (pp + 4 > len) { set_last_error("pols: truncated record header"); return WS_ERR_FORMAT; }
+        uint32_t nc; memcpy(&nc, pols + pp, 4); pp += 4;
+        if ((uint64_t)nc * 36 > len - pp) { set_last_error("pols: truncated coefficient records"); return WS_ERR_FORMAT; }
+        for (uint32_t j = 0; j < nc; j++) {
+            uint32_t idx; memcpy(&idx, pols + pp, 4);
+            if (idx >= domain) { set_last_error("pols: coefficient index >= domainSize"); return WS_ERR_FORMAT; }
+            row_ptr[(size_t)idx + 1]++;
+            pp += 36;
+        }
+        nnz += nc;
+    }
+    if (nnz >= ((uint64_t)1 << 32)) return WS_ERR_SIZE;
+    for (uint32_t r = 0; r < domain; r++) row_ptr[(size_t)r + 1] += row_ptr[r];
+    std::vector<uint32_t> col((size_t)nnz ? (size_t)nnz : 1);
+    std::vector<Fe> coef((size_t)nnz ? (size_t)nnz : 1);
+    std::vector<uint32_t> fill(row_ptr.begin(), row_ptr.end() - 1);
+    pp = 0;
+    for (uint32_t i = 0; i < n_signals; i++) {
+        uint32_t nc; memcpy(&nc, pols + pp, 4); pp += 4;
+        for (uint32_t j = 0; j < nc; j++) {
+            uint32_t idx; memcpy(&idx, pols + pp, 4);
+            const uint32_t k = fill[idx]++;
+            col[k] = i;
+            memcpy(&coef[k], pols + pp + 4, 32);
+            pp += 36;
+        }
+    }
+    if (consumed) *consumed = pp;
+    out->n_rows = domain; out->n_cols = n_signals; out->nnz = nnz;
+    WS_HIP_CHECK(out->row_ptr.alloc(row_ptr.size() * 4));
+    WS_HIP_CHECK(out->col.alloc(col.size() * 4));
+    WS_HIP_CHECK(out->coef.alloc(coef.size() * sizeof(Fe)));
+    WS_HIP_CHECK(hipMemcpyAsync(out->row_ptr.p, row_ptr.data(), row_ptr.size() * 4, hipMemcpyHostToDevice, s));
+    WS_HIP_CHECK(hipMemcpyAsync(out->col.p, col.data(), col.size() * 4, hipMemcpyHostToDevice, s));
+    WS_HIP_CHECK(hipMemcpyAsync(out->coef.p, coef.data(), coef.size() * sizeof(Fe), hipMemcpyHostToDevice, s));
+    WS_HIP_CHECK(hipStreamSynchronize(s));
+    return WS_OK;
+}
+
+int calc_h_dev(const Fe* d_signals_plain, uint32_t n_signals, const CsrMatrix& A, const CsrMatrix& B, uint32_t domain,
+               Fe* d_h_out, hipStream_t s) {
+    Context* C = ctx();
+    if (!C) return WS_ERR_NOINIT;
+    if (!s) s = C->stream;
+    // src/build_fft.js:137-154: the transforms trap unless the size is a power of two; the 2n-sized
+    // inverse of the reference needs 2*domain <= 2^28
+    if (domain < 2 || (domain & (domain - 1)) || domain > (1u << 27)) return WS_ERR_SIZE;
+    if (A.n_rows != domain || B.n_rows != domain || A.n_cols != n_signals || B.n_cols != n_signals) return WS_ERR_ARG;
+    int bits = 0;
+    while ((1u << bits) < domain) bits++;
+    const size_t nb = (size_t)domain * sizeof(Fe);
+    {
+        std::lock_guard<std::mutex> lk(C->mu);
+        WS_HIP_CHECK(C->calch_buf[0].reserve((size_t)n_signals * sizeof(Fe)));
+        for (int i = 1; i < 4; i++) WS_HIP_CHECK(C->calch_buf[i].reserve(nb));
+    }
+    Fe* sigM = C->calch_buf[0].as<Fe>();
+    Fe* a = C->calch_buf[1].as<Fe>();
+    Fe* b = C->calch_buf[2].as<Fe>();
+    Fe* e = C->calch_buf[3].as<Fe>();
+    KernelTimer& T = C->timer;
+    const dim3 blk(256), grd(ceil_div_u64(domain, 256));
+    int rc;
+
+    T.begin("fr_to_montgomery", s);                                  // bn128.js:139
+    rc = fr_map_dev(d_signals_plain, sigM, n_signals, 1, s);
+    T.end(s);
+    if (rc) return rc;
+    T.begin("lc_spmv", s);                                           // bn128.js:141-145
+    hipLaunchKernelGGL(lc_spmv_kernel, grd, blk, 0, s, A.row_ptr.as<uint32_t>(), A.col.as<uint32_t>(), A.coef.as<Fe>(), sigM, domain, a);
+    hipLaunchKernelGGL(lc_spmv_kernel, grd, blk, 0, s, B.row_ptr.as<uint32_t>(), B.col.as<uint32_t>(), B.coef.as<Fe>(), sigM, domain, b);
+    T.end(s);
+    T.begin("fr_pointwise", s);
+    hipLaunchKernelGGL(fr_mul_kernel, grd, blk, 0, s, a, b, e, (uint64_t)domain);   // E = A.B on the domain
+    T.end(s);
+    WS_HIP_CHECK(hipGetLastError());
+    if ((rc = ntt_dev(a, domain, 0, 1, s))) return rc;               // bn128.js:150-151  evaluations -> coefficients
+    if ((rc = ntt_dev(b, domain, 0, 1, s))) return rc;
+    if ((rc = ntt_dev(a, domain, 1, 0, s))) return rc;               // bn128.js:152-153  -> odd-coset evaluations
+    if ((rc = ntt_dev(b, domain, 1, 0, s))) return rc;
+    T.begin("fr_pointwise", s);
+    hipLaunchKernelGGL(fr_mul_kernel, grd, blk, 0, s, a, b, a, (uint64_t)domain);   // O = A.B on the coset (bn128.js:158)
+    T.end(s);
+    if ((rc = ntt_dev(e, domain, 0, 1, s))) return rc;               // bn128.js:160, split in two halves
+    if ((rc = ntt_dev(a, domain, 0, 1, s))) return rc;
+    const Fe *cs_lo, *cs_hi;
+    int hc;
+    Fe n_inv;
+    if ((rc = ntt_coset_tables(bits, &cs_lo, &cs_hi, &hc, &n_inv, s))) return rc;
+    Fe half = Fr::inv(Fr::add(Fr::one(), Fr::one()));
+    T.begin("calch_combine", s);                                     // bn128.js:162-164 (+ the upper-half selection)
+    hipLaunchKernelGGL(calch_combine_kernel, grd, blk, 0, s, e, a, cs_lo, cs_hi, (uint32_t)hc, domain, half, d_h_out);
+    T.end(s);
+    WS_HIP_CHECK(hipGetLastError());
+    return WS_OK;
+}
+
+}  // namespace wsnark

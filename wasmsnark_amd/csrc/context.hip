@@ -1,0 +1,89 @@
+// context.hip -- library context, error string, per-kernel HIP-event timing.
+#include <stdlib.h>
+
+#include "internal.h"
+
+namespace wsnark {
+
+static thread_local std::string t_last_error;
+void set_last_error(const std::string& s) { t_last_error = s; }
+const std::string& get_last_error() { return t_last_error; }
+
+static Context* g_ctx = nullptr;
+static std::mutex g_ctx_mu;
+static std::string g_devinfo;
+
+Context* ctx() { return g_ctx; }
+
+int context_init(int device) {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    if (g_ctx) return WS_OK;
+    if (device < 0) {
+        const char* lr = getenv("LOCAL_RANK");
+        device = lr ? atoi(lr) : 0;
+    }
+    int count = 0;
+    WS_HIP_CHECK(hipGetDeviceCount(&count));
+    if (count <= 0) { set_last_error("no HIP device visible"); return WS_ERR_HIP; }
+    if (device >= count) device = device % count;
+    WS_HIP_CHECK(hipSetDevice(device));
+    Context* C = new Context();
+    C->device = device;
+    hipDeviceProp_t prop;
+    WS_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    C->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    g_devinfo = std::string(prop.name) + " " + prop.gcnArchName + " CUs=" + std::to_string(C->num_cu);
+    WS_HIP_CHECK(hipStreamCreateWithFlags(&C->stream, hipStreamNonBlocking));
+    g_ctx = C;
+    return WS_OK;
+}
+
+void context_shutdown() {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    if (!g_ctx) return;
+    (void)hipStreamSynchronize(g_ctx->stream);
+    g_ctx->timer.reset();
+    g_ctx->ntt_plans.clear();
+    g_ctx->ntt_scratch.release();
+    g_ctx->msm_scratch[0].reset();
+    g_ctx->msm_scratch[1].reset();
+    (void)hipStreamDestroy(g_ctx->stream);
+    delete g_ctx;
+    g_ctx = nullptr;
+}
+
+const std::string& device_info() { return g_devinfo; }
+
+// ---- KernelTimer ----
+void KernelTimer::begin(const char* name, hipStream_t s) {
+    if (!enabled) return;
+    Rec r;
+    r.name = name;
+    (void)hipEventCreate(&r.a);
+    (void)hipEventCreate(&r.b);
+    (void)hipEventRecord(r.a, s);
+    recs.push_back(r);
+}
+void KernelTimer::end(hipStream_t s) {
+    if (!enabled || recs.empty()) return;
+    (void)hipEventRecord(recs.back().b, s);
+}
+void KernelTimer::collect() {
+    for (auto& r : recs) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(r.b);
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        auto& a = acc[r.name];
+        a.first += ms;
+        a.second += 1;
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    recs.clear();
+}
+void KernelTimer::reset() {
+    collect();
+    acc.clear();
+}
+
+}  // namespace wsnark

@@ -1,0 +1,168 @@
+// curve.h -- BN128 group arithmetic (y^2 = x^3 + b, a = 0), generic over the
+// coordinate field F (Fq for G1, Fq2 for G2).
+//
+// Replaces SURVEY.md section 8a rows a7-a10 (/root/reference
+// src/build_curve_jacobian_a0.js:174-235 double, :280-385 add, :33-172/:387-457
+// zero/neg/affine, src/build_timesscalar.js:20-80 timesScalar).  The reference
+// works in Jacobian (x,y,z) with full 11M+5S additions; this build accumulates in
+// XYZZ coordinates (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2) with MIXED additions of the
+// key's affine points (8M+2S) -- a build-side optimisation: results are only ever
+// compared after affine normalisation (src/bn128.js:706-712), where the group
+// element's coordinates are unique.
+//
+// Conventions kept from the reference: an affine input with x == 0 is the point
+// at infinity (src/build_multiexp.js:335-349); infinity in XYZZ is ZZ == 0; the
+// canonical affine/Jacobian infinity written out is (0, 1, 0) (:87-113).
+#pragma once
+#include "field.h"
+#include "fp2.h"
+
+namespace wsnark {
+
+template <class F>
+struct Affine {
+    typename F::El x, y;
+};
+template <class F>
+struct XYZZ {
+    typename F::El x, y, zz, zzz;
+};
+template <class F>
+struct Jac {
+    typename F::El x, y, z;
+};
+
+template <class F>
+struct Curve {
+    typedef typename F::El El;
+    typedef Affine<F> Aff;
+    typedef XYZZ<F> Pt;
+
+    WS_HD static Pt infinity() { return Pt{F::zero(), F::one(), F::zero(), F::zero()}; }
+    WS_HD static bool is_inf(const Pt& p) { return F::is_zero(p.zz); }
+    WS_HD static bool aff_is_inf(const Aff& a) { return F::is_zero(a.x); }
+    WS_HD static Pt from_affine(const Aff& a) {
+        if (aff_is_inf(a)) return infinity();
+        return Pt{a.x, a.y, F::one(), F::one()};
+    }
+    WS_HD static Pt neg(const Pt& p) { return Pt{p.x, F::neg(p.y), p.zz, p.zzz}; }
+
+    // dbl-2008-s-1 (a = 0).  ZZ == 0 or Y == 0 yield ZZ3 == 0 (infinity) by themselves.
+    WS_HD static Pt dbl(const Pt& p) {
+        El U = F::dbl(p.y);
+        El V = F::sqr(U);
+        El W = F::mul(U, V);
+        El S = F::mul(p.x, V);
+        El X2 = F::sqr(p.x);
+        El M = F::add(F::dbl(X2), X2);
+        El X3 = F::sub(F::sqr(M), F::dbl(S));
+        El Y3 = F::sub(F::mul(M, F::sub(S, X3)), F::mul(W, p.y));
+        return Pt{X3, Y3, F::mul(V, p.zz), F::mul(W, p.zzz)};
+    }
+    // doubling of an affine point (mdbl-2008-s-1)
+    WS_HD static Pt dbl_affine(const El& x, const El& y) {
+        El U = F::dbl(y);
+        El V = F::sqr(U);
+        El W = F::mul(U, V);
+        El S = F::mul(x, V);
+        El X2 = F::sqr(x);
+        El M = F::add(F::dbl(X2), X2);
+        El X3 = F::sub(F::sqr(M), F::dbl(S));
+        El Y3 = F::sub(F::mul(M, F::sub(S, X3)), F::mul(W, y));
+        return Pt{X3, Y3, V, W};
+    }
+
+    // acc += (+/-) affine point  (madd-2008-s, 8M+2S) with all corner cases:
+    // affine infinity (x == 0) -> no-op; acc infinity -> copy; equal -> double;
+    // opposite -> infinity.  (reference branches: build_curve_jacobian_a0.js:322-356)
+    WS_HD static void madd(Pt& acc, const Aff& a, bool negate) {
+        if (aff_is_inf(a)) return;
+        El y2 = F::cneg(a.y, negate);
+        if (is_inf(acc)) {
+            acc = Pt{a.x, y2, F::one(), F::one()};
+            return;
+        }
+        El U2 = F::mul(a.x, acc.zz);
+        El S2 = F::mul(y2, acc.zzz);
+        El P = F::sub(U2, acc.x);
+        El R = F::sub(S2, acc.y);
+        if (F::is_zero(P)) {
+            if (F::is_zero(R)) acc = dbl_affine(a.x, y2);
+            else acc = infinity();
+            return;
+        }
+        El PP = F::sqr(P);
+        El PPP = F::mul(P, PP);
+        El Q = F::mul(acc.x, PP);
+        El X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
+        El Y3 = F::sub(F::mul(R, F::sub(Q, X3)), F::mul(acc.y, PPP));
+        acc.x = X3;
+        acc.y = Y3;
+        acc.zz = F::mul(acc.zz, PP);
+        acc.zzz = F::mul(acc.zzz, PPP);
+    }
+
+    // full addition (add-2008-s, 12M+2S) with all corner cases
+    WS_HD static Pt add(const Pt& a, const Pt& b) {
+        if (is_inf(a)) return b;
+        if (is_inf(b)) return a;
+        El U1 = F::mul(a.x, b.zz);
+        El U2 = F::mul(b.x, a.zz);
+        El S1 = F::mul(a.y, b.zzz);
+        El S2 = F::mul(b.y, a.zzz);
+        El P = F::sub(U2, U1);
+        El R = F::sub(S2, S1);
+        if (F::is_zero(P)) {
+            if (F::is_zero(R)) return dbl(a);
+            return infinity();
+        }
+        El PP = F::sqr(P);
+        El PPP = F::mul(P, PP);
+        El Q = F::mul(U1, PP);
+        El X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
+        El Y3 = F::sub(F::mul(R, F::sub(Q, X3)), F::mul(S1, PPP));
+        return Pt{X3, Y3, F::mul(F::mul(a.zz, b.zz), PP), F::mul(F::mul(a.zzz, b.zzz), PPP)};
+    }
+
+    // k * p for a small unsigned k (MSB-first double-and-add)
+    WS_HD static Pt mul_small(const Pt& p, uint32_t k) {
+        Pt r = infinity();
+        for (int i = 31; i >= 0; i--) {
+            r = dbl(r);
+            if ((k >> i) & 1) r = add(r, p);
+        }
+        return r;
+    }
+
+    // MSB-first double-and-add over `nbytes` little-endian scalar bytes
+    // (the evaluation order of build_timesscalar.js:20-80; any order gives the same group element)
+    WS_HD static Pt mul_bytes(const Pt& p, const uint8_t* scalar, int nbytes) {
+        Pt r = infinity();
+        for (int i = nbytes * 8 - 1; i >= 0; i--) {
+            r = dbl(r);
+            if ((scalar[i >> 3] >> (i & 7)) & 1) r = add(r, p);
+        }
+        return r;
+    }
+
+    // affine normalisation into the reference's Jacobian-Montgomery triple:
+    // infinity -> (0, 1, 0), else (x, y, 1)   (build_curve_jacobian_a0.js:421-457)
+    WS_HD static Jac<F> to_affine_jac(const Pt& p) {
+        if (is_inf(p)) return Jac<F>{F::zero(), F::one(), F::zero()};
+        El inv = F::inv(F::mul(p.zz, p.zzz));
+        El izz = F::mul(inv, p.zzz);    // 1/ZZ
+        El izzz = F::mul(inv, p.zz);    // 1/ZZZ
+        return Jac<F>{F::mul(p.x, izz), F::mul(p.y, izzz), F::one()};
+    }
+    // Jacobian (x,y,z) -> XYZZ (X, Y, z^2, z^3)
+    WS_HD static Pt from_jac(const Jac<F>& j) {
+        if (F::is_zero(j.z)) return infinity();
+        El zz = F::sqr(j.z);
+        return Pt{j.x, j.y, zz, F::mul(zz, j.z)};
+    }
+};
+
+typedef Curve<Fq> G1;
+typedef Curve<Fq2> G2;
+
+}  // namespace wsnark

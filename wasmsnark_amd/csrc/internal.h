@@ -1,0 +1,79 @@
+// internal.h -- C++ interfaces between the translation units of libwsnark.
+#pragma once
+#include <map>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "curve.h"
+#include "rt.h"
+
+namespace wsnark {
+
+// ---- per-kernel timing (HIP events on the library's stream) ----
+struct KernelTimer {
+    bool enabled = false;
+    struct Rec { std::string name; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::map<std::string, std::pair<double, uint64_t>> acc;   // name -> (total ms, launches)
+    void begin(const char* name, hipStream_t s);
+    void end(hipStream_t s);
+    void collect();     // sync + fold recs into acc
+    void reset();
+};
+
+struct NttPlan;    // ntt.hip
+struct MsmScratch; // msm.hip
+
+struct Context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cu = 256;
+    std::mutex mu;
+    std::map<int, std::shared_ptr<NttPlan>> ntt_plans;   // by log2(n)
+    DevBuf ntt_scratch;
+    std::shared_ptr<MsmScratch> msm_scratch[2];          // [0] G1, [1] G2
+    DevBuf calch_buf[4];                                 // sigM, A, B, E
+    KernelTimer timer;
+};
+
+Context* ctx();   // nullptr before wsnark_init
+
+// ---- NTT (ntt.hip) ----
+// In-place transform of n Montgomery Fr elements resident on the device.
+// Semantics of the reference's fft_fft / fft_ifft (src/build_fft.js:159-221):
+//   forward: y[k] = sum_i x[i] * w_{2n}^{(2k+odd) i}       (natural order in and out)
+//   inverse: rawfft, then y[i] = raw[(n-i) mod n] / n
+int ntt_dev(Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s);
+
+int ntt_coset_tables(int bits, const Fe** lo, const Fe** hi, int* hc, Fe* n_inv, hipStream_t s);
+
+// ---- MSM (msm.hip) ----
+// sum_i scalars[i] * points[i]; scalars raw 256-bit LE (not reduced), points affine
+// Montgomery (x == 0 => infinity).  Result written to host memory as the reference's
+// Jacobian-Montgomery triple, affine-normalised: (x, y, 1) or (0, 1, 0).
+int msm_g1_dev(const Fe* d_scalars, const Affine<Fq>* d_points, uint64_t n, Jac<Fq>* out_host, hipStream_t s);
+int msm_g2_dev(const Fe* d_scalars, const Affine<Fq2>* d_points, uint64_t n, Jac<Fq2>* out_host, hipStream_t s);
+// XYZZ result left to the caller (host memory), no affine normalisation
+int msm_g1_dev_xyzz(const Fe* d_scalars, const Affine<Fq>* d_points, uint64_t n, XYZZ<Fq>* out_host, hipStream_t s);
+int msm_g2_dev_xyzz(const Fe* d_scalars, const Affine<Fq2>* d_points, uint64_t n, XYZZ<Fq2>* out_host, hipStream_t s);
+
+// ---- CALC_H pieces (calch.hip) ----
+struct CsrMatrix {            // row-major transpose of the reference's column-major pols blob
+    uint32_t n_rows = 0;      // domain size
+    uint32_t n_cols = 0;      // nSignals
+    uint64_t nnz = 0;
+    DevBuf row_ptr;           // (n_rows + 1) x u32
+    DevBuf col;               // nnz x u32 (signal index)
+    DevBuf coef;              // nnz x Fe (Fr Montgomery)
+};
+// parse `ncoefs, (idx, coef)*` records (src/build_pol.js:62-144) for n_signals columns;
+// returns bytes consumed via *consumed.
+int pols_to_csr(const uint8_t* pols, size_t len, uint32_t n_signals, uint32_t domain, CsrMatrix* out,
+                size_t* consumed, hipStream_t s);
+// d_h_out[domain] (plain form) from a device-resident plain witness
+int calc_h_dev(const Fe* d_signals_plain, uint32_t n_signals, const CsrMatrix& A, const CsrMatrix& B,
+               uint32_t domain, Fe* d_h_out, hipStream_t s);
+int fr_map_dev(const Fe* d_in, Fe* d_out, uint64_t n, int to_mont, hipStream_t s);
+
+}  // namespace wsnark

@@ -1,0 +1,401 @@
+// msm.hip -- bucket (Pippenger) multi-scalar multiplication on BN128 G1 / G2 for gfx950.
+//
+// Replaces SURVEY.md section 8a rows a11-a14 and the sharding of a20
+// (/root/reference src/build_multiexp.js: __packbits :30-155, subset table :295-429,
+// g1m_multiexp2 :651-744, g2m_multiexp :498-580; host split/gather src/bn128.js:353-415).
+// The reference's method (w=7 bit-sliced subset tables, 256 per-bit accumulators) is NOT
+// reproduced: any correct MSM yields the same group element, and results are compared
+// after affine normalisation (src/bn128.js:706-712).
+//
+// Pipeline (all device-resident; one lane = one scalar / one bucket):
+//   1 msm_digits      scalar (32 B coalesced) -> reduced mod r -> W signed c-bit digits
+//                      -> (key = window*NB + |d|-1, val = index | sign<<31), window-major
+//   2 radix sort      (hipCUB device radix sort over the used key bits)
+//   3 msm_bounds      bucket start/end from the sorted keys
+//   4 msm_accumulate  one lane per bucket: mixed additions (XYZZ += affine, 8M+2S) of the
+//                      bucket's points, gathered 64/128 B per lane; buckets longer than LMAX
+//                      spill fixed-size tasks to a hot list
+//   5 msm_hot_*       one lane per hot task, then one wavefront per hot bucket: LDS tree
+//   6 msm_chunks      one lane per 8 buckets: S_j = sum B, A_j = sum (i-i0+1) B
+//   7 msm_tree        per (window, bit q): LDS tree sums U_q = sum_{j: bit q} S_j, and sum A_j
+//   8 host            sum_w 2^(c w) (A_w + 8 sum_q 2^q U_{w,q}): ~W*(log J + 1) points, a serial
+//                      doubling chain that is faster on one CPU core than on one GPU lane.
+#include <algorithm>
+
+#include "internal.h"
+#ifndef WSNARK_EMUL
+#include <hipcub/hipcub.hpp>
+#endif
+
+namespace wsnark {
+
+static const uint32_t CHUNK = 8;          // buckets per msm_chunks lane
+
+struct HotTask { uint32_t bucket, start, len; };
+struct HotBucket { uint32_t bucket, first_task, ntasks; };
+
+struct MsmScratch {
+    DevBuf keys, vals, keys_out, vals_out, sort_tmp;
+    DevBuf bstart, bend, buckets, counters, hot_tasks, hot_buckets, partials;
+    DevBuf chunkS, chunkA, sums;
+};
+
+// ---------------------------------------------------------------------------
+// 1. digits
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void msm_digits(const Fe* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t W,
+                                                    uint32_t sentinel, uint32_t* __restrict__ keys,
+                                                    uint32_t* __restrict__ vals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // raw 256-bit scalars (possibly >= r, src/bn128.js:642-661 and fact 3 of SURVEY.md):
+    // points have prime order r, so reduce first; then s < 2^254 and the top window cannot carry.
+    Fe s = Fr::reduce_full(scalars[i]);
+    const uint32_t NB = 1u << (c - 1);
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < W; w++) {
+        const uint32_t bit = w * c;
+        const uint32_t limb = bit >> 6, off = bit & 63;
+        uint64_t v = limb < 4 ? (s.l[limb] >> off) : 0;
+        if (off + c > 64 && limb + 1 < 4) v |= s.l[limb + 1] << (64 - off);
+        uint32_t d = (uint32_t)(v & ((1u << c) - 1)) + carry;
+        uint32_t neg = 0;
+        if (d > NB) { d = (1u << c) - d; neg = 1; carry = 1; } else carry = 0;
+        const uint64_t o = (uint64_t)w * n + i;
+        keys[o] = d ? (w * NB + d - 1) : sentinel;   // zero digits sort behind every bucket
+        vals[o] = i | (neg << 31);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 3. bucket boundaries in the sorted key array
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void msm_bounds(const uint32_t* __restrict__ keys, uint64_t total, uint32_t sentinel,
+                                                    uint32_t* __restrict__ bstart, uint32_t* __restrict__ bend) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const uint32_t k = keys[i];
+    if (k == sentinel) return;
+    if (i == 0 || keys[i - 1] != k) bstart[k] = (uint32_t)i;
+    if (i + 1 == total || keys[i + 1] != k) bend[k] = (uint32_t)(i + 1);
+}
+
+// ---------------------------------------------------------------------------
+// 4/5. accumulation
+// ---------------------------------------------------------------------------
+template <class C>
+__device__ __forceinline__ typename C::Pt accumulate_range(const typename C::Aff* __restrict__ points,
+                                                           const uint32_t* __restrict__ vals, uint32_t s, uint32_t len) {
+    typename C::Pt acc = C::infinity();
+    if (len == 0) return acc;
+    // software pipeline: the next point's gather is in flight while the current one is added
+    uint32_t v = vals[s];
+    typename C::Aff nxt = points[v & 0x7FFFFFFFu];
+    for (uint32_t k = 0; k < len; k++) {
+        const typename C::Aff cur = nxt;
+        const bool neg = (v >> 31) != 0;
+        if (k + 1 < len) {
+            v = vals[s + k + 1];
+            nxt = points[v & 0x7FFFFFFFu];
+        }
+        C::madd(acc, cur, neg);
+    }
+    return acc;
+}
+
+template <class C>
+__global__ __launch_bounds__(256) void msm_accumulate(const typename C::Aff* __restrict__ points,
+                                                        const uint32_t* __restrict__ vals,
+                                                        const uint32_t* __restrict__ bstart,
+                                                        const uint32_t* __restrict__ bend, uint32_t nbuckets,
+                                                        uint32_t lmax, typename C::Pt* __restrict__ buckets,
+                                                        uint32_t* __restrict__ counters, HotTask* __restrict__ hot_tasks,
+                                                        HotBucket* __restrict__ hot_buckets, uint32_t hot_cap) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbuckets) return;
+    const uint32_t s = bstart[b], cnt = bend[b] - s;
+    const uint32_t first = cnt < lmax ? cnt : lmax;
+    buckets[b] = accumulate_range<C>(points, vals, s, first);
+    if (cnt > lmax) {
+        const uint32_t rest = cnt - lmax;
+        const uint32_t nt = (rest + lmax - 1) / lmax;
+        const uint32_t slot = atomicAdd(&counters[0], nt);
+        const uint32_t hb = atomicAdd(&counters[1], 1u);
+        if (slot + nt <= hot_cap && hb < hot_cap) {
+            hot_buckets[hb] = HotBucket{b, slot, nt};
+            for (uint32_t k = 0; k < nt; k++) {
+                const uint32_t off = lmax * (k + 1);
+                const uint32_t len = (cnt - off) < lmax ? (cnt - off) : lmax;
+                hot_tasks[slot + k] = HotTask{b, s + off, len};
+            }
+        } else {
+            atomicAdd(&counters[2], 1u);   // overflow flag (cannot happen: hot_cap >= total/lmax + buckets)
+        }
+    }
+}
+
+template <class C>
+__global__ __launch_bounds__(256) void msm_hot_tasks(const typename C::Aff* __restrict__ points,
+                                                       const uint32_t* __restrict__ vals,
+                                                       const HotTask* __restrict__ tasks, uint32_t ntasks,
+                                                       typename C::Pt* __restrict__ partials) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntasks) return;
+    const HotTask h = tasks[t];
+    partials[t] = accumulate_range<C>(points, vals, h.start, h.len);
+}
+
+// one wavefront (64 lanes) per hot bucket: lanes stride over the bucket's partial sums, then an
+// LDS tree folds the 64 lane sums into the bucket
+template <class C>
+__global__ __launch_bounds__(64) void msm_hot_combine(const HotBucket* __restrict__ hbs, uint32_t nhb,
+                                                        const typename C::Pt* __restrict__ partials,
+                                                        typename C::Pt* __restrict__ buckets) {
+    __shared__ typename C::Pt sh[64];
+    const uint32_t hb = blockIdx.x;
+    if (hb >= nhb) return;
+    const HotBucket h = hbs[hb];
+    const uint32_t lane = threadIdx.x;
+    typename C::Pt acc = C::infinity();
+    for (uint32_t k = lane; k < h.ntasks; k += 64) acc = C::add(acc, partials[h.first_task + k]);
+    sh[lane] = acc;
+    __syncthreads();
+    for (uint32_t step = 32; step >= 1; step >>= 1) {
+        if (lane < step) sh[lane] = C::add(sh[lane], sh[lane + step]);
+        __syncthreads();
+    }
+    if (lane == 0) buckets[h.bucket] = C::add(buckets[h.bucket], sh[0]);
+}
+
+// ---------------------------------------------------------------------------
+// 6. chunk sums: for CHUNK consecutive buckets of one window
+//    S = sum B_i,  A = sum (i - i0 + 1) B_i   (descending running sum)
+// ---------------------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(256) void msm_chunks(const typename C::Pt* __restrict__ buckets, uint32_t nchunks,
+                                                    uint32_t m, typename C::Pt* __restrict__ chunkS,
+                                                    typename C::Pt* __restrict__ chunkA) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nchunks) return;
+    typename C::Pt run = C::infinity(), acc = C::infinity();
+    const typename C::Pt* B = buckets + (uint64_t)j * m;
+    for (int i = (int)m - 1; i >= 0; i--) {
+        run = C::add(run, B[i]);
+        acc = C::add(acc, run);
+    }
+    chunkS[j] = run;
+    chunkA[j] = acc;
+}
+
+// ---------------------------------------------------------------------------
+// 7. masked tree sums per window: blockIdx.y = window, blockIdx.x = q
+//    q < logJ : U_q = sum_{j : bit q of j set} S_j ;  q == logJ : sum_j A_j
+// ---------------------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(sizeof(typename C::Pt) > 128 ? 256 : 512) void msm_tree(const typename C::Pt* __restrict__ chunkS,
+                                                   const typename C::Pt* __restrict__ chunkA, uint32_t J,
+                                                   uint32_t logJ, typename C::Pt* __restrict__ sums) {
+    WS_DYN_SMEM(typename C::Pt, sh);
+    const uint32_t q = blockIdx.x, w = blockIdx.y;
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+    const typename C::Pt* src = (q == logJ ? chunkA : chunkS) + (uint64_t)w * J;
+    typename C::Pt acc = C::infinity();
+    for (uint32_t j = tid; j < J; j += nthr) {
+        if (q == logJ || ((j >> q) & 1)) acc = C::add(acc, src[j]);
+    }
+    sh[tid] = acc;
+    __syncthreads();
+    for (uint32_t step = nthr >> 1; step >= 1; step >>= 1) {
+        if (tid < step) sh[tid] = C::add(sh[tid], sh[tid + step]);
+        __syncthreads();
+    }
+    if (tid == 0) sums[(uint64_t)w * (logJ + 1) + q] = sh[0];
+}
+
+// ---------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------
+static int sort_pairs(MsmScratch& S, uint64_t total, int end_bit, hipStream_t s) {
+#ifdef WSNARK_EMUL
+    (void)end_bit; (void)s;
+    std::vector<std::pair<uint32_t, uint32_t>> kv(total);
+    uint32_t* k = S.keys.as<uint32_t>(); uint32_t* v = S.vals.as<uint32_t>();
+    for (uint64_t i = 0; i < total; i++) kv[i] = {k[i], v[i]};
+    std::stable_sort(kv.begin(), kv.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; });
+    uint32_t* ko = S.keys_out.as<uint32_t>(); uint32_t* vo = S.vals_out.as<uint32_t>();
+    for (uint64_t i = 0; i < total; i++) { ko[i] = kv[i].first; vo[i] = kv[i].second; }
+    return WS_OK;
+#else
+    size_t tmp_bytes = 0;
+    WS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, S.keys.as<uint32_t>(), S.keys_out.as<uint32_t>(),
+                                                    S.vals.as<uint32_t>(), S.vals_out.as<uint32_t>(), total, 0, end_bit, s));
+    WS_HIP_CHECK(S.sort_tmp.reserve(tmp_bytes));
+    WS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(S.sort_tmp.p, tmp_bytes, S.keys.as<uint32_t>(), S.keys_out.as<uint32_t>(),
+                                                    S.vals.as<uint32_t>(), S.vals_out.as<uint32_t>(), total, 0, end_bit, s));
+    return WS_OK;
+#endif
+}
+
+static uint32_t pick_window(uint64_t n) {
+    const char* e = getenv("WSNARK_MSM_C");
+    if (e) { int c = atoi(e); if (c >= 4 && c <= 16) return (uint32_t)c; }
+    int lg = 0;
+    while (((uint64_t)1 << (lg + 1)) <= n) lg++;
+    int c = lg - 4;
+    if (c < 4) c = 4;
+    if (c > 16) c = 16;
+    return (uint32_t)c;
+}
+
+template <class C>
+static int msm_run(int which, const Fe* d_scalars, const typename C::Aff* d_points, uint64_t n,
+                   typename C::Pt* out_host, hipStream_t s) {
+    typedef typename C::Pt Pt;
+    Context* X = ctx();
+    if (!X) return WS_ERR_NOINIT;
+    if (n == 0) { *out_host = C::infinity(); return WS_OK; }   // multiexp with n=0 leaves pr unchanged
+    if (!d_scalars || !d_points || !out_host) return WS_ERR_ARG;
+    if (n > ((uint64_t)1 << 28)) return WS_ERR_SIZE;
+    if (!s) s = X->stream;
+
+    const uint32_t c = pick_window(n);
+    const uint32_t W = (255 + c - 1) / c;
+    const uint32_t NB = 1u << (c - 1);
+    const uint32_t nbuckets = W * NB;
+    const uint64_t total = n * W;
+    if (total >= ((uint64_t)1 << 32)) return WS_ERR_SIZE;
+    const uint32_t m = NB < CHUNK ? NB : CHUNK;
+    const uint32_t J = NB / m;
+    uint32_t logJ = 0;
+    while ((1u << logJ) < J) logJ++;
+    const uint32_t nsum = logJ + 1;
+    uint32_t lmax = (uint32_t)(2 * ((n + NB - 1) / NB));
+    if (lmax < 32) lmax = 32;
+    const uint32_t hot_cap = (uint32_t)(total / lmax) + nbuckets + 16;
+
+    std::lock_guard<std::mutex> lk(X->mu);   // scratch is shared: one MSM at a time per curve
+    if (!X->msm_scratch[which]) X->msm_scratch[which] = std::make_shared<MsmScratch>();
+    MsmScratch& S = *X->msm_scratch[which];
+    WS_HIP_CHECK(S.keys.reserve(total * 4));
+    WS_HIP_CHECK(S.vals.reserve(total * 4));
+    WS_HIP_CHECK(S.keys_out.reserve(total * 4));
+    WS_HIP_CHECK(S.vals_out.reserve(total * 4));
+    WS_HIP_CHECK(S.bstart.reserve((size_t)nbuckets * 4));
+    WS_HIP_CHECK(S.bend.reserve((size_t)nbuckets * 4));
+    WS_HIP_CHECK(S.buckets.reserve((size_t)nbuckets * sizeof(Pt)));
+    WS_HIP_CHECK(S.counters.reserve(64));
+    WS_HIP_CHECK(S.hot_tasks.reserve((size_t)hot_cap * sizeof(HotTask)));
+    WS_HIP_CHECK(S.hot_buckets.reserve((size_t)hot_cap * sizeof(HotBucket)));
+    WS_HIP_CHECK(S.chunkS.reserve((size_t)W * J * sizeof(Pt)));
+    WS_HIP_CHECK(S.chunkA.reserve((size_t)W * J * sizeof(Pt)));
+    WS_HIP_CHECK(S.sums.reserve((size_t)W * nsum * sizeof(Pt)));
+
+    KernelTimer& T = X->timer;
+    T.begin("msm_digits", s);
+    hipLaunchKernelGGL(msm_digits, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s, d_scalars, (uint32_t)n, c, W, nbuckets,
+                       S.keys.as<uint32_t>(), S.vals.as<uint32_t>());
+    T.end(s);
+    WS_HIP_CHECK(hipGetLastError());
+
+    T.begin("msm_sort", s);
+    int key_bits = 1;
+    while (((uint64_t)1 << key_bits) <= nbuckets) key_bits++;   // keys are 0..nbuckets (nbuckets = "no digit")
+    int rc = sort_pairs(S, total, key_bits, s);
+    T.end(s);
+    if (rc) return rc;
+
+    WS_HIP_CHECK(hipMemsetAsync(S.bstart.p, 0, (size_t)nbuckets * 4, s));
+    WS_HIP_CHECK(hipMemsetAsync(S.bend.p, 0, (size_t)nbuckets * 4, s));
+    WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, 64, s));
+    T.begin("msm_bounds", s);
+    hipLaunchKernelGGL(msm_bounds, dim3(ceil_div_u64(total, 256)), dim3(256), 0, s, S.keys_out.as<uint32_t>(), total,
+                       nbuckets, S.bstart.as<uint32_t>(), S.bend.as<uint32_t>());
+    T.end(s);
+    WS_HIP_CHECK(hipGetLastError());
+
+    T.begin(which ? "msm_accumulate_g2" : "msm_accumulate_g1", s);
+    hipLaunchKernelGGL(msm_accumulate<C>, dim3(ceil_div_u64(nbuckets, 256)), dim3(256), 0, s, d_points,
+                       S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(), nbuckets, lmax,
+                       S.buckets.as<Pt>(), S.counters.as<uint32_t>(), S.hot_tasks.as<HotTask>(),
+                       S.hot_buckets.as<HotBucket>(), hot_cap);
+    T.end(s);
+    WS_HIP_CHECK(hipGetLastError());
+
+    uint32_t cnt[4] = {0, 0, 0, 0};
+    WS_HIP_CHECK(hipMemcpyAsync(cnt, S.counters.p, sizeof cnt, hipMemcpyDeviceToHost, s));
+    WS_HIP_CHECK(hipStreamSynchronize(s));
+    if (cnt[2]) { set_last_error("msm: hot list overflow"); return WS_ERR_HIP; }
+    if (cnt[0]) {
+        WS_HIP_CHECK(S.partials.reserve((size_t)cnt[0] * sizeof(Pt)));
+        T.begin("msm_hot_tasks", s);
+        hipLaunchKernelGGL(msm_hot_tasks<C>, dim3(ceil_div_u64(cnt[0], 256)), dim3(256), 0, s, d_points,
+                           S.vals_out.as<uint32_t>(), S.hot_tasks.as<HotTask>(), cnt[0], S.partials.as<Pt>());
+        T.end(s);
+        T.begin("msm_hot_combine", s);
+        hipLaunchKernelGGL(msm_hot_combine<C>, dim3(cnt[1]), dim3(64), 0, s, S.hot_buckets.as<HotBucket>(), cnt[1],
+                           S.partials.as<Pt>(), S.buckets.as<Pt>());
+        T.end(s);
+        WS_HIP_CHECK(hipGetLastError());
+    }
+
+    T.begin("msm_chunks", s);
+    hipLaunchKernelGGL(msm_chunks<C>, dim3(ceil_div_u64((uint64_t)W * J, 256)), dim3(256), 0, s, S.buckets.as<Pt>(),
+                       W * J, m, S.chunkS.as<Pt>(), S.chunkA.as<Pt>());
+    T.end(s);
+    WS_HIP_CHECK(hipGetLastError());
+
+    uint32_t tthreads = 1;
+    const uint32_t tmax = sizeof(Pt) > 128 ? 256 : 512;   // LDS: threads * sizeof(Pt) <= 64 KiB
+    while (tthreads < J && tthreads < tmax) tthreads <<= 1;
+    T.begin("msm_tree", s);
+    hipLaunchKernelGGL(msm_tree<C>, dim3(nsum, W), dim3(tthreads), (size_t)tthreads * sizeof(Pt), s,
+                       S.chunkS.as<Pt>(), S.chunkA.as<Pt>(), J, logJ, S.sums.as<Pt>());
+    T.end(s);
+    WS_HIP_CHECK(hipGetLastError());
+
+    std::vector<Pt> sums((size_t)W * nsum);
+    WS_HIP_CHECK(hipMemcpyAsync(sums.data(), S.sums.p, sums.size() * sizeof(Pt), hipMemcpyDeviceToHost, s));
+    WS_HIP_CHECK(hipStreamSynchronize(s));
+
+    // 8. host tail: result = sum_w 2^(c w) [ A_w + m * sum_q 2^q U_{w,q} ]   (Horner, MSB first)
+    uint32_t logm = 0;
+    while ((1u << logm) < m) logm++;
+    Pt acc = C::infinity();
+    for (int w = (int)W - 1; w >= 0; w--) {
+        for (uint32_t k = 0; k < c; k++) acc = C::dbl(acc);
+        const Pt* row = &sums[(size_t)w * nsum];
+        Pt u = C::infinity();
+        for (int q = (int)logJ - 1; q >= 0; q--) {
+            u = C::dbl(u);
+            u = C::add(u, row[q]);
+        }
+        for (uint32_t k = 0; k < logm; k++) u = C::dbl(u);
+        u = C::add(u, row[logJ]);
+        acc = C::add(acc, u);
+    }
+    *out_host = acc;
+    return WS_OK;
+}
+
+int msm_g1_dev_xyzz(const Fe* d_scalars, const Affine<Fq>* d_points, uint64_t n, XYZZ<Fq>* out_host, hipStream_t s) {
+    return msm_run<G1>(0, d_scalars, d_points, n, out_host, s);
+}
+int msm_g2_dev_xyzz(const Fe* d_scalars, const Affine<Fq2>* d_points, uint64_t n, XYZZ<Fq2>* out_host, hipStream_t s) {
+    return msm_run<G2>(1, d_scalars, d_points, n, out_host, s);
+}
+int msm_g1_dev(const Fe* d_scalars, const Affine<Fq>* d_points, uint64_t n, Jac<Fq>* out_host, hipStream_t s) {
+    XYZZ<Fq> r;
+    int rc = msm_g1_dev_xyzz(d_scalars, d_points, n, &r, s);
+    if (rc) return rc;
+    *out_host = G1::to_affine_jac(r);
+    return WS_OK;
+}
+int msm_g2_dev(const Fe* d_scalars, const Affine<Fq2>* d_points, uint64_t n, Jac<Fq2>* out_host, hipStream_t s) {
+    XYZZ<Fq2> r;
+    int rc = msm_g2_dev_xyzz(d_scalars, d_points, n, &r, s);
+    if (rc) return rc;
+    *out_host = G2::to_affine_jac(r);
+    return WS_OK;
+}
+
+}  // namespace wsnark

@@ -1,0 +1,321 @@
+// ntt.hip -- radix-2 NTT / iNTT over BN128 Fr for gfx950.
+//
+// Replaces SURVEY.md section 8a rows a15-a17 (/root/reference src/build_fft.js:
+// __rawfft :223-372, fft_fft :159-187, __finalInverse :550-648, fft_ifft :189-221,
+// __reversePermutation :650-715).  Same function, different algorithm: the reference
+// bit-reverses and then runs log2(n) in-place DIT stages over the whole array from one
+// thread; here the transform is factored n = L0*L1*...(<= 4 digits of <= 2^10) and each
+// digit is one kernel pass whose length-L sub-transforms run entirely in LDS:
+//
+//   pass p (not last): tile = L_p x T elements {hi*L*S + j*S + lo0+t}: T-element (T*32 B)
+//        coalesced runs, DIF butterflies in LDS, inter-digit twiddle w_N^(c*k*i_rest) applied
+//        on the way out, stored back to the same places;
+//   last pass: tile = T values of the first digit x L contiguous elements; results are
+//        written to their final natural-order (digit-reversed) position in T-element runs,
+//        so no separate permutation pass exists.
+//   first pass reads the caller's buffer and writes a scratch buffer, the last pass reads
+//   scratch and writes the caller's buffer => in place for the caller, no extra copy.
+//
+// HBM traffic: np passes x (32 B read + 32 B write) per element, np = 3 at 2^22.
+// Arithmetic is exact, so outputs are bit-identical to the reference's.
+#include "internal.h"
+
+namespace wsnark {
+
+struct alignas(16) Q128 {
+    uint64_t a, b;
+};
+
+struct PassArgs {
+    const Fe* in;
+    Fe* out;
+    uint32_t log_n, log_L, log_S, log_T;
+    uint32_t is_last, log_S0, log_L0;         // last pass: stride and size of digit 0
+    uint32_t np, kdig[4];
+    const Fe* tw_small; uint32_t log_lmax;    // w_Lmax^j, j < Lmax/2 (direction-specific)
+    const Fe* tw_lo; const Fe* tw_hi; uint32_t h;   // two-level w_N^e = tw_hi[e>>h] * tw_lo[e & mask]
+    uint32_t apply_twiddle;
+    const Fe* cs_lo; const Fe* cs_hi; uint32_t hc; uint32_t prescale;   // coset factors w_2N^i
+    uint32_t scale;
+    Fe n_inv;
+};
+
+__device__ __forceinline__ Fe lds_get(const Q128* plo, const Q128* phi, uint32_t i) {
+    Q128 a = plo[i], b = phi[i];
+    return Fe{{a.a, a.b, b.a, b.b}};
+}
+__device__ __forceinline__ void lds_put(Q128* plo, Q128* phi, uint32_t i, const Fe& v) {
+    plo[i] = Q128{v.l[0], v.l[1]};
+    phi[i] = Q128{v.l[2], v.l[3]};
+}
+
+__global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
+    WS_DYN_SMEM(Q128, sm);
+    const uint32_t log_L = A.log_L, log_T = A.log_T;
+    const uint32_t L = 1u << log_L, T = 1u << log_T, LT = L << log_T;
+    Q128* plo = sm;
+    Q128* phi = sm + LT;
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+    const uint32_t w = blockIdx.x;
+
+    // ---- tile coordinates ----
+    uint64_t base = 0;       // non-last: hi*L*S + lo0
+    uint32_t lo0 = 0;        // non-last: first lower-digit value of the tile
+    uint32_t a0 = 0, mid = 0;
+    if (!A.is_last) {
+        const uint32_t tiles_per_block = 1u << (A.log_S - log_T);
+        const uint32_t hi = w >> (A.log_S - log_T);
+        lo0 = (w & (tiles_per_block - 1)) << log_T;
+        base = ((uint64_t)hi << (log_L + A.log_S)) + lo0;
+    } else {
+        const uint32_t log_groups = A.log_L0 - log_T;     // tiles along digit 0
+        a0 = (w & ((1u << log_groups) - 1)) << log_T;
+        mid = w >> log_groups;
+    }
+
+    // ---- load tile into LDS (element (j,t) at j*T + t), optional coset pre-scale ----
+    for (uint32_t idx = tid; idx < LT; idx += nthr) {
+        uint32_t j, t;
+        uint64_t g;
+        if (!A.is_last) {
+            t = idx & (T - 1); j = idx >> log_T;
+            g = base + ((uint64_t)j << A.log_S) + t;
+        } else {
+            j = idx & (L - 1); t = idx >> log_L;
+            g = ((uint64_t)(a0 + t) << A.log_S0) + ((uint64_t)mid << log_L) + j;
+        }
+        Fe v = A.in[g];
+        if (A.prescale) {   // only ever set for pass 0, where storage index == input index
+            uint32_t e = (uint32_t)g;
+            Fe f = Fr::mul(A.cs_hi[e >> A.hc], A.cs_lo[e & ((1u << A.hc) - 1)]);
+            v = Fr::mul(v, f);
+        }
+        lds_put(plo, phi, (j << log_T) + t, v);
+    }
+    __syncthreads();
+
+    // ---- length-L DIF transform of every column t (Gentleman-Sande; output bit-reversed) ----
+    const uint32_t nbf = LT >> 1;
+    for (int hs = (int)log_L - 1; hs >= 0; hs--) {
+        const uint32_t hmask = (1u << hs) - 1;
+        for (uint32_t idx = tid; idx < nbf; idx += nthr) {
+            const uint32_t t = idx & (T - 1), bb = idx >> log_T;
+            const uint32_t jlow = bb & hmask;
+            const uint32_t j = ((bb >> hs) << (hs + 1)) | jlow;
+            const uint32_t i0 = (j << log_T) + t, i1 = i0 + (1u << (hs + log_T));
+            Fe u = lds_get(plo, phi, i0), v = lds_get(plo, phi, i1);
+            Fe s = Fr::add(u, v), d = Fr::sub(u, v);
+            if (hs > 0) {
+                // w_{2h}^{jlow} = w_Lmax^(jlow * Lmax/(2h))
+                const uint32_t ti = jlow << (A.log_lmax - 1 - hs);
+                d = Fr::mul(d, A.tw_small[ti]);
+            }
+            lds_put(plo, phi, i0, s);
+            lds_put(plo, phi, i1, d);
+        }
+        __syncthreads();
+    }
+
+    // ---- write out ----
+    if (!A.is_last) {
+        const uint32_t log_c = A.log_n - log_L - A.log_S;   // c = N / (L*S)
+        for (uint32_t idx = tid; idx < LT; idx += nthr) {
+            const uint32_t t = idx & (T - 1), kk = idx >> log_T;
+            const uint32_t r = __brev(kk) >> (32 - log_L);
+            Fe v = lds_get(plo, phi, (r << log_T) + t);
+            if (A.apply_twiddle) {
+                const uint32_t e = (kk * (lo0 + t)) << log_c;
+                Fe f = Fr::mul(A.tw_hi[e >> A.h], A.tw_lo[e & ((1u << A.h) - 1)]);
+                v = Fr::mul(v, f);
+            }
+            A.out[base + ((uint64_t)kk << A.log_S) + t] = v;
+        }
+    } else {
+        // digit-reverse the middle digits k_1..k_{np-2} of this tile
+        uint64_t revmid = 0;
+        {
+            uint32_t rem = mid, shift = 0;
+            for (uint32_t d = 0; d + 1 < A.np; d++) shift += A.kdig[d];   // = log2(L_0..L_{np-2})
+            for (int d = (int)A.np - 2; d >= 1; d--) {
+                shift -= A.kdig[d];
+                const uint32_t kd = rem & ((1u << A.kdig[d]) - 1);
+                rem >>= A.kdig[d];
+                revmid += (uint64_t)kd << shift;
+            }
+        }
+        const uint32_t log_rest = A.log_n - log_L;   // multiplier of the last digit
+        for (uint32_t idx = tid; idx < LT; idx += nthr) {
+            const uint32_t t = idx & (T - 1), kk = idx >> log_T;
+            const uint32_t r = (log_L == 0) ? 0 : (__brev(kk) >> (32 - log_L));
+            Fe v = lds_get(plo, phi, (r << log_T) + t);
+            if (A.scale) v = Fr::mul(v, A.n_inv);
+            A.out[((uint64_t)kk << log_rest) + revmid + a0 + t] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side: plans (twiddle tables) and pass scheduling
+// ---------------------------------------------------------------------------
+static const int LOG_LMAX = 10;
+
+struct NttPlan {
+    int bits = 0;
+    int np = 1;
+    int k[4] = {0, 0, 0, 0};
+    int h = 0, hc = 0;
+    DevBuf tw_small[2], tw_lo[2], tw_hi[2];   // [0] forward root, [1] inverse root
+    DevBuf cs_lo, cs_hi;                      // coset w_{2n}^i (forward root)
+    Fe n_inv;
+};
+
+// w_{2^28} = 5^((r-1)/2^28) (src/build_fft.js:29-47), plain form
+static Fe root_2_28_mont() {
+    Fe plain = {{0x9bd61b6e725b19f0ull, 0x402d111e41112ed4ull, 0x00e0a7eb8ef62abcull, 0x2a3c09f0a58a7e85ull}};
+    return Fr::to_mont(plain);
+}
+static Fe root_of_unity(int s) {   // w_{2^s}, Montgomery
+    Fe w = root_2_28_mont();
+    for (int i = 28; i > s; i--) w = Fr::sqr(w);
+    return w;
+}
+static void powers(const Fe& base, size_t count, std::vector<Fe>& out) {
+    out.resize(count);
+    Fe acc = Fr::one();
+    for (size_t i = 0; i < count; i++) { out[i] = acc; acc = Fr::mul(acc, base); }
+}
+static int upload(DevBuf& b, const std::vector<Fe>& v, hipStream_t s) {
+    WS_HIP_CHECK(b.alloc(v.size() * sizeof(Fe)));
+    WS_HIP_CHECK(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(Fe), hipMemcpyHostToDevice, s));
+    WS_HIP_CHECK(hipStreamSynchronize(s));   // v is a host temporary
+    return WS_OK;
+}
+
+static int build_plan(int bits, NttPlan& P, hipStream_t s) {
+    P.bits = bits;
+    P.np = bits <= LOG_LMAX ? 1 : (bits <= 16 ? 2 : (bits <= 24 ? 3 : 4));
+    int basek = bits / P.np, rem = bits % P.np;
+    for (int d = 0; d < P.np; d++) P.k[d] = basek + (d < rem ? 1 : 0);
+    P.h = (bits + 1) / 2;
+    P.hc = (bits + 1) / 2;
+    std::vector<Fe> tmp;
+    for (int dir = 0; dir < 2; dir++) {
+        Fe wl = root_of_unity(LOG_LMAX), wn = root_of_unity(bits);
+        if (dir) { wl = Fr::inv(wl); wn = Fr::inv(wn); }
+        powers(wl, (size_t)1 << (LOG_LMAX - 1), tmp);
+        int rc = upload(P.tw_small[dir], tmp, s); if (rc) return rc;
+        powers(wn, (size_t)1 << P.h, tmp);
+        rc = upload(P.tw_lo[dir], tmp, s); if (rc) return rc;
+        powers(Fr::pow_u64(wn, (uint64_t)1 << P.h), (size_t)1 << (bits - P.h), tmp);
+        rc = upload(P.tw_hi[dir], tmp, s); if (rc) return rc;
+    }
+    if (bits < 28) {
+        Fe g = root_of_unity(bits + 1);
+        powers(g, (size_t)1 << P.hc, tmp);
+        int rc = upload(P.cs_lo, tmp, s); if (rc) return rc;
+        powers(Fr::pow_u64(g, (uint64_t)1 << P.hc), (size_t)1 << (bits - P.hc), tmp);
+        rc = upload(P.cs_hi, tmp, s); if (rc) return rc;
+    }
+    // n^-1 = (2^-1)^bits  (INV2 table of build_fft.js:59-72)
+    Fe two = Fr::add(Fr::one(), Fr::one());
+    Fe half = Fr::inv(two), ninv = Fr::one();
+    for (int i = 0; i < bits; i++) ninv = Fr::mul(ninv, half);
+    P.n_inv = ninv;
+    return WS_OK;
+}
+
+static int get_plan(Context* C, int bits, std::shared_ptr<NttPlan>& P, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(C->mu);
+    auto it = C->ntt_plans.find(bits);
+    if (it == C->ntt_plans.end()) {
+        P = std::make_shared<NttPlan>();
+        int rc = build_plan(bits, *P, s);
+        if (rc) return rc;
+        C->ntt_plans[bits] = P;
+    } else {
+        P = it->second;
+    }
+    return WS_OK;
+}
+
+// two-level table of the coset factors w_{2n}^i, i < n (n = 2^bits): value = hi[i >> hc] * lo[i & mask]
+int ntt_coset_tables(int bits, const Fe** lo, const Fe** hi, int* hc, Fe* n_inv, hipStream_t s) {
+    Context* C = ctx();
+    if (!C) return WS_ERR_NOINIT;
+    if (bits < 1 || bits >= 28) return WS_ERR_SIZE;
+    std::shared_ptr<NttPlan> P;
+    int rc = get_plan(C, bits, P, s);
+    if (rc) return rc;
+    *lo = P->cs_lo.as<Fe>(); *hi = P->cs_hi.as<Fe>(); *hc = P->hc; *n_inv = P->n_inv;
+    return WS_OK;
+}
+
+int ntt_dev(Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s) {
+    Context* C = ctx();
+    if (!C) return WS_ERR_NOINIT;
+    if (!d_data) return WS_ERR_ARG;
+    if (!s) s = C->stream;
+    // src/build_fft.js:92-157: n must be a power of two <= 2^28 (the reference traps otherwise)
+    if (n == 0 || (n & (n - 1)) || n > ((uint64_t)1 << 28)) return WS_ERR_SIZE;
+    int bits = 0;
+    while (((uint64_t)1 << bits) < n) bits++;
+    if (odd && bits >= 28) return WS_ERR_SIZE;   // needs w_{2^29}, which does not exist
+    if (bits == 0) {
+        // fft(n=1) is the identity; ifft(n=1) never terminates in the reference
+        // (src/build_fft.js:575-583) -> reported as a size error here
+        return inverse ? WS_ERR_SIZE : WS_OK;
+    }
+    std::shared_ptr<NttPlan> P;
+    {
+        int rc = get_plan(C, bits, P, s);
+        if (rc) return rc;
+        std::lock_guard<std::mutex> lk(C->mu);
+        if (P->np > 1) WS_HIP_CHECK(C->ntt_scratch.reserve(n * sizeof(Fe)));
+    }
+    Fe* scratch = C->ntt_scratch.as<Fe>();
+    // inverse (reference semantics): raw forward transform, then y[i] = raw[(n-i) mod n]/n
+    //   == DFT with the inverse root, scaled by 1/n; an `odd` input keeps the FORWARD coset
+    //   factors w_2n^i because rawfft(odd) multiplies x[i] by w_2n^i before the index flip.
+    const int dir = inverse ? 1 : 0;
+    int sum_after = bits;
+    for (int p = 0; p < P->np; p++) {
+        PassArgs A;
+        const bool last = (p == P->np - 1);
+        sum_after -= P->k[p];
+        A.in = (p == 0) ? d_data : scratch;
+        A.out = last ? d_data : scratch;
+        A.log_n = bits; A.log_L = P->k[p]; A.log_S = sum_after;
+        A.is_last = last ? 1 : 0;
+        A.log_L0 = P->k[0]; A.log_S0 = bits - P->k[0];
+        A.np = P->np;
+        for (int d = 0; d < 4; d++) A.kdig[d] = P->k[d];
+        A.tw_small = P->tw_small[dir].as<Fe>(); A.log_lmax = LOG_LMAX;
+        A.tw_lo = P->tw_lo[dir].as<Fe>(); A.tw_hi = P->tw_hi[dir].as<Fe>(); A.h = P->h;
+        A.apply_twiddle = last ? 0 : 1;
+        A.cs_lo = P->cs_lo.as<Fe>(); A.cs_hi = P->cs_hi.as<Fe>(); A.hc = P->hc;
+        A.prescale = (odd && p == 0) ? 1 : 0;
+        A.scale = (inverse && last) ? 1 : 0;
+        A.n_inv = P->n_inv;
+        // tile: up to 2048 elements (64 KiB of LDS)
+        int log_T = 11 - (int)A.log_L;
+        if (log_T > 5) log_T = 5;
+        if (log_T < 0) log_T = 0;
+        if (P->np == 1) {
+            log_T = 0; A.log_S0 = 0; A.log_L0 = 0;
+        } else if (last) {
+            if (log_T > (int)A.log_L0) log_T = A.log_L0;
+        } else {
+            if (log_T > (int)A.log_S) log_T = A.log_S;
+        }
+        A.log_T = log_T;
+        const uint32_t grid = (uint32_t)(n >> (A.log_L + log_T));
+        const size_t smem = ((size_t)1 << (A.log_L + log_T)) * 2 * sizeof(Q128);
+        C->timer.begin(last ? "ntt_pass_last" : "ntt_pass", s);
+        hipLaunchKernelGGL(ntt_pass_kernel, dim3(grid), dim3(512), smem, s, A);
+        C->timer.end(s);
+        WS_HIP_CHECK(hipGetLastError());
+    }
+    return WS_OK;
+}
+
+}  // namespace wsnark

@@ -1,0 +1,173 @@
+// prove.hip -- proving-key ingestion and Groth16 proof assembly.
+//
+// Replaces SURVEY.md section 8a rows a21-a23 (/root/reference src/bn128.js:580-720
+// Bn128.groth16GenProof; key layout tools/buildpkey.js:124-240; loadPoint1/2
+// src/bn128.js:441-453).  The five MSMs and CALC_H run on the GPU with the key resident in
+// HBM; the O(1) tail (5 scalar multiplications, 9 additions, 3 inversions, src/bn128.js:671-712)
+// runs on the host with the same field/curve headers.
+#include <stdio.h>
+#include <string.h>
+
+#include "internal.h"
+
+namespace wsnark {
+
+struct ProvingKey {
+    uint32_t n_vars = 0, n_public = 0, domain = 0;
+    Affine<Fq> alfa1, beta1, delta1;
+    Affine<Fq2> beta2, delta2;
+    CsrMatrix polsA, polsB;
+    DevBuf pointsA, pointsB1, pointsB2, pointsC, pointsH;
+    DevBuf witness, h;          // per-proof device buffers (grow-only)
+    std::mutex mu;              // one proof at a time per handle
+};
+
+static bool range_ok(uint64_t off, uint64_t bytes, size_t len) { return off <= len && bytes <= len - off; }
+
+int pkey_load(const uint8_t* buf, size_t len, ProvingKey** out) {
+    Context* C = ctx();
+    if (!C) return WS_ERR_NOINIT;
+    if (!buf || !out) return WS_ERR_ARG;
+    // 10 x u32 header (src/bn128.js:581-591), then alfa1, beta1, delta1 (3 x 64 B), beta2, delta2 (2 x 128 B)
+    if (len < 40 + 448) { set_last_error("proving key shorter than its fixed header"); return WS_ERR_FORMAT; }
+    uint32_t h[10];
+    memcpy(h, buf, 40);
+    const uint32_t nv = h[0], np = h[1], dom = h[2];
+    const uint64_t pPolsA = h[3], pPolsB = h[4], pA = h[5], pB1 = h[6], pB2 = h[7], pC = h[8], pH = h[9];
+    if (nv == 0 || np + 1 > nv) { set_last_error("proving key: nPublic + 1 > nVars"); return WS_ERR_FORMAT; }
+    if (dom < 2 || (dom & (dom - 1)) || dom > (1u << 27)) { set_last_error("proving key: domainSize must be a power of two in [2, 2^27]"); return WS_ERR_SIZE; }
+    const uint64_t nC = (uint64_t)nv - np - 1;
+    if (!(pPolsA >= 488 && pPolsA <= pPolsB && pPolsB <= pA) || !range_ok(pA, (uint64_t)nv * 64, len) ||
+        !range_ok(pB1, (uint64_t)nv * 64, len) || !range_ok(pB2, (uint64_t)nv * 128, len) ||
+        !range_ok(pC, nC * 64, len) || !range_ok(pH, (uint64_t)dom * 64, len)) {
+        set_last_error("proving key: section offsets out of range");
+        return WS_ERR_FORMAT;
+    }
+    std::unique_ptr<ProvingKey> K(new ProvingKey());
+    K->n_vars = nv; K->n_public = np; K->domain = dom;
+    memcpy(&K->alfa1, buf + 40, 64);
+    memcpy(&K->beta1, buf + 40 + 64, 64);
+    memcpy(&K->delta1, buf + 40 + 128, 64);
+    memcpy(&K->beta2, buf + 40 + 192, 128);
+    memcpy(&K->delta2, buf + 40 + 320, 128);
+    hipStream_t s = C->stream;
+    // true section bounds from the header (the reference slices over-long: src/bn128.js:592-593)
+    size_t used = 0;
+    int rc = pols_to_csr(buf + pPolsA, (size_t)(pPolsB - pPolsA), nv, dom, &K->polsA, &used, s);
+    if (rc) return rc;
+    rc = pols_to_csr(buf + pPolsB, (size_t)(pA - pPolsB), nv, dom, &K->polsB, &used, s);
+    if (rc) return rc;
+    struct Sec { DevBuf* d; uint64_t off, bytes; } secs[5] = {
+        {&K->pointsA, pA, (uint64_t)nv * 64}, {&K->pointsB1, pB1, (uint64_t)nv * 64}, {&K->pointsB2, pB2, (uint64_t)nv * 128},
+        {&K->pointsC, pC, nC * 64}, {&K->pointsH, pH, (uint64_t)dom * 64}};
+    for (auto& sc : secs) {
+        WS_HIP_CHECK(sc.d->alloc((size_t)sc.bytes));
+        if (sc.bytes) WS_HIP_CHECK(hipMemcpyAsync(sc.d->p, buf + sc.off, (size_t)sc.bytes, hipMemcpyHostToDevice, s));
+    }
+    WS_HIP_CHECK(K->witness.alloc((size_t)nv * 32));
+    WS_HIP_CHECK(K->h.alloc((size_t)dom * 32));
+    WS_HIP_CHECK(hipStreamSynchronize(s));
+    *out = K.release();
+    return WS_OK;
+}
+
+void pkey_free(ProvingKey* K) { delete K; }
+void pkey_info(const ProvingKey* K, uint32_t* nv, uint32_t* np, uint32_t* dom) {
+    if (nv) *nv = K->n_vars;
+    if (np) *np = K->n_public;
+    if (dom) *dom = K->domain;
+}
+
+static int os_random(uint8_t* out, size_t n) {
+    FILE* f = fopen("/dev/urandom", "rb");
+    if (!f) return -1;
+    size_t got = fread(out, 1, n, f);
+    fclose(f);
+    return got == n ? 0 : -1;
+}
+
+static void store_plain(uint8_t* dst, const Fe& mont) {
+    Fe p = Fq::from_mont(mont);
+    memcpy(dst, &p, 32);
+}
+
+// witness already in K->witness (device) -- or d_witness given
+int groth16_prove(ProvingKey* K, const Fe* d_witness, const uint8_t* r32, const uint8_t* s32, uint8_t* out384,
+                  hipStream_t s) {
+    Context* C = ctx();
+    if (!C) return WS_ERR_NOINIT;
+    if (!s) s = C->stream;
+    const uint32_t nv = K->n_vars, np = K->n_public, dom = K->domain;
+    uint8_t rnd[64];
+    if (!r32 || !s32) {
+        if (os_random(rnd, 64)) { set_last_error("cannot read /dev/urandom"); return WS_ERR_ARG; }
+        if (!r32) r32 = rnd;
+        if (!s32) s32 = rnd + 32;
+    }
+    int rc;
+    // CALC_H, then the H MSM over domainSize pairs (src/bn128.js:607-615)
+    Fe* d_h = K->h.as<Fe>();
+    if ((rc = calc_h_dev(d_witness, nv, K->polsA, K->polsB, dom, d_h, s))) return rc;
+    XYZZ<Fq> sA, sB1, sC, sH;
+    XYZZ<Fq2> sB2;
+    if ((rc = msm_g1_dev_xyzz(d_h, K->pointsH.as<Affine<Fq>>(), dom, &sH, s))) return rc;
+    if ((rc = msm_g1_dev_xyzz(d_witness, K->pointsA.as<Affine<Fq>>(), nv, &sA, s))) return rc;              // :617
+    if ((rc = msm_g1_dev_xyzz(d_witness, K->pointsB1.as<Affine<Fq>>(), nv, &sB1, s))) return rc;            // :618
+    if ((rc = msm_g2_dev_xyzz(d_witness, K->pointsB2.as<Affine<Fq2>>(), nv, &sB2, s))) return rc;           // :619
+    if ((rc = msm_g1_dev_xyzz(d_witness + (np + 1), K->pointsC.as<Affine<Fq>>(), (uint64_t)nv - np - 1, &sC, s))) return rc;  // :620
+
+    // r, s are raw 256-bit values (not reduced, src/bn128.js:642-661); every point here has prime
+    // order r, so k*P == (k mod r)*P and (r*s)*P == ((r mod r)(s mod r) mod r)*P  (:700-702)
+    Fe rr, ss;
+    memcpy(&rr, r32, 32);
+    memcpy(&ss, s32, 32);
+    rr = Fr::reduce_full(rr);
+    ss = Fr::reduce_full(ss);
+    Fe rs = Fr::from_mont(Fr::mul(Fr::to_mont(rr), Fr::to_mont(ss)));
+    const uint8_t* rb = reinterpret_cast<const uint8_t*>(&rr);
+    const uint8_t* sb = reinterpret_cast<const uint8_t*>(&ss);
+    const uint8_t* rsb = reinterpret_cast<const uint8_t*>(&rs);
+
+    const G1::Pt alfa1 = G1::from_affine(K->alfa1), beta1 = G1::from_affine(K->beta1), delta1 = G1::from_affine(K->delta1);
+    const G2::Pt beta2 = G2::from_affine(K->beta2), delta2 = G2::from_affine(K->delta2);
+    // pi_a = sum A + alfa1 + r*delta1                               (:671-673)
+    G1::Pt pi_a = G1::add(G1::add(alfa1, sA), G1::mul_bytes(delta1, rb, 32));
+    // pi_b = sum B2 + beta2 + s*delta2                              (:676-678)
+    G2::Pt pi_b = G2::add(G2::add(beta2, sB2), G2::mul_bytes(delta2, sb, 32));
+    // pib1 = sum B1 + beta1 + s*delta1                              (:681-683)
+    G1::Pt pib1 = G1::add(G1::add(beta1, sB1), G1::mul_bytes(delta1, sb, 32));
+    // pi_c = sum C + sum H + s*pi_a + r*pib1 - (r*s)*delta1         (:687-704)
+    G1::Pt pi_c = G1::add(sC, sH);
+    pi_c = G1::add(pi_c, G1::mul_bytes(pi_a, sb, 32));
+    pi_c = G1::add(pi_c, G1::mul_bytes(pib1, rb, 32));
+    pi_c = G1::add(pi_c, G1::neg(G1::mul_bytes(delta1, rsb, 32)));
+
+    // affine + fromMontgomery (:706-712); infinity prints as (0, 1, 0)
+    Jac<Fq> a = G1::to_affine_jac(pi_a), c = G1::to_affine_jac(pi_c);
+    Jac<Fq2> b = G2::to_affine_jac(pi_b);
+    store_plain(out384 + 0, a.x); store_plain(out384 + 32, a.y); store_plain(out384 + 64, a.z);
+    store_plain(out384 + 96, b.x.c0); store_plain(out384 + 128, b.x.c1);
+    store_plain(out384 + 160, b.y.c0); store_plain(out384 + 192, b.y.c1);
+    store_plain(out384 + 224, b.z.c0); store_plain(out384 + 256, b.z.c1);
+    store_plain(out384 + 288, c.x); store_plain(out384 + 320, c.y); store_plain(out384 + 352, c.z);
+    return WS_OK;
+}
+
+int groth16_prove_host_witness(ProvingKey* K, const uint8_t* witness, size_t witness_len, const uint8_t* r32,
+                               const uint8_t* s32, uint8_t* out384) {
+    Context* C = ctx();
+    if (!C) return WS_ERR_NOINIT;
+    if ((uint64_t)witness_len < (uint64_t)K->n_vars * 32) { set_last_error("witness shorter than nVars*32 bytes"); return WS_ERR_SIZE; }
+    std::lock_guard<std::mutex> lk(K->mu);
+    WS_HIP_CHECK(hipMemcpyAsync(K->witness.p, witness, (size_t)K->n_vars * 32, hipMemcpyHostToDevice, C->stream));
+    return groth16_prove(K, K->witness.as<Fe>(), r32, s32, out384, C->stream);
+}
+
+int groth16_prove_dev_witness(ProvingKey* K, const Fe* d_witness, size_t witness_len, const uint8_t* r32,
+                              const uint8_t* s32, uint8_t* out384, hipStream_t s) {
+    if ((uint64_t)witness_len < (uint64_t)K->n_vars * 32) { set_last_error("witness shorter than nVars*32 bytes"); return WS_ERR_SIZE; }
+    std::lock_guard<std::mutex> lk(K->mu);
+    return groth16_prove(K, d_witness, r32, s32, out384, s);
+}
+
+}  // namespace wsnark

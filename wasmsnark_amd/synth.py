@@ -1,0 +1,230 @@
+"""Synthetic Groth16 circuits, proving keys and witnesses in the reference's binary formats.
+
+The reference ships no proving key (test/data/proving_key.bin is missing), so
+end-to-end proving runs on synthetic keys built here from KNOWN toxic waste (tau, alpha, beta,
+gamma, delta).  Formats follow /root/reference tools/buildpkey.js:124-240 (proving_key.bin) and
+tools/buildwitness.js:36-69 (witness.bin); key semantics are snarkjs "groth" (SURVEY.md section 8
+row a22): A[s] = a_s(tau) G1, B1/B2[s] = b_s(tau) G, C[s] = ((beta a_s + alpha b_s + c_s)(tau)/delta) G1
+for s > nPublic, hExps[i] = (tau^i Z(tau)/delta) G1, pols in the Lagrange basis over w_n.
+
+Because the toxic waste is known, the expected proof for given (r, s) can be written down in the
+exponent (expected_proof_scalars), which gives a size-independent end-to-end check that needs no
+pairing: the GPU proof must equal (a G1, b G2, c G1).
+
+Group scalar multiplications are delegated to a `mul_base(g, scalars_bytes) -> affine bytes`
+callable (the GPU library at full size; tests may pass the CPU oracle for tiny sizes).
+"""
+import random
+import struct
+
+Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+W28 = 0x2a3c09f0a58a7e8500e0a7eb8ef62abc402d111e41112ed49bd61b6e725b19f0  # 5^((r-1)/2^28), src/build_fft.js:29-47
+MONT = 1 << 256
+
+
+def root_of_unity(bits):
+    w = W28
+    for _ in range(28 - bits):
+        w = w * w % R
+    return w
+
+
+def le32(v):
+    return int(v).to_bytes(32, "little")
+
+
+class Circuit:
+    """R1CS in column form: cols[M][s] = {constraint: coef} for M in A,B,C."""
+
+    def __init__(self, n_vars, n_public, domain, A, B, Cm, witness):
+        self.n_vars, self.n_public, self.domain = n_vars, n_public, domain
+        self.A, self.B, self.C = A, B, Cm
+        self.witness = witness
+
+
+def make_circuit(log_domain, n_public=2, seed=1, nnz_extra=0.5):
+    """Multiplication-chain circuit with domainSize = 2^log_domain exactly:
+    nConstraints = domain - nPublic - 1 'real' rows, then the nPublic+1 input-binding rows
+    (w_i * 0 = 0) old snarkjs appends.  Every constraint defines one
+    fresh variable: w[out] = (sum A w)(sum B w), so the witness is computed on the fly."""
+    rnd = random.Random(seed)
+    domain = 1 << log_domain
+    n_cons = domain - n_public - 1
+    if n_cons < 1:
+        raise ValueError("domain too small for nPublic")
+    n_free = n_public + 2                      # public inputs + two private seeds
+    n_vars = 1 + n_free + n_cons
+    w = [0] * n_vars
+    w[0] = 1
+    for i in range(1, 1 + n_free):
+        w[i] = rnd.randrange(1, R) if i % 3 else rnd.randrange(1, 1 << 32)
+    A = [dict() for _ in range(n_vars)]
+    B = [dict() for _ in range(n_vars)]
+    Cm = [dict() for _ in range(n_vars)]
+    for c in range(n_cons):
+        out = 1 + n_free + c
+        lhs = rhs = 0
+        for M, acc in ((A, 0), (B, 1)):
+            k = 1 + (1 if rnd.random() < nnz_extra else 0)
+            tot = 0
+            used = set()
+            for _ in range(k):
+                s = rnd.randrange(0, out)
+                if s in used:
+                    continue
+                used.add(s)
+                coef = rnd.randrange(1, R) if rnd.random() < 0.5 else rnd.randrange(1, 8)
+                M[s][c] = coef
+                tot = (tot + coef * w[s]) % R
+            if acc == 0:
+                lhs = tot
+            else:
+                rhs = tot
+        Cm[out][c] = 1
+        w[out] = lhs * rhs % R
+    for i in range(n_public + 1):              # input-binding rows: A = w_i, B = 0, C = 0
+        A[i][n_cons + i] = 1
+    return Circuit(n_vars, n_public, domain, A, B, Cm, w)
+
+
+def lagrange_at(tau, log_domain):
+    """L_c(tau) for the domain {w^c}: (tau^n - 1)/n * w^c/(tau - w^c), by batch inversion."""
+    n = 1 << log_domain
+    w = root_of_unity(log_domain)
+    pw = [1] * n
+    for i in range(1, n):
+        pw[i] = pw[i - 1] * w % R
+    den = [(tau - x) % R for x in pw]
+    pref = [1] * (n + 1)
+    for i in range(n):
+        pref[i + 1] = pref[i] * den[i] % R
+    inv = pow(pref[n], R - 2, R)
+    z = (pow(tau, n, R) - 1) % R
+    zn = z * pow(n, R - 2, R) % R
+    L = [0] * n
+    for i in range(n - 1, -1, -1):
+        di = inv * pref[i] % R
+        inv = inv * den[i] % R
+        L[i] = zn * pw[i] % R * di % R
+    return L, z
+
+
+class Setup:
+    pass
+
+
+def setup(circ, seed=7):
+    """Toxic waste + per-signal scalars a_s, b_s, c_s at tau."""
+    rnd = random.Random(seed)
+    S = Setup()
+    S.tau, S.alpha, S.beta, S.gamma, S.delta = (rnd.randrange(2, R) for _ in range(5))
+    log_domain = circ.domain.bit_length() - 1
+    L, S.z = lagrange_at(S.tau, log_domain)
+    ev = lambda col: sum(coef * L[c] for c, coef in col.items()) % R
+    S.a = [ev(c) for c in circ.A]
+    S.b = [ev(c) for c in circ.B]
+    S.c = [ev(c) for c in circ.C]
+    return S
+
+
+def _pol_blob(cols):
+    # tools/buildpkey.js:79-89 writeTransformedPolynomial: u32 count, then (u32 idx, 32 B coef Montgomery)
+    out = bytearray()
+    for col in cols:
+        out += struct.pack("<I", len(col))
+        for idx, coef in col.items():
+            out += struct.pack("<I", idx) + le32(coef * MONT % R)
+    return bytes(out)
+
+
+def build_key(circ, S, mul_base):
+    """Returns (proving_key.bin bytes, verification key dict in the reference's JSON shape)."""
+    nv, npub, dom = circ.n_vars, circ.n_public, circ.domain
+    dinv, ginv = pow(S.delta, R - 2, R), pow(S.gamma, R - 2, R)
+    kc = [(S.beta * S.a[s] + S.alpha * S.b[s] + S.c[s]) % R for s in range(nv)]
+    hs, t = [], S.z * dinv % R
+    for _ in range(dom):
+        hs.append(t)
+        t = t * S.tau % R
+    cat = lambda xs: b"".join(le32(x) for x in xs)
+    g1_scalars = ([S.alpha, S.beta, S.delta] + S.a + S.b + [kc[s] * dinv % R for s in range(npub + 1, nv)] + hs
+                  + [kc[s] * ginv % R for s in range(npub + 1)])
+    g1 = mul_base(1, cat(g1_scalars))
+    g2 = mul_base(2, cat([S.beta, S.delta, S.gamma] + S.b))
+    P1 = lambda i: g1[64 * i:64 * (i + 1)]
+    P2 = lambda i: g2[128 * i:128 * (i + 1)]
+    o = 3
+    ptsA = g1[64 * o:64 * (o + nv)]; o += nv
+    ptsB1 = g1[64 * o:64 * (o + nv)]; o += nv
+    nC = nv - npub - 1
+    ptsC = g1[64 * o:64 * (o + nC)]; o += nC
+    ptsH = g1[64 * o:64 * (o + dom)]; o += dom
+    ic = [P1(o + i) for i in range(npub + 1)]
+    ptsB2 = g2[128 * 3:128 * (3 + nv)]
+    polsA, polsB = _pol_blob(circ.A), _pol_blob(circ.B)
+    # tools/buildpkey.js:124-186 layout
+    fixed = P1(0) + P1(1) + P1(2) + P2(0) + P2(1)
+    pPolsA = 40 + len(fixed)
+    pPolsB = pPolsA + len(polsA)
+    pA = pPolsB + len(polsB)
+    pB1 = pA + len(ptsA)
+    pB2 = pB1 + len(ptsB1)
+    pC = pB2 + len(ptsB2)
+    pH = pC + len(ptsC)
+    header = struct.pack("<10I", nv, npub, dom, pPolsA, pPolsB, pA, pB1, pB2, pC, pH)
+    pkey = header + fixed + polsA + polsB + ptsA + ptsB1 + ptsB2 + ptsC + ptsH
+
+    def dec1(p):  # Montgomery affine bytes -> decimal strings (x, y, 1)
+        rinv = pow(MONT, Q - 2, Q)
+        x = int.from_bytes(p[:32], "little") * rinv % Q
+        y = int.from_bytes(p[32:64], "little") * rinv % Q
+        return [str(x), str(y), "1"]
+
+    def dec2(p):
+        rinv = pow(MONT, Q - 2, Q)
+        v = [str(int.from_bytes(p[i:i + 32], "little") * rinv % Q) for i in range(0, 128, 32)]
+        return [[v[0], v[1]], [v[2], v[3]], ["1", "0"]]
+
+    vk = {"protocol": "groth", "nPublic": npub, "vk_alfa_1": dec1(P1(0)), "vk_beta_2": dec2(P2(0)),
+          "vk_gamma_2": dec2(P2(2)), "vk_delta_2": dec2(P2(1)), "IC": [dec1(p) for p in ic]}
+    return pkey, vk
+
+
+def witness_bin(circ):
+    return b"".join(le32(x) for x in circ.witness)   # tools/buildwitness.js:36-41: plain LE
+
+
+def public_signals(circ):
+    return [str(x) for x in circ.witness[1:circ.n_public + 1]]
+
+
+def expected_proof_scalars(circ, S, r32, s32):
+    """Discrete logs (a, b, c) of the proof elements w.r.t. G1/G2/G1 for blinding bytes r32, s32."""
+    r = int.from_bytes(r32, "little") % R
+    s = int.from_bytes(s32, "little") % R
+    w = circ.witness
+    Aw = sum(x * y for x, y in zip(w, S.a)) % R
+    Bw = sum(x * y for x, y in zip(w, S.b)) % R
+    Cw = sum(x * y for x, y in zip(w, S.c)) % R
+    dinv = pow(S.delta, R - 2, R)
+    h_tau_z = (Aw * Bw - Cw) % R                   # h(tau) Z(tau) = A(tau)B(tau) - C(tau)
+    a = (S.alpha + Aw + r * S.delta) % R
+    b = (S.beta + Bw + s * S.delta) % R
+    priv = sum(w[i] * ((S.beta * S.a[i] + S.alpha * S.b[i] + S.c[i]) % R) for i in range(circ.n_public + 1, circ.n_vars)) % R
+    c = ((priv + h_tau_z) * dinv + s * a + r * b - r * s % R * S.delta) % R
+    return a, b, c
+
+
+def expected_proof(circ, S, r32, s32, mul_base):
+    """The proof object (decimal strings, reference shape) computed from the toxic waste."""
+    a, b, c = expected_proof_scalars(circ, S, r32, s32)
+    g1 = mul_base(1, le32(a) + le32(c))
+    g2 = mul_base(2, le32(b))
+    rinv = pow(MONT, Q - 2, Q)
+    dec = lambda bs: str(int.from_bytes(bs, "little") * rinv % Q)
+    def p1(p):
+        return ["0", "1", "0"] if p[:32] == b"\0" * 32 else [dec(p[:32]), dec(p[32:64]), "1"]
+    pa, pc = p1(g1[:64]), p1(g1[64:128])
+    pb = [[dec(g2[0:32]), dec(g2[32:64])], [dec(g2[64:96]), dec(g2[96:128])], ["1", "0"]]
+    return {"pi_a": pa, "pi_b": pb, "pi_c": pc}
