@@ -62,6 +62,13 @@ int wsnark_g2_msm(const void* scalars, const void* points_affine, uint64_t n, vo
 int wsnark_g1_msm_dev(const void* d_scalars, const void* d_points_affine, uint64_t n, void* out96_host, void* stream);
 int wsnark_g2_msm_dev(const void* d_scalars, const void* d_points_affine, uint64_t n, void* out192_host, void* stream);
 
+/* The gather step of Bn128.g1_multiexp / g2_multiexp (src/bn128.js:374-382, 406-414): serial EC
+ * sum of `count` Jacobian-Montgomery partial results (any z), host arithmetic, no GPU needed.
+ * Used to combine per-GPU partial MSMs after the one all-gather of a sharded run.
+ * out = affine-normalised Jacobian-Montgomery. */
+int wsnark_g1_sum(const void* jac_points, uint64_t count, void* out96);
+int wsnark_g2_sum(const void* jac_points, uint64_t count, void* out192);
+
 /* fft_fft / fft_ifft (src/build_fft.js:159-221), in place on n Montgomery Fr elements.
  * n must be a power of two <= 2^28 (the reference traps otherwise, :137-154);
  * inverse with n == 1 is rejected (the reference never returns, :575-583). */

@@ -1,0 +1,55 @@
+"""N>1 path on CPU: two processes (gloo), each computes the partial MSM of its contiguous shard
+(kernel sources under the CPU emulator), one all_gather of the 96/192-byte partials, local EC sum;
+every rank must hold the full MSM (src/bn128.js:353-383 with workers = ranks)."""
+import os
+import random
+import subprocess
+import sys
+
+from conftest import ROOT
+
+WORKER = r'''
+import os, sys, random
+sys.path.insert(0, os.environ["WS_ROOT"]); sys.path.insert(0, os.path.join(os.environ["WS_ROOT"], "tests"))
+import torch.distributed as dist
+from emul_util import emul_bn128
+from oracle import pyoracle as orc
+from wasmsnark_amd import dist as wd
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+bn = emul_bn128()
+rnd = random.Random(42)
+for g, n in ((1, 45), (2, 21)):
+    sz = 64 if g == 1 else 128
+    ks = b"".join(rnd.randrange(1, orc.R).to_bytes(32, "little") for _ in range(n))
+    pts = bn.mul_base(g, ks)
+    sc = b"".join(rnd.randrange(1 << 256).to_bytes(32, "little") for _ in range(n))
+    lo, hi = wd.shard_bounds(n, world, rank)
+    f = bn.g1_multiexp if g == 1 else bn.g2_multiexp
+    part = f(sc[lo * 32:hi * 32], pts[lo * sz:hi * sz])
+    full = wd.sharded_msm(bn, g, part)
+    want = orc.g_affine(g, orc.multiexp(g, "multiexp", sc, pts, n))
+    assert full == want, (g, rank)
+dist.barrier()
+open(os.path.join(os.environ["WS_OUT"], "rank%d.ok" % rank), "w").write("ok")
+'''
+
+
+def test_sharded_msm_world2(tmp_path):
+    from emul_util import emul_bn128
+    emul_bn128()   # build the emulator library once, before the ranks race for it
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, WS_ROOT=ROOT, WS_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29611", str(script)],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
+
+
+def test_shard_bounds():
+    from wasmsnark_amd.dist import shard_bounds
+    # floor(n/W) each, remainder to the last; n < W gives the first W-1 workers nothing
+    assert [shard_bounds(10, 4, r) for r in range(4)] == [(0, 2), (2, 4), (4, 6), (6, 10)]
+    assert [shard_bounds(3, 8, r) for r in range(8)][-1] == (0, 3)

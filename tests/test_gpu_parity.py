@@ -1,0 +1,232 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI of
+libwsnark.so, against (1) the reference-generated golden vectors, (2) the pinned CPU oracle on
+seeded inputs at sizes it finishes in seconds, and (3) size-independent exact properties at
+BASELINE.json's full sizes (NTT round trip / coset identity at 2^22 and 2^20, MSM of 2^20 pairs
+against its closed form in the exponent, Groth16 proofs against the toxic-waste closed form).
+Everything is integer arithmetic: the bar is bit-exact equality."""
+import base64
+import ctypes
+import json
+import os
+import random
+
+import pytest
+
+from conftest import GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+H = bytes.fromhex
+B64 = base64.b64decode
+
+
+@pytest.fixture(scope="module")
+def bn():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import wasmsnark_amd
+    b = wasmsnark_amd.build(device=0)
+    assert b.lib.path.endswith("wasmsnark_amd/libwsnark.so")   # the native HIP library, in-tree
+    return b
+
+
+def rand_fr(rnd, n):
+    return b"".join(rnd.randrange(1 << 256).to_bytes(32, "little") for _ in range(n))
+
+
+# ------------------------------------------------------------------ golden vectors
+def test_fft_golden(bn):
+    for c in load_golden("fft.json")["cases"]:
+        x = B64(c["input_mont"])
+        assert bn.fft(x, 0) == B64(c["fft0"])
+        assert bn.fft(x, 1) == B64(c["fft1"])
+        if c["n"] == 1:
+            with pytest.raises(Exception):
+                bn.ifft(x, 0)
+        else:
+            assert bn.ifft(x, 0) == B64(c["ifft0"])
+            assert bn.ifft(x, 1) == B64(c["ifft1"])
+    for n in (0, 3, 6, 1000):                     # the reference traps (src/build_fft.js:137-154)
+        with pytest.raises(Exception):
+            bn.fft(b"\0" * (32 * n), 0)
+
+
+@pytest.mark.parametrize("g", [1, 2])
+def test_msm_golden(bn, g):
+    for c in load_golden("msm.json")["g%d" % g]:
+        if c["flavour"] == "accumulate_into_3G":
+            continue
+        s, p = B64(c["scalars"]), B64(c["points"])
+        out = bn.g1_multiexp(s, p) if g == 1 else bn.g2_multiexp(s, p)
+        assert out == H(c["multiexp_affine"]), (g, c["n"], c["flavour"])
+
+
+def test_calc_h_golden(bn):
+    for c in load_golden("calch.json"):
+        h = bn.calcH(B64(c["signals"]), B64(c["polsA"]), B64(c["polsB"]), c["nSignals"], c["domain"])
+        assert h == B64(c["h"])
+
+
+@pytest.mark.parametrize("name", ["t3", "t6"])
+def test_proofs_golden(bn, name):
+    rd = lambda ext: open(os.path.join(GOLDEN, "keys", name + ext), "rb").read()
+    key = bn.load_key(rd(".pkey.bin"))
+    for c in load_golden("proofs.json")[name]:
+        assert bn.groth16GenProof(rd(".witness.bin"), key, r=H(c["r"]), s=H(c["s"])) == c["proof"]
+
+
+# ------------------------------------------------------------------ vs the oracle
+@pytest.mark.parametrize("bits", [1, 4, 9, 10, 11, 14, 16, 17, 18])
+def test_ntt_vs_oracle(bn, orc, bits):
+    n = 1 << bits
+    x = orc.to_mont_n(rand_fr(random.Random(bits), n))
+    for odd in (0, 1):
+        assert bn.fft(x, odd) == orc.fft(x, n, odd)
+        assert bn.ifft(x, odd) == orc.fft(x, n, odd, inverse=True)
+
+
+def test_montgomery_maps_vs_oracle(bn, orc):
+    x = rand_fr(random.Random(9), 5000)
+    xr = b"".join((int.from_bytes(x[i:i + 32], "little") % orc.R).to_bytes(32, "little") for i in range(0, len(x), 32))
+    assert bn.toMontgomeryN(xr) == orc.to_mont_n(xr)
+    assert bn.fromMontgomeryN(xr) == orc.from_mont_n(xr)
+
+
+def _skewed_scalars(rnd, n, R):
+    out = []
+    for _ in range(n):
+        u = rnd.random()          # example-witness histogram of SURVEY.md section 8d
+        if u < 0.067: v = 0
+        elif u < 0.098: v = 1
+        elif u < 0.2: v = rnd.randrange(1 << 32)
+        elif u < 0.22: v = (1 << 256) - 1 - rnd.randrange(1 << 30)      # >= r, raw 256-bit
+        else: v = rnd.randrange(R)
+        out.append(v.to_bytes(32, "little"))
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("g,n", [(1, 1), (1, 63), (1, 4096), (1, 20000), (2, 1), (2, 1500)])
+def test_msm_vs_oracle(bn, orc, g, n):
+    rnd = random.Random(1000 * g + n)
+    sz = 64 if g == 1 else 128
+    pts = bytearray(bn.mul_base(g, b"".join(rnd.randrange(1, orc.R).to_bytes(32, "little") for _ in range(n))))
+    if n > 10:   # planted: infinity points, a duplicated point, a P / -P pair
+        pts[3 * sz:4 * sz] = b"\0" * sz
+        pts[5 * sz:6 * sz] = pts[4 * sz:5 * sz]
+    sc = _skewed_scalars(rnd, n, orc.R)
+    got = bn.g1_multiexp(sc, bytes(pts)) if g == 1 else bn.g2_multiexp(sc, bytes(pts))
+    want = orc.g_affine(g, orc.multiexp(g, "workers8", sc, bytes(pts), n))
+    assert got == want
+
+
+def test_msm_all_same_point(bn, orc):
+    n = 3000
+    pts = bn.mul_base(1, (7).to_bytes(32, "little")) * n
+    sc = (5).to_bytes(32, "little") * n
+    want = bn.mul_base(1, (35 * n % orc.R).to_bytes(32, "little"))
+    assert bn.g1_multiexp(sc, pts)[:64] == want
+
+
+def test_msm_window_override(bn, orc, monkeypatch):
+    rnd = random.Random(77)
+    n = 2000
+    pts = bn.mul_base(1, b"".join(rnd.randrange(1, orc.R).to_bytes(32, "little") for _ in range(n)))
+    sc = _skewed_scalars(rnd, n, orc.R)
+    want = orc.g_affine(1, orc.multiexp(1, "workers8", sc, pts, n))
+    for c in ("4", "9", "13", "16"):
+        monkeypatch.setenv("WSNARK_MSM_C", c)
+        assert bn.g1_multiexp(sc, pts) == want, c
+
+
+def test_calc_h_vs_oracle(bn, orc):
+    import struct
+    rnd = random.Random(31)
+    nS, dom = 3000, 4096
+    sig = b"".join(rnd.randrange(orc.R).to_bytes(32, "little") for _ in range(nS))
+    def pols():
+        out = bytearray()
+        for s in range(nS):
+            k = rnd.randrange(0, 4)
+            out += struct.pack("<I", k)
+            for idx in rnd.sample(range(dom), k):
+                out += struct.pack("<I", idx) + rnd.randrange(orc.R).to_bytes(32, "little")
+        return bytes(out)
+    A, B = pols(), pols()
+    assert bn.calcH(sig, A, B, nS, dom) == orc.calc_h(sig, A, B, nS, dom)
+
+
+# ------------------------------------------------------------------ full-size properties
+def _torch_bytes(t):
+    return t.cpu().numpy().tobytes()
+
+
+def test_ntt_2p22_roundtrip_and_coset_identity(bn):
+    # reference test/fft.js:16-121 at BASELINE config 3 size, device-resident
+    import torch
+    n = 1 << 22
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randint(0, 256, (n * 32,), dtype=torch.uint8, generator=g)
+    x[31::32] &= 0x1F                              # < 2^253 < r: valid field elements
+    d = x.cuda()
+    y = d.clone()
+    bn.fft_dev(y.data_ptr(), n, 0)
+    assert not torch.equal(y, d)
+    bn.fft_dev(y.data_ptr(), n, 0, inverse=True)
+    torch.cuda.synchronize()
+    assert torch.equal(y, d)                       # ifft(fft(x)) == x, bit for bit
+    # coset identity at n = 2^21 -> 2n = 2^22: fft(x,0) and fft(x,1) interleaved == fft(pad(x), 2n)
+    m = n // 2
+    e, o = d[: m * 32].clone(), d[: m * 32].clone()
+    bn.fft_dev(e.data_ptr(), m, 0)
+    bn.fft_dev(o.data_ptr(), m, 1)
+    big = torch.zeros(n * 32, dtype=torch.uint8, device="cuda")
+    big[: m * 32] = d[: m * 32]
+    bn.fft_dev(big.data_ptr(), n, 0)
+    torch.cuda.synchronize()
+    inter = torch.stack([e.view(m, 32), o.view(m, 32)], dim=1).reshape(-1)
+    assert torch.equal(inter, big)
+
+
+def test_msm_2p20_closed_form(bn, orc):
+    # BASELINE config 2: 2^20 pairs.  P_i = k_i G, so MSM == (sum s_i k_i mod r) G exactly.
+    import torch
+    n = 1 << 20
+    rnd = random.Random(2020)
+    ks = [rnd.randrange(1, orc.R) for _ in range(n)]
+    pts = bn.mul_base(1, b"".join(k.to_bytes(32, "little") for k in ks))
+    for flavour in ("uniform", "circuit"):
+        if flavour == "uniform":
+            ss = [rnd.randrange(orc.R) for _ in range(n)]
+            sc = b"".join(s.to_bytes(32, "little") for s in ss)
+        else:
+            sc = _skewed_scalars(rnd, n, orc.R)
+            ss = [int.from_bytes(sc[i:i + 32], "little") for i in range(0, n * 32, 32)]
+        expect = sum(s * k for s, k in zip(ss, ks)) % orc.R
+        want = bn.mul_base(1, expect.to_bytes(32, "little"))
+        d_s = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
+        d_p = torch.frombuffer(bytearray(pts), dtype=torch.uint8).cuda()
+        got = bn.g1_multiexp_dev(d_s.data_ptr(), d_p.data_ptr(), n)
+        assert got[:64] == want, flavour
+        assert got == bn.g1_multiexp(sc, pts)      # host-pointer boundary gives the same
+
+
+@pytest.mark.parametrize("logd", [10, 16])
+def test_prove_vs_toxic_waste_closed_form(bn, logd):
+    from wasmsnark_amd import synth
+    circ = synth.make_circuit(logd, n_public=5, seed=logd)
+    S = synth.setup(circ, seed=3)
+    pkey, _ = synth.build_key(circ, S, bn.mul_base)
+    key = bn.load_key(pkey)
+    wit = synth.witness_bin(circ)
+    for r, s in ((b"\0" * 32, b"\0" * 32), (b"\xff" * 32, b"\xfe" + b"\xff" * 31), (os.urandom(32), os.urandom(32))):
+        got = bn.groth16GenProof(wit, key, r=r, s=s)
+        assert got == synth.expected_proof(circ, S, r, s, bn.mul_base)
+
+
+def test_prove_small_vs_oracle(bn, orc):
+    from wasmsnark_amd import synth
+    circ = synth.make_circuit(8, n_public=2, seed=88)
+    S = synth.setup(circ, seed=5)
+    pkey, _ = synth.build_key(circ, S, bn.mul_base)
+    wit = synth.witness_bin(circ)
+    r, s = os.urandom(32), os.urandom(32)
+    assert bn.groth16GenProof(wit, pkey, r=r, s=s) == orc.groth16_prove(wit, pkey, r, s, workers=8)

@@ -16,6 +16,7 @@ ERRORS = {1: "WSNARK_ERR_SIZE", 2: "WSNARK_ERR_FORMAT", 3: "WSNARK_ERR_HIP", 4: 
 SYMBOLS = [
     "wsnark_init", "wsnark_shutdown", "wsnark_last_error", "wsnark_device_info",
     "wsnark_g1_msm", "wsnark_g2_msm", "wsnark_g1_msm_dev", "wsnark_g2_msm_dev",
+    "wsnark_g1_sum", "wsnark_g2_sum",
     "wsnark_fr_ntt", "wsnark_fr_ntt_dev", "wsnark_fr_to_montgomery", "wsnark_fr_from_montgomery",
     "wsnark_calc_h", "wsnark_pkey_load", "wsnark_pkey_free", "wsnark_pkey_info",
     "wsnark_groth16_prove", "wsnark_groth16_prove_dev",
@@ -51,6 +52,8 @@ class Lib:
         c.wsnark_g2_msm.argtypes = [vp, vp, u64, vp]
         c.wsnark_g1_msm_dev.argtypes = [vp, vp, u64, vp, vp]
         c.wsnark_g2_msm_dev.argtypes = [vp, vp, u64, vp, vp]
+        c.wsnark_g1_sum.argtypes = [vp, u64, vp]
+        c.wsnark_g2_sum.argtypes = [vp, u64, vp]
         c.wsnark_fr_ntt.argtypes = [vp, u64, C.c_int, C.c_int]
         c.wsnark_fr_ntt_dev.argtypes = [vp, u64, C.c_int, C.c_int, vp]
         c.wsnark_fr_to_montgomery.argtypes = [vp, vp, u64]

@@ -88,6 +88,40 @@ class Bn128:
         self.lib.check(self.lib.c.wsnark_g2_msm(s, p, n, out))
         return bytes(out)
 
+    # --- the gather loop of src/bn128.js:374-382 / 406-414: EC sum of Jacobian partials ---
+    def g1_sum(self, partials):
+        b, n = _buf(partials)
+        out = (C.c_uint8 * 96)()
+        self.lib.check(self.lib.c.wsnark_g1_sum(b, n // 96, out))
+        return bytes(out)
+
+    def g2_sum(self, partials):
+        b, n = _buf(partials)
+        out = (C.c_uint8 * 192)()
+        self.lib.check(self.lib.c.wsnark_g2_sum(b, n // 192, out))
+        return bytes(out)
+
+    # --- device-resident variants (pointers from torch tensors / hipMalloc) ---
+    def g1_multiexp_dev(self, d_scalars, d_points, n, stream=None):
+        out = (C.c_uint8 * 96)()
+        self.lib.check(self.lib.c.wsnark_g1_msm_dev(d_scalars, d_points, n, out, stream))
+        return bytes(out)
+
+    def g2_multiexp_dev(self, d_scalars, d_points, n, stream=None):
+        out = (C.c_uint8 * 192)()
+        self.lib.check(self.lib.c.wsnark_g2_msm_dev(d_scalars, d_points, n, out, stream))
+        return bytes(out)
+
+    def fft_dev(self, d_buf, n, odd=0, inverse=False, stream=None):
+        self.lib.check(self.lib.c.wsnark_fr_ntt_dev(d_buf, n, int(odd), 1 if inverse else 0, stream))
+
+    def groth16GenProof_dev(self, d_witness, witness_len, key, r=None, s=None, stream=None):
+        out = (C.c_uint8 * 384)()
+        rb = _buf(r)[0] if r is not None else None
+        sb = _buf(s)[0] if s is not None else None
+        self.lib.check(self.lib.c.wsnark_groth16_prove_dev(key._h, d_witness, witness_len, rb, sb, out, stream))
+        return proof_from_bytes(bytes(out))
+
     # --- src/bn128.js:569-578 (worker CALC_H :126-166) ---
     def calcH(self, signals, polsA, polsB, nSignals, domainSize):
         s, _ = _buf(signals)

@@ -17,6 +17,8 @@ int groth16_prove_host_witness(ProvingKey* K, const uint8_t* witness, size_t wit
                                const uint8_t* s32, uint8_t* out384);
 int groth16_prove_dev_witness(ProvingKey* K, const Fe* d_witness, size_t witness_len, const uint8_t* r32,
                               const uint8_t* s32, uint8_t* out384, hipStream_t s);
+void g1_sum_host(const uint8_t* pts, uint64_t count, uint8_t* out96);
+void g2_sum_host(const uint8_t* pts, uint64_t count, uint8_t* out192);
 int g1_mul_base_batch(const void* base, const void* scalars, uint64_t n, void* out);
 int g2_mul_base_batch(const void* base, const void* scalars, uint64_t n, void* out);
 }  // namespace wsnark
@@ -81,6 +83,17 @@ int wsnark_g2_msm_dev(const void* d_scalars, const void* d_points, uint64_t n, v
     int rc = msm_g2_dev((const Fe*)d_scalars, (const Affine<Fq2>*)d_points, n, &r, (hipStream_t)stream);
     if (rc) return rc;
     memcpy(out192_host, &r, sizeof r);
+    return WSNARK_OK;
+}
+
+int wsnark_g1_sum(const void* jac_points, uint64_t count, void* out96) {
+    if (!out96 || (count && !jac_points)) return WSNARK_ERR_ARG;
+    g1_sum_host((const uint8_t*)jac_points, count, (uint8_t*)out96);
+    return WSNARK_OK;
+}
+int wsnark_g2_sum(const void* jac_points, uint64_t count, void* out192) {
+    if (!out192 || (count && !jac_points)) return WSNARK_ERR_ARG;
+    g2_sum_host((const uint8_t*)jac_points, count, (uint8_t*)out192);
     return WSNARK_OK;
 }
 

@@ -78,6 +78,22 @@ void pkey_info(const ProvingKey* K, uint32_t* nv, uint32_t* np, uint32_t* dom) {
     if (dom) *dom = K->domain;
 }
 
+// serial EC sum of Jacobian-Montgomery partials: the main-thread gather loop of the reference
+// (src/bn128.js:374-382 g1m_add over the workers' results; :406-414 for G2).  Host arithmetic.
+template <class C, class F>
+static void sum_jac(const uint8_t* pts, uint64_t count, uint8_t* out) {
+    typename C::Pt acc = C::infinity();
+    for (uint64_t i = 0; i < count; i++) {
+        Jac<F> j;
+        memcpy(&j, pts + i * sizeof(Jac<F>), sizeof j);
+        acc = C::add(acc, C::from_jac(j));
+    }
+    Jac<F> r = C::to_affine_jac(acc);
+    memcpy(out, &r, sizeof r);
+}
+void g1_sum_host(const uint8_t* pts, uint64_t count, uint8_t* out96) { sum_jac<G1, Fq>(pts, count, out96); }
+void g2_sum_host(const uint8_t* pts, uint64_t count, uint8_t* out192) { sum_jac<G2, Fq2>(pts, count, out192); }
+
 static int os_random(uint8_t* out, size_t n) {
     FILE* f = fopen("/dev/urandom", "rb");
     if (!f) return -1;

@@ -1,0 +1,37 @@
+"""Multi-GPU sharding of the MSM: one process per GPU (torch.distributed; backend "nccl" is RCCL
+over xGMI on ROCm, "gloo" in the CPU tests).
+
+Mirrors the reference's only parallel strategy -- contiguous split of the (scalar, point) pairs
+over workers, then gather + serial EC sum of the 96/192-byte Jacobian partials on the main thread
+(/root/reference src/bn128.js:353-383, 385-415) -- with workers = GPUs and the gather = ONE
+all_gather of 96 (G1) or 192 (G2) bytes per rank.  RCCL has no elliptic-curve reduction operator,
+so the 'all-reduce' of partial sums is all_gather + a local W-way EC sum on every rank
+(wsnark_g1_sum / wsnark_g2_sum), which is bit-identical on all ranks.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n, world, rank):
+    """floor(n/W) pairs per worker, remainder to the last (src/bn128.js:354-361)."""
+    per = n // world
+    lo = rank * per
+    hi = n if rank == world - 1 else lo + per
+    return lo, hi
+
+
+def allgather_partials(partial, device=None):
+    """partial: bytes (96 or 192).  Returns the concatenation over ranks, in rank order."""
+    world = dist.get_world_size()
+    t = torch.frombuffer(bytearray(partial), dtype=torch.uint8)
+    if device is not None:
+        t = t.to(device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return b"".join(bytes(o.cpu().numpy().tobytes()) for o in out)
+
+
+def sharded_msm(bn, g, local_partial, device=None):
+    """Combine per-rank partial MSM results (Jacobian-Montgomery bytes) into the full sum."""
+    allp = allgather_partials(local_partial, device)
+    return bn.g1_sum(allp) if g == 1 else bn.g2_sum(allp)
