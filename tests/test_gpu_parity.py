@@ -160,28 +160,33 @@ def _torch_bytes(t):
 
 
 def test_ntt_2p22_roundtrip_and_coset_identity(bn):
-    # reference test/fft.js:16-121 at BASELINE config 3 size, device-resident
+    # reference test/fft.js:16-121 at BASELINE config 3 size, device-resident.
+    # The _dev entry points run on the library's own stream: synchronise around them.
     import torch
+    sync = torch.cuda.synchronize
     n = 1 << 22
     g = torch.Generator(device="cpu").manual_seed(5)
     x = torch.randint(0, 256, (n * 32,), dtype=torch.uint8, generator=g)
     x[31::32] &= 0x1F                              # < 2^253 < r: valid field elements
     d = x.cuda()
     y = d.clone()
+    sync()
     bn.fft_dev(y.data_ptr(), n, 0)
+    sync()
     assert not torch.equal(y, d)
     bn.fft_dev(y.data_ptr(), n, 0, inverse=True)
-    torch.cuda.synchronize()
+    sync()
     assert torch.equal(y, d)                       # ifft(fft(x)) == x, bit for bit
     # coset identity at n = 2^21 -> 2n = 2^22: fft(x,0) and fft(x,1) interleaved == fft(pad(x), 2n)
     m = n // 2
     e, o = d[: m * 32].clone(), d[: m * 32].clone()
-    bn.fft_dev(e.data_ptr(), m, 0)
-    bn.fft_dev(o.data_ptr(), m, 1)
     big = torch.zeros(n * 32, dtype=torch.uint8, device="cuda")
     big[: m * 32] = d[: m * 32]
+    sync()
+    bn.fft_dev(e.data_ptr(), m, 0)
+    bn.fft_dev(o.data_ptr(), m, 1)
     bn.fft_dev(big.data_ptr(), n, 0)
-    torch.cuda.synchronize()
+    sync()
     inter = torch.stack([e.view(m, 32), o.view(m, 32)], dim=1).reshape(-1)
     assert torch.equal(inter, big)
 
@@ -204,6 +209,7 @@ def test_msm_2p20_closed_form(bn, orc):
         want = bn.mul_base(1, expect.to_bytes(32, "little"))
         d_s = torch.frombuffer(bytearray(sc), dtype=torch.uint8).cuda()
         d_p = torch.frombuffer(bytearray(pts), dtype=torch.uint8).cuda()
+        torch.cuda.synchronize()
         got = bn.g1_multiexp_dev(d_s.data_ptr(), d_p.data_ptr(), n)
         assert got[:64] == want, flavour
         assert got == bn.g1_multiexp(sc, pts)      # host-pointer boundary gives the same
