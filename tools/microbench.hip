@@ -73,6 +73,86 @@ __global__ void k_modmul(Fe* out, const Fe* in, int iters) {
     out[t] = r;
 }
 
+// ---- candidate multipliers (timing probes only; not canonical, not used by the product) ----
+#define M29 0x1FFFFFFFu
+// radix 2^29, 9 limbs, one 64-bit accumulator per column chain: no carries, no moves
+__device__ __forceinline__ void mul_r29(const uint32_t a[9], const uint32_t b[9], uint32_t r[9]) {
+    const uint32_t p[9] = {0x187cfd47u, 0x10460b6cu, 0x1c72a34fu, 0x02d522d0u, 0x1585d978u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+    const uint32_t np = 0x04866389u;
+    uint32_t m[9];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)a[i] * b[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * p[k - i];
+        m[k] = ((uint32_t)acc * np) & M29;
+        acc += (uint64_t)m[k] * p[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) acc += (uint64_t)a[i] * b[k - i];
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) acc += (uint64_t)m[i] * p[k - i];
+        r[k - 9] = (uint32_t)acc & M29;
+        acc >>= 29;
+    }
+    r[8] = (uint32_t)acc;
+}
+// same with two interleaved accumulators (even / odd product index) to shorten the dependent chain
+__device__ __forceinline__ void mul_r29x2(const uint32_t a[9], const uint32_t b[9], uint32_t r[9]) {
+    const uint32_t p[9] = {0x187cfd47u, 0x10460b6cu, 0x1c72a34fu, 0x02d522d0u, 0x1585d978u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+    const uint32_t np = 0x04866389u;
+    uint32_t m[9];
+    uint64_t acc = 0, acc2 = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)a[i] * b[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc2 += (uint64_t)m[i] * p[k - i];
+        acc += acc2; acc2 = 0;
+        m[k] = ((uint32_t)acc * np) & M29;
+        acc += (uint64_t)m[k] * p[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) acc += (uint64_t)a[i] * b[k - i];
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) acc2 += (uint64_t)m[i] * p[k - i];
+        acc += acc2; acc2 = 0;
+        r[k - 9] = (uint32_t)acc & M29;
+        acc >>= 29;
+    }
+    r[8] = (uint32_t)acc;
+}
+template <int VAR, int CHAINS>
+__global__ void k_r29(uint32_t* out, const uint32_t* in, int iters) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t x[CHAINS][9], y[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) { y[j] = in[t * 8 + (j & 7)] & M29; }
+#pragma unroll
+    for (int k = 0; k < CHAINS; k++)
+#pragma unroll
+        for (int j = 0; j < 9; j++) x[k][j] = (in[t * 8 + (j & 7)] + k) & M29;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < CHAINS; k++) { if (VAR == 0) mul_r29(x[k], y, x[k]); else mul_r29x2(x[k], y, x[k]); }
+    }
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < CHAINS; k++)
+#pragma unroll
+        for (int j = 0; j < 9; j++) r ^= x[k][j];
+    out[t] = r;
+}
+
 template <class F>
 static int run(const char* name, F launch, double ops_per_thread_iter, int iters, int threads_total) {
     hipEvent_t a, b;
@@ -111,5 +191,11 @@ int main() {
     run("mont_mul32 x1 chain (modmul/s)", [&](int n) { hipLaunchKernelGGL(k_modmul<1>, dim3(blocks), dim3(threads), 0, 0, (Fe*)buf, in, n); }, 1, im, total);
     run("mont_mul32 x2 chains (modmul/s)", [&](int n) { hipLaunchKernelGGL(k_modmul<2>, dim3(blocks), dim3(threads), 0, 0, (Fe*)buf, in, n); }, 2, im, total);
     run("mont_mul32 x4 chains (modmul/s)", [&](int n) { hipLaunchKernelGGL(k_modmul<4>, dim3(blocks), dim3(threads), 0, 0, (Fe*)buf, in, n); }, 4, im, total);
+    run("radix29 mul x1 chain (modmul/s)", [&](int n) { hipLaunchKernelGGL((k_r29<0, 1>), dim3(blocks), dim3(threads), 0, 0, (uint32_t*)buf, (const uint32_t*)in, n); }, 1, im, total);
+    run("radix29 mul x2 chains (modmul/s)", [&](int n) { hipLaunchKernelGGL((k_r29<0, 2>), dim3(blocks), dim3(threads), 0, 0, (uint32_t*)buf, (const uint32_t*)in, n); }, 2, im, total);
+    run("radix29 2-acc mul x1 chain (modmul/s)", [&](int n) { hipLaunchKernelGGL((k_r29<1, 1>), dim3(blocks), dim3(threads), 0, 0, (uint32_t*)buf, (const uint32_t*)in, n); }, 1, im, total);
+    run("mont_mul32 x1 chain, 2 blocks/CU", [&](int n) { hipLaunchKernelGGL(k_modmul<1>, dim3(prop.multiProcessorCount * 2), dim3(threads), 0, 0, (Fe*)buf, in, n); }, 1, im, prop.multiProcessorCount * 2 * threads);
+    run("radix29 x1 chain, 2 blocks/CU", [&](int n) { hipLaunchKernelGGL((k_r29<0, 1>), dim3(prop.multiProcessorCount * 2), dim3(threads), 0, 0, (uint32_t*)buf, (const uint32_t*)in, n); }, 1, im, prop.multiProcessorCount * 2 * threads);
+    run("radix29 x1 chain, 4 blocks/CU", [&](int n) { hipLaunchKernelGGL((k_r29<0, 1>), dim3(prop.multiProcessorCount * 4), dim3(threads), 0, 0, (uint32_t*)buf, (const uint32_t*)in, n); }, 1, im, prop.multiProcessorCount * 4 * threads);
     return 0;
 }

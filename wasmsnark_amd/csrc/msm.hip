@@ -31,12 +31,9 @@ namespace wsnark {
 
 static const uint32_t CHUNK = 8;          // buckets per msm_chunks lane
 
-struct HotTask { uint32_t bucket, start, len; };
-struct HotBucket { uint32_t bucket, first_task, ntasks; };
-
 struct MsmScratch {
     DevBuf keys, vals, keys_out, vals_out, sort_tmp;
-    DevBuf bstart, bend, buckets, counters, hot_tasks, hot_buckets, partials;
+    DevBuf bstart, bend, buckets, counters, tasks, multi, partials;
     DevBuf chunkS, chunkA, sums;
 };
 
@@ -103,68 +100,134 @@ __device__ __forceinline__ typename C::Pt accumulate_range(const typename C::Aff
     return acc;
 }
 
-template <class C>
-__global__ __launch_bounds__(256) void msm_accumulate(const typename C::Aff* __restrict__ points,
-                                                        const uint32_t* __restrict__ vals,
-                                                        const uint32_t* __restrict__ bstart,
-                                                        const uint32_t* __restrict__ bend, uint32_t nbuckets,
-                                                        uint32_t lmax, typename C::Pt* __restrict__ buckets,
-                                                        uint32_t* __restrict__ counters, HotTask* __restrict__ hot_tasks,
-                                                        HotBucket* __restrict__ hot_buckets, uint32_t hot_cap) {
+// ---- task planning: every bucket is cut into tasks of <= lmax entries; tasks are ordered
+// longest-first (counting sort on a 255-level length key) so that (a) the lanes of one wavefront
+// run (almost) the same trip count and (b) long tasks start first and never form the tail.
+static const uint32_t PARTIAL_FLAG = 0x80000000u;
+struct Task { uint32_t dst, start, len; };          // dst: bucket index, or PARTIAL_FLAG | partial slot
+struct MultiBucket { uint32_t bucket, first_partial, ntasks; };
+
+__device__ __forceinline__ uint32_t len_key(uint32_t len, uint32_t lmax) {   // 1..255, monotone in len
+    uint32_t k = (len * 255u + lmax - 1) / lmax;
+    return k > 255u ? 255u : (k < 1u ? 1u : k);
+}
+
+__global__ __launch_bounds__(256) void msm_plan_hist(const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bend,
+                                                       uint32_t nbuckets, uint32_t lmax, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lcnt[256];
+    lcnt[threadIdx.x] = 0;
+    __syncthreads();
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nbuckets) return;
-    const uint32_t s = bstart[b], cnt = bend[b] - s;
-    const uint32_t first = cnt < lmax ? cnt : lmax;
-    buckets[b] = accumulate_range<C>(points, vals, s, first);
-    if (cnt > lmax) {
-        const uint32_t rest = cnt - lmax;
-        const uint32_t nt = (rest + lmax - 1) / lmax;
-        const uint32_t slot = atomicAdd(&counters[0], nt);
-        const uint32_t hb = atomicAdd(&counters[1], 1u);
-        if (slot + nt <= hot_cap && hb < hot_cap) {
-            hot_buckets[hb] = HotBucket{b, slot, nt};
-            for (uint32_t k = 0; k < nt; k++) {
-                const uint32_t off = lmax * (k + 1);
-                const uint32_t len = (cnt - off) < lmax ? (cnt - off) : lmax;
-                hot_tasks[slot + k] = HotTask{b, s + off, len};
-            }
-        } else {
-            atomicAdd(&counters[2], 1u);   // overflow flag (cannot happen: hot_cap >= total/lmax + buckets)
+    if (b < nbuckets) {
+        const uint32_t cnt = bend[b] - bstart[b];
+        if (cnt) {
+            const uint32_t nt = (cnt + lmax - 1) / lmax, rem = cnt - (nt - 1) * lmax;
+            if (nt > 1) atomicAdd(&lcnt[255], nt - 1);
+            atomicAdd(&lcnt[len_key(rem, lmax)], 1u);
         }
+    }
+    __syncthreads();
+    if (lcnt[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lcnt[threadIdx.x]);
+}
+
+// cursor[k] = number of tasks with a longer key (descending order); counters[3] = total tasks
+__global__ void msm_plan_offsets(const uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor, uint32_t* __restrict__ counters) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t off = 0;
+    for (int k = 255; k >= 0; k--) { cursor[k] = off; off += hist[k]; }
+    counters[3] = off;
+}
+
+template <class C>
+__global__ __launch_bounds__(256) void msm_plan_emit(const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bend,
+                                                       uint32_t nbuckets, uint32_t lmax, uint32_t* __restrict__ cursor,
+                                                       Task* __restrict__ tasks, uint32_t* __restrict__ counters,
+                                                       MultiBucket* __restrict__ multi, typename C::Pt* __restrict__ buckets) {
+    __shared__ uint32_t lcnt[256];
+    __shared__ uint32_t lbase[256];
+    lcnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t cnt = 0, s = 0, nt = 0, rem = 0, krem = 0, r255 = 0, rrem = 0;
+    if (b < nbuckets) {
+        s = bstart[b];
+        cnt = bend[b] - s;
+        if (cnt) {
+            nt = (cnt + lmax - 1) / lmax;
+            rem = cnt - (nt - 1) * lmax;
+            krem = len_key(rem, lmax);
+            if (nt > 1) r255 = atomicAdd(&lcnt[255], nt - 1);
+            rrem = atomicAdd(&lcnt[krem], 1u);
+        } else {
+            buckets[b] = C::infinity();
+        }
+    }
+    __syncthreads();
+    lbase[threadIdx.x] = lcnt[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], lcnt[threadIdx.x]) : 0;
+    __syncthreads();
+    if (!cnt) return;
+    // the full tasks were ranked before the remainder when krem == 255: keep the two ranges disjoint
+    if (nt == 1) {
+        tasks[lbase[krem] + rrem] = Task{b, s, rem};
+    } else {
+        const uint32_t pbase = atomicAdd(&counters[0], nt);
+        multi[atomicAdd(&counters[1], 1u)] = MultiBucket{b, pbase, nt};
+        for (uint32_t k = 0; k + 1 < nt; k++) tasks[lbase[255] + r255 + k] = Task{PARTIAL_FLAG | (pbase + k), s + k * lmax, lmax};
+        tasks[lbase[krem] + rrem] = Task{PARTIAL_FLAG | (pbase + nt - 1), s + (nt - 1) * lmax, rem};
     }
 }
 
+// 4. one lane per task: mixed additions of the task's points
 template <class C>
-__global__ __launch_bounds__(256) void msm_hot_tasks(const typename C::Aff* __restrict__ points,
-                                                       const uint32_t* __restrict__ vals,
-                                                       const HotTask* __restrict__ tasks, uint32_t ntasks,
-                                                       typename C::Pt* __restrict__ partials) {
+__global__ __launch_bounds__(256) void msm_accumulate(const typename C::Aff* __restrict__ points,
+                                                        const uint32_t* __restrict__ vals,
+                                                        const Task* __restrict__ tasks, uint32_t ntasks,
+                                                        typename C::Pt* __restrict__ buckets,
+                                                        typename C::Pt* __restrict__ partials) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntasks) return;
-    const HotTask h = tasks[t];
-    partials[t] = accumulate_range<C>(points, vals, h.start, h.len);
+    const Task k = tasks[t];
+    const typename C::Pt acc = accumulate_range<C>(points, vals, k.start, k.len);
+    if (k.dst & PARTIAL_FLAG) partials[k.dst & ~PARTIAL_FLAG] = acc;
+    else buckets[k.dst] = acc;
 }
 
-// one wavefront (64 lanes) per hot bucket: lanes stride over the bucket's partial sums, then an
-// LDS tree folds the 64 lane sums into the bucket
+// 5a. buckets cut into a few tasks: one lane sums the partials
+static const uint32_t WAVE_COMBINE_MIN = 17;
 template <class C>
-__global__ __launch_bounds__(64) void msm_hot_combine(const HotBucket* __restrict__ hbs, uint32_t nhb,
-                                                        const typename C::Pt* __restrict__ partials,
-                                                        typename C::Pt* __restrict__ buckets) {
+__global__ __launch_bounds__(256) void msm_combine_small(const MultiBucket* __restrict__ mbs, uint32_t nmb,
+                                                           const typename C::Pt* __restrict__ partials,
+                                                           typename C::Pt* __restrict__ buckets) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nmb) return;
+    const MultiBucket h = mbs[i];
+    if (h.ntasks >= WAVE_COMBINE_MIN) return;
+    typename C::Pt acc = partials[h.first_partial];
+    for (uint32_t k = 1; k < h.ntasks; k++) acc = C::add(acc, partials[h.first_partial + k]);
+    buckets[h.bucket] = acc;
+}
+
+// 5b. hot buckets (many tasks): one wavefront per bucket, lanes stride over the partial sums,
+// then an LDS tree folds the 64 lane sums (wavefront segmented reduction)
+template <class C>
+__global__ __launch_bounds__(64) void msm_combine_wave(const MultiBucket* __restrict__ mbs, uint32_t nmb,
+                                                         const typename C::Pt* __restrict__ partials,
+                                                         typename C::Pt* __restrict__ buckets) {
     __shared__ typename C::Pt sh[64];
     const uint32_t hb = blockIdx.x;
-    if (hb >= nhb) return;
-    const HotBucket h = hbs[hb];
+    if (hb >= nmb) return;
+    const MultiBucket h = mbs[hb];
+    if (h.ntasks < WAVE_COMBINE_MIN) return;
     const uint32_t lane = threadIdx.x;
     typename C::Pt acc = C::infinity();
-    for (uint32_t k = lane; k < h.ntasks; k += 64) acc = C::add(acc, partials[h.first_task + k]);
+    for (uint32_t k = lane; k < h.ntasks; k += 64) acc = C::add(acc, partials[h.first_partial + k]);
     sh[lane] = acc;
     __syncthreads();
     for (uint32_t step = 32; step >= 1; step >>= 1) {
         if (lane < step) sh[lane] = C::add(sh[lane], sh[lane + step]);
         __syncthreads();
     }
-    if (lane == 0) buckets[h.bucket] = C::add(buckets[h.bucket], sh[0]);
+    if (lane == 0) buckets[h.bucket] = sh[0];
 }
 
 // ---------------------------------------------------------------------------
@@ -283,9 +346,10 @@ static int msm_run(int which, const Fe* d_scalars, const typename C::Aff* d_poin
     WS_HIP_CHECK(S.bstart.reserve((size_t)nbuckets * 4));
     WS_HIP_CHECK(S.bend.reserve((size_t)nbuckets * 4));
     WS_HIP_CHECK(S.buckets.reserve((size_t)nbuckets * sizeof(Pt)));
-    WS_HIP_CHECK(S.counters.reserve(64));
-    WS_HIP_CHECK(S.hot_tasks.reserve((size_t)hot_cap * sizeof(HotTask)));
-    WS_HIP_CHECK(S.hot_buckets.reserve((size_t)hot_cap * sizeof(HotBucket)));
+    WS_HIP_CHECK(S.counters.reserve(4096));
+    WS_HIP_CHECK(S.tasks.reserve((size_t)hot_cap * sizeof(Task)));
+    WS_HIP_CHECK(S.multi.reserve((size_t)hot_cap * sizeof(MultiBucket)));
+    WS_HIP_CHECK(S.partials.reserve((size_t)hot_cap * sizeof(Pt)));
     WS_HIP_CHECK(S.chunkS.reserve((size_t)W * J * sizeof(Pt)));
     WS_HIP_CHECK(S.chunkA.reserve((size_t)W * J * sizeof(Pt)));
     WS_HIP_CHECK(S.sums.reserve((size_t)W * nsum * sizeof(Pt)));
@@ -304,35 +368,43 @@ static int msm_run(int which, const Fe* d_scalars, const typename C::Aff* d_poin
     T.end(s);
     if (rc) return rc;
 
+    // counters: [0] partial slots, [1] multi-task buckets, [3] total tasks; [16..271] length histogram,
+    // [272..527] cursors
+    uint32_t* d_cnt = S.counters.as<uint32_t>();
     WS_HIP_CHECK(hipMemsetAsync(S.bstart.p, 0, (size_t)nbuckets * 4, s));
     WS_HIP_CHECK(hipMemsetAsync(S.bend.p, 0, (size_t)nbuckets * 4, s));
-    WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, 64, s));
+    WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, 4096, s));
     T.begin("msm_bounds", s);
     hipLaunchKernelGGL(msm_bounds, dim3(ceil_div_u64(total, 256)), dim3(256), 0, s, S.keys_out.as<uint32_t>(), total,
                        nbuckets, S.bstart.as<uint32_t>(), S.bend.as<uint32_t>());
     T.end(s);
-    WS_HIP_CHECK(hipGetLastError());
-
-    T.begin(which ? "msm_accumulate_g2" : "msm_accumulate_g1", s);
-    hipLaunchKernelGGL(msm_accumulate<C>, dim3(ceil_div_u64(nbuckets, 256)), dim3(256), 0, s, d_points,
-                       S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(), nbuckets, lmax,
-                       S.buckets.as<Pt>(), S.counters.as<uint32_t>(), S.hot_tasks.as<HotTask>(),
-                       S.hot_buckets.as<HotBucket>(), hot_cap);
+    T.begin("msm_plan", s);
+    hipLaunchKernelGGL(msm_plan_hist, dim3(ceil_div_u64(nbuckets, 256)), dim3(256), 0, s, S.bstart.as<uint32_t>(),
+                       S.bend.as<uint32_t>(), nbuckets, lmax, d_cnt + 16);
+    hipLaunchKernelGGL(msm_plan_offsets, dim3(1), dim3(64), 0, s, d_cnt + 16, d_cnt + 272, d_cnt);
+    hipLaunchKernelGGL(msm_plan_emit<C>, dim3(ceil_div_u64(nbuckets, 256)), dim3(256), 0, s, S.bstart.as<uint32_t>(),
+                       S.bend.as<uint32_t>(), nbuckets, lmax, d_cnt + 272, S.tasks.as<Task>(), d_cnt,
+                       S.multi.as<MultiBucket>(), S.buckets.as<Pt>());
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
-
     uint32_t cnt[4] = {0, 0, 0, 0};
     WS_HIP_CHECK(hipMemcpyAsync(cnt, S.counters.p, sizeof cnt, hipMemcpyDeviceToHost, s));
     WS_HIP_CHECK(hipStreamSynchronize(s));
-    if (cnt[2]) { set_last_error("msm: hot list overflow"); return WS_ERR_HIP; }
-    if (cnt[0]) {
-        WS_HIP_CHECK(S.partials.reserve((size_t)cnt[0] * sizeof(Pt)));
-        T.begin("msm_hot_tasks", s);
-        hipLaunchKernelGGL(msm_hot_tasks<C>, dim3(ceil_div_u64(cnt[0], 256)), dim3(256), 0, s, d_points,
-                           S.vals_out.as<uint32_t>(), S.hot_tasks.as<HotTask>(), cnt[0], S.partials.as<Pt>());
+    const uint32_t ntasks = cnt[3], nmulti = cnt[1];
+    if (ntasks > hot_cap || cnt[0] > hot_cap) { set_last_error("msm: task list overflow"); return WS_ERR_HIP; }
+
+    if (ntasks) {
+        T.begin(which ? "msm_accumulate_g2" : "msm_accumulate_g1", s);
+        hipLaunchKernelGGL(msm_accumulate<C>, dim3(ceil_div_u64(ntasks, 256)), dim3(256), 0, s, d_points,
+                           S.vals_out.as<uint32_t>(), S.tasks.as<Task>(), ntasks, S.buckets.as<Pt>(), S.partials.as<Pt>());
         T.end(s);
-        T.begin("msm_hot_combine", s);
-        hipLaunchKernelGGL(msm_hot_combine<C>, dim3(cnt[1]), dim3(64), 0, s, S.hot_buckets.as<HotBucket>(), cnt[1],
+        WS_HIP_CHECK(hipGetLastError());
+    }
+    if (nmulti) {
+        T.begin("msm_combine", s);
+        hipLaunchKernelGGL(msm_combine_small<C>, dim3(ceil_div_u64(nmulti, 256)), dim3(256), 0, s,
+                           S.multi.as<MultiBucket>(), nmulti, S.partials.as<Pt>(), S.buckets.as<Pt>());
+        hipLaunchKernelGGL(msm_combine_wave<C>, dim3(nmulti), dim3(64), 0, s, S.multi.as<MultiBucket>(), nmulti,
                            S.partials.as<Pt>(), S.buckets.as<Pt>());
         T.end(s);
         WS_HIP_CHECK(hipGetLastError());
