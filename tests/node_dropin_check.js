@@ -1,0 +1,54 @@
+// Drives wasmsnark_amd/js (the Node drop-in) through the reference's call shapes and compares
+// with the reference-generated proofs in tests/golden/proofs.json.  Run by tests/test_node_dropin.py.
+"use strict";
+const fs = require("fs");
+const path = require("path");
+const root = path.join(__dirname, "..");
+const ws = require(path.join(root, "wasmsnark_amd", "js", "index.js"));
+const gold = path.join(root, "tests", "golden");
+const toAB = (b) => b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength);
+
+(async () => {
+    const bn = await ws.buildBn128();
+    const proofs = JSON.parse(fs.readFileSync(path.join(gold, "proofs.json"), "utf8"));
+    let checked = 0;
+    for (const name of Object.keys(proofs)) {
+        const pkey = toAB(fs.readFileSync(path.join(gold, "keys", name + ".pkey.bin")));   // ArrayBuffer, as the reference requires
+        const wit = fs.readFileSync(path.join(gold, "keys", name + ".witness.bin"));        // Buffer: also accepted
+        for (const c of proofs[name]) {
+            const p = await bn.groth16GenProof(wit, pkey, { r: Buffer.from(c.r, "hex"), s: Buffer.from(c.s, "hex") });
+            if (JSON.stringify(p) !== JSON.stringify(c.proof)) throw new Error("proof mismatch for " + name);
+            checked++;
+        }
+    }
+    // MSM + FFT vectors through the worker-command-shaped calls
+    const msm = JSON.parse(fs.readFileSync(path.join(gold, "msm.json"), "utf8"));
+    for (const c of msm.g1) {
+        if (c.flavour === "accumulate_into_3G") continue;
+        const r = await bn.g1_multiexp(Buffer.from(c.scalars, "base64"), Buffer.from(c.points, "base64"));
+        if (Buffer.from(r).toString("hex") !== c.multiexp_affine) throw new Error("g1 msm mismatch n=" + c.n);
+        checked++;
+    }
+    const fft = JSON.parse(fs.readFileSync(path.join(gold, "fft.json"), "utf8"));
+    for (const c of fft.cases) {
+        if (c.n < 2) continue;
+        const r = await bn.ifft(new Uint8Array(Buffer.from(c.input_mont, "base64")), 0);
+        if (Buffer.from(r).toString("base64") !== c.ifft0) throw new Error("ifft mismatch n=" + c.n);
+        checked++;
+    }
+    // node-style callback + README name, random blinding
+    const name = "t3";
+    const pkey = toAB(fs.readFileSync(path.join(gold, "keys", name + ".pkey.bin")));
+    const wit = toAB(fs.readFileSync(path.join(gold, "keys", name + ".witness.bin")));
+    await new Promise((res, rej) => ws.genZKSnarkProof(wit, pkey, (err, proof) => {
+        if (err) return rej(err);
+        if (proof.pi_a[2] !== "1" || proof.pi_b[2][0] !== "1") return rej(new Error("bad proof shape"));
+        res();
+    }));
+    // error path: rejected Promise, not a hang (the reference hangs: SURVEY section 5)
+    let rejected = false;
+    try { await bn.fft(new Uint8Array(96), 0); } catch (e) { rejected = true; }
+    if (!rejected) throw new Error("non power-of-two fft did not reject");
+    console.log("NODE_DROPIN_OK", checked, bn.deviceInfo);
+    bn.terminate();
+})().catch((e) => { console.error("NODE_DROPIN_FAIL", e); process.exit(1); });

@@ -1,0 +1,54 @@
+"""The Node.js drop-in (wasmsnark_amd/js: N-API addon + index.js) end to end.
+CPU: driven against the thread-emulator build of the kernel sources ($WSNARK_LIB), so the JS
+marshalling, Promise/callback shapes and decimal formatting are tested without a GPU.
+GPU (-m gpu): the same script against the real libwsnark.so."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+JS = os.path.join(ROOT, "wasmsnark_amd", "js")
+needs_node = pytest.mark.skipif(shutil.which("node") is None or not os.path.exists("/usr/include/node/node_api.h"),
+                                reason="node / N-API headers not available")
+
+
+def _build_addon():
+    subprocess.check_call(["make", "-C", JS, "-s"])
+
+
+def _run(env_extra):
+    env = dict(os.environ, **env_extra)
+    return subprocess.run(["node", os.path.join(ROOT, "tests", "node_dropin_check.js")], env=env,
+                          capture_output=True, text=True, timeout=900)
+
+
+@needs_node
+def test_node_dropin_against_emulated_kernels():
+    from emul_util import emul_bn128, SO
+    emul_bn128()
+    _build_addon()
+    out = _run({"WSNARK_LIB": SO})
+    assert out.returncode == 0 and "NODE_DROPIN_OK" in out.stdout, out.stdout + out.stderr
+
+
+@needs_node
+def test_node_addon_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    _build_addon()
+    code = "require('%s/index.js').buildBn128().then(()=>{console.log('UNEXPECTED_OK')},e=>{console.log('REJECTED',e.message)})" % JS
+    out = subprocess.run(["node", "-e", code], capture_output=True, text=True, timeout=120,
+                         env={k: v for k, v in os.environ.items() if k != "WSNARK_LIB"})
+    assert "REJECTED" in out.stdout and "no CPU fallback" in out.stdout, out.stdout + out.stderr
+
+
+@needs_node
+@pytest.mark.gpu
+def test_node_dropin_on_gpu():
+    _build_addon()
+    out = _run({})
+    assert out.returncode == 0 and "NODE_DROPIN_OK" in out.stdout, out.stdout + out.stderr

@@ -1,0 +1,295 @@
+/*
+ * wsnark_napi.c -- thin N-API addon over the C ABI of libwsnark.so (include/wsnark.h).
+ *
+ * This is the binding a wasmsnark maintainer would add to replace the worker pool: each JS
+ * function maps 1:1 to one C entry point and returns a Promise (napi async work, so the event
+ * loop is never blocked), with the reference's byte layouts (Jacobian-Montgomery 96/192 B,
+ * plain-form h, ...).  Reference seam: src/bn128.js:102-166 (worker commands), :353-415, :569-720.
+ * libwsnark.so is dlopen'ed at load time ($WSNARK_LIB or ../libwsnark.so next to this addon);
+ * there is no fallback: if it cannot be loaded, requiring the addon throws.
+ */
+#define NAPI_VERSION 4
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct wsnark_pkey wsnark_pkey_t;
+static struct {
+    void* h;
+    int (*init)(int);
+    void (*shutdown)(void);
+    const char* (*last_error)(void);
+    const char* (*device_info)(void);
+    int (*g1_msm)(const void*, const void*, uint64_t, void*);
+    int (*g2_msm)(const void*, const void*, uint64_t, void*);
+    int (*fr_ntt)(void*, uint64_t, int, int);
+    int (*calc_h)(const void*, const void*, size_t, const void*, size_t, uint32_t, uint32_t, void*);
+    int (*pkey_load)(const void*, size_t, wsnark_pkey_t**);
+    void (*pkey_free)(wsnark_pkey_t*);
+    int (*pkey_info)(const wsnark_pkey_t*, uint32_t*, uint32_t*, uint32_t*);
+    int (*prove)(wsnark_pkey_t*, const void*, size_t, const void*, const void*, void*);
+} L;
+
+#define CHECK(env, call)                                                        \
+    do {                                                                        \
+        if ((call) != napi_ok) {                                                \
+            napi_throw_error((env), NULL, "wsnark_napi: N-API call failed: " #call); \
+            return NULL;                                                        \
+        }                                                                       \
+    } while (0)
+
+static int load_lib(const char* addon_dir, char* err, size_t errlen) {
+    char path[4096];
+    const char* envp = getenv("WSNARK_LIB");
+    if (envp && *envp) snprintf(path, sizeof path, "%s", envp);
+    else snprintf(path, sizeof path, "%s/../../libwsnark.so", addon_dir);
+    L.h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+    if (!L.h) { snprintf(err, errlen, "cannot load %s: %s", path, dlerror()); return -1; }
+#define SYM(field, name)                                                            \
+    *(void**)(&L.field) = dlsym(L.h, name);                                         \
+    if (!L.field) { snprintf(err, errlen, "%s lacks symbol %s", path, name); return -1; }
+    SYM(init, "wsnark_init") SYM(shutdown, "wsnark_shutdown") SYM(last_error, "wsnark_last_error")
+    SYM(device_info, "wsnark_device_info") SYM(g1_msm, "wsnark_g1_msm") SYM(g2_msm, "wsnark_g2_msm")
+    SYM(fr_ntt, "wsnark_fr_ntt") SYM(calc_h, "wsnark_calc_h") SYM(pkey_load, "wsnark_pkey_load")
+    SYM(pkey_free, "wsnark_pkey_free") SYM(pkey_info, "wsnark_pkey_info") SYM(prove, "wsnark_groth16_prove")
+#undef SYM
+    return 0;
+}
+
+/* ArrayBuffer | Buffer | TypedArray | DataView -> (ptr, len); returns 0 on failure */
+static int get_bytes(napi_env env, napi_value v, uint8_t** p, size_t* n) {
+    bool is;
+    if (napi_is_arraybuffer(env, v, &is) == napi_ok && is) return napi_get_arraybuffer_info(env, v, (void**)p, n) == napi_ok;
+    if (napi_is_buffer(env, v, &is) == napi_ok && is) return napi_get_buffer_info(env, v, (void**)p, n) == napi_ok;
+    if (napi_is_typedarray(env, v, &is) == napi_ok && is) {
+        napi_typedarray_type t; size_t len, off; napi_value ab; void* data;
+        if (napi_get_typedarray_info(env, v, &t, &len, &data, &ab, &off) != napi_ok) return 0;
+        static const size_t esz[] = {1, 1, 1, 2, 2, 4, 4, 4, 8, 8, 8};
+        *p = (uint8_t*)data; *n = len * esz[t];
+        return 1;
+    }
+    if (napi_is_dataview(env, v, &is) == napi_ok && is) {
+        size_t len, off; napi_value ab; void* data;
+        if (napi_get_dataview_info(env, v, &len, &data, &ab, &off) != napi_ok) return 0;
+        *p = (uint8_t*)data; *n = len;
+        return 1;
+    }
+    return 0;
+}
+
+enum { OP_G1, OP_G2, OP_NTT, OP_CALCH, OP_PROVE, OP_LOADKEY };
+typedef struct {
+    int op, rc;
+    napi_async_work work;
+    napi_deferred deferred;
+    napi_ref refs[4];
+    int nrefs;
+    uint8_t *a, *b, *c, *r32, *s32;
+    size_t na, nb, nc;
+    uint32_t u0, u1;
+    int i0, i1;
+    wsnark_pkey_t* key;
+    uint8_t* out;
+    size_t nout;
+    char err[512];
+} job_t;
+
+static void job_execute(napi_env env, void* data) {
+    (void)env;
+    job_t* j = (job_t*)data;
+    switch (j->op) {
+    case OP_G1: j->rc = L.g1_msm(j->a, j->b, j->na / 32, j->out); break;
+    case OP_G2: j->rc = L.g2_msm(j->a, j->b, j->na / 32, j->out); break;
+    case OP_NTT: memcpy(j->out, j->a, j->na); j->rc = L.fr_ntt(j->out, j->na / 32, j->i0, j->i1); break;
+    case OP_CALCH: j->rc = L.calc_h(j->a, j->b, j->nb, j->c, j->nc, j->u0, j->u1, j->out); break;
+    case OP_PROVE: j->rc = L.prove(j->key, j->a, j->na, j->r32, j->s32, j->out); break;
+    case OP_LOADKEY: j->rc = L.pkey_load(j->a, j->na, &j->key); break;
+    }
+    if (j->rc) snprintf(j->err, sizeof j->err, "wsnark error %d: %s", j->rc, L.last_error());
+}
+
+static void key_finalize(napi_env env, void* data, void* hint) {
+    (void)env; (void)hint;
+    if (data) L.pkey_free((wsnark_pkey_t*)data);
+}
+
+static void job_complete(napi_env env, napi_status status, void* data) {
+    job_t* j = (job_t*)data;
+    napi_value res;
+    if (status != napi_ok || j->rc) {
+        napi_value msg, e;
+        napi_create_string_utf8(env, j->rc ? j->err : "async work cancelled", NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, NULL, msg, &e);
+        napi_reject_deferred(env, j->deferred, e);
+    } else if (j->op == OP_LOADKEY) {
+        napi_create_external(env, j->key, key_finalize, NULL, &res);
+        napi_resolve_deferred(env, j->deferred, res);
+    } else {
+        void* dst;
+        napi_create_arraybuffer(env, j->nout, &dst, &res);   /* results are fresh ArrayBuffers, as in the reference */
+        memcpy(dst, j->out, j->nout);
+        napi_resolve_deferred(env, j->deferred, res);
+    }
+    for (int i = 0; i < j->nrefs; i++) napi_delete_reference(env, j->refs[i]);
+    napi_delete_async_work(env, j->work);
+    free(j->out);
+    free(j);
+}
+
+static napi_value start_job(napi_env env, job_t* j, const char* name) {
+    napi_value promise, rname;
+    CHECK(env, napi_create_promise(env, &j->deferred, &promise));
+    CHECK(env, napi_create_string_utf8(env, name, NAPI_AUTO_LENGTH, &rname));
+    CHECK(env, napi_create_async_work(env, NULL, rname, job_execute, job_complete, j, &j->work));
+    CHECK(env, napi_queue_async_work(env, j->work));
+    return promise;
+}
+static int keep(napi_env env, job_t* j, napi_value v) {   /* inputs stay referenced until completion */
+    return napi_create_reference(env, v, 1, &j->refs[j->nrefs++]) == napi_ok;
+}
+#define FAIL(env, j, msg) do { free((j)->out); free(j); napi_throw_type_error((env), NULL, (msg)); return NULL; } while (0)
+
+/* g1Multiexp(scalars, points) / g2Multiexp(scalars, points) -> Promise<ArrayBuffer 96/192> */
+static napi_value msm_common(napi_env env, napi_callback_info info, int op) {
+    size_t argc = 2; napi_value argv[2];
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    job_t* j = (job_t*)calloc(1, sizeof *j);
+    j->op = op; j->nout = op == OP_G1 ? 96 : 192; j->out = (uint8_t*)malloc(j->nout);
+    if (argc < 2 || !get_bytes(env, argv[0], &j->a, &j->na) || !get_bytes(env, argv[1], &j->b, &j->nb))
+        FAIL(env, j, "expected (scalars, points) byte buffers");
+    if (j->nb < (j->na / 32) * (op == OP_G1 ? 64 : 128)) FAIL(env, j, "points buffer too short for the number of scalars");
+    keep(env, j, argv[0]); keep(env, j, argv[1]);
+    return start_job(env, j, op == OP_G1 ? "wsnark_g1_msm" : "wsnark_g2_msm");
+}
+static napi_value js_g1(napi_env env, napi_callback_info info) { return msm_common(env, info, OP_G1); }
+static napi_value js_g2(napi_env env, napi_callback_info info) { return msm_common(env, info, OP_G2); }
+
+/* fft(buf, odd, inverse) -> Promise<ArrayBuffer> (out of place: the input is left untouched) */
+static napi_value js_fft(napi_env env, napi_callback_info info) {
+    size_t argc = 3; napi_value argv[3];
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    job_t* j = (job_t*)calloc(1, sizeof *j);
+    j->op = OP_NTT;
+    if (argc < 1 || !get_bytes(env, argv[0], &j->a, &j->na)) FAIL(env, j, "expected a byte buffer");
+    if (argc > 1) napi_get_value_int32(env, argv[1], &j->i0);
+    if (argc > 2) { bool b = false; napi_coerce_to_bool(env, argv[2], &argv[2]); napi_get_value_bool(env, argv[2], &b); j->i1 = b; }
+    j->nout = j->na; j->out = (uint8_t*)malloc(j->na ? j->na : 1);
+    keep(env, j, argv[0]);
+    return start_job(env, j, "wsnark_fr_ntt");
+}
+
+/* calcH(signals, polsA, polsB, nSignals, domainSize) -> Promise<ArrayBuffer domain*32> */
+static napi_value js_calch(napi_env env, napi_callback_info info) {
+    size_t argc = 5; napi_value argv[5];
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    job_t* j = (job_t*)calloc(1, sizeof *j);
+    j->op = OP_CALCH;
+    if (argc < 5 || !get_bytes(env, argv[0], &j->a, &j->na) || !get_bytes(env, argv[1], &j->b, &j->nb) ||
+        !get_bytes(env, argv[2], &j->c, &j->nc) || napi_get_value_uint32(env, argv[3], &j->u0) != napi_ok ||
+        napi_get_value_uint32(env, argv[4], &j->u1) != napi_ok)
+        FAIL(env, j, "expected (signals, polsA, polsB, nSignals, domainSize)");
+    if (j->na < (size_t)j->u0 * 32) FAIL(env, j, "signals shorter than nSignals*32 bytes");
+    j->nout = (size_t)j->u1 * 32; j->out = (uint8_t*)malloc(j->nout ? j->nout : 1);
+    keep(env, j, argv[0]); keep(env, j, argv[1]); keep(env, j, argv[2]);
+    return start_job(env, j, "wsnark_calc_h");
+}
+
+/* loadKey(pkey) -> Promise<external handle>; freed by the GC finalizer */
+static napi_value js_loadkey(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1];
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    job_t* j = (job_t*)calloc(1, sizeof *j);
+    j->op = OP_LOADKEY;
+    if (argc < 1 || !get_bytes(env, argv[0], &j->a, &j->na)) FAIL(env, j, "expected a proving_key.bin byte buffer");
+    keep(env, j, argv[0]);
+    return start_job(env, j, "wsnark_pkey_load");
+}
+
+/* prove(keyHandle, witness, r32|null, s32|null) -> Promise<ArrayBuffer 384> */
+static napi_value js_prove(napi_env env, napi_callback_info info) {
+    size_t argc = 4; napi_value argv[4];
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    job_t* j = (job_t*)calloc(1, sizeof *j);
+    j->op = OP_PROVE; j->nout = 384; j->out = (uint8_t*)malloc(384);
+    if (argc < 2 || napi_get_value_external(env, argv[0], (void**)&j->key) != napi_ok || !j->key ||
+        !get_bytes(env, argv[1], &j->a, &j->na))
+        FAIL(env, j, "expected (keyHandle, witness[, r32, s32])");
+    keep(env, j, argv[0]); keep(env, j, argv[1]);
+    size_t n;
+    napi_valuetype t;
+    if (argc > 2 && napi_typeof(env, argv[2], &t) == napi_ok && t != napi_null && t != napi_undefined) {
+        if (!get_bytes(env, argv[2], &j->r32, &n) || n != 32) FAIL(env, j, "r must be 32 bytes");
+        keep(env, j, argv[2]);
+    }
+    if (argc > 3 && napi_typeof(env, argv[3], &t) == napi_ok && t != napi_null && t != napi_undefined) {
+        if (!get_bytes(env, argv[3], &j->s32, &n) || n != 32) FAIL(env, j, "s must be 32 bytes");
+        keep(env, j, argv[3]);
+    }
+    return start_job(env, j, "wsnark_groth16_prove");
+}
+
+static napi_value js_keyinfo(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1], o, v;
+    wsnark_pkey_t* k = NULL;
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 1 || napi_get_value_external(env, argv[0], (void**)&k) != napi_ok || !k) { napi_throw_type_error(env, NULL, "expected a key handle"); return NULL; }
+    uint32_t nv, np, dom;
+    L.pkey_info(k, &nv, &np, &dom);
+    napi_create_object(env, &o);
+    napi_create_uint32(env, nv, &v); napi_set_named_property(env, o, "nVars", v);
+    napi_create_uint32(env, np, &v); napi_set_named_property(env, o, "nPublic", v);
+    napi_create_uint32(env, dom, &v); napi_set_named_property(env, o, "domainSize", v);
+    return o;
+}
+
+static napi_value js_init(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1], s;
+    int32_t dev = -1;
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc > 0) napi_get_value_int32(env, argv[0], &dev);
+    int rc = L.init(dev);
+    if (rc) {
+        char msg[600];
+        snprintf(msg, sizeof msg, "wsnark_init failed (%d): %s -- there is no CPU fallback", rc, L.last_error());
+        napi_throw_error(env, NULL, msg);
+        return NULL;
+    }
+    napi_create_string_utf8(env, L.device_info(), NAPI_AUTO_LENGTH, &s);
+    return s;
+}
+static napi_value js_shutdown(napi_env env, napi_callback_info info) {
+    (void)info;
+    L.shutdown();
+    napi_value u; napi_get_undefined(env, &u);
+    return u;
+}
+
+static napi_value module_init(napi_env env, napi_value exports) {
+    Dl_info di;
+    char dir[4096] = ".";
+    if (dladdr((void*)module_init, &di) && di.dli_fname) {
+        snprintf(dir, sizeof dir, "%s", di.dli_fname);
+        char* sl = strrchr(dir, '/');
+        if (sl) *sl = 0;
+    }
+    char err[4600];
+    if (load_lib(dir, err, sizeof err)) { napi_throw_error(env, NULL, err); return NULL; }
+    napi_property_descriptor props[] = {
+        {"init", NULL, js_init, NULL, NULL, NULL, napi_default, NULL},
+        {"shutdown", NULL, js_shutdown, NULL, NULL, NULL, napi_default, NULL},
+        {"g1Multiexp", NULL, js_g1, NULL, NULL, NULL, napi_default, NULL},
+        {"g2Multiexp", NULL, js_g2, NULL, NULL, NULL, napi_default, NULL},
+        {"fft", NULL, js_fft, NULL, NULL, NULL, napi_default, NULL},
+        {"calcH", NULL, js_calch, NULL, NULL, NULL, napi_default, NULL},
+        {"loadKey", NULL, js_loadkey, NULL, NULL, NULL, napi_default, NULL},
+        {"keyInfo", NULL, js_keyinfo, NULL, NULL, NULL, napi_default, NULL},
+        {"prove", NULL, js_prove, NULL, NULL, NULL, napi_default, NULL},
+    };
+    CHECK(env, napi_define_properties(env, exports, sizeof props / sizeof props[0], props));
+    return exports;
+}
+NAPI_MODULE(NODE_GYP_MODULE_NAME, module_init)
