@@ -16,6 +16,7 @@
 #pragma once
 #include "field.h"
 #include "fp2.h"
+#include "field29.h"
 
 namespace wsnark {
 
@@ -31,12 +32,35 @@ template <class F>
 struct Jac {
     typename F::El x, y, z;
 };
+// global-memory forms (32-byte coordinates; identical to the above for the 4x64 fields)
+template <class F>
+struct AffineP {
+    typename F::Packed x, y;
+};
+template <class F>
+struct XYZZP {
+    typename F::Packed x, y, zz, zzz;
+};
 
 template <class F>
 struct Curve {
+    typedef F Field;
     typedef typename F::El El;
     typedef Affine<F> Aff;
     typedef XYZZ<F> Pt;
+    typedef AffineP<F> AffP;
+    typedef XYZZP<F> PtP;
+
+    // packed <-> register forms (no domain change)
+    WS_HD static Aff unpack_aff(const AffP& a) { return Aff{F::unpack(a.x), F::unpack(a.y)}; }
+    WS_HD static AffP pack_aff(const Aff& a) { return AffP{F::pack(a.x), F::pack(a.y)}; }
+    WS_HD static Pt unpack_pt(const PtP& p) { return Pt{F::unpack(p.x), F::unpack(p.y), F::unpack(p.zz), F::unpack(p.zzz)}; }
+    WS_HD static PtP pack_pt(const Pt& p) { return PtP{F::pack(p.x), F::pack(p.y), F::pack(p.zz), F::pack(p.zzz)}; }
+    // reference format (canonical Montgomery R = 2^256) <-> the field's internal domain
+    WS_HD static Aff aff_to_internal(const AffP& a) { return Aff{F::to_internal(a.x), F::to_internal(a.y)}; }
+    WS_HD static PtP pt_from_internal(const Pt& p) {
+        return PtP{F::from_internal(p.x), F::from_internal(p.y), F::from_internal(p.zz), F::from_internal(p.zzz)};
+    }
 
     WS_HD static Pt infinity() { return Pt{F::zero(), F::one(), F::zero(), F::zero()}; }
     WS_HD static bool is_inf(const Pt& p) { return F::is_zero(p.zz); }
@@ -164,5 +188,8 @@ struct Curve {
 
 typedef Curve<Fq> G1;
 typedef Curve<Fq2> G2;
+// device-side curves over the carry-free radix-2^29 field (heavy kernels only)
+typedef Curve<Fq29> G1R29;
+typedef Curve<Fp2T<Fq29>> G2R29;
 
 }  // namespace wsnark

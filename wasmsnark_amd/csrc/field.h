@@ -132,6 +132,13 @@ Fe mont_mul32(Fe a, Fe b) {
 template <class P>
 struct Field {
     typedef Fe El;
+    typedef Fe Packed;                             // global-memory form == register form here
+    static constexpr bool kInternalDomain = false;
+    WS_HD static Fe unpack(const Fe& x) { return x; }
+    WS_HD static Fe pack(const Fe& x) { return x; }
+    WS_HD static Fe to_internal(const Fe& x) { return x; }
+    WS_HD static Fe from_internal(const Fe& x) { return x; }
+    WS_HD static Fe canonical(const Fe& x) { return x; }
     WS_HD static Fe zero() { return Fe{{0, 0, 0, 0}}; }
     WS_HD static Fe one() { return Fe{{P::R0, P::R1, P::R2_, P::R3}}; }   // Montgomery 1
     WS_HD static Fe rsq() { return Fe{{P::RR0, P::RR1, P::RR2, P::RR3}}; }

@@ -1,0 +1,273 @@
+// field29.h -- carry-free radix-2^29 Montgomery arithmetic for the heavy device kernels.
+//
+// Why: on gfx950 a saturated 8x32-bit multiplier spends more instructions on carries, 64-bit adds
+// and register moves than on products (584 VALU instructions per product, 96 G modmul/s measured),
+// and every carry chain through VCC pays wait states.  With 9 limbs of 29 bits every column of the
+// schoolbook product (<= 9 a*b + 9 m*p terms of < 2^58) fits one 64-bit accumulator, so a whole
+// Montgomery product is a chain of v_mad_u64_u32 (162) plus 9 v_mul_lo, 17 shifts and 18 masks:
+// no carries, no moves (221 instructions, 172 G modmul/s measured; tools/microbench.hip).
+//
+// Semantics.  Same field, same results: this is an internal representation of the heavy kernels
+// (MSM curve arithmetic, NTT butterflies).  It replaces the same reference functions as field.h
+// (/root/reference src/build_f1m.js:67-113, 235-436).
+//   * Montgomery radix here is R' = 2^261 (9 x 29 bits).  External data stays in the reference's
+//     format (R = 2^256, canonical, 32-byte LE): to_internal() / from_internal() convert with one
+//     product each (x * 2^5 and x * 2^-5), and from_internal() canonicalises to [0,p).
+//   * Inside, values are kept in [0, 2p) ("lazy mod 2p") with limbs v[0..7] < 2^29: add/sub
+//     correct by 2p once, so every operand bound is uniform and the generic curve formulas of
+//     curve.h work unchanged.  A value is zero iff it is 0 or p.
+//   * Packed form (global memory / LDS between kernels): 32 bytes, any value < 2^256.
+#pragma once
+#include "field.h"
+
+namespace wsnark {
+
+struct F29 {
+    uint32_t v[9];
+};
+
+struct Fq29Params : FqParams {
+    // 2^261 mod p (one in the internal domain) and 2^266 mod p (the to_internal multiplier)
+    static constexpr uint64_t ONE0 = 0x4e8384eb157ccc21ull, ONE1 = 0xfb90a6020ce148c3ull, ONE2 = 0x5301fa84819caa36ull, ONE3 = 0x0dc83629563d4475ull;
+    static constexpr uint64_t CIN0 = 0xb34bb09513349ca1ull, CIN1 = 0x1e880124f028f972ull, CIN2 = 0xe56cdd25a6092b95ull, CIN3 = 0x05800320dce9ed32ull;
+};
+struct Fr29Params : FrParams {
+    static constexpr uint64_t ONE0 = 0x2fd4e1568fffff57ull, ONE1 = 0x75bba827a494b01aull, ONE2 = 0x5301fa84819caa80ull, ONE3 = 0x0dc83629563d4475ull;
+    static constexpr uint64_t CIN0 = 0x97aa889e8fffead7ull, CIN1 = 0x4da1da684b110e2aull, CIN2 = 0xe56cdd25a60934c8ull, CIN3 = 0x05800320dce9ed32ull;
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WS_NOINLINE_DEV __device__ __attribute__((noinline))
+#else
+#define WS_NOINLINE_DEV inline
+#endif
+// operands travel as 18 / 9 scalar arguments: the AMDGPU calling convention keeps scalars in VGPRs,
+// whereas a 36-byte aggregate is partly passed through scratch memory
+#define WS_L9(p) uint32_t p##0, uint32_t p##1, uint32_t p##2, uint32_t p##3, uint32_t p##4, uint32_t p##5, uint32_t p##6, uint32_t p##7, uint32_t p##8
+#define WS_A9(x) (x).v[0], (x).v[1], (x).v[2], (x).v[3], (x).v[4], (x).v[5], (x).v[6], (x).v[7], (x).v[8]
+template <class P> WS_NOINLINE_DEV F29 mont_mul29(WS_L9(a), WS_L9(b));
+template <class P> WS_NOINLINE_DEV F29 mont_sqr29(WS_L9(a));
+
+#define WS_M29 0x1FFFFFFFu
+
+// limb i (29 bits; limb 8 takes the rest) of the 256-bit integer (w3:w2:w1:w0)
+constexpr uint32_t ws_limb29(uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3, int i) {
+    const int o = 29 * i, k = o >> 6, s = o & 63;
+    const uint64_t lo = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? w2 : w3;
+    const uint64_t hi = k == 0 ? w1 : k == 1 ? w2 : k == 2 ? w3 : 0;
+    const uint64_t x = (lo >> s) | (s ? (hi << (64 - s)) : 0);
+    return i == 8 ? (uint32_t)x : (uint32_t)(x & WS_M29);
+}
+
+template <class P>
+struct Field29 {
+    typedef F29 El;
+    typedef Fe Packed;
+    static constexpr bool kInternalDomain = true;
+
+    // ---- constants as compile-time limbs ----
+    WS_HD static constexpr uint32_t p_limb(int i) { return ws_limb29(P::P0, P::P1, P::P2, P::P3, i); }
+    WS_HD static constexpr uint32_t p2_limb(int i) {   // 2p
+        return ws_limb29(P::P0 << 1, (P::P1 << 1) | (P::P0 >> 63), (P::P2 << 1) | (P::P1 >> 63), (P::P3 << 1) | (P::P2 >> 63), i);
+    }
+    static constexpr uint32_t NP29 = (uint32_t)(P::NP & WS_M29);
+
+    WS_HD static F29 from_words(uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3) {
+        F29 r;
+#pragma unroll
+        for (int i = 0; i < 9; i++) r.v[i] = ws_limb29(w0, w1, w2, w3, i);
+        return r;
+    }
+    WS_HD static F29 zero() { return F29{{0, 0, 0, 0, 0, 0, 0, 0, 0}}; }
+    WS_HD static F29 one() { return from_words(P::ONE0, P::ONE1, P::ONE2, P::ONE3); }   // 1 in the internal domain
+
+    // ---- pack / unpack (32-byte <-> 9 x 29) ----
+    WS_HD static F29 unpack(const Fe& x) { return from_words(x.l[0], x.l[1], x.l[2], x.l[3]); }
+    WS_HD static Fe pack(const F29& a) {   // value must be < 2^256 (v[8] < 2^24)
+        uint32_t w[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int o = 32 * j, i0 = o / 29, s = o - 29 * i0;   // word j starts inside limb i0 at bit s
+            uint32_t x = a.v[i0] >> s;
+            x |= a.v[i0 + 1] << (29 - s);
+            w[j] = x;
+        }
+        Fe r;
+#pragma unroll
+        for (int k = 0; k < 4; k++) r.l[k] = (uint64_t)w[2 * k] | ((uint64_t)w[2 * k + 1] << 32);
+        return r;
+    }
+
+    // ---- predicates ----
+    WS_HD static bool is_zero(const F29& a) {   // value in [0,2p): zero iff 0 or p
+        uint32_t o = 0, d = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) { o |= a.v[i]; d |= a.v[i] ^ p_limb(i); }
+        return o == 0 || d == 0;
+    }
+    WS_HD static bool eq(const F29& a, const F29& b) { return is_zero(sub(a, b)); }
+
+    // ---- add / sub / neg, all results in [0, 2p) with tight limbs ----
+    // r = s - 2p if s >= 2p else s, for s < 4p given with tight limbs
+    WS_HD static F29 cond_sub_2p(const F29& s) {
+        F29 d;
+        int32_t bw = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int32_t t = (int32_t)s.v[i] - (int32_t)p2_limb(i) + bw;
+            d.v[i] = (uint32_t)t & WS_M29;
+            bw = t >> 29;
+        }
+        const int32_t t8 = (int32_t)s.v[8] - (int32_t)p2_limb(8) + bw;
+        d.v[8] = (uint32_t)t8;
+        const bool neg = t8 < 0;
+        F29 r;
+#pragma unroll
+        for (int i = 0; i < 9; i++) r.v[i] = neg ? s.v[i] : d.v[i];
+        return r;
+    }
+    WS_HD static F29 add(const F29& a, const F29& b) {
+        F29 s;
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t t = a.v[i] + b.v[i] + c;
+            s.v[i] = t & WS_M29;
+            c = t >> 29;
+        }
+        s.v[8] = a.v[8] + b.v[8] + c;
+        return cond_sub_2p(s);
+    }
+    WS_HD static F29 dbl(const F29& a) { return add(a, a); }
+    WS_HD static F29 sub(const F29& a, const F29& b) {
+        // d = a - b + 2p in (0, 4p), then one conditional subtraction of 2p
+        F29 d;
+        int32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int32_t t = (int32_t)a.v[i] - (int32_t)b.v[i] + (int32_t)p2_limb(i) + c;
+            d.v[i] = (uint32_t)t & WS_M29;
+            c = t >> 29;
+        }
+        d.v[8] = (uint32_t)((int32_t)a.v[8] - (int32_t)b.v[8] + (int32_t)p2_limb(8) + c);
+        return cond_sub_2p(d);
+    }
+    WS_HD static F29 neg(const F29& a) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) o |= a.v[i];
+        if (o == 0) return a;                 // 2p - 0 would leave [0, 2p)
+        F29 d;
+        int32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int32_t t = (int32_t)p2_limb(i) - (int32_t)a.v[i] + c;
+            d.v[i] = (uint32_t)t & WS_M29;
+            c = t >> 29;
+        }
+        d.v[8] = (uint32_t)((int32_t)p2_limb(8) - (int32_t)a.v[8] + c);
+        return d;
+    }
+    WS_HD static F29 cneg(const F29& a, bool s) { return s ? neg(a) : a; }
+
+    // ---- Montgomery product a*b*2^-261 mod p; inputs < 2p (limbs < 2^29), output < 2p ----
+    WS_HD static F29 mul(const F29& a, const F29& b) { return mont_mul29<P>(WS_A9(a), WS_A9(b)); }
+    WS_HD static F29 sqr(const F29& a) { return mont_sqr29<P>(WS_A9(a)); }
+
+    // canonical representative in [0, p) of a value in [0, 2p)
+    WS_HD static F29 canonical(const F29& a) {
+        F29 d;
+        int32_t bw = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int32_t t = (int32_t)a.v[i] - (int32_t)p_limb(i) + bw;
+            d.v[i] = (uint32_t)t & WS_M29;
+            bw = t >> 29;
+        }
+        const int32_t t8 = (int32_t)a.v[8] - (int32_t)p_limb(8) + bw;
+        d.v[8] = (uint32_t)t8;
+        const bool neg = t8 < 0;
+        F29 r;
+#pragma unroll
+        for (int i = 0; i < 9; i++) r.v[i] = neg ? a.v[i] : d.v[i];
+        return r;
+    }
+    // reference format (canonical, Montgomery R = 2^256) -> internal (Montgomery R' = 2^261): x * 2^5
+    WS_HD static F29 to_internal(const Fe& x) { return mul(unpack(x), from_words(P::CIN0, P::CIN1, P::CIN2, P::CIN3)); }
+    // internal -> reference format: x * 2^-5, canonical
+    WS_HD static Fe from_internal(const F29& a) { return pack(canonical(mul(a, from_words(P::R0, P::R1, P::R2_, P::R3)))); }
+    // the multiplier that turns a reference-format table entry t into the internal-domain entry of
+    // t * 2^k is itself a host-side job (see ntt.hip); only the device ops live here.
+};
+
+// ---- the multipliers: real functions (not inlined) taking operands by value in VGPRs ----
+
+template <class P>
+WS_NOINLINE_DEV F29 mont_mul29(WS_L9(a), WS_L9(b)) {
+    typedef Field29<P> F;
+    const F29 a = {{a0, a1, a2, a3, a4, a5, a6, a7, a8}}, b = {{b0, b1, b2, b3, b4, b5, b6, b7, b8}};
+    uint32_t m[9];
+    uint64_t acc = 0;
+    F29 r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * F::p_limb(k - i);
+        m[k] = ((uint32_t)acc * F::NP29) & WS_M29;
+        acc += (uint64_t)m[k] * F::p_limb(0);
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) acc += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) acc += (uint64_t)m[i] * F::p_limb(k - i);
+        r.v[k - 9] = (uint32_t)acc & WS_M29;
+        acc >>= 29;
+    }
+    r.v[8] = (uint32_t)acc;
+    return r;
+}
+
+// squaring: off-diagonal products once, doubled (45 instead of 81 a*a products)
+template <class P>
+WS_NOINLINE_DEV F29 mont_sqr29(WS_L9(a)) {
+    typedef Field29<P> F;
+    const F29 a = {{a0, a1, a2, a3, a4, a5, a6, a7, a8}};
+    uint32_t m[9], ad[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) ad[i] = a.v[i] << 1;
+    uint64_t acc = 0;
+    F29 r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; 2 * i < k; i++) acc += (uint64_t)ad[i] * a.v[k - i];
+        if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * F::p_limb(k - i);
+        m[k] = ((uint32_t)acc * F::NP29) & WS_M29;
+        acc += (uint64_t)m[k] * F::p_limb(0);
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; 2 * i < k; i++) acc += (uint64_t)ad[i] * a.v[k - i];
+        if ((k & 1) == 0) acc += (uint64_t)a.v[k / 2] * a.v[k / 2];
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) acc += (uint64_t)m[i] * F::p_limb(k - i);
+        r.v[k - 9] = (uint32_t)acc & WS_M29;
+        acc >>= 29;
+    }
+    r.v[8] = (uint32_t)acc;
+    return r;
+}
+
+typedef Field29<Fq29Params> Fq29;
+typedef Field29<Fr29Params> Fr29;
+
+}  // namespace wsnark

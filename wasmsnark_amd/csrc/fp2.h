@@ -1,4 +1,5 @@
-// fp2.h -- Fq2 = Fq[u]/(u^2 + 1) for BN128 G2 coordinates.
+// fp2.h -- quadratic extension Fq2 = Fq[u]/(u^2 + 1) for BN128 G2 coordinates, generic over the
+// base-field implementation (Field<FqParams> on the host, Field29<Fq29Params> in the heavy kernels).
 // Replaces SURVEY.md section 8a row a6: f2m_mul/square/add/sub/neg/inverse/isZero/eq
 // (/root/reference src/build_f2m.js:127-163, 186-227, 30-108, 353-383; the
 // non-residue map is f1m_neg, src/bn128/build_bn128.js:40).
@@ -8,40 +9,53 @@
 
 namespace wsnark {
 
-struct alignas(16) Fe2 {
-    Fe c0, c1;
+template <class E>
+struct alignas(16) Fe2T {
+    E c0, c1;
 };
+typedef Fe2T<Fe> Fe2;
 
-struct Fq2 {
-    typedef Fe2 El;
-    WS_HD static Fe2 zero() { return Fe2{Fq::zero(), Fq::zero()}; }
-    WS_HD static Fe2 one() { return Fe2{Fq::one(), Fq::zero()}; }
-    WS_HD static bool is_zero(const Fe2& a) { return Fq::is_zero(a.c0) && Fq::is_zero(a.c1); }
-    WS_HD static bool eq(const Fe2& a, const Fe2& b) { return Fq::eq(a.c0, b.c0) && Fq::eq(a.c1, b.c1); }
-    WS_HD static Fe2 add(const Fe2& a, const Fe2& b) { return Fe2{Fq::add(a.c0, b.c0), Fq::add(a.c1, b.c1)}; }
-    WS_HD static Fe2 dbl(const Fe2& a) { return Fe2{Fq::dbl(a.c0), Fq::dbl(a.c1)}; }
-    WS_HD static Fe2 sub(const Fe2& a, const Fe2& b) { return Fe2{Fq::sub(a.c0, b.c0), Fq::sub(a.c1, b.c1)}; }
-    WS_HD static Fe2 neg(const Fe2& a) { return Fe2{Fq::neg(a.c0), Fq::neg(a.c1)}; }
-    WS_HD static Fe2 cneg(const Fe2& a, bool s) { return s ? neg(a) : a; }
+template <class B>
+struct Fp2T {
+    typedef typename B::El BE;
+    typedef Fe2T<BE> El;
+    typedef Fe2T<typename B::Packed> Packed;
+    static constexpr bool kInternalDomain = B::kInternalDomain;
+    WS_HD static El unpack(const Packed& x) { return El{B::unpack(x.c0), B::unpack(x.c1)}; }
+    WS_HD static Packed pack(const El& x) { return Packed{B::pack(x.c0), B::pack(x.c1)}; }
+    WS_HD static El to_internal(const Packed& x) { return El{B::to_internal(x.c0), B::to_internal(x.c1)}; }
+    WS_HD static Packed from_internal(const El& x) { return Packed{B::from_internal(x.c0), B::from_internal(x.c1)}; }
+
+    WS_HD static El zero() { return El{B::zero(), B::zero()}; }
+    WS_HD static El one() { return El{B::one(), B::zero()}; }
+    WS_HD static bool is_zero(const El& a) { return B::is_zero(a.c0) && B::is_zero(a.c1); }
+    WS_HD static bool eq(const El& a, const El& b) { return B::eq(a.c0, b.c0) && B::eq(a.c1, b.c1); }
+    WS_HD static El add(const El& a, const El& b) { return El{B::add(a.c0, b.c0), B::add(a.c1, b.c1)}; }
+    WS_HD static El dbl(const El& a) { return El{B::dbl(a.c0), B::dbl(a.c1)}; }
+    WS_HD static El sub(const El& a, const El& b) { return El{B::sub(a.c0, b.c0), B::sub(a.c1, b.c1)}; }
+    WS_HD static El neg(const El& a) { return El{B::neg(a.c0), B::neg(a.c1)}; }
+    WS_HD static El cneg(const El& a, bool s) { return s ? neg(a) : a; }
     // Karatsuba, 3 base-field products (build_f2m.js:127-163)
-    WS_HD static Fe2 mul(const Fe2& a, const Fe2& b) {
-        Fe A = Fq::mul(a.c0, b.c0);
-        Fe B = Fq::mul(a.c1, b.c1);
-        Fe C = Fq::mul(Fq::add(a.c0, a.c1), Fq::add(b.c0, b.c1));
-        return Fe2{Fq::sub(A, B), Fq::sub(C, Fq::add(A, B))};
+    WS_HD static El mul(const El& a, const El& b) {
+        BE A = B::mul(a.c0, b.c0);
+        BE Bv = B::mul(a.c1, b.c1);
+        BE C = B::mul(B::add(a.c0, a.c1), B::add(b.c0, b.c1));
+        return El{B::sub(A, Bv), B::sub(C, B::add(A, Bv))};
     }
     // complex squaring, 2 base-field products (build_f2m.js:186-227)
-    WS_HD static Fe2 sqr(const Fe2& a) {
-        Fe AB = Fq::mul(a.c0, a.c1);
-        Fe t = Fq::mul(Fq::add(a.c0, a.c1), Fq::sub(a.c0, a.c1));
-        return Fe2{t, Fq::dbl(AB)};
+    WS_HD static El sqr(const El& a) {
+        BE AB = B::mul(a.c0, a.c1);
+        BE t = B::mul(B::add(a.c0, a.c1), B::sub(a.c0, a.c1));
+        return El{t, B::dbl(AB)};
     }
     // inverse via the norm (build_f2m.js:353-383)
-    WS_HD static Fe2 inv(const Fe2& a) {
-        Fe t = Fq::inv(Fq::add(Fq::sqr(a.c0), Fq::sqr(a.c1)));
-        return Fe2{Fq::mul(a.c0, t), Fq::neg(Fq::mul(a.c1, t))};
+    WS_HD static El inv(const El& a) {
+        BE t = B::inv(B::add(B::sqr(a.c0), B::sqr(a.c1)));
+        return El{B::mul(a.c0, t), B::neg(B::mul(a.c1, t))};
     }
-    WS_HD static Fe2 from_mont(const Fe2& a) { return Fe2{Fq::from_mont(a.c0), Fq::from_mont(a.c1)}; }
+    WS_HD static El from_mont(const El& a) { return El{B::from_mont(a.c0), B::from_mont(a.c1)}; }
 };
+
+typedef Fp2T<Fq> Fq2;
 
 }  // namespace wsnark

@@ -55,8 +55,13 @@ int ntt_coset_tables(int bits, const Fe** lo, const Fe** hi, int* hc, Fe* n_inv,
 int msm_g1_dev(const Fe* d_scalars, const Affine<Fq>* d_points, uint64_t n, Jac<Fq>* out_host, hipStream_t s);
 int msm_g2_dev(const Fe* d_scalars, const Affine<Fq2>* d_points, uint64_t n, Jac<Fq2>* out_host, hipStream_t s);
 // XYZZ result left to the caller (host memory), no affine normalisation
-int msm_g1_dev_xyzz(const Fe* d_scalars, const Affine<Fq>* d_points, uint64_t n, XYZZ<Fq>* out_host, hipStream_t s);
-int msm_g2_dev_xyzz(const Fe* d_scalars, const Affine<Fq2>* d_points, uint64_t n, XYZZ<Fq2>* out_host, hipStream_t s);
+// `prepared` = the point array was converted in place by msm_prepare_points (resident keys)
+int msm_g1_dev_xyzz(const Fe* d_scalars, const Affine<Fq>* d_points, uint64_t n, XYZZ<Fq>* out_host, hipStream_t s,
+                    bool prepared = false);
+int msm_g2_dev_xyzz(const Fe* d_scalars, const Affine<Fq2>* d_points, uint64_t n, XYZZ<Fq2>* out_host, hipStream_t s,
+                    bool prepared = false);
+int msm_prepare_points(int which, void* d_points, uint64_t n, hipStream_t s);
+bool msm_uses_field29();
 
 // ---- CALC_H pieces (calch.hip) ----
 struct CsrMatrix {            // row-major transpose of the reference's column-major pols blob

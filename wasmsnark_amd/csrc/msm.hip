@@ -34,7 +34,7 @@ static const uint32_t CHUNK = 8;          // buckets per msm_chunks lane
 struct MsmScratch {
     DevBuf keys, vals, keys_out, vals_out, sort_tmp;
     DevBuf bstart, bend, buckets, counters, tasks, multi, partials;
-    DevBuf chunkS, chunkA, sums;
+    DevBuf chunkS, chunkA, sums, points_conv;
 };
 
 // ---------------------------------------------------------------------------
@@ -81,15 +81,15 @@ __global__ __launch_bounds__(256) void msm_bounds(const uint32_t* __restrict__ k
 // 4/5. accumulation
 // ---------------------------------------------------------------------------
 template <class C>
-__device__ __forceinline__ typename C::Pt accumulate_range(const typename C::Aff* __restrict__ points,
+__device__ __forceinline__ typename C::Pt accumulate_range(const typename C::AffP* __restrict__ points,
                                                            const uint32_t* __restrict__ vals, uint32_t s, uint32_t len) {
     typename C::Pt acc = C::infinity();
     if (len == 0) return acc;
     // software pipeline: the next point's gather is in flight while the current one is added
     uint32_t v = vals[s];
-    typename C::Aff nxt = points[v & 0x7FFFFFFFu];
+    typename C::AffP nxt = points[v & 0x7FFFFFFFu];
     for (uint32_t k = 0; k < len; k++) {
-        const typename C::Aff cur = nxt;
+        const typename C::Aff cur = C::unpack_aff(nxt);
         const bool neg = (v >> 31) != 0;
         if (k + 1 < len) {
             v = vals[s + k + 1];
@@ -98,6 +98,15 @@ __device__ __forceinline__ typename C::Pt accumulate_range(const typename C::Aff
         C::madd(acc, cur, neg);
     }
     return acc;
+}
+
+// reference-format affine points -> the device field's internal domain (identity for the 4x64 field)
+template <class C>
+__global__ __launch_bounds__(256) void msm_convert_points(const typename C::AffP* __restrict__ in,
+                                                            typename C::AffP* __restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = C::pack_aff(C::aff_to_internal(in[i]));
 }
 
 // ---- task planning: every bucket is cut into tasks of <= lmax entries; tasks are ordered
@@ -142,7 +151,7 @@ template <class C>
 __global__ __launch_bounds__(256) void msm_plan_emit(const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bend,
                                                        uint32_t nbuckets, uint32_t lmax, uint32_t* __restrict__ cursor,
                                                        Task* __restrict__ tasks, uint32_t* __restrict__ counters,
-                                                       MultiBucket* __restrict__ multi, typename C::Pt* __restrict__ buckets) {
+                                                       MultiBucket* __restrict__ multi, typename C::PtP* __restrict__ buckets) {
     __shared__ uint32_t lcnt[256];
     __shared__ uint32_t lbase[256];
     lcnt[threadIdx.x] = 0;
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(256) void msm_plan_emit(const uint32_t* __restrict_
             if (nt > 1) r255 = atomicAdd(&lcnt[255], nt - 1);
             rrem = atomicAdd(&lcnt[krem], 1u);
         } else {
-            buckets[b] = C::infinity();
+            buckets[b] = C::pack_pt(C::infinity());
         }
     }
     __syncthreads();
@@ -179,15 +188,15 @@ __global__ __launch_bounds__(256) void msm_plan_emit(const uint32_t* __restrict_
 
 // 4. one lane per task: mixed additions of the task's points
 template <class C>
-__global__ __launch_bounds__(256) void msm_accumulate(const typename C::Aff* __restrict__ points,
+__global__ __launch_bounds__(256) void msm_accumulate(const typename C::AffP* __restrict__ points,
                                                         const uint32_t* __restrict__ vals,
                                                         const Task* __restrict__ tasks, uint32_t ntasks,
-                                                        typename C::Pt* __restrict__ buckets,
-                                                        typename C::Pt* __restrict__ partials) {
+                                                        typename C::PtP* __restrict__ buckets,
+                                                        typename C::PtP* __restrict__ partials) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntasks) return;
     const Task k = tasks[t];
-    const typename C::Pt acc = accumulate_range<C>(points, vals, k.start, k.len);
+    const typename C::PtP acc = C::pack_pt(accumulate_range<C>(points, vals, k.start, k.len));
     if (k.dst & PARTIAL_FLAG) partials[k.dst & ~PARTIAL_FLAG] = acc;
     else buckets[k.dst] = acc;
 }
@@ -196,35 +205,35 @@ __global__ __launch_bounds__(256) void msm_accumulate(const typename C::Aff* __r
 static const uint32_t WAVE_COMBINE_MIN = 17;
 template <class C>
 __global__ __launch_bounds__(256) void msm_combine_small(const MultiBucket* __restrict__ mbs, uint32_t nmb,
-                                                           const typename C::Pt* __restrict__ partials,
-                                                           typename C::Pt* __restrict__ buckets) {
+                                                           const typename C::PtP* __restrict__ partials,
+                                                           typename C::PtP* __restrict__ buckets) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nmb) return;
     const MultiBucket h = mbs[i];
     if (h.ntasks >= WAVE_COMBINE_MIN) return;
-    typename C::Pt acc = partials[h.first_partial];
-    for (uint32_t k = 1; k < h.ntasks; k++) acc = C::add(acc, partials[h.first_partial + k]);
-    buckets[h.bucket] = acc;
+    typename C::Pt acc = C::unpack_pt(partials[h.first_partial]);
+    for (uint32_t k = 1; k < h.ntasks; k++) acc = C::add(acc, C::unpack_pt(partials[h.first_partial + k]));
+    buckets[h.bucket] = C::pack_pt(acc);
 }
 
 // 5b. hot buckets (many tasks): one wavefront per bucket, lanes stride over the partial sums,
 // then an LDS tree folds the 64 lane sums (wavefront segmented reduction)
 template <class C>
 __global__ __launch_bounds__(64) void msm_combine_wave(const MultiBucket* __restrict__ mbs, uint32_t nmb,
-                                                         const typename C::Pt* __restrict__ partials,
-                                                         typename C::Pt* __restrict__ buckets) {
-    __shared__ typename C::Pt sh[64];
+                                                         const typename C::PtP* __restrict__ partials,
+                                                         typename C::PtP* __restrict__ buckets) {
+    __shared__ typename C::PtP sh[64];
     const uint32_t hb = blockIdx.x;
     if (hb >= nmb) return;
     const MultiBucket h = mbs[hb];
     if (h.ntasks < WAVE_COMBINE_MIN) return;
     const uint32_t lane = threadIdx.x;
     typename C::Pt acc = C::infinity();
-    for (uint32_t k = lane; k < h.ntasks; k += 64) acc = C::add(acc, partials[h.first_partial + k]);
-    sh[lane] = acc;
+    for (uint32_t k = lane; k < h.ntasks; k += 64) acc = C::add(acc, C::unpack_pt(partials[h.first_partial + k]));
+    sh[lane] = C::pack_pt(acc);
     __syncthreads();
     for (uint32_t step = 32; step >= 1; step >>= 1) {
-        if (lane < step) sh[lane] = C::add(sh[lane], sh[lane + step]);
+        if (lane < step) sh[lane] = C::pack_pt(C::add(C::unpack_pt(sh[lane]), C::unpack_pt(sh[lane + step])));
         __syncthreads();
     }
     if (lane == 0) buckets[h.bucket] = sh[0];
@@ -235,19 +244,19 @@ __global__ __launch_bounds__(64) void msm_combine_wave(const MultiBucket* __rest
 //    S = sum B_i,  A = sum (i - i0 + 1) B_i   (descending running sum)
 // ---------------------------------------------------------------------------
 template <class C>
-__global__ __launch_bounds__(256) void msm_chunks(const typename C::Pt* __restrict__ buckets, uint32_t nchunks,
-                                                    uint32_t m, typename C::Pt* __restrict__ chunkS,
-                                                    typename C::Pt* __restrict__ chunkA) {
+__global__ __launch_bounds__(256) void msm_chunks(const typename C::PtP* __restrict__ buckets, uint32_t nchunks,
+                                                    uint32_t m, typename C::PtP* __restrict__ chunkS,
+                                                    typename C::PtP* __restrict__ chunkA) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nchunks) return;
     typename C::Pt run = C::infinity(), acc = C::infinity();
-    const typename C::Pt* B = buckets + (uint64_t)j * m;
+    const typename C::PtP* B = buckets + (uint64_t)j * m;
     for (int i = (int)m - 1; i >= 0; i--) {
-        run = C::add(run, B[i]);
+        run = C::add(run, C::unpack_pt(B[i]));
         acc = C::add(acc, run);
     }
-    chunkS[j] = run;
-    chunkA[j] = acc;
+    chunkS[j] = C::pack_pt(run);
+    chunkA[j] = C::pack_pt(acc);
 }
 
 // ---------------------------------------------------------------------------
@@ -255,24 +264,25 @@ __global__ __launch_bounds__(256) void msm_chunks(const typename C::Pt* __restri
 //    q < logJ : U_q = sum_{j : bit q of j set} S_j ;  q == logJ : sum_j A_j
 // ---------------------------------------------------------------------------
 template <class C>
-__global__ __launch_bounds__(sizeof(typename C::Pt) > 128 ? 256 : 512) void msm_tree(const typename C::Pt* __restrict__ chunkS,
-                                                   const typename C::Pt* __restrict__ chunkA, uint32_t J,
-                                                   uint32_t logJ, typename C::Pt* __restrict__ sums) {
-    WS_DYN_SMEM(typename C::Pt, sh);
+__global__ __launch_bounds__(sizeof(typename C::PtP) > 128 ? 256 : 512) void msm_tree(const typename C::PtP* __restrict__ chunkS,
+                                                   const typename C::PtP* __restrict__ chunkA, uint32_t J,
+                                                   uint32_t logJ, typename C::PtP* __restrict__ sums) {
+    WS_DYN_SMEM(typename C::PtP, sh);
     const uint32_t q = blockIdx.x, w = blockIdx.y;
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
-    const typename C::Pt* src = (q == logJ ? chunkA : chunkS) + (uint64_t)w * J;
+    const typename C::PtP* src = (q == logJ ? chunkA : chunkS) + (uint64_t)w * J;
     typename C::Pt acc = C::infinity();
     for (uint32_t j = tid; j < J; j += nthr) {
-        if (q == logJ || ((j >> q) & 1)) acc = C::add(acc, src[j]);
+        if (q == logJ || ((j >> q) & 1)) acc = C::add(acc, C::unpack_pt(src[j]));
     }
-    sh[tid] = acc;
+    sh[tid] = C::pack_pt(acc);
     __syncthreads();
     for (uint32_t step = nthr >> 1; step >= 1; step >>= 1) {
-        if (tid < step) sh[tid] = C::add(sh[tid], sh[tid + step]);
+        if (tid < step) sh[tid] = C::pack_pt(C::add(C::unpack_pt(sh[tid]), C::unpack_pt(sh[tid + step])));
         __syncthreads();
     }
-    if (tid == 0) sums[(uint64_t)w * (logJ + 1) + q] = sh[0];
+    // results leave the device in the reference format (canonical, Montgomery R = 2^256)
+    if (tid == 0) sums[(uint64_t)w * (logJ + 1) + q] = C::pt_from_internal(C::unpack_pt(sh[0]));
 }
 
 // ---------------------------------------------------------------------------
@@ -310,13 +320,25 @@ static uint32_t pick_window(uint64_t n) {
     return (uint32_t)c;
 }
 
-template <class C>
-static int msm_run(int which, const Fe* d_scalars, const typename C::Aff* d_points, uint64_t n,
-                   typename C::Pt* out_host, hipStream_t s) {
-    typedef typename C::Pt Pt;
+// which field implementation the heavy kernels use: radix-2^29 (default) or the saturated 8x32
+// multiplier (WSNARK_FIELD=32; kept for A/B measurements)
+bool msm_uses_field29() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("WSNARK_FIELD"); v = (e && atoi(e) == 32) ? 0 : 1; }
+    return v == 1;
+}
+
+// C = device curve (arithmetic of the kernels), H = host curve (reference-format results, host tail).
+// `prepared`: d_points are already in C's internal domain (msm_prepare_points).
+template <class C, class H>
+static int msm_run(int which, const Fe* d_scalars, const typename H::Aff* d_points_ref, uint64_t n, bool prepared,
+                   typename H::Pt* out_host, hipStream_t s) {
+    typedef typename C::PtP Pt;      // packed accumulator in global memory (same bytes as H::Pt)
+    static_assert(sizeof(typename C::PtP) == sizeof(typename H::Pt) && sizeof(typename C::AffP) == sizeof(typename H::Aff), "layouts");
     Context* X = ctx();
     if (!X) return WS_ERR_NOINIT;
-    if (n == 0) { *out_host = C::infinity(); return WS_OK; }   // multiexp with n=0 leaves pr unchanged
+    if (n == 0) { *out_host = H::infinity(); return WS_OK; }   // multiexp with n=0 leaves pr unchanged
+    const typename C::AffP* d_points = reinterpret_cast<const typename C::AffP*>(d_points_ref);
     if (!d_scalars || !d_points || !out_host) return WS_ERR_ARG;
     if (n > ((uint64_t)1 << 28)) return WS_ERR_SIZE;
     if (!s) s = X->stream;
@@ -355,6 +377,14 @@ static int msm_run(int which, const Fe* d_scalars, const typename C::Aff* d_poin
     WS_HIP_CHECK(S.sums.reserve((size_t)W * nsum * sizeof(Pt)));
 
     KernelTimer& T = X->timer;
+    if (C::Field::kInternalDomain && !prepared) {
+        WS_HIP_CHECK(S.points_conv.reserve((size_t)n * sizeof(typename C::AffP)));
+        T.begin("msm_convert_points", s);
+        hipLaunchKernelGGL(msm_convert_points<C>, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s, d_points,
+                           S.points_conv.as<typename C::AffP>(), n);
+        T.end(s);
+        d_points = S.points_conv.as<typename C::AffP>();
+    }
     T.begin("msm_digits", s);
     hipLaunchKernelGGL(msm_digits, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s, d_scalars, (uint32_t)n, c, W, nbuckets,
                        S.keys.as<uint32_t>(), S.vals.as<uint32_t>());
@@ -417,7 +447,7 @@ static int msm_run(int which, const Fe* d_scalars, const typename C::Aff* d_poin
     WS_HIP_CHECK(hipGetLastError());
 
     uint32_t tthreads = 1;
-    const uint32_t tmax = sizeof(Pt) > 128 ? 256 : 512;   // LDS: threads * sizeof(Pt) <= 64 KiB
+    const uint32_t tmax = sizeof(Pt) > 128 ? 256 : 512;   // LDS: threads * sizeof(packed point) <= 64 KiB
     while (tthreads < J && tthreads < tmax) tthreads <<= 1;
     T.begin("msm_tree", s);
     hipLaunchKernelGGL(msm_tree<C>, dim3(nsum, W), dim3(tthreads), (size_t)tthreads * sizeof(Pt), s,
@@ -425,35 +455,58 @@ static int msm_run(int which, const Fe* d_scalars, const typename C::Aff* d_poin
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
 
-    std::vector<Pt> sums((size_t)W * nsum);
-    WS_HIP_CHECK(hipMemcpyAsync(sums.data(), S.sums.p, sums.size() * sizeof(Pt), hipMemcpyDeviceToHost, s));
+    typedef typename H::Pt HPt;
+    std::vector<HPt> sums((size_t)W * nsum);
+    WS_HIP_CHECK(hipMemcpyAsync(sums.data(), S.sums.p, sums.size() * sizeof(HPt), hipMemcpyDeviceToHost, s));
     WS_HIP_CHECK(hipStreamSynchronize(s));
 
     // 8. host tail: result = sum_w 2^(c w) [ A_w + m * sum_q 2^q U_{w,q} ]   (Horner, MSB first)
     uint32_t logm = 0;
     while ((1u << logm) < m) logm++;
-    Pt acc = C::infinity();
+    HPt acc = H::infinity();
     for (int w = (int)W - 1; w >= 0; w--) {
-        for (uint32_t k = 0; k < c; k++) acc = C::dbl(acc);
-        const Pt* row = &sums[(size_t)w * nsum];
-        Pt u = C::infinity();
+        for (uint32_t k = 0; k < c; k++) acc = H::dbl(acc);
+        const HPt* row = &sums[(size_t)w * nsum];
+        HPt u = H::infinity();
         for (int q = (int)logJ - 1; q >= 0; q--) {
-            u = C::dbl(u);
-            u = C::add(u, row[q]);
+            u = H::dbl(u);
+            u = H::add(u, row[q]);
         }
-        for (uint32_t k = 0; k < logm; k++) u = C::dbl(u);
-        u = C::add(u, row[logJ]);
-        acc = C::add(acc, u);
+        for (uint32_t k = 0; k < logm; k++) u = H::dbl(u);
+        u = H::add(u, row[logJ]);
+        acc = H::add(acc, u);
     }
     *out_host = acc;
     return WS_OK;
 }
 
-int msm_g1_dev_xyzz(const Fe* d_scalars, const Affine<Fq>* d_points, uint64_t n, XYZZ<Fq>* out_host, hipStream_t s) {
-    return msm_run<G1>(0, d_scalars, d_points, n, out_host, s);
+// in-place conversion of a resident point array (the proving key's sections) to the device field's
+// internal domain, so that proofs skip the per-MSM conversion pass
+int msm_prepare_points(int which, void* d_points, uint64_t n, hipStream_t s) {
+    Context* X = ctx();
+    if (!X) return WS_ERR_NOINIT;
+    if (!s) s = X->stream;
+    if (!msm_uses_field29() || n == 0) return WS_OK;
+    if (which == 0) {
+        hipLaunchKernelGGL(msm_convert_points<G1R29>, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s,
+                           (const G1R29::AffP*)d_points, (G1R29::AffP*)d_points, n);
+    } else {
+        hipLaunchKernelGGL(msm_convert_points<G2R29>, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s,
+                           (const G2R29::AffP*)d_points, (G2R29::AffP*)d_points, n);
+    }
+    WS_HIP_CHECK(hipGetLastError());
+    return WS_OK;
 }
-int msm_g2_dev_xyzz(const Fe* d_scalars, const Affine<Fq2>* d_points, uint64_t n, XYZZ<Fq2>* out_host, hipStream_t s) {
-    return msm_run<G2>(1, d_scalars, d_points, n, out_host, s);
+
+int msm_g1_dev_xyzz(const Fe* d_scalars, const Affine<Fq>* d_points, uint64_t n, XYZZ<Fq>* out_host, hipStream_t s,
+                    bool prepared) {
+    if (msm_uses_field29()) return msm_run<G1R29, G1>(0, d_scalars, d_points, n, prepared, out_host, s);
+    return msm_run<G1, G1>(0, d_scalars, d_points, n, prepared, out_host, s);
+}
+int msm_g2_dev_xyzz(const Fe* d_scalars, const Affine<Fq2>* d_points, uint64_t n, XYZZ<Fq2>* out_host, hipStream_t s,
+                    bool prepared) {
+    if (msm_uses_field29()) return msm_run<G2R29, G2>(1, d_scalars, d_points, n, prepared, out_host, s);
+    return msm_run<G2, G2>(1, d_scalars, d_points, n, prepared, out_host, s);
 }
 int msm_g1_dev(const Fe* d_scalars, const Affine<Fq>* d_points, uint64_t n, Jac<Fq>* out_host, hipStream_t s) {
     XYZZ<Fq> r;

@@ -19,6 +19,7 @@
 // HBM traffic: np passes x (32 B read + 32 B write) per element, np = 3 at 2^22.
 // Arithmetic is exact, so outputs are bit-identical to the reference's.
 #include "internal.h"
+#include "field29.h"
 
 namespace wsnark {
 
@@ -36,25 +37,48 @@ struct PassArgs {
     const Fe* tw_lo; const Fe* tw_hi; uint32_t h;   // two-level w_N^e = tw_hi[e>>h] * tw_lo[e & mask]
     uint32_t apply_twiddle;
     const Fe* cs_lo; const Fe* cs_hi; uint32_t hc; uint32_t prescale;   // coset factors w_2N^i
-    uint32_t scale;
-    Fe n_inv;
+    uint32_t scale, first;
+    Fe out_scale;   // reference-format Montgomery form of 1/n (inverse) or 1
 };
 
-__device__ __forceinline__ Fe lds_get(const Q128* plo, const Q128* phi, uint32_t i) {
-    Q128 a = plo[i], b = phi[i];
-    return Fe{{a.a, a.b, b.a, b.b}};
-}
-__device__ __forceinline__ void lds_put(Q128* plo, Q128* phi, uint32_t i, const Fe& v) {
-    plo[i] = Q128{v.l[0], v.l[1]};
-    phi[i] = Q128{v.l[2], v.l[3]};
-}
+// LDS tile storage: 16-byte planes so that consecutive lanes read consecutive 16-byte slots.
+// 4x64 field: two planes (32 B/element).  Radix-2^29 field: limbs 0-3, limbs 4-7 and limb 8 in
+// three planes (36 B/element), i.e. elements stay unpacked between butterflies.
+template <class F> struct LdsTile;
+template <class P> struct LdsTile<Field<P>> {
+    static constexpr uint32_t kBytes = 32;
+    Q128 *plo, *phi;
+    __device__ __forceinline__ LdsTile(unsigned char* base, uint32_t LT) : plo((Q128*)base), phi((Q128*)base + LT) {}
+    __device__ __forceinline__ Fe get(uint32_t i) const { Q128 a = plo[i], b = phi[i]; return Fe{{a.a, a.b, b.a, b.b}}; }
+    __device__ __forceinline__ void put(uint32_t i, const Fe& v) { plo[i] = Q128{v.l[0], v.l[1]}; phi[i] = Q128{v.l[2], v.l[3]}; }
+};
+struct alignas(16) U4 { uint32_t x, y, z, w; };
+template <class P> struct LdsTile<Field29<P>> {
+    static constexpr uint32_t kBytes = 36;
+    U4 *p0, *p1; uint32_t* p2;
+    __device__ __forceinline__ LdsTile(unsigned char* base, uint32_t LT) : p0((U4*)base), p1((U4*)base + LT), p2((uint32_t*)((U4*)base + 2 * LT)) {}
+    __device__ __forceinline__ F29 get(uint32_t i) const {
+        U4 a = p0[i], b = p1[i];
+        return F29{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, p2[i]}};
+    }
+    __device__ __forceinline__ void put(uint32_t i, const F29& v) {
+        p0[i] = U4{v.v[0], v.v[1], v.v[2], v.v[3]};
+        p1[i] = U4{v.v[4], v.v[5], v.v[6], v.v[7]};
+        p2[i] = v.v[8];
+    }
+};
 
+// F = Field<FrParams> (saturated 4x64, values canonical, tables in the reference Montgomery form) or
+// Field29<Fr29Params> (values in [0,2p), internal domain R' = 2^261; the host scales every table by
+// 2^5 so that table products land in the internal domain, and the conversions from / to the
+// reference format are folded into the first load and the last store).
+template <class F>
 __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
-    WS_DYN_SMEM(Q128, sm);
+    typedef typename F::El El;
+    WS_DYN_SMEM(unsigned char, sm);
     const uint32_t log_L = A.log_L, log_T = A.log_T;
     const uint32_t L = 1u << log_L, T = 1u << log_T, LT = L << log_T;
-    Q128* plo = sm;
-    Q128* phi = sm + LT;
+    LdsTile<F> tile(sm, LT);
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     const uint32_t w = blockIdx.x;
 
@@ -84,13 +108,15 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
             j = idx & (L - 1); t = idx >> log_L;
             g = ((uint64_t)(a0 + t) << A.log_S0) + ((uint64_t)mid << log_L) + j;
         }
-        Fe v = A.in[g];
+        El v = F::unpack(A.in[g]);
         if (A.prescale) {   // only ever set for pass 0, where storage index == input index
-            uint32_t e = (uint32_t)g;
-            Fe f = Fr::mul(A.cs_hi[e >> A.hc], A.cs_lo[e & ((1u << A.hc) - 1)]);
-            v = Fr::mul(v, f);
+            const uint32_t e = (uint32_t)g;
+            El f = F::mul(F::unpack(A.cs_hi[e >> A.hc]), F::unpack(A.cs_lo[e & ((1u << A.hc) - 1)]));
+            v = F::mul(v, f);          // (radix-2^29: cs_lo carries the extra 2^5 => also converts the domain)
+        } else if (F::kInternalDomain && A.first) {
+            v = F::to_internal(A.in[g]);
         }
-        lds_put(plo, phi, (j << log_T) + t, v);
+        tile.put((j << log_T) + t, v);
     }
     __syncthreads();
 
@@ -103,15 +129,15 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
             const uint32_t jlow = bb & hmask;
             const uint32_t j = ((bb >> hs) << (hs + 1)) | jlow;
             const uint32_t i0 = (j << log_T) + t, i1 = i0 + (1u << (hs + log_T));
-            Fe u = lds_get(plo, phi, i0), v = lds_get(plo, phi, i1);
-            Fe s = Fr::add(u, v), d = Fr::sub(u, v);
+            El u = tile.get(i0), v = tile.get(i1);
+            El s = F::add(u, v), d = F::sub(u, v);
             if (hs > 0) {
                 // w_{2h}^{jlow} = w_Lmax^(jlow * Lmax/(2h))
                 const uint32_t ti = jlow << (A.log_lmax - 1 - hs);
-                d = Fr::mul(d, A.tw_small[ti]);
+                d = F::mul(d, F::unpack(A.tw_small[ti]));
             }
-            lds_put(plo, phi, i0, s);
-            lds_put(plo, phi, i1, d);
+            tile.put(i0, s);
+            tile.put(i1, d);
         }
         __syncthreads();
     }
@@ -122,13 +148,13 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
         for (uint32_t idx = tid; idx < LT; idx += nthr) {
             const uint32_t t = idx & (T - 1), kk = idx >> log_T;
             const uint32_t r = __brev(kk) >> (32 - log_L);
-            Fe v = lds_get(plo, phi, (r << log_T) + t);
+            El v = tile.get((r << log_T) + t);
             if (A.apply_twiddle) {
                 const uint32_t e = (kk * (lo0 + t)) << log_c;
-                Fe f = Fr::mul(A.tw_hi[e >> A.h], A.tw_lo[e & ((1u << A.h) - 1)]);
-                v = Fr::mul(v, f);
+                El f = F::mul(F::unpack(A.tw_hi[e >> A.h]), F::unpack(A.tw_lo[e & ((1u << A.h) - 1)]));
+                v = F::mul(v, f);
             }
-            A.out[base + ((uint64_t)kk << A.log_S) + t] = v;
+            A.out[base + ((uint64_t)kk << A.log_S) + t] = F::pack(v);
         }
     } else {
         // digit-reverse the middle digits k_1..k_{np-2} of this tile
@@ -147,9 +173,17 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
         for (uint32_t idx = tid; idx < LT; idx += nthr) {
             const uint32_t t = idx & (T - 1), kk = idx >> log_T;
             const uint32_t r = (log_L == 0) ? 0 : (__brev(kk) >> (32 - log_L));
-            Fe v = lds_get(plo, phi, (r << log_T) + t);
-            if (A.scale) v = Fr::mul(v, A.n_inv);
-            A.out[((uint64_t)kk << log_rest) + revmid + a0 + t] = v;
+            El v = tile.get((r << log_T) + t);
+            Fe o;
+            if (F::kInternalDomain) {
+                // out_scale = 1 or 1/n in the REFERENCE Montgomery form: as an internal-domain operand it is
+                // (2^-5) or (2^-5 / n), so this one product also converts back; then canonicalise
+                o = F::pack(F::canonical(F::mul(v, F::unpack(A.out_scale))));
+            } else {
+                if (A.scale) v = F::mul(v, F::unpack(A.out_scale));
+                o = F::pack(v);
+            }
+            A.out[((uint64_t)kk << log_rest) + revmid + a0 + t] = o;
         }
     }
 }
@@ -164,9 +198,11 @@ struct NttPlan {
     int np = 1;
     int k[4] = {0, 0, 0, 0};
     int h = 0, hc = 0;
+    bool field29 = false;                     // table format: internal domain of Field29 (entries x 2^5)
     DevBuf tw_small[2], tw_lo[2], tw_hi[2];   // [0] forward root, [1] inverse root
-    DevBuf cs_lo, cs_hi;                      // coset w_{2n}^i (forward root)
-    Fe n_inv;
+    DevBuf cs_lo, cs_hi;                      // coset w_{2n}^i (forward root), format of the NTT kernel
+    DevBuf cs_lo_ref, cs_hi_ref;              // the same in the reference Montgomery form (calch.hip)
+    Fe n_inv;                                 // reference Montgomery form of 1/n
 };
 
 // w_{2^28} = 5^((r-1)/2^28) (src/build_fft.js:29-47), plain form
@@ -184,6 +220,11 @@ static void powers(const Fe& base, size_t count, std::vector<Fe>& out) {
     Fe acc = Fr::one();
     for (size_t i = 0; i < count; i++) { out[i] = acc; acc = Fr::mul(acc, base); }
 }
+// x -> x * 2^5 : reference Montgomery form (R = 2^256) -> internal form of Field29 (R' = 2^261)
+static void scale32(std::vector<Fe>& v) {
+    const Fe m32 = Fr::to_mont(Fe{{32, 0, 0, 0}});
+    for (auto& x : v) x = Fr::mul(x, m32);
+}
 static int upload(DevBuf& b, const std::vector<Fe>& v, hipStream_t s) {
     WS_HIP_CHECK(b.alloc(v.size() * sizeof(Fe)));
     WS_HIP_CHECK(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(Fe), hipMemcpyHostToDevice, s));
@@ -198,22 +239,31 @@ static int build_plan(int bits, NttPlan& P, hipStream_t s) {
     for (int d = 0; d < P.np; d++) P.k[d] = basek + (d < rem ? 1 : 0);
     P.h = (bits + 1) / 2;
     P.hc = (bits + 1) / 2;
+    P.field29 = msm_uses_field29();
+    const bool f29 = P.field29;
     std::vector<Fe> tmp;
     for (int dir = 0; dir < 2; dir++) {
         Fe wl = root_of_unity(LOG_LMAX), wn = root_of_unity(bits);
         if (dir) { wl = Fr::inv(wl); wn = Fr::inv(wn); }
         powers(wl, (size_t)1 << (LOG_LMAX - 1), tmp);
+        if (f29) scale32(tmp);
         int rc = upload(P.tw_small[dir], tmp, s); if (rc) return rc;
         powers(wn, (size_t)1 << P.h, tmp);
+        if (f29) scale32(tmp);
         rc = upload(P.tw_lo[dir], tmp, s); if (rc) return rc;
         powers(Fr::pow_u64(wn, (uint64_t)1 << P.h), (size_t)1 << (bits - P.h), tmp);
+        if (f29) scale32(tmp);
         rc = upload(P.tw_hi[dir], tmp, s); if (rc) return rc;
     }
     if (bits < 28) {
         Fe g = root_of_unity(bits + 1);
         powers(g, (size_t)1 << P.hc, tmp);
-        int rc = upload(P.cs_lo, tmp, s); if (rc) return rc;
+        int rc = upload(P.cs_lo_ref, tmp, s); if (rc) return rc;
+        if (f29) { scale32(tmp); scale32(tmp); }   // carries the 2^5 of the entry AND the 2^5 that converts the loaded value
+        rc = upload(P.cs_lo, tmp, s); if (rc) return rc;
         powers(Fr::pow_u64(g, (uint64_t)1 << P.hc), (size_t)1 << (bits - P.hc), tmp);
+        rc = upload(P.cs_hi_ref, tmp, s); if (rc) return rc;
+        if (f29) scale32(tmp);
         rc = upload(P.cs_hi, tmp, s); if (rc) return rc;
     }
     // n^-1 = (2^-1)^bits  (INV2 table of build_fft.js:59-72)
@@ -246,7 +296,7 @@ int ntt_coset_tables(int bits, const Fe** lo, const Fe** hi, int* hc, Fe* n_inv,
     std::shared_ptr<NttPlan> P;
     int rc = get_plan(C, bits, P, s);
     if (rc) return rc;
-    *lo = P->cs_lo.as<Fe>(); *hi = P->cs_hi.as<Fe>(); *hc = P->hc; *n_inv = P->n_inv;
+    *lo = P->cs_lo_ref.as<Fe>(); *hi = P->cs_hi_ref.as<Fe>(); *hc = P->hc; *n_inv = P->n_inv;
     return WS_OK;
 }
 
@@ -295,7 +345,8 @@ int ntt_dev(Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s) {
         A.cs_lo = P->cs_lo.as<Fe>(); A.cs_hi = P->cs_hi.as<Fe>(); A.hc = P->hc;
         A.prescale = (odd && p == 0) ? 1 : 0;
         A.scale = (inverse && last) ? 1 : 0;
-        A.n_inv = P->n_inv;
+        A.first = (p == 0) ? 1 : 0;
+        A.out_scale = A.scale ? P->n_inv : Fr::one();
         // tile: up to 2048 elements (64 KiB of LDS)
         int log_T = 11 - (int)A.log_L;
         if (log_T > 5) log_T = 5;
@@ -309,9 +360,21 @@ int ntt_dev(Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s) {
         }
         A.log_T = log_T;
         const uint32_t grid = (uint32_t)(n >> (A.log_L + log_T));
-        const size_t smem = ((size_t)1 << (A.log_L + log_T)) * 2 * sizeof(Q128);
+        const size_t elems = (size_t)1 << (A.log_L + log_T);
         C->timer.begin(last ? "ntt_pass_last" : "ntt_pass", s);
-        hipLaunchKernelGGL(ntt_pass_kernel, dim3(grid), dim3(512), smem, s, A);
+        if (P->field29) {
+            const size_t smem = elems * LdsTile<Fr29>::kBytes;
+            static bool attr_set = false;
+            if (!attr_set) {   // 2048-element tiles need 72 KiB of dynamic LDS (> the 64 KiB default cap)
+                WS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<Fr29>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * 36));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(ntt_pass_kernel<Fr29>, dim3(grid), dim3(512), smem, s, A);
+        } else {
+            const size_t smem = elems * LdsTile<Fr>::kBytes;
+            hipLaunchKernelGGL(ntt_pass_kernel<Fr>, dim3(grid), dim3(512), smem, s, A);
+        }
         C->timer.end(s);
         WS_HIP_CHECK(hipGetLastError());
     }

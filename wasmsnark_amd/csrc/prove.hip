@@ -64,6 +64,12 @@ int pkey_load(const uint8_t* buf, size_t len, ProvingKey** out) {
         WS_HIP_CHECK(sc.d->alloc((size_t)sc.bytes));
         if (sc.bytes) WS_HIP_CHECK(hipMemcpyAsync(sc.d->p, buf + sc.off, (size_t)sc.bytes, hipMemcpyHostToDevice, s));
     }
+    // resident keys are kept in the device field's internal domain: no per-proof conversion pass
+    if ((rc = msm_prepare_points(0, K->pointsA.p, nv, s))) return rc;
+    if ((rc = msm_prepare_points(0, K->pointsB1.p, nv, s))) return rc;
+    if ((rc = msm_prepare_points(1, K->pointsB2.p, nv, s))) return rc;
+    if ((rc = msm_prepare_points(0, K->pointsC.p, nC, s))) return rc;
+    if ((rc = msm_prepare_points(0, K->pointsH.p, dom, s))) return rc;
     WS_HIP_CHECK(K->witness.alloc((size_t)nv * 32));
     WS_HIP_CHECK(K->h.alloc((size_t)dom * 32));
     WS_HIP_CHECK(hipStreamSynchronize(s));
@@ -126,11 +132,11 @@ int groth16_prove(ProvingKey* K, const Fe* d_witness, const uint8_t* r32, const 
     if ((rc = calc_h_dev(d_witness, nv, K->polsA, K->polsB, dom, d_h, s))) return rc;
     XYZZ<Fq> sA, sB1, sC, sH;
     XYZZ<Fq2> sB2;
-    if ((rc = msm_g1_dev_xyzz(d_h, K->pointsH.as<Affine<Fq>>(), dom, &sH, s))) return rc;
-    if ((rc = msm_g1_dev_xyzz(d_witness, K->pointsA.as<Affine<Fq>>(), nv, &sA, s))) return rc;              // :617
-    if ((rc = msm_g1_dev_xyzz(d_witness, K->pointsB1.as<Affine<Fq>>(), nv, &sB1, s))) return rc;            // :618
-    if ((rc = msm_g2_dev_xyzz(d_witness, K->pointsB2.as<Affine<Fq2>>(), nv, &sB2, s))) return rc;           // :619
-    if ((rc = msm_g1_dev_xyzz(d_witness + (np + 1), K->pointsC.as<Affine<Fq>>(), (uint64_t)nv - np - 1, &sC, s))) return rc;  // :620
+    if ((rc = msm_g1_dev_xyzz(d_h, K->pointsH.as<Affine<Fq>>(), dom, &sH, s, true))) return rc;
+    if ((rc = msm_g1_dev_xyzz(d_witness, K->pointsA.as<Affine<Fq>>(), nv, &sA, s, true))) return rc;              // :617
+    if ((rc = msm_g1_dev_xyzz(d_witness, K->pointsB1.as<Affine<Fq>>(), nv, &sB1, s, true))) return rc;            // :618
+    if ((rc = msm_g2_dev_xyzz(d_witness, K->pointsB2.as<Affine<Fq2>>(), nv, &sB2, s, true))) return rc;           // :619
+    if ((rc = msm_g1_dev_xyzz(d_witness + (np + 1), K->pointsC.as<Affine<Fq>>(), (uint64_t)nv - np - 1, &sC, s, true))) return rc;  // :620
 
     // r, s are raw 256-bit values (not reduced, src/bn128.js:642-661); every point here has prime
     // order r, so k*P == (k mod r)*P and (r*s)*P == ((r mod r)(s mod r) mod r)*P  (:700-702)
