@@ -120,7 +120,7 @@ def main():
     out = {"metric": "BN128 G1 MSM Mpoints/s (2^%d pairs/GPU)" % args.log_n, "value": round(value, 3),
            "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "u256 (4xu64 Montgomery, 32-bit mad)", "data": "synthetic",
+           "vs_baseline": None, "dtype": "u256 (Montgomery; 9x29-bit limbs, v_mad_u64_u32)", "data": "synthetic",
            "config": {"workload": "BN128 G1 Pippenger MSM, 2^%d random (scalar,point) pairs per GPU, inputs resident in HBM" % args.log_n,
                       "pairs_per_gpu": n, "parallelism": "points-sharded x%d, 1 all_gather of 96 B partials" % world,
                       "device": bn.device_info},
