@@ -60,6 +60,12 @@ int msm_g1_dev_xyzz(const Fe* d_scalars, const Affine<Fq>* d_points, uint64_t n,
                     bool prepared = false);
 int msm_g2_dev_xyzz(const Fe* d_scalars, const Affine<Fq2>* d_points, uint64_t n, XYZZ<Fq2>* out_host, hipStream_t s,
                     bool prepared = false);
+// two-phase form: one digit/sort/task plan per scalar vector, then any number of point sets of the
+// same length against it (the prover's A, B1, B2 and C sums all use the witness as scalars).
+// Callers serialise on Context::mu.
+int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s);
+int msm_g1_exec_xyzz(const Affine<Fq>* d_points, XYZZ<Fq>* out_host, hipStream_t s, bool prepared);
+int msm_g2_exec_xyzz(const Affine<Fq2>* d_points, XYZZ<Fq2>* out_host, hipStream_t s, bool prepared);
 int msm_prepare_points(int which, void* d_points, uint64_t n, hipStream_t s);
 bool msm_uses_field29();
 

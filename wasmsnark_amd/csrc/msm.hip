@@ -147,11 +147,10 @@ __global__ void msm_plan_offsets(const uint32_t* __restrict__ hist, uint32_t* __
     counters[3] = off;
 }
 
-template <class C>
 __global__ __launch_bounds__(256) void msm_plan_emit(const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bend,
                                                        uint32_t nbuckets, uint32_t lmax, uint32_t* __restrict__ cursor,
                                                        Task* __restrict__ tasks, uint32_t* __restrict__ counters,
-                                                       MultiBucket* __restrict__ multi, typename C::PtP* __restrict__ buckets) {
+                                                       MultiBucket* __restrict__ multi) {
     __shared__ uint32_t lcnt[256];
     __shared__ uint32_t lbase[256];
     lcnt[threadIdx.x] = 0;
@@ -167,8 +166,6 @@ __global__ __launch_bounds__(256) void msm_plan_emit(const uint32_t* __restrict_
             krem = len_key(rem, lmax);
             if (nt > 1) r255 = atomicAdd(&lcnt[255], nt - 1);
             rrem = atomicAdd(&lcnt[krem], 1u);
-        } else {
-            buckets[b] = C::pack_pt(C::infinity());
         }
     }
     __syncthreads();
@@ -184,6 +181,15 @@ __global__ __launch_bounds__(256) void msm_plan_emit(const uint32_t* __restrict_
         for (uint32_t k = 0; k + 1 < nt; k++) tasks[lbase[255] + r255 + k] = Task{PARTIAL_FLAG | (pbase + k), s + k * lmax, lmax};
         tasks[lbase[krem] + rrem] = Task{PARTIAL_FLAG | (pbase + nt - 1), s + (nt - 1) * lmax, rem};
     }
+}
+
+// empty buckets = infinity (ZZ == 0); the others are written by their (last) task or by the combine step
+template <class C>
+__global__ __launch_bounds__(256) void msm_clear_empty(const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bend,
+                                                         uint32_t nbuckets, typename C::PtP* __restrict__ buckets) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbuckets) return;
+    if (bend[b] == bstart[b]) buckets[b] = C::pack_pt(C::infinity());
 }
 
 // 4. one lane per task: mixed additions of the task's points
@@ -328,63 +334,61 @@ bool msm_uses_field29() {
     return v == 1;
 }
 
-// C = device curve (arithmetic of the kernels), H = host curve (reference-format results, host tail).
-// `prepared`: d_points are already in C's internal domain (msm_prepare_points).
-template <class C, class H>
-static int msm_run(int which, const Fe* d_scalars, const typename H::Aff* d_points_ref, uint64_t n, bool prepared,
-                   typename H::Pt* out_host, hipStream_t s) {
-    typedef typename C::PtP Pt;      // packed accumulator in global memory (same bytes as H::Pt)
-    static_assert(sizeof(typename C::PtP) == sizeof(typename H::Pt) && sizeof(typename C::AffP) == sizeof(typename H::Aff), "layouts");
+// ---- phase 1 (independent of the points and of the curve): digits, sort, bounds, task list ----
+struct MsmPlanInfo {
+    uint64_t n = 0;
+    uint32_t c = 0, W = 0, NB = 0, nbuckets = 0, m = 0, J = 0, logJ = 0, nsum = 0, lmax = 0, hot_cap = 0;
+    uint32_t ntasks = 0, nmulti = 0;
+    bool valid = false;
+};
+struct MsmPlanBufs {
+    MsmScratch S;
+    MsmPlanInfo info;
+};
+static MsmPlanBufs* plan_bufs(Context* X) {
+    if (!X->msm_scratch[0]) X->msm_scratch[0] = std::make_shared<MsmScratch>();   // slot 0: plan buffers + G1 exec buffers
+    if (!X->msm_scratch[1]) X->msm_scratch[1] = std::make_shared<MsmScratch>();   // slot 1: G2 exec buffers
+    static MsmPlanBufs P;   // info only; buffers live in the context scratch
+    return &P;
+}
+
+int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
     Context* X = ctx();
     if (!X) return WS_ERR_NOINIT;
-    if (n == 0) { *out_host = H::infinity(); return WS_OK; }   // multiexp with n=0 leaves pr unchanged
-    const typename C::AffP* d_points = reinterpret_cast<const typename C::AffP*>(d_points_ref);
-    if (!d_scalars || !d_points || !out_host) return WS_ERR_ARG;
-    if (n > ((uint64_t)1 << 28)) return WS_ERR_SIZE;
     if (!s) s = X->stream;
-
-    const uint32_t c = pick_window(n);
-    const uint32_t W = (255 + c - 1) / c;
-    const uint32_t NB = 1u << (c - 1);
-    const uint32_t nbuckets = W * NB;
-    const uint64_t total = n * W;
+    MsmPlanInfo& I = plan_bufs(X)->info;
+    I = MsmPlanInfo();
+    if (n == 0) { I.valid = true; return WS_OK; }
+    if (!d_scalars) return WS_ERR_ARG;
+    if (n > ((uint64_t)1 << 28)) return WS_ERR_SIZE;
+    I.n = n;
+    I.c = pick_window(n);
+    I.W = (255 + I.c - 1) / I.c;
+    I.NB = 1u << (I.c - 1);
+    I.nbuckets = I.W * I.NB;
+    const uint64_t total = n * I.W;
     if (total >= ((uint64_t)1 << 32)) return WS_ERR_SIZE;
-    const uint32_t m = NB < CHUNK ? NB : CHUNK;
-    const uint32_t J = NB / m;
-    uint32_t logJ = 0;
-    while ((1u << logJ) < J) logJ++;
-    const uint32_t nsum = logJ + 1;
-    uint32_t lmax = (uint32_t)(2 * ((n + NB - 1) / NB));
-    if (lmax < 32) lmax = 32;
-    const uint32_t hot_cap = (uint32_t)(total / lmax) + nbuckets + 16;
+    I.m = I.NB < CHUNK ? I.NB : CHUNK;
+    I.J = I.NB / I.m;
+    while ((1u << I.logJ) < I.J) I.logJ++;
+    I.nsum = I.logJ + 1;
+    I.lmax = (uint32_t)(2 * ((n + I.NB - 1) / I.NB));
+    if (I.lmax < 32) I.lmax = 32;
+    I.hot_cap = (uint32_t)(total / I.lmax) + I.nbuckets + 16;
+    const uint32_t c = I.c, W = I.W, nbuckets = I.nbuckets, lmax = I.lmax;
 
-    std::lock_guard<std::mutex> lk(X->mu);   // scratch is shared: one MSM at a time per curve
-    if (!X->msm_scratch[which]) X->msm_scratch[which] = std::make_shared<MsmScratch>();
-    MsmScratch& S = *X->msm_scratch[which];
+    MsmScratch& S = *X->msm_scratch[0];
     WS_HIP_CHECK(S.keys.reserve(total * 4));
     WS_HIP_CHECK(S.vals.reserve(total * 4));
     WS_HIP_CHECK(S.keys_out.reserve(total * 4));
     WS_HIP_CHECK(S.vals_out.reserve(total * 4));
     WS_HIP_CHECK(S.bstart.reserve((size_t)nbuckets * 4));
     WS_HIP_CHECK(S.bend.reserve((size_t)nbuckets * 4));
-    WS_HIP_CHECK(S.buckets.reserve((size_t)nbuckets * sizeof(Pt)));
     WS_HIP_CHECK(S.counters.reserve(4096));
-    WS_HIP_CHECK(S.tasks.reserve((size_t)hot_cap * sizeof(Task)));
-    WS_HIP_CHECK(S.multi.reserve((size_t)hot_cap * sizeof(MultiBucket)));
-    WS_HIP_CHECK(S.partials.reserve((size_t)hot_cap * sizeof(Pt)));
-    WS_HIP_CHECK(S.chunkS.reserve((size_t)W * J * sizeof(Pt)));
-    WS_HIP_CHECK(S.chunkA.reserve((size_t)W * J * sizeof(Pt)));
-    WS_HIP_CHECK(S.sums.reserve((size_t)W * nsum * sizeof(Pt)));
+    WS_HIP_CHECK(S.tasks.reserve((size_t)I.hot_cap * sizeof(Task)));
+    WS_HIP_CHECK(S.multi.reserve((size_t)I.hot_cap * sizeof(MultiBucket)));
 
     KernelTimer& T = X->timer;
-    if (C::Field::kInternalDomain && !prepared) {
-        WS_HIP_CHECK(S.points_conv.reserve((size_t)n * sizeof(typename C::AffP)));
-        T.begin("msm_convert_points", s);
-        hipLaunchKernelGGL(msm_convert_points<C>, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s, d_points,
-                           S.points_conv.as<typename C::AffP>(), n);
-        T.end(s);
-        d_points = S.points_conv.as<typename C::AffP>();
-    }
     T.begin("msm_digits", s);
     hipLaunchKernelGGL(msm_digits, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s, d_scalars, (uint32_t)n, c, W, nbuckets,
                        S.keys.as<uint32_t>(), S.vals.as<uint32_t>());
@@ -412,29 +416,71 @@ static int msm_run(int which, const Fe* d_scalars, const typename H::Aff* d_poin
     hipLaunchKernelGGL(msm_plan_hist, dim3(ceil_div_u64(nbuckets, 256)), dim3(256), 0, s, S.bstart.as<uint32_t>(),
                        S.bend.as<uint32_t>(), nbuckets, lmax, d_cnt + 16);
     hipLaunchKernelGGL(msm_plan_offsets, dim3(1), dim3(64), 0, s, d_cnt + 16, d_cnt + 272, d_cnt);
-    hipLaunchKernelGGL(msm_plan_emit<C>, dim3(ceil_div_u64(nbuckets, 256)), dim3(256), 0, s, S.bstart.as<uint32_t>(),
+    hipLaunchKernelGGL(msm_plan_emit, dim3(ceil_div_u64(nbuckets, 256)), dim3(256), 0, s, S.bstart.as<uint32_t>(),
                        S.bend.as<uint32_t>(), nbuckets, lmax, d_cnt + 272, S.tasks.as<Task>(), d_cnt,
-                       S.multi.as<MultiBucket>(), S.buckets.as<Pt>());
+                       S.multi.as<MultiBucket>());
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
     uint32_t cnt[4] = {0, 0, 0, 0};
     WS_HIP_CHECK(hipMemcpyAsync(cnt, S.counters.p, sizeof cnt, hipMemcpyDeviceToHost, s));
     WS_HIP_CHECK(hipStreamSynchronize(s));
-    const uint32_t ntasks = cnt[3], nmulti = cnt[1];
-    if (ntasks > hot_cap || cnt[0] > hot_cap) { set_last_error("msm: task list overflow"); return WS_ERR_HIP; }
+    I.ntasks = cnt[3];
+    I.nmulti = cnt[1];
+    if (I.ntasks > I.hot_cap || cnt[0] > I.hot_cap) { set_last_error("msm: task list overflow"); return WS_ERR_HIP; }
+    I.valid = true;
+    return WS_OK;
+}
 
-    if (ntasks) {
-        T.begin(which ? "msm_accumulate_g2" : "msm_accumulate_g1", s);
-        hipLaunchKernelGGL(msm_accumulate<C>, dim3(ceil_div_u64(ntasks, 256)), dim3(256), 0, s, d_points,
-                           S.vals_out.as<uint32_t>(), S.tasks.as<Task>(), ntasks, S.buckets.as<Pt>(), S.partials.as<Pt>());
+// ---- phase 2: bucket accumulation and reduction for one point set, against the current plan ----
+// C = device curve (arithmetic of the kernels), H = host curve (reference-format results, host tail).
+// `prepared`: d_points are already in C's internal domain (msm_prepare_points).
+template <class C, class H>
+static int msm_exec(int which, const typename H::Aff* d_points_ref, bool prepared, typename H::Pt* out_host, hipStream_t s) {
+    typedef typename C::PtP Pt;      // packed accumulator in global memory (same bytes as H::Pt)
+    static_assert(sizeof(typename C::PtP) == sizeof(typename H::Pt) && sizeof(typename C::AffP) == sizeof(typename H::Aff), "layouts");
+    Context* X = ctx();
+    if (!X) return WS_ERR_NOINIT;
+    if (!s) s = X->stream;
+    const MsmPlanInfo& I = plan_bufs(X)->info;
+    if (!I.valid) { set_last_error("msm: no plan"); return WS_ERR_ARG; }
+    if (I.n == 0) { *out_host = H::infinity(); return WS_OK; }   // multiexp with n=0 leaves pr unchanged
+    if (!d_points_ref || !out_host) return WS_ERR_ARG;
+    const typename C::AffP* d_points = reinterpret_cast<const typename C::AffP*>(d_points_ref);
+    const uint64_t n = I.n;
+    const uint32_t c = I.c, W = I.W, nbuckets = I.nbuckets, m = I.m, J = I.J, logJ = I.logJ, nsum = I.nsum;
+    const uint32_t ntasks = I.ntasks, nmulti = I.nmulti;
+
+    MsmScratch& PS = *X->msm_scratch[0];        // plan buffers
+    MsmScratch& S = *X->msm_scratch[which];     // this curve's accumulation buffers
+    WS_HIP_CHECK(S.buckets.reserve((size_t)nbuckets * sizeof(Pt)));
+    WS_HIP_CHECK(S.partials.reserve((size_t)I.hot_cap * sizeof(Pt)));
+    WS_HIP_CHECK(S.chunkS.reserve((size_t)W * J * sizeof(Pt)));
+    WS_HIP_CHECK(S.chunkA.reserve((size_t)W * J * sizeof(Pt)));
+    WS_HIP_CHECK(S.sums.reserve((size_t)W * nsum * sizeof(Pt)));
+
+    KernelTimer& T = X->timer;
+    if (C::Field::kInternalDomain && !prepared) {
+        WS_HIP_CHECK(S.points_conv.reserve((size_t)n * sizeof(typename C::AffP)));
+        T.begin("msm_convert_points", s);
+        hipLaunchKernelGGL(msm_convert_points<C>, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s, d_points,
+                           S.points_conv.as<typename C::AffP>(), n);
         T.end(s);
-        WS_HIP_CHECK(hipGetLastError());
+        d_points = S.points_conv.as<typename C::AffP>();
     }
+    T.begin(which ? "msm_accumulate_g2" : "msm_accumulate_g1", s);
+    hipLaunchKernelGGL(msm_clear_empty<C>, dim3(ceil_div_u64(nbuckets, 256)), dim3(256), 0, s, PS.bstart.as<uint32_t>(),
+                       PS.bend.as<uint32_t>(), nbuckets, S.buckets.as<Pt>());
+    if (ntasks) {
+        hipLaunchKernelGGL(msm_accumulate<C>, dim3(ceil_div_u64(ntasks, 256)), dim3(256), 0, s, d_points,
+                           PS.vals_out.as<uint32_t>(), PS.tasks.as<Task>(), ntasks, S.buckets.as<Pt>(), S.partials.as<Pt>());
+    }
+    T.end(s);
+    WS_HIP_CHECK(hipGetLastError());
     if (nmulti) {
         T.begin("msm_combine", s);
         hipLaunchKernelGGL(msm_combine_small<C>, dim3(ceil_div_u64(nmulti, 256)), dim3(256), 0, s,
-                           S.multi.as<MultiBucket>(), nmulti, S.partials.as<Pt>(), S.buckets.as<Pt>());
-        hipLaunchKernelGGL(msm_combine_wave<C>, dim3(nmulti), dim3(64), 0, s, S.multi.as<MultiBucket>(), nmulti,
+                           PS.multi.as<MultiBucket>(), nmulti, S.partials.as<Pt>(), S.buckets.as<Pt>());
+        hipLaunchKernelGGL(msm_combine_wave<C>, dim3(nmulti), dim3(64), 0, s, PS.multi.as<MultiBucket>(), nmulti,
                            S.partials.as<Pt>(), S.buckets.as<Pt>());
         T.end(s);
         WS_HIP_CHECK(hipGetLastError());
@@ -480,6 +526,19 @@ static int msm_run(int which, const Fe* d_scalars, const typename H::Aff* d_poin
     return WS_OK;
 }
 
+int msm_g1_exec_xyzz(const Affine<Fq>* d_points, XYZZ<Fq>* out_host, hipStream_t s, bool prepared) {
+    Context* X = ctx();
+    if (!X) return WS_ERR_NOINIT;
+    if (msm_uses_field29()) return msm_exec<G1R29, G1>(0, d_points, prepared, out_host, s);
+    return msm_exec<G1, G1>(0, d_points, prepared, out_host, s);
+}
+int msm_g2_exec_xyzz(const Affine<Fq2>* d_points, XYZZ<Fq2>* out_host, hipStream_t s, bool prepared) {
+    Context* X = ctx();
+    if (!X) return WS_ERR_NOINIT;
+    if (msm_uses_field29()) return msm_exec<G2R29, G2>(1, d_points, prepared, out_host, s);
+    return msm_exec<G2, G2>(1, d_points, prepared, out_host, s);
+}
+
 // in-place conversion of a resident point array (the proving key's sections) to the device field's
 // internal domain, so that proofs skip the per-MSM conversion pass
 int msm_prepare_points(int which, void* d_points, uint64_t n, hipStream_t s) {
@@ -500,13 +559,23 @@ int msm_prepare_points(int which, void* d_points, uint64_t n, hipStream_t s) {
 
 int msm_g1_dev_xyzz(const Fe* d_scalars, const Affine<Fq>* d_points, uint64_t n, XYZZ<Fq>* out_host, hipStream_t s,
                     bool prepared) {
-    if (msm_uses_field29()) return msm_run<G1R29, G1>(0, d_scalars, d_points, n, prepared, out_host, s);
-    return msm_run<G1, G1>(0, d_scalars, d_points, n, prepared, out_host, s);
+    Context* X = ctx();
+    if (!X) return WS_ERR_NOINIT;
+    if (n && !d_points) return WS_ERR_ARG;
+    std::lock_guard<std::mutex> lk(X->mu);   // plan + scratch are shared: one MSM at a time
+    int rc = msm_plan_dev(d_scalars, n, s);
+    if (rc) return rc;
+    return msm_g1_exec_xyzz(d_points, out_host, s, prepared);
 }
 int msm_g2_dev_xyzz(const Fe* d_scalars, const Affine<Fq2>* d_points, uint64_t n, XYZZ<Fq2>* out_host, hipStream_t s,
                     bool prepared) {
-    if (msm_uses_field29()) return msm_run<G2R29, G2>(1, d_scalars, d_points, n, prepared, out_host, s);
-    return msm_run<G2, G2>(1, d_scalars, d_points, n, prepared, out_host, s);
+    Context* X = ctx();
+    if (!X) return WS_ERR_NOINIT;
+    if (n && !d_points) return WS_ERR_ARG;
+    std::lock_guard<std::mutex> lk(X->mu);
+    int rc = msm_plan_dev(d_scalars, n, s);
+    if (rc) return rc;
+    return msm_g2_exec_xyzz(d_points, out_host, s, prepared);
 }
 int msm_g1_dev(const Fe* d_scalars, const Affine<Fq>* d_points, uint64_t n, Jac<Fq>* out_host, hipStream_t s) {
     XYZZ<Fq> r;

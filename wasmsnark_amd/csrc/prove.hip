@@ -61,6 +61,15 @@ int pkey_load(const uint8_t* buf, size_t len, ProvingKey** out) {
         {&K->pointsA, pA, (uint64_t)nv * 64}, {&K->pointsB1, pB1, (uint64_t)nv * 64}, {&K->pointsB2, pB2, (uint64_t)nv * 128},
         {&K->pointsC, pC, nC * 64}, {&K->pointsH, pH, (uint64_t)dom * 64}};
     for (auto& sc : secs) {
+        if (sc.d == &K->pointsC) {
+            // C holds points for signals nPublic+1.. only (src/bn128.js:620 slices the scalars instead).
+            // Resident copy: padded in front with nPublic+1 points at infinity (x == 0), so that the C sum
+            // uses the SAME scalar vector -- and the same digit/sort plan -- as A, B1 and B2.
+            WS_HIP_CHECK(sc.d->alloc((size_t)nv * 64));
+            WS_HIP_CHECK(hipMemsetAsync(sc.d->p, 0, (size_t)(np + 1) * 64, s));
+            if (sc.bytes) WS_HIP_CHECK(hipMemcpyAsync((uint8_t*)sc.d->p + (size_t)(np + 1) * 64, buf + sc.off, (size_t)sc.bytes, hipMemcpyHostToDevice, s));
+            continue;
+        }
         WS_HIP_CHECK(sc.d->alloc((size_t)sc.bytes));
         if (sc.bytes) WS_HIP_CHECK(hipMemcpyAsync(sc.d->p, buf + sc.off, (size_t)sc.bytes, hipMemcpyHostToDevice, s));
     }
@@ -68,7 +77,7 @@ int pkey_load(const uint8_t* buf, size_t len, ProvingKey** out) {
     if ((rc = msm_prepare_points(0, K->pointsA.p, nv, s))) return rc;
     if ((rc = msm_prepare_points(0, K->pointsB1.p, nv, s))) return rc;
     if ((rc = msm_prepare_points(1, K->pointsB2.p, nv, s))) return rc;
-    if ((rc = msm_prepare_points(0, K->pointsC.p, nC, s))) return rc;
+    if ((rc = msm_prepare_points(0, K->pointsC.p, nv, s))) return rc;
     if ((rc = msm_prepare_points(0, K->pointsH.p, dom, s))) return rc;
     WS_HIP_CHECK(K->witness.alloc((size_t)nv * 32));
     WS_HIP_CHECK(K->h.alloc((size_t)dom * 32));
@@ -132,11 +141,17 @@ int groth16_prove(ProvingKey* K, const Fe* d_witness, const uint8_t* r32, const 
     if ((rc = calc_h_dev(d_witness, nv, K->polsA, K->polsB, dom, d_h, s))) return rc;
     XYZZ<Fq> sA, sB1, sC, sH;
     XYZZ<Fq2> sB2;
-    if ((rc = msm_g1_dev_xyzz(d_h, K->pointsH.as<Affine<Fq>>(), dom, &sH, s, true))) return rc;
-    if ((rc = msm_g1_dev_xyzz(d_witness, K->pointsA.as<Affine<Fq>>(), nv, &sA, s, true))) return rc;              // :617
-    if ((rc = msm_g1_dev_xyzz(d_witness, K->pointsB1.as<Affine<Fq>>(), nv, &sB1, s, true))) return rc;            // :618
-    if ((rc = msm_g2_dev_xyzz(d_witness, K->pointsB2.as<Affine<Fq2>>(), nv, &sB2, s, true))) return rc;           // :619
-    if ((rc = msm_g1_dev_xyzz(d_witness + (np + 1), K->pointsC.as<Affine<Fq>>(), (uint64_t)nv - np - 1, &sC, s, true))) return rc;  // :620
+    {
+        std::lock_guard<std::mutex> lk(C->mu);   // the digit/sort plan and the MSM scratch are per context
+        if ((rc = msm_plan_dev(d_h, dom, s))) return rc;
+        if ((rc = msm_g1_exec_xyzz(K->pointsH.as<Affine<Fq>>(), &sH, s, true))) return rc;                 // :614
+        // one plan for the four sums whose scalars are the witness (:617-620)
+        if ((rc = msm_plan_dev(d_witness, nv, s))) return rc;
+        if ((rc = msm_g1_exec_xyzz(K->pointsA.as<Affine<Fq>>(), &sA, s, true))) return rc;                 // :617
+        if ((rc = msm_g1_exec_xyzz(K->pointsB1.as<Affine<Fq>>(), &sB1, s, true))) return rc;               // :618
+        if ((rc = msm_g2_exec_xyzz(K->pointsB2.as<Affine<Fq2>>(), &sB2, s, true))) return rc;              // :619
+        if ((rc = msm_g1_exec_xyzz(K->pointsC.as<Affine<Fq>>(), &sC, s, true))) return rc;                 // :620 (padded)
+    }
 
     // r, s are raw 256-bit values (not reduced, src/bn128.js:642-661); every point here has prime
     // order r, so k*P == (k mod r)*P and (r*s)*P == ((r mod r)(s mod r) mod r)*P  (:700-702)
