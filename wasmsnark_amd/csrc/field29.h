@@ -139,6 +139,14 @@ struct Field29 {
         return cond_sub_2p(s);
     }
     WS_HD static F29 dbl(const F29& a) { return add(a, a); }
+    // a + b WITHOUT carry propagation or reduction: limbs < 2^30, value < 4p.  Only valid as a direct
+    // operand of mul/sqr (column sums stay < 9*2^60 + 9*2^58 < 2^64; output < p(1 + 16p/2^261) < 2p).
+    WS_HD static F29 add_lazy(const F29& a, const F29& b) {
+        F29 s;
+#pragma unroll
+        for (int i = 0; i < 9; i++) s.v[i] = a.v[i] + b.v[i];
+        return s;
+    }
     WS_HD static F29 sub(const F29& a, const F29& b) {
         // d = a - b + 2p in (0, 4p), then one conditional subtraction of 2p
         F29 d;

@@ -39,13 +39,13 @@ struct Fp2T {
     WS_HD static El mul(const El& a, const El& b) {
         BE A = B::mul(a.c0, b.c0);
         BE Bv = B::mul(a.c1, b.c1);
-        BE C = B::mul(B::add(a.c0, a.c1), B::add(b.c0, b.c1));
+        BE C = B::mul(B::add_lazy(a.c0, a.c1), B::add_lazy(b.c0, b.c1));   // sums feed a product only
         return El{B::sub(A, Bv), B::sub(C, B::add(A, Bv))};
     }
     // complex squaring, 2 base-field products (build_f2m.js:186-227)
     WS_HD static El sqr(const El& a) {
         BE AB = B::mul(a.c0, a.c1);
-        BE t = B::mul(B::add(a.c0, a.c1), B::sub(a.c0, a.c1));
+        BE t = B::mul(B::add_lazy(a.c0, a.c1), B::sub(a.c0, a.c1));
         return El{t, B::dbl(AB)};
     }
     // inverse via the norm (build_f2m.js:353-383)

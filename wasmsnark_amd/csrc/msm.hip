@@ -29,6 +29,9 @@
 
 namespace wsnark {
 
+#ifndef WS_ACC_WAVES
+#define WS_ACC_WAVES 3
+#endif
 static const uint32_t CHUNK = 8;          // buckets per msm_chunks lane
 
 struct MsmScratch {
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256) void msm_clear_empty(const uint32_t* __restric
 
 // 4. one lane per task: mixed additions of the task's points
 template <class C>
-__global__ __launch_bounds__(256) void msm_accumulate(const typename C::AffP* __restrict__ points,
+__global__ __launch_bounds__(256, (sizeof(typename C::PtP) > 128 ? 1 : WS_ACC_WAVES)) void msm_accumulate(const typename C::AffP* __restrict__ points,
                                                         const uint32_t* __restrict__ vals,
                                                         const Task* __restrict__ tasks, uint32_t ntasks,
                                                         typename C::PtP* __restrict__ buckets,
@@ -372,7 +375,10 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
     I.J = I.NB / I.m;
     while ((1u << I.logJ) < I.J) I.logJ++;
     I.nsum = I.logJ + 1;
-    I.lmax = (uint32_t)(2 * ((n + I.NB - 1) / I.NB));
+    // task length cap: a multiple of the mean bucket load (default 2x); WSNARK_MSM_LMAX_X4 = multiplier * 4 for tuning
+    uint32_t mult4 = 8;
+    if (const char* e = getenv("WSNARK_MSM_LMAX_X4")) { int v = atoi(e); if (v >= 1 && v <= 64) mult4 = (uint32_t)v; }
+    I.lmax = (uint32_t)((mult4 * ((n + I.NB - 1) / I.NB) + 3) / 4);
     if (I.lmax < 32) I.lmax = 32;
     I.hot_cap = (uint32_t)(total / I.lmax) + I.nbuckets + 16;
     const uint32_t c = I.c, W = I.W, nbuckets = I.nbuckets, lmax = I.lmax;
