@@ -236,3 +236,19 @@ def test_prove_small_vs_oracle(bn, orc):
     wit = synth.witness_bin(circ)
     r, s = os.urandom(32), os.urandom(32)
     assert bn.groth16GenProof(wit, pkey, r=r, s=s) == orc.groth16_prove(wit, pkey, r, s, workers=8)
+
+
+def test_c1_example_witness_vs_reference_proof(bn, orc):
+    """BASELINE config 1: the reference's example witness (66 232 signals, real circuit value
+    distribution: zeros, ones, small values) on a seeded pseudo-key; expected proof = what the
+    REFERENCE prover (Node + WASM) produced for the same bytes (tests/gen_golden_c1.py)."""
+    import hashlib
+    from wasmsnark_amd import synth
+    g = load_golden("c1_example.json")
+    wit = open(os.path.join(GOLDEN, "example_witness.bin"), "rb").read()
+    pkey = synth.pseudo_key(g["n_vars"], g["n_public"], g["domain"], g["key_seed"], bn.mul_base)
+    assert hashlib.sha256(pkey).hexdigest() == g["pkey_sha256"]          # same key bytes as the reference saw
+    r, s = H(g["r"]), H(g["s"])
+    key = bn.load_key(pkey)
+    assert bn.groth16GenProof(wit, key, r=r, s=s) == g["proof"]
+    assert orc.groth16_prove(wit, pkey, r, s, workers=32) == g["proof"]  # and the oracle agrees at this size too

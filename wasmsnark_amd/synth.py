@@ -228,3 +228,45 @@ def expected_proof(circ, S, r32, s32, mul_base):
     pa, pc = p1(g1[:64]), p1(g1[64:128])
     pb = [[dec(g2[0:32]), dec(g2[32:64])], [dec(g2[64:96]), dec(g2[96:128])], ["1", "0"]]
     return {"pi_a": pa, "pi_b": pb, "pi_c": pc}
+
+
+def pseudo_key(n_vars, n_public, domain, seed, mul_base):
+    """A well-formed but NOT circuit-valid proving key with the given header: every point is
+    k * G for seeded pseudo-random k, polsA/polsB have one pseudo-random coefficient per signal.
+    groth16GenProof is a pure function of (witness, key, r, s), so such a key is enough to compare
+    provers bit for bit on a real witness whose proving key is not available (BASELINE config 1:
+    the reference's example/bn128/witness.bin)."""
+    rnd = random.Random(seed)
+    nC = n_vars - n_public - 1
+    ks1 = [rnd.randrange(1, R) for _ in range(3 + 2 * n_vars + nC + domain)]
+    ks2 = [rnd.randrange(1, R) for _ in range(2 + n_vars)]
+    # a few points at infinity, as real keys have for signals absent from B (SURVEY.md fact 6)
+    for i in range(0, n_vars, 97):
+        ks1[3 + n_vars + i] = 0
+        ks2[2 + i] = 0
+    g1 = mul_base(1, b"".join(le32(k) for k in ks1))
+    g2 = mul_base(2, b"".join(le32(k) for k in ks2))
+
+    def pols():
+        out = bytearray()
+        for _ in range(n_vars):
+            out += struct.pack("<I", 1) + struct.pack("<I", rnd.randrange(domain)) + le32(rnd.randrange(R))
+        return bytes(out)
+
+    polsA, polsB = pols(), pols()
+    fixed = g1[:192] + g2[:256]
+    o = 3
+    ptsA = g1[64 * o:64 * (o + n_vars)]; o += n_vars
+    ptsB1 = g1[64 * o:64 * (o + n_vars)]; o += n_vars
+    ptsC = g1[64 * o:64 * (o + nC)]; o += nC
+    ptsH = g1[64 * o:64 * (o + domain)]
+    ptsB2 = g2[256:256 + 128 * n_vars]
+    pPolsA = 40 + len(fixed)
+    pPolsB = pPolsA + len(polsA)
+    pA = pPolsB + len(polsB)
+    pB1 = pA + len(ptsA)
+    pB2 = pB1 + len(ptsB1)
+    pC = pB2 + len(ptsB2)
+    pH = pC + len(ptsC)
+    header = struct.pack("<10I", n_vars, n_public, domain, pPolsA, pPolsB, pA, pB1, pB2, pC, pH)
+    return header + fixed + polsA + polsB + ptsA + ptsB1 + ptsB2 + ptsC + ptsH
