@@ -69,6 +69,13 @@ int wsnark_g2_msm_dev(const void* d_scalars, const void* d_points_affine, uint64
 int wsnark_g1_sum(const void* jac_points, uint64_t count, void* out96);
 int wsnark_g2_sum(const void* jac_points, uint64_t count, void* out192);
 
+/* Multi-GPU alternative to splitting the pairs: every rank is given ALL pairs and computes only the
+ * Pippenger windows w with w % world == rank; its MSM result is then a partial sum already scaled by
+ * 2^(c*w), so the partials of all ranks combine by plain EC addition (all_gather + wsnark_g*_sum).
+ * Applies to every MSM issued afterwards by this process (including those inside
+ * wsnark_groth16_prove).  (rank 0, world 1) restores the default. */
+int wsnark_set_window_shard(uint32_t rank, uint32_t world);
+
 /* fft_fft / fft_ifft (src/build_fft.js:159-221), in place on n Montgomery Fr elements.
  * n must be a power of two <= 2^28 (the reference traps otherwise, :137-154);
  * inverse with n == 1 is rejected (the reference never returns, :575-583). */

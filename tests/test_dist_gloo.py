@@ -30,6 +30,18 @@ for g, n in ((1, 45), (2, 21)):
     full = wd.sharded_msm(bn, g, part)
     want = orc.g_affine(g, orc.multiexp(g, "multiexp", sc, pts, n))
     assert full == want, (g, rank)
+# north-star variant: every rank sees all pairs, owns the windows w % world == rank
+bn.set_window_shard(rank, world)
+for g, n in ((1, 45), (2, 21)):
+    rnd2 = random.Random(7 + g)
+    ks = b"".join(rnd2.randrange(1, orc.R).to_bytes(32, "little") for _ in range(n))
+    pts = bn.mul_base(g, ks)
+    sc = b"".join(rnd2.randrange(1 << 256).to_bytes(32, "little") for _ in range(n))
+    part = (bn.g1_multiexp if g == 1 else bn.g2_multiexp)(sc, pts)
+    full = wd.sharded_msm(bn, g, part)
+    want = orc.g_affine(g, orc.multiexp(g, "multiexp", sc, pts, n))
+    assert full == want, ("windows", g, rank)
+bn.set_window_shard(0, 1)
 dist.barrier()
 open(os.path.join(os.environ["WS_OUT"], "rank%d.ok" % rank), "w").write("ok")
 '''
@@ -53,3 +65,25 @@ def test_shard_bounds():
     # floor(n/W) each, remainder to the last; n < W gives the first W-1 workers nothing
     assert [shard_bounds(10, 4, r) for r in range(4)] == [(0, 2), (2, 4), (4, 6), (6, 10)]
     assert [shard_bounds(3, 8, r) for r in range(8)][-1] == (0, 3)
+
+
+def test_window_shards_sum_to_full_msm(orc):
+    """single process: the partial sums of the window shards of any world size add up to the MSM"""
+    import random
+    from emul_util import emul_bn128
+    bn = emul_bn128()
+    rnd = random.Random(99)
+    n = 70
+    pts = bn.mul_base(1, b"".join(rnd.randrange(1, orc.R).to_bytes(32, "little") for _ in range(n)))
+    sc = b"".join(rnd.randrange(1 << 256).to_bytes(32, "little") for _ in range(n))
+    want = orc.g_affine(1, orc.multiexp(1, "multiexp2", sc, pts, n))
+    try:
+        for world in (2, 3, 8, 70):
+            parts = b""
+            for rank in range(world):
+                bn.set_window_shard(rank, world)
+                parts += bn.g1_multiexp(sc, pts)
+            assert bn.g1_sum(parts) == want, world
+    finally:
+        bn.set_window_shard(0, 1)
+    assert bn.g1_multiexp(sc, pts) == want

@@ -16,7 +16,7 @@ ERRORS = {1: "WSNARK_ERR_SIZE", 2: "WSNARK_ERR_FORMAT", 3: "WSNARK_ERR_HIP", 4: 
 SYMBOLS = [
     "wsnark_init", "wsnark_shutdown", "wsnark_last_error", "wsnark_device_info",
     "wsnark_g1_msm", "wsnark_g2_msm", "wsnark_g1_msm_dev", "wsnark_g2_msm_dev",
-    "wsnark_g1_sum", "wsnark_g2_sum",
+    "wsnark_g1_sum", "wsnark_g2_sum", "wsnark_set_window_shard",
     "wsnark_fr_ntt", "wsnark_fr_ntt_dev", "wsnark_fr_to_montgomery", "wsnark_fr_from_montgomery",
     "wsnark_calc_h", "wsnark_pkey_load", "wsnark_pkey_free", "wsnark_pkey_info",
     "wsnark_groth16_prove", "wsnark_groth16_prove_dev",

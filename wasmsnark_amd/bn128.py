@@ -101,6 +101,10 @@ class Bn128:
         self.lib.check(self.lib.c.wsnark_g2_sum(b, n // 192, out))
         return bytes(out)
 
+    def set_window_shard(self, rank, world):
+        """Multi-GPU window sharding (include/wsnark.h: wsnark_set_window_shard)."""
+        self.lib.check(self.lib.c.wsnark_set_window_shard(rank, world))
+
     # --- device-resident variants (pointers from torch tensors / hipMalloc) ---
     def g1_multiexp_dev(self, d_scalars, d_points, n, stream=None):
         out = (C.c_uint8 * 96)()

@@ -86,6 +86,14 @@ int wsnark_g2_msm_dev(const void* d_scalars, const void* d_points, uint64_t n, v
     return WSNARK_OK;
 }
 
+int wsnark_set_window_shard(uint32_t rank, uint32_t world) {
+    REQUIRE_CTX();
+    if (world == 0 || rank >= world) return WSNARK_ERR_ARG;
+    std::lock_guard<std::mutex> lk(C->mu);
+    C->shard_off = rank;
+    C->shard_stride = world;
+    return WSNARK_OK;
+}
 int wsnark_g1_sum(const void* jac_points, uint64_t count, void* out96) {
     if (!out96 || (count && !jac_points)) return WSNARK_ERR_ARG;
     g1_sum_host((const uint8_t*)jac_points, count, (uint8_t*)out96);

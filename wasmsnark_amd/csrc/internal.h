@@ -29,6 +29,7 @@ struct Context {
     int device = 0;
     hipStream_t stream = nullptr;
     int num_cu = 256;
+    uint32_t shard_off = 0, shard_stride = 1;   // MSM window sharding (wsnark_set_window_shard)
     std::mutex mu;
     std::map<int, std::shared_ptr<NttPlan>> ntt_plans;   // by log2(n)
     DevBuf ntt_scratch;

@@ -43,7 +43,10 @@ struct MsmScratch {
 // ---------------------------------------------------------------------------
 // 1. digits
 // ---------------------------------------------------------------------------
+// (w_off, w_stride): this process owns windows w_off, w_off + w_stride, ... (multi-GPU window sharding;
+// 0, 1 = all windows).  Carries run through every window, only the owned digits are emitted.
 __global__ __launch_bounds__(256) void msm_digits(const Fe* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t W,
+                                                    uint32_t w_off, uint32_t w_stride,
                                                     uint32_t sentinel, uint32_t* __restrict__ keys,
                                                     uint32_t* __restrict__ vals) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(256) void msm_digits(const Fe* __restrict__ scalars
     // points have prime order r, so reduce first; then s < 2^254 and the top window cannot carry.
     Fe s = Fr::reduce_full(scalars[i]);
     const uint32_t NB = 1u << (c - 1);
-    uint32_t carry = 0;
+    uint32_t carry = 0, k = 0;
     for (uint32_t w = 0; w < W; w++) {
         const uint32_t bit = w * c;
         const uint32_t limb = bit >> 6, off = bit & 63;
@@ -61,9 +64,12 @@ __global__ __launch_bounds__(256) void msm_digits(const Fe* __restrict__ scalars
         uint32_t d = (uint32_t)(v & ((1u << c) - 1)) + carry;
         uint32_t neg = 0;
         if (d > NB) { d = (1u << c) - d; neg = 1; carry = 1; } else carry = 0;
-        const uint64_t o = (uint64_t)w * n + i;
-        keys[o] = d ? (w * NB + d - 1) : sentinel;   // zero digits sort behind every bucket
-        vals[o] = i | (neg << 31);
+        if (w >= w_off && (w - w_off) % w_stride == 0) {
+            const uint64_t o = (uint64_t)k * n + i;
+            keys[o] = d ? (k * NB + d - 1) : sentinel;   // zero digits sort behind every bucket
+            vals[o] = i | (neg << 31);
+            k++;
+        }
     }
 }
 
@@ -341,6 +347,7 @@ bool msm_uses_field29() {
 struct MsmPlanInfo {
     uint64_t n = 0;
     uint32_t c = 0, W = 0, NB = 0, nbuckets = 0, m = 0, J = 0, logJ = 0, nsum = 0, lmax = 0, hot_cap = 0;
+    uint32_t Wall = 0, w_off = 0, w_stride = 1;   // W = owned windows; Wall = windows of the whole scalar
     uint32_t ntasks = 0, nmulti = 0;
     bool valid = false;
 };
@@ -366,7 +373,11 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
     if (n > ((uint64_t)1 << 28)) return WS_ERR_SIZE;
     I.n = n;
     I.c = pick_window(n);
-    I.W = (255 + I.c - 1) / I.c;
+    I.Wall = (255 + I.c - 1) / I.c;
+    I.w_off = X->shard_off;
+    I.w_stride = X->shard_stride ? X->shard_stride : 1;
+    I.W = I.w_off < I.Wall ? (I.Wall - I.w_off + I.w_stride - 1) / I.w_stride : 0;
+    if (I.W == 0) { I.n = 0; I.valid = true; return WS_OK; }   // this rank owns no window: partial = infinity
     I.NB = 1u << (I.c - 1);
     I.nbuckets = I.W * I.NB;
     const uint64_t total = n * I.W;
@@ -396,8 +407,8 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
 
     KernelTimer& T = X->timer;
     T.begin("msm_digits", s);
-    hipLaunchKernelGGL(msm_digits, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s, d_scalars, (uint32_t)n, c, W, nbuckets,
-                       S.keys.as<uint32_t>(), S.vals.as<uint32_t>());
+    hipLaunchKernelGGL(msm_digits, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s, d_scalars, (uint32_t)n, c, I.Wall,
+                       I.w_off, I.w_stride, nbuckets, S.keys.as<uint32_t>(), S.vals.as<uint32_t>());
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
 
@@ -516,8 +527,10 @@ static int msm_exec(int which, const typename H::Aff* d_points_ref, bool prepare
     uint32_t logm = 0;
     while ((1u << logm) < m) logm++;
     HPt acc = H::infinity();
-    for (int w = (int)W - 1; w >= 0; w--) {
+    for (int wg = (int)I.Wall - 1; wg >= 0; wg--) {      // global window index; rows exist for the owned ones
         for (uint32_t k = 0; k < c; k++) acc = H::dbl(acc);
+        if ((uint32_t)wg < I.w_off || ((uint32_t)wg - I.w_off) % I.w_stride) continue;
+        const uint32_t w = ((uint32_t)wg - I.w_off) / I.w_stride;
         const HPt* row = &sums[(size_t)w * nsum];
         HPt u = H::infinity();
         for (int q = (int)logJ - 1; q >= 0; q--) {

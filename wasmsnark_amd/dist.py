@@ -7,6 +7,11 @@ over workers, then gather + serial EC sum of the 96/192-byte Jacobian partials o
 all_gather of 96 (G1) or 192 (G2) bytes per rank.  RCCL has no elliptic-curve reduction operator,
 so the 'all-reduce' of partial sums is all_gather + a local W-way EC sum on every rank
 (wsnark_g1_sum / wsnark_g2_sum), which is bit-identical on all ranks.
+
+Alternative (the north star's wording): `bn.set_window_shard(rank, world)` makes every rank compute,
+over ALL pairs, only the Pippenger windows w % world == rank; partials are pre-scaled by 2^(c w) and
+combine with the same all_gather + EC sum.  That divides one MSM's latency by the number of GPUs
+(strong scaling) at the price of every GPU reading all points; `bench.py --shard windows` measures it.
 """
 import torch
 import torch.distributed as dist
