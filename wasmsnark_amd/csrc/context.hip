@@ -9,6 +9,7 @@ static thread_local std::string t_last_error;
 void set_last_error(const std::string& s) { t_last_error = s; }
 const std::string& get_last_error() { return t_last_error; }
 
+void msm_release_pending();
 static Context* g_ctx = nullptr;
 static std::mutex g_ctx_mu;
 static std::string g_devinfo;
@@ -45,6 +46,7 @@ void context_shutdown() {
     g_ctx->timer.reset();
     g_ctx->ntt_plans.clear();
     g_ctx->ntt_scratch.release();
+    msm_release_pending();
     g_ctx->msm_scratch[0].reset();
     g_ctx->msm_scratch[1].reset();
     (void)hipStreamDestroy(g_ctx->stream);

@@ -67,6 +67,13 @@ int msm_g2_dev_xyzz(const Fe* d_scalars, const Affine<Fq2>* d_points, uint64_t n
 int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s);
 int msm_g1_exec_xyzz(const Affine<Fq>* d_points, XYZZ<Fq>* out_host, hipStream_t s, bool prepared);
 int msm_g2_exec_xyzz(const Affine<Fq2>* d_points, XYZZ<Fq2>* out_host, hipStream_t s, bool prepared);
+// asynchronous form of exec: launch enqueues the kernels and the copy of the window sums, finish waits
+// for that copy and runs the serial host tail
+int msm_g1_launch(const Affine<Fq>* d_points, bool prepared, int* slot, hipStream_t s);
+int msm_g2_launch(const Affine<Fq2>* d_points, bool prepared, int* slot, hipStream_t s);
+int msm_g1_finish(int slot, XYZZ<Fq>* out_host);
+int msm_g2_finish(int slot, XYZZ<Fq2>* out_host);
+void msm_abort_pending(hipStream_t s);
 int msm_prepare_points(int which, void* d_points, uint64_t n, hipStream_t s);
 bool msm_uses_field29();
 

@@ -32,6 +32,9 @@ namespace wsnark {
 #ifndef WS_ACC_WAVES
 #define WS_ACC_WAVES 3
 #endif
+#ifndef WS_ACC_WAVES_G2
+#define WS_ACC_WAVES_G2 2
+#endif
 static const uint32_t CHUNK = 8;          // buckets per msm_chunks lane
 
 struct MsmScratch {
@@ -94,6 +97,16 @@ __device__ __forceinline__ typename C::Pt accumulate_range(const typename C::Aff
                                                            const uint32_t* __restrict__ vals, uint32_t s, uint32_t len) {
     typename C::Pt acc = C::infinity();
     if (len == 0) return acc;
+    if (sizeof(typename C::AffP) > 64) {
+        // G2: the accumulator alone is 72 VGPRs; holding a prefetched 128-byte point as well costs a
+        // wavefront of occupancy, so the gather is issued just before use
+        for (uint32_t k = 0; k < len; k++) {
+            const uint32_t v = vals[s + k];
+            const typename C::Aff cur = C::unpack_aff(points[v & 0x7FFFFFFFu]);
+            C::madd(acc, cur, (v >> 31) != 0);
+        }
+        return acc;
+    }
     // software pipeline: the next point's gather is in flight while the current one is added
     uint32_t v = vals[s];
     typename C::AffP nxt = points[v & 0x7FFFFFFFu];
@@ -203,7 +216,7 @@ __global__ __launch_bounds__(256) void msm_clear_empty(const uint32_t* __restric
 
 // 4. one lane per task: mixed additions of the task's points
 template <class C>
-__global__ __launch_bounds__(256, (sizeof(typename C::PtP) > 128 ? 1 : WS_ACC_WAVES)) void msm_accumulate(const typename C::AffP* __restrict__ points,
+__global__ __launch_bounds__(256, (sizeof(typename C::PtP) > 128 ? WS_ACC_WAVES_G2 : WS_ACC_WAVES)) void msm_accumulate(const typename C::AffP* __restrict__ points,
                                                         const uint32_t* __restrict__ vals,
                                                         const Task* __restrict__ tasks, uint32_t ntasks,
                                                         typename C::PtP* __restrict__ buckets,
@@ -448,11 +461,78 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
     return WS_OK;
 }
 
+// ---- asynchronous completion: the last kernel's W x nsum window sums are copied to pinned host memory
+// and an event is recorded; the serial host tail (a 240-doubling Horner chain, faster on a CPU core than
+// on a GPU lane) runs later in msm_finish, so the GPU can already work on the next point set.
+struct MsmPending {
+    bool active = false;
+    int which = 0;
+    MsmPlanInfo info;
+    DevBuf d_sums;
+    void* h_sums = nullptr;
+    size_t h_bytes = 0;
+    hipEvent_t ev = nullptr;
+    void release() {
+        if (h_sums) (void)hipHostFree(h_sums);
+        if (ev) (void)hipEventDestroy(ev);
+        h_sums = nullptr; ev = nullptr; h_bytes = 0; active = false;
+        d_sums.release();
+    }
+};
+static const int kPendingSlots = 8;
+static MsmPending* g_slots = nullptr;   // released by msm_release_pending() at shutdown, while the runtime is alive
+static MsmPending* pending_slots() {
+    if (!g_slots) g_slots = new MsmPending[kPendingSlots];
+    return g_slots;
+}
+// error paths: forget launches whose results will never be collected
+void msm_abort_pending(hipStream_t s) {
+    if (!g_slots) return;
+    (void)hipStreamSynchronize(s);
+    for (int i = 0; i < kPendingSlots; i++) g_slots[i].active = false;
+}
+void msm_release_pending() {
+    if (!g_slots) return;
+    for (int i = 0; i < kPendingSlots; i++) g_slots[i].release();
+    delete[] g_slots;
+    g_slots = nullptr;
+}
+
+template <class H>
+static int msm_finish_t(MsmPending& P, typename H::Pt* out_host) {
+    typedef typename H::Pt HPt;
+    const MsmPlanInfo& I = P.info;
+    if (I.n == 0) { *out_host = H::infinity(); P.active = false; return WS_OK; }
+    WS_HIP_CHECK(hipEventSynchronize(P.ev));
+    const HPt* sums = reinterpret_cast<const HPt*>(P.h_sums);
+    // 8. host tail: result = sum_w 2^(c w) [ A_w + m * sum_q 2^q U_{w,q} ]   (Horner, MSB first)
+    uint32_t logm = 0;
+    while ((1u << logm) < I.m) logm++;
+    HPt acc = H::infinity();
+    for (int wg = (int)I.Wall - 1; wg >= 0; wg--) {      // global window index; rows exist for the owned ones
+        for (uint32_t k = 0; k < I.c; k++) acc = H::dbl(acc);
+        if ((uint32_t)wg < I.w_off || ((uint32_t)wg - I.w_off) % I.w_stride) continue;
+        const uint32_t w = ((uint32_t)wg - I.w_off) / I.w_stride;
+        const HPt* row = &sums[(size_t)w * I.nsum];
+        HPt u = H::infinity();
+        for (int q = (int)I.logJ - 1; q >= 0; q--) {
+            u = H::dbl(u);
+            u = H::add(u, row[q]);
+        }
+        for (uint32_t k = 0; k < logm; k++) u = H::dbl(u);
+        u = H::add(u, row[I.logJ]);
+        acc = H::add(acc, u);
+    }
+    *out_host = acc;
+    P.active = false;
+    return WS_OK;
+}
+
 // ---- phase 2: bucket accumulation and reduction for one point set, against the current plan ----
 // C = device curve (arithmetic of the kernels), H = host curve (reference-format results, host tail).
 // `prepared`: d_points are already in C's internal domain (msm_prepare_points).
 template <class C, class H>
-static int msm_exec(int which, const typename H::Aff* d_points_ref, bool prepared, typename H::Pt* out_host, hipStream_t s) {
+static int msm_launch(int which, const typename H::Aff* d_points_ref, bool prepared, int* slot_out, hipStream_t s) {
     typedef typename C::PtP Pt;      // packed accumulator in global memory (same bytes as H::Pt)
     static_assert(sizeof(typename C::PtP) == sizeof(typename H::Pt) && sizeof(typename C::AffP) == sizeof(typename H::Aff), "layouts");
     Context* X = ctx();
@@ -460,8 +540,16 @@ static int msm_exec(int which, const typename H::Aff* d_points_ref, bool prepare
     if (!s) s = X->stream;
     const MsmPlanInfo& I = plan_bufs(X)->info;
     if (!I.valid) { set_last_error("msm: no plan"); return WS_ERR_ARG; }
-    if (I.n == 0) { *out_host = H::infinity(); return WS_OK; }   // multiexp with n=0 leaves pr unchanged
-    if (!d_points_ref || !out_host) return WS_ERR_ARG;
+    MsmPending* slots = pending_slots();
+    int slot = -1;
+    for (int i = 0; i < kPendingSlots; i++) if (!slots[i].active) { slot = i; break; }
+    if (slot < 0) { set_last_error("msm: too many unfinished launches"); return WS_ERR_ARG; }
+    MsmPending& P = slots[slot];
+    P.which = which;
+    P.info = I;
+    *slot_out = slot;
+    if (I.n == 0) { P.active = true; return WS_OK; }   // multiexp with n=0 leaves pr unchanged
+    if (!d_points_ref) return WS_ERR_ARG;
     const typename C::AffP* d_points = reinterpret_cast<const typename C::AffP*>(d_points_ref);
     const uint64_t n = I.n;
     const uint32_t c = I.c, W = I.W, nbuckets = I.nbuckets, m = I.m, J = I.J, logJ = I.logJ, nsum = I.nsum;
@@ -473,7 +561,15 @@ static int msm_exec(int which, const typename H::Aff* d_points_ref, bool prepare
     WS_HIP_CHECK(S.partials.reserve((size_t)I.hot_cap * sizeof(Pt)));
     WS_HIP_CHECK(S.chunkS.reserve((size_t)W * J * sizeof(Pt)));
     WS_HIP_CHECK(S.chunkA.reserve((size_t)W * J * sizeof(Pt)));
-    WS_HIP_CHECK(S.sums.reserve((size_t)W * nsum * sizeof(Pt)));
+    const size_t sums_bytes = (size_t)W * nsum * sizeof(Pt);
+    WS_HIP_CHECK(P.d_sums.reserve(sums_bytes));
+    if (P.h_bytes < sums_bytes) {
+        if (P.h_sums) (void)hipHostFree(P.h_sums);
+        P.h_sums = nullptr;
+        WS_HIP_CHECK(hipHostMalloc(&P.h_sums, sums_bytes, 0));
+        P.h_bytes = sums_bytes;
+    }
+    if (!P.ev) WS_HIP_CHECK(hipEventCreate(&P.ev));
 
     KernelTimer& T = X->timer;
     if (C::Field::kInternalDomain && !prepared) {
@@ -514,48 +610,44 @@ static int msm_exec(int which, const typename H::Aff* d_points_ref, bool prepare
     while (tthreads < J && tthreads < tmax) tthreads <<= 1;
     T.begin("msm_tree", s);
     hipLaunchKernelGGL(msm_tree<C>, dim3(nsum, W), dim3(tthreads), (size_t)tthreads * sizeof(Pt), s,
-                       S.chunkS.as<Pt>(), S.chunkA.as<Pt>(), J, logJ, S.sums.as<Pt>());
+                       S.chunkS.as<Pt>(), S.chunkA.as<Pt>(), J, logJ, P.d_sums.as<Pt>());
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
-
-    typedef typename H::Pt HPt;
-    std::vector<HPt> sums((size_t)W * nsum);
-    WS_HIP_CHECK(hipMemcpyAsync(sums.data(), S.sums.p, sums.size() * sizeof(HPt), hipMemcpyDeviceToHost, s));
-    WS_HIP_CHECK(hipStreamSynchronize(s));
-
-    // 8. host tail: result = sum_w 2^(c w) [ A_w + m * sum_q 2^q U_{w,q} ]   (Horner, MSB first)
-    uint32_t logm = 0;
-    while ((1u << logm) < m) logm++;
-    HPt acc = H::infinity();
-    for (int wg = (int)I.Wall - 1; wg >= 0; wg--) {      // global window index; rows exist for the owned ones
-        for (uint32_t k = 0; k < c; k++) acc = H::dbl(acc);
-        if ((uint32_t)wg < I.w_off || ((uint32_t)wg - I.w_off) % I.w_stride) continue;
-        const uint32_t w = ((uint32_t)wg - I.w_off) / I.w_stride;
-        const HPt* row = &sums[(size_t)w * nsum];
-        HPt u = H::infinity();
-        for (int q = (int)logJ - 1; q >= 0; q--) {
-            u = H::dbl(u);
-            u = H::add(u, row[q]);
-        }
-        for (uint32_t k = 0; k < logm; k++) u = H::dbl(u);
-        u = H::add(u, row[logJ]);
-        acc = H::add(acc, u);
-    }
-    *out_host = acc;
+    WS_HIP_CHECK(hipMemcpyAsync(P.h_sums, P.d_sums.p, sums_bytes, hipMemcpyDeviceToHost, s));
+    WS_HIP_CHECK(hipEventRecord(P.ev, s));
+    P.active = true;
     return WS_OK;
 }
 
+int msm_g1_launch(const Affine<Fq>* d_points, bool prepared, int* slot, hipStream_t s) {
+    if (!ctx()) return WS_ERR_NOINIT;
+    if (msm_uses_field29()) return msm_launch<G1R29, G1>(0, d_points, prepared, slot, s);
+    return msm_launch<G1, G1>(0, d_points, prepared, slot, s);
+}
+int msm_g2_launch(const Affine<Fq2>* d_points, bool prepared, int* slot, hipStream_t s) {
+    if (!ctx()) return WS_ERR_NOINIT;
+    if (msm_uses_field29()) return msm_launch<G2R29, G2>(1, d_points, prepared, slot, s);
+    return msm_launch<G2, G2>(1, d_points, prepared, slot, s);
+}
+int msm_g1_finish(int slot, XYZZ<Fq>* out_host) {
+    if (slot < 0 || slot >= kPendingSlots || !pending_slots()[slot].active || pending_slots()[slot].which != 0) return WS_ERR_ARG;
+    return msm_finish_t<G1>(pending_slots()[slot], out_host);
+}
+int msm_g2_finish(int slot, XYZZ<Fq2>* out_host) {
+    if (slot < 0 || slot >= kPendingSlots || !pending_slots()[slot].active || pending_slots()[slot].which != 1) return WS_ERR_ARG;
+    return msm_finish_t<G2>(pending_slots()[slot], out_host);
+}
 int msm_g1_exec_xyzz(const Affine<Fq>* d_points, XYZZ<Fq>* out_host, hipStream_t s, bool prepared) {
-    Context* X = ctx();
-    if (!X) return WS_ERR_NOINIT;
-    if (msm_uses_field29()) return msm_exec<G1R29, G1>(0, d_points, prepared, out_host, s);
-    return msm_exec<G1, G1>(0, d_points, prepared, out_host, s);
+    int slot = -1;
+    int rc = msm_g1_launch(d_points, prepared, &slot, s);
+    if (rc) return rc;
+    return msm_g1_finish(slot, out_host);
 }
 int msm_g2_exec_xyzz(const Affine<Fq2>* d_points, XYZZ<Fq2>* out_host, hipStream_t s, bool prepared) {
-    Context* X = ctx();
-    if (!X) return WS_ERR_NOINIT;
-    if (msm_uses_field29()) return msm_exec<G2R29, G2>(1, d_points, prepared, out_host, s);
-    return msm_exec<G2, G2>(1, d_points, prepared, out_host, s);
+    int slot = -1;
+    int rc = msm_g2_launch(d_points, prepared, &slot, s);
+    if (rc) return rc;
+    return msm_g2_finish(slot, out_host);
 }
 
 // in-place conversion of a resident point array (the proving key's sections) to the device field's

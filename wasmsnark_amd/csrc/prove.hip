@@ -8,6 +8,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <future>
+
 #include "internal.h"
 
 namespace wsnark {
@@ -136,23 +138,6 @@ int groth16_prove(ProvingKey* K, const Fe* d_witness, const uint8_t* r32, const 
         if (!s32) s32 = rnd + 32;
     }
     int rc;
-    // CALC_H, then the H MSM over domainSize pairs (src/bn128.js:607-615)
-    Fe* d_h = K->h.as<Fe>();
-    if ((rc = calc_h_dev(d_witness, nv, K->polsA, K->polsB, dom, d_h, s))) return rc;
-    XYZZ<Fq> sA, sB1, sC, sH;
-    XYZZ<Fq2> sB2;
-    {
-        std::lock_guard<std::mutex> lk(C->mu);   // the digit/sort plan and the MSM scratch are per context
-        if ((rc = msm_plan_dev(d_h, dom, s))) return rc;
-        if ((rc = msm_g1_exec_xyzz(K->pointsH.as<Affine<Fq>>(), &sH, s, true))) return rc;                 // :614
-        // one plan for the four sums whose scalars are the witness (:617-620)
-        if ((rc = msm_plan_dev(d_witness, nv, s))) return rc;
-        if ((rc = msm_g1_exec_xyzz(K->pointsA.as<Affine<Fq>>(), &sA, s, true))) return rc;                 // :617
-        if ((rc = msm_g1_exec_xyzz(K->pointsB1.as<Affine<Fq>>(), &sB1, s, true))) return rc;               // :618
-        if ((rc = msm_g2_exec_xyzz(K->pointsB2.as<Affine<Fq2>>(), &sB2, s, true))) return rc;              // :619
-        if ((rc = msm_g1_exec_xyzz(K->pointsC.as<Affine<Fq>>(), &sC, s, true))) return rc;                 // :620 (padded)
-    }
-
     // r, s are raw 256-bit values (not reduced, src/bn128.js:642-661); every point here has prime
     // order r, so k*P == (k mod r)*P and (r*s)*P == ((r mod r)(s mod r) mod r)*P  (:700-702)
     Fe rr, ss;
@@ -164,20 +149,58 @@ int groth16_prove(ProvingKey* K, const Fe* d_witness, const uint8_t* r32, const 
     const uint8_t* rb = reinterpret_cast<const uint8_t*>(&rr);
     const uint8_t* sb = reinterpret_cast<const uint8_t*>(&ss);
     const uint8_t* rsb = reinterpret_cast<const uint8_t*>(&rs);
-
     const G1::Pt alfa1 = G1::from_affine(K->alfa1), beta1 = G1::from_affine(K->beta1), delta1 = G1::from_affine(K->delta1);
     const G2::Pt beta2 = G2::from_affine(K->beta2), delta2 = G2::from_affine(K->delta2);
+    // the scalar multiplications that do not depend on the MSMs run on a host thread while the GPU works
+    struct Pre { G1::Pt r_delta1, s_delta1, rs_delta1; G2::Pt s_delta2; };
+    std::future<Pre> pre = std::async(std::launch::async, [&]() {
+        Pre p;
+        p.r_delta1 = G1::mul_bytes(delta1, rb, 32);
+        p.s_delta1 = G1::mul_bytes(delta1, sb, 32);
+        p.rs_delta1 = G1::mul_bytes(delta1, rsb, 32);
+        p.s_delta2 = G2::mul_bytes(delta2, sb, 32);
+        return p;
+    });
+    struct WaitPre { std::future<Pre>& f; ~WaitPre() { if (f.valid()) f.wait(); } } wait_pre{pre};   // never outlive the captures
+
+    // CALC_H, then the H MSM over domainSize pairs (src/bn128.js:607-615)
+    Fe* d_h = K->h.as<Fe>();
+    if ((rc = calc_h_dev(d_witness, nv, K->polsA, K->polsB, dom, d_h, s))) return rc;
+    XYZZ<Fq> sA, sB1, sC, sH;
+    XYZZ<Fq2> sB2;
+    {
+        std::lock_guard<std::mutex> lk(C->mu);   // the digit/sort plan and the MSM scratch are per context
+        int hH = -1, hA = -1, hB1 = -1, hB2 = -1, hC = -1;
+        struct Abort { hipStream_t s; bool armed; ~Abort() { if (armed) msm_abort_pending(s); } } guard{s, true};
+        if ((rc = msm_plan_dev(d_h, dom, s))) return rc;
+        if ((rc = msm_g1_launch(K->pointsH.as<Affine<Fq>>(), true, &hH, s))) return rc;                    // :614
+        // one plan for the four sums whose scalars are the witness (:617-620); each host tail runs while
+        // the GPU already accumulates the next point set
+        if ((rc = msm_plan_dev(d_witness, nv, s))) return rc;
+        if ((rc = msm_g1_launch(K->pointsA.as<Affine<Fq>>(), true, &hA, s))) return rc;                    // :617
+        if ((rc = msm_g1_finish(hH, &sH))) return rc;
+        if ((rc = msm_g1_launch(K->pointsB1.as<Affine<Fq>>(), true, &hB1, s))) return rc;                  // :618
+        if ((rc = msm_g2_launch(K->pointsB2.as<Affine<Fq2>>(), true, &hB2, s))) return rc;                 // :619
+        if ((rc = msm_g1_launch(K->pointsC.as<Affine<Fq>>(), true, &hC, s))) return rc;                    // :620 (padded)
+        if ((rc = msm_g1_finish(hA, &sA))) return rc;
+        if ((rc = msm_g1_finish(hB1, &sB1))) return rc;
+        if ((rc = msm_g2_finish(hB2, &sB2))) return rc;
+        if ((rc = msm_g1_finish(hC, &sC))) return rc;
+        guard.armed = false;
+    }
+    const Pre pp = pre.get();
+
     // pi_a = sum A + alfa1 + r*delta1                               (:671-673)
-    G1::Pt pi_a = G1::add(G1::add(alfa1, sA), G1::mul_bytes(delta1, rb, 32));
+    G1::Pt pi_a = G1::add(G1::add(alfa1, sA), pp.r_delta1);
     // pi_b = sum B2 + beta2 + s*delta2                              (:676-678)
-    G2::Pt pi_b = G2::add(G2::add(beta2, sB2), G2::mul_bytes(delta2, sb, 32));
+    G2::Pt pi_b = G2::add(G2::add(beta2, sB2), pp.s_delta2);
     // pib1 = sum B1 + beta1 + s*delta1                              (:681-683)
-    G1::Pt pib1 = G1::add(G1::add(beta1, sB1), G1::mul_bytes(delta1, sb, 32));
+    G1::Pt pib1 = G1::add(G1::add(beta1, sB1), pp.s_delta1);
     // pi_c = sum C + sum H + s*pi_a + r*pib1 - (r*s)*delta1         (:687-704)
     G1::Pt pi_c = G1::add(sC, sH);
     pi_c = G1::add(pi_c, G1::mul_bytes(pi_a, sb, 32));
     pi_c = G1::add(pi_c, G1::mul_bytes(pib1, rb, 32));
-    pi_c = G1::add(pi_c, G1::neg(G1::mul_bytes(delta1, rsb, 32)));
+    pi_c = G1::add(pi_c, G1::neg(pp.rs_delta1));
 
     // affine + fromMontgomery (:706-712); infinity prints as (0, 1, 0)
     Jac<Fq> a = G1::to_affine_jac(pi_a), c = G1::to_affine_jac(pi_c);
