@@ -173,6 +173,31 @@ def main():
             del dx
         except Exception as e:  # noqa: BLE001
             extras["ntt_error"] = repr(e)
+        try:
+            # the same MSM with a circuit-like scalar distribution (example-witness
+            # histogram: 6.7 % zeros, 3.1 % ones, 10 % < 2^32, the rest full width): exercises hot buckets
+            u = rng.random(n)
+            sk = sc.copy()
+            sk[u < 0.067] = 0
+            ones = (u >= 0.067) & (u < 0.098)
+            sk[ones] = 0
+            sk[ones, 0] = 1
+            small = (u >= 0.098) & (u < 0.2)
+            sk[small, 4:] = 0
+            d_sk = torch.from_numpy(sk.reshape(-1)).to(dev)
+            torch.cuda.synchronize()
+            bn.g1_multiexp_dev(d_sk.data_ptr(), d_p.data_ptr(), n)
+            bn.lib.c.wsnark_timing_reset(); bn.lib.c.wsnark_timing_enable(1)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                bn.g1_multiexp_dev(d_sk.data_ptr(), d_p.data_ptr(), n)
+            t = (time.perf_counter() - t0) / 5
+            bn.lib.c.wsnark_timing_enable(0)
+            extras["msm_circuit_like_scalars_ms"] = round(t * 1e3, 4)
+            extras["msm_circuit_like_kernel_ms"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in bn.lib.timing_report().items()}
+            del d_sk
+        except Exception as e:  # noqa: BLE001
+            extras["msm_circuit_like_error"] = repr(e)
         if args.prove_log_domain:
             try:
                 from wasmsnark_amd import synth

@@ -218,11 +218,13 @@ __global__ __launch_bounds__(256) void msm_clear_empty(const uint32_t* __restric
 template <class C>
 __global__ __launch_bounds__(256, (sizeof(typename C::PtP) > 128 ? WS_ACC_WAVES_G2 : WS_ACC_WAVES)) void msm_accumulate(const typename C::AffP* __restrict__ points,
                                                         const uint32_t* __restrict__ vals,
-                                                        const Task* __restrict__ tasks, uint32_t ntasks,
+                                                        const Task* __restrict__ tasks,
+                                                        const uint32_t* __restrict__ counters,
                                                         typename C::PtP* __restrict__ buckets,
                                                         typename C::PtP* __restrict__ partials) {
+    // the grid is sized for the worst case; the real task count stays on the device (no host round trip)
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ntasks) return;
+    if (t >= counters[3]) return;
     const Task k = tasks[t];
     const typename C::PtP acc = C::pack_pt(accumulate_range<C>(points, vals, k.start, k.len));
     if (k.dst & PARTIAL_FLAG) partials[k.dst & ~PARTIAL_FLAG] = acc;
@@ -232,39 +234,44 @@ __global__ __launch_bounds__(256, (sizeof(typename C::PtP) > 128 ? WS_ACC_WAVES_
 // 5a. buckets cut into a few tasks: one lane sums the partials
 static const uint32_t WAVE_COMBINE_MIN = 17;
 template <class C>
-__global__ __launch_bounds__(256) void msm_combine_small(const MultiBucket* __restrict__ mbs, uint32_t nmb,
+__global__ __launch_bounds__(256) void msm_combine_small(const MultiBucket* __restrict__ mbs,
+                                                           const uint32_t* __restrict__ counters,
                                                            const typename C::PtP* __restrict__ partials,
                                                            typename C::PtP* __restrict__ buckets) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nmb) return;
-    const MultiBucket h = mbs[i];
-    if (h.ntasks >= WAVE_COMBINE_MIN) return;
-    typename C::Pt acc = C::unpack_pt(partials[h.first_partial]);
-    for (uint32_t k = 1; k < h.ntasks; k++) acc = C::add(acc, C::unpack_pt(partials[h.first_partial + k]));
-    buckets[h.bucket] = C::pack_pt(acc);
+    const uint32_t nmb = counters[1];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nmb; i += gridDim.x * blockDim.x) {
+        const MultiBucket h = mbs[i];
+        if (h.ntasks >= WAVE_COMBINE_MIN) continue;
+        typename C::Pt acc = C::unpack_pt(partials[h.first_partial]);
+        for (uint32_t k = 1; k < h.ntasks; k++) acc = C::add(acc, C::unpack_pt(partials[h.first_partial + k]));
+        buckets[h.bucket] = C::pack_pt(acc);
+    }
 }
 
 // 5b. hot buckets (many tasks): one wavefront per bucket, lanes stride over the partial sums,
 // then an LDS tree folds the 64 lane sums (wavefront segmented reduction)
 template <class C>
-__global__ __launch_bounds__(64) void msm_combine_wave(const MultiBucket* __restrict__ mbs, uint32_t nmb,
+__global__ __launch_bounds__(64) void msm_combine_wave(const MultiBucket* __restrict__ mbs,
+                                                         const uint32_t* __restrict__ counters,
                                                          const typename C::PtP* __restrict__ partials,
                                                          typename C::PtP* __restrict__ buckets) {
     __shared__ typename C::PtP sh[64];
-    const uint32_t hb = blockIdx.x;
-    if (hb >= nmb) return;
-    const MultiBucket h = mbs[hb];
-    if (h.ntasks < WAVE_COMBINE_MIN) return;
+    const uint32_t nmb = counters[1];
     const uint32_t lane = threadIdx.x;
-    typename C::Pt acc = C::infinity();
-    for (uint32_t k = lane; k < h.ntasks; k += 64) acc = C::add(acc, C::unpack_pt(partials[h.first_partial + k]));
-    sh[lane] = C::pack_pt(acc);
-    __syncthreads();
-    for (uint32_t step = 32; step >= 1; step >>= 1) {
-        if (lane < step) sh[lane] = C::pack_pt(C::add(C::unpack_pt(sh[lane]), C::unpack_pt(sh[lane + step])));
+    for (uint32_t hb = blockIdx.x; hb < nmb; hb += gridDim.x) {     // uniform per block
+        const MultiBucket h = mbs[hb];
+        if (h.ntasks < WAVE_COMBINE_MIN) continue;
+        typename C::Pt acc = C::infinity();
+        for (uint32_t k = lane; k < h.ntasks; k += 64) acc = C::add(acc, C::unpack_pt(partials[h.first_partial + k]));
+        sh[lane] = C::pack_pt(acc);
+        __syncthreads();
+        for (uint32_t step = 32; step >= 1; step >>= 1) {
+            if (lane < step) sh[lane] = C::pack_pt(C::add(C::unpack_pt(sh[lane]), C::unpack_pt(sh[lane + step])));
+            __syncthreads();
+        }
+        if (lane == 0) buckets[h.bucket] = sh[0];
         __syncthreads();
     }
-    if (lane == 0) buckets[h.bucket] = sh[0];
 }
 
 // ---------------------------------------------------------------------------
@@ -395,7 +402,9 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
     I.nbuckets = I.W * I.NB;
     const uint64_t total = n * I.W;
     if (total >= ((uint64_t)1 << 32)) return WS_ERR_SIZE;
-    I.m = I.NB < CHUNK ? I.NB : CHUNK;
+    uint32_t chunk = CHUNK;
+    if (const char* e = getenv("WSNARK_MSM_CHUNK")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32) chunk = (uint32_t)v; }
+    I.m = I.NB < chunk ? I.NB : chunk;
     I.J = I.NB / I.m;
     while ((1u << I.logJ) < I.J) I.logJ++;
     I.nsum = I.logJ + 1;
@@ -451,12 +460,10 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
                        S.multi.as<MultiBucket>());
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
-    uint32_t cnt[4] = {0, 0, 0, 0};
-    WS_HIP_CHECK(hipMemcpyAsync(cnt, S.counters.p, sizeof cnt, hipMemcpyDeviceToHost, s));
-    WS_HIP_CHECK(hipStreamSynchronize(s));
-    I.ntasks = cnt[3];
-    I.nmulti = cnt[1];
-    if (I.ntasks > I.hot_cap || cnt[0] > I.hot_cap) { set_last_error("msm: task list overflow"); return WS_ERR_HIP; }
+    // task / partial counts stay on the device (counters[3], [1], [0]); by construction
+    // tasks <= total/lmax + nbuckets <= hot_cap, so the worst-case grids below always cover them
+    I.ntasks = I.hot_cap;
+    I.nmulti = 0;
     I.valid = true;
     return WS_OK;
 }
@@ -553,7 +560,7 @@ static int msm_launch(int which, const typename H::Aff* d_points_ref, bool prepa
     const typename C::AffP* d_points = reinterpret_cast<const typename C::AffP*>(d_points_ref);
     const uint64_t n = I.n;
     const uint32_t c = I.c, W = I.W, nbuckets = I.nbuckets, m = I.m, J = I.J, logJ = I.logJ, nsum = I.nsum;
-    const uint32_t ntasks = I.ntasks, nmulti = I.nmulti;
+    const uint32_t ntasks = I.ntasks;
 
     MsmScratch& PS = *X->msm_scratch[0];        // plan buffers
     MsmScratch& S = *X->msm_scratch[which];     // this curve's accumulation buffers
@@ -583,21 +590,18 @@ static int msm_launch(int which, const typename H::Aff* d_points_ref, bool prepa
     T.begin(which ? "msm_accumulate_g2" : "msm_accumulate_g1", s);
     hipLaunchKernelGGL(msm_clear_empty<C>, dim3(ceil_div_u64(nbuckets, 256)), dim3(256), 0, s, PS.bstart.as<uint32_t>(),
                        PS.bend.as<uint32_t>(), nbuckets, S.buckets.as<Pt>());
-    if (ntasks) {
-        hipLaunchKernelGGL(msm_accumulate<C>, dim3(ceil_div_u64(ntasks, 256)), dim3(256), 0, s, d_points,
-                           PS.vals_out.as<uint32_t>(), PS.tasks.as<Task>(), ntasks, S.buckets.as<Pt>(), S.partials.as<Pt>());
-    }
+    hipLaunchKernelGGL(msm_accumulate<C>, dim3(ceil_div_u64(ntasks, 256)), dim3(256), 0, s, d_points,
+                       PS.vals_out.as<uint32_t>(), PS.tasks.as<Task>(), PS.counters.as<uint32_t>(), S.buckets.as<Pt>(),
+                       S.partials.as<Pt>());
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
-    if (nmulti) {
-        T.begin("msm_combine", s);
-        hipLaunchKernelGGL(msm_combine_small<C>, dim3(ceil_div_u64(nmulti, 256)), dim3(256), 0, s,
-                           PS.multi.as<MultiBucket>(), nmulti, S.partials.as<Pt>(), S.buckets.as<Pt>());
-        hipLaunchKernelGGL(msm_combine_wave<C>, dim3(nmulti), dim3(64), 0, s, PS.multi.as<MultiBucket>(), nmulti,
-                           S.partials.as<Pt>(), S.buckets.as<Pt>());
-        T.end(s);
-        WS_HIP_CHECK(hipGetLastError());
-    }
+    T.begin("msm_combine", s);
+    hipLaunchKernelGGL(msm_combine_small<C>, dim3(256), dim3(256), 0, s, PS.multi.as<MultiBucket>(),
+                       PS.counters.as<uint32_t>(), S.partials.as<Pt>(), S.buckets.as<Pt>());
+    hipLaunchKernelGGL(msm_combine_wave<C>, dim3(2048), dim3(64), 0, s, PS.multi.as<MultiBucket>(),
+                       PS.counters.as<uint32_t>(), S.partials.as<Pt>(), S.buckets.as<Pt>());
+    T.end(s);
+    WS_HIP_CHECK(hipGetLastError());
 
     T.begin("msm_chunks", s);
     hipLaunchKernelGGL(msm_chunks<C>, dim3(ceil_div_u64((uint64_t)W * J, 256)), dim3(256), 0, s, S.buckets.as<Pt>(),
