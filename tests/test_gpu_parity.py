@@ -252,3 +252,22 @@ def test_c1_example_witness_vs_reference_proof(bn, orc):
     key = bn.load_key(pkey)
     assert bn.groth16GenProof(wit, key, r=r, s=s) == g["proof"]
     assert orc.groth16_prove(wit, pkey, r, s, workers=32) == g["proof"]  # and the oracle agrees at this size too
+
+
+def test_window_shards_sum_to_full_msm_on_gpu(bn, orc):
+    # wsnark_set_window_shard: the partial sums over the window shards of any world size add up
+    rnd = random.Random(321)
+    n = 5000
+    pts = bn.mul_base(1, b"".join(rnd.randrange(1, orc.R).to_bytes(32, "little") for _ in range(n)))
+    sc = _skewed_scalars(rnd, n, orc.R)
+    want = orc.g_affine(1, orc.multiexp(1, "workers8", sc, pts, n))
+    try:
+        for world in (2, 8):
+            parts = b""
+            for rank in range(world):
+                bn.set_window_shard(rank, world)
+                parts += bn.g1_multiexp(sc, pts)
+            assert bn.g1_sum(parts) == want, world
+    finally:
+        bn.set_window_shard(0, 1)
+    assert bn.g1_multiexp(sc, pts) == want
