@@ -371,6 +371,83 @@ struct MsmPlanInfo {
     uint32_t ntasks = 0, nmulti = 0;
     bool valid = false;
 };
+// ---- asynchronous completion: the last kernel's W x nsum window sums are copied to pinned host memory
+// and an event is recorded; the serial host tail (a 240-doubling Horner chain, faster on a CPU core than
+// on a GPU lane) runs later in msm_finish, so the GPU can already work on the next point set.
+struct MsmPending {
+    bool active = false;
+    int which = 0;
+    MsmPlanInfo info;
+    DevBuf d_sums;
+    MsmScratch S;                 // this launch's accumulation buffers (buckets, partials, chunk sums)
+    hipStream_t stream = nullptr; // every slot runs on its own stream: the latency-bound reduction kernels of
+                                  // one point set overlap the accumulation of the next
+    void* h_sums = nullptr;
+    size_t h_bytes = 0;
+    hipEvent_t ev = nullptr;
+    void release() {
+        if (h_sums) (void)hipHostFree(h_sums);
+        if (ev) (void)hipEventDestroy(ev);
+        if (stream) (void)hipStreamDestroy(stream);
+        h_sums = nullptr; ev = nullptr; stream = nullptr; h_bytes = 0; active = false;
+        d_sums.release();
+        S.buckets.release(); S.partials.release(); S.chunkS.release(); S.chunkA.release(); S.points_conv.release();
+    }
+};
+static hipEvent_t g_plan_done = nullptr;   // recorded at the end of msm_plan_dev
+static const int kPendingSlots = 8;
+static MsmPending* g_slots = nullptr;   // released by msm_release_pending() at shutdown, while the runtime is alive
+static MsmPending* pending_slots() {
+    if (!g_slots) g_slots = new MsmPending[kPendingSlots];
+    return g_slots;
+}
+// error paths: forget launches whose results will never be collected
+void msm_abort_pending(hipStream_t s) {
+    if (!g_slots) return;
+    (void)hipStreamSynchronize(s);
+    for (int i = 0; i < kPendingSlots; i++) {
+        if (g_slots[i].stream) (void)hipStreamSynchronize(g_slots[i].stream);
+        g_slots[i].active = false;
+    }
+}
+void msm_release_pending() {
+    if (g_plan_done) { (void)hipEventDestroy(g_plan_done); g_plan_done = nullptr; }
+    if (!g_slots) return;
+    for (int i = 0; i < kPendingSlots; i++) g_slots[i].release();
+    delete[] g_slots;
+    g_slots = nullptr;
+}
+
+template <class H>
+static int msm_finish_t(MsmPending& P, typename H::Pt* out_host) {
+    typedef typename H::Pt HPt;
+    const MsmPlanInfo& I = P.info;
+    if (I.n == 0) { *out_host = H::infinity(); P.active = false; return WS_OK; }
+    WS_HIP_CHECK(hipEventSynchronize(P.ev));
+    const HPt* sums = reinterpret_cast<const HPt*>(P.h_sums);
+    // 8. host tail: result = sum_w 2^(c w) [ A_w + m * sum_q 2^q U_{w,q} ]   (Horner, MSB first)
+    uint32_t logm = 0;
+    while ((1u << logm) < I.m) logm++;
+    HPt acc = H::infinity();
+    for (int wg = (int)I.Wall - 1; wg >= 0; wg--) {      // global window index; rows exist for the owned ones
+        for (uint32_t k = 0; k < I.c; k++) acc = H::dbl(acc);
+        if ((uint32_t)wg < I.w_off || ((uint32_t)wg - I.w_off) % I.w_stride) continue;
+        const uint32_t w = ((uint32_t)wg - I.w_off) / I.w_stride;
+        const HPt* row = &sums[(size_t)w * I.nsum];
+        HPt u = H::infinity();
+        for (int q = (int)I.logJ - 1; q >= 0; q--) {
+            u = H::dbl(u);
+            u = H::add(u, row[q]);
+        }
+        for (uint32_t k = 0; k < logm; k++) u = H::dbl(u);
+        u = H::add(u, row[I.logJ]);
+        acc = H::add(acc, u);
+    }
+    *out_host = acc;
+    P.active = false;
+    return WS_OK;
+}
+
 struct MsmPlanBufs {
     MsmScratch S;
     MsmPlanInfo info;
@@ -416,6 +493,9 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
     I.hot_cap = (uint32_t)(total / I.lmax) + I.nbuckets + 16;
     const uint32_t c = I.c, W = I.W, nbuckets = I.nbuckets, lmax = I.lmax;
 
+    // launches of the previous plan may still be reading the plan buffers on their own streams
+    for (int i = 0; g_slots && i < kPendingSlots; i++)
+        if (g_slots[i].active && g_slots[i].ev && g_slots[i].info.n) WS_HIP_CHECK(hipStreamWaitEvent(s, g_slots[i].ev, 0));
     MsmScratch& S = *X->msm_scratch[0];
     WS_HIP_CHECK(S.keys.reserve(total * 4));
     WS_HIP_CHECK(S.vals.reserve(total * 4));
@@ -464,74 +544,9 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
     // tasks <= total/lmax + nbuckets <= hot_cap, so the worst-case grids below always cover them
     I.ntasks = I.hot_cap;
     I.nmulti = 0;
+    if (!g_plan_done) WS_HIP_CHECK(hipEventCreate(&g_plan_done));
+    WS_HIP_CHECK(hipEventRecord(g_plan_done, s));
     I.valid = true;
-    return WS_OK;
-}
-
-// ---- asynchronous completion: the last kernel's W x nsum window sums are copied to pinned host memory
-// and an event is recorded; the serial host tail (a 240-doubling Horner chain, faster on a CPU core than
-// on a GPU lane) runs later in msm_finish, so the GPU can already work on the next point set.
-struct MsmPending {
-    bool active = false;
-    int which = 0;
-    MsmPlanInfo info;
-    DevBuf d_sums;
-    void* h_sums = nullptr;
-    size_t h_bytes = 0;
-    hipEvent_t ev = nullptr;
-    void release() {
-        if (h_sums) (void)hipHostFree(h_sums);
-        if (ev) (void)hipEventDestroy(ev);
-        h_sums = nullptr; ev = nullptr; h_bytes = 0; active = false;
-        d_sums.release();
-    }
-};
-static const int kPendingSlots = 8;
-static MsmPending* g_slots = nullptr;   // released by msm_release_pending() at shutdown, while the runtime is alive
-static MsmPending* pending_slots() {
-    if (!g_slots) g_slots = new MsmPending[kPendingSlots];
-    return g_slots;
-}
-// error paths: forget launches whose results will never be collected
-void msm_abort_pending(hipStream_t s) {
-    if (!g_slots) return;
-    (void)hipStreamSynchronize(s);
-    for (int i = 0; i < kPendingSlots; i++) g_slots[i].active = false;
-}
-void msm_release_pending() {
-    if (!g_slots) return;
-    for (int i = 0; i < kPendingSlots; i++) g_slots[i].release();
-    delete[] g_slots;
-    g_slots = nullptr;
-}
-
-template <class H>
-static int msm_finish_t(MsmPending& P, typename H::Pt* out_host) {
-    typedef typename H::Pt HPt;
-    const MsmPlanInfo& I = P.info;
-    if (I.n == 0) { *out_host = H::infinity(); P.active = false; return WS_OK; }
-    WS_HIP_CHECK(hipEventSynchronize(P.ev));
-    const HPt* sums = reinterpret_cast<const HPt*>(P.h_sums);
-    // 8. host tail: result = sum_w 2^(c w) [ A_w + m * sum_q 2^q U_{w,q} ]   (Horner, MSB first)
-    uint32_t logm = 0;
-    while ((1u << logm) < I.m) logm++;
-    HPt acc = H::infinity();
-    for (int wg = (int)I.Wall - 1; wg >= 0; wg--) {      // global window index; rows exist for the owned ones
-        for (uint32_t k = 0; k < I.c; k++) acc = H::dbl(acc);
-        if ((uint32_t)wg < I.w_off || ((uint32_t)wg - I.w_off) % I.w_stride) continue;
-        const uint32_t w = ((uint32_t)wg - I.w_off) / I.w_stride;
-        const HPt* row = &sums[(size_t)w * I.nsum];
-        HPt u = H::infinity();
-        for (int q = (int)I.logJ - 1; q >= 0; q--) {
-            u = H::dbl(u);
-            u = H::add(u, row[q]);
-        }
-        for (uint32_t k = 0; k < logm; k++) u = H::dbl(u);
-        u = H::add(u, row[I.logJ]);
-        acc = H::add(acc, u);
-    }
-    *out_host = acc;
-    P.active = false;
     return WS_OK;
 }
 
@@ -562,8 +577,11 @@ static int msm_launch(int which, const typename H::Aff* d_points_ref, bool prepa
     const uint32_t c = I.c, W = I.W, nbuckets = I.nbuckets, m = I.m, J = I.J, logJ = I.logJ, nsum = I.nsum;
     const uint32_t ntasks = I.ntasks;
 
-    MsmScratch& PS = *X->msm_scratch[0];        // plan buffers
-    MsmScratch& S = *X->msm_scratch[which];     // this curve's accumulation buffers
+    MsmScratch& PS = *X->msm_scratch[0];        // plan buffers (read-only here)
+    MsmScratch& S = P.S;                        // this launch's accumulation buffers
+    if (!P.stream) WS_HIP_CHECK(hipStreamCreateWithFlags(&P.stream, hipStreamNonBlocking));
+    s = P.stream;
+    WS_HIP_CHECK(hipStreamWaitEvent(s, g_plan_done, 0));
     WS_HIP_CHECK(S.buckets.reserve((size_t)nbuckets * sizeof(Pt)));
     WS_HIP_CHECK(S.partials.reserve((size_t)I.hot_cap * sizeof(Pt)));
     WS_HIP_CHECK(S.chunkS.reserve((size_t)W * J * sizeof(Pt)));
