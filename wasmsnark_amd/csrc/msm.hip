@@ -384,10 +384,12 @@ struct MsmPending {
                                   // one point set overlap the accumulation of the next
     void* h_sums = nullptr;
     size_t h_bytes = 0;
-    hipEvent_t ev = nullptr;
+    hipEvent_t ev = nullptr, ev_acc = nullptr;
     void release() {
         if (h_sums) (void)hipHostFree(h_sums);
         if (ev) (void)hipEventDestroy(ev);
+        if (ev_acc) (void)hipEventDestroy(ev_acc);
+        ev_acc = nullptr;
         if (stream) (void)hipStreamDestroy(stream);
         h_sums = nullptr; ev = nullptr; stream = nullptr; h_bytes = 0; active = false;
         d_sums.release();
@@ -579,9 +581,11 @@ static int msm_launch(int which, const typename H::Aff* d_points_ref, bool prepa
 
     MsmScratch& PS = *X->msm_scratch[0];        // plan buffers (read-only here)
     MsmScratch& S = P.S;                        // this launch's accumulation buffers
+    // accumulation (throughput-bound, wants the whole chip) stays on the caller's stream, in order;
+    // the latency-bound reduction tail (chunks, tree, copy) moves to the slot's own stream so that it
+    // overlaps the accumulation of the next point set (concurrent accumulations only thrash the caches)
     if (!P.stream) WS_HIP_CHECK(hipStreamCreateWithFlags(&P.stream, hipStreamNonBlocking));
-    s = P.stream;
-    WS_HIP_CHECK(hipStreamWaitEvent(s, g_plan_done, 0));
+    if (!P.ev_acc) WS_HIP_CHECK(hipEventCreate(&P.ev_acc));
     WS_HIP_CHECK(S.buckets.reserve((size_t)nbuckets * sizeof(Pt)));
     WS_HIP_CHECK(S.partials.reserve((size_t)I.hot_cap * sizeof(Pt)));
     WS_HIP_CHECK(S.chunkS.reserve((size_t)W * J * sizeof(Pt)));
@@ -621,6 +625,11 @@ static int msm_launch(int which, const typename H::Aff* d_points_ref, bool prepa
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
 
+    WS_HIP_CHECK(hipEventRecord(P.ev_acc, s));
+    hipStream_t main_stream = s;
+    (void)main_stream;
+    s = P.stream;
+    WS_HIP_CHECK(hipStreamWaitEvent(s, P.ev_acc, 0));
     T.begin("msm_chunks", s);
     hipLaunchKernelGGL(msm_chunks<C>, dim3(ceil_div_u64((uint64_t)W * J, 256)), dim3(256), 0, s, S.buckets.as<Pt>(),
                        W * J, m, S.chunkS.as<Pt>(), S.chunkA.as<Pt>());
