@@ -581,9 +581,7 @@ static int msm_launch(int which, const typename H::Aff* d_points_ref, bool prepa
 
     MsmScratch& PS = *X->msm_scratch[0];        // plan buffers (read-only here)
     MsmScratch& S = P.S;                        // this launch's accumulation buffers
-    // accumulation (throughput-bound, wants the whole chip) stays on the caller's stream, in order;
-    // the latency-bound reduction tail (chunks, tree, copy) moves to the slot's own stream so that it
-    // overlaps the accumulation of the next point set (concurrent accumulations only thrash the caches)
+    // everything runs in order on the caller's stream (concurrent accumulations only thrash the caches)
     if (!P.stream) WS_HIP_CHECK(hipStreamCreateWithFlags(&P.stream, hipStreamNonBlocking));
     if (!P.ev_acc) WS_HIP_CHECK(hipEventCreate(&P.ev_acc));
     WS_HIP_CHECK(S.buckets.reserve((size_t)nbuckets * sizeof(Pt)));
@@ -625,11 +623,15 @@ static int msm_launch(int which, const typename H::Aff* d_points_ref, bool prepa
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
 
-    WS_HIP_CHECK(hipEventRecord(P.ev_acc, s));
-    hipStream_t main_stream = s;
-    (void)main_stream;
-    s = P.stream;
-    WS_HIP_CHECK(hipStreamWaitEvent(s, P.ev_acc, 0));
+    // Optional (WSNARK_MSM_TAIL_STREAM=1): run the latency-bound reduction tail on the slot's own stream so it
+    // overlaps the next accumulation.  Measured on MI355X (round 1, sessions 7-8): a loss -- the concurrent
+    // kernels starve each other (prove 2^20: 16.4 ms vs 15.9 ms in order), so the default keeps one stream.
+    static const bool tail_stream = [] { const char* e = getenv("WSNARK_MSM_TAIL_STREAM"); return e && atoi(e) == 1; }();
+    if (tail_stream) {
+        WS_HIP_CHECK(hipEventRecord(P.ev_acc, s));
+        s = P.stream;
+        WS_HIP_CHECK(hipStreamWaitEvent(s, P.ev_acc, 0));
+    }
     T.begin("msm_chunks", s);
     hipLaunchKernelGGL(msm_chunks<C>, dim3(ceil_div_u64((uint64_t)W * J, 256)), dim3(256), 0, s, S.buckets.as<Pt>(),
                        W * J, m, S.chunkS.as<Pt>(), S.chunkA.as<Pt>());
