@@ -98,6 +98,23 @@ int wsnark_pkey_load(const void* pkey, size_t len, wsnark_pkey_t** out_handle);
 void wsnark_pkey_free(wsnark_pkey_t* handle);
 int wsnark_pkey_info(const wsnark_pkey_t* handle, uint32_t* n_vars, uint32_t* n_public, uint32_t* domain);
 
+/* The same key given as separate host buffers with 64-bit lengths: proving_key.bin addresses its
+ * sections with u32 byte offsets (tools/buildpkey.js:133-139), which caps a key at 4 GiB (~2^23
+ * constraints); this entry point is the container for larger keys (BASELINE config 5).
+ * pointsC holds nVars-nPublic-1 points (signals nPublic+1..), as in the file. */
+typedef struct {
+    uint32_t n_vars, n_public, domain;
+    const void *alfa1, *beta1, *delta1;      /* 64 B each  */
+    const void *beta2, *delta2;              /* 128 B each */
+    const void* polsA; uint64_t polsA_len;   /* record streams, src/build_pol.js:62-144 */
+    const void* polsB; uint64_t polsB_len;
+    const void *pointsA, *pointsB1;          /* nVars x 64 B  */
+    const void* pointsB2;                    /* nVars x 128 B */
+    const void* pointsC;                     /* (nVars-nPublic-1) x 64 B */
+    const void* pointsH;                     /* domain x 64 B */
+} wsnark_key_sections_t;
+int wsnark_pkey_load_sections(const wsnark_key_sections_t* sections, wsnark_pkey_t** out_handle);
+
 /* Bn128.groth16GenProof (src/bn128.js:580-720).  witness: nVars x 32 B plain
  * (tools/buildwitness.js:36-41).  r32 / s32: the two 32-byte blinding values the reference
  * draws from crypto.randomBytes (src/bn128.js:642-661); NULL => drawn from the OS CSPRNG.
@@ -109,6 +126,16 @@ int wsnark_groth16_prove(wsnark_pkey_t* handle, const void* witness, size_t witn
 /* same, witness already on the device */
 int wsnark_groth16_prove_dev(wsnark_pkey_t* handle, const void* d_witness, size_t witness_len, const void* r32,
                              const void* s32, void* out384_host, void* stream);
+
+/* Multi-GPU proving (one process per GPU, window-sharded: call wsnark_set_window_shard first).
+ * prove_partial runs CALC_H and the five MSMs on this rank's windows and writes ONE 576-byte record:
+ * A | B1 | C | H (4 x 96 B G1) | B2 (192 B G2), Jacobian-Montgomery -- the reference's per-worker
+ * partial results (src/bn128.js:374-382, 406-414) for all five sums at once.  After a single
+ * all_gather of these records, prove_finish (host arithmetic only) sums them and assembles the proof
+ * exactly as wsnark_groth16_prove does (src/bn128.js:671-718). */
+int wsnark_groth16_prove_partial(wsnark_pkey_t* handle, const void* witness, size_t witness_len, void* out576);
+int wsnark_groth16_prove_finish(wsnark_pkey_t* handle, const void* partials, uint64_t n_ranks, const void* r32,
+                                const void* s32, void* out384);
 
 /* ---- synthetic-input helpers: NO reference counterpart ----
  * out[i] = scalars[i] * base (affine Montgomery in and out; infinity written as all-zero bytes).

@@ -42,6 +42,14 @@ for g, n in ((1, 45), (2, 21)):
     want = orc.g_affine(g, orc.multiexp(g, "multiexp", sc, pts, n))
     assert full == want, ("windows", g, rank)
 bn.set_window_shard(0, 1)
+# whole proof, window-sharded: one 576-byte record per rank, one all_gather
+import json
+gold = os.path.join(os.environ["WS_ROOT"], "tests", "golden")
+key = bn.load_key(open(os.path.join(gold, "keys", "t6.pkey.bin"), "rb").read())
+wit = open(os.path.join(gold, "keys", "t6.witness.bin"), "rb").read()
+for c in json.load(open(os.path.join(gold, "proofs.json")))["t6"]:
+    got = wd.sharded_prove(bn, key, wit, r=bytes.fromhex(c["r"]), s=bytes.fromhex(c["s"]))
+    assert got == c["proof"], ("sharded prove", rank)
 dist.barrier()
 open(os.path.join(os.environ["WS_OUT"], "rank%d.ok" % rank), "w").write("ok")
 '''

@@ -271,3 +271,26 @@ def test_window_shards_sum_to_full_msm_on_gpu(bn, orc):
     finally:
         bn.set_window_shard(0, 1)
     assert bn.g1_multiexp(sc, pts) == want
+
+
+def test_sharded_prove_records_on_gpu(bn):
+    """wsnark_groth16_prove_partial / _finish: the 576-byte records of a simulated world of 4 window
+    shards combine to the single-GPU proof (and to the toxic-waste closed form)."""
+    from wasmsnark_amd import synth
+    circ = synth.make_circuit(12, n_public=3, seed=77)
+    S = synth.setup(circ, seed=9)
+    pkey, _ = synth.build_key(circ, S, bn.mul_base)
+    key = bn.load_key(pkey)
+    wit = synth.witness_bin(circ)
+    r, s = os.urandom(32), os.urandom(32)
+    want = synth.expected_proof(circ, S, r, s, bn.mul_base)
+    assert bn.groth16GenProof(wit, key, r=r, s=s) == want
+    parts = b""
+    try:
+        for rank in range(4):
+            bn.set_window_shard(rank, 4)
+            parts += bn.groth16_prove_partial(wit, key)
+    finally:
+        bn.set_window_shard(0, 1)
+    assert len(parts) == 4 * 576
+    assert bn.groth16_prove_finish(key, parts, r=r, s=s) == want

@@ -84,3 +84,31 @@ def test_key_format_errors():
         bn.load_key(bytes(bad))
     with pytest.raises(WsnarkError):
         bn.groth16GenProof(wit[:64], pkey)            # witness too short
+
+
+def test_partial_finish_and_sections_loader():
+    """prove_partial + prove_finish (world = 1 and a simulated world = 3) and the section-based key loader
+    reproduce the reference's proofs."""
+    import struct
+    bn = emul_bn128()
+    pkey, wit, _ = _key("t6")
+    h = struct.unpack("<10I", pkey[:40])
+    nv, npub, dom, pPA, pPB, pA, pB1, pB2, pC, pH = h
+    sec = {"n_vars": nv, "n_public": npub, "domain": dom, "alfa1": pkey[40:104], "beta1": pkey[104:168],
+           "delta1": pkey[168:232], "beta2": pkey[232:360], "delta2": pkey[360:488], "polsA": pkey[pPA:pPB],
+           "polsB": pkey[pPB:pA], "pointsA": pkey[pA:pA + nv * 64], "pointsB1": pkey[pB1:pB1 + nv * 64],
+           "pointsB2": pkey[pB2:pB2 + nv * 128], "pointsC": pkey[pC:pC + (nv - npub - 1) * 64],
+           "pointsH": pkey[pH:pH + dom * 64]}
+    key = bn.load_key(sections=sec)
+    c = load_golden("proofs.json")["t6"][3]
+    r, s = bytes.fromhex(c["r"]), bytes.fromhex(c["s"])
+    assert bn.groth16GenProof(wit, key, r=r, s=s) == c["proof"]
+    assert bn.groth16_prove_finish(key, bn.groth16_prove_partial(wit, key), r=r, s=s) == c["proof"]
+    parts = b""
+    try:
+        for rank in range(3):
+            bn.set_window_shard(rank, 3)
+            parts += bn.groth16_prove_partial(wit, key)
+    finally:
+        bn.set_window_shard(0, 1)
+    assert bn.groth16_prove_finish(key, parts, r=r, s=s) == c["proof"]

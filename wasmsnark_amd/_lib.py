@@ -19,7 +19,8 @@ SYMBOLS = [
     "wsnark_g1_sum", "wsnark_g2_sum", "wsnark_set_window_shard",
     "wsnark_fr_ntt", "wsnark_fr_ntt_dev", "wsnark_fr_to_montgomery", "wsnark_fr_from_montgomery",
     "wsnark_calc_h", "wsnark_pkey_load", "wsnark_pkey_free", "wsnark_pkey_info",
-    "wsnark_groth16_prove", "wsnark_groth16_prove_dev",
+    "wsnark_groth16_prove", "wsnark_groth16_prove_dev", "wsnark_pkey_load_sections",
+    "wsnark_groth16_prove_partial", "wsnark_groth16_prove_finish",
     "wsnark_g1_mul_base_batch", "wsnark_g2_mul_base_batch",
     "wsnark_timing_enable", "wsnark_timing_reset", "wsnark_timing_report",
 ]
@@ -65,6 +66,9 @@ class Lib:
         c.wsnark_pkey_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
         c.wsnark_groth16_prove.argtypes = [vp, vp, sz, vp, vp, vp]
         c.wsnark_groth16_prove_dev.argtypes = [vp, vp, sz, vp, vp, vp, vp]
+        c.wsnark_pkey_load_sections.argtypes = [vp, C.POINTER(vp)]
+        c.wsnark_groth16_prove_partial.argtypes = [vp, vp, sz, vp]
+        c.wsnark_groth16_prove_finish.argtypes = [vp, vp, u64, vp, vp, vp]
         c.wsnark_g1_mul_base_batch.argtypes = [vp, vp, u64, vp]
         c.wsnark_g2_mul_base_batch.argtypes = [vp, vp, u64, vp]
         self.initialised = False

@@ -34,14 +34,37 @@ def _buf(b):
     raise TypeError("expected a bytes-like object (the reference takes ArrayBuffers)")
 
 
-class ProvingKey:
-    """Device-resident proving key (wsnark_pkey_load)."""
+class _KeySections(C.Structure):   # wsnark_key_sections_t
+    _fields_ = [("n_vars", C.c_uint32), ("n_public", C.c_uint32), ("domain", C.c_uint32),
+                ("alfa1", C.c_void_p), ("beta1", C.c_void_p), ("delta1", C.c_void_p),
+                ("beta2", C.c_void_p), ("delta2", C.c_void_p),
+                ("polsA", C.c_void_p), ("polsA_len", C.c_uint64), ("polsB", C.c_void_p), ("polsB_len", C.c_uint64),
+                ("pointsA", C.c_void_p), ("pointsB1", C.c_void_p), ("pointsB2", C.c_void_p),
+                ("pointsC", C.c_void_p), ("pointsH", C.c_void_p)]
 
-    def __init__(self, lib, data):
+
+class ProvingKey:
+    """Device-resident proving key (wsnark_pkey_load, or wsnark_pkey_load_sections for `sections`)."""
+
+    def __init__(self, lib, data=None, sections=None):
         self._lib = lib
         self._h = C.c_void_p()
-        b, n = _buf(data)
-        lib.check(lib.c.wsnark_pkey_load(b, n, C.byref(self._h)))
+        if sections is not None:
+            # dict: n_vars, n_public, domain + byte strings alfa1, beta1, delta1, beta2, delta2, polsA, polsB,
+            # pointsA, pointsB1, pointsB2, pointsC, pointsH (64-bit lengths: keys beyond the 4 GiB file format)
+            ks = _KeySections(sections["n_vars"], sections["n_public"], sections["domain"])
+            keep = []
+            for name in ("alfa1", "beta1", "delta1", "beta2", "delta2", "polsA", "polsB", "pointsA", "pointsB1",
+                         "pointsB2", "pointsC", "pointsH"):
+                b, n = _buf(sections[name])
+                keep.append(b)
+                setattr(ks, name, C.cast(b, C.c_void_p))
+                if name in ("polsA", "polsB"):
+                    setattr(ks, name + "_len", n)
+            lib.check(lib.c.wsnark_pkey_load_sections(C.byref(ks), C.byref(self._h)))
+        else:
+            b, n = _buf(data)
+            lib.check(lib.c.wsnark_pkey_load(b, n, C.byref(self._h)))
         nv, npub, dom = C.c_uint32(), C.c_uint32(), C.c_uint32()
         lib.check(lib.c.wsnark_pkey_info(self._h, C.byref(nv), C.byref(npub), C.byref(dom)))
         self.n_vars, self.n_public, self.domain = nv.value, npub.value, dom.value
@@ -165,8 +188,23 @@ class Bn128:
         self.lib.check(fn(b, s, n, out))
         return bytes(out)[: n * sz]
 
-    def load_key(self, pkey):
-        return ProvingKey(self.lib, pkey)
+    def load_key(self, pkey=None, sections=None):
+        return ProvingKey(self.lib, pkey, sections)
+
+    # --- multi-GPU proving: per-rank partial sums + host-side finish (include/wsnark.h) ---
+    def groth16_prove_partial(self, signals, key):
+        w, nw = _buf(signals)
+        out = (C.c_uint8 * 576)()
+        self.lib.check(self.lib.c.wsnark_groth16_prove_partial(key._h, w, nw, out))
+        return bytes(out)
+
+    def groth16_prove_finish(self, key, partials, r=None, s=None):
+        p, n = _buf(partials)
+        out = (C.c_uint8 * 384)()
+        rb = _buf(r)[0] if r is not None else None
+        sb = _buf(s)[0] if s is not None else None
+        self.lib.check(self.lib.c.wsnark_groth16_prove_finish(key._h, p, n // 576, rb, sb, out))
+        return proof_from_bytes(bytes(out))
 
     # --- src/bn128.js:580-720 ---
     def groth16GenProof(self, signals, pkey, r=None, s=None):

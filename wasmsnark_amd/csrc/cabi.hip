@@ -15,6 +15,17 @@ void pkey_free(ProvingKey* K);
 void pkey_info(const ProvingKey* K, uint32_t* nv, uint32_t* np, uint32_t* dom);
 int groth16_prove_host_witness(ProvingKey* K, const uint8_t* witness, size_t witness_len, const uint8_t* r32,
                                const uint8_t* s32, uint8_t* out384);
+struct KeySections {
+    uint32_t n_vars, n_public, domain;
+    const uint8_t *alfa1, *beta1, *delta1, *beta2, *delta2;
+    const uint8_t* polsA; uint64_t lenA;
+    const uint8_t* polsB; uint64_t lenB;
+    const uint8_t *A, *B1, *B2, *Cpts, *H;
+};
+int pkey_load_sections(const KeySections& S, ProvingKey** out);
+int groth16_prove_partial(ProvingKey* K, const uint8_t* witness, size_t witness_len, uint8_t* out576);
+int groth16_prove_finish(ProvingKey* K, const uint8_t* partials, uint64_t n_ranks, const uint8_t* r32,
+                         const uint8_t* s32, uint8_t* out384);
 int groth16_prove_dev_witness(ProvingKey* K, const Fe* d_witness, size_t witness_len, const uint8_t* r32,
                               const uint8_t* s32, uint8_t* out384, hipStream_t s);
 void g1_sum_host(const uint8_t* pts, uint64_t count, uint8_t* out96);
@@ -193,6 +204,35 @@ int wsnark_groth16_prove_dev(wsnark_pkey_t* h, const void* d_witness, size_t wit
     if (!h || !d_witness || !out384_host) return WSNARK_ERR_ARG;
     return groth16_prove_dev_witness(reinterpret_cast<ProvingKey*>(h), (const Fe*)d_witness, witness_len,
                                      (const uint8_t*)r32, (const uint8_t*)s32, (uint8_t*)out384_host, (hipStream_t)stream);
+}
+
+int wsnark_pkey_load_sections(const wsnark_key_sections_t* ks, wsnark_pkey_t** out_handle) {
+    REQUIRE_CTX();
+    if (!ks || !out_handle || !ks->alfa1 || !ks->beta1 || !ks->delta1 || !ks->beta2 || !ks->delta2 || !ks->polsA ||
+        !ks->polsB || !ks->pointsA || !ks->pointsB1 || !ks->pointsB2 || !ks->pointsH ||
+        (!ks->pointsC && ks->n_vars > ks->n_public + 1))
+        return WSNARK_ERR_ARG;
+    KeySections S{ks->n_vars, ks->n_public, ks->domain, (const uint8_t*)ks->alfa1, (const uint8_t*)ks->beta1,
+                  (const uint8_t*)ks->delta1, (const uint8_t*)ks->beta2, (const uint8_t*)ks->delta2,
+                  (const uint8_t*)ks->polsA, ks->polsA_len, (const uint8_t*)ks->polsB, ks->polsB_len,
+                  (const uint8_t*)ks->pointsA, (const uint8_t*)ks->pointsB1, (const uint8_t*)ks->pointsB2,
+                  (const uint8_t*)ks->pointsC, (const uint8_t*)ks->pointsH};
+    ProvingKey* K = nullptr;
+    int rc = pkey_load_sections(S, &K);
+    if (rc) return rc;
+    *out_handle = reinterpret_cast<wsnark_pkey_t*>(K);
+    return WSNARK_OK;
+}
+int wsnark_groth16_prove_partial(wsnark_pkey_t* h, const void* witness, size_t witness_len, void* out576) {
+    REQUIRE_CTX();
+    if (!h || !witness || !out576) return WSNARK_ERR_ARG;
+    return groth16_prove_partial(reinterpret_cast<ProvingKey*>(h), (const uint8_t*)witness, witness_len, (uint8_t*)out576);
+}
+int wsnark_groth16_prove_finish(wsnark_pkey_t* h, const void* partials, uint64_t n_ranks, const void* r32,
+                                const void* s32, void* out384) {
+    if (!h || !out384 || (n_ranks && !partials)) return WSNARK_ERR_ARG;
+    return groth16_prove_finish(reinterpret_cast<ProvingKey*>(h), (const uint8_t*)partials, n_ranks,
+                                (const uint8_t*)r32, (const uint8_t*)s32, (uint8_t*)out384);
 }
 
 // ---- synthetic-input helpers (no reference counterpart) ----

@@ -26,42 +26,37 @@ struct ProvingKey {
 
 static bool range_ok(uint64_t off, uint64_t bytes, size_t len) { return off <= len && bytes <= len - off; }
 
-int pkey_load(const uint8_t* buf, size_t len, ProvingKey** out) {
+struct KeySections {      // everything wsnark_pkey_load reads from proving_key.bin, as separate host buffers
+    uint32_t n_vars, n_public, domain;
+    const uint8_t *alfa1, *beta1, *delta1, *beta2, *delta2;
+    const uint8_t* polsA; uint64_t lenA;
+    const uint8_t* polsB; uint64_t lenB;
+    const uint8_t *A, *B1, *B2, *Cpts, *H;     // nVars, nVars, nVars, nVars-nPublic-1, domain points
+};
+
+int pkey_load_sections(const KeySections& S, ProvingKey** out) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
-    if (!buf || !out) return WS_ERR_ARG;
-    // 10 x u32 header (src/bn128.js:581-591), then alfa1, beta1, delta1 (3 x 64 B), beta2, delta2 (2 x 128 B)
-    if (len < 40 + 448) { set_last_error("proving key shorter than its fixed header"); return WS_ERR_FORMAT; }
-    uint32_t h[10];
-    memcpy(h, buf, 40);
-    const uint32_t nv = h[0], np = h[1], dom = h[2];
-    const uint64_t pPolsA = h[3], pPolsB = h[4], pA = h[5], pB1 = h[6], pB2 = h[7], pC = h[8], pH = h[9];
+    const uint32_t nv = S.n_vars, np = S.n_public, dom = S.domain;
     if (nv == 0 || np + 1 > nv) { set_last_error("proving key: nPublic + 1 > nVars"); return WS_ERR_FORMAT; }
     if (dom < 2 || (dom & (dom - 1)) || dom > (1u << 27)) { set_last_error("proving key: domainSize must be a power of two in [2, 2^27]"); return WS_ERR_SIZE; }
     const uint64_t nC = (uint64_t)nv - np - 1;
-    if (!(pPolsA >= 488 && pPolsA <= pPolsB && pPolsB <= pA) || !range_ok(pA, (uint64_t)nv * 64, len) ||
-        !range_ok(pB1, (uint64_t)nv * 64, len) || !range_ok(pB2, (uint64_t)nv * 128, len) ||
-        !range_ok(pC, nC * 64, len) || !range_ok(pH, (uint64_t)dom * 64, len)) {
-        set_last_error("proving key: section offsets out of range");
-        return WS_ERR_FORMAT;
-    }
     std::unique_ptr<ProvingKey> K(new ProvingKey());
     K->n_vars = nv; K->n_public = np; K->domain = dom;
-    memcpy(&K->alfa1, buf + 40, 64);
-    memcpy(&K->beta1, buf + 40 + 64, 64);
-    memcpy(&K->delta1, buf + 40 + 128, 64);
-    memcpy(&K->beta2, buf + 40 + 192, 128);
-    memcpy(&K->delta2, buf + 40 + 320, 128);
+    memcpy(&K->alfa1, S.alfa1, 64);
+    memcpy(&K->beta1, S.beta1, 64);
+    memcpy(&K->delta1, S.delta1, 64);
+    memcpy(&K->beta2, S.beta2, 128);
+    memcpy(&K->delta2, S.delta2, 128);
     hipStream_t s = C->stream;
-    // true section bounds from the header (the reference slices over-long: src/bn128.js:592-593)
     size_t used = 0;
-    int rc = pols_to_csr(buf + pPolsA, (size_t)(pPolsB - pPolsA), nv, dom, &K->polsA, &used, s);
+    int rc = pols_to_csr(S.polsA, (size_t)S.lenA, nv, dom, &K->polsA, &used, s);
     if (rc) return rc;
-    rc = pols_to_csr(buf + pPolsB, (size_t)(pA - pPolsB), nv, dom, &K->polsB, &used, s);
+    rc = pols_to_csr(S.polsB, (size_t)S.lenB, nv, dom, &K->polsB, &used, s);
     if (rc) return rc;
-    struct Sec { DevBuf* d; uint64_t off, bytes; } secs[5] = {
-        {&K->pointsA, pA, (uint64_t)nv * 64}, {&K->pointsB1, pB1, (uint64_t)nv * 64}, {&K->pointsB2, pB2, (uint64_t)nv * 128},
-        {&K->pointsC, pC, nC * 64}, {&K->pointsH, pH, (uint64_t)dom * 64}};
+    struct Sec { DevBuf* d; const uint8_t* src; uint64_t bytes; } secs[5] = {
+        {&K->pointsA, S.A, (uint64_t)nv * 64}, {&K->pointsB1, S.B1, (uint64_t)nv * 64}, {&K->pointsB2, S.B2, (uint64_t)nv * 128},
+        {&K->pointsC, S.Cpts, nC * 64}, {&K->pointsH, S.H, (uint64_t)dom * 64}};
     for (auto& sc : secs) {
         if (sc.d == &K->pointsC) {
             // C holds points for signals nPublic+1.. only (src/bn128.js:620 slices the scalars instead).
@@ -69,11 +64,11 @@ int pkey_load(const uint8_t* buf, size_t len, ProvingKey** out) {
             // uses the SAME scalar vector -- and the same digit/sort plan -- as A, B1 and B2.
             WS_HIP_CHECK(sc.d->alloc((size_t)nv * 64));
             WS_HIP_CHECK(hipMemsetAsync(sc.d->p, 0, (size_t)(np + 1) * 64, s));
-            if (sc.bytes) WS_HIP_CHECK(hipMemcpyAsync((uint8_t*)sc.d->p + (size_t)(np + 1) * 64, buf + sc.off, (size_t)sc.bytes, hipMemcpyHostToDevice, s));
+            if (sc.bytes) WS_HIP_CHECK(hipMemcpyAsync((uint8_t*)sc.d->p + (size_t)(np + 1) * 64, sc.src, (size_t)sc.bytes, hipMemcpyHostToDevice, s));
             continue;
         }
         WS_HIP_CHECK(sc.d->alloc((size_t)sc.bytes));
-        if (sc.bytes) WS_HIP_CHECK(hipMemcpyAsync(sc.d->p, buf + sc.off, (size_t)sc.bytes, hipMemcpyHostToDevice, s));
+        if (sc.bytes) WS_HIP_CHECK(hipMemcpyAsync(sc.d->p, sc.src, (size_t)sc.bytes, hipMemcpyHostToDevice, s));
     }
     // resident keys are kept in the device field's internal domain: no per-proof conversion pass
     if ((rc = msm_prepare_points(0, K->pointsA.p, nv, s))) return rc;
@@ -86,6 +81,30 @@ int pkey_load(const uint8_t* buf, size_t len, ProvingKey** out) {
     WS_HIP_CHECK(hipStreamSynchronize(s));
     *out = K.release();
     return WS_OK;
+}
+
+int pkey_load(const uint8_t* buf, size_t len, ProvingKey** out) {
+    if (!ctx()) return WS_ERR_NOINIT;
+    if (!buf || !out) return WS_ERR_ARG;
+    // 10 x u32 header (src/bn128.js:581-591), then alfa1, beta1, delta1 (3 x 64 B), beta2, delta2 (2 x 128 B)
+    if (len < 40 + 448) { set_last_error("proving key shorter than its fixed header"); return WS_ERR_FORMAT; }
+    uint32_t h[10];
+    memcpy(h, buf, 40);
+    const uint32_t nv = h[0], np = h[1], dom = h[2];
+    const uint64_t pPolsA = h[3], pPolsB = h[4], pA = h[5], pB1 = h[6], pB2 = h[7], pC = h[8], pH = h[9];
+    if (nv == 0 || np + 1 > nv) { set_last_error("proving key: nPublic + 1 > nVars"); return WS_ERR_FORMAT; }
+    const uint64_t nC = (uint64_t)nv - np - 1;
+    if (!(pPolsA >= 488 && pPolsA <= pPolsB && pPolsB <= pA) || !range_ok(pA, (uint64_t)nv * 64, len) ||
+        !range_ok(pB1, (uint64_t)nv * 64, len) || !range_ok(pB2, (uint64_t)nv * 128, len) ||
+        !range_ok(pC, nC * 64, len) || !range_ok(pH, (uint64_t)dom * 64, len)) {
+        set_last_error("proving key: section offsets out of range");
+        return WS_ERR_FORMAT;
+    }
+    // true section bounds from the header (the reference slices over-long: src/bn128.js:592-593)
+    KeySections S{nv, np, dom, buf + 40, buf + 104, buf + 168, buf + 232, buf + 360,
+                  buf + pPolsA, pPolsB - pPolsA, buf + pPolsB, pA - pPolsB,
+                  buf + pA, buf + pB1, buf + pB2, buf + pC, buf + pH};
+    return pkey_load_sections(S, out);
 }
 
 void pkey_free(ProvingKey* K) { delete K; }
@@ -124,84 +143,95 @@ static void store_plain(uint8_t* dst, const Fe& mont) {
     memcpy(dst, &p, 32);
 }
 
-// witness already in K->witness (device) -- or d_witness given
-int groth16_prove(ProvingKey* K, const Fe* d_witness, const uint8_t* r32, const uint8_t* s32, uint8_t* out384,
-                  hipStream_t s) {
+struct MsmSums {
+    XYZZ<Fq> A, B1, C, H;
+    XYZZ<Fq2> B2;
+};
+
+// CALC_H and the five MSMs (src/bn128.js:607-620).  With window sharding active
+// (wsnark_set_window_shard) the sums are this rank's partial sums.
+static int prove_msms(ProvingKey* K, const Fe* d_witness, MsmSums* out, hipStream_t s) {
     Context* C = ctx();
-    if (!C) return WS_ERR_NOINIT;
-    if (!s) s = C->stream;
-    const uint32_t nv = K->n_vars, np = K->n_public, dom = K->domain;
+    const uint32_t nv = K->n_vars, dom = K->domain;
+    int rc;
+    // CALC_H, then the H MSM over domainSize pairs (src/bn128.js:607-615)
+    Fe* d_h = K->h.as<Fe>();
+    if ((rc = calc_h_dev(d_witness, nv, K->polsA, K->polsB, dom, d_h, s))) return rc;
+    std::lock_guard<std::mutex> lk(C->mu);   // the digit/sort plan and the MSM scratch are per context
+    int hH = -1, hA = -1, hB1 = -1, hB2 = -1, hC = -1;
+    struct Abort { hipStream_t s; bool armed; ~Abort() { if (armed) msm_abort_pending(s); } } guard{s, true};
+    if ((rc = msm_plan_dev(d_h, dom, s))) return rc;
+    if ((rc = msm_g1_launch(K->pointsH.as<Affine<Fq>>(), true, &hH, s))) return rc;                    // :614
+    // one plan for the four sums whose scalars are the witness (:617-620); each host tail runs while
+    // the GPU already accumulates the next point set
+    if ((rc = msm_plan_dev(d_witness, nv, s))) return rc;
+    if ((rc = msm_g1_launch(K->pointsA.as<Affine<Fq>>(), true, &hA, s))) return rc;                    // :617
+    if ((rc = msm_g1_finish(hH, &out->H))) return rc;
+    if ((rc = msm_g1_launch(K->pointsB1.as<Affine<Fq>>(), true, &hB1, s))) return rc;                  // :618
+    if ((rc = msm_g2_launch(K->pointsB2.as<Affine<Fq2>>(), true, &hB2, s))) return rc;                 // :619
+    if ((rc = msm_g1_launch(K->pointsC.as<Affine<Fq>>(), true, &hC, s))) return rc;                    // :620 (padded)
+    if ((rc = msm_g1_finish(hA, &out->A))) return rc;
+    if ((rc = msm_g1_finish(hB1, &out->B1))) return rc;
+    if ((rc = msm_g2_finish(hB2, &out->B2))) return rc;
+    if ((rc = msm_g1_finish(hC, &out->C))) return rc;
+    guard.armed = false;
+    return WS_OK;
+}
+
+struct Blinding {
+    Fe rr, ss, rs;                 // r mod r, s mod r, r*s mod r (plain)
+    struct Pre { G1::Pt r_delta1, s_delta1, rs_delta1; G2::Pt s_delta2; };
+    std::future<Pre> pre;
+    const uint8_t* rb() const { return reinterpret_cast<const uint8_t*>(&rr); }
+    const uint8_t* sb() const { return reinterpret_cast<const uint8_t*>(&ss); }
+    ~Blinding() { if (pre.valid()) pre.wait(); }
+};
+
+// r, s are raw 256-bit values (not reduced, src/bn128.js:642-661); every point here has prime order r, so
+// k*P == (k mod r)*P and (r*s)*P == ((r mod r)(s mod r) mod r)*P (:700-702).  The scalar multiplications
+// that involve key points only start on a host thread at once (they overlap the GPU work).
+static int start_blinding(ProvingKey* K, const uint8_t* r32, const uint8_t* s32, Blinding* B) {
     uint8_t rnd[64];
     if (!r32 || !s32) {
         if (os_random(rnd, 64)) { set_last_error("cannot read /dev/urandom"); return WS_ERR_ARG; }
         if (!r32) r32 = rnd;
         if (!s32) s32 = rnd + 32;
     }
-    int rc;
-    // r, s are raw 256-bit values (not reduced, src/bn128.js:642-661); every point here has prime
-    // order r, so k*P == (k mod r)*P and (r*s)*P == ((r mod r)(s mod r) mod r)*P  (:700-702)
-    Fe rr, ss;
-    memcpy(&rr, r32, 32);
-    memcpy(&ss, s32, 32);
-    rr = Fr::reduce_full(rr);
-    ss = Fr::reduce_full(ss);
-    Fe rs = Fr::from_mont(Fr::mul(Fr::to_mont(rr), Fr::to_mont(ss)));
-    const uint8_t* rb = reinterpret_cast<const uint8_t*>(&rr);
-    const uint8_t* sb = reinterpret_cast<const uint8_t*>(&ss);
-    const uint8_t* rsb = reinterpret_cast<const uint8_t*>(&rs);
-    const G1::Pt alfa1 = G1::from_affine(K->alfa1), beta1 = G1::from_affine(K->beta1), delta1 = G1::from_affine(K->delta1);
-    const G2::Pt beta2 = G2::from_affine(K->beta2), delta2 = G2::from_affine(K->delta2);
-    // the scalar multiplications that do not depend on the MSMs run on a host thread while the GPU works
-    struct Pre { G1::Pt r_delta1, s_delta1, rs_delta1; G2::Pt s_delta2; };
-    std::future<Pre> pre = std::async(std::launch::async, [&]() {
-        Pre p;
-        p.r_delta1 = G1::mul_bytes(delta1, rb, 32);
-        p.s_delta1 = G1::mul_bytes(delta1, sb, 32);
-        p.rs_delta1 = G1::mul_bytes(delta1, rsb, 32);
-        p.s_delta2 = G2::mul_bytes(delta2, sb, 32);
+    memcpy(&B->rr, r32, 32);
+    memcpy(&B->ss, s32, 32);
+    B->rr = Fr::reduce_full(B->rr);
+    B->ss = Fr::reduce_full(B->ss);
+    B->rs = Fr::from_mont(Fr::mul(Fr::to_mont(B->rr), Fr::to_mont(B->ss)));
+    const Fe rr = B->rr, ss = B->ss, rs = B->rs;
+    const G1::Pt delta1 = G1::from_affine(K->delta1);
+    const G2::Pt delta2 = G2::from_affine(K->delta2);
+    B->pre = std::async(std::launch::async, [rr, ss, rs, delta1, delta2]() {
+        Blinding::Pre p;
+        p.r_delta1 = G1::mul_bytes(delta1, reinterpret_cast<const uint8_t*>(&rr), 32);
+        p.s_delta1 = G1::mul_bytes(delta1, reinterpret_cast<const uint8_t*>(&ss), 32);
+        p.rs_delta1 = G1::mul_bytes(delta1, reinterpret_cast<const uint8_t*>(&rs), 32);
+        p.s_delta2 = G2::mul_bytes(delta2, reinterpret_cast<const uint8_t*>(&ss), 32);
         return p;
     });
-    struct WaitPre { std::future<Pre>& f; ~WaitPre() { if (f.valid()) f.wait(); } } wait_pre{pre};   // never outlive the captures
+    return WS_OK;
+}
 
-    // CALC_H, then the H MSM over domainSize pairs (src/bn128.js:607-615)
-    Fe* d_h = K->h.as<Fe>();
-    if ((rc = calc_h_dev(d_witness, nv, K->polsA, K->polsB, dom, d_h, s))) return rc;
-    XYZZ<Fq> sA, sB1, sC, sH;
-    XYZZ<Fq2> sB2;
-    {
-        std::lock_guard<std::mutex> lk(C->mu);   // the digit/sort plan and the MSM scratch are per context
-        int hH = -1, hA = -1, hB1 = -1, hB2 = -1, hC = -1;
-        struct Abort { hipStream_t s; bool armed; ~Abort() { if (armed) msm_abort_pending(s); } } guard{s, true};
-        if ((rc = msm_plan_dev(d_h, dom, s))) return rc;
-        if ((rc = msm_g1_launch(K->pointsH.as<Affine<Fq>>(), true, &hH, s))) return rc;                    // :614
-        // one plan for the four sums whose scalars are the witness (:617-620); each host tail runs while
-        // the GPU already accumulates the next point set
-        if ((rc = msm_plan_dev(d_witness, nv, s))) return rc;
-        if ((rc = msm_g1_launch(K->pointsA.as<Affine<Fq>>(), true, &hA, s))) return rc;                    // :617
-        if ((rc = msm_g1_finish(hH, &sH))) return rc;
-        if ((rc = msm_g1_launch(K->pointsB1.as<Affine<Fq>>(), true, &hB1, s))) return rc;                  // :618
-        if ((rc = msm_g2_launch(K->pointsB2.as<Affine<Fq2>>(), true, &hB2, s))) return rc;                 // :619
-        if ((rc = msm_g1_launch(K->pointsC.as<Affine<Fq>>(), true, &hC, s))) return rc;                    // :620 (padded)
-        if ((rc = msm_g1_finish(hA, &sA))) return rc;
-        if ((rc = msm_g1_finish(hB1, &sB1))) return rc;
-        if ((rc = msm_g2_finish(hB2, &sB2))) return rc;
-        if ((rc = msm_g1_finish(hC, &sC))) return rc;
-        guard.armed = false;
-    }
-    const Pre pp = pre.get();
-
+// src/bn128.js:671-718
+static void prove_assemble(ProvingKey* K, const MsmSums& M, Blinding& B, uint8_t* out384) {
+    const G1::Pt alfa1 = G1::from_affine(K->alfa1), beta1 = G1::from_affine(K->beta1);
+    const G2::Pt beta2 = G2::from_affine(K->beta2);
+    const Blinding::Pre pp = B.pre.get();
     // pi_a = sum A + alfa1 + r*delta1                               (:671-673)
-    G1::Pt pi_a = G1::add(G1::add(alfa1, sA), pp.r_delta1);
+    G1::Pt pi_a = G1::add(G1::add(alfa1, M.A), pp.r_delta1);
     // pi_b = sum B2 + beta2 + s*delta2                              (:676-678)
-    G2::Pt pi_b = G2::add(G2::add(beta2, sB2), pp.s_delta2);
+    G2::Pt pi_b = G2::add(G2::add(beta2, M.B2), pp.s_delta2);
     // pib1 = sum B1 + beta1 + s*delta1                              (:681-683)
-    G1::Pt pib1 = G1::add(G1::add(beta1, sB1), pp.s_delta1);
+    G1::Pt pib1 = G1::add(G1::add(beta1, M.B1), pp.s_delta1);
     // pi_c = sum C + sum H + s*pi_a + r*pib1 - (r*s)*delta1         (:687-704)
-    G1::Pt pi_c = G1::add(sC, sH);
-    pi_c = G1::add(pi_c, G1::mul_bytes(pi_a, sb, 32));
-    pi_c = G1::add(pi_c, G1::mul_bytes(pib1, rb, 32));
+    G1::Pt pi_c = G1::add(M.C, M.H);
+    pi_c = G1::add(pi_c, G1::mul_bytes(pi_a, B.sb(), 32));
+    pi_c = G1::add(pi_c, G1::mul_bytes(pib1, B.rb(), 32));
     pi_c = G1::add(pi_c, G1::neg(pp.rs_delta1));
-
     // affine + fromMontgomery (:706-712); infinity prints as (0, 1, 0)
     Jac<Fq> a = G1::to_affine_jac(pi_a), c = G1::to_affine_jac(pi_c);
     Jac<Fq2> b = G2::to_affine_jac(pi_b);
@@ -210,6 +240,61 @@ int groth16_prove(ProvingKey* K, const Fe* d_witness, const uint8_t* r32, const 
     store_plain(out384 + 160, b.y.c0); store_plain(out384 + 192, b.y.c1);
     store_plain(out384 + 224, b.z.c0); store_plain(out384 + 256, b.z.c1);
     store_plain(out384 + 288, c.x); store_plain(out384 + 320, c.y); store_plain(out384 + 352, c.z);
+}
+
+// witness on the device
+int groth16_prove(ProvingKey* K, const Fe* d_witness, const uint8_t* r32, const uint8_t* s32, uint8_t* out384,
+                  hipStream_t s) {
+    Context* C = ctx();
+    if (!C) return WS_ERR_NOINIT;
+    if (!s) s = C->stream;
+    Blinding B;
+    int rc = start_blinding(K, r32, s32, &B);
+    if (rc) return rc;
+    MsmSums M;
+    if ((rc = prove_msms(K, d_witness, &M, s))) return rc;
+    prove_assemble(K, M, B, out384);
+    return WS_OK;
+}
+
+// ---- multi-GPU proving: per-rank partial sums, then one 576-byte record per rank to combine ----
+// record = A | B1 | C | H (4 x 96 B G1) | B2 (192 B G2), Jacobian-Montgomery, affine-normalised
+int groth16_prove_partial(ProvingKey* K, const uint8_t* witness, size_t witness_len, uint8_t* out576) {
+    Context* C = ctx();
+    if (!C) return WS_ERR_NOINIT;
+    if ((uint64_t)witness_len < (uint64_t)K->n_vars * 32) { set_last_error("witness shorter than nVars*32 bytes"); return WS_ERR_SIZE; }
+    std::lock_guard<std::mutex> lk(K->mu);
+    WS_HIP_CHECK(hipMemcpyAsync(K->witness.p, witness, (size_t)K->n_vars * 32, hipMemcpyHostToDevice, C->stream));
+    MsmSums M;
+    int rc = prove_msms(K, K->witness.as<Fe>(), &M, C->stream);
+    if (rc) return rc;
+    Jac<Fq> j;
+    j = G1::to_affine_jac(M.A); memcpy(out576, &j, 96);
+    j = G1::to_affine_jac(M.B1); memcpy(out576 + 96, &j, 96);
+    j = G1::to_affine_jac(M.C); memcpy(out576 + 192, &j, 96);
+    j = G1::to_affine_jac(M.H); memcpy(out576 + 288, &j, 96);
+    Jac<Fq2> j2 = G2::to_affine_jac(M.B2); memcpy(out576 + 384, &j2, 192);
+    return WS_OK;
+}
+int groth16_prove_finish(ProvingKey* K, const uint8_t* partials, uint64_t n_ranks, const uint8_t* r32,
+                         const uint8_t* s32, uint8_t* out384) {
+    Blinding B;
+    int rc = start_blinding(K, r32, s32, &B);
+    if (rc) return rc;
+    MsmSums M;
+    M.A = M.B1 = M.C = M.H = G1::infinity();
+    M.B2 = G2::infinity();
+    for (uint64_t i = 0; i < n_ranks; i++) {
+        const uint8_t* rec = partials + i * 576;
+        Jac<Fq> j;
+        memcpy(&j, rec, 96); M.A = G1::add(M.A, G1::from_jac(j));
+        memcpy(&j, rec + 96, 96); M.B1 = G1::add(M.B1, G1::from_jac(j));
+        memcpy(&j, rec + 192, 96); M.C = G1::add(M.C, G1::from_jac(j));
+        memcpy(&j, rec + 288, 96); M.H = G1::add(M.H, G1::from_jac(j));
+        Jac<Fq2> j2;
+        memcpy(&j2, rec + 384, 192); M.B2 = G2::add(M.B2, G2::from_jac(j2));
+    }
+    prove_assemble(K, M, B, out384);
     return WS_OK;
 }
 

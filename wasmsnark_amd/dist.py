@@ -40,3 +40,16 @@ def sharded_msm(bn, g, local_partial, device=None):
     """Combine per-rank partial MSM results (Jacobian-Montgomery bytes) into the full sum."""
     allp = allgather_partials(local_partial, device)
     return bn.g1_sum(allp) if g == 1 else bn.g2_sum(allp)
+
+
+def sharded_prove(bn, key, witness, r=None, s=None, device=None):
+    """Groth16 proof with the MSM windows sharded over the ranks (one process per GPU, same key and
+    witness everywhere): every rank computes its 576-byte record of partial sums, ONE all_gather, then
+    every rank assembles the identical proof on the host.  r, s must be the same on all ranks."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    bn.set_window_shard(rank, world)
+    try:
+        part = bn.groth16_prove_partial(witness, key)
+    finally:
+        bn.set_window_shard(0, 1)
+    return bn.groth16_prove_finish(key, allgather_partials(part, device), r=r, s=s)
