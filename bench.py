@@ -60,6 +60,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    if local_rank == 0:
+        import __graft_entry__
+        __graft_entry__.ensure_built()      # in-tree hipcc build if the library is not there yet
+    if world > 1:
+        dist.barrier()
     import wasmsnark_amd
     from wasmsnark_amd import dist as wdist
     bn = wasmsnark_amd.build(device=local_rank)

@@ -23,6 +23,8 @@ B64 = base64.b64decode
 def bn():
     import torch
     assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import __graft_entry__
+    __graft_entry__.ensure_built()     # hipcc is in the image: build in-tree if the snapshot came without the .so
     import wasmsnark_amd
     b = wasmsnark_amd.build(device=0)
     assert b.lib.path.endswith("wasmsnark_amd/libwsnark.so")   # the native HIP library, in-tree

@@ -49,6 +49,8 @@ def test_node_addon_fails_loudly_without_gpu():
 @needs_node
 @pytest.mark.gpu
 def test_node_dropin_on_gpu():
+    import __graft_entry__
+    __graft_entry__.ensure_built()
     _build_addon()
     out = _run({})
     assert out.returncode == 0 and "NODE_DROPIN_OK" in out.stdout, out.stdout + out.stderr
