@@ -177,6 +177,7 @@ struct Field {
     }
     WS_HD static Fe dbl(const Fe& a) { return add(a, a); }
     WS_HD static Fe add_lazy(const Fe& a, const Fe& b) { return add(a, b); }   // (no lazy form for the saturated limbs)
+    static constexpr bool kHasMul2Add = false;
 
     // build_f1m.js:86-100
     WS_HD static Fe sub(const Fe& a, const Fe& b) {

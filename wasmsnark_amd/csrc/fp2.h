@@ -5,6 +5,8 @@
 // non-residue map is f1m_neg, src/bn128/build_bn128.js:40).
 // Layout: (c0, c1) = 64 bytes, each Montgomery LE, as in the reference.
 #pragma once
+#include <type_traits>
+
 #include "field.h"
 
 namespace wsnark {
@@ -35,8 +37,16 @@ struct Fp2T {
     WS_HD static El sub(const El& a, const El& b) { return El{B::sub(a.c0, b.c0), B::sub(a.c1, b.c1)}; }
     WS_HD static El neg(const El& a) { return El{B::neg(a.c0), B::neg(a.c1)}; }
     WS_HD static El cneg(const El& a, bool s) { return s ? neg(a) : a; }
-    // Karatsuba, 3 base-field products (build_f2m.js:127-163)
-    WS_HD static El mul(const El& a, const El& b) {
+    // (a0 + a1 u)(b0 + b1 u) = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u.  The reference uses Karatsuba with 3
+    // base-field products (build_f2m.js:127-163); with a fused double product (one Montgomery reduction per
+    // component) the radix-2^29 field does it in two calls and one negation: ~30 % fewer instructions.
+    template <class BB = B>
+    WS_HD static typename std::enable_if<BB::kHasMul2Add, El>::type mul(const El& a, const El& b) {
+        const BE nb1 = B::neg(b.c1);
+        return El{B::mul2add(a.c0, b.c0, a.c1, nb1), B::mul2add(a.c0, b.c1, a.c1, b.c0)};
+    }
+    template <class BB = B>
+    WS_HD static typename std::enable_if<!BB::kHasMul2Add, El>::type mul(const El& a, const El& b) {
         BE A = B::mul(a.c0, b.c0);
         BE Bv = B::mul(a.c1, b.c1);
         BE C = B::mul(B::add_lazy(a.c0, a.c1), B::add_lazy(b.c0, b.c1));   // sums feed a product only
