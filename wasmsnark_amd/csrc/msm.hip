@@ -35,6 +35,9 @@ namespace wsnark {
 #ifndef WS_ACC_WAVES_G2
 #define WS_ACC_WAVES_G2 2
 #endif
+#ifndef WS_G2_PREFETCH
+#define WS_G2_PREFETCH 0
+#endif
 static const uint32_t CHUNK = 8;          // buckets per msm_chunks lane
 
 struct MsmScratch {
@@ -97,7 +100,7 @@ __device__ __forceinline__ typename C::Pt accumulate_range(const typename C::Aff
                                                            const uint32_t* __restrict__ vals, uint32_t s, uint32_t len) {
     typename C::Pt acc = C::infinity();
     if (len == 0) return acc;
-    if (sizeof(typename C::AffP) > 64) {
+    if (sizeof(typename C::AffP) > 64 && !WS_G2_PREFETCH) {
         // G2: the accumulator alone is 72 VGPRs; holding a prefetched 128-byte point as well costs a
         // wavefront of occupancy, so the gather is issued just before use
         for (uint32_t k = 0; k < len; k++) {
