@@ -80,7 +80,7 @@ struct Curve {
         El X2 = F::sqr(p.x);
         El M = F::add(F::dbl(X2), X2);
         El X3 = F::sub(F::sqr(M), F::dbl(S));
-        El Y3 = F::sub(F::mul(M, F::sub(S, X3)), F::mul(W, p.y));
+        El Y3 = F::sub(F::mul(M, F::sub_weak(S, X3)), F::mul(W, p.y));
         return Pt{X3, Y3, F::mul(V, p.zz), F::mul(W, p.zzz)};
     }
     // doubling of an affine point (mdbl-2008-s-1)
@@ -92,7 +92,7 @@ struct Curve {
         El X2 = F::sqr(x);
         El M = F::add(F::dbl(X2), X2);
         El X3 = F::sub(F::sqr(M), F::dbl(S));
-        El Y3 = F::sub(F::mul(M, F::sub(S, X3)), F::mul(W, y));
+        El Y3 = F::sub(F::mul(M, F::sub_weak(S, X3)), F::mul(W, y));
         return Pt{X3, Y3, V, W};
     }
 
@@ -108,10 +108,12 @@ struct Curve {
         }
         El U2 = F::mul(a.x, acc.zz);
         El S2 = F::mul(y2, acc.zzz);
-        El P = F::sub(U2, acc.x);
-        El R = F::sub(S2, acc.y);
-        if (F::is_zero(P)) {
-            if (F::is_zero(R)) acc = dbl_affine(a.x, y2);
+        // P, R and (Q - X3) only feed products (and the zero tests): the uncorrected "weak" difference
+        // saves the second carry pass on the radix-2^29 field (plain sub elsewhere)
+        El P = F::sub_weak(U2, acc.x);
+        El R = F::sub_weak(S2, acc.y);
+        if (F::is_zero_weak(P)) {
+            if (F::is_zero_weak(R)) acc = dbl_affine(a.x, y2);
             else acc = infinity();
             return;
         }
@@ -119,7 +121,7 @@ struct Curve {
         El PPP = F::mul(P, PP);
         El Q = F::mul(acc.x, PP);
         El X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
-        El Y3 = F::sub(F::mul(R, F::sub(Q, X3)), F::mul(acc.y, PPP));
+        El Y3 = F::sub(F::mul(R, F::sub_weak(Q, X3)), F::mul(acc.y, PPP));
         acc.x = X3;
         acc.y = Y3;
         acc.zz = F::mul(acc.zz, PP);
@@ -134,17 +136,17 @@ struct Curve {
         El U2 = F::mul(b.x, a.zz);
         El S1 = F::mul(a.y, b.zzz);
         El S2 = F::mul(b.y, a.zzz);
-        El P = F::sub(U2, U1);
-        El R = F::sub(S2, S1);
-        if (F::is_zero(P)) {
-            if (F::is_zero(R)) return dbl(a);
+        El P = F::sub_weak(U2, U1);
+        El R = F::sub_weak(S2, S1);
+        if (F::is_zero_weak(P)) {
+            if (F::is_zero_weak(R)) return dbl(a);
             return infinity();
         }
         El PP = F::sqr(P);
         El PPP = F::mul(P, PP);
         El Q = F::mul(U1, PP);
         El X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
-        El Y3 = F::sub(F::mul(R, F::sub(Q, X3)), F::mul(S1, PPP));
+        El Y3 = F::sub(F::mul(R, F::sub_weak(Q, X3)), F::mul(S1, PPP));
         return Pt{X3, Y3, F::mul(F::mul(a.zz, b.zz), PP), F::mul(F::mul(a.zzz, b.zzz), PPP)};
     }
 

@@ -178,6 +178,8 @@ struct Field {
     WS_HD static Fe dbl(const Fe& a) { return add(a, a); }
     WS_HD static Fe add_lazy(const Fe& a, const Fe& b) { return add(a, b); }   // (no lazy form for the saturated limbs)
     static constexpr bool kHasMul2Add = false;
+    WS_HD static Fe sub_weak(const Fe& a, const Fe& b) { return sub(a, b); }
+    WS_HD static bool is_zero_weak(const Fe& a) { return is_zero(a); }
 
     // build_f1m.js:86-100
     WS_HD static Fe sub(const Fe& a, const Fe& b) {

@@ -162,6 +162,28 @@ struct Field29 {
         d.v[8] = (uint32_t)((int32_t)a.v[8] - (int32_t)b.v[8] + (int32_t)p2_limb(8) + c);
         return cond_sub_2p(d);
     }
+    // a - b + 2p in (0, 4p) WITHOUT the final correction: tight limbs.  Valid only as an operand of
+    // mul / sqr / is_zero_weak (16 p^2 / 2^261 < 0.1 p keeps products below 2p).
+    WS_HD static F29 sub_weak(const F29& a, const F29& b) {
+        F29 d;
+        int32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int32_t t = (int32_t)a.v[i] - (int32_t)b.v[i] + (int32_t)p2_limb(i) + c;
+            d.v[i] = (uint32_t)t & WS_M29;
+            c = t >> 29;
+        }
+        d.v[8] = (uint32_t)((int32_t)a.v[8] - (int32_t)b.v[8] + (int32_t)p2_limb(8) + c);
+        return d;
+    }
+    // zero test for a sub_weak result (value in (0, 4p)): zero iff p, 2p or 3p
+    WS_HD static bool is_zero_weak(const F29& a) {
+        // cheap filter on the lowest limb first (a multiple of p matches one of three constants)
+        const uint32_t l0 = a.v[0];
+        if (l0 != p_limb(0) && l0 != p2_limb(0) && l0 != ((p_limb(0) + p2_limb(0)) & WS_M29)) return false;
+        F29 t = cond_sub_2p(a);        // now in [0, 2p)
+        return is_zero(t);
+    }
     WS_HD static F29 neg(const F29& a) {
         uint32_t o = 0;
 #pragma unroll

@@ -35,6 +35,9 @@ struct Fp2T {
     WS_HD static El add(const El& a, const El& b) { return El{B::add(a.c0, b.c0), B::add(a.c1, b.c1)}; }
     WS_HD static El dbl(const El& a) { return El{B::dbl(a.c0), B::dbl(a.c1)}; }
     WS_HD static El sub(const El& a, const El& b) { return El{B::sub(a.c0, b.c0), B::sub(a.c1, b.c1)}; }
+    // (the quadratic extension keeps strict operands: its products negate and re-add components)
+    WS_HD static El sub_weak(const El& a, const El& b) { return sub(a, b); }
+    WS_HD static bool is_zero_weak(const El& a) { return is_zero(a); }
     WS_HD static El neg(const El& a) { return El{B::neg(a.c0), B::neg(a.c1)}; }
     WS_HD static El cneg(const El& a, bool s) { return s ? neg(a) : a; }
     // (a0 + a1 u)(b0 + b1 u) = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u.  The reference uses Karatsuba with 3
