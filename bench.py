@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--no-extras", action="store_true", help="skip the NTT / prove extras")
+    ap.add_argument("--extras", default="ntt,skewed,prove", help="comma list of extras to run: ntt, skewed, prove")
     ap.add_argument("--prove-log-domain", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["msm", "prove"], default="msm",
@@ -159,9 +160,12 @@ def main():
            "roofline": roof, "kernel_ms": kernel_ms}
 
     # ---------------- extras: NTT 2^22 and full prove ----------------
-    if not args.no_extras and world == 1:
+    want = set() if args.no_extras else set(x for x in args.extras.split(",") if x)
+    if want and world == 1:
         extras = {}
         try:
+            if "ntt" not in want:
+                raise KeyError("skip")
             m = 1 << 22
             x = torch.from_numpy(rng.integers(0, 256, size=(m, 32), dtype=np.uint8))
             x[:, 31] &= 0x1F
@@ -182,9 +186,13 @@ def main():
             extras["ntt_2p22_hbm_frac"] = round(2 * 64.0 * m / t / 1e9 / HBM_PEAK_GBS, 5)
             extras["ntt_kernel_ms"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in bn.lib.timing_report().items()}
             del dx
+        except KeyError:
+            pass
         except Exception as e:  # noqa: BLE001
             extras["ntt_error"] = repr(e)
         try:
+            if "skewed" not in want:
+                raise KeyError("skip")
             # the same MSM with a circuit-like scalar distribution (example-witness
             # histogram: 6.7 % zeros, 3.1 % ones, 10 % < 2^32, the rest full width): exercises hot buckets
             u = rng.random(n)
@@ -207,9 +215,11 @@ def main():
             extras["msm_circuit_like_scalars_ms"] = round(t * 1e3, 4)
             extras["msm_circuit_like_kernel_ms"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in bn.lib.timing_report().items()}
             del d_sk
+        except KeyError:
+            pass
         except Exception as e:  # noqa: BLE001
             extras["msm_circuit_like_error"] = repr(e)
-        if args.prove_log_domain:
+        if args.prove_log_domain and "prove" in want:
             try:
                 from wasmsnark_amd import synth
                 t0 = time.perf_counter()
