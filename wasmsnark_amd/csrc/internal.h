@@ -71,6 +71,7 @@ int msm_g2_exec_xyzz(const Affine<Fq2>* d_points, XYZZ<Fq2>* out_host, hipStream
 // for that copy and runs the serial host tail
 int msm_g1_launch(const Affine<Fq>* d_points, bool prepared, int* slot, hipStream_t s);
 int msm_g2_launch(const Affine<Fq2>* d_points, bool prepared, int* slot, hipStream_t s);
+int msm_g1_launch_batch(const Affine<Fq>* const* d_points, int nsets, bool prepared, int* slots, hipStream_t s);
 int msm_g1_finish(int slot, XYZZ<Fq>* out_host);
 int msm_g2_finish(int slot, XYZZ<Fq2>* out_host);
 void msm_abort_pending(hipStream_t s);

@@ -305,10 +305,21 @@ __global__ __launch_bounds__(64) void msm_combine_wave(const MultiBucket* __rest
 // 6. chunk sums: for CHUNK consecutive buckets of one window
 //    S = sum B_i,  A = sum (i - i0 + 1) B_i   (descending running sum)
 // ---------------------------------------------------------------------------
+// the reduction tail is latency-bound (a dependent chain of ~33 full additions), so up to 4 point sets that
+// share a plan (the prover's A, B1, C) go through it in ONE launch: blockIdx.y / .z selects the set
 template <class C>
-__global__ __launch_bounds__(256) void msm_chunks(const typename C::PtP* __restrict__ buckets, uint32_t nchunks,
-                                                    uint32_t m, typename C::PtP* __restrict__ chunkS,
-                                                    typename C::PtP* __restrict__ chunkA) {
+struct TailSets {
+    const typename C::PtP* buckets[4];
+    typename C::PtP* chunkS[4];
+    typename C::PtP* chunkA[4];
+    typename C::PtP* sums[4];
+};
+
+template <class C>
+__global__ __launch_bounds__(256) void msm_chunks(TailSets<C> ts, uint32_t nchunks, uint32_t m) {
+    const typename C::PtP* __restrict__ buckets = ts.buckets[blockIdx.y];
+    typename C::PtP* __restrict__ chunkS = ts.chunkS[blockIdx.y];
+    typename C::PtP* __restrict__ chunkA = ts.chunkA[blockIdx.y];
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nchunks) return;
     typename C::Pt run = C::infinity(), acc = C::infinity();
@@ -326,9 +337,11 @@ __global__ __launch_bounds__(256) void msm_chunks(const typename C::PtP* __restr
 //    q < logJ : U_q = sum_{j : bit q of j set} S_j ;  q == logJ : sum_j A_j
 // ---------------------------------------------------------------------------
 template <class C>
-__global__ __launch_bounds__(sizeof(typename C::PtP) > 128 ? 256 : 512) void msm_tree(const typename C::PtP* __restrict__ chunkS,
-                                                   const typename C::PtP* __restrict__ chunkA, uint32_t J,
-                                                   uint32_t logJ, typename C::PtP* __restrict__ sums) {
+__global__ __launch_bounds__(sizeof(typename C::PtP) > 128 ? 256 : 512) void msm_tree(TailSets<C> ts, uint32_t J,
+                                                                                           uint32_t logJ) {
+    const typename C::PtP* __restrict__ chunkS = ts.chunkS[blockIdx.z];
+    const typename C::PtP* __restrict__ chunkA = ts.chunkA[blockIdx.z];
+    typename C::PtP* __restrict__ sums = ts.sums[blockIdx.z];
     WS_DYN_SMEM(typename C::PtP, sh);
     const uint32_t q = blockIdx.x, w = blockIdx.y;
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
@@ -407,18 +420,16 @@ struct MsmPending {
     MsmPlanInfo info;
     DevBuf d_sums, d_queue;
     MsmScratch S;                 // this launch's accumulation buffers (buckets, partials, chunk sums)
-    hipStream_t stream = nullptr; // every slot runs on its own stream: the latency-bound reduction kernels of
-                                  // one point set overlap the accumulation of the next
     void* h_sums = nullptr;
     size_t h_bytes = 0;
+    bool acc_done = false;
     hipEvent_t ev = nullptr, ev_acc = nullptr;
     void release() {
         if (h_sums) (void)hipHostFree(h_sums);
         if (ev) (void)hipEventDestroy(ev);
         if (ev_acc) (void)hipEventDestroy(ev_acc);
         ev_acc = nullptr;
-        if (stream) (void)hipStreamDestroy(stream);
-        h_sums = nullptr; ev = nullptr; stream = nullptr; h_bytes = 0; active = false;
+        h_sums = nullptr; ev = nullptr; h_bytes = 0; active = false;
         d_sums.release(); d_queue.release();
         S.buckets.release(); S.partials.release(); S.chunkS.release(); S.chunkA.release(); S.points_conv.release();
     }
@@ -435,7 +446,6 @@ void msm_abort_pending(hipStream_t s) {
     if (!g_slots) return;
     (void)hipStreamSynchronize(s);
     for (int i = 0; i < kPendingSlots; i++) {
-        if (g_slots[i].stream) (void)hipStreamSynchronize(g_slots[i].stream);
         g_slots[i].active = false;
     }
 }
@@ -583,7 +593,7 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
 // C = device curve (arithmetic of the kernels), H = host curve (reference-format results, host tail).
 // `prepared`: d_points are already in C's internal domain (msm_prepare_points).
 template <class C, class H>
-static int msm_launch(int which, const typename H::Aff* d_points_ref, bool prepared, int* slot_out, hipStream_t s) {
+static int msm_launch_acc(int which, const typename H::Aff* d_points_ref, bool prepared, int* slot_out, hipStream_t s) {
     typedef typename C::PtP Pt;      // packed accumulator in global memory (same bytes as H::Pt)
     static_assert(sizeof(typename C::PtP) == sizeof(typename H::Pt) && sizeof(typename C::AffP) == sizeof(typename H::Aff), "layouts");
     Context* X = ctx();
@@ -599,7 +609,8 @@ static int msm_launch(int which, const typename H::Aff* d_points_ref, bool prepa
     P.which = which;
     P.info = I;
     *slot_out = slot;
-    if (I.n == 0) { P.active = true; return WS_OK; }   // multiexp with n=0 leaves pr unchanged
+    P.active = true;
+    if (I.n == 0) return WS_OK;   // multiexp with n=0 leaves pr unchanged
     if (!d_points_ref) return WS_ERR_ARG;
     const typename C::AffP* d_points = reinterpret_cast<const typename C::AffP*>(d_points_ref);
     const uint64_t n = I.n;
@@ -608,9 +619,9 @@ static int msm_launch(int which, const typename H::Aff* d_points_ref, bool prepa
 
     MsmScratch& PS = *X->msm_scratch[0];        // plan buffers (read-only here)
     MsmScratch& S = P.S;                        // this launch's accumulation buffers
-    // everything runs in order on the caller's stream (concurrent accumulations only thrash the caches)
-    if (!P.stream) WS_HIP_CHECK(hipStreamCreateWithFlags(&P.stream, hipStreamNonBlocking));
-    if (!P.ev_acc) WS_HIP_CHECK(hipEventCreate(&P.ev_acc));
+    // Everything runs in order on the caller's stream.  Tried and measured slower on MI355X (round 1, sessions
+    // 7, 8, 11): accumulations on concurrent streams (cache thrash), and the reduction tail on a second,
+    // high-priority stream (the kernels starve each other: prove 2^20 16.4-16.7 ms vs 14.6 ms in order).
     WS_HIP_CHECK(S.buckets.reserve((size_t)nbuckets * sizeof(Pt)));
     WS_HIP_CHECK(S.partials.reserve((size_t)I.hot_cap * sizeof(Pt)));
     WS_HIP_CHECK(S.chunkS.reserve((size_t)W * J * sizeof(Pt)));
@@ -659,33 +670,66 @@ static int msm_launch(int which, const typename H::Aff* d_points_ref, bool prepa
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
 
-    // Optional (WSNARK_MSM_TAIL_STREAM=1): run the latency-bound reduction tail on the slot's own stream so it
-    // overlaps the next accumulation.  Measured on MI355X (round 1, sessions 7-8): a loss -- the concurrent
-    // kernels starve each other (prove 2^20: 16.4 ms vs 15.9 ms in order), so the default keeps one stream.
-    static const bool tail_stream = [] { const char* e = getenv("WSNARK_MSM_TAIL_STREAM"); return e && atoi(e) == 1; }();
-    if (tail_stream) {
-        WS_HIP_CHECK(hipEventRecord(P.ev_acc, s));
-        s = P.stream;
-        WS_HIP_CHECK(hipStreamWaitEvent(s, P.ev_acc, 0));
+    P.acc_done = true;
+    return WS_OK;
+}
+
+// reduction tail (chunks, tree, copy of the window sums, completion event) for up to 4 launches of one plan
+template <class C>
+static int msm_launch_tail(const int* slot_ids, int nslots, hipStream_t s) {
+    typedef typename C::PtP Pt;
+    Context* X = ctx();
+    if (!s) s = X->stream;
+    MsmPending* slots = pending_slots();
+    const MsmPlanInfo& I = slots[slot_ids[0]].info;
+    if (I.n == 0) return WS_OK;
+    TailSets<C> ts;
+    for (int k = 0; k < 4; k++) {
+        MsmPending& P = slots[slot_ids[k < nslots ? k : 0]];
+        ts.buckets[k] = P.S.buckets.template as<Pt>();
+        ts.chunkS[k] = P.S.chunkS.template as<Pt>();
+        ts.chunkA[k] = P.S.chunkA.template as<Pt>();
+        ts.sums[k] = P.d_sums.template as<Pt>();
     }
+    const uint32_t W = I.W, J = I.J, logJ = I.logJ, nsum = I.nsum, m = I.m;
+    KernelTimer& T = X->timer;
     T.begin("msm_chunks", s);
-    hipLaunchKernelGGL(msm_chunks<C>, dim3(ceil_div_u64((uint64_t)W * J, 256)), dim3(256), 0, s, S.buckets.as<Pt>(),
-                       W * J, m, S.chunkS.as<Pt>(), S.chunkA.as<Pt>());
+    hipLaunchKernelGGL(msm_chunks<C>, dim3(ceil_div_u64((uint64_t)W * J, 256), nslots), dim3(256), 0, s, ts, W * J, m);
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
-
     uint32_t tthreads = 1;
     const uint32_t tmax = sizeof(Pt) > 128 ? 256 : 512;   // LDS: threads * sizeof(packed point) <= 64 KiB
     while (tthreads < J && tthreads < tmax) tthreads <<= 1;
     T.begin("msm_tree", s);
-    hipLaunchKernelGGL(msm_tree<C>, dim3(nsum, W), dim3(tthreads), (size_t)tthreads * sizeof(Pt), s,
-                       S.chunkS.as<Pt>(), S.chunkA.as<Pt>(), J, logJ, P.d_sums.as<Pt>());
+    hipLaunchKernelGGL(msm_tree<C>, dim3(nsum, W, nslots), dim3(tthreads), (size_t)tthreads * sizeof(Pt), s, ts, J, logJ);
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
-    WS_HIP_CHECK(hipMemcpyAsync(P.h_sums, P.d_sums.p, sums_bytes, hipMemcpyDeviceToHost, s));
-    WS_HIP_CHECK(hipEventRecord(P.ev, s));
-    P.active = true;
+    const size_t sums_bytes = (size_t)W * nsum * sizeof(Pt);
+    for (int k = 0; k < nslots; k++) {
+        MsmPending& P = slots[slot_ids[k]];
+        WS_HIP_CHECK(hipMemcpyAsync(P.h_sums, P.d_sums.p, sums_bytes, hipMemcpyDeviceToHost, s));
+        WS_HIP_CHECK(hipEventRecord(P.ev, s));
+    }
     return WS_OK;
+}
+
+template <class C, class H>
+static int msm_launch(int which, const typename H::Aff* d_points_ref, bool prepared, int* slot_out, hipStream_t s) {
+    int rc = msm_launch_acc<C, H>(which, d_points_ref, prepared, slot_out, s);
+    if (rc) return rc;
+    return msm_launch_tail<C>(slot_out, 1, s);
+}
+
+// several G1 point sets against the current plan: accumulations back to back, then ONE batched tail
+int msm_g1_launch_batch(const Affine<Fq>* const* d_points, int nsets, bool prepared, int* slots, hipStream_t s) {
+    if (!ctx()) return WS_ERR_NOINIT;
+    if (nsets < 1 || nsets > 4) return WS_ERR_ARG;
+    for (int k = 0; k < nsets; k++) {
+        int rc = msm_uses_field29() ? msm_launch_acc<G1R29, G1>(0, d_points[k], prepared, &slots[k], s)
+                                    : msm_launch_acc<G1, G1>(0, d_points[k], prepared, &slots[k], s);
+        if (rc) return rc;
+    }
+    return msm_uses_field29() ? msm_launch_tail<G1R29>(slots, nsets, s) : msm_launch_tail<G1>(slots, nsets, s);
 }
 
 int msm_g1_launch(const Affine<Fq>* d_points, bool prepared, int* slot, hipStream_t s) {

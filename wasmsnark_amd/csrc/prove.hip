@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <chrono>
 #include <future>
 
 #include "internal.h"
@@ -143,6 +144,21 @@ static void store_plain(uint8_t* dst, const Fe& mont) {
     memcpy(dst, &p, 32);
 }
 
+// WSNARK_TRACE=1: host-side wall-clock of the proof phases on stderr
+struct Trace {
+    bool on;
+    std::chrono::steady_clock::time_point t0, last;
+    Trace() : on(getenv("WSNARK_TRACE") && atoi(getenv("WSNARK_TRACE")) == 1) { t0 = last = std::chrono::steady_clock::now(); }
+    void mark(const char* what) {
+        if (!on) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[wsnark trace] %-28s +%8.3f ms  (t=%8.3f)\n", what,
+                std::chrono::duration<double, std::milli>(now - last).count(),
+                std::chrono::duration<double, std::milli>(now - t0).count());
+        last = now;
+    }
+};
+
 struct MsmSums {
     XYZZ<Fq> A, B1, C, H;
     XYZZ<Fq2> B2;
@@ -152,28 +168,39 @@ struct MsmSums {
 // (wsnark_set_window_shard) the sums are this rank's partial sums.
 static int prove_msms(ProvingKey* K, const Fe* d_witness, MsmSums* out, hipStream_t s) {
     Context* C = ctx();
+    Trace tr;
     const uint32_t nv = K->n_vars, dom = K->domain;
     int rc;
     // CALC_H, then the H MSM over domainSize pairs (src/bn128.js:607-615)
     Fe* d_h = K->h.as<Fe>();
     if ((rc = calc_h_dev(d_witness, nv, K->polsA, K->polsB, dom, d_h, s))) return rc;
+    tr.mark("calc_h enqueued");
     std::lock_guard<std::mutex> lk(C->mu);   // the digit/sort plan and the MSM scratch are per context
     int hH = -1, hA = -1, hB1 = -1, hB2 = -1, hC = -1;
     struct Abort { hipStream_t s; bool armed; ~Abort() { if (armed) msm_abort_pending(s); } } guard{s, true};
     if ((rc = msm_plan_dev(d_h, dom, s))) return rc;
     if ((rc = msm_g1_launch(K->pointsH.as<Affine<Fq>>(), true, &hH, s))) return rc;                    // :614
+    tr.mark("plan(h) + launch H");
     // one plan for the four sums whose scalars are the witness (:617-620); each host tail runs while
     // the GPU already accumulates the next point set
     if ((rc = msm_plan_dev(d_witness, nv, s))) return rc;
-    if ((rc = msm_g1_launch(K->pointsA.as<Affine<Fq>>(), true, &hA, s))) return rc;                    // :617
+    // A, B1 and C share the plan: three accumulations back to back, then ONE batched reduction tail
+    // (the tail is a latency-bound chain of ~33 dependent additions; three sets ride it for the price of one)
+    const Affine<Fq>* g1sets[3] = {K->pointsA.as<Affine<Fq>>(), K->pointsB1.as<Affine<Fq>>(), K->pointsC.as<Affine<Fq>>()};
+    int g1slots[3] = {-1, -1, -1};
+    if ((rc = msm_g1_launch_batch(g1sets, 3, true, g1slots, s))) return rc;                              // :617, :618, :620 (padded)
+    hA = g1slots[0]; hB1 = g1slots[1]; hC = g1slots[2];
+    tr.mark("plan(w) + launch A,B1,C");
     if ((rc = msm_g1_finish(hH, &out->H))) return rc;
-    if ((rc = msm_g1_launch(K->pointsB1.as<Affine<Fq>>(), true, &hB1, s))) return rc;                  // :618
+    tr.mark("finish H");
     if ((rc = msm_g2_launch(K->pointsB2.as<Affine<Fq2>>(), true, &hB2, s))) return rc;                 // :619
-    if ((rc = msm_g1_launch(K->pointsC.as<Affine<Fq>>(), true, &hC, s))) return rc;                    // :620 (padded)
+    tr.mark("launch B2");
     if ((rc = msm_g1_finish(hA, &out->A))) return rc;
     if ((rc = msm_g1_finish(hB1, &out->B1))) return rc;
-    if ((rc = msm_g2_finish(hB2, &out->B2))) return rc;
     if ((rc = msm_g1_finish(hC, &out->C))) return rc;
+    tr.mark("finish A, B1, C");
+    if ((rc = msm_g2_finish(hB2, &out->B2))) return rc;
+    tr.mark("finish B2");
     guard.armed = false;
     return WS_OK;
 }
@@ -253,7 +280,9 @@ int groth16_prove(ProvingKey* K, const Fe* d_witness, const uint8_t* r32, const 
     if (rc) return rc;
     MsmSums M;
     if ((rc = prove_msms(K, d_witness, &M, s))) return rc;
+    Trace tr;
     prove_assemble(K, M, B, out384);
+    tr.mark("assemble (host)");
     return WS_OK;
 }
 
