@@ -192,6 +192,7 @@ typedef Curve<Fq> G1;
 typedef Curve<Fq2> G2;
 // device-side curves over the carry-free radix-2^29 field (heavy kernels only)
 typedef Curve<Fq29> G1R29;
+typedef Curve<Fq29I> G1R29I;   // inlined products: reduction-tail kernels
 typedef Curve<Fp2T<Fq29>> G2R29;
 
 }  // namespace wsnark

@@ -48,6 +48,7 @@ struct Fr29Params : FrParams {
 template <class P> WS_NOINLINE_DEV F29 mont_mul29(WS_L9(a), WS_L9(b));
 template <class P> WS_NOINLINE_DEV F29 mont_sqr29(WS_L9(a));
 template <class P> WS_NOINLINE_DEV F29 mont_mul2add29(WS_L9(a), WS_L9(b), WS_L9(c), WS_L9(d));
+template <class P> WS_HD F29 mont_mul29_body(const F29& a, const F29& b);
 
 #define WS_M29 0x1FFFFFFFu
 
@@ -242,8 +243,14 @@ struct Field29 {
 
 template <class P>
 WS_NOINLINE_DEV F29 mont_mul29(WS_L9(a), WS_L9(b)) {
-    typedef Field29<P> F;
     const F29 a = {{a0, a1, a2, a3, a4, a5, a6, a7, a8}}, b = {{b0, b1, b2, b3, b4, b5, b6, b7, b8}};
+    return mont_mul29_body<P>(a, b);
+}
+// the same product as an inlinable body: latency-bound kernels (the MSM reduction tail runs ~1 wavefront
+// per SIMD) let the compiler interleave the independent products of one group addition
+template <class P>
+WS_HD F29 mont_mul29_body(const F29& a, const F29& b) {
+    typedef Field29<P> F;
     uint32_t m[9];
     uint64_t acc = 0;
     F29 r;
@@ -340,7 +347,15 @@ WS_NOINLINE_DEV F29 mont_sqr29(WS_L9(a)) {
     return r;
 }
 
+// variant whose products are inlined (see mont_mul29_body)
+template <class P>
+struct Field29I : Field29<P> {
+    WS_HD static F29 mul(const F29& a, const F29& b) { return mont_mul29_body<P>(a, b); }
+    WS_HD static F29 sqr(const F29& a) { return mont_mul29_body<P>(a, a); }
+};
+
 typedef Field29<Fq29Params> Fq29;
+typedef Field29I<Fq29Params> Fq29I;
 typedef Field29<Fr29Params> Fr29;
 
 }  // namespace wsnark

@@ -347,8 +347,15 @@ __global__ __launch_bounds__(sizeof(typename C::PtP) > 128 ? 256 : 512) void msm
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     const typename C::PtP* src = (q == logJ ? chunkA : chunkS) + (uint64_t)w * J;
     typename C::Pt acc = C::infinity();
-    for (uint32_t j = tid; j < J; j += nthr) {
-        if (q == logJ || ((j >> q) & 1)) acc = C::add(acc, C::unpack_pt(src[j]));
+    if (q == logJ) {
+        for (uint32_t j = tid; j < J; j += nthr) acc = C::add(acc, C::unpack_pt(src[j]));
+    } else {
+        // enumerate only the J/2 indices whose bit q is set (insert a 1 at bit q): every lane stays busy
+        const uint32_t low = (1u << q) - 1;
+        for (uint32_t i = tid; i < (J >> 1); i += nthr) {
+            const uint32_t j = ((i & ~low) << 1) | (1u << q) | (i & low);
+            acc = C::add(acc, C::unpack_pt(src[j]));
+        }
     }
     sh[tid] = C::pack_pt(acc);
     __syncthreads();
@@ -674,6 +681,16 @@ static int msm_launch_acc(int which, const typename H::Aff* d_points_ref, bool p
     return WS_OK;
 }
 
+// which curve type the tail kernels are instantiated with: G1 on the radix-2^29 field uses the variant with
+// inlined products (same packed layouts), everything else the accumulation's own type
+template <class C> struct TailCurve { typedef C type; };
+#ifndef WS_TAIL_INLINE
+#define WS_TAIL_INLINE 1
+#endif
+#if WS_TAIL_INLINE
+template <> struct TailCurve<G1R29> { typedef G1R29I type; };
+#endif
+
 // reduction tail (chunks, tree, copy of the window sums, completion event) for up to 4 launches of one plan
 template <class C>
 static int msm_launch_tail(const int* slot_ids, int nslots, hipStream_t s) {
@@ -717,7 +734,7 @@ template <class C, class H>
 static int msm_launch(int which, const typename H::Aff* d_points_ref, bool prepared, int* slot_out, hipStream_t s) {
     int rc = msm_launch_acc<C, H>(which, d_points_ref, prepared, slot_out, s);
     if (rc) return rc;
-    return msm_launch_tail<C>(slot_out, 1, s);
+    return msm_launch_tail<typename TailCurve<C>::type>(slot_out, 1, s);
 }
 
 // several G1 point sets against the current plan: accumulations back to back, then ONE batched tail
@@ -729,7 +746,7 @@ int msm_g1_launch_batch(const Affine<Fq>* const* d_points, int nsets, bool prepa
                                     : msm_launch_acc<G1, G1>(0, d_points[k], prepared, &slots[k], s);
         if (rc) return rc;
     }
-    return msm_uses_field29() ? msm_launch_tail<G1R29>(slots, nsets, s) : msm_launch_tail<G1>(slots, nsets, s);
+    return msm_uses_field29() ? msm_launch_tail<TailCurve<G1R29>::type>(slots, nsets, s) : msm_launch_tail<G1>(slots, nsets, s);
 }
 
 int msm_g1_launch(const Affine<Fq>* d_points, bool prepared, int* slot, hipStream_t s) {
