@@ -20,6 +20,8 @@
 //   7 msm_tree        per (window, bit q): LDS tree sums U_q = sum_{j: bit q} S_j, and sum A_j
 //   8 host            sum_w 2^(c w) (A_w + 8 sum_q 2^q U_{w,q}): ~W*(log J + 1) points, a serial
 //                      doubling chain that is faster on one CPU core than on one GPU lane.
+#include <string.h>
+
 #include <algorithm>
 
 #include "internal.h"
@@ -41,7 +43,7 @@ namespace wsnark {
 static const uint32_t CHUNK = 8;          // buckets per msm_chunks lane
 
 struct MsmScratch {
-    DevBuf keys, vals, keys_out, vals_out, sort_tmp;
+    DevBuf keys, vals, keys_out, vals_out, sort_tmp, entries, bins;
     DevBuf bstart, bend, buckets, counters, tasks, multi, partials;
     DevBuf chunkS, chunkA, sums, points_conv;
 };
@@ -75,6 +77,201 @@ __global__ __launch_bounds__(256) void msm_digits(const Fe* __restrict__ scalars
             keys[o] = d ? (k * NB + d - 1) : sentinel;   // zero digits sort behind every bucket
             vals[o] = i | (neg << 31);
             k++;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 1'/2'. bucket grouping without a general sort ("presort", the default).
+// Only the grouping matters (order inside a bucket is free), and keys have structure: window (known per
+// digit position) x 15-bit bucket.  So: (a) digits are extracted on the fly from the scalars -- no key
+// arrays are written; (b) ONE scatter into W*HB coarse bins (bin = window, top bits of the bucket) with
+// block-reserved ranges -- no stability needed, so ranks come from LDS atomics; (c) one workgroup per bin
+// finishes with an LDS counting sort over the low 7 bucket bits and writes the bucket bounds directly.
+// HBM traffic at 2^20: 2 x 32 MB scalars + 128 MB bins written + 128 MB read + 64 MB values written
+// (vs 160 MB digits + ~830 MB three-pass radix sort + 64 MB bounds).
+// ---------------------------------------------------------------------------
+static const uint32_t PRESORT_MAX_BINS = 4096; // W * HB, 16 KiB of LDS counters
+
+// calls f(k, d, neg) for every owned window k (local index) with a non-zero signed digit d in [1, NB]
+template <class Fn>
+__device__ __forceinline__ void for_each_digit(const Fe& raw, uint32_t c, uint32_t Wall, uint32_t w_off, uint32_t w_stride, Fn f) {
+    const Fe s = Fr::reduce_full(raw);
+    const uint32_t NB = 1u << (c - 1);
+    uint32_t carry = 0, k = 0;
+    for (uint32_t w = 0; w < Wall; w++) {
+        const uint32_t bit = w * c;
+        const uint32_t limb = bit >> 6, off = bit & 63;
+        uint64_t v = limb < 4 ? (s.l[limb] >> off) : 0;
+        if (off + c > 64 && limb + 1 < 4) v |= s.l[limb + 1] << (64 - off);
+        uint32_t d = (uint32_t)(v & ((1u << c) - 1)) + carry;
+        uint32_t neg = 0;
+        if (d > NB) { d = (1u << c) - d; neg = 1; carry = 1; } else carry = 0;
+        if (w >= w_off && (w - w_off) % w_stride == 0) {
+            if (d) f(k, d, neg);
+            k++;
+        }
+    }
+}
+
+struct PresortArgs {
+    const Fe* scalars;
+    uint32_t n, c, Wall, w_off, w_stride;
+    uint32_t lo_bits, HB, nbins;       // bin = k*HB + ((d-1) >> lo_bits)
+    uint32_t tile;                     // scalars per workgroup
+    uint32_t idx_bits;                 // packed 4-byte entries: idx | neg << idx_bits | lo << (idx_bits+1)
+};
+
+// 8-byte entry = (low bucket bits << 32) | (index | sign << 31); 4-byte entries when bits(n)+1+lo_bits <= 32
+template <class E> struct PresortEntry;
+template <> struct PresortEntry<uint64_t> {
+    static __device__ __forceinline__ uint64_t make(uint32_t i, uint32_t neg, uint32_t lo, uint32_t) {
+        return ((uint64_t)lo << 32) | (uint64_t)(i | (neg << 31));
+    }
+    static __device__ __forceinline__ uint32_t lo(uint64_t e, uint32_t) { return (uint32_t)(e >> 32); }
+    static __device__ __forceinline__ uint32_t val(uint64_t e, uint32_t) { return (uint32_t)e; }
+};
+template <> struct PresortEntry<uint32_t> {
+    static __device__ __forceinline__ uint32_t make(uint32_t i, uint32_t neg, uint32_t lo, uint32_t ib) {
+        return i | (neg << ib) | (lo << (ib + 1));
+    }
+    static __device__ __forceinline__ uint32_t lo(uint32_t e, uint32_t ib) { return e >> (ib + 1); }
+    static __device__ __forceinline__ uint32_t val(uint32_t e, uint32_t ib) {
+        return (e & ((1u << ib) - 1)) | (((e >> ib) & 1u) << 31);
+    }
+};
+
+__global__ __launch_bounds__(1024) void presort_count(PresortArgs A, uint32_t* __restrict__ bin_count) {
+    __shared__ uint32_t cnt[PRESORT_MAX_BINS];
+    for (uint32_t b = threadIdx.x; b < A.nbins; b += blockDim.x) cnt[b] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * A.tile;
+    for (uint32_t i = base + threadIdx.x; i < base + A.tile && i < A.n; i += blockDim.x) {
+        for_each_digit(A.scalars[i], A.c, A.Wall, A.w_off, A.w_stride, [&](uint32_t k, uint32_t d, uint32_t) {
+            atomicAdd(&cnt[k * A.HB + ((d - 1) >> A.lo_bits)], 1u);
+        });
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < A.nbins; b += blockDim.x)
+        if (cnt[b]) atomicAdd(&bin_count[b], cnt[b]);
+}
+
+// exclusive scan of the (<= 4096) bin counts: bin_start[0..nbins], cursors = starts
+__global__ __launch_bounds__(256) void presort_scan(const uint32_t* __restrict__ bin_count, uint32_t nbins,
+                                                      uint32_t* __restrict__ bin_start, uint32_t* __restrict__ bin_cursor) {
+    __shared__ uint32_t part[256];
+    const uint32_t per = (nbins + 255) / 256, lo = threadIdx.x * per;
+    uint32_t sum = 0;
+    for (uint32_t b = lo; b < lo + per && b < nbins; b++) sum += bin_count[b];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t t = 0; t < 256; t++) { const uint32_t v = part[t]; part[t] = run; run += v; }
+        bin_start[nbins] = run;
+    }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (uint32_t b = lo; b < lo + per && b < nbins; b++) {
+        bin_start[b] = run;
+        bin_cursor[b] = run;
+        run += bin_count[b];
+    }
+}
+
+template <class E>
+__global__ __launch_bounds__(1024) void presort_scatter(PresortArgs A, uint32_t* __restrict__ bin_cursor, E* __restrict__ entries) {
+    __shared__ uint32_t cnt[PRESORT_MAX_BINS];
+    __shared__ uint32_t gbase[PRESORT_MAX_BINS];
+    for (uint32_t b = threadIdx.x; b < A.nbins; b += blockDim.x) cnt[b] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * A.tile;
+    for (uint32_t i = base + threadIdx.x; i < base + A.tile && i < A.n; i += blockDim.x) {
+        for_each_digit(A.scalars[i], A.c, A.Wall, A.w_off, A.w_stride, [&](uint32_t k, uint32_t d, uint32_t) {
+            atomicAdd(&cnt[k * A.HB + ((d - 1) >> A.lo_bits)], 1u);
+        });
+    }
+    __syncthreads();
+    // reserve this workgroup's range in every bin it touches; then reuse cnt[] as the local rank counters
+    for (uint32_t b = threadIdx.x; b < A.nbins; b += blockDim.x) {
+        const uint32_t c0 = cnt[b];
+        gbase[b] = c0 ? atomicAdd(&bin_cursor[b], c0) : 0;
+        cnt[b] = 0;
+    }
+    __syncthreads();
+    const uint32_t lo_mask = (1u << A.lo_bits) - 1;
+    for (uint32_t i = base + threadIdx.x; i < base + A.tile && i < A.n; i += blockDim.x) {
+        for_each_digit(A.scalars[i], A.c, A.Wall, A.w_off, A.w_stride, [&](uint32_t k, uint32_t d, uint32_t neg) {
+            const uint32_t b = k * A.HB + ((d - 1) >> A.lo_bits);
+            const uint32_t r = atomicAdd(&cnt[b], 1u);
+            entries[gbase[b] + r] = PresortEntry<E>::make(i, neg, (d - 1) & lo_mask, A.idx_bits);
+        });
+    }
+}
+
+// one workgroup per bin: LDS counting sort over the low bucket bits, bucket bounds written directly
+static const uint32_t PRESORT_MAX_LO = 10;
+template <class E>
+__global__ __launch_bounds__(1024) void presort_bins(const E* __restrict__ entries, const uint32_t* __restrict__ bin_start,
+                                                       uint32_t lo_bits, uint32_t idx_bits, uint32_t* __restrict__ vals_out,
+                                                       uint32_t* __restrict__ bstart, uint32_t* __restrict__ bend) {
+    __shared__ uint32_t sub[1u << PRESORT_MAX_LO];
+    __shared__ uint32_t off[1u << PRESORT_MAX_LO];
+    __shared__ uint32_t part[1024];
+    const uint32_t bin = blockIdx.x, SUB = 1u << lo_bits;
+    const uint32_t s = bin_start[bin], e = bin_start[bin + 1];
+    for (uint32_t t = threadIdx.x; t < SUB; t += blockDim.x) sub[t] = 0;
+    __syncthreads();
+    // four independent loads in flight per thread: the bin loops are latency-bound otherwise
+    for (uint32_t i = s + threadIdx.x; i < e; i += 4 * blockDim.x) {
+        E v[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t j = i + u * blockDim.x;
+            v[u] = j < e ? entries[j] : (E)0;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++)
+            if (i + u * blockDim.x < e) atomicAdd(&sub[PresortEntry<E>::lo(v[u], idx_bits)], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of sub[0..SUB): thread t owns `per` consecutive counters, Hillis-Steele over the partials
+    const uint32_t per = (SUB + blockDim.x - 1) / blockDim.x, t0 = threadIdx.x * per;
+    uint32_t mine = 0;
+    for (uint32_t t = t0; t < t0 + per && t < SUB; t++) mine += sub[t];
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    for (uint32_t d = 1; d < blockDim.x; d <<= 1) {
+        const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = s + part[threadIdx.x] - mine;
+    for (uint32_t t = t0; t < t0 + per && t < SUB; t++) {
+        const uint32_t cnt = sub[t];
+        const uint32_t bucket = (bin << lo_bits) + t;   // == k*NB + (hi << lo_bits | lo)
+        off[t] = run;
+        bstart[bucket] = run;
+        bend[bucket] = run + cnt;
+        run += cnt;
+        sub[t] = 0;                                     // becomes the placement cursor
+    }
+    __syncthreads();
+    for (uint32_t i = s + threadIdx.x; i < e; i += 4 * blockDim.x) {
+        E v[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t j = i + u * blockDim.x;
+            v[u] = j < e ? entries[j] : (E)0;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            if (i + u * blockDim.x < e) {
+                const uint32_t lo = PresortEntry<E>::lo(v[u], idx_bits);
+                const uint32_t r = atomicAdd(&sub[lo], 1u);
+                vals_out[off[lo] + r] = PresortEntry<E>::val(v[u], idx_bits);
+            }
         }
     }
 }
@@ -543,9 +740,6 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
     for (int i = 0; g_slots && i < kPendingSlots; i++)
         if (g_slots[i].active && g_slots[i].ev && g_slots[i].info.n) WS_HIP_CHECK(hipStreamWaitEvent(s, g_slots[i].ev, 0));
     MsmScratch& S = *X->msm_scratch[0];
-    WS_HIP_CHECK(S.keys.reserve(total * 4));
-    WS_HIP_CHECK(S.vals.reserve(total * 4));
-    WS_HIP_CHECK(S.keys_out.reserve(total * 4));
     WS_HIP_CHECK(S.vals_out.reserve(total * 4));
     WS_HIP_CHECK(S.bstart.reserve((size_t)nbuckets * 4));
     WS_HIP_CHECK(S.bend.reserve((size_t)nbuckets * 4));
@@ -554,29 +748,77 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
     WS_HIP_CHECK(S.multi.reserve((size_t)I.hot_cap * sizeof(MultiBucket)));
 
     KernelTimer& T = X->timer;
-    T.begin("msm_digits", s);
-    hipLaunchKernelGGL(msm_digits, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s, d_scalars, (uint32_t)n, c, I.Wall,
-                       I.w_off, I.w_stride, nbuckets, S.keys.as<uint32_t>(), S.vals.as<uint32_t>());
-    T.end(s);
-    WS_HIP_CHECK(hipGetLastError());
-
-    T.begin("msm_sort", s);
-    int key_bits = 1;
-    while (((uint64_t)1 << key_bits) <= nbuckets) key_bits++;   // keys are 0..nbuckets (nbuckets = "no digit")
-    int rc = sort_pairs(S, total, key_bits, s);
-    T.end(s);
-    if (rc) return rc;
-
     // counters: [0] partial slots, [1] multi-task buckets, [3] total tasks; [16..271] length histogram,
     // [272..527] cursors
     uint32_t* d_cnt = S.counters.as<uint32_t>();
-    WS_HIP_CHECK(hipMemsetAsync(S.bstart.p, 0, (size_t)nbuckets * 4, s));
-    WS_HIP_CHECK(hipMemsetAsync(S.bend.p, 0, (size_t)nbuckets * 4, s));
     WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, 4096, s));
-    T.begin("msm_bounds", s);
-    hipLaunchKernelGGL(msm_bounds, dim3(ceil_div_u64(total, 256)), dim3(256), 0, s, S.keys_out.as<uint32_t>(), total,
-                       nbuckets, S.bstart.as<uint32_t>(), S.bend.as<uint32_t>());
-    T.end(s);
+    static const bool use_cub = [] { const char* e = getenv("WSNARK_MSM_SORT"); return e && !strcmp(e, "cub"); }();
+    static const uint32_t env_lo = [] { const char* e = getenv("WSNARK_MSM_LO_BITS"); return e ? (uint32_t)atoi(e) : 7u; }();
+    static const uint32_t env_tile = [] { const char* e = getenv("WSNARK_MSM_TILE"); return e ? (uint32_t)atoi(e) : 1024u; }();
+    static const uint32_t env_thr = [] { const char* e = getenv("WSNARK_MSM_TILE_THREADS"); return e ? (uint32_t)atoi(e) : 1024u; }();
+    static const bool env_e64 = [] { const char* e = getenv("WSNARK_MSM_ENTRY64"); return e && atoi(e) != 0; }();
+    uint32_t lo_bits = env_lo > PRESORT_MAX_LO ? PRESORT_MAX_LO : env_lo;
+    if (lo_bits > c - 1) lo_bits = c - 1;
+    while ((uint64_t)W * (I.NB >> lo_bits) > PRESORT_MAX_BINS && lo_bits < c - 1 && lo_bits < PRESORT_MAX_LO) lo_bits++;
+    const uint32_t HB = I.NB >> lo_bits, nbins = W * HB;
+    if (!use_cub && nbins <= PRESORT_MAX_BINS) {
+        // ---- grouping by coarse bins + per-bin LDS counting sort (hand-written; see the kernels above) ----
+        uint32_t idx_bits = 1;
+        while (((uint64_t)1 << idx_bits) < n) idx_bits++;
+        const bool e32 = !env_e64 && idx_bits + 1 + lo_bits <= 32;
+        WS_HIP_CHECK(S.entries.reserve(total * (e32 ? 4 : 8)));
+        WS_HIP_CHECK(S.bins.reserve(((size_t)nbins + 1) * 4 * 3));
+        uint32_t* bin_count = S.bins.as<uint32_t>();
+        uint32_t* bin_start = bin_count + (nbins + 1);
+        uint32_t* bin_cursor = bin_start + (nbins + 1);
+        WS_HIP_CHECK(hipMemsetAsync(bin_count, 0, ((size_t)nbins + 1) * 4, s));
+        PresortArgs PA{d_scalars, (uint32_t)n, c, I.Wall, I.w_off, I.w_stride, lo_bits, HB, nbins, env_tile, idx_bits};
+        const dim3 grid(ceil_div_u64(n, env_tile)), blk(env_thr);
+        T.begin("msm_presort_count", s);
+        hipLaunchKernelGGL(presort_count, grid, blk, 0, s, PA, bin_count);
+        hipLaunchKernelGGL(presort_scan, dim3(1), dim3(256), 0, s, bin_count, nbins, bin_start, bin_cursor);
+        T.end(s);
+        T.begin("msm_presort_scatter", s);
+        if (e32) hipLaunchKernelGGL(presort_scatter<uint32_t>, grid, blk, 0, s, PA, bin_cursor, S.entries.as<uint32_t>());
+        else hipLaunchKernelGGL(presort_scatter<uint64_t>, grid, blk, 0, s, PA, bin_cursor, S.entries.as<uint64_t>());
+        T.end(s);
+        // one workgroup per bin, about eight entries per thread (two rounds of four loads in flight)
+        static const uint32_t env_bthr = [] { const char* e = getenv("WSNARK_MSM_BIN_THREADS"); return e ? (uint32_t)atoi(e) : 0u; }();
+        uint32_t bthr = env_bthr ? env_bthr : (uint32_t)((total / nbins / 8 + 63) / 64 * 64);
+        bthr = bthr < 64 ? 64 : bthr > 1024 ? 1024 : bthr;
+        const dim3 bblk(bthr);
+        T.begin("msm_presort_bins", s);
+        if (e32)
+            hipLaunchKernelGGL(presort_bins<uint32_t>, dim3(nbins), bblk, 0, s, S.entries.as<uint32_t>(), bin_start, lo_bits,
+                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>());
+        else
+            hipLaunchKernelGGL(presort_bins<uint64_t>, dim3(nbins), bblk, 0, s, S.entries.as<uint64_t>(), bin_start, lo_bits,
+                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>());
+        T.end(s);
+        WS_HIP_CHECK(hipGetLastError());
+    } else {
+        // ---- reference pipeline: explicit digit arrays + hipCUB radix sort (WSNARK_MSM_SORT=cub) ----
+        WS_HIP_CHECK(S.keys.reserve(total * 4));
+        WS_HIP_CHECK(S.vals.reserve(total * 4));
+        WS_HIP_CHECK(S.keys_out.reserve(total * 4));
+        T.begin("msm_digits", s);
+        hipLaunchKernelGGL(msm_digits, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s, d_scalars, (uint32_t)n, c, I.Wall,
+                           I.w_off, I.w_stride, nbuckets, S.keys.as<uint32_t>(), S.vals.as<uint32_t>());
+        T.end(s);
+        WS_HIP_CHECK(hipGetLastError());
+        T.begin("msm_sort", s);
+        int key_bits = 1;
+        while (((uint64_t)1 << key_bits) <= nbuckets) key_bits++;   // keys are 0..nbuckets (nbuckets = "no digit")
+        int rc = sort_pairs(S, total, key_bits, s);
+        T.end(s);
+        if (rc) return rc;
+        WS_HIP_CHECK(hipMemsetAsync(S.bstart.p, 0, (size_t)nbuckets * 4, s));
+        WS_HIP_CHECK(hipMemsetAsync(S.bend.p, 0, (size_t)nbuckets * 4, s));
+        T.begin("msm_bounds", s);
+        hipLaunchKernelGGL(msm_bounds, dim3(ceil_div_u64(total, 256)), dim3(256), 0, s, S.keys_out.as<uint32_t>(), total,
+                           nbuckets, S.bstart.as<uint32_t>(), S.bend.as<uint32_t>());
+        T.end(s);
+    }
     T.begin("msm_plan", s);
     hipLaunchKernelGGL(msm_plan_hist, dim3(ceil_div_u64(nbuckets, 256)), dim3(256), 0, s, S.bstart.as<uint32_t>(),
                        S.bend.as<uint32_t>(), nbuckets, lmax, d_cnt + 16);
