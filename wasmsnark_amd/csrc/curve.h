@@ -80,7 +80,7 @@ struct Curve {
         El X2 = F::sqr(p.x);
         El M = F::add(F::dbl(X2), X2);
         El X3 = F::sub(F::sqr(M), F::dbl(S));
-        El Y3 = F::sub(F::mul(M, F::sub_weak(S, X3)), F::mul(W, p.y));
+        El Y3 = F::mulsub2(M, F::sub_weak(S, X3), W, p.y);
         return Pt{X3, Y3, F::mul(V, p.zz), F::mul(W, p.zzz)};
     }
     // doubling of an affine point (mdbl-2008-s-1)
@@ -92,7 +92,7 @@ struct Curve {
         El X2 = F::sqr(x);
         El M = F::add(F::dbl(X2), X2);
         El X3 = F::sub(F::sqr(M), F::dbl(S));
-        El Y3 = F::sub(F::mul(M, F::sub_weak(S, X3)), F::mul(W, y));
+        El Y3 = F::mulsub2(M, F::sub_weak(S, X3), W, y);
         return Pt{X3, Y3, V, W};
     }
 
@@ -121,7 +121,7 @@ struct Curve {
         El PPP = F::mul(P, PP);
         El Q = F::mul(acc.x, PP);
         El X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
-        El Y3 = F::sub(F::mul(R, F::sub_weak(Q, X3)), F::mul(acc.y, PPP));
+        El Y3 = F::mulsub2(R, F::sub_weak(Q, X3), acc.y, PPP);
         acc.x = X3;
         acc.y = Y3;
         acc.zz = F::mul(acc.zz, PP);
@@ -146,7 +146,7 @@ struct Curve {
         El PPP = F::mul(P, PP);
         El Q = F::mul(U1, PP);
         El X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
-        El Y3 = F::sub(F::mul(R, F::sub_weak(Q, X3)), F::mul(S1, PPP));
+        El Y3 = F::mulsub2(R, F::sub_weak(Q, X3), S1, PPP);
         return Pt{X3, Y3, F::mul(F::mul(a.zz, b.zz), PP), F::mul(F::mul(a.zzz, b.zzz), PPP)};
     }
 

@@ -55,6 +55,7 @@ struct Fp2T {
         BE C = B::mul(B::add_lazy(a.c0, a.c1), B::add_lazy(b.c0, b.c1));   // sums feed a product only
         return El{B::sub(A, Bv), B::sub(C, B::add(A, Bv))};
     }
+    WS_HD static El mulsub2(const El& a, const El& b, const El& c, const El& d) { return sub(mul(a, b), mul(c, d)); }
     // complex squaring, 2 base-field products (build_f2m.js:186-227)
     WS_HD static El sqr(const El& a) {
         BE AB = B::mul(a.c0, a.c1);

@@ -209,18 +209,28 @@ __global__ __launch_bounds__(1024) void presort_scatter(PresortArgs A, uint32_t*
     }
 }
 
-// one workgroup per bin: LDS counting sort over the low bucket bits, bucket bounds written directly
+// 1..255, monotone in len: the task planner's length key (see msm_plan_* below)
+__device__ __forceinline__ uint32_t len_key(uint32_t len, uint32_t lmax) {
+    uint32_t k = (len * 255u + lmax - 1) / lmax;
+    return k > 255u ? 255u : (k < 1u ? 1u : k);
+}
+
+// one workgroup per bin: LDS counting sort over the low bucket bits, bucket bounds written directly;
+// the bucket lengths are known here, so the planner's task-length histogram is taken on the way
 static const uint32_t PRESORT_MAX_LO = 10;
 template <class E>
 __global__ __launch_bounds__(1024) void presort_bins(const E* __restrict__ entries, const uint32_t* __restrict__ bin_start,
                                                        uint32_t lo_bits, uint32_t idx_bits, uint32_t* __restrict__ vals_out,
-                                                       uint32_t* __restrict__ bstart, uint32_t* __restrict__ bend) {
+                                                       uint32_t* __restrict__ bstart, uint32_t* __restrict__ bend,
+                                                       uint32_t lmax, uint32_t* __restrict__ hist) {
     __shared__ uint32_t sub[1u << PRESORT_MAX_LO];
     __shared__ uint32_t off[1u << PRESORT_MAX_LO];
     __shared__ uint32_t part[1024];
+    __shared__ uint32_t lhist[256];
     const uint32_t bin = blockIdx.x, SUB = 1u << lo_bits;
     const uint32_t s = bin_start[bin], e = bin_start[bin + 1];
     for (uint32_t t = threadIdx.x; t < SUB; t += blockDim.x) sub[t] = 0;
+    for (uint32_t t = threadIdx.x; t < 256; t += blockDim.x) lhist[t] = 0;
     __syncthreads();
     // four independent loads in flight per thread: the bin loops are latency-bound otherwise
     for (uint32_t i = s + threadIdx.x; i < e; i += 4 * blockDim.x) {
@@ -256,8 +266,15 @@ __global__ __launch_bounds__(1024) void presort_bins(const E* __restrict__ entri
         bend[bucket] = run + cnt;
         run += cnt;
         sub[t] = 0;                                     // becomes the placement cursor
+        if (cnt) {                                      // == msm_plan_hist
+            const uint32_t nt = (cnt + lmax - 1) / lmax, rem = cnt - (nt - 1) * lmax;
+            if (nt > 1) atomicAdd(&lhist[255], nt - 1);
+            atomicAdd(&lhist[len_key(rem, lmax)], 1u);
+        }
     }
     __syncthreads();
+    for (uint32_t t = threadIdx.x; t < 256; t += blockDim.x)
+        if (lhist[t]) atomicAdd(&hist[t], lhist[t]);
     for (uint32_t i = s + threadIdx.x; i < e; i += 4 * blockDim.x) {
         E v[4];
 #pragma unroll
@@ -337,11 +354,6 @@ __global__ __launch_bounds__(256) void msm_convert_points(const typename C::AffP
 static const uint32_t PARTIAL_FLAG = 0x80000000u;
 struct Task { uint32_t dst, start, len; };          // dst: bucket index, or PARTIAL_FLAG | partial slot
 struct MultiBucket { uint32_t bucket, first_partial, ntasks; };
-
-__device__ __forceinline__ uint32_t len_key(uint32_t len, uint32_t lmax) {   // 1..255, monotone in len
-    uint32_t k = (len * 255u + lmax - 1) / lmax;
-    return k > 255u ? 255u : (k < 1u ? 1u : k);
-}
 
 __global__ __launch_bounds__(256) void msm_plan_hist(const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bend,
                                                        uint32_t nbuckets, uint32_t lmax, uint32_t* __restrict__ hist) {
@@ -752,6 +764,7 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
     // [272..527] cursors
     uint32_t* d_cnt = S.counters.as<uint32_t>();
     WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, 4096, s));
+    bool have_hist = false;
     static const bool use_cub = [] { const char* e = getenv("WSNARK_MSM_SORT"); return e && !strcmp(e, "cub"); }();
     static const uint32_t env_lo = [] { const char* e = getenv("WSNARK_MSM_LO_BITS"); return e ? (uint32_t)atoi(e) : 7u; }();
     static const uint32_t env_tile = [] { const char* e = getenv("WSNARK_MSM_TILE"); return e ? (uint32_t)atoi(e) : 1024u; }();
@@ -790,12 +803,13 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
         T.begin("msm_presort_bins", s);
         if (e32)
             hipLaunchKernelGGL(presort_bins<uint32_t>, dim3(nbins), bblk, 0, s, S.entries.as<uint32_t>(), bin_start, lo_bits,
-                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>());
+                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(), lmax, d_cnt + 16);
         else
             hipLaunchKernelGGL(presort_bins<uint64_t>, dim3(nbins), bblk, 0, s, S.entries.as<uint64_t>(), bin_start, lo_bits,
-                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>());
+                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(), lmax, d_cnt + 16);
         T.end(s);
         WS_HIP_CHECK(hipGetLastError());
+        have_hist = true;
     } else {
         // ---- reference pipeline: explicit digit arrays + hipCUB radix sort (WSNARK_MSM_SORT=cub) ----
         WS_HIP_CHECK(S.keys.reserve(total * 4));
@@ -820,8 +834,9 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
         T.end(s);
     }
     T.begin("msm_plan", s);
-    hipLaunchKernelGGL(msm_plan_hist, dim3(ceil_div_u64(nbuckets, 256)), dim3(256), 0, s, S.bstart.as<uint32_t>(),
-                       S.bend.as<uint32_t>(), nbuckets, lmax, d_cnt + 16);
+    if (!have_hist)
+        hipLaunchKernelGGL(msm_plan_hist, dim3(ceil_div_u64(nbuckets, 256)), dim3(256), 0, s, S.bstart.as<uint32_t>(),
+                           S.bend.as<uint32_t>(), nbuckets, lmax, d_cnt + 16);
     hipLaunchKernelGGL(msm_plan_offsets, dim3(1), dim3(64), 0, s, d_cnt + 16, d_cnt + 272, d_cnt);
     hipLaunchKernelGGL(msm_plan_emit, dim3(ceil_div_u64(nbuckets, 256)), dim3(256), 0, s, S.bstart.as<uint32_t>(),
                        S.bend.as<uint32_t>(), nbuckets, lmax, d_cnt + 272, S.tasks.as<Task>(), d_cnt,
