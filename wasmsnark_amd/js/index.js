@@ -66,4 +66,6 @@ function groth16GenProof(witness, provingKey, cb) {   // main_bn128.js:26-39
     return p;
 }
 
-module.exports = { buildBn128, groth16GenProof, genZKSnarkProof: groth16GenProof, Bn128, proofFromBytes };
+const formats = require("./formats.js");     // snarkjs JSON -> proving_key.bin / witness.bin (reference tools/build*.js)
+module.exports = { buildBn128, groth16GenProof, genZKSnarkProof: groth16GenProof, Bn128, proofFromBytes,
+    pkeyJsonToBin: formats.pkeyJsonToBin, witnessJsonToBin: formats.witnessJsonToBin };
