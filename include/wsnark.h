@@ -145,7 +145,9 @@ int wsnark_g1_mul_base_batch(const void* base64, const void* scalars, uint64_t n
 int wsnark_g2_mul_base_batch(const void* base128, const void* scalars, uint64_t n, void* out_affine);
 
 /* ---- measurement hooks (bench.py) ---- */
-/* enable/disable per-kernel HIP-event timing on the stream kernels are launched on */
+/* per-kernel HIP-event timing on the stream the kernels are launched on: 0 = off, 1 = every kernel,
+ * 2 = only the dominant kernel (msm_accumulate_*), for timed regions where the brackets themselves must
+ * stay out of the way */
 void wsnark_timing_enable(int on);
 void wsnark_timing_reset(void);
 /* writes "name total_ms launches\n" lines; returns bytes needed (excluding NUL) */

@@ -246,7 +246,7 @@ int wsnark_g2_mul_base_batch(const void* base128, const void* scalars, uint64_t 
 // ---- timing ----
 void wsnark_timing_enable(int on) {
     Context* C = ctx();
-    if (C) C->timer.enabled = on != 0;
+    if (C) { C->timer.enabled = on != 0; C->timer.dominant_only = on == 2; }
 }
 void wsnark_timing_reset(void) {
     Context* C = ctx();

@@ -1,5 +1,6 @@
 // context.hip -- library context, error string, per-kernel HIP-event timing.
 #include <stdlib.h>
+#include <string.h>
 
 #include "internal.h"
 
@@ -44,6 +45,8 @@ void context_shutdown() {
     if (!g_ctx) return;
     (void)hipStreamSynchronize(g_ctx->stream);
     g_ctx->timer.reset();
+    for (hipEvent_t e : g_ctx->timer.pool) (void)hipEventDestroy(e);
+    g_ctx->timer.pool.clear();
     g_ctx->ntt_plans.clear();
     g_ctx->ntt_scratch.release();
     msm_release_pending();
@@ -57,17 +60,25 @@ void context_shutdown() {
 const std::string& device_info() { return g_devinfo; }
 
 // ---- KernelTimer ----
+static hipEvent_t timer_event(std::vector<hipEvent_t>& pool) {
+    hipEvent_t e;
+    if (!pool.empty()) { e = pool.back(); pool.pop_back(); return e; }
+    (void)hipEventCreate(&e);
+    return e;
+}
 void KernelTimer::begin(const char* name, hipStream_t s) {
     if (!enabled) return;
+    skipped = dominant_only && strncmp(name, "msm_accumulate", 14) != 0;
+    if (skipped) return;
     Rec r;
-    r.name = name;
-    (void)hipEventCreate(&r.a);
-    (void)hipEventCreate(&r.b);
+    r.name = name;          // string literals only
+    r.a = timer_event(pool);
+    r.b = timer_event(pool);
     (void)hipEventRecord(r.a, s);
     recs.push_back(r);
 }
 void KernelTimer::end(hipStream_t s) {
-    if (!enabled || recs.empty()) return;
+    if (!enabled || skipped || recs.empty()) return;
     (void)hipEventRecord(recs.back().b, s);
 }
 void KernelTimer::collect() {
@@ -78,8 +89,8 @@ void KernelTimer::collect() {
         auto& a = acc[r.name];
         a.first += ms;
         a.second += 1;
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
+        pool.push_back(r.a);
+        pool.push_back(r.b);
     }
     recs.clear();
 }

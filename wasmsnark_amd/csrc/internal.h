@@ -13,8 +13,11 @@ namespace wsnark {
 // ---- per-kernel timing (HIP events on the library's stream) ----
 struct KernelTimer {
     bool enabled = false;
-    struct Rec { std::string name; hipEvent_t a, b; };
+    bool dominant_only = false;   // mode 2: bracket only the kernel the roofline is quoted on (msm_accumulate_*)
+    bool skipped = false;         // the begin() of the current bracket was filtered out
+    struct Rec { const char* name; hipEvent_t a, b; };
     std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;   // events are recycled: creating them costs more than recording them
     std::map<std::string, std::pair<double, uint64_t>> acc;   // name -> (total ms, launches)
     void begin(const char* name, hipStream_t s);
     void end(hipStream_t s);

@@ -11,6 +11,8 @@
 #include <chrono>
 #include <future>
 
+#include <functional>
+
 #include "internal.h"
 
 namespace wsnark {
@@ -166,41 +168,49 @@ struct MsmSums {
 
 // CALC_H and the five MSMs (src/bn128.js:607-620).  With window sharding active
 // (wsnark_set_window_shard) the sums are this rank's partial sums.
-static int prove_msms(ProvingKey* K, const Fe* d_witness, MsmSums* out, hipStream_t s) {
+//
+// Order on the stream: A, B1, C (one plan, one batched tail) -> B2 (same plan) -> CALC_H -> H.  The host
+// finishes each sum while the GPU works on the next ones, so only H's short G1 tail is left after the last
+// kernel; `after_ab1` (optional) runs on the host as soon as A and B1 are known, under B2's accumulation.
+static int prove_msms(ProvingKey* K, const Fe* d_witness, MsmSums* out, hipStream_t s,
+                      const std::function<void(const MsmSums&)>& after_ab1 = nullptr) {
     Context* C = ctx();
     Trace tr;
     const uint32_t nv = K->n_vars, dom = K->domain;
     int rc;
-    // CALC_H, then the H MSM over domainSize pairs (src/bn128.js:607-615)
-    Fe* d_h = K->h.as<Fe>();
-    if ((rc = calc_h_dev(d_witness, nv, K->polsA, K->polsB, dom, d_h, s))) return rc;
-    tr.mark("calc_h enqueued");
-    std::lock_guard<std::mutex> lk(C->mu);   // the digit/sort plan and the MSM scratch are per context
+    std::unique_lock<std::mutex> lk(C->mu);   // the digit/sort plan and the MSM scratch are per context
     int hH = -1, hA = -1, hB1 = -1, hB2 = -1, hC = -1;
     struct Abort { hipStream_t s; bool armed; ~Abort() { if (armed) msm_abort_pending(s); } } guard{s, true};
-    if ((rc = msm_plan_dev(d_h, dom, s))) return rc;
-    if ((rc = msm_g1_launch(K->pointsH.as<Affine<Fq>>(), true, &hH, s))) return rc;                    // :614
-    tr.mark("plan(h) + launch H");
-    // one plan for the four sums whose scalars are the witness (:617-620); each host tail runs while
-    // the GPU already accumulates the next point set
+    // one plan for the four sums whose scalars are the witness (:617-620)
     if ((rc = msm_plan_dev(d_witness, nv, s))) return rc;
     // A, B1 and C share the plan: three accumulations back to back, then ONE batched reduction tail
-    // (the tail is a latency-bound chain of ~33 dependent additions; three sets ride it for the price of one)
     const Affine<Fq>* g1sets[3] = {K->pointsA.as<Affine<Fq>>(), K->pointsB1.as<Affine<Fq>>(), K->pointsC.as<Affine<Fq>>()};
     int g1slots[3] = {-1, -1, -1};
     if ((rc = msm_g1_launch_batch(g1sets, 3, true, g1slots, s))) return rc;                              // :617, :618, :620 (padded)
     hA = g1slots[0]; hB1 = g1slots[1]; hC = g1slots[2];
     tr.mark("plan(w) + launch A,B1,C");
-    if ((rc = msm_g1_finish(hH, &out->H))) return rc;
-    tr.mark("finish H");
     if ((rc = msm_g2_launch(K->pointsB2.as<Affine<Fq2>>(), true, &hB2, s))) return rc;                 // :619
     tr.mark("launch B2");
+    // CALC_H, then the H MSM over domainSize pairs (src/bn128.js:607-615)
+    Fe* d_h = K->h.as<Fe>();
+    lk.unlock();                              // (the NTT plan cache takes the same mutex; everything launched so far
+    rc = calc_h_dev(d_witness, nv, K->polsA, K->polsB, dom, d_h, s);   //  is ordered on the stream)
+    lk.lock();
+    if (rc) return rc;
+    tr.mark("calc_h enqueued");
+    if ((rc = msm_plan_dev(d_h, dom, s))) return rc;
+    if ((rc = msm_g1_launch(K->pointsH.as<Affine<Fq>>(), true, &hH, s))) return rc;                    // :614
+    tr.mark("plan(h) + launch H");
     if ((rc = msm_g1_finish(hA, &out->A))) return rc;
     if ((rc = msm_g1_finish(hB1, &out->B1))) return rc;
+    tr.mark("finish A, B1");
+    if (after_ab1) after_ab1(*out);
     if ((rc = msm_g1_finish(hC, &out->C))) return rc;
-    tr.mark("finish A, B1, C");
+    tr.mark("host work on A, B1; finish C");
     if ((rc = msm_g2_finish(hB2, &out->B2))) return rc;
     tr.mark("finish B2");
+    if ((rc = msm_g1_finish(hH, &out->H))) return rc;
+    tr.mark("finish H");
     guard.armed = false;
     return WS_OK;
 }
@@ -243,24 +253,32 @@ static int start_blinding(ProvingKey* K, const uint8_t* r32, const uint8_t* s32,
     return WS_OK;
 }
 
-// src/bn128.js:671-718
-static void prove_assemble(ProvingKey* K, const MsmSums& M, Blinding& B, uint8_t* out384) {
+// src/bn128.js:671-718, in two steps: everything that needs only A and B1 (incl. the two 256-bit scalar
+// multiplications of pi_c) can run while the GPU is still busy with B2 and H
+struct EarlyParts { G1::Pt pi_a, s_pi_a, r_pib1; bool done = false; };
+static void prove_assemble_early(ProvingKey* K, const MsmSums& M, Blinding& B, Blinding::Pre& pp, EarlyParts* E) {
     const G1::Pt alfa1 = G1::from_affine(K->alfa1), beta1 = G1::from_affine(K->beta1);
-    const G2::Pt beta2 = G2::from_affine(K->beta2);
-    const Blinding::Pre pp = B.pre.get();
+    pp = B.pre.get();
     // pi_a = sum A + alfa1 + r*delta1                               (:671-673)
-    G1::Pt pi_a = G1::add(G1::add(alfa1, M.A), pp.r_delta1);
+    E->pi_a = G1::add(G1::add(alfa1, M.A), pp.r_delta1);
+    // pib1 = sum B1 + beta1 + s*delta1                              (:681-683)
+    const G1::Pt pib1 = G1::add(G1::add(beta1, M.B1), pp.s_delta1);
+    E->s_pi_a = G1::mul_bytes(E->pi_a, B.sb(), 32);                  // (:692)
+    E->r_pib1 = G1::mul_bytes(pib1, B.rb(), 32);                     // (:696)
+    E->done = true;
+}
+static void prove_assemble(ProvingKey* K, const MsmSums& M, Blinding& B, Blinding::Pre& pp, EarlyParts& E, uint8_t* out384) {
+    if (!E.done) prove_assemble_early(K, M, B, pp, &E);
+    const G2::Pt beta2 = G2::from_affine(K->beta2);
     // pi_b = sum B2 + beta2 + s*delta2                              (:676-678)
     G2::Pt pi_b = G2::add(G2::add(beta2, M.B2), pp.s_delta2);
-    // pib1 = sum B1 + beta1 + s*delta1                              (:681-683)
-    G1::Pt pib1 = G1::add(G1::add(beta1, M.B1), pp.s_delta1);
     // pi_c = sum C + sum H + s*pi_a + r*pib1 - (r*s)*delta1         (:687-704)
     G1::Pt pi_c = G1::add(M.C, M.H);
-    pi_c = G1::add(pi_c, G1::mul_bytes(pi_a, B.sb(), 32));
-    pi_c = G1::add(pi_c, G1::mul_bytes(pib1, B.rb(), 32));
+    pi_c = G1::add(pi_c, E.s_pi_a);
+    pi_c = G1::add(pi_c, E.r_pib1);
     pi_c = G1::add(pi_c, G1::neg(pp.rs_delta1));
     // affine + fromMontgomery (:706-712); infinity prints as (0, 1, 0)
-    Jac<Fq> a = G1::to_affine_jac(pi_a), c = G1::to_affine_jac(pi_c);
+    Jac<Fq> a = G1::to_affine_jac(E.pi_a), c = G1::to_affine_jac(pi_c);
     Jac<Fq2> b = G2::to_affine_jac(pi_b);
     store_plain(out384 + 0, a.x); store_plain(out384 + 32, a.y); store_plain(out384 + 64, a.z);
     store_plain(out384 + 96, b.x.c0); store_plain(out384 + 128, b.x.c1);
@@ -279,9 +297,11 @@ int groth16_prove(ProvingKey* K, const Fe* d_witness, const uint8_t* r32, const 
     int rc = start_blinding(K, r32, s32, &B);
     if (rc) return rc;
     MsmSums M;
-    if ((rc = prove_msms(K, d_witness, &M, s))) return rc;
+    Blinding::Pre pp;
+    EarlyParts E;
+    if ((rc = prove_msms(K, d_witness, &M, s, [&](const MsmSums& m) { prove_assemble_early(K, m, B, pp, &E); }))) return rc;
     Trace tr;
-    prove_assemble(K, M, B, out384);
+    prove_assemble(K, M, B, pp, E, out384);
     tr.mark("assemble (host)");
     return WS_OK;
 }
@@ -323,7 +343,9 @@ int groth16_prove_finish(ProvingKey* K, const uint8_t* partials, uint64_t n_rank
         Jac<Fq2> j2;
         memcpy(&j2, rec + 384, 192); M.B2 = G2::add(M.B2, G2::from_jac(j2));
     }
-    prove_assemble(K, M, B, out384);
+    Blinding::Pre pp;
+    EarlyParts E;
+    prove_assemble(K, M, B, pp, E, out384);
     return WS_OK;
 }
 
