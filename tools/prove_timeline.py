@@ -10,8 +10,10 @@ def short(n):
     base = n.split("(")[0]
     tag = "G2" if "Fp2T" in base else ("Fr" if "Fr29" in base or "FrParams" in base else "")
     return base.split("<")[0] + ("<" + tag + ">" if tag else "")
-# the last proof starts at the last lc/spmv-like first kernel: find last occurrence of 'fr_to_montgomery'
-idx = max(i for i, r in enumerate(rows) if "fr_map_kernel" in r["Kernel_Name"] and (i == 0 or "fr_map_kernel" not in rows[i - 1]["Kernel_Name"]))
+# a proof launches presort_count twice (witness plan first, then the H plan): the last proof starts at the
+# second-to-last one, after the memsets that precede it
+pc = [i for i, r in enumerate(rows) if "presort_count" in r["Kernel_Name"]]
+idx = pc[-2] if len(pc) >= 2 else 0
 while idx > 0 and "rocclr" in rows[idx - 1]["Kernel_Name"]: idx -= 1
 sel = rows[idx:]
 t0 = int(sel[0]["Start_Timestamp"]); prev_end = t0; busy = 0

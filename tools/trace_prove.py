@@ -5,7 +5,8 @@ import wasmsnark_amd
 from wasmsnark_amd import synth
 bn = wasmsnark_amd.build(device=0)
 circ = synth.make_circuit(20, n_public=5, seed=1); S = synth.setup(circ, seed=2)
-pkey, _ = synth.build_key(circ, S, bn.mul_base); key = bn.load_key(pkey); wit = synth.witness_bin(circ)
+pkey, _ = synth.build_key(circ, S, bn.mul_base)
+t0 = time.perf_counter(); key = bn.load_key(pkey); print('load_key s', time.perf_counter() - t0, file=sys.stderr); wit = synth.witness_bin(circ)
 d_w = torch.frombuffer(bytearray(wit), dtype=torch.uint8).cuda(); torch.cuda.synchronize()
 r32, s32 = bytes(range(32)), bytes(range(32, 64))
 for i in range(3):
