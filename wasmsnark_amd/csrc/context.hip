@@ -36,6 +36,7 @@ int context_init(int device) {
     C->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     g_devinfo = std::string(prop.name) + " " + prop.gcnArchName + " CUs=" + std::to_string(C->num_cu);
     WS_HIP_CHECK(hipStreamCreateWithFlags(&C->stream, hipStreamNonBlocking));
+    WS_HIP_CHECK(hipStreamCreateWithFlags(&C->stream2, hipStreamNonBlocking));
     g_ctx = C;
     return WS_OK;
 }
@@ -44,6 +45,7 @@ void context_shutdown() {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     if (!g_ctx) return;
     (void)hipStreamSynchronize(g_ctx->stream);
+    (void)hipStreamSynchronize(g_ctx->stream2);
     g_ctx->timer.reset();
     for (hipEvent_t e : g_ctx->timer.pool) (void)hipEventDestroy(e);
     g_ctx->timer.pool.clear();
@@ -53,6 +55,7 @@ void context_shutdown() {
     g_ctx->msm_scratch[0].reset();
     g_ctx->msm_scratch[1].reset();
     (void)hipStreamDestroy(g_ctx->stream);
+    (void)hipStreamDestroy(g_ctx->stream2);
     delete g_ctx;
     g_ctx = nullptr;
 }

@@ -31,6 +31,7 @@ struct MsmScratch; // msm.hip
 struct Context {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;              // second in-order queue (prover: CALC_H and the H sum beside the tails)
     int num_cu = 256;
     uint32_t shard_off = 0, shard_stride = 1;   // MSM window sharding (wsnark_set_window_shard)
     std::mutex mu;
@@ -73,8 +74,13 @@ int msm_g2_exec_xyzz(const Affine<Fq2>* d_points, XYZZ<Fq2>* out_host, hipStream
 // asynchronous form of exec: launch enqueues the kernels and the copy of the window sums, finish waits
 // for that copy and runs the serial host tail
 int msm_g1_launch(const Affine<Fq>* d_points, bool prepared, int* slot, hipStream_t s);
-int msm_g2_launch(const Affine<Fq2>* d_points, bool prepared, int* slot, hipStream_t s);
-int msm_g1_launch_batch(const Affine<Fq>* const* d_points, int nsets, bool prepared, int* slots, hipStream_t s);
+int msm_g2_launch(const Affine<Fq2>* d_points, bool prepared, int* slot, hipStream_t s, hipEvent_t before_tail = nullptr);
+// `before_tail` (optional) is recorded on s after the accumulations, before the batched reduction tail
+int msm_g1_launch_batch(const Affine<Fq>* const* d_points, int nsets, bool prepared, int* slots, hipStream_t s,
+                        hipEvent_t before_tail = nullptr);
+// two independent plans (digit/sort/task buffers) can be alive at once; plan and launches use the selected one
+void msm_select_plan(int id);
+bool msm_ready(int slot);     // the launch's window sums have reached the host (finish will not block)
 int msm_g1_finish(int slot, XYZZ<Fq>* out_host);
 int msm_g2_finish(int slot, XYZZ<Fq2>* out_host);
 void msm_abort_pending(hipStream_t s);

@@ -633,6 +633,7 @@ struct MsmPlanInfo {
 struct MsmPending {
     bool active = false;
     int which = 0;
+    int plan_id = 0;
     MsmPlanInfo info;
     DevBuf d_sums, d_queue;
     MsmScratch S;                 // this launch's accumulation buffers (buckets, partials, chunk sums)
@@ -707,12 +708,17 @@ struct MsmPlanBufs {
     MsmScratch S;
     MsmPlanInfo info;
 };
+// two plans can be alive at once (the prover builds the H plan on a second stream while the sums over the
+// witness still read theirs); msm_select_plan picks the one msm_plan_dev and the launches work with
+static int g_plan_cur = 0;
+void msm_select_plan(int id) { g_plan_cur = id ? 1 : 0; }
 static MsmPlanBufs* plan_bufs(Context* X) {
-    if (!X->msm_scratch[0]) X->msm_scratch[0] = std::make_shared<MsmScratch>();   // slot 0: plan buffers + G1 exec buffers
-    if (!X->msm_scratch[1]) X->msm_scratch[1] = std::make_shared<MsmScratch>();   // slot 1: G2 exec buffers
-    static MsmPlanBufs P;   // info only; buffers live in the context scratch
-    return &P;
+    if (!X->msm_scratch[0]) X->msm_scratch[0] = std::make_shared<MsmScratch>();   // plan 0 buffers
+    if (!X->msm_scratch[1]) X->msm_scratch[1] = std::make_shared<MsmScratch>();   // plan 1 buffers
+    static MsmPlanBufs P[2];   // info only; buffers live in the context scratch
+    return &P[g_plan_cur];
 }
+static MsmScratch& plan_scratch(Context* X) { return *X->msm_scratch[g_plan_cur]; }
 
 int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
     Context* X = ctx();
@@ -750,8 +756,9 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
 
     // launches of the previous plan may still be reading the plan buffers on their own streams
     for (int i = 0; g_slots && i < kPendingSlots; i++)
-        if (g_slots[i].active && g_slots[i].ev && g_slots[i].info.n) WS_HIP_CHECK(hipStreamWaitEvent(s, g_slots[i].ev, 0));
-    MsmScratch& S = *X->msm_scratch[0];
+        if (g_slots[i].active && g_slots[i].ev && g_slots[i].info.n && g_slots[i].plan_id == g_plan_cur)
+            WS_HIP_CHECK(hipStreamWaitEvent(s, g_slots[i].ev, 0));
+    MsmScratch& S = plan_scratch(X);
     WS_HIP_CHECK(S.vals_out.reserve(total * 4));
     WS_HIP_CHECK(S.bstart.reserve((size_t)nbuckets * 4));
     WS_HIP_CHECK(S.bend.reserve((size_t)nbuckets * 4));
@@ -881,7 +888,8 @@ static int msm_launch_acc(int which, const typename H::Aff* d_points_ref, bool p
     const uint32_t c = I.c, W = I.W, nbuckets = I.nbuckets, m = I.m, J = I.J, logJ = I.logJ, nsum = I.nsum;
     const uint32_t ntasks = I.ntasks;
 
-    MsmScratch& PS = *X->msm_scratch[0];        // plan buffers (read-only here)
+    MsmScratch& PS = plan_scratch(X);           // plan buffers (read-only here)
+    P.plan_id = g_plan_cur;
     MsmScratch& S = P.S;                        // this launch's accumulation buffers
     // Everything runs in order on the caller's stream.  Tried and measured slower on MI355X (round 1, sessions
     // 7, 8, 11): accumulations on concurrent streams (cache thrash), and the reduction tail on a second,
@@ -988,14 +996,17 @@ static int msm_launch_tail(const int* slot_ids, int nslots, hipStream_t s) {
 }
 
 template <class C, class H>
-static int msm_launch(int which, const typename H::Aff* d_points_ref, bool prepared, int* slot_out, hipStream_t s) {
+static int msm_launch(int which, const typename H::Aff* d_points_ref, bool prepared, int* slot_out, hipStream_t s,
+                      hipEvent_t before_tail = nullptr) {
     int rc = msm_launch_acc<C, H>(which, d_points_ref, prepared, slot_out, s);
     if (rc) return rc;
+    if (before_tail) WS_HIP_CHECK(hipEventRecord(before_tail, s ? s : ctx()->stream));
     return msm_launch_tail<typename TailCurve<C>::type>(slot_out, 1, s);
 }
 
 // several G1 point sets against the current plan: accumulations back to back, then ONE batched tail
-int msm_g1_launch_batch(const Affine<Fq>* const* d_points, int nsets, bool prepared, int* slots, hipStream_t s) {
+int msm_g1_launch_batch(const Affine<Fq>* const* d_points, int nsets, bool prepared, int* slots, hipStream_t s,
+                        hipEvent_t before_tail) {
     if (!ctx()) return WS_ERR_NOINIT;
     if (nsets < 1 || nsets > 4) return WS_ERR_ARG;
     for (int k = 0; k < nsets; k++) {
@@ -1003,6 +1014,7 @@ int msm_g1_launch_batch(const Affine<Fq>* const* d_points, int nsets, bool prepa
                                     : msm_launch_acc<G1, G1>(0, d_points[k], prepared, &slots[k], s);
         if (rc) return rc;
     }
+    if (before_tail) WS_HIP_CHECK(hipEventRecord(before_tail, s ? s : ctx()->stream));
     return msm_uses_field29() ? msm_launch_tail<TailCurve<G1R29>::type>(slots, nsets, s) : msm_launch_tail<G1>(slots, nsets, s);
 }
 
@@ -1011,10 +1023,15 @@ int msm_g1_launch(const Affine<Fq>* d_points, bool prepared, int* slot, hipStrea
     if (msm_uses_field29()) return msm_launch<G1R29, G1>(0, d_points, prepared, slot, s);
     return msm_launch<G1, G1>(0, d_points, prepared, slot, s);
 }
-int msm_g2_launch(const Affine<Fq2>* d_points, bool prepared, int* slot, hipStream_t s) {
+int msm_g2_launch(const Affine<Fq2>* d_points, bool prepared, int* slot, hipStream_t s, hipEvent_t before_tail) {
     if (!ctx()) return WS_ERR_NOINIT;
-    if (msm_uses_field29()) return msm_launch<G2R29, G2>(1, d_points, prepared, slot, s);
-    return msm_launch<G2, G2>(1, d_points, prepared, slot, s);
+    if (msm_uses_field29()) return msm_launch<G2R29, G2>(1, d_points, prepared, slot, s, before_tail);
+    return msm_launch<G2, G2>(1, d_points, prepared, slot, s, before_tail);
+}
+bool msm_ready(int slot) {
+    if (slot < 0 || slot >= kPendingSlots) return false;
+    MsmPending& P = pending_slots()[slot];
+    return P.active && (P.info.n == 0 || (P.ev && hipEventQuery(P.ev) == hipSuccess));
 }
 int msm_g1_finish(int slot, XYZZ<Fq>* out_host) {
     if (slot < 0 || slot >= kPendingSlots || !pending_slots()[slot].active || pending_slots()[slot].which != 0) return WS_ERR_ARG;

@@ -25,6 +25,12 @@ struct ProvingKey {
     DevBuf pointsA, pointsB1, pointsB2, pointsC, pointsH;
     DevBuf witness, h;          // per-proof device buffers (grow-only)
     std::mutex mu;              // one proof at a time per handle
+    hipEvent_t ev_start = nullptr, ev_tail = nullptr, ev_h = nullptr;   // cross-queue ordering of one proof
+    ~ProvingKey() {
+        if (ev_start) (void)hipEventDestroy(ev_start);
+        if (ev_tail) (void)hipEventDestroy(ev_tail);
+        if (ev_h) (void)hipEventDestroy(ev_h);
+    }
 };
 
 static bool range_ok(uint64_t off, uint64_t bytes, size_t len) { return off <= len && bytes <= len - off; }
@@ -169,37 +175,52 @@ struct MsmSums {
 // CALC_H and the five MSMs (src/bn128.js:607-620).  With window sharding active
 // (wsnark_set_window_shard) the sums are this rank's partial sums.
 //
-// Order on the stream: A, B1, C (one plan, one batched tail) -> B2 (same plan) -> CALC_H -> H.  The host
-// finishes each sum while the GPU works on the next ones, so only H's short G1 tail is left after the last
-// kernel; `after_ab1` (optional) runs on the host as soon as A and B1 are known, under B2's accumulation.
+// Two in-order queues.  Stream s: the witness plan, A, B1, C (one batched tail), B2.  Stream 2: CALC_H, the H
+// plan and the H sum -- released when the first reduction tail starts, so its full-width kernels fill the
+// SIMDs that the latency-bound tails (a chain of ~30 dependent point additions on a few hundred wavefronts)
+// leave idle (measured on MI355X, prove 2^20: 14.5 ms on one queue, 13.5-13.8 ms with two; releasing the second
+// queue at once (=2) or holding H back until B2's tail is the same within noise).  The host finishes each sum
+// while the GPU works on the next ones; `after_ab1` (optional) runs on the host as soon as A and B1 are known.
+// WSNARK_PROVE_OVERLAP=0 keeps everything on one queue.
 static int prove_msms(ProvingKey* K, const Fe* d_witness, MsmSums* out, hipStream_t s,
                       const std::function<void(const MsmSums&)>& after_ab1 = nullptr) {
     Context* C = ctx();
     Trace tr;
     const uint32_t nv = K->n_vars, dom = K->domain;
     int rc;
-    std::unique_lock<std::mutex> lk(C->mu);   // the digit/sort plan and the MSM scratch are per context
+    static const int overlap = [] { const char* e = getenv("WSNARK_PROVE_OVERLAP"); return e ? atoi(e) : 1; }();
+    hipStream_t s2 = overlap ? C->stream2 : s;
+    if (s2 == s) s2 = s;   // (caller passed the second queue itself: degenerate, stays in order)
+    std::unique_lock<std::mutex> lk(C->mu);   // the digit/sort plans and the MSM scratch are per context
     int hH = -1, hA = -1, hB1 = -1, hB2 = -1, hC = -1;
-    struct Abort { hipStream_t s; bool armed; ~Abort() { if (armed) msm_abort_pending(s); } } guard{s, true};
+    struct Abort { hipStream_t a, b; bool armed; ~Abort() { if (armed) { msm_select_plan(0); msm_abort_pending(a); if (b != a) msm_abort_pending(b); } } } guard{s, s2, true};
+    if (!K->ev_start) { WS_HIP_CHECK(hipEventCreateWithFlags(&K->ev_start, hipEventDisableTiming)); WS_HIP_CHECK(hipEventCreateWithFlags(&K->ev_tail, hipEventDisableTiming)); WS_HIP_CHECK(hipEventCreateWithFlags(&K->ev_h, hipEventDisableTiming)); }
+    WS_HIP_CHECK(hipEventRecord(K->ev_start, s));          // the witness is ready on s
     // one plan for the four sums whose scalars are the witness (:617-620)
+    msm_select_plan(0);
     if ((rc = msm_plan_dev(d_witness, nv, s))) return rc;
     // A, B1 and C share the plan: three accumulations back to back, then ONE batched reduction tail
     const Affine<Fq>* g1sets[3] = {K->pointsA.as<Affine<Fq>>(), K->pointsB1.as<Affine<Fq>>(), K->pointsC.as<Affine<Fq>>()};
     int g1slots[3] = {-1, -1, -1};
-    if ((rc = msm_g1_launch_batch(g1sets, 3, true, g1slots, s))) return rc;                              // :617, :618, :620 (padded)
+    if ((rc = msm_g1_launch_batch(g1sets, 3, true, g1slots, s, K->ev_tail))) return rc;                  // :617, :618, :620 (padded)
     hA = g1slots[0]; hB1 = g1slots[1]; hC = g1slots[2];
     tr.mark("plan(w) + launch A,B1,C");
     if ((rc = msm_g2_launch(K->pointsB2.as<Affine<Fq2>>(), true, &hB2, s))) return rc;                 // :619
     tr.mark("launch B2");
     // CALC_H, then the H MSM over domainSize pairs (src/bn128.js:607-615)
+    if (s2 != s) WS_HIP_CHECK(hipStreamWaitEvent(s2, overlap == 2 ? K->ev_start : K->ev_tail, 0));
     Fe* d_h = K->h.as<Fe>();
     lk.unlock();                              // (the NTT plan cache takes the same mutex; everything launched so far
-    rc = calc_h_dev(d_witness, nv, K->polsA, K->polsB, dom, d_h, s);   //  is ordered on the stream)
+    rc = calc_h_dev(d_witness, nv, K->polsA, K->polsB, dom, d_h, s2);  //  is ordered on its stream)
     lk.lock();
     if (rc) return rc;
     tr.mark("calc_h enqueued");
-    if ((rc = msm_plan_dev(d_h, dom, s))) return rc;
-    if ((rc = msm_g1_launch(K->pointsH.as<Affine<Fq>>(), true, &hH, s))) return rc;                    // :614
+    msm_select_plan(s2 != s ? 1 : 0);
+    rc = msm_plan_dev(d_h, dom, s2);
+    if (!rc) rc = msm_g1_launch(K->pointsH.as<Affine<Fq>>(), true, &hH, s2);                           // :614
+    msm_select_plan(0);
+    if (rc) return rc;
+    if (s2 != s) { WS_HIP_CHECK(hipEventRecord(K->ev_h, s2)); WS_HIP_CHECK(hipStreamWaitEvent(s, K->ev_h, 0)); }   // s stays the caller's ordering point
     tr.mark("plan(h) + launch H");
     if ((rc = msm_g1_finish(hA, &out->A))) return rc;
     if ((rc = msm_g1_finish(hB1, &out->B1))) return rc;
@@ -207,10 +228,15 @@ static int prove_msms(ProvingKey* K, const Fe* d_witness, MsmSums* out, hipStrea
     if (after_ab1) after_ab1(*out);
     if ((rc = msm_g1_finish(hC, &out->C))) return rc;
     tr.mark("host work on A, B1; finish C");
-    if ((rc = msm_g2_finish(hB2, &out->B2))) return rc;
-    tr.mark("finish B2");
-    if ((rc = msm_g1_finish(hH, &out->H))) return rc;
-    tr.mark("finish H");
+    // the two queues end independently: take whichever sum is ready first
+    if (msm_ready(hB2)) {
+        if ((rc = msm_g2_finish(hB2, &out->B2))) return rc;
+        if ((rc = msm_g1_finish(hH, &out->H))) return rc;
+    } else {
+        if ((rc = msm_g1_finish(hH, &out->H))) return rc;
+        if ((rc = msm_g2_finish(hB2, &out->B2))) return rc;
+    }
+    tr.mark("finish H, B2");
     guard.armed = false;
     return WS_OK;
 }
