@@ -1,15 +1,16 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-rm -f gpurun_out/split.txt
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --timeout 300 -p no:cacheprovider > gpurun_out/pytest_prove.log 2>&1
 B="python bench.py --steps 10 --warmup 2 --no-extras --no-cpu-baseline"
-run() { echo "== $*" ; env "$@" $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['achieved'], d['kernel_ms'])"; }
+run() { echo "== $*" ; env "$@" $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); k=d['kernel_ms']; print(d['value'], d['ms_per_step'], 'count', k.get('msm_presort_count'), 'scatter', k.get('msm_presort_scatter'), 'bins', k.get('msm_presort_bins'), 'acc', k.get('msm_accumulate_g1'))"; }
 {
-run WSNARK_MSM_SPLIT=1
-run WSNARK_MSM_SPLIT=0
-run WSNARK_MSM_SPLIT=1
-run WSNARK_MSM_SPLIT=0
-for sp in 0 1; do echo "== g2 split=$sp"; WSNARK_MSM_SPLIT=$sp timeout 300 python tools/g2bench.py 2>&1 | tail -3; done
-} > gpurun_out/split.txt 2>&1
-tail -3 gpurun_out/pytest_prove.log; cat gpurun_out/split.txt
+run WSNARK_MSM_STAGE=1
+run WSNARK_MSM_STAGE=0
+run WSNARK_MSM_STAGE=1 WSNARK_MSM_LO_BITS=8
+run WSNARK_MSM_STAGE=0 WSNARK_MSM_LO_BITS=8
+run WSNARK_MSM_STAGE=1 WSNARK_MSM_LO_BITS=9
+run WSNARK_MSM_STAGE=1 WSNARK_MSM_TILE=512 WSNARK_MSM_TILE_THREADS=512
+run WSNARK_MSM_STAGE=1 WSNARK_MSM_TILE=1536 WSNARK_MSM_TILE_THREADS=768 WSNARK_MSM_LO_BITS=8
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --timeout 300 -p no:cacheprovider -k "msm or multiexp or prove" 2>&1 | tail -2
+} > gpurun_out/stage.txt 2>&1
+cat gpurun_out/stage.txt

@@ -773,7 +773,7 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
     WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, 4096, s));
     bool have_hist = false;
     static const bool use_cub = [] { const char* e = getenv("WSNARK_MSM_SORT"); return e && !strcmp(e, "cub"); }();
-    static const uint32_t env_lo = [] { const char* e = getenv("WSNARK_MSM_LO_BITS"); return e ? (uint32_t)atoi(e) : 7u; }();
+    static const uint32_t env_lo = [] { const char* e = getenv("WSNARK_MSM_LO_BITS"); return e ? (uint32_t)atoi(e) : 8u; }();
     static const uint32_t env_tile = [] { const char* e = getenv("WSNARK_MSM_TILE"); return e ? (uint32_t)atoi(e) : 1024u; }();
     static const uint32_t env_thr = [] { const char* e = getenv("WSNARK_MSM_TILE_THREADS"); return e ? (uint32_t)atoi(e) : 1024u; }();
     static const bool env_e64 = [] { const char* e = getenv("WSNARK_MSM_ENTRY64"); return e && atoi(e) != 0; }();
