@@ -126,23 +126,47 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
     __syncthreads();
 
     // ---- length-L DIF transform of every column t (Gentleman-Sande; output bit-reversed) ----
-    const uint32_t nbf = LT >> 1;
-    for (int hs = (int)log_L - 1; hs >= 0; hs--) {
-        const uint32_t hmask = (1u << hs) - 1;
-        for (uint32_t idx = tid; idx < nbf; idx += nthr) {
-            const uint32_t t = idx & (T - 1), bb = idx >> log_T;
-            const uint32_t jlow = bb & hmask;
-            const uint32_t j = ((bb >> hs) << (hs + 1)) | jlow;
-            const uint32_t i0 = (j << log_T) + t, i1 = i0 + (1u << (hs + log_T));
-            El u = tile.get(i0), v = tile.get(i1);
-            El s = F::add(u, v), d = F::sub(u, v);
-            if (hs > 0) {
-                // w_{2h}^{jlow} = w_Lmax^(jlow * Lmax/(2h))
-                const uint32_t ti = jlow << (A.log_lmax - 1 - hs);
-                d = F::mul(d, F::unpack(A.tw_small[ti]));
+    // Two stages per LDS round trip: a lane takes the four elements j0, j0+h/2, j0+h, j0+3h/2 of one column
+    // through stage hs (span h) and stage hs-1 (span h/2) in registers -- half the LDS traffic and half the
+    // barriers of a stage-by-stage loop, same products.
+    int hs = (int)log_L - 1;
+    for (; hs >= 1; hs -= 2) {
+        const uint32_t qmask = (1u << (hs - 1)) - 1;              // bits below the two stage bits
+        const uint32_t sh_hi = A.log_lmax - 1 - hs;               // table stride of stage hs (w_{2h})
+        for (uint32_t idx = tid; idx < (LT >> 2); idx += nthr) {
+            const uint32_t t = idx & (T - 1), g = idx >> log_T;
+            const uint32_t jl = g & qmask;
+            const uint32_t j0 = ((g >> (hs - 1)) << (hs + 1)) | jl;
+            const uint32_t q = 1u << (hs - 1 + log_T);            // h/2 in LDS slots
+            const uint32_t i0 = (j0 << log_T) + t;
+            El x0 = tile.get(i0), x1 = tile.get(i0 + q), x2 = tile.get(i0 + 2 * q), x3 = tile.get(i0 + 3 * q);
+            // stage hs: (j0, j0+h) with w_{2h}^{jl}, (j0+h/2, j0+3h/2) with w_{2h}^{jl+h/2}
+            El s0 = F::add(x0, x2), d0 = F::mul(F::sub_weak(x0, x2), F::unpack(A.tw_small[jl << sh_hi]));
+            El s1 = F::add(x1, x3), d1 = F::mul(F::sub_weak(x1, x3), F::unpack(A.tw_small[(jl + (1u << (hs - 1))) << sh_hi]));
+            // stage hs-1: (j0, j0+h/2) and (j0+h, j0+3h/2), both with w_{h}^{jl}
+            El y0 = F::add(s0, s1), y2 = F::add(d0, d1), y1, y3;
+            if (hs > 1) {
+                const El w = F::unpack(A.tw_small[jl << (sh_hi + 1)]);
+                y1 = F::mul(F::sub_weak(s0, s1), w);
+                y3 = F::mul(F::sub_weak(d0, d1), w);
+            } else {
+                y1 = F::sub(s0, s1);
+                y3 = F::sub(d0, d1);
             }
-            tile.put(i0, s);
-            tile.put(i1, d);
+            tile.put(i0, y0);
+            tile.put(i0 + q, y1);
+            tile.put(i0 + 2 * q, y2);
+            tile.put(i0 + 3 * q, y3);
+        }
+        __syncthreads();
+    }
+    if (hs == 0) {                                                // odd log_L: one plain stage of span 1, no twiddle
+        for (uint32_t idx = tid; idx < (LT >> 1); idx += nthr) {
+            const uint32_t t = idx & (T - 1), bb = idx >> log_T;
+            const uint32_t i0 = ((bb << 1) << log_T) + t, i1 = i0 + T;
+            El u = tile.get(i0), v = tile.get(i1);
+            tile.put(i0, F::add(u, v));
+            tile.put(i1, F::sub(u, v));
         }
         __syncthreads();
     }
