@@ -217,6 +217,75 @@ def test_msm_2p20_closed_form(bn, orc):
         assert got == bn.g1_multiexp(sc, pts)      # host-pointer boundary gives the same
 
 
+@pytest.mark.parametrize("g", [1, 2])
+def test_msm_full_size_adversarial_closed_forms(bn, orc, g):
+    """2^20 (G1) / 2^18 (G2) pairs with inputs that stress the grouping and the hot-bucket paths: every scalar
+    equal (16 buckets hold everything), cancelling +P / -P pairs (sum is infinity), scalars >= r up to
+    2^256 - 1 (reduced mod r like the reference's double-and-add), all-zero scalars, x == 0 points."""
+    import time
+    import torch
+    n = 1 << (20 if g == 1 else 18)
+    esz = 64 if g == 1 else 128
+    rnd = random.Random(77 + g)
+    ks = [rnd.randrange(1, orc.R) for _ in range(n)]
+    pts = bn.mul_base(g, b"".join(k.to_bytes(32, "little") for k in ks))
+    d_p = torch.frombuffer(bytearray(pts), dtype=torch.uint8).cuda()
+    msm = bn.g1_multiexp_dev if g == 1 else bn.g2_multiexp_dev
+    one = ((1 << 256) % orc.Q).to_bytes(32, "little")          # 1 in Montgomery form
+    inf = bytes(esz // 2) + one + bytes(esz // 2 - 32)          # affine part of the reference's infinity (0, 1, 0)
+
+    def run(sc_bytes, d_points=d_p):
+        d_s = torch.frombuffer(bytearray(sc_bytes), dtype=torch.uint8).cuda()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = msm(d_s.data_ptr(), d_points.data_ptr(), n)
+        return out, time.perf_counter() - t0
+
+    def expect(e):
+        return bn.mul_base(g, (e % orc.R).to_bytes(32, "little"))
+
+    ksum = sum(ks) % orc.R
+    # (a) every scalar equal: one bucket per window holds all n entries
+    s0 = 0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF % orc.R
+    out, dt = run(s0.to_bytes(32, "little") * n)
+    assert out[:esz] == expect(s0 * ksum)
+    assert dt < 2.0                                     # degraded (hot buckets), not pathological
+    # (b) all scalars 2^256 - 1 (>= r: raw 256-bit values are legal, src/build_multiexp.js:651-744)
+    big = (1 << 256) - 1
+    out, _ = run(big.to_bytes(32, "little") * n)
+    assert out[:esz] == expect(big * ksum)
+    # (c) all-zero scalars: infinity = (0, 1, 0)
+    out, _ = run(bytes(32 * n))
+    assert out[:esz] == inf and out[esz:] == bytes(len(out) - esz)
+    # (d) second half = negated first half, same scalars: everything cancels
+    half = n // 2
+    q = orc.Q
+    neg = bytearray(pts[:half * esz])
+    nested = neg
+    for i in range(half):
+        o = i * esz + esz // 2
+        if g == 1:
+            y = int.from_bytes(nested[o:o + 32], "little")
+            nested[o:o + 32] = ((q - y) % q).to_bytes(32, "little")
+        else:
+            for c in (0, 32):
+                y = int.from_bytes(nested[o + c:o + c + 32], "little")
+                nested[o + c:o + c + 32] = ((q - y) % q).to_bytes(32, "little")
+    d_pn = torch.frombuffer(bytearray(pts[:half * esz]) + nested, dtype=torch.uint8).cuda()
+    sc_half = rand_fr(rnd, half)
+    out, _ = run(sc_half + sc_half, d_pn)
+    assert out[:esz] == inf
+    # (e) x == 0 marks infinity whatever y is: zero the x of the odd points, they must drop out
+    holes = bytearray(pts)
+    xz = esz // 2
+    for i in range(1, n, 2):
+        holes[i * esz:i * esz + xz] = bytes(xz)
+    d_ph = torch.frombuffer(holes, dtype=torch.uint8).cuda()
+    ss = [rnd.randrange(orc.R) for _ in range(n)]
+    out, _ = run(b"".join(v.to_bytes(32, "little") for v in ss), d_ph)
+    assert out[:esz] == expect(sum(ss[i] * ks[i] for i in range(0, n, 2)))
+
+
 @pytest.mark.parametrize("logd", [10, 16])
 def test_prove_vs_toxic_waste_closed_form(bn, logd):
     from wasmsnark_amd import synth
