@@ -1,5 +1,5 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --timeout 600 -p no:cacheprovider -k "adversarial" --durations=5 > gpurun_out/adv.txt 2>&1
-tail -25 gpurun_out/adv.txt
+timeout 1500 python tools/prove_big.py 22 24 > gpurun_out/prove_big.txt 2> gpurun_out/prove_big.err
+cat gpurun_out/prove_big.txt; tail -5 gpurun_out/prove_big.err

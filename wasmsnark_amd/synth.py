@@ -138,8 +138,10 @@ def _pol_blob(cols):
     return bytes(out)
 
 
-def build_key(circ, S, mul_base):
-    """Returns (proving_key.bin bytes, verification key dict in the reference's JSON shape)."""
+def build_sections(circ, S, mul_base):
+    """The key as separate sections (the input of wsnark_pkey_load_sections / Bn128.load_key(sections=...)):
+    what proving_key.bin holds, without its u32 offsets -- keys beyond 4 GiB (2^23 constraints and up) only
+    exist in this form.  Returns (sections dict, (IC points, beta2/delta2/gamma2 bytes) for the verification key)."""
     nv, npub, dom = circ.n_vars, circ.n_public, circ.domain
     dinv, ginv = pow(S.delta, R - 2, R), pow(S.gamma, R - 2, R)
     kc = [(S.beta * S.a[s] + S.alpha * S.b[s] + S.c[s]) % R for s in range(nv)]
@@ -161,19 +163,27 @@ def build_key(circ, S, mul_base):
     ptsC = g1[64 * o:64 * (o + nC)]; o += nC
     ptsH = g1[64 * o:64 * (o + dom)]; o += dom
     ic = [P1(o + i) for i in range(npub + 1)]
-    ptsB2 = g2[128 * 3:128 * (3 + nv)]
-    polsA, polsB = _pol_blob(circ.A), _pol_blob(circ.B)
+    sec = {"n_vars": nv, "n_public": npub, "domain": dom, "alfa1": P1(0), "beta1": P1(1), "delta1": P1(2),
+           "beta2": P2(0), "delta2": P2(1), "polsA": _pol_blob(circ.A), "polsB": _pol_blob(circ.B),
+           "pointsA": ptsA, "pointsB1": ptsB1, "pointsB2": g2[128 * 3:128 * (3 + nv)], "pointsC": ptsC, "pointsH": ptsH}
+    return sec, (ic, P2(2))
+
+
+def build_key(circ, S, mul_base):
+    """Returns (proving_key.bin bytes, verification key dict in the reference's JSON shape)."""
+    npub = circ.n_public
+    sec, (ic, gamma2) = build_sections(circ, S, mul_base)
+    P1 = lambda i: (sec["alfa1"], sec["beta1"], sec["delta1"])[i]
+    P2 = lambda i: (sec["beta2"], sec["delta2"], gamma2)[i]
     # tools/buildpkey.js:124-186 layout
-    fixed = P1(0) + P1(1) + P1(2) + P2(0) + P2(1)
-    pPolsA = 40 + len(fixed)
-    pPolsB = pPolsA + len(polsA)
-    pA = pPolsB + len(polsB)
-    pB1 = pA + len(ptsA)
-    pB2 = pB1 + len(ptsB1)
-    pC = pB2 + len(ptsB2)
-    pH = pC + len(ptsC)
-    header = struct.pack("<10I", nv, npub, dom, pPolsA, pPolsB, pA, pB1, pB2, pC, pH)
-    pkey = header + fixed + polsA + polsB + ptsA + ptsB1 + ptsB2 + ptsC + ptsH
+    fixed = sec["alfa1"] + sec["beta1"] + sec["delta1"] + sec["beta2"] + sec["delta2"]
+    parts = [sec["polsA"], sec["polsB"], sec["pointsA"], sec["pointsB1"], sec["pointsB2"], sec["pointsC"], sec["pointsH"]]
+    offs, o = [], 40 + len(fixed)
+    for part in parts:
+        offs.append(o)
+        o += len(part)
+    header = struct.pack("<10I", sec["n_vars"], npub, sec["domain"], *offs)
+    pkey = header + fixed + b"".join(parts)
 
     def dec1(p):  # Montgomery affine bytes -> decimal strings (x, y, 1)
         rinv = pow(MONT, Q - 2, Q)
