@@ -28,9 +28,22 @@ G2_GEN = (_mont(1085704699902305713594457076223282948137075635957851808699051999
 
 
 def _buf(b):
+    """Private mutable copy (for entry points that work in place)."""
     if isinstance(b, (bytes, bytearray, memoryview)):
         b = bytes(b)
         return (C.c_uint8 * max(len(b), 1)).from_buffer_copy(b if len(b) else b"\0"), len(b)
+    raise TypeError("expected a bytes-like object (the reference takes ArrayBuffers)")
+
+
+def _ro(b):
+    """Read-only input without a copy: the C side borrows the caller's bytes for the duration of the call
+    (a 2^20-pair MSM input is 96 MB; copying it in Python cost more than the MSM)."""
+    if isinstance(b, bytes):
+        return (C.c_char_p(b) if len(b) else C.c_char_p(b"\0")), len(b)
+    if isinstance(b, bytearray):
+        return ((C.c_uint8 * len(b)).from_buffer(b) if len(b) else C.c_char_p(b"\0")), len(b)
+    if isinstance(b, memoryview):
+        return _ro(b.obj if isinstance(b.obj, (bytes, bytearray)) and b.nbytes == len(b.obj) else bytes(b))
     raise TypeError("expected a bytes-like object (the reference takes ArrayBuffers)")
 
 
@@ -56,14 +69,14 @@ class ProvingKey:
             keep = []
             for name in ("alfa1", "beta1", "delta1", "beta2", "delta2", "polsA", "polsB", "pointsA", "pointsB1",
                          "pointsB2", "pointsC", "pointsH"):
-                b, n = _buf(sections[name])
+                b, n = _ro(sections[name])
                 keep.append(b)
                 setattr(ks, name, C.cast(b, C.c_void_p))
                 if name in ("polsA", "polsB"):
                     setattr(ks, name + "_len", n)
             lib.check(lib.c.wsnark_pkey_load_sections(C.byref(ks), C.byref(self._h)))
         else:
-            b, n = _buf(data)
+            b, n = _ro(data)
             lib.check(lib.c.wsnark_pkey_load(b, n, C.byref(self._h)))
         nv, npub, dom = C.c_uint32(), C.c_uint32(), C.c_uint32()
         lib.check(lib.c.wsnark_pkey_info(self._h, C.byref(nv), C.byref(npub), C.byref(dom)))
@@ -91,8 +104,8 @@ class Bn128:
 
     # --- src/bn128.js:353-383 ---
     def g1_multiexp(self, scalars, points):
-        s, ns = _buf(scalars)
-        p, np_ = _buf(points)
+        s, ns = _ro(scalars)
+        p, np_ = _ro(points)
         n = ns // 32
         if np_ < n * 64:
             raise ValueError("points buffer shorter than n*64 bytes")
@@ -102,8 +115,8 @@ class Bn128:
 
     # --- src/bn128.js:385-415 ---
     def g2_multiexp(self, scalars, points):
-        s, ns = _buf(scalars)
-        p, np_ = _buf(points)
+        s, ns = _ro(scalars)
+        p, np_ = _ro(points)
         n = ns // 32
         if np_ < n * 128:
             raise ValueError("points buffer shorter than n*128 bytes")
@@ -113,13 +126,13 @@ class Bn128:
 
     # --- the gather loop of src/bn128.js:374-382 / 406-414: EC sum of Jacobian partials ---
     def g1_sum(self, partials):
-        b, n = _buf(partials)
+        b, n = _ro(partials)
         out = (C.c_uint8 * 96)()
         self.lib.check(self.lib.c.wsnark_g1_sum(b, n // 96, out))
         return bytes(out)
 
     def g2_sum(self, partials):
-        b, n = _buf(partials)
+        b, n = _ro(partials)
         out = (C.c_uint8 * 192)()
         self.lib.check(self.lib.c.wsnark_g2_sum(b, n // 192, out))
         return bytes(out)
@@ -144,16 +157,16 @@ class Bn128:
 
     def groth16GenProof_dev(self, d_witness, witness_len, key, r=None, s=None, stream=None):
         out = (C.c_uint8 * 384)()
-        rb = _buf(r)[0] if r is not None else None
-        sb = _buf(s)[0] if s is not None else None
+        rb = _ro(r)[0] if r is not None else None
+        sb = _ro(s)[0] if s is not None else None
         self.lib.check(self.lib.c.wsnark_groth16_prove_dev(key._h, d_witness, witness_len, rb, sb, out, stream))
         return proof_from_bytes(bytes(out))
 
     # --- src/bn128.js:569-578 (worker CALC_H :126-166) ---
     def calcH(self, signals, polsA, polsB, nSignals, domainSize):
-        s, _ = _buf(signals)
-        a, la = _buf(polsA)
-        b, lb = _buf(polsB)
+        s, _ = _ro(signals)
+        a, la = _ro(polsA)
+        b, lb = _ro(polsB)
         out = (C.c_uint8 * (domainSize * 32))()
         self.lib.check(self.lib.c.wsnark_calc_h(s, a, la, b, lb, nSignals, domainSize, out))
         return bytes(out)
@@ -179,10 +192,10 @@ class Bn128:
 
     # --- synthetic-input helper (no reference counterpart): scalars[i] * generator, affine ---
     def mul_base(self, g, scalars, base=None):
-        s, ns = _buf(scalars)
+        s, ns = _ro(scalars)
         n = ns // 32
         sz = 64 if g == 1 else 128
-        b, _ = _buf(base if base is not None else (G1_GEN if g == 1 else G2_GEN))
+        b, _ = _ro(base if base is not None else (G1_GEN if g == 1 else G2_GEN))
         out = (C.c_uint8 * max(n * sz, 1))()
         fn = self.lib.c.wsnark_g1_mul_base_batch if g == 1 else self.lib.c.wsnark_g2_mul_base_batch
         self.lib.check(fn(b, s, n, out))
@@ -193,16 +206,16 @@ class Bn128:
 
     # --- multi-GPU proving: per-rank partial sums + host-side finish (include/wsnark.h) ---
     def groth16_prove_partial(self, signals, key):
-        w, nw = _buf(signals)
+        w, nw = _ro(signals)
         out = (C.c_uint8 * 576)()
         self.lib.check(self.lib.c.wsnark_groth16_prove_partial(key._h, w, nw, out))
         return bytes(out)
 
     def groth16_prove_finish(self, key, partials, r=None, s=None):
-        p, n = _buf(partials)
+        p, n = _ro(partials)
         out = (C.c_uint8 * 384)()
-        rb = _buf(r)[0] if r is not None else None
-        sb = _buf(s)[0] if s is not None else None
+        rb = _ro(r)[0] if r is not None else None
+        sb = _ro(s)[0] if s is not None else None
         self.lib.check(self.lib.c.wsnark_groth16_prove_finish(key._h, p, n // 576, rb, sb, out))
         return proof_from_bytes(bytes(out))
 
@@ -212,10 +225,10 @@ class Bn128:
         r, s: optional 32-byte blinding values (the reference draws them with
         crypto.randomBytes, src/bn128.js:642-661). Returns {pi_a, pi_b, pi_c} of decimal strings."""
         key = pkey if isinstance(pkey, ProvingKey) else ProvingKey(self.lib, pkey)
-        w, nw = _buf(signals)
+        w, nw = _ro(signals)
         out = (C.c_uint8 * 384)()
-        rb = _buf(r)[0] if r is not None else None
-        sb = _buf(s)[0] if s is not None else None
+        rb = _ro(r)[0] if r is not None else None
+        sb = _ro(s)[0] if s is not None else None
         if (r is not None and len(r) != 32) or (s is not None and len(s) != 32):
             raise ValueError("r and s must be 32 bytes")
         self.lib.check(self.lib.c.wsnark_groth16_prove(key._h, w, nw, rb, sb, out))

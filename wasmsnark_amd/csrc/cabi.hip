@@ -45,25 +45,6 @@ static_assert(sizeof(XYZZ<Fq>) == 128 && sizeof(XYZZ<Fq2>) == 256, "xyzz layouts
     Context* C = ctx();                                                      \
     if (!C) { set_last_error("wsnark_init() has not been called"); return WSNARK_ERR_NOINIT; }
 
-template <class AffT, class JacT, int (*FN)(const Fe*, const AffT*, uint64_t, JacT*, hipStream_t)>
-static int msm_host(const void* scalars, const void* points, uint64_t n, void* out) {
-    REQUIRE_CTX();
-    if (!out || (n && (!scalars || !points))) return WSNARK_ERR_ARG;
-    if (n > ((uint64_t)1 << 28)) return WSNARK_ERR_SIZE;
-    DevBuf ds, dp;
-    if (n) {
-        WS_HIP_CHECK(ds.alloc(n * 32));
-        WS_HIP_CHECK(dp.alloc(n * sizeof(AffT)));
-        WS_HIP_CHECK(hipMemcpyAsync(ds.p, scalars, n * 32, hipMemcpyHostToDevice, C->stream));
-        WS_HIP_CHECK(hipMemcpyAsync(dp.p, points, n * sizeof(AffT), hipMemcpyHostToDevice, C->stream));
-    }
-    JacT r;
-    int rc = FN(ds.as<Fe>(), dp.as<AffT>(), n, &r, C->stream);
-    if (rc) return rc;
-    memcpy(out, &r, sizeof r);
-    return WSNARK_OK;
-}
-
 extern "C" {
 
 int wsnark_init(int device) { return context_init(device); }
@@ -73,10 +54,24 @@ const char* wsnark_device_info(void) { return device_info().c_str(); }
 
 // ---- MSM ----
 int wsnark_g1_msm(const void* scalars, const void* points, uint64_t n, void* out96) {
-    return msm_host<Affine<Fq>, Jac<Fq>, msm_g1_dev>(scalars, points, n, out96);
+    REQUIRE_CTX();
+    if (!out96 || (n && (!scalars || !points))) return WSNARK_ERR_ARG;
+    if (n > ((uint64_t)1 << 28)) return WSNARK_ERR_SIZE;
+    Jac<Fq> r;
+    int rc = msm_g1_host(scalars, points, n, &r);
+    if (rc) return rc;
+    memcpy(out96, &r, sizeof r);
+    return WSNARK_OK;
 }
 int wsnark_g2_msm(const void* scalars, const void* points, uint64_t n, void* out192) {
-    return msm_host<Affine<Fq2>, Jac<Fq2>, msm_g2_dev>(scalars, points, n, out192);
+    REQUIRE_CTX();
+    if (!out192 || (n && (!scalars || !points))) return WSNARK_ERR_ARG;
+    if (n > ((uint64_t)1 << 28)) return WSNARK_ERR_SIZE;
+    Jac<Fq2> r;
+    int rc = msm_g2_host(scalars, points, n, &r);
+    if (rc) return rc;
+    memcpy(out192, &r, sizeof r);
+    return WSNARK_OK;
 }
 int wsnark_g1_msm_dev(const void* d_scalars, const void* d_points, uint64_t n, void* out96_host, void* stream) {
     REQUIRE_CTX();

@@ -2,6 +2,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <thread>
+
 #include "internal.h"
 
 namespace wsnark {
@@ -52,6 +55,10 @@ void context_shutdown() {
     g_ctx->ntt_plans.clear();
     g_ctx->ntt_scratch.release();
     msm_release_pending();
+    if (g_ctx->pin_ring) { (void)hipHostFree(g_ctx->pin_ring); g_ctx->pin_ring = nullptr; }
+    for (auto& e : g_ctx->pin_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    g_ctx->host_in[0].release();
+    g_ctx->host_in[1].release();
     g_ctx->msm_scratch[0].reset();
     g_ctx->msm_scratch[1].reset();
     (void)hipStreamDestroy(g_ctx->stream);
@@ -61,6 +68,54 @@ void context_shutdown() {
 }
 
 const std::string& device_info() { return g_devinfo; }
+
+// ---- staged uploads ----
+static const size_t PIN_CHUNK = (size_t)8 << 20;
+static const int PIN_WORKERS = 4, PIN_PER_WORKER = 2;
+int upload_staged(void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
+    Context* C = ctx();
+    if (!C) return WS_ERR_NOINIT;
+    if (!s) s = C->stream;
+    if (bytes == 0) return WS_OK;
+#ifdef WSNARK_EMUL
+    WS_HIP_CHECK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, s));
+    return WS_OK;
+#else
+    if (bytes < PIN_CHUNK / 2) {
+        WS_HIP_CHECK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, s));
+        return WS_OK;
+    }
+    static std::mutex ring_mu;                      // one upload at a time uses the ring
+    std::lock_guard<std::mutex> lk(ring_mu);
+    if (!C->pin_ring) {
+        WS_HIP_CHECK(hipHostMalloc(&C->pin_ring, PIN_CHUNK * PIN_WORKERS * PIN_PER_WORKER, 0));
+        for (auto& e : C->pin_ev) WS_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const size_t nchunks = (bytes + PIN_CHUNK - 1) / PIN_CHUNK;
+    const int device = C->device;
+    std::atomic<int> err(0);
+    auto worker = [&](int w) {
+        if (hipSetDevice(device) != hipSuccess) { err = 1; return; }
+        int use = 0;
+        for (size_t c = (size_t)w; c < nchunks; c += PIN_WORKERS, use++) {
+            const int b = w * PIN_PER_WORKER + (use % PIN_PER_WORKER);
+            char* pin = (char*)C->pin_ring + (size_t)b * PIN_CHUNK;
+            // the buffer's previous DMA (this call or an earlier one) must have drained
+            if (hipEventSynchronize(C->pin_ev[b]) != hipSuccess) { err = 1; return; }
+            const size_t off = c * PIN_CHUNK, len = off + PIN_CHUNK <= bytes ? PIN_CHUNK : bytes - off;
+            memcpy(pin, (const char*)h_src + off, len);
+            if (hipMemcpyAsync((char*)d_dst + off, pin, len, hipMemcpyHostToDevice, s) != hipSuccess ||
+                hipEventRecord(C->pin_ev[b], s) != hipSuccess) { err = 1; return; }
+        }
+    };
+    std::thread th[PIN_WORKERS - 1];
+    for (int w = 1; w < PIN_WORKERS; w++) th[w - 1] = std::thread(worker, w);
+    worker(0);
+    for (auto& t : th) t.join();
+    if (err) { set_last_error("staged upload failed"); return WS_ERR_HIP; }
+    return WS_OK;
+#endif
+}
 
 // ---- KernelTimer ----
 static hipEvent_t timer_event(std::vector<hipEvent_t>& pool) {

@@ -40,7 +40,17 @@ struct Context {
     std::shared_ptr<MsmScratch> msm_scratch[2];          // [0] G1, [1] G2
     DevBuf calch_buf[4];                                 // sigM, A, B, E
     KernelTimer timer;
+    // host-pointer boundary: pinned staging ring for uploads, grow-only device copies of the caller's buffers
+    void* pin_ring = nullptr;
+    hipEvent_t pin_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    DevBuf host_in[2];
 };
+
+// Host -> device copy of caller memory that may be pageable and never touched by the runtime before: worker
+// threads memcpy chunks into a pinned ring and queue one DMA per chunk on `s` (the runtime's own pageable
+// path pins fresh pages at ~10 GB/s; this runs at memcpy speed, ~40 GB/s).  Returns once the source has been
+// read completely; the DMAs may still be in flight on `s`.
+int upload_staged(void* d_dst, const void* h_src, size_t bytes, hipStream_t s);
 
 Context* ctx();   // nullptr before wsnark_init
 
@@ -58,6 +68,9 @@ int ntt_coset_tables(int bits, const Fe** lo, const Fe** hi, int* hc, Fe* n_inv,
 // Montgomery (x == 0 => infinity).  Result written to host memory as the reference's
 // Jacobian-Montgomery triple, affine-normalised: (x, y, 1) or (0, 1, 0).
 int msm_g1_dev(const Fe* d_scalars, const Affine<Fq>* d_points, uint64_t n, Jac<Fq>* out_host, hipStream_t s);
+// the same from host buffers (staged upload; the plan is built while the points are still on their way)
+int msm_g1_host(const void* h_scalars, const void* h_points, uint64_t n, Jac<Fq>* out_host);
+int msm_g2_host(const void* h_scalars, const void* h_points, uint64_t n, Jac<Fq2>* out_host);
 int msm_g2_dev(const Fe* d_scalars, const Affine<Fq2>* d_points, uint64_t n, Jac<Fq2>* out_host, hipStream_t s);
 // XYZZ result left to the caller (host memory), no affine normalisation
 // `prepared` = the point array was converted in place by msm_prepare_points (resident keys)

@@ -652,6 +652,7 @@ struct MsmPending {
     }
 };
 static hipEvent_t g_plan_done = nullptr;   // recorded at the end of msm_plan_dev
+static hipEvent_t g_host_ev = nullptr;     // msm_host_t: points uploaded (second queue)
 static const int kPendingSlots = 8;
 static MsmPending* g_slots = nullptr;   // released by msm_release_pending() at shutdown, while the runtime is alive
 static MsmPending* pending_slots() {
@@ -668,6 +669,7 @@ void msm_abort_pending(hipStream_t s) {
 }
 void msm_release_pending() {
     if (g_plan_done) { (void)hipEventDestroy(g_plan_done); g_plan_done = nullptr; }
+    if (g_host_ev) { (void)hipEventDestroy(g_host_ev); g_host_ev = nullptr; }
     if (!g_slots) return;
     for (int i = 0; i < kPendingSlots; i++) g_slots[i].release();
     delete[] g_slots;
@@ -1092,6 +1094,41 @@ int msm_g2_dev_xyzz(const Fe* d_scalars, const Affine<Fq2>* d_points, uint64_t n
     if (rc) return rc;
     return msm_g2_exec_xyzz(d_points, out_host, s, prepared);
 }
+// Host-pointer boundary (what the reference's g1_multiexp / g2_multiexp callers hold: plain host buffers).
+// Scalars go up first; the plan is built on the GPU while worker threads stage the points on the second queue.
+template <class H, class JacT>
+static int msm_host_t(int which, const void* h_scalars, const void* h_points, uint64_t n, JacT* out_host) {
+    Context* X = ctx();
+    if (!X) return WS_ERR_NOINIT;
+    if (n == 0) { *out_host = H::to_affine_jac(H::infinity()); return WS_OK; }
+    if (!h_scalars || !h_points) return WS_ERR_ARG;
+    hipStream_t s = X->stream, s2 = X->stream2;
+    std::lock_guard<std::mutex> lk(X->mu);
+    WS_HIP_CHECK(X->host_in[0].reserve((size_t)n * 32));
+    WS_HIP_CHECK(X->host_in[1].reserve((size_t)n * sizeof(typename H::Aff)));
+    if (!g_host_ev) WS_HIP_CHECK(hipEventCreateWithFlags(&g_host_ev, hipEventDisableTiming));
+    int rc = upload_staged(X->host_in[0].p, h_scalars, (size_t)n * 32, s);
+    if (rc) return rc;
+    if ((rc = msm_plan_dev(X->host_in[0].as<Fe>(), n, s))) return rc;
+    if ((rc = upload_staged(X->host_in[1].p, h_points, (size_t)n * sizeof(typename H::Aff), s2))) return rc;
+    WS_HIP_CHECK(hipEventRecord(g_host_ev, s2));
+    WS_HIP_CHECK(hipStreamWaitEvent(s, g_host_ev, 0));
+    typename H::Pt r;
+    int slot = -1;
+    rc = which == 0 ? msm_g1_launch(reinterpret_cast<const Affine<Fq>*>(X->host_in[1].p), false, &slot, s)
+                    : msm_g2_launch(reinterpret_cast<const Affine<Fq2>*>(X->host_in[1].p), false, &slot, s);
+    if (rc) return rc;
+    if ((rc = msm_finish_t<H>(pending_slots()[slot], &r))) return rc;
+    *out_host = H::to_affine_jac(r);
+    return WS_OK;
+}
+int msm_g1_host(const void* h_scalars, const void* h_points, uint64_t n, Jac<Fq>* out_host) {
+    return msm_host_t<G1, Jac<Fq>>(0, h_scalars, h_points, n, out_host);
+}
+int msm_g2_host(const void* h_scalars, const void* h_points, uint64_t n, Jac<Fq2>* out_host) {
+    return msm_host_t<G2, Jac<Fq2>>(1, h_scalars, h_points, n, out_host);
+}
+
 int msm_g1_dev(const Fe* d_scalars, const Affine<Fq>* d_points, uint64_t n, Jac<Fq>* out_host, hipStream_t s) {
     XYZZ<Fq> r;
     int rc = msm_g1_dev_xyzz(d_scalars, d_points, n, &r, s);

@@ -73,11 +73,11 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out) {
             // uses the SAME scalar vector -- and the same digit/sort plan -- as A, B1 and B2.
             WS_HIP_CHECK(sc.d->alloc((size_t)nv * 64));
             WS_HIP_CHECK(hipMemsetAsync(sc.d->p, 0, (size_t)(np + 1) * 64, s));
-            if (sc.bytes) WS_HIP_CHECK(hipMemcpyAsync((uint8_t*)sc.d->p + (size_t)(np + 1) * 64, sc.src, (size_t)sc.bytes, hipMemcpyHostToDevice, s));
+            if (sc.bytes && (rc = upload_staged((uint8_t*)sc.d->p + (size_t)(np + 1) * 64, sc.src, (size_t)sc.bytes, s))) return rc;
             continue;
         }
         WS_HIP_CHECK(sc.d->alloc((size_t)sc.bytes));
-        if (sc.bytes) WS_HIP_CHECK(hipMemcpyAsync(sc.d->p, sc.src, (size_t)sc.bytes, hipMemcpyHostToDevice, s));
+        if (sc.bytes && (rc = upload_staged(sc.d->p, sc.src, (size_t)sc.bytes, s))) return rc;
     }
     // resident keys are kept in the device field's internal domain: no per-proof conversion pass
     if ((rc = msm_prepare_points(0, K->pointsA.p, nv, s))) return rc;
@@ -339,7 +339,7 @@ int groth16_prove_partial(ProvingKey* K, const uint8_t* witness, size_t witness_
     if (!C) return WS_ERR_NOINIT;
     if ((uint64_t)witness_len < (uint64_t)K->n_vars * 32) { set_last_error("witness shorter than nVars*32 bytes"); return WS_ERR_SIZE; }
     std::lock_guard<std::mutex> lk(K->mu);
-    WS_HIP_CHECK(hipMemcpyAsync(K->witness.p, witness, (size_t)K->n_vars * 32, hipMemcpyHostToDevice, C->stream));
+    { int urc = upload_staged(K->witness.p, witness, (size_t)K->n_vars * 32, C->stream); if (urc) return urc; }
     MsmSums M;
     int rc = prove_msms(K, K->witness.as<Fe>(), &M, C->stream);
     if (rc) return rc;
@@ -381,7 +381,7 @@ int groth16_prove_host_witness(ProvingKey* K, const uint8_t* witness, size_t wit
     if (!C) return WS_ERR_NOINIT;
     if ((uint64_t)witness_len < (uint64_t)K->n_vars * 32) { set_last_error("witness shorter than nVars*32 bytes"); return WS_ERR_SIZE; }
     std::lock_guard<std::mutex> lk(K->mu);
-    WS_HIP_CHECK(hipMemcpyAsync(K->witness.p, witness, (size_t)K->n_vars * 32, hipMemcpyHostToDevice, C->stream));
+    { int urc = upload_staged(K->witness.p, witness, (size_t)K->n_vars * 32, C->stream); if (urc) return urc; }
     return groth16_prove(K, K->witness.as<Fe>(), r32, s32, out384, C->stream);
 }
 
