@@ -1,6 +1,10 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-timeout 600 python tools/hostpath.py > gpurun_out/hostpath.txt 2>&1
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --timeout 300 -p no:cacheprovider 2>&1 | tail -2 >> gpurun_out/hostpath.txt
-tail -8 gpurun_out/hostpath.txt
+rm -f gpurun_out/overlap2.txt
+for cfg in "1 0" "3 1" "1 1" "3 0" "2 1" "3 1" "1 0"; do
+  set -- $cfg
+  echo "== OVERLAP=$1 S2_PRIO=$2" >> gpurun_out/overlap2.txt
+  WSNARK_PROVE_OVERLAP=$1 WSNARK_S2_PRIO=$2 timeout 300 python tools/trace_prove.py 2>&1 | grep -E "prove ms" | tail -2 >> gpurun_out/overlap2.txt
+done
+cat gpurun_out/overlap2.txt

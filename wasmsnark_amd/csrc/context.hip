@@ -39,7 +39,15 @@ int context_init(int device) {
     C->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     g_devinfo = std::string(prop.name) + " " + prop.gcnArchName + " CUs=" + std::to_string(C->num_cu);
     WS_HIP_CHECK(hipStreamCreateWithFlags(&C->stream, hipStreamNonBlocking));
-    WS_HIP_CHECK(hipStreamCreateWithFlags(&C->stream2, hipStreamNonBlocking));
+    {   // the second queue gets the device's highest priority (WSNARK_S2_PRIO=0 turns that off): its work is released
+        // at chosen points of the first queue's schedule and should then be dispatched ahead of what is still queued
+        const char* e = getenv("WSNARK_S2_PRIO");
+        int lo = 0, hi = 0;
+        if (!(e && atoi(e) == 0) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
+            WS_HIP_CHECK(hipStreamCreateWithPriority(&C->stream2, hipStreamNonBlocking, hi));
+        else
+            WS_HIP_CHECK(hipStreamCreateWithFlags(&C->stream2, hipStreamNonBlocking));
+    }
     g_ctx = C;
     return WS_OK;
 }

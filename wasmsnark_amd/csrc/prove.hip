@@ -178,7 +178,8 @@ struct MsmSums {
 // Two in-order queues.  Stream s: the witness plan, A, B1, C (one batched tail), B2.  Stream 2: CALC_H, the H
 // plan and the H sum -- released when the first reduction tail starts, so its full-width kernels fill the
 // SIMDs that the latency-bound tails (a chain of ~30 dependent point additions on a few hundred wavefronts)
-// leave idle (measured on MI355X, prove 2^20: 14.5 ms on one queue, 13.5-13.8 ms with two; releasing the second
+// leave idle (measured on MI355X, prove 2^20: 14.5 ms on one queue, 13.5-13.8 ms with two, 13.2 ms when the second
+// queue also has the device's highest priority, so that CALC_H is dispatched ahead of the rest of B2; releasing the second
 // queue at once (=2) or holding H back until B2's tail is the same within noise).  The host finishes each sum
 // while the GPU works on the next ones; `after_ab1` (optional) runs on the host as soon as A and B1 are known.
 // WSNARK_PROVE_OVERLAP=0 keeps everything on one queue.
