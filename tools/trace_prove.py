@@ -11,3 +11,7 @@ d_w = torch.frombuffer(bytearray(wit), dtype=torch.uint8).cuda(); torch.cuda.syn
 r32, s32 = bytes(range(32)), bytes(range(32, 64))
 for i in range(3):
     t0 = time.perf_counter(); bn.groth16GenProof_dev(d_w.data_ptr(), len(wit), key, r=r32, s=s32); print("prove ms", (time.perf_counter() - t0) * 1e3, file=sys.stderr)
+if os.environ.get("WSNARK_TIMELINE") == "1":
+    bn.lib.c.wsnark_timing_reset(); bn.lib.c.wsnark_timing_enable(1)
+    bn.groth16GenProof_dev(d_w.data_ptr(), len(wit), key, r=r32, s=s32)
+    bn.lib.c.wsnark_timing_enable(0); bn.lib.timing_report()

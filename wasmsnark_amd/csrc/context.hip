@@ -1,4 +1,5 @@
 // context.hip -- library context, error string, per-kernel HIP-event timing.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -148,10 +149,17 @@ void KernelTimer::end(hipStream_t s) {
     (void)hipEventRecord(recs.back().b, s);
 }
 void KernelTimer::collect() {
+    // WSNARK_TIMELINE=1: start/end of every bracket relative to the first one (both queues share the device clock)
+    static const bool timeline = [] { const char* e = getenv("WSNARK_TIMELINE"); return e && atoi(e) == 1; }();
     for (auto& r : recs) {
         float ms = 0.f;
         (void)hipEventSynchronize(r.b);
         (void)hipEventElapsedTime(&ms, r.a, r.b);
+        if (timeline && !recs.empty()) {
+            float t0 = 0.f;
+            (void)hipEventElapsedTime(&t0, recs.front().a, r.a);
+            fprintf(stderr, "[wsnark timeline] %9.3f -> %9.3f  %s\n", t0, t0 + ms, r.name);
+        }
         auto& a = acc[r.name];
         a.first += ms;
         a.second += 1;
