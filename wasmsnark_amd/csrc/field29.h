@@ -215,7 +215,8 @@ struct Field29 {
 
     // a*b - c*d with one reduction: a*b + (2p - c)*d.  a, b may be sub_weak results (< 4p), c, d < 2p:
     // (16 p^2 + 4 p^2 + 2^261 p) / 2^261 < 1.12 p.
-    WS_HD static F29 mulsub2(const F29& a, const F29& b, const F29& c, const F29& d) {
+    // 2p - c for c in [0, 2p): in (0, 2p], tight limbs; only ever an operand of a product
+    WS_HD static F29 neg_weak(const F29& c) {
         F29 n;
         int32_t cy = 0;
 #pragma unroll
@@ -225,7 +226,52 @@ struct Field29 {
             cy = t >> 29;
         }
         n.v[8] = (uint32_t)((int32_t)p2_limb(8) - (int32_t)c.v[8] + cy);
+        return n;
+    }
+    WS_HD static F29 mulsub2(const F29& a, const F29& b, const F29& c, const F29& d) {
+        const F29 n = neg_weak(c);
         return mont_mul2add29<P>(WS_A9(a), WS_A9(b), WS_A9(n), WS_A9(d));
+    }
+    // (a*b + c*d + e*f + g*h) * 2^-261 mod p with ONE reduction: one component of a*b - c*d in the quadratic
+    // extension.  Operands < 2p with tight limbs: every column holds <= 36 products + 9 reduction terms
+    // < 45 * 2^58 < 2^64; (16 p^2 + 2^261 p) / 2^261 < 1.1 p.  Inlined (eight operands do not fit the registers
+    // of the calling convention).
+    WS_HD static F29 mul4add(const F29& a, const F29& b, const F29& c, const F29& d, const F29& e, const F29& f,
+                             const F29& g, const F29& h) {
+        uint32_t m[9];
+        uint64_t acc = 0;
+        F29 r;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+#pragma unroll
+            for (int i = 0; i <= k; i++) {
+                acc += (uint64_t)a.v[i] * b.v[k - i];
+                acc += (uint64_t)c.v[i] * d.v[k - i];
+                acc += (uint64_t)e.v[i] * f.v[k - i];
+                acc += (uint64_t)g.v[i] * h.v[k - i];
+            }
+#pragma unroll
+            for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * p_limb(k - i);
+            m[k] = ((uint32_t)acc * NP29) & WS_M29;
+            acc += (uint64_t)m[k] * p_limb(0);
+            acc >>= 29;
+        }
+#pragma unroll
+        for (int k = 9; k < 17; k++) {
+#pragma unroll
+            for (int i = k - 8; i <= 8; i++) {
+                acc += (uint64_t)a.v[i] * b.v[k - i];
+                acc += (uint64_t)c.v[i] * d.v[k - i];
+                acc += (uint64_t)e.v[i] * f.v[k - i];
+                acc += (uint64_t)g.v[i] * h.v[k - i];
+            }
+#pragma unroll
+            for (int i = k - 8; i <= 8; i++) acc += (uint64_t)m[i] * p_limb(k - i);
+            r.v[k - 9] = (uint32_t)acc & WS_M29;
+            acc >>= 29;
+        }
+        r.v[8] = (uint32_t)acc;
+        return r;
     }
 
     // canonical representative in [0, p) of a value in [0, 2p)

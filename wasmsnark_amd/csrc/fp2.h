@@ -55,7 +55,17 @@ struct Fp2T {
         BE C = B::mul(B::add_lazy(a.c0, a.c1), B::add_lazy(b.c0, b.c1));   // sums feed a product only
         return El{B::sub(A, Bv), B::sub(C, B::add(A, Bv))};
     }
-    WS_HD static El mulsub2(const El& a, const El& b, const El& c, const El& d) { return sub(mul(a, b), mul(c, d)); }
+    // a*b - c*d: with the fused four-product reduction two Montgomery passes instead of four products + a correction
+    template <class BB = B>
+    WS_HD static typename std::enable_if<BB::kHasMul2Add, El>::type mulsub2(const El& a, const El& b, const El& c, const El& d) {
+        const BE nb1 = B::neg_weak(b.c1), nc0 = B::neg_weak(c.c0), nc1 = B::neg_weak(c.c1);
+        return El{B::mul4add(a.c0, b.c0, a.c1, nb1, nc0, d.c0, c.c1, d.c1),
+                  B::mul4add(a.c0, b.c1, a.c1, b.c0, nc0, d.c1, nc1, d.c0)};
+    }
+    template <class BB = B>
+    WS_HD static typename std::enable_if<!BB::kHasMul2Add, El>::type mulsub2(const El& a, const El& b, const El& c, const El& d) {
+        return sub(mul(a, b), mul(c, d));
+    }
     // complex squaring, 2 base-field products (build_f2m.js:186-227)
     WS_HD static El sqr(const El& a) {
         BE AB = B::mul(a.c0, a.c1);
