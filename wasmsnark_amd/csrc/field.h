@@ -181,6 +181,7 @@ struct Field {
     WS_HD static Fe sub_weak(const Fe& a, const Fe& b) { return sub(a, b); }
     WS_HD static bool is_zero_weak(const Fe& a) { return is_zero(a); }
     WS_HD static Fe mulsub2(const Fe& a, const Fe& b, const Fe& c, const Fe& d) { return sub(mul(a, b), mul(c, d)); }
+    WS_HD static Fe mul_inl(const Fe& a, const Fe& b) { return mul(a, b); }
 
     // build_f1m.js:86-100
     WS_HD static Fe sub(const Fe& a, const Fe& b) {

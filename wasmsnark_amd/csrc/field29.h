@@ -51,6 +51,9 @@ template <class P> WS_NOINLINE_DEV F29 mont_mul2add29(WS_L9(a), WS_L9(b), WS_L9(
 template <class P> WS_HD F29 mont_mul29_body(const F29& a, const F29& b);
 
 #define WS_M29 0x1FFFFFFFu
+#ifndef WS_F29_MULSUB_INLINE
+#define WS_F29_MULSUB_INLINE 0
+#endif
 
 // limb i (29 bits; limb 8 takes the rest) of the 256-bit integer (w3:w2:w1:w0)
 constexpr uint32_t ws_limb29(uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3, int i) {
@@ -206,6 +209,7 @@ struct Field29 {
     // ---- Montgomery product a*b*2^-261 mod p; inputs < 2p (limbs < 2^29), output < 2p ----
     WS_HD static F29 mul(const F29& a, const F29& b) { return mont_mul29<P>(WS_A9(a), WS_A9(b)); }
     WS_HD static F29 sqr(const F29& a) { return mont_sqr29<P>(WS_A9(a)); }
+    WS_HD static F29 mul_inl(const F29& a, const F29& b) { return mont_mul29_body<P>(a, b); }
     // (a*b + c*d) * 2^-261 mod p with ONE Montgomery reduction (the quadratic-extension product needs two
     // of these instead of three products and five additions).  Inputs < 2p, output < 2p:
     // (8p^2 + 2^261 p)/2^261 < 1.05p; columns <= 18 products + 9 reduction terms < 2^63.
@@ -230,7 +234,45 @@ struct Field29 {
     }
     WS_HD static F29 mulsub2(const F29& a, const F29& b, const F29& c, const F29& d) {
         const F29 n = neg_weak(c);
+#if WS_F29_MULSUB_INLINE
+        return mul2add_inl(a, b, n, d);
+#else
         return mont_mul2add29<P>(WS_A9(a), WS_A9(b), WS_A9(n), WS_A9(d));
+#endif
+    }
+    // mul2add as an inlinable body (the quadratic extension's products: the call passes 36 operands, four of
+    // them through scratch memory)
+    WS_HD static F29 mul2add_inl(const F29& a, const F29& b, const F29& c, const F29& d) {
+        uint32_t m[9];
+        uint64_t acc = 0;
+        F29 r;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+#pragma unroll
+            for (int i = 0; i <= k; i++) {
+                acc += (uint64_t)a.v[i] * b.v[k - i];
+                acc += (uint64_t)c.v[i] * d.v[k - i];
+            }
+#pragma unroll
+            for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * p_limb(k - i);
+            m[k] = ((uint32_t)acc * NP29) & WS_M29;
+            acc += (uint64_t)m[k] * p_limb(0);
+            acc >>= 29;
+        }
+#pragma unroll
+        for (int k = 9; k < 17; k++) {
+#pragma unroll
+            for (int i = k - 8; i <= 8; i++) {
+                acc += (uint64_t)a.v[i] * b.v[k - i];
+                acc += (uint64_t)c.v[i] * d.v[k - i];
+            }
+#pragma unroll
+            for (int i = k - 8; i <= 8; i++) acc += (uint64_t)m[i] * p_limb(k - i);
+            r.v[k - 9] = (uint32_t)acc & WS_M29;
+            acc >>= 29;
+        }
+        r.v[8] = (uint32_t)acc;
+        return r;
     }
     // (a*b + c*d + e*f + g*h) * 2^-261 mod p with ONE reduction: one component of a*b - c*d in the quadratic
     // extension.  Operands < 2p with tight limbs: every column holds <= 36 products + 9 reduction terms

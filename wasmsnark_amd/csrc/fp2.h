@@ -9,6 +9,14 @@
 
 #include "field.h"
 
+#ifndef WS_FP2_INLINE
+#define WS_FP2_INLINE 1   // products of the quadratic extension as inlined bodies (G2 accumulate 4.15 -> 3.93 ms)
+#endif
+
+#ifndef WS_FP2_SQR_INLINE
+#define WS_FP2_SQR_INLINE 1   // (G2 accumulate 3.76 -> 3.65 ms)
+#endif
+
 namespace wsnark {
 
 template <class E>
@@ -46,7 +54,11 @@ struct Fp2T {
     template <class BB = B>
     WS_HD static typename std::enable_if<BB::kHasMul2Add, El>::type mul(const El& a, const El& b) {
         const BE nb1 = B::neg(b.c1);
+#if WS_FP2_INLINE
+        return El{B::mul2add_inl(a.c0, b.c0, a.c1, nb1), B::mul2add_inl(a.c0, b.c1, a.c1, b.c0)};
+#else
         return El{B::mul2add(a.c0, b.c0, a.c1, nb1), B::mul2add(a.c0, b.c1, a.c1, b.c0)};
+#endif
     }
     template <class BB = B>
     WS_HD static typename std::enable_if<!BB::kHasMul2Add, El>::type mul(const El& a, const El& b) {
@@ -68,8 +80,13 @@ struct Fp2T {
     }
     // complex squaring, 2 base-field products (build_f2m.js:186-227)
     WS_HD static El sqr(const El& a) {
+#if WS_FP2_SQR_INLINE
+        BE AB = B::mul_inl(a.c0, a.c1);
+        BE t = B::mul_inl(B::add_lazy(a.c0, a.c1), B::sub(a.c0, a.c1));
+#else
         BE AB = B::mul(a.c0, a.c1);
         BE t = B::mul(B::add_lazy(a.c0, a.c1), B::sub(a.c0, a.c1));
+#endif
         return El{t, B::dbl(AB)};
     }
     // inverse via the norm (build_f2m.js:353-383)
