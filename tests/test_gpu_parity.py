@@ -299,6 +299,66 @@ def test_prove_vs_toxic_waste_closed_form(bn, logd):
         assert got == synth.expected_proof(circ, S, r, s, bn.mul_base)
 
 
+def test_concurrent_callers(bn, orc):
+    """Four host threads at once on one context: proofs with two different resident keys, host-pointer MSMs,
+    and NTT / CALC_H calls.  The library serialises what shares scratch; every result must still be exact."""
+    import threading
+    from wasmsnark_amd import synth
+    jobs = []
+    for logd, seed in ((12, 21), (13, 22)):
+        circ = synth.make_circuit(logd, n_public=3, seed=seed)
+        S = synth.setup(circ, seed=seed + 100)
+        pkey, _ = synth.build_key(circ, S, bn.mul_base)
+        r32, s32 = bytes([seed]) * 32, bytes([seed + 1]) * 32
+        jobs.append((bn.load_key(pkey), synth.witness_bin(circ), r32, s32, synth.expected_proof(circ, S, r32, s32, bn.mul_base)))
+    n = 5000
+    rnd = random.Random(5)
+    ks = [rnd.randrange(1, orc.R) for _ in range(n)]
+    pts = bn.mul_base(1, b"".join(k.to_bytes(32, "little") for k in ks))
+    ss = [rnd.randrange(1 << 256) for _ in range(n)]
+    sc = b"".join(v.to_bytes(32, "little") for v in ss)
+    want_msm = bn.mul_base(1, (sum(a * b for a, b in zip(ss, ks)) % orc.R).to_bytes(32, "little"))
+    errors = []
+
+    def prover(key, wit, r32, s32, want):
+        try:
+            for _ in range(6):
+                if bn.groth16GenProof(wit, key, r=r32, s=s32) != want:
+                    errors.append("proof mismatch")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def msms():
+        try:
+            for _ in range(12):
+                if bn.g1_multiexp(sc, pts)[:64] != want_msm:
+                    errors.append("msm mismatch")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def transforms():
+        try:
+            data = rand_fr(random.Random(9), 1 << 12)
+            mont = bn.toMontgomeryN(data)
+            for _ in range(10):
+                if bn.ifft(bn.fft(mont)) != mont:
+                    errors.append("ntt round trip mismatch")
+            for c in load_golden("calch.json"):
+                h = bn.calcH(B64(c["signals"]), B64(c["polsA"]), B64(c["polsB"]), c["nSignals"], c["domain"])
+                if h != B64(c["h"]):
+                    errors.append("calcH mismatch")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = ([threading.Thread(target=prover, args=j) for j in jobs] + [threading.Thread(target=msms)]
+          + [threading.Thread(target=transforms)])
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:3]
+
+
 def test_prove_small_vs_oracle(bn, orc):
     from wasmsnark_amd import synth
     circ = synth.make_circuit(8, n_public=2, seed=88)

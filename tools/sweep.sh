@@ -1,12 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-B="python bench.py --steps 10 --warmup 2 --no-extras --no-cpu-baseline"
-run() { echo "== $*" ; env "$@" $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); k=d['kernel_ms']; print(d['value'], d['ms_per_step'], k['msm_accumulate_g1'], k['msm_chunks'], k['msm_tree'])"; }
-{
-run X=1
-run WSNARK_LIB=$GRAFT_REPO_ROOT/tools/alt/libwsnark_mulsub_inline.so
-run X=2
-run WSNARK_LIB=$GRAFT_REPO_ROOT/tools/alt/libwsnark_mulsub_inline.so
-} > gpurun_out/inl.txt 2>&1
-cat gpurun_out/inl.txt
+for i in 1 2 3; do timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --timeout 300 -p no:cacheprovider -k "concurrent" 2>&1 | tail -2; done > gpurun_out/conc.txt 2>&1
+timeout 900 python -m pytest tests -m gpu -q -x --timeout 300 -p no:cacheprovider 2>&1 | tail -2 >> gpurun_out/conc.txt
+timeout 300 python tools/trace_prove.py 2>&1 | grep "prove ms" | tail -2 >> gpurun_out/conc.txt
+cat gpurun_out/conc.txt

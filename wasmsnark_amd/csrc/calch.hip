@@ -129,6 +129,7 @@ int calc_h_dev(const Fe* d_signals_plain, uint32_t n_signals, const CsrMatrix& A
     int bits = 0;
     while ((1u << bits) < domain) bits++;
     const size_t nb = (size_t)domain * sizeof(Fe);
+    ScratchGuard scratch_turn(C->calch_chain, s);   // the work arrays below are shared by every CALC_H of the context
     {
         std::lock_guard<std::mutex> lk(C->mu);
         WS_HIP_CHECK(C->calch_buf[0].reserve((size_t)n_signals * sizeof(Fe)));

@@ -63,6 +63,8 @@ void context_shutdown() {
     g_ctx->timer.pool.clear();
     g_ctx->ntt_plans.clear();
     g_ctx->ntt_scratch.release();
+    if (g_ctx->ntt_chain.done) (void)hipEventDestroy(g_ctx->ntt_chain.done);
+    if (g_ctx->calch_chain.done) (void)hipEventDestroy(g_ctx->calch_chain.done);
     msm_release_pending();
     if (g_ctx->pin_ring) { (void)hipHostFree(g_ctx->pin_ring); g_ctx->pin_ring = nullptr; }
     for (auto& e : g_ctx->pin_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }

@@ -25,6 +25,28 @@ struct KernelTimer {
     void reset();
 };
 
+// Users of a context-wide scratch area (NTT ping-pong buffer, CALC_H work arrays) come from any host thread on
+// any stream: one of them enqueues at a time, and on the device each one starts after the previous one -- which may
+// have run on another stream -- has finished.
+struct ScratchChain {
+    std::mutex mu;
+    hipEvent_t done = nullptr;
+    hipStream_t last = nullptr;
+};
+struct ScratchGuard {
+    ScratchChain& c;
+    hipStream_t s;
+    std::unique_lock<std::mutex> lk;
+    ScratchGuard(ScratchChain& c_, hipStream_t s_) : c(c_), s(s_), lk(c_.mu) {
+        if (c.done && c.last != s) (void)hipStreamWaitEvent(s, c.done, 0);
+    }
+    ~ScratchGuard() {
+        if (!c.done) (void)hipEventCreateWithFlags(&c.done, hipEventDisableTiming);
+        (void)hipEventRecord(c.done, s);
+        c.last = s;
+    }
+};
+
 struct NttPlan;    // ntt.hip
 struct MsmScratch; // msm.hip
 
@@ -39,6 +61,7 @@ struct Context {
     DevBuf ntt_scratch;
     std::shared_ptr<MsmScratch> msm_scratch[2];          // [0] G1, [1] G2
     DevBuf calch_buf[4];                                 // sigM, A, B, E
+    ScratchChain ntt_chain, calch_chain;                 // who may touch ntt_scratch / calch_buf next
     KernelTimer timer;
     // host-pointer boundary: pinned staging ring for uploads, grow-only device copies of the caller's buffers
     void* pin_ring = nullptr;

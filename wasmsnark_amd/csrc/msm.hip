@@ -653,7 +653,7 @@ struct MsmPending {
 };
 static hipEvent_t g_plan_done = nullptr;   // recorded at the end of msm_plan_dev
 static hipEvent_t g_host_ev = nullptr;     // msm_host_t: points uploaded (second queue)
-static const int kPendingSlots = 8;
+static const int kPendingSlots = 16;   // two proofs of different keys may have launches in flight at once (5 each)
 static MsmPending* g_slots = nullptr;   // released by msm_release_pending() at shutdown, while the runtime is alive
 static MsmPending* pending_slots() {
     if (!g_slots) g_slots = new MsmPending[kPendingSlots];

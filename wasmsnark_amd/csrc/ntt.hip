@@ -363,6 +363,7 @@ int ntt_dev(Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s) {
         // (src/build_fft.js:575-583) -> reported as a size error here
         return inverse ? WS_ERR_SIZE : WS_OK;
     }
+    ScratchGuard scratch_turn(C->ntt_chain, s);   // the ping-pong buffer is shared by every transform of the context
     std::shared_ptr<NttPlan> P;
     {
         int rc = get_plan(C, bits, P, s);
