@@ -23,6 +23,12 @@
  * "_dev" variants take DEVICE pointers (hipMalloc / torch tensor data_ptr) and a
  * hipStream_t (as void*; NULL = the library's own stream); results that are a single
  * group element are still written to HOST memory.
+ *
+ * Threading: every entry point may be called from any host thread at any time (the Node addon calls from
+ * the libuv pool).  Calls that share device scratch are serialised inside the library (one MSM plan at a
+ * time per context, one proof at a time per key handle); unlike the reference's WASM instance
+ * (static scratch, non-re-entrant) no caller-side queue is needed.
+ * Host buffers are read through a pinned staging ring and are free for reuse when the call returns.
  */
 #ifndef WSNARK_H
 #define WSNARK_H
