@@ -67,6 +67,19 @@ static inline uint32_t __shfl_xor(uint32_t v, int m, int width = 64) {
     return ::hip_emul::shfl_exchange(v, (int)(threadIdx.x & 63) ^ m, 64);
 }
 
+// wave vote: every lane of the wave must call it (butterfly OR of one-bit masks over the exchange primitive)
+static inline unsigned long long __ballot(int pred) {
+    const int lane = (int)(threadIdx.x & 63);
+    uint32_t lo = (pred && lane < 32) ? (1u << lane) : 0u, hi = (pred && lane >= 32) ? (1u << (lane - 32)) : 0u;
+    for (int m = 1; m < 64; m <<= 1) {
+        lo |= ::hip_emul::shfl_exchange(lo, lane ^ m, 64);
+        hi |= ::hip_emul::shfl_exchange(hi, lane ^ m, 64);
+    }
+    return ((unsigned long long)hi << 32) | lo;
+}
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+
 template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }

@@ -103,6 +103,19 @@ def test_msm_vs_oracle_skewed(bn, orc, g, n):
     assert out == want
 
 
+@pytest.mark.parametrize("g,n", [(1, 700), (2, 200)])
+def test_msm_hot_bucket_path(bn, orc, monkeypatch, g, n):
+    """Buckets with very many tasks (one scalar value shared by most pairs: the ones of a boolean-heavy witness)
+    have their task list and their partial sums handled by many workgroups; forced here with a tiny threshold."""
+    monkeypatch.setenv("WSNARK_MSM_HOT_MIN", "2")
+    rnd = random.Random(300 + g)
+    ks = [rnd.randrange(1, orc.R) for _ in range(n)]
+    pts = _points(orc, g, ks)
+    sc = b"".join((1 if rnd.random() < 0.7 else rnd.randrange(orc.R)).to_bytes(32, "little") for _ in range(n))
+    out = bn.g1_multiexp(sc, pts) if g == 1 else bn.g2_multiexp(sc, pts)
+    assert out == orc.g_affine(g, orc.multiexp(g, "multiexp2" if g == 1 else "multiexp", sc, pts, n))
+
+
 def test_msm_same_point_many_times(bn, orc):
     # every pair identical: exercises the doubling branch of the mixed add and hot buckets
     n = 257

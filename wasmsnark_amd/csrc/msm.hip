@@ -43,7 +43,7 @@ namespace wsnark {
 static const uint32_t CHUNK = 8;          // buckets per msm_chunks lane
 
 struct MsmScratch {
-    DevBuf keys, vals, keys_out, vals_out, sort_tmp, entries, bins;
+    DevBuf keys, vals, keys_out, vals_out, sort_tmp, entries, bins, hot, hot_sums;
     DevBuf bstart, bend, buckets, counters, tasks, multi, partials;
     DevBuf chunkS, chunkA, sums, points_conv;
 };
@@ -218,6 +218,28 @@ __device__ __forceinline__ uint32_t len_key(uint32_t len, uint32_t lmax) {
 // one workgroup per bin: LDS counting sort over the low bucket bits, bucket bounds written directly;
 // the bucket lengths are known here, so the planner's task-length histogram is taken on the way
 static const uint32_t PRESORT_MAX_LO = 10;
+// counters[key] += 1 for every active lane, returning the lane's rank.  When the whole wavefront hits ONE counter
+// (a hot bucket: boolean-heavy witnesses put half their entries into digit 1 of window 0) a single atomic serves
+// all 64 lanes instead of a 64-way LDS conflict.  Every lane of the wavefront must call it.
+__device__ __forceinline__ uint32_t wave_rank_add(uint32_t* counters, uint32_t key, bool active) {
+    const unsigned long long act = __ballot(active);
+    if (act == 0) return 0;
+    const uint32_t lane = threadIdx.x & 63;
+    const int first = __ffsll(act) - 1;
+    const uint32_t k0 = __shfl(key, first);
+    const unsigned long long same = __ballot(active && key == k0);
+    uint32_t r = 0;
+    if (same == act) {
+        uint32_t base = 0;
+        if (lane == (uint32_t)first) base = atomicAdd(&counters[k0], (uint32_t)__popcll(act));
+        base = __shfl(base, first);
+        r = base + (uint32_t)__popcll(act & ((1ull << lane) - 1));
+    } else if (active) {
+        r = atomicAdd(&counters[key], 1u);
+    }
+    return r;
+}
+
 template <class E>
 __global__ __launch_bounds__(1024) void presort_bins(const E* __restrict__ entries, const uint32_t* __restrict__ bin_start,
                                                        uint32_t lo_bits, uint32_t idx_bits, uint32_t* __restrict__ vals_out,
@@ -232,8 +254,12 @@ __global__ __launch_bounds__(1024) void presort_bins(const E* __restrict__ entri
     for (uint32_t t = threadIdx.x; t < SUB; t += blockDim.x) sub[t] = 0;
     for (uint32_t t = threadIdx.x; t < 256; t += blockDim.x) lhist[t] = 0;
     __syncthreads();
-    // four independent loads in flight per thread: the bin loops are latency-bound otherwise
-    for (uint32_t i = s + threadIdx.x; i < e; i += 4 * blockDim.x) {
+    // four independent loads in flight per thread (the bin loops are latency-bound otherwise); the trip count is
+    // uniform over the workgroup because the counter updates are wavefront-cooperative
+    const uint32_t stride = 4 * blockDim.x;
+    const uint32_t iters = (e - s + stride - 1) / stride;
+    for (uint32_t it = 0; it < iters; it++) {
+        const uint32_t i = s + threadIdx.x + it * stride;
         E v[4];
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) {
@@ -241,8 +267,7 @@ __global__ __launch_bounds__(1024) void presort_bins(const E* __restrict__ entri
             v[u] = j < e ? entries[j] : (E)0;
         }
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++)
-            if (i + u * blockDim.x < e) atomicAdd(&sub[PresortEntry<E>::lo(v[u], idx_bits)], 1u);
+        for (uint32_t u = 0; u < 4; u++) (void)wave_rank_add(sub, PresortEntry<E>::lo(v[u], idx_bits), i + u * blockDim.x < e);
     }
     __syncthreads();
     // exclusive scan of sub[0..SUB): thread t owns `per` consecutive counters, Hillis-Steele over the partials
@@ -275,7 +300,8 @@ __global__ __launch_bounds__(1024) void presort_bins(const E* __restrict__ entri
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < 256; t += blockDim.x)
         if (lhist[t]) atomicAdd(&hist[t], lhist[t]);
-    for (uint32_t i = s + threadIdx.x; i < e; i += 4 * blockDim.x) {
+    for (uint32_t it = 0; it < iters; it++) {
+        const uint32_t i = s + threadIdx.x + it * stride;
         E v[4];
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) {
@@ -284,11 +310,10 @@ __global__ __launch_bounds__(1024) void presort_bins(const E* __restrict__ entri
         }
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) {
-            if (i + u * blockDim.x < e) {
-                const uint32_t lo = PresortEntry<E>::lo(v[u], idx_bits);
-                const uint32_t r = atomicAdd(&sub[lo], 1u);
-                vals_out[off[lo] + r] = PresortEntry<E>::val(v[u], idx_bits);
-            }
+            const bool active = i + u * blockDim.x < e;
+            const uint32_t lo = PresortEntry<E>::lo(v[u], idx_bits);
+            const uint32_t r = wave_rank_add(sub, lo, active);
+            if (active) vals_out[off[lo] + r] = PresortEntry<E>::val(v[u], idx_bits);
         }
     }
 }
@@ -354,6 +379,11 @@ __global__ __launch_bounds__(256) void msm_convert_points(const typename C::AffP
 static const uint32_t PARTIAL_FLAG = 0x80000000u;
 struct Task { uint32_t dst, start, len; };          // dst: bucket index, or PARTIAL_FLAG | partial slot
 struct MultiBucket { uint32_t bucket, first_partial, ntasks; };
+// Very hot buckets (>= HOT_MIN tasks: one value shared by a large part of the scalars, e.g. the ones of a
+// boolean-heavy witness) get their task list written and their partial sums combined by many workgroups.
+static const uint32_t HOT_MIN = 1024;      // tasks
+static const uint32_t HOT_SLICE = 512;     // partial sums per first-stage wavefront
+struct HotBucket { uint32_t bucket, first_partial, ntasks, task_base, rem_index, start, rem, slice_base; };
 
 __global__ __launch_bounds__(256) void msm_plan_hist(const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bend,
                                                        uint32_t nbuckets, uint32_t lmax, uint32_t* __restrict__ hist) {
@@ -384,7 +414,8 @@ __global__ void msm_plan_offsets(const uint32_t* __restrict__ hist, uint32_t* __
 __global__ __launch_bounds__(256) void msm_plan_emit(const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bend,
                                                        uint32_t nbuckets, uint32_t lmax, uint32_t* __restrict__ cursor,
                                                        Task* __restrict__ tasks, uint32_t* __restrict__ counters,
-                                                       MultiBucket* __restrict__ multi) {
+                                                       MultiBucket* __restrict__ multi, HotBucket* __restrict__ hot,
+                                                       uint32_t hot_min) {
     __shared__ uint32_t lcnt[256];
     __shared__ uint32_t lbase[256];
     lcnt[threadIdx.x] = 0;
@@ -411,9 +442,27 @@ __global__ __launch_bounds__(256) void msm_plan_emit(const uint32_t* __restrict_
         tasks[lbase[krem] + rrem] = Task{b, s, rem};
     } else {
         const uint32_t pbase = atomicAdd(&counters[0], nt);
+        if (nt >= hot_min) {      // task list and combine are spread over many workgroups (msm_plan_emit_hot, msm_combine_hot*)
+            const uint32_t nsl = (nt + HOT_SLICE - 1) / HOT_SLICE;
+            hot[atomicAdd(&counters[4], 1u)] = HotBucket{b, pbase, nt, lbase[255] + r255, lbase[krem] + rrem, s, rem,
+                                                         atomicAdd(&counters[5], nsl)};
+            return;
+        }
         multi[atomicAdd(&counters[1], 1u)] = MultiBucket{b, pbase, nt};
         for (uint32_t k = 0; k + 1 < nt; k++) tasks[lbase[255] + r255 + k] = Task{PARTIAL_FLAG | (pbase + k), s + k * lmax, lmax};
         tasks[lbase[krem] + rrem] = Task{PARTIAL_FLAG | (pbase + nt - 1), s + (nt - 1) * lmax, rem};
+    }
+}
+
+__global__ __launch_bounds__(256) void msm_plan_emit_hot(const HotBucket* __restrict__ hot, const uint32_t* __restrict__ counters,
+                                                           uint32_t lmax, Task* __restrict__ tasks) {
+    const uint32_t nhot = counters[4];
+    for (uint32_t hb = blockIdx.x; hb < nhot; hb += gridDim.x) {
+        const HotBucket h = hot[hb];
+        for (uint32_t k = threadIdx.x; k + 1 < h.ntasks; k += blockDim.x)
+            tasks[h.task_base + k] = Task{PARTIAL_FLAG | (h.first_partial + k), h.start + k * lmax, lmax};
+        if (threadIdx.x == 0)
+            tasks[h.rem_index] = Task{PARTIAL_FLAG | (h.first_partial + h.ntasks - 1), h.start + (h.ntasks - 1) * lmax, h.rem};
     }
 }
 
@@ -499,6 +548,57 @@ __global__ __launch_bounds__(64) void msm_combine_wave(const MultiBucket* __rest
         if (h.ntasks < WAVE_COMBINE_MIN) continue;
         typename C::Pt acc = C::infinity();
         for (uint32_t k = lane; k < h.ntasks; k += 64) acc = C::add(acc, C::unpack_pt(partials[h.first_partial + k]));
+        sh[lane] = C::pack_pt(acc);
+        __syncthreads();
+        for (uint32_t step = 32; step >= 1; step >>= 1) {
+            if (lane < step) sh[lane] = C::pack_pt(C::add(C::unpack_pt(sh[lane]), C::unpack_pt(sh[lane + step])));
+            __syncthreads();
+        }
+        if (lane == 0) buckets[h.bucket] = sh[0];
+        __syncthreads();
+    }
+}
+
+// 5c. very hot buckets: stage 1 = one wavefront per HOT_SLICE partial sums (lanes stride, LDS tree), stage 2 = one
+// wavefront per bucket over the slice sums
+template <class C>
+__global__ __launch_bounds__(64) void msm_combine_hot1(const HotBucket* __restrict__ hot, const uint32_t* __restrict__ counters,
+                                                         const typename C::PtP* __restrict__ partials,
+                                                         typename C::PtP* __restrict__ slice_sums) {
+    __shared__ typename C::PtP sh[64];
+    const uint32_t nhot = counters[4], lane = threadIdx.x;
+    for (uint32_t hb = 0; hb < nhot; hb++) {                          // few entries; every workgroup walks them all
+        const HotBucket h = hot[hb];
+        const uint32_t nsl = (h.ntasks + HOT_SLICE - 1) / HOT_SLICE;
+        // slices are dealt round-robin over the workgroups by their GLOBAL number, so that many moderately hot
+        // buckets spread as well as one very hot one
+        const uint32_t sl0 = (blockIdx.x + gridDim.x - h.slice_base % gridDim.x) % gridDim.x;
+        for (uint32_t sl = sl0; sl < nsl; sl += gridDim.x) {          // uniform per workgroup
+            const uint32_t lo = sl * HOT_SLICE, hi = lo + HOT_SLICE < h.ntasks ? lo + HOT_SLICE : h.ntasks;
+            typename C::Pt acc = C::infinity();
+            for (uint32_t k = lo + lane; k < hi; k += 64) acc = C::add(acc, C::unpack_pt(partials[h.first_partial + k]));
+            sh[lane] = C::pack_pt(acc);
+            __syncthreads();
+            for (uint32_t step = 32; step >= 1; step >>= 1) {
+                if (lane < step) sh[lane] = C::pack_pt(C::add(C::unpack_pt(sh[lane]), C::unpack_pt(sh[lane + step])));
+                __syncthreads();
+            }
+            if (lane == 0) slice_sums[h.slice_base + sl] = sh[0];
+            __syncthreads();
+        }
+    }
+}
+template <class C>
+__global__ __launch_bounds__(64) void msm_combine_hot2(const HotBucket* __restrict__ hot, const uint32_t* __restrict__ counters,
+                                                         const typename C::PtP* __restrict__ slice_sums,
+                                                         typename C::PtP* __restrict__ buckets) {
+    __shared__ typename C::PtP sh[64];
+    const uint32_t nhot = counters[4], lane = threadIdx.x;
+    for (uint32_t hb = blockIdx.x; hb < nhot; hb += gridDim.x) {
+        const HotBucket h = hot[hb];
+        const uint32_t nsl = (h.ntasks + HOT_SLICE - 1) / HOT_SLICE;
+        typename C::Pt acc = C::infinity();
+        for (uint32_t k = lane; k < nsl; k += 64) acc = C::add(acc, C::unpack_pt(slice_sums[h.slice_base + k]));
         sh[lane] = C::pack_pt(acc);
         __syncthreads();
         for (uint32_t step = 32; step >= 1; step >>= 1) {
@@ -623,6 +723,7 @@ bool msm_uses_field29() {
 struct MsmPlanInfo {
     uint64_t n = 0;
     uint32_t c = 0, W = 0, NB = 0, nbuckets = 0, m = 0, J = 0, logJ = 0, nsum = 0, lmax = 0, hot_cap = 0;
+    uint32_t hot_min = 1024;
     uint32_t Wall = 0, w_off = 0, w_stride = 1;   // W = owned windows; Wall = windows of the whole scalar
     uint32_t ntasks = 0, nmulti = 0;
     bool valid = false;
@@ -648,7 +749,7 @@ struct MsmPending {
         ev_acc = nullptr;
         h_sums = nullptr; ev = nullptr; h_bytes = 0; active = false;
         d_sums.release(); d_queue.release();
-        S.buckets.release(); S.partials.release(); S.chunkS.release(); S.chunkA.release(); S.points_conv.release();
+        S.buckets.release(); S.partials.release(); S.chunkS.release(); S.chunkA.release(); S.points_conv.release(); S.hot_sums.release();
     }
 };
 static hipEvent_t g_plan_done = nullptr;   // recorded at the end of msm_plan_dev
@@ -767,6 +868,10 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
     WS_HIP_CHECK(S.counters.reserve(4096));
     WS_HIP_CHECK(S.tasks.reserve((size_t)I.hot_cap * sizeof(Task)));
     WS_HIP_CHECK(S.multi.reserve((size_t)I.hot_cap * sizeof(MultiBucket)));
+    uint32_t hot_min = HOT_MIN;      // (WSNARK_MSM_HOT_MIN: lets small tests reach the hot-bucket path)
+    if (const char* e = getenv("WSNARK_MSM_HOT_MIN")) { int v = atoi(e); if (v >= 2) hot_min = (uint32_t)v; }
+    I.hot_min = hot_min;
+    WS_HIP_CHECK(S.hot.reserve(((size_t)I.hot_cap / hot_min + 16) * sizeof(HotBucket)));
 
     KernelTimer& T = X->timer;
     // counters: [0] partial slots, [1] multi-task buckets, [3] total tasks; [16..271] length histogram,
@@ -849,7 +954,8 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
     hipLaunchKernelGGL(msm_plan_offsets, dim3(1), dim3(64), 0, s, d_cnt + 16, d_cnt + 272, d_cnt);
     hipLaunchKernelGGL(msm_plan_emit, dim3(ceil_div_u64(nbuckets, 256)), dim3(256), 0, s, S.bstart.as<uint32_t>(),
                        S.bend.as<uint32_t>(), nbuckets, lmax, d_cnt + 272, S.tasks.as<Task>(), d_cnt,
-                       S.multi.as<MultiBucket>());
+                       S.multi.as<MultiBucket>(), S.hot.as<HotBucket>(), hot_min);
+    hipLaunchKernelGGL(msm_plan_emit_hot, dim3(64), dim3(256), 0, s, S.hot.as<HotBucket>(), d_cnt, lmax, S.tasks.as<Task>());
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
     // task / partial counts stay on the device (counters[3], [1], [0]); by construction
@@ -941,6 +1047,12 @@ static int msm_launch_acc(int which, const typename H::Aff* d_points_ref, bool p
                        PS.counters.as<uint32_t>(), S.partials.as<Pt>(), S.buckets.as<Pt>());
     hipLaunchKernelGGL(msm_combine_wave<C>, dim3(2048), dim3(64), 0, s, PS.multi.as<MultiBucket>(),
                        PS.counters.as<uint32_t>(), S.partials.as<Pt>(), S.buckets.as<Pt>());
+    // (slice sums: at most one per HOT_SLICE tasks plus one per hot bucket)
+    WS_HIP_CHECK(S.hot_sums.reserve(((size_t)I.hot_cap / HOT_SLICE + (size_t)I.hot_cap / I.hot_min + 32) * sizeof(Pt)));
+    hipLaunchKernelGGL(msm_combine_hot1<C>, dim3(1024), dim3(64), 0, s, PS.hot.as<HotBucket>(), PS.counters.as<uint32_t>(),
+                       S.partials.as<Pt>(), S.hot_sums.as<Pt>());
+    hipLaunchKernelGGL(msm_combine_hot2<C>, dim3(64), dim3(64), 0, s, PS.hot.as<HotBucket>(), PS.counters.as<uint32_t>(),
+                       S.hot_sums.as<Pt>(), S.buckets.as<Pt>());
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
 
