@@ -7,18 +7,23 @@
 // reproduced: any correct MSM yields the same group element, and results are compared
 // after affine normalisation (src/bn128.js:706-712).
 //
-// Pipeline (all device-resident; one lane = one scalar / one bucket):
-//   1 msm_digits      scalar (32 B coalesced) -> reduced mod r -> W signed c-bit digits
-//                      -> (key = window*NB + |d|-1, val = index | sign<<31), window-major
-//   2 radix sort      (hipCUB device radix sort over the used key bits)
-//   3 msm_bounds      bucket start/end from the sorted keys
-//   4 msm_accumulate  one lane per bucket: mixed additions (XYZZ += affine, 8M+2S) of the
-//                      bucket's points, gathered 64/128 B per lane; buckets longer than LMAX
-//                      spill fixed-size tasks to a hot list
-//   5 msm_hot_*       one lane per hot task, then one wavefront per hot bucket: LDS tree
-//   6 msm_chunks      one lane per 8 buckets: S_j = sum B, A_j = sum (i-i0+1) B
-//   7 msm_tree        per (window, bit q): LDS tree sums U_q = sum_{j: bit q} S_j, and sum A_j
-//   8 host            sum_w 2^(c w) (A_w + 8 sum_q 2^q U_{w,q}): ~W*(log J + 1) points, a serial
+// Pipeline (all device-resident; a plan depends on the scalars only and is shared by every point set that
+// uses the same scalars -- the prover's A, B1, B2 and C sums):
+//   plan  1 presort_count/scan/scatter  scalar (32 B coalesced) -> reduced mod r -> signed c-bit digits on the
+//                      fly -> ONE scatter of (index | sign | low bucket bits) entries into coarse bins
+//                      (window x top bucket bits), block-reserved ranges, ranks from LDS atomics
+//         2 presort_bins   one workgroup per bin: LDS counting sort over the low bucket bits, bucket bounds,
+//                      task-length histogram (wavefront-aggregated counters for hot buckets)
+//         3 msm_plan_*     buckets cut into tasks of <= lmax entries, ordered longest-first (255-level
+//                      counting sort); very hot buckets get their task list from a workgroup each
+//         (WSNARK_MSM_SORT=cub: msm_digits + hipCUB radix sort + msm_bounds, the first version, for A/B runs)
+//   exec  4 msm_accumulate  one lane per task: mixed additions (XYZZ += affine, 8M+2S) of the task's points,
+//                      gathered 64/128 B per lane, next point in flight during the current addition
+//         5 msm_combine_*   partial sums of split buckets: one lane, one wavefront (LDS tree), or -- very hot
+//                      buckets -- one wavefront per 512 partial sums and a second stage per bucket
+//         6 msm_chunks      one lane per 8 buckets: S_j = sum B, A_j = sum (i-i0+1) B
+//         7 msm_tree        per (window, bit q): LDS tree sums U_q = sum_{j: bit q} S_j, and sum A_j
+//         8 host            sum_w 2^(c w) (A_w + 8 sum_q 2^q U_{w,q}): ~W*(log J + 1) points, a serial
 //                      doubling chain that is faster on one CPU core than on one GPU lane.
 #include <string.h>
 
