@@ -773,9 +773,11 @@ void msm_abort_pending(hipStream_t s) {
         g_slots[i].active = false;
     }
 }
+void msm_release_conv();
 void msm_release_pending() {
     if (g_plan_done) { (void)hipEventDestroy(g_plan_done); g_plan_done = nullptr; }
     if (g_host_ev) { (void)hipEventDestroy(g_host_ev); g_host_ev = nullptr; }
+    msm_release_conv();
     if (!g_slots) return;
     for (int i = 0; i < kPendingSlots; i++) g_slots[i].release();
     delete[] g_slots;
@@ -1191,25 +1193,63 @@ int msm_prepare_points(int which, void* d_points, uint64_t n, hipStream_t s) {
     return WS_OK;
 }
 
+// The conversion of caller points to the device field's internal domain does not depend on the plan: it runs on
+// the second queue while the first one groups the digits (returns the array the accumulation should read).
+static hipEvent_t g_conv_ev[2] = {nullptr, nullptr};
+static DevBuf* g_conv_buf = nullptr;
+template <class CD, class AffT>
+static int convert_beside_plan(Context* X, const AffT* d_points, uint64_t n, hipStream_t s, const AffT** out, bool* prepared) {
+    *out = d_points;
+    if (*prepared || !msm_uses_field29() || !CD::Field::kInternalDomain || n < (1u << 14) || s == X->stream2) return WS_OK;
+    for (auto& e : g_conv_ev) if (!e) WS_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (!g_conv_buf) g_conv_buf = new DevBuf();
+    WS_HIP_CHECK(g_conv_buf->reserve((size_t)n * sizeof(typename CD::AffP)));
+    WS_HIP_CHECK(hipEventRecord(g_conv_ev[0], s));                 // the caller's points are ready on s
+    WS_HIP_CHECK(hipStreamWaitEvent(X->stream2, g_conv_ev[0], 0));
+    X->timer.begin("msm_convert_points", X->stream2);
+    hipLaunchKernelGGL(msm_convert_points<CD>, dim3(ceil_div_u64(n, 256)), dim3(256), 0, X->stream2,
+                       reinterpret_cast<const typename CD::AffP*>(d_points), g_conv_buf->as<typename CD::AffP>(), n);
+    X->timer.end(X->stream2);
+    WS_HIP_CHECK(hipEventRecord(g_conv_ev[1], X->stream2));
+    *out = g_conv_buf->as<AffT>();
+    *prepared = true;
+    return WS_OK;
+}
+
+void msm_release_conv() {
+    for (auto& e : g_conv_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    if (g_conv_buf) { delete g_conv_buf; g_conv_buf = nullptr; }
+}
+
 int msm_g1_dev_xyzz(const Fe* d_scalars, const Affine<Fq>* d_points, uint64_t n, XYZZ<Fq>* out_host, hipStream_t s,
                     bool prepared) {
     Context* X = ctx();
     if (!X) return WS_ERR_NOINIT;
     if (n && !d_points) return WS_ERR_ARG;
+    if (!s) s = X->stream;
     std::lock_guard<std::mutex> lk(X->mu);   // plan + scratch are shared: one MSM at a time
-    int rc = msm_plan_dev(d_scalars, n, s);
+    const Affine<Fq>* pts = d_points;
+    const bool was_prepared = prepared;
+    int rc = convert_beside_plan<G1R29>(X, d_points, n, s, &pts, &prepared);
     if (rc) return rc;
-    return msm_g1_exec_xyzz(d_points, out_host, s, prepared);
+    if ((rc = msm_plan_dev(d_scalars, n, s))) return rc;
+    if (prepared && !was_prepared) WS_HIP_CHECK(hipStreamWaitEvent(s, g_conv_ev[1], 0));
+    return msm_g1_exec_xyzz(pts, out_host, s, prepared);
 }
 int msm_g2_dev_xyzz(const Fe* d_scalars, const Affine<Fq2>* d_points, uint64_t n, XYZZ<Fq2>* out_host, hipStream_t s,
                     bool prepared) {
     Context* X = ctx();
     if (!X) return WS_ERR_NOINIT;
     if (n && !d_points) return WS_ERR_ARG;
+    if (!s) s = X->stream;
     std::lock_guard<std::mutex> lk(X->mu);
-    int rc = msm_plan_dev(d_scalars, n, s);
+    const Affine<Fq2>* pts = d_points;
+    const bool was_prepared = prepared;
+    int rc = convert_beside_plan<G2R29>(X, d_points, n, s, &pts, &prepared);
     if (rc) return rc;
-    return msm_g2_exec_xyzz(d_points, out_host, s, prepared);
+    if ((rc = msm_plan_dev(d_scalars, n, s))) return rc;
+    if (prepared && !was_prepared) WS_HIP_CHECK(hipStreamWaitEvent(s, g_conv_ev[1], 0));
+    return msm_g2_exec_xyzz(pts, out_host, s, prepared);
 }
 // Host-pointer boundary (what the reference's g1_multiexp / g2_multiexp callers hold: plain host buffers).
 // Scalars go up first; the plan is built on the GPU while worker threads stage the points on the second queue.
