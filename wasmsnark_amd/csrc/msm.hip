@@ -791,23 +791,23 @@ static int msm_finish_t(MsmPending& P, typename H::Pt* out_host) {
     if (I.n == 0) { *out_host = H::infinity(); P.active = false; return WS_OK; }
     WS_HIP_CHECK(hipEventSynchronize(P.ev));
     const HPt* sums = reinterpret_cast<const HPt*>(P.h_sums);
-    // 8. host tail: result = sum_w 2^(c w) [ A_w + m * sum_q 2^q U_{w,q} ]   (Horner, MSB first)
+    // 8. host tail: result = sum_w 2^(c w) [ A_w + m * sum_q 2^q U_{w,q} ].  ONE Horner chain over the bit
+    // positions of the whole scalar (MSB first): U_{w,q} sits at bit c*w + log2(m) + q, A_w at bit c*w, and
+    // log2(m) + logJ = c - 1, so every window's terms fall inside its own c positions: c*Wall doublings and
+    // (logJ + 1) additions per owned window -- no per-window inner chain.
     uint32_t logm = 0;
     while ((1u << logm) < I.m) logm++;
     HPt acc = H::infinity();
+    bool started = false;                                  // leading doublings of infinity are skipped
     for (int wg = (int)I.Wall - 1; wg >= 0; wg--) {      // global window index; rows exist for the owned ones
-        for (uint32_t k = 0; k < I.c; k++) acc = H::dbl(acc);
-        if ((uint32_t)wg < I.w_off || ((uint32_t)wg - I.w_off) % I.w_stride) continue;
-        const uint32_t w = ((uint32_t)wg - I.w_off) / I.w_stride;
-        const HPt* row = &sums[(size_t)w * I.nsum];
-        HPt u = H::infinity();
-        for (int q = (int)I.logJ - 1; q >= 0; q--) {
-            u = H::dbl(u);
-            u = H::add(u, row[q]);
+        const bool owned = (uint32_t)wg >= I.w_off && ((uint32_t)wg - I.w_off) % I.w_stride == 0;
+        const HPt* row = owned ? &sums[(size_t)(((uint32_t)wg - I.w_off) / I.w_stride) * I.nsum] : nullptr;
+        for (int k = (int)I.c - 1; k >= 0; k--) {
+            if (started) acc = H::dbl(acc);
+            if (!owned) continue;
+            if ((uint32_t)k >= logm && (uint32_t)k - logm < I.logJ) { acc = H::add(acc, row[(uint32_t)k - logm]); started = true; }
+            if (k == 0) { acc = H::add(acc, row[I.logJ]); started = true; }
         }
-        for (uint32_t k = 0; k < logm; k++) u = H::dbl(u);
-        u = H::add(u, row[I.logJ]);
-        acc = H::add(acc, u);
     }
     *out_host = acc;
     P.active = false;
