@@ -26,14 +26,21 @@ def shard_bounds(n, world, rank):
 
 
 def allgather_partials(partial, device=None):
-    """partial: bytes (96 or 192).  Returns the concatenation over ranks, in rank order."""
+    """partial: bytes (96 or 192, or a 576-byte prove record).  Returns the concatenation over ranks, in rank
+    order.  One collective into one contiguous tensor and one copy back: the per-step cost that the multi-GPU
+    bench adds to every MSM."""
     world = dist.get_world_size()
     t = torch.frombuffer(bytearray(partial), dtype=torch.uint8)
     if device is not None:
         t = t.to(device)
-    out = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(out, t)
-    return b"".join(bytes(o.cpu().numpy().tobytes()) for o in out)
+    out = torch.empty(world * t.numel(), dtype=torch.uint8, device=t.device)
+    try:
+        dist.all_gather_into_tensor(out, t)
+    except (RuntimeError, NotImplementedError, AttributeError):      # backend without the fused form
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        out = torch.cat(parts)
+    return out.cpu().numpy().tobytes()
 
 
 def sharded_msm(bn, g, local_partial, device=None):
