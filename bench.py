@@ -154,6 +154,7 @@ def main():
                 "avg_launch_ms": round(acc_ms / acc_cnt, 4), "algorithmic_bytes_per_launch": 96 * n,
                 "modmul_per_launch": 10 * 16 * n,
                 "achieved_Gmodmul_s": round(10 * 16 * n / avg_s / 1e9, 1), "peak_Gmodmul_s_microbench": 172.0,
+                "frac_of_multiplier_peak": round(10 * 16 * n / avg_s / 1e9 / 172.0, 4),
                 "note": "integer-ALU bound (256-bit modmul): 16 windows x 10 products per pair; the multiplier's "
                         "measured chip peak is 172 G modmul/s (tools/microbench.hip). Traffic is ~15x the algorithmic "
                         "bytes because a windowed MSM gathers every point once per window (16 x 64 B), mostly from the "
