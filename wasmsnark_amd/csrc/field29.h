@@ -456,7 +456,7 @@ struct Field29I : Field29<P> {
     WS_HD static F29 mul(const F29& a, const F29& b) { return mont_mul29_body<P>(a, b); }
     WS_HD static F29 sqr(const F29& a) { return mont_mul29_body<P>(a, a); }
     WS_HD static F29 mulsub2(const F29& a, const F29& b, const F29& c, const F29& d) {
-        return Field29<P>::sub(mul(a, b), mul(c, d));
+        return Field29<P>::mul2add_inl(a, b, Field29<P>::neg_weak(c), d);   // fused, like Field29's, but inlined
     }
 };
 
