@@ -497,30 +497,6 @@ __global__ __launch_bounds__(256, (sizeof(typename C::PtP) > 128 ? WS_ACC_WAVES_
     else buckets[k.dst] = acc;
 }
 
-// persistent form: a fixed grid of wavefronts pulls 64 tasks at a time from a device-side queue head
-// (tasks are sorted longest-first, so late pulls are short: no tail of partially filled CUs)
-template <class C>
-__global__ __launch_bounds__(256, (sizeof(typename C::PtP) > 128 ? WS_ACC_WAVES_G2 : WS_ACC_WAVES)) void msm_accumulate_persist(
-    const typename C::AffP* __restrict__ points, const uint32_t* __restrict__ vals, const Task* __restrict__ tasks,
-    const uint32_t* __restrict__ counters, uint32_t* __restrict__ queue_head, typename C::PtP* __restrict__ buckets,
-    typename C::PtP* __restrict__ partials) {
-    const uint32_t ntasks = counters[3];
-    const uint32_t lane = threadIdx.x & 63;
-    for (;;) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(queue_head, 64u);
-        base = __shfl(base, 0);
-        if (base >= ntasks) break;
-        const uint32_t t = base + lane;
-        if (t < ntasks) {
-            const Task k = tasks[t];
-            const typename C::PtP acc = C::pack_pt(accumulate_range<C>(points, vals, k.start, k.len));
-            if (k.dst & PARTIAL_FLAG) partials[k.dst & ~PARTIAL_FLAG] = acc;
-            else buckets[k.dst] = acc;
-        }
-    }
-}
-
 // 5a. buckets cut into a few tasks: one lane sums the partials
 static const uint32_t WAVE_COMBINE_MIN = 17;
 template <class C>
@@ -741,7 +717,7 @@ struct MsmPending {
     int which = 0;
     int plan_id = 0;
     MsmPlanInfo info;
-    DevBuf d_sums, d_queue;
+    DevBuf d_sums;
     MsmScratch S;                 // this launch's accumulation buffers (buckets, partials, chunk sums)
     void* h_sums = nullptr;
     size_t h_bytes = 0;
@@ -753,7 +729,7 @@ struct MsmPending {
         if (ev_acc) (void)hipEventDestroy(ev_acc);
         ev_acc = nullptr;
         h_sums = nullptr; ev = nullptr; h_bytes = 0; active = false;
-        d_sums.release(); d_queue.release();
+        d_sums.release();
         S.buckets.release(); S.partials.release(); S.chunkS.release(); S.chunkA.release(); S.points_conv.release(); S.hot_sums.release();
     }
 };
@@ -1035,18 +1011,9 @@ static int msm_launch_acc(int which, const typename H::Aff* d_points_ref, bool p
     T.begin(which ? "msm_accumulate_g2" : "msm_accumulate_g1", s);
     hipLaunchKernelGGL(msm_clear_empty<C>, dim3(ceil_div_u64(nbuckets, 256)), dim3(256), 0, s, PS.bstart.as<uint32_t>(),
                        PS.bend.as<uint32_t>(), nbuckets, S.buckets.as<Pt>());
-    static const int persist = [] { const char* e = getenv("WSNARK_MSM_PERSIST"); return e ? atoi(e) : 0; }();
-    if (persist > 0) {
-        WS_HIP_CHECK(P.d_queue.reserve(256));
-        WS_HIP_CHECK(hipMemsetAsync(P.d_queue.p, 0, 4, s));
-        hipLaunchKernelGGL(msm_accumulate_persist<C>, dim3((uint32_t)X->num_cu * (uint32_t)persist), dim3(256), 0, s, d_points,
-                           PS.vals_out.as<uint32_t>(), PS.tasks.as<Task>(), PS.counters.as<uint32_t>(),
-                           P.d_queue.as<uint32_t>(), S.buckets.as<Pt>(), S.partials.as<Pt>());
-    } else {
-        hipLaunchKernelGGL(msm_accumulate<C>, dim3(ceil_div_u64(ntasks, 256)), dim3(256), 0, s, d_points,
-                           PS.vals_out.as<uint32_t>(), PS.tasks.as<Task>(), PS.counters.as<uint32_t>(), S.buckets.as<Pt>(),
-                           S.partials.as<Pt>());
-    }
+    hipLaunchKernelGGL(msm_accumulate<C>, dim3(ceil_div_u64(ntasks, 256)), dim3(256), 0, s, d_points,
+                       PS.vals_out.as<uint32_t>(), PS.tasks.as<Task>(), PS.counters.as<uint32_t>(), S.buckets.as<Pt>(),
+                       S.partials.as<Pt>());
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
     T.begin("msm_combine", s);
