@@ -48,7 +48,7 @@ namespace wsnark {
 static const uint32_t CHUNK = 8;          // buckets per msm_chunks lane
 
 struct MsmScratch {
-    DevBuf keys, vals, keys_out, vals_out, sort_tmp, entries, bins, hot, hot_sums;
+    DevBuf keys, vals, keys_out, vals_out, sort_tmp, entries, hot, hot_sums;
     DevBuf bstart, bend, buckets, counters, tasks, multi, partials;
     DevBuf chunkS, chunkA, sums, points_conv;
 };
@@ -408,22 +408,32 @@ __global__ __launch_bounds__(256) void msm_plan_hist(const uint32_t* __restrict_
     if (lcnt[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lcnt[threadIdx.x]);
 }
 
-// cursor[k] = number of tasks with a longer key (descending order); counters[3] = total tasks
-__global__ void msm_plan_offsets(const uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor, uint32_t* __restrict__ counters) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint32_t off = 0;
-    for (int k = 255; k >= 0; k--) { cursor[k] = off; off += hist[k]; }
-    counters[3] = off;
-}
-
+// Tasks are laid out longest-first: the slots of key k start after all tasks with a longer key.  Every workgroup
+// derives those starts from the (complete) histogram itself -- 256 entries -- instead of a separate one-thread
+// kernel; `cursor` (zeroed) only hands out ranks within a key.  counters[3] = total tasks.
 __global__ __launch_bounds__(256) void msm_plan_emit(const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bend,
-                                                       uint32_t nbuckets, uint32_t lmax, uint32_t* __restrict__ cursor,
+                                                       uint32_t nbuckets, uint32_t lmax, const uint32_t* __restrict__ hist,
+                                                       uint32_t* __restrict__ cursor,
                                                        Task* __restrict__ tasks, uint32_t* __restrict__ counters,
                                                        MultiBucket* __restrict__ multi, HotBucket* __restrict__ hot,
                                                        uint32_t hot_min) {
     __shared__ uint32_t lcnt[256];
     __shared__ uint32_t lbase[256];
+    __shared__ uint32_t first[256];          // start of key k's slots = number of tasks with a longer key
     lcnt[threadIdx.x] = 0;
+    first[threadIdx.x] = hist[threadIdx.x];
+    __syncthreads();
+    // inclusive suffix sum over the 256 keys (Hillis-Steele), then shift to exclusive
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        const uint32_t v = threadIdx.x + d < 256 ? first[threadIdx.x + d] : 0;
+        __syncthreads();
+        first[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[3] = first[0];
+    const uint32_t excl = threadIdx.x + 1 < 256 ? first[threadIdx.x + 1] : 0;
+    __syncthreads();
+    first[threadIdx.x] = excl;
     __syncthreads();
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t cnt = 0, s = 0, nt = 0, rem = 0, krem = 0, r255 = 0, rrem = 0;
@@ -439,7 +449,7 @@ __global__ __launch_bounds__(256) void msm_plan_emit(const uint32_t* __restrict_
         }
     }
     __syncthreads();
-    lbase[threadIdx.x] = lcnt[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], lcnt[threadIdx.x]) : 0;
+    lbase[threadIdx.x] = lcnt[threadIdx.x] ? first[threadIdx.x] + atomicAdd(&cursor[threadIdx.x], lcnt[threadIdx.x]) : 0;
     __syncthreads();
     if (!cnt) return;
     // the full tasks were ranked before the remainder when krem == 255: keep the two ranges disjoint
@@ -848,7 +858,7 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
     WS_HIP_CHECK(S.vals_out.reserve(total * 4));
     WS_HIP_CHECK(S.bstart.reserve((size_t)nbuckets * 4));
     WS_HIP_CHECK(S.bend.reserve((size_t)nbuckets * 4));
-    WS_HIP_CHECK(S.counters.reserve(4096));
+    WS_HIP_CHECK(S.counters.reserve(4096 + ((size_t)PRESORT_MAX_BINS + 1) * 4 * 3));
     WS_HIP_CHECK(S.tasks.reserve((size_t)I.hot_cap * sizeof(Task)));
     WS_HIP_CHECK(S.multi.reserve((size_t)I.hot_cap * sizeof(MultiBucket)));
     uint32_t hot_min = HOT_MIN;      // (WSNARK_MSM_HOT_MIN: lets small tests reach the hot-bucket path)
@@ -859,8 +869,8 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
     KernelTimer& T = X->timer;
     // counters: [0] partial slots, [1] multi-task buckets, [3] total tasks; [16..271] length histogram,
     // [272..527] cursors
+    // (the coarse-bin counts of the grouping pass follow at [1024 ..]: one memset clears both)
     uint32_t* d_cnt = S.counters.as<uint32_t>();
-    WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, 4096, s));
     bool have_hist = false;
     static const bool use_cub = [] { const char* e = getenv("WSNARK_MSM_SORT"); return e && !strcmp(e, "cub"); }();
     static const uint32_t env_lo = [] { const char* e = getenv("WSNARK_MSM_LO_BITS"); return e ? (uint32_t)atoi(e) : 8u; }();
@@ -877,11 +887,10 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
         while (((uint64_t)1 << idx_bits) < n) idx_bits++;
         const bool e32 = !env_e64 && idx_bits + 1 + lo_bits <= 32;
         WS_HIP_CHECK(S.entries.reserve(total * (e32 ? 4 : 8)));
-        WS_HIP_CHECK(S.bins.reserve(((size_t)nbins + 1) * 4 * 3));
-        uint32_t* bin_count = S.bins.as<uint32_t>();
+        uint32_t* bin_count = d_cnt + 1024;
         uint32_t* bin_start = bin_count + (nbins + 1);
         uint32_t* bin_cursor = bin_start + (nbins + 1);
-        WS_HIP_CHECK(hipMemsetAsync(bin_count, 0, ((size_t)nbins + 1) * 4, s));
+        WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, (1024 + (size_t)nbins + 1) * 4, s));
         PresortArgs PA{d_scalars, (uint32_t)n, c, I.Wall, I.w_off, I.w_stride, lo_bits, HB, nbins, env_tile, idx_bits};
         const dim3 grid(ceil_div_u64(n, env_tile)), blk(env_thr);
         T.begin("msm_presort_count", s);
@@ -908,6 +917,7 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
         WS_HIP_CHECK(hipGetLastError());
         have_hist = true;
     } else {
+        WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, 4096, s));
         // ---- reference pipeline: explicit digit arrays + hipCUB radix sort (WSNARK_MSM_SORT=cub) ----
         WS_HIP_CHECK(S.keys.reserve(total * 4));
         WS_HIP_CHECK(S.vals.reserve(total * 4));
@@ -934,9 +944,8 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
     if (!have_hist)
         hipLaunchKernelGGL(msm_plan_hist, dim3(ceil_div_u64(nbuckets, 256)), dim3(256), 0, s, S.bstart.as<uint32_t>(),
                            S.bend.as<uint32_t>(), nbuckets, lmax, d_cnt + 16);
-    hipLaunchKernelGGL(msm_plan_offsets, dim3(1), dim3(64), 0, s, d_cnt + 16, d_cnt + 272, d_cnt);
     hipLaunchKernelGGL(msm_plan_emit, dim3(ceil_div_u64(nbuckets, 256)), dim3(256), 0, s, S.bstart.as<uint32_t>(),
-                       S.bend.as<uint32_t>(), nbuckets, lmax, d_cnt + 272, S.tasks.as<Task>(), d_cnt,
+                       S.bend.as<uint32_t>(), nbuckets, lmax, d_cnt + 16, d_cnt + 272, S.tasks.as<Task>(), d_cnt,
                        S.multi.as<MultiBucket>(), S.hot.as<HotBucket>(), hot_min);
     hipLaunchKernelGGL(msm_plan_emit_hot, dim3(64), dim3(256), 0, s, S.hot.as<HotBucket>(), d_cnt, lmax, S.tasks.as<Task>());
     T.end(s);
