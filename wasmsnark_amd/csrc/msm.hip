@@ -481,15 +481,6 @@ __global__ __launch_bounds__(256) void msm_plan_emit_hot(const HotBucket* __rest
     }
 }
 
-// empty buckets = infinity (ZZ == 0); the others are written by their (last) task or by the combine step
-template <class C>
-__global__ __launch_bounds__(256) void msm_clear_empty(const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bend,
-                                                         uint32_t nbuckets, typename C::PtP* __restrict__ buckets) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nbuckets) return;
-    if (bend[b] == bstart[b]) buckets[b] = C::pack_pt(C::infinity());
-}
-
 // 4. one lane per task: mixed additions of the task's points
 template <class C>
 __global__ __launch_bounds__(256, (sizeof(typename C::PtP) > 128 ? WS_ACC_WAVES_G2 : WS_ACC_WAVES)) void msm_accumulate(const typename C::AffP* __restrict__ points,
@@ -513,7 +504,12 @@ template <class C>
 __global__ __launch_bounds__(256) void msm_combine_small(const MultiBucket* __restrict__ mbs,
                                                            const uint32_t* __restrict__ counters,
                                                            const typename C::PtP* __restrict__ partials,
-                                                           typename C::PtP* __restrict__ buckets) {
+                                                           typename C::PtP* __restrict__ buckets,
+                                                           const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bend,
+                                                           uint32_t nbuckets) {
+    // empty buckets = infinity (ZZ == 0); the others are written by their task or by a combine step
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nbuckets; b += gridDim.x * blockDim.x)
+        if (bend[b] == bstart[b]) buckets[b] = C::pack_pt(C::infinity());
     const uint32_t nmb = counters[1];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nmb; i += gridDim.x * blockDim.x) {
         const MultiBucket h = mbs[i];
@@ -1018,8 +1014,6 @@ static int msm_launch_acc(int which, const typename H::Aff* d_points_ref, bool p
         d_points = S.points_conv.as<typename C::AffP>();
     }
     T.begin(which ? "msm_accumulate_g2" : "msm_accumulate_g1", s);
-    hipLaunchKernelGGL(msm_clear_empty<C>, dim3(ceil_div_u64(nbuckets, 256)), dim3(256), 0, s, PS.bstart.as<uint32_t>(),
-                       PS.bend.as<uint32_t>(), nbuckets, S.buckets.as<Pt>());
     hipLaunchKernelGGL(msm_accumulate<C>, dim3(ceil_div_u64(ntasks, 256)), dim3(256), 0, s, d_points,
                        PS.vals_out.as<uint32_t>(), PS.tasks.as<Task>(), PS.counters.as<uint32_t>(), S.buckets.as<Pt>(),
                        S.partials.as<Pt>());
@@ -1027,7 +1021,8 @@ static int msm_launch_acc(int which, const typename H::Aff* d_points_ref, bool p
     WS_HIP_CHECK(hipGetLastError());
     T.begin("msm_combine", s);
     hipLaunchKernelGGL(msm_combine_small<C>, dim3(256), dim3(256), 0, s, PS.multi.as<MultiBucket>(),
-                       PS.counters.as<uint32_t>(), S.partials.as<Pt>(), S.buckets.as<Pt>());
+                       PS.counters.as<uint32_t>(), S.partials.as<Pt>(), S.buckets.as<Pt>(), PS.bstart.as<uint32_t>(),
+                       PS.bend.as<uint32_t>(), nbuckets);
     hipLaunchKernelGGL(msm_combine_wave<C>, dim3(2048), dim3(64), 0, s, PS.multi.as<MultiBucket>(),
                        PS.counters.as<uint32_t>(), S.partials.as<Pt>(), S.buckets.as<Pt>());
     // (slice sums: at most one per HOT_SLICE tasks plus one per hot bucket)
