@@ -44,10 +44,10 @@ int context_init(int device) {
         // at chosen points of the first queue's schedule and should then be dispatched ahead of what is still queued
         const char* e = getenv("WSNARK_S2_PRIO");
         int lo = 0, hi = 0;
-        if (!(e && atoi(e) == 0) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
-            WS_HIP_CHECK(hipStreamCreateWithPriority(&C->stream2, hipStreamNonBlocking, hi));
-        else
-            WS_HIP_CHECK(hipStreamCreateWithFlags(&C->stream2, hipStreamNonBlocking));
+        if (!(e && atoi(e) == 0) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo &&
+            hipStreamCreateWithPriority(&C->stream2, hipStreamNonBlocking, hi) != hipSuccess)
+            C->stream2 = nullptr;                    // (no priorities here: an ordinary second queue will do)
+        if (!C->stream2) WS_HIP_CHECK(hipStreamCreateWithFlags(&C->stream2, hipStreamNonBlocking));
     }
     g_ctx = C;
     return WS_OK;
