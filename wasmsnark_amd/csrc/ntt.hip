@@ -421,8 +421,9 @@ int ntt_dev(Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s) {
                 A.tw_full = tb.as<Fe>();
             }
         }
-        // tile: up to 2048 elements (64 KiB of LDS)
-        int log_T = 11 - (int)A.log_L;
+        // tile: 2^tile_log elements of LDS
+        static const int tile_log = [] { const char* e = getenv("WSNARK_NTT_TILE_LOG"); int v = e ? atoi(e) : 10; return (v >= 9 && v <= 11) ? v : 10; }();   // 1024-element tiles (36 KiB): four workgroups per CU hide each other's load/store phases (2^22 pair 1.34 -> 1.30 ms vs 2048)
+        int log_T = tile_log - (int)A.log_L;
         if (log_T > 5) log_T = 5;
         if (log_T < 0) log_T = 0;
         if (P->np == 1) {
@@ -444,7 +445,7 @@ int ntt_dev(Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s) {
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * 36));
                 attr_set = true;
             }
-            hipLaunchKernelGGL(ntt_pass_kernel<Fr29>, dim3(grid), dim3(512), smem, s, A);
+            hipLaunchKernelGGL(ntt_pass_kernel<Fr29>, dim3(grid), dim3(512 >> (11 - tile_log)), smem, s, A);
         } else {
             const size_t smem = elems * LdsTile<Fr>::kBytes;
             hipLaunchKernelGGL(ntt_pass_kernel<Fr>, dim3(grid), dim3(512), smem, s, A);
