@@ -876,11 +876,13 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
     uint32_t lo_bits = env_lo > PRESORT_MAX_LO ? PRESORT_MAX_LO : env_lo;
     if (lo_bits > c - 1) lo_bits = c - 1;
     while ((uint64_t)W * (I.NB >> lo_bits) > PRESORT_MAX_BINS && lo_bits < c - 1 && lo_bits < PRESORT_MAX_LO) lo_bits++;
+    uint32_t idx_bits = 1;
+    while (((uint64_t)1 << idx_bits) < n) idx_bits++;
+    // large inputs (2^24 pairs): give up low bucket bits while that keeps the entries at 4 bytes and the bin count in range
+    while (!env_e64 && idx_bits + 1 + lo_bits > 32 && lo_bits > 1 && (uint64_t)W * (I.NB >> (lo_bits - 1)) <= PRESORT_MAX_BINS) lo_bits--;
     const uint32_t HB = I.NB >> lo_bits, nbins = W * HB;
     if (!use_cub && nbins <= PRESORT_MAX_BINS) {
         // ---- grouping by coarse bins + per-bin LDS counting sort (hand-written; see the kernels above) ----
-        uint32_t idx_bits = 1;
-        while (((uint64_t)1 << idx_bits) < n) idx_bits++;
         const bool e32 = !env_e64 && idx_bits + 1 + lo_bits <= 32;
         WS_HIP_CHECK(S.entries.reserve(total * (e32 ? 4 : 8)));
         uint32_t* bin_count = d_cnt + 1024;
