@@ -128,6 +128,32 @@ def test_msm_all_same_point(bn, orc):
     assert bn.g1_multiexp(sc, pts)[:64] == want
 
 
+@pytest.mark.parametrize("env", [{"WSNARK_MSM_ENTRY64": "1"}, {"WSNARK_MSM_LO_BITS": "5"}, {"WSNARK_MSM_LO_BITS": "10"},
+                                 {"WSNARK_MSM_TILE": "256", "WSNARK_MSM_TILE_THREADS": "256"}, {"WSNARK_MSM_HOT_MIN": "2"},
+                                 {"WSNARK_MSM_SORT": "cub"}])
+def test_msm_grouping_variants_agree(bn, monkeypatch, env):
+    """Entry width, bin geometry, tile shape, hot-bucket threshold and the hipCUB pipeline only change how the
+    pairs are grouped: the sum must not move by a bit (G1 and G2, 60 000 pairs with 30 % ones)."""
+    import numpy as np
+    n = 60000
+    rng = np.random.default_rng(42)
+    sc = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    ones = rng.random(n) < 0.3
+    sc[ones] = 0
+    sc[ones, 0] = 1
+    ks = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    ks[:, 31] &= 0x1F
+    for g in (1, 2):
+        pts = bn.mul_base(g, ks.tobytes())
+        msm = bn.g1_multiexp if g == 1 else bn.g2_multiexp
+        base = msm(sc.tobytes(), pts)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        assert msm(sc.tobytes(), pts) == base
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_msm_window_override(bn, orc, monkeypatch):
     rnd = random.Random(77)
     n = 2000

@@ -868,11 +868,11 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
     // (the coarse-bin counts of the grouping pass follow at [1024 ..]: one memset clears both)
     uint32_t* d_cnt = S.counters.as<uint32_t>();
     bool have_hist = false;
-    static const bool use_cub = [] { const char* e = getenv("WSNARK_MSM_SORT"); return e && !strcmp(e, "cub"); }();
-    static const uint32_t env_lo = [] { const char* e = getenv("WSNARK_MSM_LO_BITS"); return e ? (uint32_t)atoi(e) : 8u; }();
-    static const uint32_t env_tile = [] { const char* e = getenv("WSNARK_MSM_TILE"); return e ? (uint32_t)atoi(e) : 1024u; }();
-    static const uint32_t env_thr = [] { const char* e = getenv("WSNARK_MSM_TILE_THREADS"); return e ? (uint32_t)atoi(e) : 1024u; }();
-    static const bool env_e64 = [] { const char* e = getenv("WSNARK_MSM_ENTRY64"); return e && atoi(e) != 0; }();
+    const bool use_cub = [] { const char* e = getenv("WSNARK_MSM_SORT"); return e && !strcmp(e, "cub"); }();
+    const uint32_t env_lo = [] { const char* e = getenv("WSNARK_MSM_LO_BITS"); return e ? (uint32_t)atoi(e) : 8u; }();
+    const uint32_t env_tile = [] { const char* e = getenv("WSNARK_MSM_TILE"); return e ? (uint32_t)atoi(e) : 1024u; }();
+    const uint32_t env_thr = [] { const char* e = getenv("WSNARK_MSM_TILE_THREADS"); return e ? (uint32_t)atoi(e) : 1024u; }();
+    const bool env_e64 = [] { const char* e = getenv("WSNARK_MSM_ENTRY64"); return e && atoi(e) != 0; }();
     uint32_t lo_bits = env_lo > PRESORT_MAX_LO ? PRESORT_MAX_LO : env_lo;
     if (lo_bits > c - 1) lo_bits = c - 1;
     while ((uint64_t)W * (I.NB >> lo_bits) > PRESORT_MAX_BINS && lo_bits < c - 1 && lo_bits < PRESORT_MAX_LO) lo_bits++;
@@ -900,7 +900,7 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
         else hipLaunchKernelGGL(presort_scatter<uint64_t>, grid, blk, 0, s, PA, bin_cursor, S.entries.as<uint64_t>());
         T.end(s);
         // one workgroup per bin, about eight entries per thread (two rounds of four loads in flight)
-        static const uint32_t env_bthr = [] { const char* e = getenv("WSNARK_MSM_BIN_THREADS"); return e ? (uint32_t)atoi(e) : 0u; }();
+        const uint32_t env_bthr = [] { const char* e = getenv("WSNARK_MSM_BIN_THREADS"); return e ? (uint32_t)atoi(e) : 0u; }();
         uint32_t bthr = env_bthr ? env_bthr : (uint32_t)((total / nbins / 8 + 63) / 64 * 64);
         bthr = bthr < 64 ? 64 : bthr > 1024 ? 1024 : bthr;
         const dim3 bblk(bthr);
