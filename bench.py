@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--no-extras", action="store_true", help="skip the NTT / prove extras")
     ap.add_argument("--extras", default="ntt,skewed,prove", help="comma list of extras to run: ntt, skewed, prove")
