@@ -12,7 +12,7 @@ timeout 2400 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider 
 echo "pytest rc=$?" >> gpurun_out/env.log
 timeout 1200 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err
 echo "bench rc=$?" >> gpurun_out/env.log
-( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o r01 -- python "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --extras ntt ) > gpurun_out/prof.log 2>&1
+( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o r01 -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --extras ntt ) > gpurun_out/prof.log 2>&1
 echo "rocprof rc=$?" >> gpurun_out/env.log
 # HBM traffic counters: separate --pmc passes, kernel-trace only (never combined with sys/hip/hsa traces)
 for CTR in FETCH_SIZE WRITE_SIZE; do
