@@ -260,8 +260,14 @@ def main():
                 bn.groth16GenProof_dev(d_w.data_ptr(), len(wit), key, r=r32, s=s32)
                 bn.lib.c.wsnark_timing_enable(0)
                 extras["prove_ms"] = round(t * 1e3, 3)
+                import struct as _st
+                _nv, _pb1 = _st.unpack_from("<I", pkey, 0)[0], _st.unpack_from("<I", pkey, 24)[0]
+                _b1x = np.frombuffer(pkey, dtype=np.uint8, count=_nv * 64, offset=_pb1).reshape(_nv, 64)[:, :32]
                 extras["prove_config"] = {"log_domain": args.prove_log_domain, "n_vars": circ.n_vars,
-                                          "key_bytes": len(pkey), "key_resident": True}
+                                          "key_bytes": len(pkey), "key_resident": True,
+                                          # variables absent from matrix B (B1 = B2 = infinity): the prover leaves
+                                          # them out of the two B sums (WSNARK_PROVE_SPARSE=0 turns that off)
+                                          "b_points_at_infinity_frac": round(float((~_b1x.any(axis=1)).mean()), 4)}
                 extras["prove_matches_toxic_waste_closed_form"] = bool(ok)
                 extras["prove_kernel_ms_total"] = {k: round(v[0], 4) for k, v in bn.lib.timing_report().items()}
                 extras["reference_wasm_8_workers_prove_2p20_s"] = 132.6   # BASELINE.md (survey container, other hardware)

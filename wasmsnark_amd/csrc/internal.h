@@ -104,7 +104,11 @@ int msm_g2_dev_xyzz(const Fe* d_scalars, const Affine<Fq2>* d_points, uint64_t n
 // two-phase form: one digit/sort/task plan per scalar vector, then any number of point sets of the
 // same length against it (the prover's A, B1, B2 and C sums all use the witness as scalars).
 // Callers serialise on Context::mu.
-int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s);
+// d_mask (optional, n bytes): pairs with mask 0 are left out of the plan -- an optimisation only, for point sets
+// that are infinity there (a plan built without it gives the same sums)
+int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s, const uint8_t* d_mask = nullptr);
+// mask[i] = 0 where the point is infinity (x == 0, reference format) in every given set; *skipped_host = how many
+int msm_points_mask(const Affine<Fq>* d_g1, const Affine<Fq2>* d_g2, uint64_t n, uint8_t* d_mask, uint32_t* skipped_host, hipStream_t s);
 int msm_g1_exec_xyzz(const Affine<Fq>* d_points, XYZZ<Fq>* out_host, hipStream_t s, bool prepared);
 int msm_g2_exec_xyzz(const Affine<Fq2>* d_points, XYZZ<Fq2>* out_host, hipStream_t s, bool prepared);
 // asynchronous form of exec: launch enqueues the kernels and the copy of the window sums, finish waits

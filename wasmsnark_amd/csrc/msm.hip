@@ -125,6 +125,7 @@ struct PresortArgs {
     uint32_t lo_bits, HB, nbins;       // bin = k*HB + ((d-1) >> lo_bits)
     uint32_t tile;                     // scalars per workgroup
     uint32_t idx_bits;                 // packed 4-byte entries: idx | neg << idx_bits | lo << (idx_bits+1)
+    const uint8_t* mask;               // optional: pairs with mask[i] == 0 are left out (their point is infinity)
 };
 
 // 8-byte entry = (low bucket bits << 32) | (index | sign << 31); 4-byte entries when bits(n)+1+lo_bits <= 32
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(1024) void presort_count(PresortArgs A, uint32_t* _
     __syncthreads();
     const uint32_t base = blockIdx.x * A.tile;
     for (uint32_t i = base + threadIdx.x; i < base + A.tile && i < A.n; i += blockDim.x) {
+        if (A.mask && !A.mask[i]) continue;
         for_each_digit(A.scalars[i], A.c, A.Wall, A.w_off, A.w_stride, [&](uint32_t k, uint32_t d, uint32_t) {
             atomicAdd(&cnt[k * A.HB + ((d - 1) >> A.lo_bits)], 1u);
         });
@@ -192,6 +194,7 @@ __global__ __launch_bounds__(1024) void presort_scatter(PresortArgs A, uint32_t*
     __syncthreads();
     const uint32_t base = blockIdx.x * A.tile;
     for (uint32_t i = base + threadIdx.x; i < base + A.tile && i < A.n; i += blockDim.x) {
+        if (A.mask && !A.mask[i]) continue;
         for_each_digit(A.scalars[i], A.c, A.Wall, A.w_off, A.w_stride, [&](uint32_t k, uint32_t d, uint32_t) {
             atomicAdd(&cnt[k * A.HB + ((d - 1) >> A.lo_bits)], 1u);
         });
@@ -206,6 +209,7 @@ __global__ __launch_bounds__(1024) void presort_scatter(PresortArgs A, uint32_t*
     __syncthreads();
     const uint32_t lo_mask = (1u << A.lo_bits) - 1;
     for (uint32_t i = base + threadIdx.x; i < base + A.tile && i < A.n; i += blockDim.x) {
+        if (A.mask && !A.mask[i]) continue;
         for_each_digit(A.scalars[i], A.c, A.Wall, A.w_off, A.w_stride, [&](uint32_t k, uint32_t d, uint32_t neg) {
             const uint32_t b = k * A.HB + ((d - 1) >> A.lo_bits);
             const uint32_t r = atomicAdd(&cnt[b], 1u);
@@ -812,7 +816,7 @@ static MsmPlanBufs* plan_bufs(Context* X) {
 }
 static MsmScratch& plan_scratch(Context* X) { return *X->msm_scratch[g_plan_cur]; }
 
-int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
+int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s, const uint8_t* d_mask) {
     Context* X = ctx();
     if (!X) return WS_ERR_NOINIT;
     if (!s) s = X->stream;
@@ -889,7 +893,7 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s) {
         uint32_t* bin_start = bin_count + (nbins + 1);
         uint32_t* bin_cursor = bin_start + (nbins + 1);
         WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, (1024 + (size_t)nbins + 1) * 4, s));
-        PresortArgs PA{d_scalars, (uint32_t)n, c, I.Wall, I.w_off, I.w_stride, lo_bits, HB, nbins, env_tile, idx_bits};
+        PresortArgs PA{d_scalars, (uint32_t)n, c, I.Wall, I.w_off, I.w_stride, lo_bits, HB, nbins, env_tile, idx_bits, d_mask};
         const dim3 grid(ceil_div_u64(n, env_tile)), blk(env_thr);
         T.begin("msm_presort_count", s);
         hipLaunchKernelGGL(presort_count, grid, blk, 0, s, PA, bin_count);
@@ -1146,6 +1150,35 @@ int msm_g2_exec_xyzz(const Affine<Fq2>* d_points, XYZZ<Fq2>* out_host, hipStream
     int rc = msm_g2_launch(d_points, prepared, &slot, s);
     if (rc) return rc;
     return msm_g2_finish(slot, out_host);
+}
+
+// Which pairs can be left out of a sum whatever the scalar: those whose point is infinity in EVERY given set
+// (x == 0, reference format).  Real circuits leave many variables out of the B matrix, so B1 / B2 are sparse;
+// the prover groups the witness once more with this mask for those two sums.
+__global__ __launch_bounds__(256) void msm_points_mask_kernel(const Affine<Fq>* __restrict__ g1, const Affine<Fq2>* __restrict__ g2,
+                                                                uint64_t n, uint8_t* __restrict__ mask, uint32_t* __restrict__ skipped) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool inf = true;
+    if (g1) inf = inf && Fq::is_zero(g1[i].x);
+    if (g2) inf = inf && Fq::is_zero(g2[i].x.c0) && Fq::is_zero(g2[i].x.c1);
+    mask[i] = inf ? 0 : 1;
+    if (inf) atomicAdd(skipped, 1u);
+}
+int msm_points_mask(const Affine<Fq>* d_g1, const Affine<Fq2>* d_g2, uint64_t n, uint8_t* d_mask, uint32_t* skipped_host, hipStream_t s) {
+    Context* X = ctx();
+    if (!X) return WS_ERR_NOINIT;
+    if (!s) s = X->stream;
+    *skipped_host = 0;
+    if (n == 0) return WS_OK;
+    DevBuf cnt;
+    WS_HIP_CHECK(cnt.alloc(4));
+    WS_HIP_CHECK(hipMemsetAsync(cnt.p, 0, 4, s));
+    hipLaunchKernelGGL(msm_points_mask_kernel, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s, d_g1, d_g2, n, d_mask, cnt.as<uint32_t>());
+    WS_HIP_CHECK(hipGetLastError());
+    WS_HIP_CHECK(hipMemcpyAsync(skipped_host, cnt.p, 4, hipMemcpyDeviceToHost, s));
+    WS_HIP_CHECK(hipStreamSynchronize(s));
+    return WS_OK;
 }
 
 // in-place conversion of a resident point array (the proving key's sections) to the device field's

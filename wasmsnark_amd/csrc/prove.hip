@@ -24,6 +24,9 @@ struct ProvingKey {
     CsrMatrix polsA, polsB;
     DevBuf pointsA, pointsB1, pointsB2, pointsC, pointsH;
     DevBuf witness, h;          // per-proof device buffers (grow-only)
+    DevBuf maskB;               // 1 byte per signal: 0 where B1 and B2 are both infinity (the variable is not in matrix B)
+    uint32_t infB = 0;          // how many of those there are
+    bool sparseB = false;       // enough of them to give B1 / B2 their own (masked) plan
     std::mutex mu;              // one proof at a time per handle
     hipEvent_t ev_start = nullptr, ev_tail = nullptr, ev_h = nullptr;   // cross-queue ordering of one proof
     ~ProvingKey() {
@@ -78,6 +81,17 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out) {
         }
         WS_HIP_CHECK(sc.d->alloc((size_t)sc.bytes));
         if (sc.bytes && (rc = upload_staged(sc.d->p, sc.src, (size_t)sc.bytes, s))) return rc;
+    }
+    // Variables that do not occur in matrix B have B1 = B2 = infinity (common: real circuits put far fewer terms
+    // on the B side).  Their pairs cost a lane slot each in the two B sums, so when there are enough of them
+    // those sums get a plan of their own that leaves them out (one more grouping pass, ~0.33 ms at 2^20, against
+    // the share of a 4.9 ms G1+G2 accumulation they would waste).  WSNARK_PROVE_SPARSE: 0 never, 2 always.
+    WS_HIP_CHECK(K->maskB.alloc((size_t)nv));
+    if ((rc = msm_points_mask(K->pointsB1.as<Affine<Fq>>(), K->pointsB2.as<Affine<Fq2>>(), nv, K->maskB.as<uint8_t>(), &K->infB, s))) return rc;
+    {
+        const char* e = getenv("WSNARK_PROVE_SPARSE");
+        const int mode = e ? atoi(e) : 1;
+        K->sparseB = mode == 2 || (mode == 1 && (uint64_t)K->infB * 100 >= (uint64_t)nv * 8 && nv >= (1u << 14));
     }
     // resident keys are kept in the device field's internal domain: no per-proof conversion pass
     if ((rc = msm_prepare_points(0, K->pointsA.p, nv, s))) return rc;
@@ -197,15 +211,27 @@ static int prove_msms(ProvingKey* K, const Fe* d_witness, MsmSums* out, hipStrea
     struct Abort { hipStream_t a, b; bool armed; ~Abort() { if (armed) { msm_select_plan(0); msm_abort_pending(a); if (b != a) msm_abort_pending(b); } } } guard{s, s2, true};
     if (!K->ev_start) { WS_HIP_CHECK(hipEventCreateWithFlags(&K->ev_start, hipEventDisableTiming)); WS_HIP_CHECK(hipEventCreateWithFlags(&K->ev_tail, hipEventDisableTiming)); WS_HIP_CHECK(hipEventCreateWithFlags(&K->ev_h, hipEventDisableTiming)); }
     WS_HIP_CHECK(hipEventRecord(K->ev_start, s));          // the witness is ready on s
-    // one plan for the four sums whose scalars are the witness (:617-620)
+    // the four sums whose scalars are the witness (:617-620)
     msm_select_plan(0);
     if ((rc = msm_plan_dev(d_witness, nv, s))) return rc;
-    // A, B1 and C share the plan: three accumulations back to back, then ONE batched reduction tail
-    const Affine<Fq>* g1sets[3] = {K->pointsA.as<Affine<Fq>>(), K->pointsB1.as<Affine<Fq>>(), K->pointsC.as<Affine<Fq>>()};
-    int g1slots[3] = {-1, -1, -1};
-    if ((rc = msm_g1_launch_batch(g1sets, 3, true, g1slots, s, K->ev_tail))) return rc;                  // :617, :618, :620 (padded)
-    hA = g1slots[0]; hB1 = g1slots[1]; hC = g1slots[2];
-    tr.mark("plan(w) + launch A,B1,C");
+    if (!K->sparseB) {
+        // one plan for all four.  A, B1 and C: three accumulations back to back, then ONE batched reduction tail
+        const Affine<Fq>* g1sets[3] = {K->pointsA.as<Affine<Fq>>(), K->pointsB1.as<Affine<Fq>>(), K->pointsC.as<Affine<Fq>>()};
+        int g1slots[3] = {-1, -1, -1};
+        if ((rc = msm_g1_launch_batch(g1sets, 3, true, g1slots, s, K->ev_tail))) return rc;              // :617, :618, :620 (padded)
+        hA = g1slots[0]; hB1 = g1slots[1]; hC = g1slots[2];
+        tr.mark("plan(w) + launch A,B1,C");
+    } else {
+        // many variables are absent from matrix B: A and C on the full plan, then a second grouping of the witness
+        // that leaves those variables out, for B1 and B2 (same sums: the left-out points are infinity)
+        const Affine<Fq>* g1sets[2] = {K->pointsA.as<Affine<Fq>>(), K->pointsC.as<Affine<Fq>>()};
+        int g1slots[2] = {-1, -1};
+        if ((rc = msm_g1_launch_batch(g1sets, 2, true, g1slots, s, K->ev_tail))) return rc;              // :617, :620 (padded)
+        hA = g1slots[0]; hC = g1slots[1];
+        if ((rc = msm_plan_dev(d_witness, nv, s, K->maskB.as<uint8_t>()))) return rc;
+        if ((rc = msm_g1_launch(K->pointsB1.as<Affine<Fq>>(), true, &hB1, s))) return rc;               // :618
+        tr.mark("plan(w) + launch A,C + plan(w | B) + launch B1");
+    }
     if ((rc = msm_g2_launch(K->pointsB2.as<Affine<Fq2>>(), true, &hB2, s))) return rc;                 // :619
     tr.mark("launch B2");
     // CALC_H, then the H MSM over domainSize pairs (src/bn128.js:607-615)
