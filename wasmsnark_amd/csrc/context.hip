@@ -70,8 +70,7 @@ void context_shutdown() {
     for (auto& e : g_ctx->pin_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     g_ctx->host_in[0].release();
     g_ctx->host_in[1].release();
-    g_ctx->msm_scratch[0].reset();
-    g_ctx->msm_scratch[1].reset();
+    for (auto& sc : g_ctx->msm_scratch) sc.reset();
     (void)hipStreamDestroy(g_ctx->stream);
     (void)hipStreamDestroy(g_ctx->stream2);
     delete g_ctx;

@@ -59,7 +59,7 @@ struct Context {
     std::mutex mu;
     std::map<int, std::shared_ptr<NttPlan>> ntt_plans;   // by log2(n)
     DevBuf ntt_scratch;
-    std::shared_ptr<MsmScratch> msm_scratch[2];          // [0] G1, [1] G2
+    std::shared_ptr<MsmScratch> msm_scratch[4];          // buffers of the selectable plans (msm_select_plan)
     DevBuf calch_buf[4];                                 // sigM, A, B, E
     ScratchChain ntt_chain, calch_chain;                 // who may touch ntt_scratch / calch_buf next
     KernelTimer timer;
@@ -116,10 +116,15 @@ int msm_g2_exec_xyzz(const Affine<Fq2>* d_points, XYZZ<Fq2>* out_host, hipStream
 int msm_g1_launch(const Affine<Fq>* d_points, bool prepared, int* slot, hipStream_t s);
 int msm_g2_launch(const Affine<Fq2>* d_points, bool prepared, int* slot, hipStream_t s, hipEvent_t before_tail = nullptr);
 // `before_tail` (optional) is recorded on s after the accumulations, before the batched reduction tail
+// plan_ids (optional): the plan each set is accumulated against (variants of one plan: same geometry)
 int msm_g1_launch_batch(const Affine<Fq>* const* d_points, int nsets, bool prepared, int* slots, hipStream_t s,
-                        hipEvent_t before_tail = nullptr);
+                        hipEvent_t before_tail = nullptr, const int* plan_ids = nullptr);
 // two independent plans (digit/sort/task buffers) can be alive at once; plan and launches use the selected one
-void msm_select_plan(int id);
+void msm_select_plan(int id);      // id in [0, 4)
+// A second plan over the SAME scalars that leaves out the pairs with mask[i] == 0, derived from plan `src_id`
+// (which must just have been built by msm_plan_dev): only the per-bin counting sort and the task list are redone,
+// the digit extraction and the coarse scatter are shared.  Becomes plan `dst_id`.
+int msm_plan_variant(int src_id, int dst_id, const uint8_t* d_mask, hipStream_t s);
 bool msm_ready(int slot);     // the launch's window sums have reached the host (finish will not block)
 int msm_g1_finish(int slot, XYZZ<Fq>* out_host);
 int msm_g2_finish(int slot, XYZZ<Fq2>* out_host);

@@ -253,7 +253,8 @@ template <class E>
 __global__ __launch_bounds__(1024) void presort_bins(const E* __restrict__ entries, const uint32_t* __restrict__ bin_start,
                                                        uint32_t lo_bits, uint32_t idx_bits, uint32_t* __restrict__ vals_out,
                                                        uint32_t* __restrict__ bstart, uint32_t* __restrict__ bend,
-                                                       uint32_t lmax, uint32_t* __restrict__ hist) {
+                                                       uint32_t lmax, uint32_t* __restrict__ hist,
+                                                       const uint8_t* __restrict__ mask) {
     __shared__ uint32_t sub[1u << PRESORT_MAX_LO];
     __shared__ uint32_t off[1u << PRESORT_MAX_LO];
     __shared__ uint32_t part[1024];
@@ -276,7 +277,11 @@ __global__ __launch_bounds__(1024) void presort_bins(const E* __restrict__ entri
             v[u] = j < e ? entries[j] : (E)0;
         }
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++) (void)wave_rank_add(sub, PresortEntry<E>::lo(v[u], idx_bits), i + u * blockDim.x < e);
+        for (uint32_t u = 0; u < 4; u++) {
+            bool active = i + u * blockDim.x < e;
+            if (mask && active) active = mask[PresortEntry<E>::val(v[u], idx_bits) & 0x7FFFFFFFu] != 0;   // plan variant: pair left out
+            (void)wave_rank_add(sub, PresortEntry<E>::lo(v[u], idx_bits), active);
+        }
     }
     __syncthreads();
     // exclusive scan of sub[0..SUB): thread t owns `per` consecutive counters, Hillis-Steele over the partials
@@ -319,7 +324,8 @@ __global__ __launch_bounds__(1024) void presort_bins(const E* __restrict__ entri
         }
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) {
-            const bool active = i + u * blockDim.x < e;
+            bool active = i + u * blockDim.x < e;
+            if (mask && active) active = mask[PresortEntry<E>::val(v[u], idx_bits) & 0x7FFFFFFFu] != 0;
             const uint32_t lo = PresortEntry<E>::lo(v[u], idx_bits);
             const uint32_t r = wave_rank_add(sub, lo, active);
             if (active) vals_out[off[lo] + r] = PresortEntry<E>::val(v[u], idx_bits);
@@ -715,6 +721,8 @@ struct MsmPlanInfo {
     uint64_t n = 0;
     uint32_t c = 0, W = 0, NB = 0, nbuckets = 0, m = 0, J = 0, logJ = 0, nsum = 0, lmax = 0, hot_cap = 0;
     uint32_t hot_min = 1024;
+    uint32_t ps_lo_bits = 0, ps_idx_bits = 0, ps_nbins = 0, ps_bthr = 0;   // grouping pass geometry (presort plans)
+    bool ps_valid = false, ps_e32 = false;
     uint32_t Wall = 0, w_off = 0, w_stride = 1;   // W = owned windows; Wall = windows of the whole scalar
     uint32_t ntasks = 0, nmulti = 0;
     bool valid = false;
@@ -807,11 +815,11 @@ struct MsmPlanBufs {
 // two plans can be alive at once (the prover builds the H plan on a second stream while the sums over the
 // witness still read theirs); msm_select_plan picks the one msm_plan_dev and the launches work with
 static int g_plan_cur = 0;
-void msm_select_plan(int id) { g_plan_cur = id ? 1 : 0; }
+static const int kPlans = 4;
+void msm_select_plan(int id) { g_plan_cur = (id >= 0 && id < kPlans) ? id : 0; }
 static MsmPlanBufs* plan_bufs(Context* X) {
-    if (!X->msm_scratch[0]) X->msm_scratch[0] = std::make_shared<MsmScratch>();   // plan 0 buffers
-    if (!X->msm_scratch[1]) X->msm_scratch[1] = std::make_shared<MsmScratch>();   // plan 1 buffers
-    static MsmPlanBufs P[2];   // info only; buffers live in the context scratch
+    for (auto& sc : X->msm_scratch) if (!sc) sc = std::make_shared<MsmScratch>();
+    static MsmPlanBufs P[kPlans];   // info only; buffers live in the context scratch
     return &P[g_plan_cur];
 }
 static MsmScratch& plan_scratch(Context* X) { return *X->msm_scratch[g_plan_cur]; }
@@ -911,13 +919,15 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s, const uint8_t* 
         T.begin("msm_presort_bins", s);
         if (e32)
             hipLaunchKernelGGL(presort_bins<uint32_t>, dim3(nbins), bblk, 0, s, S.entries.as<uint32_t>(), bin_start, lo_bits,
-                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(), lmax, d_cnt + 16);
+                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(), lmax, d_cnt + 16, nullptr);
         else
             hipLaunchKernelGGL(presort_bins<uint64_t>, dim3(nbins), bblk, 0, s, S.entries.as<uint64_t>(), bin_start, lo_bits,
-                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(), lmax, d_cnt + 16);
+                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(), lmax, d_cnt + 16, nullptr);
         T.end(s);
         WS_HIP_CHECK(hipGetLastError());
         have_hist = true;
+        I.ps_valid = d_mask == nullptr;      // (a masked scatter cannot be the source of further variants)
+        I.ps_lo_bits = lo_bits; I.ps_idx_bits = idx_bits; I.ps_nbins = nbins; I.ps_bthr = bthr; I.ps_e32 = e32;
     } else {
         WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, 4096, s));
         // ---- reference pipeline: explicit digit arrays + hipCUB radix sort (WSNARK_MSM_SORT=cub) ----
@@ -959,6 +969,57 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s, const uint8_t* 
     if (!g_plan_done) WS_HIP_CHECK(hipEventCreate(&g_plan_done));
     WS_HIP_CHECK(hipEventRecord(g_plan_done, s));
     I.valid = true;
+    return WS_OK;
+}
+
+int msm_plan_variant(int src_id, int dst_id, const uint8_t* d_mask, hipStream_t s) {
+    Context* X = ctx();
+    if (!X) return WS_ERR_NOINIT;
+    if (!s) s = X->stream;
+    if (src_id < 0 || src_id >= kPlans || dst_id < 0 || dst_id >= kPlans || src_id == dst_id || !d_mask) return WS_ERR_ARG;
+    const int keep = g_plan_cur;
+    msm_select_plan(src_id);
+    const MsmPlanInfo src = plan_bufs(X)->info;
+    MsmScratch& SS = plan_scratch(X);
+    msm_select_plan(dst_id);
+    MsmPlanInfo& I = plan_bufs(X)->info;
+    MsmScratch& S = plan_scratch(X);
+    struct Restore { int id; ~Restore() { msm_select_plan(id); } } restore{keep};
+    if (!src.valid || !src.ps_valid || src.n == 0) { set_last_error("msm_plan_variant: the source plan has no shared grouping pass"); return WS_ERR_ARG; }
+    for (int i = 0; g_slots && i < kPendingSlots; i++)
+        if (g_slots[i].active && g_slots[i].ev && g_slots[i].info.n && g_slots[i].plan_id == dst_id)
+            WS_HIP_CHECK(hipStreamWaitEvent(s, g_slots[i].ev, 0));
+    I = src;
+    I.ps_valid = false;
+    const uint64_t total = src.n * src.W;
+    WS_HIP_CHECK(S.vals_out.reserve(total * 4));
+    WS_HIP_CHECK(S.bstart.reserve((size_t)src.nbuckets * 4));
+    WS_HIP_CHECK(S.bend.reserve((size_t)src.nbuckets * 4));
+    WS_HIP_CHECK(S.counters.reserve(4096 + ((size_t)PRESORT_MAX_BINS + 1) * 4 * 3));
+    WS_HIP_CHECK(S.tasks.reserve((size_t)src.hot_cap * sizeof(Task)));
+    WS_HIP_CHECK(S.multi.reserve((size_t)src.hot_cap * sizeof(MultiBucket)));
+    WS_HIP_CHECK(S.hot.reserve(((size_t)src.hot_cap / src.hot_min + 16) * sizeof(HotBucket)));
+    uint32_t* d_cnt = S.counters.as<uint32_t>();
+    WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, 4096, s));
+    const uint32_t* bin_start = SS.counters.as<uint32_t>() + 1024 + (src.ps_nbins + 1);
+    KernelTimer& T = X->timer;
+    T.begin("msm_presort_bins", s);
+    if (src.ps_e32)
+        hipLaunchKernelGGL(presort_bins<uint32_t>, dim3(src.ps_nbins), dim3(src.ps_bthr), 0, s, SS.entries.as<uint32_t>(), bin_start,
+                           src.ps_lo_bits, src.ps_idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(),
+                           src.lmax, d_cnt + 16, d_mask);
+    else
+        hipLaunchKernelGGL(presort_bins<uint64_t>, dim3(src.ps_nbins), dim3(src.ps_bthr), 0, s, SS.entries.as<uint64_t>(), bin_start,
+                           src.ps_lo_bits, src.ps_idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(),
+                           src.lmax, d_cnt + 16, d_mask);
+    T.end(s);
+    T.begin("msm_plan", s);
+    hipLaunchKernelGGL(msm_plan_emit, dim3(ceil_div_u64(src.nbuckets, 256)), dim3(256), 0, s, S.bstart.as<uint32_t>(),
+                       S.bend.as<uint32_t>(), src.nbuckets, src.lmax, d_cnt + 16, d_cnt + 272, S.tasks.as<Task>(), d_cnt,
+                       S.multi.as<MultiBucket>(), S.hot.as<HotBucket>(), src.hot_min);
+    hipLaunchKernelGGL(msm_plan_emit_hot, dim3(64), dim3(256), 0, s, S.hot.as<HotBucket>(), d_cnt, src.lmax, S.tasks.as<Task>());
+    T.end(s);
+    WS_HIP_CHECK(hipGetLastError());
     return WS_OK;
 }
 
@@ -1104,12 +1165,15 @@ static int msm_launch(int which, const typename H::Aff* d_points_ref, bool prepa
 
 // several G1 point sets against the current plan: accumulations back to back, then ONE batched tail
 int msm_g1_launch_batch(const Affine<Fq>* const* d_points, int nsets, bool prepared, int* slots, hipStream_t s,
-                        hipEvent_t before_tail) {
+                        hipEvent_t before_tail, const int* plan_ids) {
     if (!ctx()) return WS_ERR_NOINIT;
     if (nsets < 1 || nsets > 4) return WS_ERR_ARG;
+    const int keep = g_plan_cur;
     for (int k = 0; k < nsets; k++) {
+        if (plan_ids) msm_select_plan(plan_ids[k]);
         int rc = msm_uses_field29() ? msm_launch_acc<G1R29, G1>(0, d_points[k], prepared, &slots[k], s)
                                     : msm_launch_acc<G1, G1>(0, d_points[k], prepared, &slots[k], s);
+        if (plan_ids) msm_select_plan(keep);
         if (rc) return rc;
     }
     if (before_tail) WS_HIP_CHECK(hipEventRecord(before_tail, s ? s : ctx()->stream));

@@ -24,9 +24,9 @@ struct ProvingKey {
     CsrMatrix polsA, polsB;
     DevBuf pointsA, pointsB1, pointsB2, pointsC, pointsH;
     DevBuf witness, h;          // per-proof device buffers (grow-only)
-    DevBuf maskB;               // 1 byte per signal: 0 where B1 and B2 are both infinity (the variable is not in matrix B)
-    uint32_t infB = 0;          // how many of those there are
-    bool sparseB = false;       // enough of them to give B1 / B2 their own (masked) plan
+    DevBuf maskA, maskB;        // 1 byte per signal: 0 where A (resp. B1 and B2) is infinity: the variable is not in that matrix
+    uint32_t infA = 0, infB = 0;   // how many of those there are
+    bool sparseA = false, sparseB = false;   // enough of them to give those sums a plan variant that leaves them out
     std::mutex mu;              // one proof at a time per handle
     hipEvent_t ev_start = nullptr, ev_tail = nullptr, ev_h = nullptr;   // cross-queue ordering of one proof
     ~ProvingKey() {
@@ -82,16 +82,21 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out) {
         WS_HIP_CHECK(sc.d->alloc((size_t)sc.bytes));
         if (sc.bytes && (rc = upload_staged(sc.d->p, sc.src, (size_t)sc.bytes, s))) return rc;
     }
-    // Variables that do not occur in matrix B have B1 = B2 = infinity (common: real circuits put far fewer terms
-    // on the B side).  Their pairs cost a lane slot each in the two B sums, so when there are enough of them
-    // those sums get a plan of their own that leaves them out (one more grouping pass, ~0.33 ms at 2^20, against
-    // the share of a 4.9 ms G1+G2 accumulation they would waste).  WSNARK_PROVE_SPARSE: 0 never, 2 always.
+    // Variables that do not occur in matrix A (resp. B) have A (resp. B1 = B2) = infinity -- common: real circuits put
+    // far fewer terms on the B side.  Their pairs cost a lane slot each in those sums, so when there are enough of
+    // them the sums run on a plan VARIANT that leaves them out (msm_plan_variant: the per-bin sort and the task list
+    // are redone, ~0.17 ms at 2^20; the digit extraction and the scatter are shared with the full plan).
+    // WSNARK_PROVE_SPARSE: 0 never, 2 always.
+    WS_HIP_CHECK(K->maskA.alloc((size_t)nv));
     WS_HIP_CHECK(K->maskB.alloc((size_t)nv));
+    if ((rc = msm_points_mask(K->pointsA.as<Affine<Fq>>(), nullptr, nv, K->maskA.as<uint8_t>(), &K->infA, s))) return rc;
     if ((rc = msm_points_mask(K->pointsB1.as<Affine<Fq>>(), K->pointsB2.as<Affine<Fq2>>(), nv, K->maskB.as<uint8_t>(), &K->infB, s))) return rc;
     {
         const char* e = getenv("WSNARK_PROVE_SPARSE");
         const int mode = e ? atoi(e) : 1;
-        K->sparseB = mode == 2 || (mode == 1 && (uint64_t)K->infB * 100 >= (uint64_t)nv * 8 && nv >= (1u << 14));
+        const bool big = nv >= (1u << 14);
+        K->sparseA = mode == 2 || (mode == 1 && big && (uint64_t)K->infA * 100 >= (uint64_t)nv * 15);   // saves a share of one G1 sum
+        K->sparseB = mode == 2 || (mode == 1 && big && (uint64_t)K->infB * 100 >= (uint64_t)nv * 5);    // ... of a G1 and a G2 sum
     }
     // resident keys are kept in the device field's internal domain: no per-proof conversion pass
     if ((rc = msm_prepare_points(0, K->pointsA.p, nv, s))) return rc;
@@ -189,21 +194,22 @@ struct MsmSums {
 // CALC_H and the five MSMs (src/bn128.js:607-620).  With window sharding active
 // (wsnark_set_window_shard) the sums are this rank's partial sums.
 //
-// Two in-order queues.  Stream s: the witness plan, A, B1, C (one batched tail), B2.  Stream 2: CALC_H, the H
-// plan and the H sum -- released when the first reduction tail starts, so its full-width kernels fill the
-// SIMDs that the latency-bound tails (a chain of ~30 dependent point additions on a few hundred wavefronts)
-// leave idle (measured on MI355X, prove 2^20: 14.5 ms on one queue, 13.5-13.8 ms with two, 13.2 ms when the second
-// queue also has the device's highest priority, so that CALC_H is dispatched ahead of the rest of B2; releasing the second
-// queue at once (=2) or holding H back until B2's tail is the same within noise).  The host finishes each sum
-// while the GPU works on the next ones; `after_ab1` (optional) runs on the host as soon as A and B1 are known.
-// WSNARK_PROVE_OVERLAP=0 keeps everything on one queue.
+// Two in-order queues.  Stream s: the witness plan (+ its variants), A, B1, C (one batched tail), B2.  Stream 2
+// (highest priority): CALC_H, the H plan and the H sum.  The reduction tails are chains of ~30 dependent point
+// additions on a few hundred wavefronts; the other queue's full-width kernels take the SIMDs they leave idle.
+// Measured on MI355X, prove 2^20: one queue (WSNARK_PROVE_OVERLAP=0) 14.5 ms -> two queues 13.2 ms (session 16);
+// with the sums on plan variants the second queue is the longer one and is released at once (=2, default:
+// 10.3 ms) rather than when the first tail starts (=1: 10.5 ms).  Stricter gating does not help: a tail that
+// shares its SIMDs with a full-width kernel just runs 2-3x slower (profiles/r01_sweep_prove_overlap.txt).
+// The host finishes each sum while the GPU works on the next ones; `after_ab1` (optional) runs on the host as soon
+// as A and B1 are known.
 static int prove_msms(ProvingKey* K, const Fe* d_witness, MsmSums* out, hipStream_t s,
                       const std::function<void(const MsmSums&)>& after_ab1 = nullptr) {
     Context* C = ctx();
     Trace tr;
     const uint32_t nv = K->n_vars, dom = K->domain;
     int rc;
-    static const int overlap = [] { const char* e = getenv("WSNARK_PROVE_OVERLAP"); return e ? atoi(e) : 1; }();
+    static const int overlap = [] { const char* e = getenv("WSNARK_PROVE_OVERLAP"); return e ? atoi(e) : 2; }();
     hipStream_t s2 = overlap ? C->stream2 : s;
     if (s2 == s) s2 = s;   // (caller passed the second queue itself: degenerate, stays in order)
     std::unique_lock<std::mutex> lk(C->mu);   // the digit/sort plans and the MSM scratch are per context
@@ -214,25 +220,24 @@ static int prove_msms(ProvingKey* K, const Fe* d_witness, MsmSums* out, hipStrea
     // the four sums whose scalars are the witness (:617-620)
     msm_select_plan(0);
     if ((rc = msm_plan_dev(d_witness, nv, s))) return rc;
-    if (!K->sparseB) {
-        // one plan for all four.  A, B1 and C: three accumulations back to back, then ONE batched reduction tail
+    // one grouping pass for all four; A and B1/B2 may run on variants of the plan that leave out the variables
+    // absent from their matrix (plan 0 = full, 2 = without B's absentees, 3 = without A's).  A, B1 and C: three
+    // accumulations back to back, then ONE batched reduction tail
+    int planA = 0, planB = 0;
+    if (K->sparseB && msm_plan_variant(0, 2, K->maskB.as<uint8_t>(), s) == WS_OK) planB = 2;   // (hipCUB pipeline: no variants,
+    if (K->sparseA && msm_plan_variant(0, 3, K->maskA.as<uint8_t>(), s) == WS_OK) planA = 3;   //  everything on the full plan)
+    {
         const Affine<Fq>* g1sets[3] = {K->pointsA.as<Affine<Fq>>(), K->pointsB1.as<Affine<Fq>>(), K->pointsC.as<Affine<Fq>>()};
+        const int plans[3] = {planA, planB, 0};
         int g1slots[3] = {-1, -1, -1};
-        if ((rc = msm_g1_launch_batch(g1sets, 3, true, g1slots, s, K->ev_tail))) return rc;              // :617, :618, :620 (padded)
+        if ((rc = msm_g1_launch_batch(g1sets, 3, true, g1slots, s, K->ev_tail, plans))) return rc;       // :617, :618, :620 (padded)
         hA = g1slots[0]; hB1 = g1slots[1]; hC = g1slots[2];
-        tr.mark("plan(w) + launch A,B1,C");
-    } else {
-        // many variables are absent from matrix B: A and C on the full plan, then a second grouping of the witness
-        // that leaves those variables out, for B1 and B2 (same sums: the left-out points are infinity)
-        const Affine<Fq>* g1sets[2] = {K->pointsA.as<Affine<Fq>>(), K->pointsC.as<Affine<Fq>>()};
-        int g1slots[2] = {-1, -1};
-        if ((rc = msm_g1_launch_batch(g1sets, 2, true, g1slots, s, K->ev_tail))) return rc;              // :617, :620 (padded)
-        hA = g1slots[0]; hC = g1slots[1];
-        if ((rc = msm_plan_dev(d_witness, nv, s, K->maskB.as<uint8_t>()))) return rc;
-        if ((rc = msm_g1_launch(K->pointsB1.as<Affine<Fq>>(), true, &hB1, s))) return rc;               // :618
-        tr.mark("plan(w) + launch A,C + plan(w | B) + launch B1");
+        tr.mark("plan(w) [+ variants] + launch A,B1,C");
     }
-    if ((rc = msm_g2_launch(K->pointsB2.as<Affine<Fq2>>(), true, &hB2, s))) return rc;                 // :619
+    msm_select_plan(planB);
+    rc = msm_g2_launch(K->pointsB2.as<Affine<Fq2>>(), true, &hB2, s);                                  // :619
+    msm_select_plan(0);
+    if (rc) return rc;
     tr.mark("launch B2");
     // CALC_H, then the H MSM over domainSize pairs (src/bn128.js:607-615)
     if (s2 != s) WS_HIP_CHECK(hipStreamWaitEvent(s2, overlap == 2 ? K->ev_start : K->ev_tail, 0));
