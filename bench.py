@@ -269,6 +269,21 @@ def main():
                                           # them out of the two B sums (WSNARK_PROVE_SPARSE=0 turns that off)
                                           "b_points_at_infinity_frac": round(float((~_b1x.any(axis=1)).mean()), 4)}
                 extras["prove_matches_toxic_waste_closed_form"] = bool(ok)
+                # the same proofs with every pair in every sum (no plan variants for the variables absent from A / B)
+                os.environ["WSNARK_PROVE_SPARSE"] = "0"
+                try:
+                    key_dense = bn.load_key(pkey)
+                    for _ in range(3):
+                        p2 = bn.groth16GenProof_dev(d_w.data_ptr(), len(wit), key_dense, r=r32, s=s32)
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    for _ in range(reps):
+                        bn.groth16GenProof_dev(d_w.data_ptr(), len(wit), key_dense, r=r32, s=s32)
+                    torch.cuda.synchronize()
+                    extras["prove_ms_all_pairs_in_every_sum"] = round((time.perf_counter() - t0) / reps * 1e3, 3)
+                    extras["prove_all_pairs_same_proof"] = bool(p2 == proof)
+                    key_dense.free()
+                finally:
+                    del os.environ["WSNARK_PROVE_SPARSE"]
                 extras["prove_kernel_ms_total"] = {k: round(v[0], 4) for k, v in bn.lib.timing_report().items()}
                 extras["reference_wasm_8_workers_prove_2p20_s"] = 132.6   # BASELINE.md (survey container, other hardware)
             except Exception as e:  # noqa: BLE001
