@@ -25,9 +25,12 @@
  * group element are still written to HOST memory.
  *
  * Threading: every entry point may be called from any host thread at any time (the Node addon calls from
- * the libuv pool).  Calls that share device scratch are serialised inside the library (one MSM plan at a
- * time per context, one proof at a time per key handle); unlike the reference's WASM instance
- * (static scratch, non-re-entrant) no caller-side queue is needed.
+ * the libuv pool); each call selects the context's GPU for its thread first.  A context has a few LANES
+ * (WSNARK_LANES, default 2): a lane holds everything one call in flight needs besides the read-only key (queues,
+ * MSM plans, transform scratch, per-proof buffers), so two proofs -- on one key handle or on two -- or a proof and
+ * an MSM overlap on one GPU; further concurrent callers wait for a lane.  There is no process-global mode: sharding
+ * parameters are per call.  Unlike the reference's WASM instance (static scratch,
+ * non-re-entrant) no caller-side queue is needed.
  * Host buffers are read through a pinned staging ring and are free for reuse when the call returns.
  */
 #ifndef WSNARK_H
@@ -75,12 +78,16 @@ int wsnark_g2_msm_dev(const void* d_scalars, const void* d_points_affine, uint64
 int wsnark_g1_sum(const void* jac_points, uint64_t count, void* out96);
 int wsnark_g2_sum(const void* jac_points, uint64_t count, void* out192);
 
-/* Multi-GPU alternative to splitting the pairs: every rank is given ALL pairs and computes only the
- * Pippenger windows w with w % world == rank; its MSM result is then a partial sum already scaled by
- * 2^(c*w), so the partials of all ranks combine by plain EC addition (all_gather + wsnark_g*_sum).
- * Applies to every MSM issued afterwards by this process (including those inside
- * wsnark_groth16_prove).  (rank 0, world 1) restores the default. */
-int wsnark_set_window_shard(uint32_t rank, uint32_t world);
+/* Multi-GPU alternative to splitting the pairs (the shard is a PER-CALL argument): every rank is given ALL pairs
+ * and computes only the Pippenger windows w with w % world == rank; its result is then a partial sum already scaled
+ * by 2^(c*w), so the partials of all ranks combine by plain EC addition (all_gather + wsnark_g*_sum) -- the worker
+ * split and gather of src/bn128.js:353-415 with GPUs as workers.  (rank 0, world 1) is the whole sum. */
+int wsnark_g1_msm_windows(const void* scalars, const void* points_affine, uint64_t n, uint32_t rank, uint32_t world, void* out96);
+int wsnark_g2_msm_windows(const void* scalars, const void* points_affine, uint64_t n, uint32_t rank, uint32_t world, void* out192);
+int wsnark_g1_msm_windows_dev(const void* d_scalars, const void* d_points_affine, uint64_t n, uint32_t rank, uint32_t world,
+                              void* out96_host, void* stream);
+int wsnark_g2_msm_windows_dev(const void* d_scalars, const void* d_points_affine, uint64_t n, uint32_t rank, uint32_t world,
+                              void* out192_host, void* stream);
 
 /* fft_fft / fft_ifft (src/build_fft.js:159-221), in place on n Montgomery Fr elements.
  * n must be a power of two <= 2^28 (the reference traps otherwise, :137-154);
@@ -114,10 +121,13 @@ typedef struct {
     const void *beta2, *delta2;              /* 128 B each */
     const void* polsA; uint64_t polsA_len;   /* record streams, src/build_pol.js:62-144 */
     const void* polsB; uint64_t polsB_len;
-    const void *pointsA, *pointsB1;          /* nVars x 64 B  */
-    const void* pointsB2;                    /* nVars x 128 B */
-    const void* pointsC;                     /* (nVars-nPublic-1) x 64 B */
-    const void* pointsH;                     /* domain x 64 B */
+    /* point arrays with the number of BYTES readable behind each pointer; a section shorter than the header
+     * implies (nVars x 64, nVars x 64, nVars x 128, (nVars-nPublic-1) x 64, domain x 64) is WSNARK_ERR_FORMAT */
+    const void* pointsA;  uint64_t pointsA_len;
+    const void* pointsB1; uint64_t pointsB1_len;
+    const void* pointsB2; uint64_t pointsB2_len;
+    const void* pointsC;  uint64_t pointsC_len;
+    const void* pointsH;  uint64_t pointsH_len;
 } wsnark_key_sections_t;
 int wsnark_pkey_load_sections(const wsnark_key_sections_t* sections, wsnark_pkey_t** out_handle);
 
@@ -133,13 +143,21 @@ int wsnark_groth16_prove(wsnark_pkey_t* handle, const void* witness, size_t witn
 int wsnark_groth16_prove_dev(wsnark_pkey_t* handle, const void* d_witness, size_t witness_len, const void* r32,
                              const void* s32, void* out384_host, void* stream);
 
-/* Multi-GPU proving (one process per GPU, window-sharded: call wsnark_set_window_shard first).
+/* The two 32-byte blinding values of the last proof assembled by the CALLING THREAD (wsnark_groth16_prove[_dev] or
+ * _prove_finish), whether injected or drawn from the OS CSPRNG: the reference keeps them the same way, "for tests",
+ * as this._pr / this._ps (src/bn128.js:662-664).  WSNARK_ERR_ARG if this thread has not proved yet. */
+int wsnark_last_blinding(void* r32_out, void* s32_out);
+
+/* Multi-GPU proving (one process per GPU; windows sharded as in wsnark_g1_msm_windows, rank / world per call).
  * prove_partial runs CALC_H and the five MSMs on this rank's windows and writes ONE 576-byte record:
  * A | B1 | C | H (4 x 96 B G1) | B2 (192 B G2), Jacobian-Montgomery -- the reference's per-worker
  * partial results (src/bn128.js:374-382, 406-414) for all five sums at once.  After a single
  * all_gather of these records, prove_finish (host arithmetic only) sums them and assembles the proof
  * exactly as wsnark_groth16_prove does (src/bn128.js:671-718). */
-int wsnark_groth16_prove_partial(wsnark_pkey_t* handle, const void* witness, size_t witness_len, void* out576);
+int wsnark_groth16_prove_partial(wsnark_pkey_t* handle, const void* witness, size_t witness_len, uint32_t rank,
+                                 uint32_t world, void* out576);
+int wsnark_groth16_prove_partial_dev(wsnark_pkey_t* handle, const void* d_witness, size_t witness_len, uint32_t rank,
+                                     uint32_t world, void* out576_host, void* stream);
 int wsnark_groth16_prove_finish(wsnark_pkey_t* handle, const void* partials, uint64_t n_ranks, const void* r32,
                                 const void* s32, void* out384);
 
@@ -149,6 +167,36 @@ int wsnark_groth16_prove_finish(wsnark_pkey_t* handle, const void* partials, uin
  * tests build valid synthetic keys from known toxic waste with these (wasmsnark_amd/synth.py). */
 int wsnark_g1_mul_base_batch(const void* base64, const void* scalars, uint64_t n, void* out_affine);
 int wsnark_g2_mul_base_batch(const void* base128, const void* scalars, uint64_t n, void* out_affine);
+
+/* ---- device self-test hooks (tests/test_gpu_primitives.py): NO reference counterpart ----
+ * The reference tests its field and group primitives directly (test/f1.js:296-400, test/bn128.js:84-185); here they
+ * are __device__ code reached only through whole kernels, so these two entry points run ONE LANE PER VECTOR through
+ * the device arithmetic itself.  Inputs and outputs are in the reference's formats; the conversion to the kernels'
+ * internal representation and back is part of what is tested.
+ *   which: 0 = Fq, 1 = Fr (32-byte elements), 2 = Fq2 (64-byte)
+ *   impl : 0 = radix-2^29 lazy field (MSM / NTT kernels), 1 = saturated 4 x 64 field on the device (light kernels),
+ *          2 = the host field (what proof assembly uses; runs on the CPU)
+ *   op   : WSNARK_ST_* below; out is n x 32 (64 for Fq2) bytes. */
+enum {
+    WSNARK_ST_MUL = 0, WSNARK_ST_SQR = 1, WSNARK_ST_ADD = 2, WSNARK_ST_SUB = 3, WSNARK_ST_NEG = 4,
+    WSNARK_ST_TOMONT = 5, WSNARK_ST_FROMMONT = 6,
+    WSNARK_ST_SUB_WEAK = 7,      /* (a - b) through the uncorrected difference feeding a product     */
+    WSNARK_ST_ADD_LAZY_MUL = 8,  /* (a + b) * b with the carry-free sum as a direct product operand  */
+    WSNARK_ST_NEG_WEAK_MUL = 9,  /* (-a) * b through the 2p - a form                                 */
+    WSNARK_ST_MUL2ADD = 10,      /* a*a + b*b with one Montgomery reduction                          */
+    WSNARK_ST_MULSUB2 = 11,      /* (a - b)*a - b*a: fused, first operand an uncorrected difference   */
+    WSNARK_ST_EQ = 12,           /* out = 1 if a == b else 0 (zero test of the strict difference)    */
+    WSNARK_ST_EQ_WEAK = 13,      /* the same through the uncorrected difference                      */
+    WSNARK_ST_INVERSE = 14       /* 1/a (a != 0); host field only (impl 2): f1m_inverse is per-proof host work */
+};
+int wsnark_selftest_field(int which, int impl, int op, const void* a, const void* b, void* out, uint64_t n);
+/*   g: 1 or 2; impl: 0 = radix-2^29 curve of the accumulation kernels, 1 = saturated-field curve on the device,
+ *   2 = host curve, 3 = (G1 only) the radix-2^29 variant of the reduction-tail kernels (inlined products).
+ *   p, q: n Jacobian-Montgomery points (96 / 192 B, any z; z == 0 = infinity); out: n affine-normalised
+ *   Jacobian-Montgomery points ((x, y, 1) or (0, 1, 0)) like every group element this ABI returns.
+ *   op: 0 = p + q (full addition), 1 = 2p, 2 = -p, 3 = p (normalisation only), 4 = p + q as a MIXED addition
+ *   (q must be affine: z == 1, or infinity), 5 = p - q as a mixed addition with the negate flag. */
+int wsnark_selftest_curve(int g, int impl, int op, const void* p, const void* q, void* out, uint64_t n);
 
 /* ---- measurement hooks (bench.py) ---- */
 /* per-kernel HIP-event timing on the stream the kernels are launched on: 0 = off, 1 = every kernel,

@@ -1,0 +1,171 @@
+"""The reference's own primitive vectors (tests/golden/fields.json, groups.json -- harvested from
+/root/reference test/f1.js:296-400 and test/bn128.js:84-185 by oracle/ref_harness/gen_golden.js) run through
+the product's field and curve arithmetic via wsnark_selftest_field / wsnark_selftest_curve.
+
+Shared by tests/test_gpu_primitives.py (-m gpu: the real device code on an MI355X) and
+tests/test_emul_primitives.py (CPU: the same sources under the thread emulator).  Everything is bit-exact."""
+import ctypes as C
+import random
+
+from conftest import load_golden
+
+H = bytes.fromhex
+
+MUL, SQR, ADD, SUB, NEG, TOMONT, FROMMONT, SUB_WEAK, ADD_LAZY_MUL, NEG_WEAK_MUL, MUL2ADD, MULSUB2, EQ, EQ_WEAK, INVERSE = range(15)
+FIELD_IMPLS = {0: "radix-2^29 device field", 1: "saturated device field", 2: "host field"}
+CURVE_IMPLS = {1: (0, 1, 2, 3), 2: (0, 1, 2)}
+
+
+def st_field(bn, which, impl, op, a_list, b_list):
+    sz = 64 if which == 2 else 32
+    n = len(a_list)
+    a, b = b"".join(a_list), b"".join(b_list)
+    assert len(a) == n * sz and len(b) == n * sz
+    out = (C.c_uint8 * (n * sz))()
+    bn.lib.check(bn.lib.c.wsnark_selftest_field(which, impl, op, a, b, out, n))
+    o = bytes(out)
+    return [o[i * sz:(i + 1) * sz] for i in range(n)]
+
+
+def st_curve(bn, g, impl, op, p_list, q_list):
+    sz = 96 if g == 1 else 192
+    n = len(p_list)
+    p, q = b"".join(p_list), b"".join(q_list)
+    assert len(p) == n * sz and len(q) == n * sz
+    out = (C.c_uint8 * (n * sz))()
+    bn.lib.check(bn.lib.c.wsnark_selftest_curve(g, impl, op, p, q, out, n))
+    o = bytes(out)
+    return [o[i * sz:(i + 1) * sz] for i in range(n)]
+
+
+def _le(v):
+    return int(v).to_bytes(32, "little")
+
+
+def _int(b):
+    return int.from_bytes(b, "little")
+
+
+def check_base_field(bn, fname, which, impl):
+    """f1m_* / frm_* vectors of the reference edge grid, plus the lazy / fused forms the kernels really use."""
+    G = load_golden("fields.json")
+    p = int(G["q" if fname == "fq" else "r"])
+    rinv = pow(1 << 256, p - 2, p)
+    F = G["fields"][fname]
+    un, bi = F["unary"], F["binary"]
+    ua = [H(c["a"]) for c in un]
+    assert st_field(bn, which, impl, SQR, ua, ua) == [H(c["square"]) for c in un]
+    assert st_field(bn, which, impl, NEG, ua, ua) == [H(c["neg"]) for c in un]
+    assert st_field(bn, which, impl, TOMONT, ua, ua) == [H(c["toMontgomery"]) for c in un]
+    assert st_field(bn, which, impl, FROMMONT, ua, ua) == [H(c["fromMontgomery"]) for c in un]
+    if impl == 2:
+        inv = [c for c in un if "inverse" in c]
+        assert inv
+        ia = [H(c["a"]) for c in inv]
+        assert st_field(bn, which, impl, INVERSE, ia, ia) == [H(c["inverse"]) for c in inv]
+    ba, bb = [H(c["a"]) for c in bi], [H(c["b"]) for c in bi]
+    assert st_field(bn, which, impl, MUL, ba, bb) == [H(c["mul"]) for c in bi]
+    assert st_field(bn, which, impl, ADD, ba, bb) == [H(c["add"]) for c in bi]
+    assert st_field(bn, which, impl, SUB, ba, bb) == [H(c["sub"]) for c in bi]
+    # the forms the kernels use around their products: same values as the strict ones
+    assert st_field(bn, which, impl, SUB_WEAK, ba, bb) == [H(c["sub"]) for c in bi]
+    # edge grid x edge grid (the reference's set: 0, 1, 2, p-1, p-2, (p-1)/2 +- k, ...) plus seeded randoms,
+    # expected values from plain integer arithmetic on the Montgomery representatives
+    rnd = random.Random(which * 10 + impl)
+    edge = sorted({_int(x) for x in ua} | {0, 1, 2, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2})
+    pairs = [(x, y) for x in edge for y in edge] + [(rnd.randrange(p), rnd.randrange(p)) for _ in range(256)]
+    pa, pb = [_le(x) for x, _ in pairs], [_le(y) for _, y in pairs]
+    assert st_field(bn, which, impl, MUL, pa, pb) == [_le(x * y * rinv % p) for x, y in pairs]
+    assert st_field(bn, which, impl, ADD, pa, pb) == [_le((x + y) % p) for x, y in pairs]
+    assert st_field(bn, which, impl, SUB, pa, pb) == [_le((x - y) % p) for x, y in pairs]
+    assert st_field(bn, which, impl, SUB_WEAK, pa, pb) == [_le((x - y) % p) for x, y in pairs]
+    assert st_field(bn, which, impl, ADD_LAZY_MUL, pa, pb) == [_le((x + y) * y * rinv % p) for x, y in pairs]
+    assert st_field(bn, which, impl, NEG_WEAK_MUL, pa, pb) == [_le((p - x) * y * rinv % p) for x, y in pairs]
+    assert st_field(bn, which, impl, MUL2ADD, pa, pb) == [_le((x * x + y * y) * rinv % p) for x, y in pairs]
+    assert st_field(bn, which, impl, MULSUB2, pa, pb) == [_le(((x - y) * x - y * x) * rinv % p) for x, y in pairs]
+    flags = [_le(1 if x == y else 0) for x, y in pairs]
+    assert st_field(bn, which, impl, EQ, pa, pb) == flags
+    assert st_field(bn, which, impl, EQ_WEAK, pa, pb) == flags
+
+
+def check_fq2(bn, impl):
+    """f2m_mul / square / inverse vectors of the reference, plus add / sub / neg / fused a*b - c*d against integers."""
+    G = load_golden("fields.json")
+    q = int(G["q"])
+    rinv = pow(1 << 256, q - 2, q)
+    cs = G["fq2"]
+    a, b = [H(c["a"]) for c in cs], [H(c["b"]) for c in cs]
+    assert st_field(bn, 2, impl, MUL, a, b) == [H(c["mul"]) for c in cs]
+    assert st_field(bn, 2, impl, SQR, a, a) == [H(c["square"]) for c in cs]
+    if impl == 2:
+        inv = [c for c in cs if "inverse" in c]
+        assert inv
+        ia = [H(c["a"]) for c in inv]
+        assert st_field(bn, 2, impl, INVERSE, ia, ia) == [H(c["inverse"]) for c in inv]
+    rnd = random.Random(200 + impl)
+    edge = [0, 1, 2, q - 1, q - 2, (q - 1) // 2, (q + 1) // 2]
+    vals = [(x, y) for x in edge for y in edge] + [(rnd.randrange(q), rnd.randrange(q)) for _ in range(64)]
+    pairs = [(rnd.choice(vals), rnd.choice(vals)) for _ in range(400)] + [(v, v) for v in vals[:60]]
+    enc = lambda v: _le(v[0]) + _le(v[1])
+    pa, pb = [enc(x) for x, _ in pairs], [enc(y) for _, y in pairs]
+    mul = lambda x, y: ((x[0] * y[0] - x[1] * y[1]) * rinv % q, (x[0] * y[1] + x[1] * y[0]) * rinv % q)   # u^2 = -1
+    sub = lambda x, y: ((x[0] - y[0]) % q, (x[1] - y[1]) % q)
+    assert st_field(bn, 2, impl, MUL, pa, pb) == [enc(mul(x, y)) for x, y in pairs]
+    assert st_field(bn, 2, impl, SQR, pa, pa) == [enc(mul(x, x)) for x, _ in pairs]
+    assert st_field(bn, 2, impl, ADD, pa, pb) == [enc(((x[0] + y[0]) % q, (x[1] + y[1]) % q)) for x, y in pairs]
+    assert st_field(bn, 2, impl, SUB, pa, pb) == [enc(sub(x, y)) for x, y in pairs]
+    assert st_field(bn, 2, impl, NEG, pa, pa) == [enc(((-x[0]) % q, (-x[1]) % q)) for x, _ in pairs]
+    want = [enc(sub(mul(sub(x, y), x), mul(y, x))) for x, y in pairs]
+    assert st_field(bn, 2, impl, MULSUB2, pa, pb) == want
+    flag = lambda v: _le(v) + bytes(32)
+    assert st_field(bn, 2, impl, EQ, pa, pb) == [flag(1 if x == y else 0) for x, y in pairs]
+    assert st_field(bn, 2, impl, EQ_WEAK, pa, pb) == [flag(1 if x == y else 0) for x, y in pairs]
+
+
+def check_group(bn, orc, g, impl):
+    """g1m_* / g2m_* vectors: generic, P+P, same point with different z, P-P, infinity operands (reference branches
+    src/build_curve_jacobian_a0.js:322-356), through the full addition, the doubling and the MIXED addition."""
+    G = load_golden("groups.json")["g%d" % g]
+    cs = G["cases"]
+    p, q = [H(c["p"]) for c in cs], [H(c["q"]) for c in cs]
+    labels = [c["label"] for c in cs]
+    got = st_curve(bn, g, impl, 0, p, q)
+    assert got == [H(c["add_affine"]) for c in cs], [l for l, x, c in zip(labels, got, cs) if x != H(c["add_affine"])]
+    assert st_curve(bn, g, impl, 0, q, p) == [H(c["add_affine"]) for c in cs]          # commutes
+    assert st_curve(bn, g, impl, 1, p, p) == [H(c["double_affine"]) for c in cs]
+    assert st_curve(bn, g, impl, 2, p, p) == [orc.g_affine(g, H(c["neg"])) for c in cs]
+    assert st_curve(bn, g, impl, 3, p, p) == [H(c["p_affine"]) for c in cs]
+    qa = [orc.g_affine(g, x) for x in q]                                              # the key's points are affine
+    got = st_curve(bn, g, impl, 4, p, qa)
+    assert got == [H(c["add_affine"]) for c in cs], [l for l, x, c in zip(labels, got, cs) if x != H(c["add_affine"])]
+    assert st_curve(bn, g, impl, 5, p, qa) == [orc.g_affine(g, orc.g_add(g, x, orc.g_neg(g, y))) for x, y in zip(p, q)]
+    # infinity is always written as (0, 1, 0) and P + (-P) lands there
+    zero = orc.g_affine(g, orc.g_zero(g))
+    assert st_curve(bn, g, impl, 0, p, [orc.g_neg(g, x) for x in p]) == [zero] * len(p)
+    assert st_curve(bn, g, impl, 5, p, [orc.g_affine(g, x) for x in p]) == [zero] * len(p)
+    # group law of test/bn128.js:84-134: 4G by additions == by doublings; 10G == timesScalar(G, 10)
+    gen = H(G["gen"])
+    two = st_curve(bn, g, impl, 1, [gen], [gen])[0]
+    four_d = st_curve(bn, g, impl, 1, [two], [two])[0]
+    acc = gen
+    multiples = [gen]
+    for _ in range(9):
+        acc = st_curve(bn, g, impl, 0, [acc], [gen])[0]
+        multiples.append(acc)
+    assert multiples[3] == four_d
+    ten = [c for c in G["times_scalar"] if _int(H(c["scalar"])) == 10 and c["bytes"] == 32]
+    assert ten and multiples[9] == H(ten[0]["affine"])
+    mixed = gen
+    for _ in range(9):
+        mixed = st_curve(bn, g, impl, 4, [mixed], [gen])[0]
+    assert mixed == multiples[9]
+    # seeded random Jacobian points with non-unit z (oracle timesScalar outputs) against the oracle's own add / double
+    rnd = random.Random(40 + g)
+    n = 24 if g == 1 else 10
+    P = [orc.g_times_scalar(g, gen, _le(rnd.randrange(1, orc.R))) for _ in range(n)]
+    Q = [orc.g_times_scalar(g, gen, _le(rnd.randrange(1, orc.R))) for _ in range(n)]
+    assert st_curve(bn, g, impl, 0, P, Q) == [orc.g_affine(g, orc.g_add(g, x, y)) for x, y in zip(P, Q)]
+    assert st_curve(bn, g, impl, 1, P, P) == [orc.g_affine(g, orc.g_double(g, x)) for x in P]
+    Qa = [orc.g_affine(g, y) for y in Q]
+    assert st_curve(bn, g, impl, 4, P, Qa) == [orc.g_affine(g, orc.g_add(g, x, y)) for x, y in zip(P, Q)]
+    assert st_curve(bn, g, impl, 4, P, [orc.g_affine(g, x) for x in P]) == [orc.g_affine(g, orc.g_double(g, x)) for x in P]

@@ -31,17 +31,16 @@ for g, n in ((1, 45), (2, 21)):
     want = orc.g_affine(g, orc.multiexp(g, "multiexp", sc, pts, n))
     assert full == want, (g, rank)
 # north-star variant: every rank sees all pairs, owns the windows w % world == rank
-bn.set_window_shard(rank, world)
 for g, n in ((1, 45), (2, 21)):
     rnd2 = random.Random(7 + g)
     ks = b"".join(rnd2.randrange(1, orc.R).to_bytes(32, "little") for _ in range(n))
     pts = bn.mul_base(g, ks)
     sc = b"".join(rnd2.randrange(1 << 256).to_bytes(32, "little") for _ in range(n))
-    part = (bn.g1_multiexp if g == 1 else bn.g2_multiexp)(sc, pts)
+    part = (bn.g1_multiexp if g == 1 else bn.g2_multiexp)(sc, pts, shard=(rank, world))
     full = wd.sharded_msm(bn, g, part)
     want = orc.g_affine(g, orc.multiexp(g, "multiexp", sc, pts, n))
     assert full == want, ("windows", g, rank)
-bn.set_window_shard(0, 1)
+    assert (bn.g1_multiexp if g == 1 else bn.g2_multiexp)(sc, pts) == want     # no mode left behind: the next call is whole
 # whole proof, window-sharded: one 576-byte record per rank, one all_gather
 import json
 gold = os.path.join(os.environ["WS_ROOT"], "tests", "golden")
@@ -50,6 +49,15 @@ wit = open(os.path.join(gold, "keys", "t6.witness.bin"), "rb").read()
 for c in json.load(open(os.path.join(gold, "proofs.json")))["t6"]:
     got = wd.sharded_prove(bn, key, wit, r=bytes.fromhex(c["r"]), s=bytes.fromhex(c["s"]))
     assert got == c["proof"], ("sharded prove", rank)
+# blinding left to the library: rank 0 draws, every rank must still assemble the SAME (valid) proof
+got = wd.sharded_prove(bn, key, wit)
+import torch
+mine = torch.frombuffer(bytearray(json.dumps(got, sort_keys=True).encode().ljust(4096)), dtype=torch.uint8)
+both = [torch.empty_like(mine) for _ in range(world)]
+dist.all_gather(both, mine)
+assert all(torch.equal(both[0], b) for b in both), "ranks disagree on the proof"
+r_used, s_used = bn.last_blinding()
+assert got == bn.groth16GenProof(wit, key, r=r_used, s=s_used)                 # == the single-process proof for those r, s
 dist.barrier()
 open(os.path.join(os.environ["WS_OUT"], "rank%d.ok" % rank), "w").write("ok")
 '''
@@ -85,13 +93,11 @@ def test_window_shards_sum_to_full_msm(orc):
     pts = bn.mul_base(1, b"".join(rnd.randrange(1, orc.R).to_bytes(32, "little") for _ in range(n)))
     sc = b"".join(rnd.randrange(1 << 256).to_bytes(32, "little") for _ in range(n))
     want = orc.g_affine(1, orc.multiexp(1, "multiexp2", sc, pts, n))
-    try:
-        for world in (2, 3, 8, 70):
-            parts = b""
-            for rank in range(world):
-                bn.set_window_shard(rank, world)
-                parts += bn.g1_multiexp(sc, pts)
-            assert bn.g1_sum(parts) == want, world
-    finally:
-        bn.set_window_shard(0, 1)
+    for world in (2, 3, 8, 70):
+        parts = b"".join(bn.g1_multiexp(sc, pts, shard=(rank, world)) for rank in range(world))
+        assert bn.g1_sum(parts) == want, world
     assert bn.g1_multiexp(sc, pts) == want
+    import pytest
+    for bad in ((1, 1), (5, 0), (3, 2)):
+        with pytest.raises(Exception):
+            bn.g1_multiexp(sc, pts, shard=bad)

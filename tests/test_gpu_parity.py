@@ -412,21 +412,15 @@ def test_c1_example_witness_vs_reference_proof(bn, orc):
 
 
 def test_window_shards_sum_to_full_msm_on_gpu(bn, orc):
-    # wsnark_set_window_shard: the partial sums over the window shards of any world size add up
+    # wsnark_g1_msm_windows: the partial sums over the window shards of any world size add up
     rnd = random.Random(321)
     n = 5000
     pts = bn.mul_base(1, b"".join(rnd.randrange(1, orc.R).to_bytes(32, "little") for _ in range(n)))
     sc = _skewed_scalars(rnd, n, orc.R)
     want = orc.g_affine(1, orc.multiexp(1, "workers8", sc, pts, n))
-    try:
-        for world in (2, 8):
-            parts = b""
-            for rank in range(world):
-                bn.set_window_shard(rank, world)
-                parts += bn.g1_multiexp(sc, pts)
-            assert bn.g1_sum(parts) == want, world
-    finally:
-        bn.set_window_shard(0, 1)
+    for world in (2, 8):
+        parts = b"".join(bn.g1_multiexp(sc, pts, shard=(rank, world)) for rank in range(world))
+        assert bn.g1_sum(parts) == want, world
     assert bn.g1_multiexp(sc, pts) == want
 
 
@@ -442,13 +436,7 @@ def test_sharded_prove_records_on_gpu(bn):
     r, s = os.urandom(32), os.urandom(32)
     want = synth.expected_proof(circ, S, r, s, bn.mul_base)
     assert bn.groth16GenProof(wit, key, r=r, s=s) == want
-    parts = b""
-    try:
-        for rank in range(4):
-            bn.set_window_shard(rank, 4)
-            parts += bn.groth16_prove_partial(wit, key)
-    finally:
-        bn.set_window_shard(0, 1)
+    parts = b"".join(bn.groth16_prove_partial(wit, key, shard=(rank, 4)) for rank in range(4))
     assert len(parts) == 4 * 576
     assert bn.groth16_prove_finish(key, parts, r=r, s=s) == want
 

@@ -12,7 +12,7 @@ import pytest
 from conftest import GOLDEN, load_golden
 from emul_util import emul_bn128
 from gen_golden_keys import oracle_mul_base
-from wasmsnark_amd import synth
+from wasmsnark_amd import WsnarkError, synth
 
 NAMES = ["t3", "t6"]
 
@@ -116,11 +116,16 @@ def test_partial_finish_and_sections_loader():
     r, s = bytes.fromhex(c["r"]), bytes.fromhex(c["s"])
     assert bn.groth16GenProof(wit, key, r=r, s=s) == c["proof"]
     assert bn.groth16_prove_finish(key, bn.groth16_prove_partial(wit, key), r=r, s=s) == c["proof"]
-    parts = b""
-    try:
-        for rank in range(3):
-            bn.set_window_shard(rank, 3)
-            parts += bn.groth16_prove_partial(wit, key)
-    finally:
-        bn.set_window_shard(0, 1)
+    parts = b"".join(bn.groth16_prove_partial(wit, key, shard=(rank, 3)) for rank in range(3))
     assert bn.groth16_prove_finish(key, parts, r=r, s=s) == c["proof"]
+    assert bn.last_blinding() == (r, s)
+    # a section shorter than the header implies is refused, not read past
+    for name in ("pointsA", "pointsB2", "pointsC", "pointsH"):
+        short = dict(sec)
+        short[name] = sec[name][:-1]
+        with pytest.raises(WsnarkError):
+            bn.load_key(sections=short)
+    bad = dict(sec)
+    bad["n_public"] = 0xFFFFFFFF                       # nPublic + 1 must not wrap around
+    with pytest.raises(WsnarkError):
+        bn.load_key(sections=bad)

@@ -16,12 +16,14 @@ ERRORS = {1: "WSNARK_ERR_SIZE", 2: "WSNARK_ERR_FORMAT", 3: "WSNARK_ERR_HIP", 4: 
 SYMBOLS = [
     "wsnark_init", "wsnark_shutdown", "wsnark_last_error", "wsnark_device_info",
     "wsnark_g1_msm", "wsnark_g2_msm", "wsnark_g1_msm_dev", "wsnark_g2_msm_dev",
-    "wsnark_g1_sum", "wsnark_g2_sum", "wsnark_set_window_shard",
+    "wsnark_g1_msm_windows", "wsnark_g2_msm_windows", "wsnark_g1_msm_windows_dev", "wsnark_g2_msm_windows_dev",
+    "wsnark_g1_sum", "wsnark_g2_sum",
     "wsnark_fr_ntt", "wsnark_fr_ntt_dev", "wsnark_fr_to_montgomery", "wsnark_fr_from_montgomery",
     "wsnark_calc_h", "wsnark_pkey_load", "wsnark_pkey_free", "wsnark_pkey_info",
-    "wsnark_groth16_prove", "wsnark_groth16_prove_dev", "wsnark_pkey_load_sections",
-    "wsnark_groth16_prove_partial", "wsnark_groth16_prove_finish",
+    "wsnark_groth16_prove", "wsnark_groth16_prove_dev", "wsnark_pkey_load_sections", "wsnark_last_blinding",
+    "wsnark_groth16_prove_partial", "wsnark_groth16_prove_partial_dev", "wsnark_groth16_prove_finish",
     "wsnark_g1_mul_base_batch", "wsnark_g2_mul_base_batch",
+    "wsnark_selftest_field", "wsnark_selftest_curve",
     "wsnark_timing_enable", "wsnark_timing_reset", "wsnark_timing_report",
 ]
 
@@ -34,7 +36,7 @@ class WsnarkError(RuntimeError):
 
 class Lib:
     def __init__(self, path=None):
-        path = path or os.environ.get("WSNARK_LIB") or DEFAULT_SO
+        path = path or DEFAULT_SO     # (no environment override: the product never loads anything but its own library)
         if not os.path.exists(path):
             raise ImportError(
                 "libwsnark.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -53,6 +55,10 @@ class Lib:
         c.wsnark_g2_msm.argtypes = [vp, vp, u64, vp]
         c.wsnark_g1_msm_dev.argtypes = [vp, vp, u64, vp, vp]
         c.wsnark_g2_msm_dev.argtypes = [vp, vp, u64, vp, vp]
+        c.wsnark_g1_msm_windows.argtypes = [vp, vp, u64, u32, u32, vp]
+        c.wsnark_g2_msm_windows.argtypes = [vp, vp, u64, u32, u32, vp]
+        c.wsnark_g1_msm_windows_dev.argtypes = [vp, vp, u64, u32, u32, vp, vp]
+        c.wsnark_g2_msm_windows_dev.argtypes = [vp, vp, u64, u32, u32, vp, vp]
         c.wsnark_g1_sum.argtypes = [vp, u64, vp]
         c.wsnark_g2_sum.argtypes = [vp, u64, vp]
         c.wsnark_fr_ntt.argtypes = [vp, u64, C.c_int, C.c_int]
@@ -67,7 +73,11 @@ class Lib:
         c.wsnark_groth16_prove.argtypes = [vp, vp, sz, vp, vp, vp]
         c.wsnark_groth16_prove_dev.argtypes = [vp, vp, sz, vp, vp, vp, vp]
         c.wsnark_pkey_load_sections.argtypes = [vp, C.POINTER(vp)]
-        c.wsnark_groth16_prove_partial.argtypes = [vp, vp, sz, vp]
+        c.wsnark_groth16_prove_partial.argtypes = [vp, vp, sz, u32, u32, vp]
+        c.wsnark_groth16_prove_partial_dev.argtypes = [vp, vp, sz, u32, u32, vp, vp]
+        c.wsnark_last_blinding.argtypes = [vp, vp]
+        c.wsnark_selftest_field.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, u64]
+        c.wsnark_selftest_curve.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, u64]
         c.wsnark_groth16_prove_finish.argtypes = [vp, vp, u64, vp, vp, vp]
         c.wsnark_g1_mul_base_batch.argtypes = [vp, vp, u64, vp]
         c.wsnark_g2_mul_base_batch.argtypes = [vp, vp, u64, vp]

@@ -52,8 +52,9 @@ class _KeySections(C.Structure):   # wsnark_key_sections_t
                 ("alfa1", C.c_void_p), ("beta1", C.c_void_p), ("delta1", C.c_void_p),
                 ("beta2", C.c_void_p), ("delta2", C.c_void_p),
                 ("polsA", C.c_void_p), ("polsA_len", C.c_uint64), ("polsB", C.c_void_p), ("polsB_len", C.c_uint64),
-                ("pointsA", C.c_void_p), ("pointsB1", C.c_void_p), ("pointsB2", C.c_void_p),
-                ("pointsC", C.c_void_p), ("pointsH", C.c_void_p)]
+                ("pointsA", C.c_void_p), ("pointsA_len", C.c_uint64), ("pointsB1", C.c_void_p), ("pointsB1_len", C.c_uint64),
+                ("pointsB2", C.c_void_p), ("pointsB2_len", C.c_uint64), ("pointsC", C.c_void_p), ("pointsC_len", C.c_uint64),
+                ("pointsH", C.c_void_p), ("pointsH_len", C.c_uint64)]
 
 
 class ProvingKey:
@@ -72,8 +73,8 @@ class ProvingKey:
                 b, n = _ro(sections[name])
                 keep.append(b)
                 setattr(ks, name, C.cast(b, C.c_void_p))
-                if name in ("polsA", "polsB"):
-                    setattr(ks, name + "_len", n)
+                if name.startswith(("pols", "points")):
+                    setattr(ks, name + "_len", n)     # the library checks every section against the header
             lib.check(lib.c.wsnark_pkey_load_sections(C.byref(ks), C.byref(self._h)))
         else:
             b, n = _ro(data)
@@ -103,25 +104,25 @@ class Bn128:
         self._keys = {}
 
     # --- src/bn128.js:353-383 ---
-    def g1_multiexp(self, scalars, points):
-        s, ns = _ro(scalars)
-        p, np_ = _ro(points)
-        n = ns // 32
-        if np_ < n * 64:
-            raise ValueError("points buffer shorter than n*64 bytes")
-        out = (C.c_uint8 * 96)()
-        self.lib.check(self.lib.c.wsnark_g1_msm(s, p, n, out))
-        return bytes(out)
+    def g1_multiexp(self, scalars, points, shard=None):
+        """shard=(rank, world): only the Pippenger windows w % world == rank (a partial sum, see g1_sum)."""
+        return self._multiexp(1, scalars, points, shard)
 
     # --- src/bn128.js:385-415 ---
-    def g2_multiexp(self, scalars, points):
+    def g2_multiexp(self, scalars, points, shard=None):
+        return self._multiexp(2, scalars, points, shard)
+
+    def _multiexp(self, g, scalars, points, shard):
         s, ns = _ro(scalars)
         p, np_ = _ro(points)
         n = ns // 32
-        if np_ < n * 128:
-            raise ValueError("points buffer shorter than n*128 bytes")
-        out = (C.c_uint8 * 192)()
-        self.lib.check(self.lib.c.wsnark_g2_msm(s, p, n, out))
+        sz = 64 if g == 1 else 128
+        if np_ < n * sz:
+            raise ValueError("points buffer shorter than n*%d bytes" % sz)
+        out = (C.c_uint8 * (96 if g == 1 else 192))()
+        rank, world = shard or (0, 1)
+        fn = self.lib.c.wsnark_g1_msm_windows if g == 1 else self.lib.c.wsnark_g2_msm_windows
+        self.lib.check(fn(s, p, n, rank, world, out))
         return bytes(out)
 
     # --- the gather loop of src/bn128.js:374-382 / 406-414: EC sum of Jacobian partials ---
@@ -137,19 +138,17 @@ class Bn128:
         self.lib.check(self.lib.c.wsnark_g2_sum(b, n // 192, out))
         return bytes(out)
 
-    def set_window_shard(self, rank, world):
-        """Multi-GPU window sharding (include/wsnark.h: wsnark_set_window_shard)."""
-        self.lib.check(self.lib.c.wsnark_set_window_shard(rank, world))
-
     # --- device-resident variants (pointers from torch tensors / hipMalloc) ---
-    def g1_multiexp_dev(self, d_scalars, d_points, n, stream=None):
+    def g1_multiexp_dev(self, d_scalars, d_points, n, stream=None, shard=None):
         out = (C.c_uint8 * 96)()
-        self.lib.check(self.lib.c.wsnark_g1_msm_dev(d_scalars, d_points, n, out, stream))
+        rank, world = shard or (0, 1)
+        self.lib.check(self.lib.c.wsnark_g1_msm_windows_dev(d_scalars, d_points, n, rank, world, out, stream))
         return bytes(out)
 
-    def g2_multiexp_dev(self, d_scalars, d_points, n, stream=None):
+    def g2_multiexp_dev(self, d_scalars, d_points, n, stream=None, shard=None):
         out = (C.c_uint8 * 192)()
-        self.lib.check(self.lib.c.wsnark_g2_msm_dev(d_scalars, d_points, n, out, stream))
+        rank, world = shard or (0, 1)
+        self.lib.check(self.lib.c.wsnark_g2_msm_windows_dev(d_scalars, d_points, n, rank, world, out, stream))
         return bytes(out)
 
     def fft_dev(self, d_buf, n, odd=0, inverse=False, stream=None):
@@ -205,11 +204,23 @@ class Bn128:
         return ProvingKey(self.lib, pkey, sections)
 
     # --- multi-GPU proving: per-rank partial sums + host-side finish (include/wsnark.h) ---
-    def groth16_prove_partial(self, signals, key):
+    def groth16_prove_partial(self, signals, key, shard=(0, 1)):
+        """shard=(rank, world): this rank's 576-byte record of partial sums (windows w % world == rank)."""
         w, nw = _ro(signals)
         out = (C.c_uint8 * 576)()
-        self.lib.check(self.lib.c.wsnark_groth16_prove_partial(key._h, w, nw, out))
+        self.lib.check(self.lib.c.wsnark_groth16_prove_partial(key._h, w, nw, shard[0], shard[1], out))
         return bytes(out)
+
+    def groth16_prove_partial_dev(self, d_witness, witness_len, key, shard=(0, 1), stream=None):
+        out = (C.c_uint8 * 576)()
+        self.lib.check(self.lib.c.wsnark_groth16_prove_partial_dev(key._h, d_witness, witness_len, shard[0], shard[1], out, stream))
+        return bytes(out)
+
+    def last_blinding(self):
+        """(r, s) of the last proof assembled by this thread -- the reference's this._pr / this._ps (src/bn128.js:662-664)."""
+        r, s = (C.c_uint8 * 32)(), (C.c_uint8 * 32)()
+        self.lib.check(self.lib.c.wsnark_last_blinding(r, s))
+        return bytes(r), bytes(s)
 
     def groth16_prove_finish(self, key, partials, r=None, s=None):
         p, n = _ro(partials)

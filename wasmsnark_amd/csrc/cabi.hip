@@ -21,17 +21,22 @@ struct KeySections {
     const uint8_t* polsA; uint64_t lenA;
     const uint8_t* polsB; uint64_t lenB;
     const uint8_t *A, *B1, *B2, *Cpts, *H;
+    uint64_t lenPA, lenPB1, lenPB2, lenPC, lenPH;
 };
 int pkey_load_sections(const KeySections& S, ProvingKey** out);
-int groth16_prove_partial(ProvingKey* K, const uint8_t* witness, size_t witness_len, uint8_t* out576);
+int groth16_prove_partial(ProvingKey* K, const uint8_t* witness, size_t witness_len, WindowShard sh, uint8_t* out576);
+int groth16_prove_partial_dev(ProvingKey* K, const Fe* d_witness, size_t witness_len, WindowShard sh, uint8_t* out576, hipStream_t s);
 int groth16_prove_finish(ProvingKey* K, const uint8_t* partials, uint64_t n_ranks, const uint8_t* r32,
                          const uint8_t* s32, uint8_t* out384);
 int groth16_prove_dev_witness(ProvingKey* K, const Fe* d_witness, size_t witness_len, const uint8_t* r32,
                               const uint8_t* s32, uint8_t* out384, hipStream_t s);
+bool last_blinding(uint8_t* r32, uint8_t* s32);
 void g1_sum_host(const uint8_t* pts, uint64_t count, uint8_t* out96);
 void g2_sum_host(const uint8_t* pts, uint64_t count, uint8_t* out192);
 int g1_mul_base_batch(const void* base, const void* scalars, uint64_t n, void* out);
 int g2_mul_base_batch(const void* base, const void* scalars, uint64_t n, void* out);
+int selftest_field(int which, int impl, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, uint64_t n);
+int selftest_curve(int g, int impl, int op, const uint8_t* p, const uint8_t* q, uint8_t* out, uint64_t n);
 }  // namespace wsnark
 
 using namespace wsnark;
@@ -41,9 +46,28 @@ static_assert(sizeof(Affine<Fq>) == 64 && sizeof(Affine<Fq2>) == 128, "affine la
 static_assert(sizeof(Jac<Fq>) == 96 && sizeof(Jac<Fq2>) == 192, "jacobian layouts");
 static_assert(sizeof(XYZZ<Fq>) == 128 && sizeof(XYZZ<Fq2>) == 256, "xyzz layouts");
 
+// HIP's current device is per host thread (default 0) and every entry point may be called from any thread (the Node
+// addon runs on the libuv pool): select the context's device first.
 #define REQUIRE_CTX()                                                        \
     Context* C = ctx();                                                      \
-    if (!C) { set_last_error("wsnark_init() has not been called"); return WSNARK_ERR_NOINIT; }
+    if (!C) { set_last_error("wsnark_init() has not been called"); return WSNARK_ERR_NOINIT; } \
+    WS_HIP_CHECK(hipSetDevice(C->device))
+static bool shard_ok(uint32_t rank, uint32_t world) { return world != 0 && rank < world; }
+
+template <class JacT, class Fn>
+static int msm_entry(Context* C, bool host, const void* scalars, const void* points, uint64_t n, uint32_t rank, uint32_t world,
+                     void* out, Fn run) {
+    if (!out || (n && (!scalars || !points))) return WSNARK_ERR_ARG;
+    if (!shard_ok(rank, world)) return WSNARK_ERR_ARG;
+    if (n > ((uint64_t)1 << 28)) return WSNARK_ERR_SIZE;
+    (void)host;
+    JacT r;
+    LaneLock L = acquire_lane(C);
+    int rc = run(*L, WindowShard{rank, world}, &r);
+    if (rc) return rc;
+    memcpy(out, &r, sizeof r);
+    return WSNARK_OK;
+}
 
 extern "C" {
 
@@ -53,53 +77,43 @@ const char* wsnark_last_error(void) { return get_last_error().c_str(); }
 const char* wsnark_device_info(void) { return device_info().c_str(); }
 
 // ---- MSM ----
-int wsnark_g1_msm(const void* scalars, const void* points, uint64_t n, void* out96) {
+int wsnark_g1_msm_windows(const void* scalars, const void* points, uint64_t n, uint32_t rank, uint32_t world, void* out96) {
     REQUIRE_CTX();
-    if (!out96 || (n && (!scalars || !points))) return WSNARK_ERR_ARG;
-    if (n > ((uint64_t)1 << 28)) return WSNARK_ERR_SIZE;
-    Jac<Fq> r;
-    int rc = msm_g1_host(scalars, points, n, &r);
-    if (rc) return rc;
-    memcpy(out96, &r, sizeof r);
-    return WSNARK_OK;
+    return msm_entry<Jac<Fq>>(C, true, scalars, points, n, rank, world, out96,
+                              [&](Lane& L, WindowShard sh, Jac<Fq>* r) { return msm_g1_host(L, scalars, points, n, sh, r); });
+}
+int wsnark_g2_msm_windows(const void* scalars, const void* points, uint64_t n, uint32_t rank, uint32_t world, void* out192) {
+    REQUIRE_CTX();
+    return msm_entry<Jac<Fq2>>(C, true, scalars, points, n, rank, world, out192,
+                               [&](Lane& L, WindowShard sh, Jac<Fq2>* r) { return msm_g2_host(L, scalars, points, n, sh, r); });
+}
+int wsnark_g1_msm_windows_dev(const void* d_scalars, const void* d_points, uint64_t n, uint32_t rank, uint32_t world,
+                              void* out96_host, void* stream) {
+    REQUIRE_CTX();
+    return msm_entry<Jac<Fq>>(C, false, d_scalars, d_points, n, rank, world, out96_host, [&](Lane& L, WindowShard sh, Jac<Fq>* r) {
+        return msm_g1_dev(L, (const Fe*)d_scalars, (const Affine<Fq>*)d_points, n, sh, r, (hipStream_t)stream);
+    });
+}
+int wsnark_g2_msm_windows_dev(const void* d_scalars, const void* d_points, uint64_t n, uint32_t rank, uint32_t world,
+                              void* out192_host, void* stream) {
+    REQUIRE_CTX();
+    return msm_entry<Jac<Fq2>>(C, false, d_scalars, d_points, n, rank, world, out192_host, [&](Lane& L, WindowShard sh, Jac<Fq2>* r) {
+        return msm_g2_dev(L, (const Fe*)d_scalars, (const Affine<Fq2>*)d_points, n, sh, r, (hipStream_t)stream);
+    });
+}
+int wsnark_g1_msm(const void* scalars, const void* points, uint64_t n, void* out96) {
+    return wsnark_g1_msm_windows(scalars, points, n, 0, 1, out96);
 }
 int wsnark_g2_msm(const void* scalars, const void* points, uint64_t n, void* out192) {
-    REQUIRE_CTX();
-    if (!out192 || (n && (!scalars || !points))) return WSNARK_ERR_ARG;
-    if (n > ((uint64_t)1 << 28)) return WSNARK_ERR_SIZE;
-    Jac<Fq2> r;
-    int rc = msm_g2_host(scalars, points, n, &r);
-    if (rc) return rc;
-    memcpy(out192, &r, sizeof r);
-    return WSNARK_OK;
+    return wsnark_g2_msm_windows(scalars, points, n, 0, 1, out192);
 }
 int wsnark_g1_msm_dev(const void* d_scalars, const void* d_points, uint64_t n, void* out96_host, void* stream) {
-    REQUIRE_CTX();
-    if (!out96_host) return WSNARK_ERR_ARG;
-    Jac<Fq> r;
-    int rc = msm_g1_dev((const Fe*)d_scalars, (const Affine<Fq>*)d_points, n, &r, (hipStream_t)stream);
-    if (rc) return rc;
-    memcpy(out96_host, &r, sizeof r);
-    return WSNARK_OK;
+    return wsnark_g1_msm_windows_dev(d_scalars, d_points, n, 0, 1, out96_host, stream);
 }
 int wsnark_g2_msm_dev(const void* d_scalars, const void* d_points, uint64_t n, void* out192_host, void* stream) {
-    REQUIRE_CTX();
-    if (!out192_host) return WSNARK_ERR_ARG;
-    Jac<Fq2> r;
-    int rc = msm_g2_dev((const Fe*)d_scalars, (const Affine<Fq2>*)d_points, n, &r, (hipStream_t)stream);
-    if (rc) return rc;
-    memcpy(out192_host, &r, sizeof r);
-    return WSNARK_OK;
+    return wsnark_g2_msm_windows_dev(d_scalars, d_points, n, 0, 1, out192_host, stream);
 }
 
-int wsnark_set_window_shard(uint32_t rank, uint32_t world) {
-    REQUIRE_CTX();
-    if (world == 0 || rank >= world) return WSNARK_ERR_ARG;
-    std::lock_guard<std::mutex> lk(C->mu);
-    C->shard_off = rank;
-    C->shard_stride = world;
-    return WSNARK_OK;
-}
 int wsnark_g1_sum(const void* jac_points, uint64_t count, void* out96) {
     if (!out96 || (count && !jac_points)) return WSNARK_ERR_ARG;
     g1_sum_host((const uint8_t*)jac_points, count, (uint8_t*)out96);
@@ -114,7 +128,8 @@ int wsnark_g2_sum(const void* jac_points, uint64_t count, void* out192) {
 // ---- NTT ----
 int wsnark_fr_ntt_dev(void* d_buf, uint64_t n, int odd, int inverse, void* stream) {
     REQUIRE_CTX();
-    return ntt_dev((Fe*)d_buf, n, odd, inverse, (hipStream_t)stream);
+    LaneLock L = acquire_lane(C);
+    return ntt_dev(*L, (Fe*)d_buf, n, odd, inverse, (hipStream_t)stream);
 }
 int wsnark_fr_ntt(void* buf, uint64_t n, int odd, int inverse) {
     REQUIRE_CTX();
@@ -122,11 +137,12 @@ int wsnark_fr_ntt(void* buf, uint64_t n, int odd, int inverse) {
     if (n == 0 || (n & (n - 1)) || n > ((uint64_t)1 << 28)) return WSNARK_ERR_SIZE;
     DevBuf d;
     WS_HIP_CHECK(d.alloc(n * 32));
-    WS_HIP_CHECK(hipMemcpyAsync(d.p, buf, n * 32, hipMemcpyHostToDevice, C->stream));
-    int rc = ntt_dev(d.as<Fe>(), n, odd, inverse, C->stream);
+    LaneLock L = acquire_lane(C);
+    WS_HIP_CHECK(hipMemcpyAsync(d.p, buf, n * 32, hipMemcpyHostToDevice, L->stream));
+    int rc = ntt_dev(*L, d.as<Fe>(), n, odd, inverse, L->stream);
     if (rc) return rc;
-    WS_HIP_CHECK(hipMemcpyAsync(buf, d.p, n * 32, hipMemcpyDeviceToHost, C->stream));
-    WS_HIP_CHECK(hipStreamSynchronize(C->stream));
+    WS_HIP_CHECK(hipMemcpyAsync(buf, d.p, n * 32, hipMemcpyDeviceToHost, L->stream));
+    WS_HIP_CHECK(hipStreamSynchronize(L->stream));
     return WSNARK_OK;
 }
 static int fr_map_host(const void* in, void* out, uint64_t n, int to_mont) {
@@ -160,11 +176,13 @@ int wsnark_calc_h(const void* signals, const void* polsA, size_t lenA, const voi
     DevBuf dsig, dh;
     WS_HIP_CHECK(dsig.alloc((size_t)n_signals * 32));
     WS_HIP_CHECK(dh.alloc((size_t)domain * 32));
-    WS_HIP_CHECK(hipMemcpyAsync(dsig.p, signals, (size_t)n_signals * 32, hipMemcpyHostToDevice, C->stream));
-    rc = calc_h_dev(dsig.as<Fe>(), n_signals, A, B, domain, dh.as<Fe>(), C->stream);
+    LaneLock L = acquire_lane(C);
+    hipStream_t s = L->stream;
+    WS_HIP_CHECK(hipMemcpyAsync(dsig.p, signals, (size_t)n_signals * 32, hipMemcpyHostToDevice, s));
+    rc = calc_h_dev(*L, dsig.as<Fe>(), n_signals, A, B, domain, dh.as<Fe>(), s);
     if (rc) return rc;
-    WS_HIP_CHECK(hipMemcpyAsync(out_h, dh.p, (size_t)domain * 32, hipMemcpyDeviceToHost, C->stream));
-    WS_HIP_CHECK(hipStreamSynchronize(C->stream));
+    WS_HIP_CHECK(hipMemcpyAsync(out_h, dh.p, (size_t)domain * 32, hipMemcpyDeviceToHost, s));
+    WS_HIP_CHECK(hipStreamSynchronize(s));
     return WSNARK_OK;
 }
 
@@ -179,7 +197,9 @@ int wsnark_pkey_load(const void* pkey, size_t len, wsnark_pkey_t** out_handle) {
     return WSNARK_OK;
 }
 void wsnark_pkey_free(wsnark_pkey_t* h) {
-    if (h) pkey_free(reinterpret_cast<ProvingKey*>(h));
+    if (!h) return;
+    if (Context* C = ctx()) (void)hipSetDevice(C->device);
+    pkey_free(reinterpret_cast<ProvingKey*>(h));
 }
 int wsnark_pkey_info(const wsnark_pkey_t* h, uint32_t* nv, uint32_t* np, uint32_t* dom) {
     if (!h) return WSNARK_ERR_ARG;
@@ -205,23 +225,36 @@ int wsnark_pkey_load_sections(const wsnark_key_sections_t* ks, wsnark_pkey_t** o
     REQUIRE_CTX();
     if (!ks || !out_handle || !ks->alfa1 || !ks->beta1 || !ks->delta1 || !ks->beta2 || !ks->delta2 || !ks->polsA ||
         !ks->polsB || !ks->pointsA || !ks->pointsB1 || !ks->pointsB2 || !ks->pointsH ||
-        (!ks->pointsC && ks->n_vars > ks->n_public + 1))
+        (!ks->pointsC && (uint64_t)ks->n_vars > (uint64_t)ks->n_public + 1))
         return WSNARK_ERR_ARG;
     KeySections S{ks->n_vars, ks->n_public, ks->domain, (const uint8_t*)ks->alfa1, (const uint8_t*)ks->beta1,
                   (const uint8_t*)ks->delta1, (const uint8_t*)ks->beta2, (const uint8_t*)ks->delta2,
                   (const uint8_t*)ks->polsA, ks->polsA_len, (const uint8_t*)ks->polsB, ks->polsB_len,
                   (const uint8_t*)ks->pointsA, (const uint8_t*)ks->pointsB1, (const uint8_t*)ks->pointsB2,
-                  (const uint8_t*)ks->pointsC, (const uint8_t*)ks->pointsH};
+                  (const uint8_t*)ks->pointsC, (const uint8_t*)ks->pointsH,
+                  ks->pointsA_len, ks->pointsB1_len, ks->pointsB2_len, ks->pointsC_len, ks->pointsH_len};
     ProvingKey* K = nullptr;
     int rc = pkey_load_sections(S, &K);
     if (rc) return rc;
     *out_handle = reinterpret_cast<wsnark_pkey_t*>(K);
     return WSNARK_OK;
 }
-int wsnark_groth16_prove_partial(wsnark_pkey_t* h, const void* witness, size_t witness_len, void* out576) {
+int wsnark_groth16_prove_partial(wsnark_pkey_t* h, const void* witness, size_t witness_len, uint32_t rank, uint32_t world,
+                                 void* out576) {
     REQUIRE_CTX();
-    if (!h || !witness || !out576) return WSNARK_ERR_ARG;
-    return groth16_prove_partial(reinterpret_cast<ProvingKey*>(h), (const uint8_t*)witness, witness_len, (uint8_t*)out576);
+    if (!h || !witness || !out576 || !shard_ok(rank, world)) return WSNARK_ERR_ARG;
+    return groth16_prove_partial(reinterpret_cast<ProvingKey*>(h), (const uint8_t*)witness, witness_len, WindowShard{rank, world},
+                                 (uint8_t*)out576);
+}
+int wsnark_groth16_prove_partial_dev(wsnark_pkey_t* h, const void* d_witness, size_t witness_len, uint32_t rank, uint32_t world,
+                                     void* out576_host, void* stream) {
+    REQUIRE_CTX();
+    if (!h || !d_witness || !out576_host || !shard_ok(rank, world)) return WSNARK_ERR_ARG;
+    return groth16_prove_partial_dev(reinterpret_cast<ProvingKey*>(h), (const Fe*)d_witness, witness_len, WindowShard{rank, world},
+                                     (uint8_t*)out576_host, (hipStream_t)stream);
+}
+int wsnark_last_blinding(void* r32, void* s32) {
+    return last_blinding((uint8_t*)r32, (uint8_t*)s32) ? WSNARK_OK : WSNARK_ERR_ARG;
 }
 int wsnark_groth16_prove_finish(wsnark_pkey_t* h, const void* partials, uint64_t n_ranks, const void* r32,
                                 const void* s32, void* out384) {
@@ -232,10 +265,24 @@ int wsnark_groth16_prove_finish(wsnark_pkey_t* h, const void* partials, uint64_t
 
 // ---- synthetic-input helpers (no reference counterpart) ----
 int wsnark_g1_mul_base_batch(const void* base64, const void* scalars, uint64_t n, void* out_affine) {
+    REQUIRE_CTX();
     return g1_mul_base_batch(base64, scalars, n, out_affine);
 }
 int wsnark_g2_mul_base_batch(const void* base128, const void* scalars, uint64_t n, void* out_affine) {
+    REQUIRE_CTX();
     return g2_mul_base_batch(base128, scalars, n, out_affine);
+}
+
+// ---- device self-test hooks (tests only; selftest.hip) ----
+int wsnark_selftest_field(int which, int impl, int op, const void* a, const void* b, void* out, uint64_t n) {
+    REQUIRE_CTX();
+    if (n && (!a || !b || !out)) return WSNARK_ERR_ARG;
+    return selftest_field(which, impl, op, (const uint8_t*)a, (const uint8_t*)b, (uint8_t*)out, n);
+}
+int wsnark_selftest_curve(int g, int impl, int op, const void* p, const void* q, void* out, uint64_t n) {
+    REQUIRE_CTX();
+    if (n && (!p || !q || !out)) return WSNARK_ERR_ARG;
+    return selftest_curve(g, impl, op, (const uint8_t*)p, (const uint8_t*)q, (uint8_t*)out, n);
 }
 
 // ---- timing ----
@@ -250,7 +297,12 @@ void wsnark_timing_reset(void) {
 size_t wsnark_timing_report(char* buf, size_t cap) {
     Context* C = ctx();
     if (!C) return 0;
+    (void)hipSetDevice(C->device);
     (void)hipStreamSynchronize(C->stream);
+    for (int i = 0; i < C->n_lanes; i++) {
+        (void)hipStreamSynchronize(C->lanes[i].stream);
+        (void)hipStreamSynchronize(C->lanes[i].stream2);
+    }
     C->timer.collect();
     std::string s;
     for (auto& kv : C->timer.acc) {

@@ -117,11 +117,11 @@ int pols_to_csr(const uint8_t* pols, size_t len, uint32_t n_signals, uint32_t do
     return WS_OK;
 }
 
-int calc_h_dev(const Fe* d_signals_plain, uint32_t n_signals, const CsrMatrix& A, const CsrMatrix& B, uint32_t domain,
+int calc_h_dev(Lane& L, const Fe* d_signals_plain, uint32_t n_signals, const CsrMatrix& A, const CsrMatrix& B, uint32_t domain,
                Fe* d_h_out, hipStream_t s) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
-    if (!s) s = C->stream;
+    if (!s) s = L.stream;
     // src/build_fft.js:137-154: the transforms trap unless the size is a power of two; the 2n-sized
     // inverse of the reference needs 2*domain <= 2^28
     if (domain < 2 || (domain & (domain - 1)) || domain > (1u << 27)) return WS_ERR_SIZE;
@@ -129,16 +129,13 @@ int calc_h_dev(const Fe* d_signals_plain, uint32_t n_signals, const CsrMatrix& A
     int bits = 0;
     while ((1u << bits) < domain) bits++;
     const size_t nb = (size_t)domain * sizeof(Fe);
-    ScratchGuard scratch_turn(C->calch_chain, s);   // the work arrays below are shared by every CALC_H of the context
-    {
-        std::lock_guard<std::mutex> lk(C->mu);
-        WS_HIP_CHECK(C->calch_buf[0].reserve((size_t)n_signals * sizeof(Fe)));
-        for (int i = 1; i < 4; i++) WS_HIP_CHECK(C->calch_buf[i].reserve(nb));
-    }
-    Fe* sigM = C->calch_buf[0].as<Fe>();
-    Fe* a = C->calch_buf[1].as<Fe>();
-    Fe* b = C->calch_buf[2].as<Fe>();
-    Fe* e = C->calch_buf[3].as<Fe>();
+    ScratchGuard scratch_turn(L.calch_chain, s);   // the work arrays below are shared by every CALC_H on this lane
+    WS_HIP_CHECK(L.calch_buf[0].reserve((size_t)n_signals * sizeof(Fe)));
+    for (int i = 1; i < 4; i++) WS_HIP_CHECK(L.calch_buf[i].reserve(nb));
+    Fe* sigM = L.calch_buf[0].as<Fe>();
+    Fe* a = L.calch_buf[1].as<Fe>();
+    Fe* b = L.calch_buf[2].as<Fe>();
+    Fe* e = L.calch_buf[3].as<Fe>();
     KernelTimer& T = C->timer;
     const dim3 blk(256), grd(ceil_div_u64(domain, 256));
     int rc;
@@ -155,15 +152,15 @@ int calc_h_dev(const Fe* d_signals_plain, uint32_t n_signals, const CsrMatrix& A
     hipLaunchKernelGGL(fr_mul_kernel, grd, blk, 0, s, a, b, e, (uint64_t)domain);   // E = A.B on the domain
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
-    if ((rc = ntt_dev(a, domain, 0, 1, s))) return rc;               // bn128.js:150-151  evaluations -> coefficients
-    if ((rc = ntt_dev(b, domain, 0, 1, s))) return rc;
-    if ((rc = ntt_dev(a, domain, 1, 0, s))) return rc;               // bn128.js:152-153  -> odd-coset evaluations
-    if ((rc = ntt_dev(b, domain, 1, 0, s))) return rc;
+    if ((rc = ntt_dev(L, a, domain, 0, 1, s))) return rc;               // bn128.js:150-151  evaluations -> coefficients
+    if ((rc = ntt_dev(L, b, domain, 0, 1, s))) return rc;
+    if ((rc = ntt_dev(L, a, domain, 1, 0, s))) return rc;               // bn128.js:152-153  -> odd-coset evaluations
+    if ((rc = ntt_dev(L, b, domain, 1, 0, s))) return rc;
     T.begin("fr_pointwise", s);
     hipLaunchKernelGGL(fr_mul_kernel, grd, blk, 0, s, a, b, a, (uint64_t)domain);   // O = A.B on the coset (bn128.js:158)
     T.end(s);
-    if ((rc = ntt_dev(e, domain, 0, 1, s))) return rc;               // bn128.js:160, split in two halves
-    if ((rc = ntt_dev(a, domain, 0, 1, s))) return rc;
+    if ((rc = ntt_dev(L, e, domain, 0, 1, s))) return rc;               // bn128.js:160, split in two halves
+    if ((rc = ntt_dev(L, a, domain, 0, 1, s))) return rc;
     const Fe *cs_lo, *cs_hi;
     int hc;
     Fe n_inv;

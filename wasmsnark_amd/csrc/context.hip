@@ -14,7 +14,6 @@ static thread_local std::string t_last_error;
 void set_last_error(const std::string& s) { t_last_error = s; }
 const std::string& get_last_error() { return t_last_error; }
 
-void msm_release_pending();
 static Context* g_ctx = nullptr;
 static std::mutex g_ctx_mu;
 static std::string g_devinfo;
@@ -40,14 +39,22 @@ int context_init(int device) {
     C->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     g_devinfo = std::string(prop.name) + " " + prop.gcnArchName + " CUs=" + std::to_string(C->num_cu);
     WS_HIP_CHECK(hipStreamCreateWithFlags(&C->stream, hipStreamNonBlocking));
-    {   // the second queue gets the device's highest priority (WSNARK_S2_PRIO=0 turns that off): its work is released
-        // at chosen points of the first queue's schedule and should then be dispatched ahead of what is still queued
-        const char* e = getenv("WSNARK_S2_PRIO");
-        int lo = 0, hi = 0;
-        if (!(e && atoi(e) == 0) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo &&
-            hipStreamCreateWithPriority(&C->stream2, hipStreamNonBlocking, hi) != hipSuccess)
-            C->stream2 = nullptr;                    // (no priorities here: an ordinary second queue will do)
-        if (!C->stream2) WS_HIP_CHECK(hipStreamCreateWithFlags(&C->stream2, hipStreamNonBlocking));
+    {
+        const char* e = getenv("WSNARK_LANES");
+        int nl = e ? atoi(e) : 2;
+        C->n_lanes = nl < 1 ? 1 : nl > kMaxLanes ? kMaxLanes : nl;
+    }
+    // every lane's second queue gets the device's highest priority (WSNARK_S2_PRIO=0 turns that off): its work is
+    // released at chosen points of the first queue's schedule and should then be dispatched ahead of what is still queued
+    const char* pe = getenv("WSNARK_S2_PRIO");
+    int lo = 0, hi = 0;
+    const bool prio = !(pe && atoi(pe) == 0) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo;
+    for (int i = 0; i < C->n_lanes; i++) {
+        Lane& L = C->lanes[i];
+        L.id = i;
+        WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        if (prio && hipStreamCreateWithPriority(&L.stream2, hipStreamNonBlocking, hi) != hipSuccess) L.stream2 = nullptr;
+        if (!L.stream2) WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream2, hipStreamNonBlocking));   // (no priorities here)
     }
     g_ctx = C;
     return WS_OK;
@@ -56,28 +63,49 @@ int context_init(int device) {
 void context_shutdown() {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     if (!g_ctx) return;
+    (void)hipSetDevice(g_ctx->device);
     (void)hipStreamSynchronize(g_ctx->stream);
-    (void)hipStreamSynchronize(g_ctx->stream2);
+    for (int i = 0; i < g_ctx->n_lanes; i++) {
+        (void)hipStreamSynchronize(g_ctx->lanes[i].stream);
+        (void)hipStreamSynchronize(g_ctx->lanes[i].stream2);
+    }
     g_ctx->timer.reset();
     for (hipEvent_t e : g_ctx->timer.pool) (void)hipEventDestroy(e);
     g_ctx->timer.pool.clear();
     g_ctx->ntt_plans.clear();
-    g_ctx->ntt_scratch.release();
-    if (g_ctx->ntt_chain.done) (void)hipEventDestroy(g_ctx->ntt_chain.done);
-    if (g_ctx->calch_chain.done) (void)hipEventDestroy(g_ctx->calch_chain.done);
-    msm_release_pending();
     if (g_ctx->pin_ring) { (void)hipHostFree(g_ctx->pin_ring); g_ctx->pin_ring = nullptr; }
     for (auto& e : g_ctx->pin_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-    g_ctx->host_in[0].release();
-    g_ctx->host_in[1].release();
-    for (auto& sc : g_ctx->msm_scratch) sc.reset();
+    for (int i = 0; i < g_ctx->n_lanes; i++) {
+        Lane& L = g_ctx->lanes[i];
+        msm_workspace_free(L);
+        for (hipEvent_t* e : {&L.ntt_chain.done, &L.calch_chain.done, &L.ev_start, &L.ev_tail, &L.ev_h})
+            if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+        L.ntt_scratch.release();
+        for (auto& b : L.calch_buf) b.release();
+        L.host_in[0].release(); L.host_in[1].release();
+        L.witness.release(); L.h.release();
+        (void)hipStreamDestroy(L.stream);
+        (void)hipStreamDestroy(L.stream2);
+    }
     (void)hipStreamDestroy(g_ctx->stream);
-    (void)hipStreamDestroy(g_ctx->stream2);
     delete g_ctx;
     g_ctx = nullptr;
 }
 
 const std::string& device_info() { return g_devinfo; }
+
+LaneLock acquire_lane(Context* C) {
+    LaneLock r;
+    for (int i = 0; i < C->n_lanes; i++) {
+        std::unique_lock<std::mutex> lk(C->lanes[i].mu, std::try_to_lock);
+        if (lk.owns_lock()) { r.L = &C->lanes[i]; r.lk = std::move(lk); return r; }
+    }
+    static std::atomic<unsigned> turn(0);
+    Lane& L = C->lanes[turn.fetch_add(1) % (unsigned)C->n_lanes];
+    r.lk = std::unique_lock<std::mutex>(L.mu);
+    r.L = &L;
+    return r;
+}
 
 // ---- staged uploads ----
 static const size_t PIN_CHUNK = (size_t)8 << 20;
@@ -134,22 +162,28 @@ static hipEvent_t timer_event(std::vector<hipEvent_t>& pool) {
     (void)hipEventCreate(&e);
     return e;
 }
+static thread_local long t_rec = -1;      // this thread's open bracket (index into recs), -1 = none / filtered out
 void KernelTimer::begin(const char* name, hipStream_t s) {
     if (!enabled) return;
-    skipped = dominant_only && strncmp(name, "msm_accumulate", 14) != 0;
-    if (skipped) return;
+    t_rec = -1;
+    if (dominant_only && strncmp(name, "msm_accumulate", 14) != 0) return;
+    std::lock_guard<std::mutex> lk(mu);
     Rec r;
     r.name = name;          // string literals only
     r.a = timer_event(pool);
     r.b = timer_event(pool);
     (void)hipEventRecord(r.a, s);
     recs.push_back(r);
+    t_rec = (long)recs.size() - 1;
 }
 void KernelTimer::end(hipStream_t s) {
-    if (!enabled || skipped || recs.empty()) return;
-    (void)hipEventRecord(recs.back().b, s);
+    if (!enabled || t_rec < 0) return;
+    std::lock_guard<std::mutex> lk(mu);
+    if ((size_t)t_rec < recs.size()) (void)hipEventRecord(recs[(size_t)t_rec].b, s);
+    t_rec = -1;
 }
 void KernelTimer::collect() {
+    std::lock_guard<std::mutex> lk(mu);
     // WSNARK_TIMELINE=1: start/end of every bracket relative to the first one (both queues share the device clock)
     static const bool timeline = [] { const char* e = getenv("WSNARK_TIMELINE"); return e && atoi(e) == 1; }();
     for (auto& r : recs) {
@@ -171,6 +205,7 @@ void KernelTimer::collect() {
 }
 void KernelTimer::reset() {
     collect();
+    std::lock_guard<std::mutex> lk(mu);
     acc.clear();
 }
 

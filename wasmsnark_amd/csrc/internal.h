@@ -14,7 +14,7 @@ namespace wsnark {
 struct KernelTimer {
     bool enabled = false;
     bool dominant_only = false;   // mode 2: bracket only the kernel the roofline is quoted on (msm_accumulate_*)
-    bool skipped = false;         // the begin() of the current bracket was filtered out
+    std::mutex mu;                // callers on several lanes bracket concurrently
     struct Rec { const char* name; hipEvent_t a, b; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;   // events are recycled: creating them costs more than recording them
@@ -47,27 +47,58 @@ struct ScratchGuard {
     }
 };
 
-struct NttPlan;    // ntt.hip
-struct MsmScratch; // msm.hip
+struct NttPlan;       // ntt.hip
+struct MsmWorkspace;  // msm.hip
+
+// Multi-GPU window sharding, given PER CALL: the call computes only the Pippenger windows w with
+// w >= off && (w - off) % stride == 0 (rank, world of the C ABI); its result is then a partial sum already scaled
+// by 2^(c*w).  {0, 1} = all windows.
+struct WindowShard {
+    uint32_t off = 0, stride = 1;
+};
+
+// A lane = everything one MSM / CALC_H / proof in flight needs besides the (read-only) key: two in-order queues,
+// the MSM plans and launch slots, the transform scratch, the per-proof witness / h buffers.  A context has a few
+// lanes (WSNARK_LANES, default 2), so that two callers (two proofs, or a proof and an MSM) overlap on one GPU: the
+// reduction tails of one are latency chains on a few hundred wavefronts, the other's full-width kernels take the
+// SIMDs they leave idle.  A caller holds the lane's mutex for the duration of its call.
+struct Lane {
+    int id = 0;
+    std::mutex mu;
+    hipStream_t stream = nullptr;               // first in-order queue (or the caller's stream for _dev entry points)
+    hipStream_t stream2 = nullptr;              // second queue (prover: CALC_H and the H sum beside the tails)
+    MsmWorkspace* msm = nullptr;                // plans, launch slots (owned; msm_workspace_free)
+    DevBuf host_in[2];                          // host-pointer boundary: grow-only device copies of the caller's buffers
+    DevBuf ntt_scratch;                         // ping-pong buffer of the multi-pass transforms
+    DevBuf calch_buf[4];                        // sigM, A, B, E
+    ScratchChain ntt_chain, calch_chain;        // who may touch ntt_scratch / calch_buf next (calls return before the GPU is done)
+    DevBuf witness, h;                          // per-proof device buffers (grow-only)
+    hipEvent_t ev_start = nullptr, ev_tail = nullptr, ev_h = nullptr;   // cross-queue ordering of one proof
+};
+static const int kMaxLanes = 4;
 
 struct Context {
     int device = 0;
-    hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;              // second in-order queue (prover: CALC_H and the H sum beside the tails)
+    hipStream_t stream = nullptr;               // utility queue: key ingestion, table builds, small host-pointer calls
     int num_cu = 256;
-    uint32_t shard_off = 0, shard_stride = 1;   // MSM window sharding (wsnark_set_window_shard)
-    std::mutex mu;
+    int n_lanes = 2;
+    Lane lanes[kMaxLanes];
+    std::mutex mu;                              // NTT plan cache
     std::map<int, std::shared_ptr<NttPlan>> ntt_plans;   // by log2(n)
-    DevBuf ntt_scratch;
-    std::shared_ptr<MsmScratch> msm_scratch[4];          // buffers of the selectable plans (msm_select_plan)
-    DevBuf calch_buf[4];                                 // sigM, A, B, E
-    ScratchChain ntt_chain, calch_chain;                 // who may touch ntt_scratch / calch_buf next
     KernelTimer timer;
-    // host-pointer boundary: pinned staging ring for uploads, grow-only device copies of the caller's buffers
+    // host-pointer boundary: pinned staging ring for uploads
     void* pin_ring = nullptr;
     hipEvent_t pin_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    DevBuf host_in[2];
 };
+
+// RAII: a free lane if there is one, else the next one in turn (blocks until its current user is done)
+struct LaneLock {
+    Lane* L = nullptr;
+    std::unique_lock<std::mutex> lk;
+    Lane* operator->() const { return L; }
+    Lane& operator*() const { return *L; }
+};
+LaneLock acquire_lane(Context* C);
 
 // Host -> device copy of caller memory that may be pageable and never touched by the runtime before: worker
 // threads memcpy chunks into a pinned ring and queue one DMA per chunk on `s` (the runtime's own pageable
@@ -82,7 +113,8 @@ Context* ctx();   // nullptr before wsnark_init
 // Semantics of the reference's fft_fft / fft_ifft (src/build_fft.js:159-221):
 //   forward: y[k] = sum_i x[i] * w_{2n}^{(2k+odd) i}       (natural order in and out)
 //   inverse: rawfft, then y[i] = raw[(n-i) mod n] / n
-int ntt_dev(Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s);
+// The multi-pass scratch comes from lane L (the caller holds it).
+int ntt_dev(Lane& L, Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s);
 
 int ntt_coset_tables(int bits, const Fe** lo, const Fe** hi, int* hc, Fe* n_inv, hipStream_t s);
 
@@ -90,45 +122,38 @@ int ntt_coset_tables(int bits, const Fe** lo, const Fe** hi, int* hc, Fe* n_inv,
 // sum_i scalars[i] * points[i]; scalars raw 256-bit LE (not reduced), points affine
 // Montgomery (x == 0 => infinity).  Result written to host memory as the reference's
 // Jacobian-Montgomery triple, affine-normalised: (x, y, 1) or (0, 1, 0).
-int msm_g1_dev(const Fe* d_scalars, const Affine<Fq>* d_points, uint64_t n, Jac<Fq>* out_host, hipStream_t s);
+// Every function works on lane L, which the caller holds.
+int msm_g1_dev(Lane& L, const Fe* d_scalars, const Affine<Fq>* d_points, uint64_t n, WindowShard sh, Jac<Fq>* out_host, hipStream_t s);
+int msm_g2_dev(Lane& L, const Fe* d_scalars, const Affine<Fq2>* d_points, uint64_t n, WindowShard sh, Jac<Fq2>* out_host, hipStream_t s);
 // the same from host buffers (staged upload; the plan is built while the points are still on their way)
-int msm_g1_host(const void* h_scalars, const void* h_points, uint64_t n, Jac<Fq>* out_host);
-int msm_g2_host(const void* h_scalars, const void* h_points, uint64_t n, Jac<Fq2>* out_host);
-int msm_g2_dev(const Fe* d_scalars, const Affine<Fq2>* d_points, uint64_t n, Jac<Fq2>* out_host, hipStream_t s);
-// XYZZ result left to the caller (host memory), no affine normalisation
-// `prepared` = the point array was converted in place by msm_prepare_points (resident keys)
-int msm_g1_dev_xyzz(const Fe* d_scalars, const Affine<Fq>* d_points, uint64_t n, XYZZ<Fq>* out_host, hipStream_t s,
-                    bool prepared = false);
-int msm_g2_dev_xyzz(const Fe* d_scalars, const Affine<Fq2>* d_points, uint64_t n, XYZZ<Fq2>* out_host, hipStream_t s,
-                    bool prepared = false);
+int msm_g1_host(Lane& L, const void* h_scalars, const void* h_points, uint64_t n, WindowShard sh, Jac<Fq>* out_host);
+int msm_g2_host(Lane& L, const void* h_scalars, const void* h_points, uint64_t n, WindowShard sh, Jac<Fq2>* out_host);
 // two-phase form: one digit/sort/task plan per scalar vector, then any number of point sets of the
 // same length against it (the prover's A, B1, B2 and C sums all use the witness as scalars).
-// Callers serialise on Context::mu.
-// d_mask (optional, n bytes): pairs with mask 0 are left out of the plan -- an optimisation only, for point sets
-// that are infinity there (a plan built without it gives the same sums)
-int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s, const uint8_t* d_mask = nullptr);
+int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipStream_t s);
 // mask[i] = 0 where the point is infinity (x == 0, reference format) in every given set; *skipped_host = how many
 int msm_points_mask(const Affine<Fq>* d_g1, const Affine<Fq2>* d_g2, uint64_t n, uint8_t* d_mask, uint32_t* skipped_host, hipStream_t s);
-int msm_g1_exec_xyzz(const Affine<Fq>* d_points, XYZZ<Fq>* out_host, hipStream_t s, bool prepared);
-int msm_g2_exec_xyzz(const Affine<Fq2>* d_points, XYZZ<Fq2>* out_host, hipStream_t s, bool prepared);
-// asynchronous form of exec: launch enqueues the kernels and the copy of the window sums, finish waits
-// for that copy and runs the serial host tail
-int msm_g1_launch(const Affine<Fq>* d_points, bool prepared, int* slot, hipStream_t s);
-int msm_g2_launch(const Affine<Fq2>* d_points, bool prepared, int* slot, hipStream_t s, hipEvent_t before_tail = nullptr);
+// asynchronous form: launch enqueues the kernels and the copy of the window sums, finish waits
+// for that copy and runs the serial host tail.  `prepared` = the point array was converted in place by
+// msm_prepare_points (resident keys).
+int msm_g1_launch(Lane& L, const Affine<Fq>* d_points, bool prepared, int* slot, hipStream_t s);
+int msm_g2_launch(Lane& L, const Affine<Fq2>* d_points, bool prepared, int* slot, hipStream_t s, hipEvent_t before_tail = nullptr);
 // `before_tail` (optional) is recorded on s after the accumulations, before the batched reduction tail
 // plan_ids (optional): the plan each set is accumulated against (variants of one plan: same geometry)
-int msm_g1_launch_batch(const Affine<Fq>* const* d_points, int nsets, bool prepared, int* slots, hipStream_t s,
+int msm_g1_launch_batch(Lane& L, const Affine<Fq>* const* d_points, int nsets, bool prepared, int* slots, hipStream_t s,
                         hipEvent_t before_tail = nullptr, const int* plan_ids = nullptr);
-// two independent plans (digit/sort/task buffers) can be alive at once; plan and launches use the selected one
-void msm_select_plan(int id);      // id in [0, 4)
+// several independent plans (digit/sort/task buffers) can be alive at once; plan and launches use the selected one
+void msm_select_plan(Lane& L, int id);      // id in [0, 4)
 // A second plan over the SAME scalars that leaves out the pairs with mask[i] == 0, derived from plan `src_id`
 // (which must just have been built by msm_plan_dev): only the per-bin counting sort and the task list are redone,
 // the digit extraction and the coarse scatter are shared.  Becomes plan `dst_id`.
-int msm_plan_variant(int src_id, int dst_id, const uint8_t* d_mask, hipStream_t s);
-bool msm_ready(int slot);     // the launch's window sums have reached the host (finish will not block)
-int msm_g1_finish(int slot, XYZZ<Fq>* out_host);
-int msm_g2_finish(int slot, XYZZ<Fq2>* out_host);
-void msm_abort_pending(hipStream_t s);
+int msm_plan_variant(Lane& L, int src_id, int dst_id, const uint8_t* d_mask, hipStream_t s);
+bool msm_ready(Lane& L, int slot);     // the launch's window sums have reached the host (finish will not block)
+int msm_g1_finish(Lane& L, int slot, XYZZ<Fq>* out_host);
+int msm_g2_finish(Lane& L, int slot, XYZZ<Fq2>* out_host);
+// error paths: forget the given launches (their results will never be collected); waits for the streams first
+void msm_abort_slots(Lane& L, const int* slots, int nslots, hipStream_t a, hipStream_t b);
+void msm_workspace_free(Lane& L);
 int msm_prepare_points(int which, void* d_points, uint64_t n, hipStream_t s);
 bool msm_uses_field29();
 
@@ -145,8 +170,8 @@ struct CsrMatrix {            // row-major transpose of the reference's column-m
 // returns bytes consumed via *consumed.
 int pols_to_csr(const uint8_t* pols, size_t len, uint32_t n_signals, uint32_t domain, CsrMatrix* out,
                 size_t* consumed, hipStream_t s);
-// d_h_out[domain] (plain form) from a device-resident plain witness
-int calc_h_dev(const Fe* d_signals_plain, uint32_t n_signals, const CsrMatrix& A, const CsrMatrix& B,
+// d_h_out[domain] (plain form) from a device-resident plain witness; work arrays of lane L
+int calc_h_dev(Lane& L, const Fe* d_signals_plain, uint32_t n_signals, const CsrMatrix& A, const CsrMatrix& B,
                uint32_t domain, Fe* d_h_out, hipStream_t s);
 int fr_map_dev(const Fe* d_in, Fe* d_out, uint64_t n, int to_mont, hipStream_t s);
 

@@ -673,6 +673,7 @@ __global__ __launch_bounds__(sizeof(typename C::PtP) > 128 ? 256 : 512) void msm
     if (tid == 0) sums[(uint64_t)w * (logJ + 1) + q] = C::pt_from_internal(C::unpack_pt(sh[0]));
 }
 
+
 // ---------------------------------------------------------------------------
 // host driver
 // ---------------------------------------------------------------------------
@@ -739,43 +740,51 @@ struct MsmPending {
     MsmScratch S;                 // this launch's accumulation buffers (buckets, partials, chunk sums)
     void* h_sums = nullptr;
     size_t h_bytes = 0;
-    bool acc_done = false;
-    hipEvent_t ev = nullptr, ev_acc = nullptr;
+    hipEvent_t ev = nullptr;
     void release() {
         if (h_sums) (void)hipHostFree(h_sums);
         if (ev) (void)hipEventDestroy(ev);
-        if (ev_acc) (void)hipEventDestroy(ev_acc);
-        ev_acc = nullptr;
         h_sums = nullptr; ev = nullptr; h_bytes = 0; active = false;
         d_sums.release();
         S.buckets.release(); S.partials.release(); S.chunkS.release(); S.chunkA.release(); S.points_conv.release(); S.hot_sums.release();
     }
 };
-static hipEvent_t g_plan_done = nullptr;   // recorded at the end of msm_plan_dev
-static hipEvent_t g_host_ev = nullptr;     // msm_host_t: points uploaded (second queue)
-static const int kPendingSlots = 16;   // two proofs of different keys may have launches in flight at once (5 each)
-static MsmPending* g_slots = nullptr;   // released by msm_release_pending() at shutdown, while the runtime is alive
-static MsmPending* pending_slots() {
-    if (!g_slots) g_slots = new MsmPending[kPendingSlots];
-    return g_slots;
+
+// Everything the MSMs of ONE lane share: up to four plans alive at once (the prover builds the H plan on the second
+// queue while the sums over the witness still read theirs; A and B1/B2 may run on variants of the witness plan),
+// the launch slots (a proof has five launches in flight), the conversion buffer of caller-format points.
+static const int kPlans = 4;
+static const int kPendingSlots = 8;
+struct MsmWorkspace {
+    struct Plan { MsmPlanInfo info; MsmScratch S; } plan[kPlans];
+    int cur = 0;
+    MsmPending slot[kPendingSlots];
+    hipEvent_t host_ev = nullptr;                      // msm_host_t: points uploaded (second queue)
+    hipEvent_t conv_ev[2] = {nullptr, nullptr};
+    DevBuf conv_buf;
+};
+static MsmWorkspace& ws(Lane& L) {
+    if (!L.msm) L.msm = new MsmWorkspace();
+    return *L.msm;
 }
-// error paths: forget launches whose results will never be collected
-void msm_abort_pending(hipStream_t s) {
-    if (!g_slots) return;
-    (void)hipStreamSynchronize(s);
-    for (int i = 0; i < kPendingSlots; i++) {
-        g_slots[i].active = false;
-    }
+void msm_workspace_free(Lane& L) {
+    if (!L.msm) return;
+    MsmWorkspace& M = *L.msm;
+    if (M.host_ev) (void)hipEventDestroy(M.host_ev);
+    for (auto& e : M.conv_ev) if (e) (void)hipEventDestroy(e);
+    for (auto& p : M.slot) p.release();
+    delete L.msm;
+    L.msm = nullptr;
 }
-void msm_release_conv();
-void msm_release_pending() {
-    if (g_plan_done) { (void)hipEventDestroy(g_plan_done); g_plan_done = nullptr; }
-    if (g_host_ev) { (void)hipEventDestroy(g_host_ev); g_host_ev = nullptr; }
-    msm_release_conv();
-    if (!g_slots) return;
-    for (int i = 0; i < kPendingSlots; i++) g_slots[i].release();
-    delete[] g_slots;
-    g_slots = nullptr;
+void msm_select_plan(Lane& L, int id) { ws(L).cur = (id >= 0 && id < kPlans) ? id : 0; }
+
+// error paths: forget launches whose results will never be collected (only the caller's own slots)
+void msm_abort_slots(Lane& L, const int* slots, int nslots, hipStream_t a, hipStream_t b) {
+    if (a) (void)hipStreamSynchronize(a);
+    if (b && b != a) (void)hipStreamSynchronize(b);
+    if (!L.msm) return;
+    for (int k = 0; k < nslots; k++)
+        if (slots[k] >= 0 && slots[k] < kPendingSlots) L.msm->slot[slots[k]].active = false;
 }
 
 template <class H>
@@ -783,6 +792,7 @@ static int msm_finish_t(MsmPending& P, typename H::Pt* out_host) {
     typedef typename H::Pt HPt;
     const MsmPlanInfo& I = P.info;
     if (I.n == 0) { *out_host = H::infinity(); P.active = false; return WS_OK; }
+    struct Done { MsmPending& p; ~Done() { p.active = false; } } done{P};   // the slot is free again whatever happens
     WS_HIP_CHECK(hipEventSynchronize(P.ev));
     const HPt* sums = reinterpret_cast<const HPt*>(P.h_sums);
     // 8. host tail: result = sum_w 2^(c w) [ A_w + m * sum_q 2^q U_{w,q} ].  ONE Horner chain over the bit
@@ -804,40 +814,32 @@ static int msm_finish_t(MsmPending& P, typename H::Pt* out_host) {
         }
     }
     *out_host = acc;
-    P.active = false;
     return WS_OK;
 }
 
-struct MsmPlanBufs {
-    MsmScratch S;
-    MsmPlanInfo info;
-};
-// two plans can be alive at once (the prover builds the H plan on a second stream while the sums over the
-// witness still read theirs); msm_select_plan picks the one msm_plan_dev and the launches work with
-static int g_plan_cur = 0;
-static const int kPlans = 4;
-void msm_select_plan(int id) { g_plan_cur = (id >= 0 && id < kPlans) ? id : 0; }
-static MsmPlanBufs* plan_bufs(Context* X) {
-    for (auto& sc : X->msm_scratch) if (!sc) sc = std::make_shared<MsmScratch>();
-    static MsmPlanBufs P[kPlans];   // info only; buffers live in the context scratch
-    return &P[g_plan_cur];
+// launches that still read plan `plan_id`'s buffers on their own streams must finish before the buffers are rewritten
+static int wait_plan_users(MsmWorkspace& M, int plan_id, hipStream_t s) {
+    for (auto& p : M.slot)
+        if (p.active && p.ev && p.info.n && p.plan_id == plan_id) WS_HIP_CHECK(hipStreamWaitEvent(s, p.ev, 0));
+    return WS_OK;
 }
-static MsmScratch& plan_scratch(Context* X) { return *X->msm_scratch[g_plan_cur]; }
 
-int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s, const uint8_t* d_mask) {
+int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipStream_t s) {
     Context* X = ctx();
     if (!X) return WS_ERR_NOINIT;
-    if (!s) s = X->stream;
-    MsmPlanInfo& I = plan_bufs(X)->info;
+    if (!s) s = L.stream;
+    MsmWorkspace& M = ws(L);
+    MsmPlanInfo& I = M.plan[M.cur].info;
     I = MsmPlanInfo();
     if (n == 0) { I.valid = true; return WS_OK; }
     if (!d_scalars) return WS_ERR_ARG;
     if (n > ((uint64_t)1 << 28)) return WS_ERR_SIZE;
+    if (sh.stride == 0) return WS_ERR_ARG;
     I.n = n;
     I.c = pick_window(n);
     I.Wall = (255 + I.c - 1) / I.c;
-    I.w_off = X->shard_off;
-    I.w_stride = X->shard_stride ? X->shard_stride : 1;
+    I.w_off = sh.off;
+    I.w_stride = sh.stride;
     I.W = I.w_off < I.Wall ? (I.Wall - I.w_off + I.w_stride - 1) / I.w_stride : 0;
     if (I.W == 0) { I.n = 0; I.valid = true; return WS_OK; }   // this rank owns no window: partial = infinity
     I.NB = 1u << (I.c - 1);
@@ -858,11 +860,9 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s, const uint8_t* 
     I.hot_cap = (uint32_t)(total / I.lmax) + I.nbuckets + 16;
     const uint32_t c = I.c, W = I.W, nbuckets = I.nbuckets, lmax = I.lmax;
 
-    // launches of the previous plan may still be reading the plan buffers on their own streams
-    for (int i = 0; g_slots && i < kPendingSlots; i++)
-        if (g_slots[i].active && g_slots[i].ev && g_slots[i].info.n && g_slots[i].plan_id == g_plan_cur)
-            WS_HIP_CHECK(hipStreamWaitEvent(s, g_slots[i].ev, 0));
-    MsmScratch& S = plan_scratch(X);
+    int rc = wait_plan_users(M, M.cur, s);
+    if (rc) return rc;
+    MsmScratch& S = M.plan[M.cur].S;
     WS_HIP_CHECK(S.vals_out.reserve(total * 4));
     WS_HIP_CHECK(S.bstart.reserve((size_t)nbuckets * 4));
     WS_HIP_CHECK(S.bend.reserve((size_t)nbuckets * 4));
@@ -901,7 +901,7 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s, const uint8_t* 
         uint32_t* bin_start = bin_count + (nbins + 1);
         uint32_t* bin_cursor = bin_start + (nbins + 1);
         WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, (1024 + (size_t)nbins + 1) * 4, s));
-        PresortArgs PA{d_scalars, (uint32_t)n, c, I.Wall, I.w_off, I.w_stride, lo_bits, HB, nbins, env_tile, idx_bits, d_mask};
+        PresortArgs PA{d_scalars, (uint32_t)n, c, I.Wall, I.w_off, I.w_stride, lo_bits, HB, nbins, env_tile, idx_bits, nullptr};
         const dim3 grid(ceil_div_u64(n, env_tile)), blk(env_thr);
         T.begin("msm_presort_count", s);
         hipLaunchKernelGGL(presort_count, grid, blk, 0, s, PA, bin_count);
@@ -926,7 +926,7 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s, const uint8_t* 
         T.end(s);
         WS_HIP_CHECK(hipGetLastError());
         have_hist = true;
-        I.ps_valid = d_mask == nullptr;      // (a masked scatter cannot be the source of further variants)
+        I.ps_valid = true;
         I.ps_lo_bits = lo_bits; I.ps_idx_bits = idx_bits; I.ps_nbins = nbins; I.ps_bthr = bthr; I.ps_e32 = e32;
     } else {
         WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, 4096, s));
@@ -942,7 +942,7 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s, const uint8_t* 
         T.begin("msm_sort", s);
         int key_bits = 1;
         while (((uint64_t)1 << key_bits) <= nbuckets) key_bits++;   // keys are 0..nbuckets (nbuckets = "no digit")
-        int rc = sort_pairs(S, total, key_bits, s);
+        rc = sort_pairs(S, total, key_bits, s);
         T.end(s);
         if (rc) return rc;
         WS_HIP_CHECK(hipMemsetAsync(S.bstart.p, 0, (size_t)nbuckets * 4, s));
@@ -966,31 +966,26 @@ int msm_plan_dev(const Fe* d_scalars, uint64_t n, hipStream_t s, const uint8_t* 
     // tasks <= total/lmax + nbuckets <= hot_cap, so the worst-case grids below always cover them
     I.ntasks = I.hot_cap;
     I.nmulti = 0;
-    if (!g_plan_done) WS_HIP_CHECK(hipEventCreate(&g_plan_done));
-    WS_HIP_CHECK(hipEventRecord(g_plan_done, s));
     I.valid = true;
     return WS_OK;
 }
 
-int msm_plan_variant(int src_id, int dst_id, const uint8_t* d_mask, hipStream_t s) {
+int msm_plan_variant(Lane& L, int src_id, int dst_id, const uint8_t* d_mask, hipStream_t s) {
     Context* X = ctx();
     if (!X) return WS_ERR_NOINIT;
-    if (!s) s = X->stream;
+    if (!s) s = L.stream;
     if (src_id < 0 || src_id >= kPlans || dst_id < 0 || dst_id >= kPlans || src_id == dst_id || !d_mask) return WS_ERR_ARG;
-    const int keep = g_plan_cur;
-    msm_select_plan(src_id);
-    const MsmPlanInfo src = plan_bufs(X)->info;
-    MsmScratch& SS = plan_scratch(X);
-    msm_select_plan(dst_id);
-    MsmPlanInfo& I = plan_bufs(X)->info;
-    MsmScratch& S = plan_scratch(X);
-    struct Restore { int id; ~Restore() { msm_select_plan(id); } } restore{keep};
+    MsmWorkspace& M = ws(L);
+    const MsmPlanInfo src = M.plan[src_id].info;
+    MsmScratch& SS = M.plan[src_id].S;
+    MsmPlanInfo& I = M.plan[dst_id].info;
+    MsmScratch& S = M.plan[dst_id].S;
     if (!src.valid || !src.ps_valid || src.n == 0) { set_last_error("msm_plan_variant: the source plan has no shared grouping pass"); return WS_ERR_ARG; }
-    for (int i = 0; g_slots && i < kPendingSlots; i++)
-        if (g_slots[i].active && g_slots[i].ev && g_slots[i].info.n && g_slots[i].plan_id == dst_id)
-            WS_HIP_CHECK(hipStreamWaitEvent(s, g_slots[i].ev, 0));
+    int rc = wait_plan_users(M, dst_id, s);
+    if (rc) return rc;
     I = src;
     I.ps_valid = false;
+    I.valid = false;
     const uint64_t total = src.n * src.W;
     WS_HIP_CHECK(S.vals_out.reserve(total * 4));
     WS_HIP_CHECK(S.bstart.reserve((size_t)src.nbuckets * 4));
@@ -1020,6 +1015,7 @@ int msm_plan_variant(int src_id, int dst_id, const uint8_t* d_mask, hipStream_t 
     hipLaunchKernelGGL(msm_plan_emit_hot, dim3(64), dim3(256), 0, s, S.hot.as<HotBucket>(), d_cnt, src.lmax, S.tasks.as<Task>());
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
+    I.valid = true;
     return WS_OK;
 }
 
@@ -1027,32 +1023,30 @@ int msm_plan_variant(int src_id, int dst_id, const uint8_t* d_mask, hipStream_t 
 // C = device curve (arithmetic of the kernels), H = host curve (reference-format results, host tail).
 // `prepared`: d_points are already in C's internal domain (msm_prepare_points).
 template <class C, class H>
-static int msm_launch_acc(int which, const typename H::Aff* d_points_ref, bool prepared, int* slot_out, hipStream_t s) {
+static int msm_launch_acc(Lane& L, int which, const typename H::Aff* d_points_ref, bool prepared, int* slot_out, hipStream_t s) {
     typedef typename C::PtP Pt;      // packed accumulator in global memory (same bytes as H::Pt)
     static_assert(sizeof(typename C::PtP) == sizeof(typename H::Pt) && sizeof(typename C::AffP) == sizeof(typename H::Aff), "layouts");
     Context* X = ctx();
     if (!X) return WS_ERR_NOINIT;
-    if (!s) s = X->stream;
-    const MsmPlanInfo& I = plan_bufs(X)->info;
+    if (!s) s = L.stream;
+    MsmWorkspace& M = ws(L);
+    const MsmPlanInfo& I = M.plan[M.cur].info;
     if (!I.valid) { set_last_error("msm: no plan"); return WS_ERR_ARG; }
-    MsmPending* slots = pending_slots();
+    if (I.n && !d_points_ref) return WS_ERR_ARG;
     int slot = -1;
-    for (int i = 0; i < kPendingSlots; i++) if (!slots[i].active) { slot = i; break; }
+    for (int i = 0; i < kPendingSlots; i++) if (!M.slot[i].active) { slot = i; break; }
     if (slot < 0) { set_last_error("msm: too many unfinished launches"); return WS_ERR_ARG; }
-    MsmPending& P = slots[slot];
+    MsmPending& P = M.slot[slot];
     P.which = which;
     P.info = I;
-    *slot_out = slot;
-    P.active = true;
-    if (I.n == 0) return WS_OK;   // multiexp with n=0 leaves pr unchanged
-    if (!d_points_ref) return WS_ERR_ARG;
+    P.plan_id = M.cur;
+    if (I.n == 0) { P.active = true; *slot_out = slot; return WS_OK; }   // multiexp with n=0 leaves pr unchanged
     const typename C::AffP* d_points = reinterpret_cast<const typename C::AffP*>(d_points_ref);
     const uint64_t n = I.n;
-    const uint32_t c = I.c, W = I.W, nbuckets = I.nbuckets, m = I.m, J = I.J, logJ = I.logJ, nsum = I.nsum;
+    const uint32_t W = I.W, nbuckets = I.nbuckets, J = I.J, nsum = I.nsum;
     const uint32_t ntasks = I.ntasks;
 
-    MsmScratch& PS = plan_scratch(X);           // plan buffers (read-only here)
-    P.plan_id = g_plan_cur;
+    MsmScratch& PS = M.plan[M.cur].S;           // plan buffers (read-only here)
     MsmScratch& S = P.S;                        // this launch's accumulation buffers
     // Everything runs in order on the caller's stream.  Tried and measured slower on MI355X (round 1, sessions
     // 7, 8, 11): accumulations on concurrent streams (cache thrash), and the reduction tail on a second,
@@ -1065,11 +1059,13 @@ static int msm_launch_acc(int which, const typename H::Aff* d_points_ref, bool p
     WS_HIP_CHECK(P.d_sums.reserve(sums_bytes));
     if (P.h_bytes < sums_bytes) {
         if (P.h_sums) (void)hipHostFree(P.h_sums);
-        P.h_sums = nullptr;
+        P.h_sums = nullptr; P.h_bytes = 0;
         WS_HIP_CHECK(hipHostMalloc(&P.h_sums, sums_bytes, 0));
         P.h_bytes = sums_bytes;
     }
     if (!P.ev) WS_HIP_CHECK(hipEventCreate(&P.ev));
+    // (slots wait for hot-bucket slice sums: at most one per HOT_SLICE tasks plus one per hot bucket)
+    WS_HIP_CHECK(S.hot_sums.reserve(((size_t)I.hot_cap / HOT_SLICE + (size_t)I.hot_cap / I.hot_min + 32) * sizeof(Pt)));
 
     KernelTimer& T = X->timer;
     if (C::Field::kInternalDomain && !prepared) {
@@ -1092,16 +1088,15 @@ static int msm_launch_acc(int which, const typename H::Aff* d_points_ref, bool p
                        PS.bend.as<uint32_t>(), nbuckets);
     hipLaunchKernelGGL(msm_combine_wave<C>, dim3(2048), dim3(64), 0, s, PS.multi.as<MultiBucket>(),
                        PS.counters.as<uint32_t>(), S.partials.as<Pt>(), S.buckets.as<Pt>());
-    // (slice sums: at most one per HOT_SLICE tasks plus one per hot bucket)
-    WS_HIP_CHECK(S.hot_sums.reserve(((size_t)I.hot_cap / HOT_SLICE + (size_t)I.hot_cap / I.hot_min + 32) * sizeof(Pt)));
     hipLaunchKernelGGL(msm_combine_hot1<C>, dim3(1024), dim3(64), 0, s, PS.hot.as<HotBucket>(), PS.counters.as<uint32_t>(),
                        S.partials.as<Pt>(), S.hot_sums.as<Pt>());
     hipLaunchKernelGGL(msm_combine_hot2<C>, dim3(64), dim3(64), 0, s, PS.hot.as<HotBucket>(), PS.counters.as<uint32_t>(),
                        S.hot_sums.as<Pt>(), S.buckets.as<Pt>());
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
-
-    P.acc_done = true;
+    // the slot is taken only now: an error above (null points, a failed reserve) leaves it free
+    P.active = true;
+    *slot_out = slot;
     return WS_OK;
 }
 
@@ -1117,11 +1112,11 @@ template <> struct TailCurve<G1R29> { typedef G1R29I type; };
 
 // reduction tail (chunks, tree, copy of the window sums, completion event) for up to 4 launches of one plan
 template <class C>
-static int msm_launch_tail(const int* slot_ids, int nslots, hipStream_t s) {
+static int msm_launch_tail(Lane& L, const int* slot_ids, int nslots, hipStream_t s) {
     typedef typename C::PtP Pt;
     Context* X = ctx();
-    if (!s) s = X->stream;
-    MsmPending* slots = pending_slots();
+    if (!s) s = L.stream;
+    MsmPending* slots = ws(L).slot;
     const MsmPlanInfo& I = slots[slot_ids[0]].info;
     if (I.n == 0) return WS_OK;
     TailSets<C> ts;
@@ -1155,65 +1150,65 @@ static int msm_launch_tail(const int* slot_ids, int nslots, hipStream_t s) {
 }
 
 template <class C, class H>
-static int msm_launch(int which, const typename H::Aff* d_points_ref, bool prepared, int* slot_out, hipStream_t s,
+static int msm_launch(Lane& L, int which, const typename H::Aff* d_points_ref, bool prepared, int* slot_out, hipStream_t s,
                       hipEvent_t before_tail = nullptr) {
-    int rc = msm_launch_acc<C, H>(which, d_points_ref, prepared, slot_out, s);
+    if (!s) s = L.stream;
+    int rc = msm_launch_acc<C, H>(L, which, d_points_ref, prepared, slot_out, s);
     if (rc) return rc;
-    if (before_tail) WS_HIP_CHECK(hipEventRecord(before_tail, s ? s : ctx()->stream));
-    return msm_launch_tail<typename TailCurve<C>::type>(slot_out, 1, s);
+    if (before_tail) WS_HIP_CHECK(hipEventRecord(before_tail, s));
+    rc = msm_launch_tail<typename TailCurve<C>::type>(L, slot_out, 1, s);
+    if (rc) msm_abort_slots(L, slot_out, 1, s, nullptr);
+    return rc;
 }
 
 // several G1 point sets against the current plan: accumulations back to back, then ONE batched tail
-int msm_g1_launch_batch(const Affine<Fq>* const* d_points, int nsets, bool prepared, int* slots, hipStream_t s,
+int msm_g1_launch_batch(Lane& L, const Affine<Fq>* const* d_points, int nsets, bool prepared, int* slots, hipStream_t s,
                         hipEvent_t before_tail, const int* plan_ids) {
     if (!ctx()) return WS_ERR_NOINIT;
     if (nsets < 1 || nsets > 4) return WS_ERR_ARG;
-    const int keep = g_plan_cur;
-    for (int k = 0; k < nsets; k++) {
-        if (plan_ids) msm_select_plan(plan_ids[k]);
-        int rc = msm_uses_field29() ? msm_launch_acc<G1R29, G1>(0, d_points[k], prepared, &slots[k], s)
-                                    : msm_launch_acc<G1, G1>(0, d_points[k], prepared, &slots[k], s);
-        if (plan_ids) msm_select_plan(keep);
-        if (rc) return rc;
+    if (!s) s = L.stream;
+    MsmWorkspace& M = ws(L);
+    const int keep = M.cur;
+    for (int k = 0; k < nsets; k++) slots[k] = -1;
+    int rc = WS_OK;
+    for (int k = 0; k < nsets && !rc; k++) {
+        if (plan_ids) msm_select_plan(L, plan_ids[k]);
+        rc = msm_uses_field29() ? msm_launch_acc<G1R29, G1>(L, 0, d_points[k], prepared, &slots[k], s)
+                                : msm_launch_acc<G1, G1>(L, 0, d_points[k], prepared, &slots[k], s);
+        if (plan_ids) msm_select_plan(L, keep);
     }
-    if (before_tail) WS_HIP_CHECK(hipEventRecord(before_tail, s ? s : ctx()->stream));
-    return msm_uses_field29() ? msm_launch_tail<TailCurve<G1R29>::type>(slots, nsets, s) : msm_launch_tail<G1>(slots, nsets, s);
+    if (!rc && before_tail && hipEventRecord(before_tail, s) != hipSuccess) rc = WS_ERR_HIP;
+    if (!rc) rc = msm_uses_field29() ? msm_launch_tail<TailCurve<G1R29>::type>(L, slots, nsets, s) : msm_launch_tail<G1>(L, slots, nsets, s);
+    if (rc) msm_abort_slots(L, slots, nsets, s, nullptr);
+    return rc;
 }
 
-int msm_g1_launch(const Affine<Fq>* d_points, bool prepared, int* slot, hipStream_t s) {
+int msm_g1_launch(Lane& L, const Affine<Fq>* d_points, bool prepared, int* slot, hipStream_t s) {
     if (!ctx()) return WS_ERR_NOINIT;
-    if (msm_uses_field29()) return msm_launch<G1R29, G1>(0, d_points, prepared, slot, s);
-    return msm_launch<G1, G1>(0, d_points, prepared, slot, s);
+    if (msm_uses_field29()) return msm_launch<G1R29, G1>(L, 0, d_points, prepared, slot, s);
+    return msm_launch<G1, G1>(L, 0, d_points, prepared, slot, s);
 }
-int msm_g2_launch(const Affine<Fq2>* d_points, bool prepared, int* slot, hipStream_t s, hipEvent_t before_tail) {
+int msm_g2_launch(Lane& L, const Affine<Fq2>* d_points, bool prepared, int* slot, hipStream_t s, hipEvent_t before_tail) {
     if (!ctx()) return WS_ERR_NOINIT;
-    if (msm_uses_field29()) return msm_launch<G2R29, G2>(1, d_points, prepared, slot, s, before_tail);
-    return msm_launch<G2, G2>(1, d_points, prepared, slot, s, before_tail);
+    if (msm_uses_field29()) return msm_launch<G2R29, G2>(L, 1, d_points, prepared, slot, s, before_tail);
+    return msm_launch<G2, G2>(L, 1, d_points, prepared, slot, s, before_tail);
 }
-bool msm_ready(int slot) {
-    if (slot < 0 || slot >= kPendingSlots) return false;
-    MsmPending& P = pending_slots()[slot];
-    return P.active && (P.info.n == 0 || (P.ev && hipEventQuery(P.ev) == hipSuccess));
+static MsmPending* live_slot(Lane& L, int slot, int which) {
+    if (!L.msm || slot < 0 || slot >= kPendingSlots) return nullptr;
+    MsmPending& P = L.msm->slot[slot];
+    return (P.active && (which < 0 || P.which == which)) ? &P : nullptr;
 }
-int msm_g1_finish(int slot, XYZZ<Fq>* out_host) {
-    if (slot < 0 || slot >= kPendingSlots || !pending_slots()[slot].active || pending_slots()[slot].which != 0) return WS_ERR_ARG;
-    return msm_finish_t<G1>(pending_slots()[slot], out_host);
+bool msm_ready(Lane& L, int slot) {
+    MsmPending* P = live_slot(L, slot, -1);
+    return P && (P->info.n == 0 || (P->ev && hipEventQuery(P->ev) == hipSuccess));
 }
-int msm_g2_finish(int slot, XYZZ<Fq2>* out_host) {
-    if (slot < 0 || slot >= kPendingSlots || !pending_slots()[slot].active || pending_slots()[slot].which != 1) return WS_ERR_ARG;
-    return msm_finish_t<G2>(pending_slots()[slot], out_host);
+int msm_g1_finish(Lane& L, int slot, XYZZ<Fq>* out_host) {
+    MsmPending* P = live_slot(L, slot, 0);
+    return P ? msm_finish_t<G1>(*P, out_host) : WS_ERR_ARG;
 }
-int msm_g1_exec_xyzz(const Affine<Fq>* d_points, XYZZ<Fq>* out_host, hipStream_t s, bool prepared) {
-    int slot = -1;
-    int rc = msm_g1_launch(d_points, prepared, &slot, s);
-    if (rc) return rc;
-    return msm_g1_finish(slot, out_host);
-}
-int msm_g2_exec_xyzz(const Affine<Fq2>* d_points, XYZZ<Fq2>* out_host, hipStream_t s, bool prepared) {
-    int slot = -1;
-    int rc = msm_g2_launch(d_points, prepared, &slot, s);
-    if (rc) return rc;
-    return msm_g2_finish(slot, out_host);
+int msm_g2_finish(Lane& L, int slot, XYZZ<Fq2>* out_host) {
+    MsmPending* P = live_slot(L, slot, 1);
+    return P ? msm_finish_t<G2>(*P, out_host) : WS_ERR_ARG;
 }
 
 // Which pairs can be left out of a sum whatever the scalar: those whose point is infinity in EVERY given set
@@ -1264,111 +1259,94 @@ int msm_prepare_points(int which, void* d_points, uint64_t n, hipStream_t s) {
 }
 
 // The conversion of caller points to the device field's internal domain does not depend on the plan: it runs on
-// the second queue while the first one groups the digits (returns the array the accumulation should read).
-static hipEvent_t g_conv_ev[2] = {nullptr, nullptr};
-static DevBuf* g_conv_buf = nullptr;
+// the lane's second queue while the first one groups the digits (returns the array the accumulation should read).
 template <class CD, class AffT>
-static int convert_beside_plan(Context* X, const AffT* d_points, uint64_t n, hipStream_t s, const AffT** out, bool* prepared) {
+static int convert_beside_plan(Lane& L, const AffT* d_points, uint64_t n, hipStream_t s, const AffT** out, bool* prepared) {
+    Context* X = ctx();
     *out = d_points;
-    if (*prepared || !msm_uses_field29() || !CD::Field::kInternalDomain || n < (1u << 14) || s == X->stream2) return WS_OK;
-    for (auto& e : g_conv_ev) if (!e) WS_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    if (!g_conv_buf) g_conv_buf = new DevBuf();
-    WS_HIP_CHECK(g_conv_buf->reserve((size_t)n * sizeof(typename CD::AffP)));
-    WS_HIP_CHECK(hipEventRecord(g_conv_ev[0], s));                 // the caller's points are ready on s
-    WS_HIP_CHECK(hipStreamWaitEvent(X->stream2, g_conv_ev[0], 0));
-    X->timer.begin("msm_convert_points", X->stream2);
-    hipLaunchKernelGGL(msm_convert_points<CD>, dim3(ceil_div_u64(n, 256)), dim3(256), 0, X->stream2,
-                       reinterpret_cast<const typename CD::AffP*>(d_points), g_conv_buf->as<typename CD::AffP>(), n);
-    X->timer.end(X->stream2);
-    WS_HIP_CHECK(hipEventRecord(g_conv_ev[1], X->stream2));
-    *out = g_conv_buf->as<AffT>();
+    if (*prepared || !msm_uses_field29() || !CD::Field::kInternalDomain || n < (1u << 14) || s == L.stream2) return WS_OK;
+    MsmWorkspace& M = ws(L);
+    for (auto& e : M.conv_ev) if (!e) WS_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    WS_HIP_CHECK(M.conv_buf.reserve((size_t)n * sizeof(typename CD::AffP)));
+    WS_HIP_CHECK(hipEventRecord(M.conv_ev[0], s));                 // the caller's points are ready on s
+    WS_HIP_CHECK(hipStreamWaitEvent(L.stream2, M.conv_ev[0], 0));
+    X->timer.begin("msm_convert_points", L.stream2);
+    hipLaunchKernelGGL(msm_convert_points<CD>, dim3(ceil_div_u64(n, 256)), dim3(256), 0, L.stream2,
+                       reinterpret_cast<const typename CD::AffP*>(d_points), M.conv_buf.as<typename CD::AffP>(), n);
+    X->timer.end(L.stream2);
+    WS_HIP_CHECK(hipEventRecord(M.conv_ev[1], L.stream2));
+    *out = M.conv_buf.as<AffT>();
     *prepared = true;
     return WS_OK;
 }
 
-void msm_release_conv() {
-    for (auto& e : g_conv_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-    if (g_conv_buf) { delete g_conv_buf; g_conv_buf = nullptr; }
-}
-
-int msm_g1_dev_xyzz(const Fe* d_scalars, const Affine<Fq>* d_points, uint64_t n, XYZZ<Fq>* out_host, hipStream_t s,
-                    bool prepared) {
-    Context* X = ctx();
-    if (!X) return WS_ERR_NOINIT;
+// one whole MSM from device pointers on lane L: conversion beside the plan, launch, host tail
+template <class CD, class H>
+static int msm_dev_t(Lane& L, int which, const Fe* d_scalars, const typename H::Aff* d_points, uint64_t n, WindowShard sh,
+                     typename H::Pt* out_host, hipStream_t s) {
+    if (!ctx()) return WS_ERR_NOINIT;
     if (n && !d_points) return WS_ERR_ARG;
-    if (!s) s = X->stream;
-    std::lock_guard<std::mutex> lk(X->mu);   // plan + scratch are shared: one MSM at a time
-    const Affine<Fq>* pts = d_points;
-    const bool was_prepared = prepared;
-    int rc = convert_beside_plan<G1R29>(X, d_points, n, s, &pts, &prepared);
+    if (!s) s = L.stream;
+    const typename H::Aff* pts = d_points;
+    bool prepared = false;
+    msm_select_plan(L, 0);
+    int rc = convert_beside_plan<CD>(L, d_points, n, s, &pts, &prepared);
     if (rc) return rc;
-    if ((rc = msm_plan_dev(d_scalars, n, s))) return rc;
-    if (prepared && !was_prepared) WS_HIP_CHECK(hipStreamWaitEvent(s, g_conv_ev[1], 0));
-    return msm_g1_exec_xyzz(pts, out_host, s, prepared);
-}
-int msm_g2_dev_xyzz(const Fe* d_scalars, const Affine<Fq2>* d_points, uint64_t n, XYZZ<Fq2>* out_host, hipStream_t s,
-                    bool prepared) {
-    Context* X = ctx();
-    if (!X) return WS_ERR_NOINIT;
-    if (n && !d_points) return WS_ERR_ARG;
-    if (!s) s = X->stream;
-    std::lock_guard<std::mutex> lk(X->mu);
-    const Affine<Fq2>* pts = d_points;
-    const bool was_prepared = prepared;
-    int rc = convert_beside_plan<G2R29>(X, d_points, n, s, &pts, &prepared);
-    if (rc) return rc;
-    if ((rc = msm_plan_dev(d_scalars, n, s))) return rc;
-    if (prepared && !was_prepared) WS_HIP_CHECK(hipStreamWaitEvent(s, g_conv_ev[1], 0));
-    return msm_g2_exec_xyzz(pts, out_host, s, prepared);
-}
-// Host-pointer boundary (what the reference's g1_multiexp / g2_multiexp callers hold: plain host buffers).
-// Scalars go up first; the plan is built on the GPU while worker threads stage the points on the second queue.
-template <class H, class JacT>
-static int msm_host_t(int which, const void* h_scalars, const void* h_points, uint64_t n, JacT* out_host) {
-    Context* X = ctx();
-    if (!X) return WS_ERR_NOINIT;
-    if (n == 0) { *out_host = H::to_affine_jac(H::infinity()); return WS_OK; }
-    if (!h_scalars || !h_points) return WS_ERR_ARG;
-    hipStream_t s = X->stream, s2 = X->stream2;
-    std::lock_guard<std::mutex> lk(X->mu);
-    WS_HIP_CHECK(X->host_in[0].reserve((size_t)n * 32));
-    WS_HIP_CHECK(X->host_in[1].reserve((size_t)n * sizeof(typename H::Aff)));
-    if (!g_host_ev) WS_HIP_CHECK(hipEventCreateWithFlags(&g_host_ev, hipEventDisableTiming));
-    int rc = upload_staged(X->host_in[0].p, h_scalars, (size_t)n * 32, s);
-    if (rc) return rc;
-    if ((rc = msm_plan_dev(X->host_in[0].as<Fe>(), n, s))) return rc;
-    if ((rc = upload_staged(X->host_in[1].p, h_points, (size_t)n * sizeof(typename H::Aff), s2))) return rc;
-    WS_HIP_CHECK(hipEventRecord(g_host_ev, s2));
-    WS_HIP_CHECK(hipStreamWaitEvent(s, g_host_ev, 0));
-    typename H::Pt r;
+    if ((rc = msm_plan_dev(L, d_scalars, n, sh, s))) return rc;
+    if (prepared) WS_HIP_CHECK(hipStreamWaitEvent(s, ws(L).conv_ev[1], 0));
     int slot = -1;
-    rc = which == 0 ? msm_g1_launch(reinterpret_cast<const Affine<Fq>*>(X->host_in[1].p), false, &slot, s)
-                    : msm_g2_launch(reinterpret_cast<const Affine<Fq2>*>(X->host_in[1].p), false, &slot, s);
+    rc = which == 0 ? msm_g1_launch(L, reinterpret_cast<const Affine<Fq>*>(pts), prepared, &slot, s)
+                    : msm_g2_launch(L, reinterpret_cast<const Affine<Fq2>*>(pts), prepared, &slot, s);
     if (rc) return rc;
-    if ((rc = msm_finish_t<H>(pending_slots()[slot], &r))) return rc;
-    *out_host = H::to_affine_jac(r);
-    return WS_OK;
+    return msm_finish_t<H>(ws(L).slot[slot], out_host);
 }
-int msm_g1_host(const void* h_scalars, const void* h_points, uint64_t n, Jac<Fq>* out_host) {
-    return msm_host_t<G1, Jac<Fq>>(0, h_scalars, h_points, n, out_host);
-}
-int msm_g2_host(const void* h_scalars, const void* h_points, uint64_t n, Jac<Fq2>* out_host) {
-    return msm_host_t<G2, Jac<Fq2>>(1, h_scalars, h_points, n, out_host);
-}
-
-int msm_g1_dev(const Fe* d_scalars, const Affine<Fq>* d_points, uint64_t n, Jac<Fq>* out_host, hipStream_t s) {
+int msm_g1_dev(Lane& L, const Fe* d_scalars, const Affine<Fq>* d_points, uint64_t n, WindowShard sh, Jac<Fq>* out_host, hipStream_t s) {
     XYZZ<Fq> r;
-    int rc = msm_g1_dev_xyzz(d_scalars, d_points, n, &r, s);
+    int rc = msm_dev_t<G1R29, G1>(L, 0, d_scalars, d_points, n, sh, &r, s);
     if (rc) return rc;
     *out_host = G1::to_affine_jac(r);
     return WS_OK;
 }
-int msm_g2_dev(const Fe* d_scalars, const Affine<Fq2>* d_points, uint64_t n, Jac<Fq2>* out_host, hipStream_t s) {
+int msm_g2_dev(Lane& L, const Fe* d_scalars, const Affine<Fq2>* d_points, uint64_t n, WindowShard sh, Jac<Fq2>* out_host, hipStream_t s) {
     XYZZ<Fq2> r;
-    int rc = msm_g2_dev_xyzz(d_scalars, d_points, n, &r, s);
+    int rc = msm_dev_t<G2R29, G2>(L, 1, d_scalars, d_points, n, sh, &r, s);
     if (rc) return rc;
     *out_host = G2::to_affine_jac(r);
     return WS_OK;
+}
+// Host-pointer boundary (what the reference's g1_multiexp / g2_multiexp callers hold: plain host buffers).
+// Scalars go up first; the plan is built on the GPU while worker threads stage the points on the second queue.
+template <class H, class JacT>
+static int msm_host_t(Lane& L, int which, const void* h_scalars, const void* h_points, uint64_t n, WindowShard sh, JacT* out_host) {
+    if (!ctx()) return WS_ERR_NOINIT;
+    if (n == 0) { *out_host = H::to_affine_jac(H::infinity()); return WS_OK; }
+    if (!h_scalars || !h_points) return WS_ERR_ARG;
+    hipStream_t s = L.stream, s2 = L.stream2;
+    MsmWorkspace& M = ws(L);
+    WS_HIP_CHECK(L.host_in[0].reserve((size_t)n * 32));
+    WS_HIP_CHECK(L.host_in[1].reserve((size_t)n * sizeof(typename H::Aff)));
+    if (!M.host_ev) WS_HIP_CHECK(hipEventCreateWithFlags(&M.host_ev, hipEventDisableTiming));
+    int rc = upload_staged(L.host_in[0].p, h_scalars, (size_t)n * 32, s);
+    if (rc) return rc;
+    msm_select_plan(L, 0);
+    if ((rc = msm_plan_dev(L, L.host_in[0].as<Fe>(), n, sh, s))) return rc;
+    if ((rc = upload_staged(L.host_in[1].p, h_points, (size_t)n * sizeof(typename H::Aff), s2))) return rc;
+    WS_HIP_CHECK(hipEventRecord(M.host_ev, s2));
+    WS_HIP_CHECK(hipStreamWaitEvent(s, M.host_ev, 0));
+    typename H::Pt r;
+    int slot = -1;
+    rc = which == 0 ? msm_g1_launch(L, reinterpret_cast<const Affine<Fq>*>(L.host_in[1].p), false, &slot, s)
+                    : msm_g2_launch(L, reinterpret_cast<const Affine<Fq2>*>(L.host_in[1].p), false, &slot, s);
+    if (rc) return rc;
+    if ((rc = msm_finish_t<H>(M.slot[slot], &r))) return rc;
+    *out_host = H::to_affine_jac(r);
+    return WS_OK;
+}
+int msm_g1_host(Lane& L, const void* h_scalars, const void* h_points, uint64_t n, WindowShard sh, Jac<Fq>* out_host) {
+    return msm_host_t<G1, Jac<Fq>>(L, 0, h_scalars, h_points, n, sh, out_host);
+}
+int msm_g2_host(Lane& L, const void* h_scalars, const void* h_points, uint64_t n, WindowShard sh, Jac<Fq2>* out_host) {
+    return msm_host_t<G2, Jac<Fq2>>(L, 1, h_scalars, h_points, n, sh, out_host);
 }
 
 }  // namespace wsnark

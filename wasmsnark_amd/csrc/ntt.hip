@@ -348,11 +348,11 @@ int ntt_coset_tables(int bits, const Fe** lo, const Fe** hi, int* hc, Fe* n_inv,
     return WS_OK;
 }
 
-int ntt_dev(Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s) {
+int ntt_dev(Lane& L, Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
     if (!d_data) return WS_ERR_ARG;
-    if (!s) s = C->stream;
+    if (!s) s = L.stream;
     // src/build_fft.js:92-157: n must be a power of two <= 2^28 (the reference traps otherwise)
     if (n == 0 || (n & (n - 1)) || n > ((uint64_t)1 << 28)) return WS_ERR_SIZE;
     int bits = 0;
@@ -363,15 +363,14 @@ int ntt_dev(Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s) {
         // (src/build_fft.js:575-583) -> reported as a size error here
         return inverse ? WS_ERR_SIZE : WS_OK;
     }
-    ScratchGuard scratch_turn(C->ntt_chain, s);   // the ping-pong buffer is shared by every transform of the context
+    ScratchGuard scratch_turn(L.ntt_chain, s);   // the ping-pong buffer is shared by every transform on this lane
     std::shared_ptr<NttPlan> P;
     {
         int rc = get_plan(C, bits, P, s);
         if (rc) return rc;
-        std::lock_guard<std::mutex> lk(C->mu);
-        if (P->np > 1) WS_HIP_CHECK(C->ntt_scratch.reserve(n * sizeof(Fe)));
+        if (P->np > 1) WS_HIP_CHECK(L.ntt_scratch.reserve(n * sizeof(Fe)));
     }
-    Fe* scratch = C->ntt_scratch.as<Fe>();
+    Fe* scratch = L.ntt_scratch.as<Fe>();
     // inverse (reference semantics): raw forward transform, then y[i] = raw[(n-i) mod n]/n
     //   == DFT with the inverse root, scaled by 1/n; an `odd` input keeps the FORWARD coset
     //   factors w_2n^i because rawfft(odd) multiplies x[i] by w_2n^i before the index flip.

@@ -23,17 +23,11 @@ struct ProvingKey {
     Affine<Fq2> beta2, delta2;
     CsrMatrix polsA, polsB;
     DevBuf pointsA, pointsB1, pointsB2, pointsC, pointsH;
-    DevBuf witness, h;          // per-proof device buffers (grow-only)
     DevBuf maskA, maskB;        // 1 byte per signal: 0 where A (resp. B1 and B2) is infinity: the variable is not in that matrix
     uint32_t infA = 0, infB = 0;   // how many of those there are
     bool sparseA = false, sparseB = false;   // enough of them to give those sums a plan variant that leaves them out
-    std::mutex mu;              // one proof at a time per handle
-    hipEvent_t ev_start = nullptr, ev_tail = nullptr, ev_h = nullptr;   // cross-queue ordering of one proof
-    ~ProvingKey() {
-        if (ev_start) (void)hipEventDestroy(ev_start);
-        if (ev_tail) (void)hipEventDestroy(ev_tail);
-        if (ev_h) (void)hipEventDestroy(ev_h);
-    }
+    // Read-only after load: any number of proofs may use one handle at once (each on its own lane, which holds the
+    // per-proof buffers and events).
 };
 
 static bool range_ok(uint64_t off, uint64_t bytes, size_t len) { return off <= len && bytes <= len - off; }
@@ -44,15 +38,21 @@ struct KeySections {      // everything wsnark_pkey_load reads from proving_key.
     const uint8_t* polsA; uint64_t lenA;
     const uint8_t* polsB; uint64_t lenB;
     const uint8_t *A, *B1, *B2, *Cpts, *H;     // nVars, nVars, nVars, nVars-nPublic-1, domain points
+    uint64_t lenPA, lenPB1, lenPB2, lenPC, lenPH;   // bytes the caller vouches for behind each of those
 };
 
 int pkey_load_sections(const KeySections& S, ProvingKey** out) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
     const uint32_t nv = S.n_vars, np = S.n_public, dom = S.domain;
-    if (nv == 0 || np + 1 > nv) { set_last_error("proving key: nPublic + 1 > nVars"); return WS_ERR_FORMAT; }
+    if (nv == 0 || (uint64_t)np + 1 > nv) { set_last_error("proving key: nPublic + 1 > nVars"); return WS_ERR_FORMAT; }
     if (dom < 2 || (dom & (dom - 1)) || dom > (1u << 27)) { set_last_error("proving key: domainSize must be a power of two in [2, 2^27]"); return WS_ERR_SIZE; }
     const uint64_t nC = (uint64_t)nv - np - 1;
+    if (S.lenPA < (uint64_t)nv * 64 || S.lenPB1 < (uint64_t)nv * 64 || S.lenPB2 < (uint64_t)nv * 128 || S.lenPC < nC * 64 ||
+        S.lenPH < (uint64_t)dom * 64) {
+        set_last_error("proving key: a point section is shorter than its header-implied size");
+        return WS_ERR_FORMAT;
+    }
     std::unique_ptr<ProvingKey> K(new ProvingKey());
     K->n_vars = nv; K->n_public = np; K->domain = dom;
     memcpy(&K->alfa1, S.alfa1, 64);
@@ -104,8 +104,6 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out) {
     if ((rc = msm_prepare_points(1, K->pointsB2.p, nv, s))) return rc;
     if ((rc = msm_prepare_points(0, K->pointsC.p, nv, s))) return rc;
     if ((rc = msm_prepare_points(0, K->pointsH.p, dom, s))) return rc;
-    WS_HIP_CHECK(K->witness.alloc((size_t)nv * 32));
-    WS_HIP_CHECK(K->h.alloc((size_t)dom * 32));
     WS_HIP_CHECK(hipStreamSynchronize(s));
     *out = K.release();
     return WS_OK;
@@ -120,7 +118,7 @@ int pkey_load(const uint8_t* buf, size_t len, ProvingKey** out) {
     memcpy(h, buf, 40);
     const uint32_t nv = h[0], np = h[1], dom = h[2];
     const uint64_t pPolsA = h[3], pPolsB = h[4], pA = h[5], pB1 = h[6], pB2 = h[7], pC = h[8], pH = h[9];
-    if (nv == 0 || np + 1 > nv) { set_last_error("proving key: nPublic + 1 > nVars"); return WS_ERR_FORMAT; }
+    if (nv == 0 || (uint64_t)np + 1 > nv) { set_last_error("proving key: nPublic + 1 > nVars"); return WS_ERR_FORMAT; }
     const uint64_t nC = (uint64_t)nv - np - 1;
     if (!(pPolsA >= 488 && pPolsA <= pPolsB && pPolsB <= pA) || !range_ok(pA, (uint64_t)nv * 64, len) ||
         !range_ok(pB1, (uint64_t)nv * 64, len) || !range_ok(pB2, (uint64_t)nv * 128, len) ||
@@ -131,7 +129,8 @@ int pkey_load(const uint8_t* buf, size_t len, ProvingKey** out) {
     // true section bounds from the header (the reference slices over-long: src/bn128.js:592-593)
     KeySections S{nv, np, dom, buf + 40, buf + 104, buf + 168, buf + 232, buf + 360,
                   buf + pPolsA, pPolsB - pPolsA, buf + pPolsB, pA - pPolsB,
-                  buf + pA, buf + pB1, buf + pB2, buf + pC, buf + pH};
+                  buf + pA, buf + pB1, buf + pB2, buf + pC, buf + pH,
+                  len - pA, len - pB1, len - pB2, len - pC, len - pH};
     return pkey_load_sections(S, out);
 }
 
@@ -191,82 +190,84 @@ struct MsmSums {
     XYZZ<Fq2> B2;
 };
 
-// CALC_H and the five MSMs (src/bn128.js:607-620).  With window sharding active
-// (wsnark_set_window_shard) the sums are this rank's partial sums.
+// CALC_H and the five MSMs (src/bn128.js:607-620) on lane L.  With a window shard other than {0, 1} the sums are
+// this rank's partial sums.
 //
-// Two in-order queues.  Stream s: the witness plan (+ its variants), A, B1, C (one batched tail), B2.  Stream 2
-// (highest priority): CALC_H, the H plan and the H sum.  The reduction tails are chains of ~30 dependent point
-// additions on a few hundred wavefronts; the other queue's full-width kernels take the SIMDs they leave idle.
+// Two in-order queues.  Stream s: the witness plan (+ its variants), A, B1, C (one batched tail), B2.  The lane's
+// second queue (highest priority): CALC_H, the H plan and the H sum.  The reduction tails are chains of ~30 dependent
+// point additions on a few hundred wavefronts; the other queue's full-width kernels take the SIMDs they leave idle.
 // Measured on MI355X, prove 2^20: one queue (WSNARK_PROVE_OVERLAP=0) 14.5 ms -> two queues 13.2 ms (session 16);
 // with the sums on plan variants the second queue is the longer one and is released at once (=2, default:
 // 10.3 ms) rather than when the first tail starts (=1: 10.5 ms).  Stricter gating does not help: a tail that
 // shares its SIMDs with a full-width kernel just runs 2-3x slower (profiles/r01_sweep_prove_overlap.txt).
 // The host finishes each sum while the GPU works on the next ones; `after_ab1` (optional) runs on the host as soon
 // as A and B1 are known.
-static int prove_msms(ProvingKey* K, const Fe* d_witness, MsmSums* out, hipStream_t s,
+static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard sh, MsmSums* out, hipStream_t s,
                       const std::function<void(const MsmSums&)>& after_ab1 = nullptr) {
-    Context* C = ctx();
     Trace tr;
     const uint32_t nv = K->n_vars, dom = K->domain;
     int rc;
     static const int overlap = [] { const char* e = getenv("WSNARK_PROVE_OVERLAP"); return e ? atoi(e) : 2; }();
-    hipStream_t s2 = overlap ? C->stream2 : s;
-    if (s2 == s) s2 = s;   // (caller passed the second queue itself: degenerate, stays in order)
-    std::unique_lock<std::mutex> lk(C->mu);   // the digit/sort plans and the MSM scratch are per context
-    int hH = -1, hA = -1, hB1 = -1, hB2 = -1, hC = -1;
-    struct Abort { hipStream_t a, b; bool armed; ~Abort() { if (armed) { msm_select_plan(0); msm_abort_pending(a); if (b != a) msm_abort_pending(b); } } } guard{s, s2, true};
-    if (!K->ev_start) { WS_HIP_CHECK(hipEventCreateWithFlags(&K->ev_start, hipEventDisableTiming)); WS_HIP_CHECK(hipEventCreateWithFlags(&K->ev_tail, hipEventDisableTiming)); WS_HIP_CHECK(hipEventCreateWithFlags(&K->ev_h, hipEventDisableTiming)); }
-    WS_HIP_CHECK(hipEventRecord(K->ev_start, s));          // the witness is ready on s
+    hipStream_t s2 = overlap ? L.stream2 : s;
+    // launch slots: A, B1, C, B2, H.  On an error path the launches of THIS proof are forgotten (other lanes' are not touched)
+    int slots[5] = {-1, -1, -1, -1, -1};
+    int &hA = slots[0], &hB1 = slots[1], &hC = slots[2], &hB2 = slots[3], &hH = slots[4];
+    struct Abort {
+        Lane& L; int* slots; hipStream_t a, b; bool armed;
+        ~Abort() { if (armed) { msm_select_plan(L, 0); msm_abort_slots(L, slots, 5, a, b); } }
+    } guard{L, slots, s, s2, true};
+    for (hipEvent_t* e : {&L.ev_start, &L.ev_tail, &L.ev_h})
+        if (!*e) WS_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    WS_HIP_CHECK(hipEventRecord(L.ev_start, s));          // the witness is ready on s
     // the four sums whose scalars are the witness (:617-620)
-    msm_select_plan(0);
-    if ((rc = msm_plan_dev(d_witness, nv, s))) return rc;
+    msm_select_plan(L, 0);
+    if ((rc = msm_plan_dev(L, d_witness, nv, sh, s))) return rc;
     // one grouping pass for all four; A and B1/B2 may run on variants of the plan that leave out the variables
     // absent from their matrix (plan 0 = full, 2 = without B's absentees, 3 = without A's).  A, B1 and C: three
     // accumulations back to back, then ONE batched reduction tail
     int planA = 0, planB = 0;
-    if (K->sparseB && msm_plan_variant(0, 2, K->maskB.as<uint8_t>(), s) == WS_OK) planB = 2;   // (hipCUB pipeline: no variants,
-    if (K->sparseA && msm_plan_variant(0, 3, K->maskA.as<uint8_t>(), s) == WS_OK) planA = 3;   //  everything on the full plan)
+    if (K->sparseB && msm_plan_variant(L, 0, 2, K->maskB.as<uint8_t>(), s) == WS_OK) planB = 2;   // (hipCUB pipeline: no variants,
+    if (K->sparseA && msm_plan_variant(L, 0, 3, K->maskA.as<uint8_t>(), s) == WS_OK) planA = 3;   //  everything on the full plan)
     {
         const Affine<Fq>* g1sets[3] = {K->pointsA.as<Affine<Fq>>(), K->pointsB1.as<Affine<Fq>>(), K->pointsC.as<Affine<Fq>>()};
         const int plans[3] = {planA, planB, 0};
         int g1slots[3] = {-1, -1, -1};
-        if ((rc = msm_g1_launch_batch(g1sets, 3, true, g1slots, s, K->ev_tail, plans))) return rc;       // :617, :618, :620 (padded)
+        rc = msm_g1_launch_batch(L, g1sets, 3, true, g1slots, s, L.ev_tail, plans);       // :617, :618, :620 (padded)
         hA = g1slots[0]; hB1 = g1slots[1]; hC = g1slots[2];
+        if (rc) return rc;
         tr.mark("plan(w) [+ variants] + launch A,B1,C");
     }
-    msm_select_plan(planB);
-    rc = msm_g2_launch(K->pointsB2.as<Affine<Fq2>>(), true, &hB2, s);                                  // :619
-    msm_select_plan(0);
+    msm_select_plan(L, planB);
+    rc = msm_g2_launch(L, K->pointsB2.as<Affine<Fq2>>(), true, &hB2, s);                                  // :619
+    msm_select_plan(L, 0);
     if (rc) return rc;
     tr.mark("launch B2");
     // CALC_H, then the H MSM over domainSize pairs (src/bn128.js:607-615)
-    if (s2 != s) WS_HIP_CHECK(hipStreamWaitEvent(s2, overlap == 2 ? K->ev_start : K->ev_tail, 0));
-    Fe* d_h = K->h.as<Fe>();
-    lk.unlock();                              // (the NTT plan cache takes the same mutex; everything launched so far
-    rc = calc_h_dev(d_witness, nv, K->polsA, K->polsB, dom, d_h, s2);  //  is ordered on its stream)
-    lk.lock();
-    if (rc) return rc;
+    if (s2 != s) WS_HIP_CHECK(hipStreamWaitEvent(s2, overlap == 2 ? L.ev_start : L.ev_tail, 0));
+    WS_HIP_CHECK(L.h.reserve((size_t)dom * 32));
+    Fe* d_h = L.h.as<Fe>();
+    if ((rc = calc_h_dev(L, d_witness, nv, K->polsA, K->polsB, dom, d_h, s2))) return rc;
     tr.mark("calc_h enqueued");
-    msm_select_plan(s2 != s ? 1 : 0);
-    rc = msm_plan_dev(d_h, dom, s2);
-    if (!rc) rc = msm_g1_launch(K->pointsH.as<Affine<Fq>>(), true, &hH, s2);                           // :614
-    msm_select_plan(0);
+    msm_select_plan(L, s2 != s ? 1 : 0);
+    rc = msm_plan_dev(L, d_h, dom, sh, s2);
+    if (!rc) rc = msm_g1_launch(L, K->pointsH.as<Affine<Fq>>(), true, &hH, s2);                           // :614
+    msm_select_plan(L, 0);
     if (rc) return rc;
-    if (s2 != s) { WS_HIP_CHECK(hipEventRecord(K->ev_h, s2)); WS_HIP_CHECK(hipStreamWaitEvent(s, K->ev_h, 0)); }   // s stays the caller's ordering point
+    if (s2 != s) { WS_HIP_CHECK(hipEventRecord(L.ev_h, s2)); WS_HIP_CHECK(hipStreamWaitEvent(s, L.ev_h, 0)); }   // s stays the caller's ordering point
     tr.mark("plan(h) + launch H");
-    if ((rc = msm_g1_finish(hA, &out->A))) return rc;
-    if ((rc = msm_g1_finish(hB1, &out->B1))) return rc;
+    if ((rc = msm_g1_finish(L, hA, &out->A))) return rc;
+    if ((rc = msm_g1_finish(L, hB1, &out->B1))) return rc;
     tr.mark("finish A, B1");
     if (after_ab1) after_ab1(*out);
-    if ((rc = msm_g1_finish(hC, &out->C))) return rc;
+    if ((rc = msm_g1_finish(L, hC, &out->C))) return rc;
     tr.mark("host work on A, B1; finish C");
     // the two queues end independently: take whichever sum is ready first
-    if (msm_ready(hB2)) {
-        if ((rc = msm_g2_finish(hB2, &out->B2))) return rc;
-        if ((rc = msm_g1_finish(hH, &out->H))) return rc;
+    if (msm_ready(L, hB2)) {
+        if ((rc = msm_g2_finish(L, hB2, &out->B2))) return rc;
+        if ((rc = msm_g1_finish(L, hH, &out->H))) return rc;
     } else {
-        if ((rc = msm_g1_finish(hH, &out->H))) return rc;
-        if ((rc = msm_g2_finish(hB2, &out->B2))) return rc;
+        if ((rc = msm_g1_finish(L, hH, &out->H))) return rc;
+        if ((rc = msm_g2_finish(L, hB2, &out->B2))) return rc;
     }
     tr.mark("finish H, B2");
     guard.armed = false;
@@ -285,6 +286,16 @@ struct Blinding {
 // r, s are raw 256-bit values (not reduced, src/bn128.js:642-661); every point here has prime order r, so
 // k*P == (k mod r)*P and (r*s)*P == ((r mod r)(s mod r) mod r)*P (:700-702).  The scalar multiplications
 // that involve key points only start on a host thread at once (they overlap the GPU work).
+static thread_local uint8_t t_last_rs[64];
+static thread_local bool t_have_rs = false;
+// the raw 32-byte r | s of the last proof assembled by the calling thread: the reference keeps them for its tests
+// in the same way (`this._pr`, `this._ps`, src/bn128.js:662-664)
+bool last_blinding(uint8_t* r32, uint8_t* s32) {
+    if (!t_have_rs) return false;
+    if (r32) memcpy(r32, t_last_rs, 32);
+    if (s32) memcpy(s32, t_last_rs + 32, 32);
+    return true;
+}
 static int start_blinding(ProvingKey* K, const uint8_t* r32, const uint8_t* s32, Blinding* B) {
     uint8_t rnd[64];
     if (!r32 || !s32) {
@@ -292,6 +303,9 @@ static int start_blinding(ProvingKey* K, const uint8_t* r32, const uint8_t* s32,
         if (!r32) r32 = rnd;
         if (!s32) s32 = rnd + 32;
     }
+    memcpy(t_last_rs, r32, 32);
+    memcpy(t_last_rs + 32, s32, 32);
+    t_have_rs = true;
     memcpy(&B->rr, r32, 32);
     memcpy(&B->ss, s32, 32);
     B->rr = Fr::reduce_full(B->rr);
@@ -345,35 +359,37 @@ static void prove_assemble(ProvingKey* K, const MsmSums& M, Blinding& B, Blindin
     store_plain(out384 + 288, c.x); store_plain(out384 + 320, c.y); store_plain(out384 + 352, c.z);
 }
 
-// witness on the device
-int groth16_prove(ProvingKey* K, const Fe* d_witness, const uint8_t* r32, const uint8_t* s32, uint8_t* out384,
-                  hipStream_t s) {
-    Context* C = ctx();
-    if (!C) return WS_ERR_NOINIT;
-    if (!s) s = C->stream;
+// witness on the device, lane L held by the caller
+static int groth16_prove(ProvingKey* K, Lane& L, const Fe* d_witness, const uint8_t* r32, const uint8_t* s32, uint8_t* out384,
+                         hipStream_t s) {
+    if (!s) s = L.stream;
     Blinding B;
     int rc = start_blinding(K, r32, s32, &B);
     if (rc) return rc;
     MsmSums M;
     Blinding::Pre pp;
     EarlyParts E;
-    if ((rc = prove_msms(K, d_witness, &M, s, [&](const MsmSums& m) { prove_assemble_early(K, m, B, pp, &E); }))) return rc;
+    if ((rc = prove_msms(K, L, d_witness, WindowShard{}, &M, s, [&](const MsmSums& m) { prove_assemble_early(K, m, B, pp, &E); }))) return rc;
     Trace tr;
     prove_assemble(K, M, B, pp, E, out384);
     tr.mark("assemble (host)");
     return WS_OK;
 }
 
+static int check_witness_len(ProvingKey* K, size_t witness_len) {
+    if ((uint64_t)witness_len < (uint64_t)K->n_vars * 32) { set_last_error("witness shorter than nVars*32 bytes"); return WS_ERR_SIZE; }
+    return WS_OK;
+}
+static int upload_witness(ProvingKey* K, Lane& L, const uint8_t* witness) {
+    WS_HIP_CHECK(L.witness.reserve((size_t)K->n_vars * 32));
+    return upload_staged(L.witness.p, witness, (size_t)K->n_vars * 32, L.stream);
+}
+
 // ---- multi-GPU proving: per-rank partial sums, then one 576-byte record per rank to combine ----
 // record = A | B1 | C | H (4 x 96 B G1) | B2 (192 B G2), Jacobian-Montgomery, affine-normalised
-int groth16_prove_partial(ProvingKey* K, const uint8_t* witness, size_t witness_len, uint8_t* out576) {
-    Context* C = ctx();
-    if (!C) return WS_ERR_NOINIT;
-    if ((uint64_t)witness_len < (uint64_t)K->n_vars * 32) { set_last_error("witness shorter than nVars*32 bytes"); return WS_ERR_SIZE; }
-    std::lock_guard<std::mutex> lk(K->mu);
-    { int urc = upload_staged(K->witness.p, witness, (size_t)K->n_vars * 32, C->stream); if (urc) return urc; }
+static int prove_partial_on(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard sh, uint8_t* out576, hipStream_t s) {
     MsmSums M;
-    int rc = prove_msms(K, K->witness.as<Fe>(), &M, C->stream);
+    int rc = prove_msms(K, L, d_witness, sh, &M, s ? s : L.stream);
     if (rc) return rc;
     Jac<Fq> j;
     j = G1::to_affine_jac(M.A); memcpy(out576, &j, 96);
@@ -382,6 +398,23 @@ int groth16_prove_partial(ProvingKey* K, const uint8_t* witness, size_t witness_
     j = G1::to_affine_jac(M.H); memcpy(out576 + 288, &j, 96);
     Jac<Fq2> j2 = G2::to_affine_jac(M.B2); memcpy(out576 + 384, &j2, 192);
     return WS_OK;
+}
+int groth16_prove_partial(ProvingKey* K, const uint8_t* witness, size_t witness_len, WindowShard sh, uint8_t* out576) {
+    Context* C = ctx();
+    if (!C) return WS_ERR_NOINIT;
+    int rc = check_witness_len(K, witness_len);
+    if (rc) return rc;
+    LaneLock L = acquire_lane(C);
+    if ((rc = upload_witness(K, *L, witness))) return rc;
+    return prove_partial_on(K, *L, L->witness.as<Fe>(), sh, out576, L->stream);
+}
+int groth16_prove_partial_dev(ProvingKey* K, const Fe* d_witness, size_t witness_len, WindowShard sh, uint8_t* out576, hipStream_t s) {
+    Context* C = ctx();
+    if (!C) return WS_ERR_NOINIT;
+    int rc = check_witness_len(K, witness_len);
+    if (rc) return rc;
+    LaneLock L = acquire_lane(C);
+    return prove_partial_on(K, *L, d_witness, sh, out576, s);
 }
 int groth16_prove_finish(ProvingKey* K, const uint8_t* partials, uint64_t n_ranks, const uint8_t* r32,
                          const uint8_t* s32, uint8_t* out384) {
@@ -411,17 +444,21 @@ int groth16_prove_host_witness(ProvingKey* K, const uint8_t* witness, size_t wit
                                const uint8_t* s32, uint8_t* out384) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
-    if ((uint64_t)witness_len < (uint64_t)K->n_vars * 32) { set_last_error("witness shorter than nVars*32 bytes"); return WS_ERR_SIZE; }
-    std::lock_guard<std::mutex> lk(K->mu);
-    { int urc = upload_staged(K->witness.p, witness, (size_t)K->n_vars * 32, C->stream); if (urc) return urc; }
-    return groth16_prove(K, K->witness.as<Fe>(), r32, s32, out384, C->stream);
+    int rc = check_witness_len(K, witness_len);
+    if (rc) return rc;
+    LaneLock L = acquire_lane(C);
+    if ((rc = upload_witness(K, *L, witness))) return rc;
+    return groth16_prove(K, *L, L->witness.as<Fe>(), r32, s32, out384, L->stream);
 }
 
 int groth16_prove_dev_witness(ProvingKey* K, const Fe* d_witness, size_t witness_len, const uint8_t* r32,
                               const uint8_t* s32, uint8_t* out384, hipStream_t s) {
-    if ((uint64_t)witness_len < (uint64_t)K->n_vars * 32) { set_last_error("witness shorter than nVars*32 bytes"); return WS_ERR_SIZE; }
-    std::lock_guard<std::mutex> lk(K->mu);
-    return groth16_prove(K, d_witness, r32, s32, out384, s);
+    Context* C = ctx();
+    if (!C) return WS_ERR_NOINIT;
+    int rc = check_witness_len(K, witness_len);
+    if (rc) return rc;
+    LaneLock L = acquire_lane(C);
+    return groth16_prove(K, *L, d_witness, r32, s32, out384, s);
 }
 
 }  // namespace wsnark

@@ -8,10 +8,11 @@ all_gather of 96 (G1) or 192 (G2) bytes per rank.  RCCL has no elliptic-curve re
 so the 'all-reduce' of partial sums is all_gather + a local W-way EC sum on every rank
 (wsnark_g1_sum / wsnark_g2_sum), which is bit-identical on all ranks.
 
-Alternative (the north star's wording): `bn.set_window_shard(rank, world)` makes every rank compute,
-over ALL pairs, only the Pippenger windows w % world == rank; partials are pre-scaled by 2^(c w) and
+Alternative (the north star's wording): `shard=(rank, world)` on the multiexp / prove_partial calls makes every rank
+compute, over ALL pairs, only the Pippenger windows w % world == rank; partials are pre-scaled by 2^(c w) and
 combine with the same all_gather + EC sum.  That divides one MSM's latency by the number of GPUs
-(strong scaling) at the price of every GPU reading all points; `bench.py --shard windows` measures it.
+(strong scaling) at the price of every GPU reading all points; `bench.py --gpus N` measures it on whole proofs.
+The shard is a per-call argument: there is no process-global mode to set and restore.
 """
 import torch
 import torch.distributed as dist
@@ -49,14 +50,26 @@ def sharded_msm(bn, g, local_partial, device=None):
     return bn.g1_sum(allp) if g == 1 else bn.g2_sum(allp)
 
 
-def sharded_prove(bn, key, witness, r=None, s=None, device=None):
+def sharded_prove(bn, key, witness, r=None, s=None, device=None, d_witness=None):
     """Groth16 proof with the MSM windows sharded over the ranks (one process per GPU, same key and
     witness everywhere): every rank computes its 576-byte record of partial sums, ONE all_gather, then
-    every rank assembles the identical proof on the host.  r, s must be the same on all ranks."""
+    every rank assembles the identical proof on the host.
+    r, s = None: rank 0 draws the blinding values and they travel with its record's all_gather slot (64 extra
+    bytes per rank; the other ranks send zeros), so that all ranks still return the same proof.
+    d_witness: (device pointer, byte length) of a witness already resident on this rank's GPU."""
+    import os
     rank, world = dist.get_rank(), dist.get_world_size()
-    bn.set_window_shard(rank, world)
-    try:
-        part = bn.groth16_prove_partial(witness, key)
-    finally:
-        bn.set_window_shard(0, 1)
-    return bn.groth16_prove_finish(key, allgather_partials(part, device), r=r, s=s)
+    if d_witness is not None:
+        part = bn.groth16_prove_partial_dev(d_witness[0], d_witness[1], key, shard=(rank, world))
+    else:
+        part = bn.groth16_prove_partial(witness, key, shard=(rank, world))
+    draw = r is None or s is None
+    if draw:
+        part += (os.urandom(64) if rank == 0 else bytes(64))
+    allp = allgather_partials(part, device)
+    if draw:
+        rec = len(part)
+        r0, s0 = allp[576:608], allp[608:640]
+        r, s = (r if r is not None else r0), (s if s is not None else s0)
+        allp = b"".join(allp[i * rec:i * rec + 576] for i in range(world))
+    return bn.groth16_prove_finish(key, allp, r=r, s=s)
