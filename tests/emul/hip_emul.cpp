@@ -3,6 +3,7 @@
 
 #include <ucontext.h>
 
+#include <mutex>
 #include <vector>
 
 namespace hip_emul {
@@ -60,6 +61,9 @@ uint32_t shfl_exchange(uint32_t v, int src_lane, int /*width*/) {
 }
 
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
+    // __shared__ arrays are process-wide statics here: kernels of different host threads (two lanes) take turns
+    static std::mutex one_kernel_at_a_time;
+    std::lock_guard<std::mutex> turn(one_kernel_at_a_time);
     const int nthr = (int)(block.x * block.y * block.z);
     std::vector<Thr> thr((size_t)nthr);
     while ((int)g_stack_pool.size() < nthr) g_stack_pool.push_back((char*)malloc(STACK_BYTES));

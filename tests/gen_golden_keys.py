@@ -28,7 +28,7 @@ def main():
     out = os.path.join(ROOT, "tests", "golden", "keys")
     os.makedirs(out, exist_ok=True)
     for name, logd, npub, seed in (("t3", 3, 1, 11), ("t6", 6, 3, 12)):
-        circ = synth.make_circuit(logd, n_public=npub, seed=seed)
+        circ = synth.make_circuit(logd, n_public=npub, seed=seed, style="rows")   # (the committed keys: round-1 generator)
         S = synth.setup(circ, seed=seed + 100)
         pkey, vk = synth.build_key(circ, S, oracle_mul_base)
         open(os.path.join(out, name + ".pkey.bin"), "wb").write(pkey)

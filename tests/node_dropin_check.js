@@ -9,7 +9,8 @@ const gold = path.join(root, "tests", "golden");
 const toAB = (b) => b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength);
 
 (async () => {
-    const bn = await ws.buildBn128();
+    const lib = process.argv[2];                       // tests only: the thread-emulator build of the same ABI
+    const bn = await ws.buildBn128(undefined, lib ? { lib } : undefined);
     const proofs = JSON.parse(fs.readFileSync(path.join(gold, "proofs.json"), "utf8"));
     let checked = 0;
     for (const name of Object.keys(proofs)) {
@@ -45,6 +46,34 @@ const toAB = (b) => b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength);
         if (proof.pi_a[2] !== "1" || proof.pi_b[2][0] !== "1") return rej(new Error("bad proof shape"));
         res();
     }));
+    // default blinding: the values drawn are kept like the reference's _pr / _ps and reproduce the proof when injected
+    const p1 = await bn.groth16GenProof(wit, pkey);
+    const r1 = Buffer.from(bn._pr), s1 = Buffer.from(bn._ps);
+    const p2 = await bn.groth16GenProof(wit, pkey, { r: r1, s: s1 });
+    if (JSON.stringify(p1) !== JSON.stringify(p2)) throw new Error("proof with drawn r, s is not reproducible");
+    const p3 = await bn.groth16GenProof(wit, pkey);
+    if (JSON.stringify(p1) === JSON.stringify(p3)) throw new Error("blinding values were not fresh");
+    // two different keys that are views of ONE ArrayBuffer must not share a cached handle (ADVICE r1)
+    {
+        const k3 = fs.readFileSync(path.join(gold, "keys", "t3.pkey.bin")), k6 = fs.readFileSync(path.join(gold, "keys", "t6.pkey.bin"));
+        const bundle = new Uint8Array(k3.length + k6.length);
+        bundle.set(k3, 0); bundle.set(k6, k3.length);
+        const v3 = bundle.subarray(0, k3.length), v6 = bundle.subarray(k3.length);
+        const w6 = fs.readFileSync(path.join(gold, "keys", "t6.witness.bin"));
+        const c3 = proofs.t3[1], c6 = proofs.t6[1];
+        const q3 = await bn.groth16GenProof(wit, v3, { r: Buffer.from(c3.r, "hex"), s: Buffer.from(c3.s, "hex") });
+        const q6 = await bn.groth16GenProof(w6, v6, { r: Buffer.from(c6.r, "hex"), s: Buffer.from(c6.s, "hex") });
+        if (JSON.stringify(q3) !== JSON.stringify(c3.proof) || JSON.stringify(q6) !== JSON.stringify(c6.proof)) throw new Error("views of one ArrayBuffer collided in the key cache");
+        // a buffer reused for another key is noticed (same object, new bytes)
+        const reuse = new Uint8Array(Math.max(k3.length, k6.length));
+        reuse.set(k3);
+        const a3 = reuse.subarray(0, k3.length);
+        await bn.groth16GenProof(wit, a3, { r: Buffer.from(c3.r, "hex"), s: Buffer.from(c3.s, "hex") });
+        const hk = await bn.loadKey(a3);
+        if ((await bn.loadKey(a3)) !== hk) throw new Error("unchanged key was reloaded");
+        a3[100] ^= 0xff;
+        if ((await bn.loadKey(a3)) === hk) throw new Error("stale key handle returned for changed bytes");
+    }
     // error path: rejected Promise, not a hang (the reference hangs: SURVEY section 5)
     let rejected = false;
     try { await bn.fft(new Uint8Array(96), 0); } catch (e) { rejected = true; }

@@ -1,0 +1,105 @@
+"""-m gpu tests that need MORE THAN ONE visible GPU; each skips itself otherwise (the build's gpurun boxes have one;
+the driver's 8-GPU node, when there is one, runs them).  One process per GPU, torch.distributed backend "nccl"
+(= RCCL over xGMI), the same code path bench.py --gpus N uses: window-sharded MSM and whole sharded proofs against
+the reference's golden proofs, and an entry point called from a thread other than the one that initialised a
+context on device 1."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpus():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+WORKER = r'''
+import json, os, random, sys
+sys.path.insert(0, os.environ["WS_ROOT"])
+import torch, torch.distributed as dist
+rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+torch.cuda.set_device(local)
+dev = torch.device("cuda", local)
+dist.init_process_group("nccl", device_id=dev)
+import wasmsnark_amd
+from wasmsnark_amd import dist as wd
+from oracle import pyoracle as orc
+bn = wasmsnark_amd.build(device=local)
+rnd = random.Random(42)
+for g, n in ((1, 3000), (2, 700)):
+    sz = 64 if g == 1 else 128
+    pts = bn.mul_base(g, b"".join(rnd.randrange(1, orc.R).to_bytes(32, "little") for _ in range(n)))
+    sc = b"".join(rnd.randrange(1 << 256).to_bytes(32, "little") for _ in range(n))
+    want = orc.g_affine(g, orc.multiexp(g, "workers8", sc, pts, n))
+    f = bn.g1_multiexp if g == 1 else bn.g2_multiexp
+    lo, hi = wd.shard_bounds(n, world, rank)                      # the reference's split (src/bn128.js:353-383)
+    assert wd.sharded_msm(bn, g, f(sc[lo * 32:hi * 32], pts[lo * sz:hi * sz]), dev) == want, ("points", g, rank)
+    assert wd.sharded_msm(bn, g, f(sc, pts, shard=(rank, world)), dev) == want, ("windows", g, rank)
+gold = os.path.join(os.environ["WS_ROOT"], "tests", "golden")
+key = bn.load_key(open(os.path.join(gold, "keys", "t6.pkey.bin"), "rb").read())
+wit = open(os.path.join(gold, "keys", "t6.witness.bin"), "rb").read()
+d_w = torch.frombuffer(bytearray(wit), dtype=torch.uint8).to(dev)
+torch.cuda.synchronize()
+for c in json.load(open(os.path.join(gold, "proofs.json")))["t6"]:
+    r, s = bytes.fromhex(c["r"]), bytes.fromhex(c["s"])
+    assert wd.sharded_prove(bn, key, wit, r=r, s=s, device=dev) == c["proof"], ("sharded prove", rank)
+    assert wd.sharded_prove(bn, key, None, r=r, s=s, device=dev, d_witness=(d_w.data_ptr(), len(wit))) == c["proof"]
+got = wd.sharded_prove(bn, key, wit, device=dev)                  # rank 0 draws r, s: all ranks, one proof
+r_used, s_used = bn.last_blinding()
+assert got == bn.groth16GenProof(wit, key, r=r_used, s=s_used)
+dist.barrier()
+open(os.path.join(os.environ["WS_OUT"], "rank%d.ok" % rank), "w").write("ok")
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_msm_and_prove_nccl(tmp_path):
+    n = _gpus()
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs (found %d)" % n)
+    world = 2
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, WS_ROOT=ROOT, WS_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                          "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert all((tmp_path / ("rank%d.ok" % r)).exists() for r in range(world))
+
+
+THREAD_WORKER = r'''
+import os, sys, threading
+sys.path.insert(0, os.environ["WS_ROOT"])
+import json
+import wasmsnark_amd
+bn = wasmsnark_amd.build(device=1)          # context on GPU 1, initialised on the main thread
+gold = os.path.join(os.environ["WS_ROOT"], "tests", "golden")
+key = bn.load_key(open(os.path.join(gold, "keys", "t6.pkey.bin"), "rb").read())
+wit = open(os.path.join(gold, "keys", "t6.witness.bin"), "rb").read()
+c = json.load(open(os.path.join(gold, "proofs.json")))["t6"][1]
+res = []
+def work():                                  # a fresh thread: HIP's current device defaults to 0 there
+    res.append(bn.groth16GenProof(wit, key, r=bytes.fromhex(c["r"]), s=bytes.fromhex(c["s"])) == c["proof"])
+    x = bn.toMontgomeryN((5).to_bytes(32, "little") * 1000)
+    res.append(bn.fromMontgomeryN(x) == (5).to_bytes(32, "little") * 1000)
+t = threading.Thread(target=work); t.start(); t.join()
+assert res == [True, True], res
+print("ok")
+'''
+
+
+def test_entry_points_from_another_thread_on_device_1(tmp_path):
+    n = _gpus()
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs (found %d)" % n)
+    script = tmp_path / "thread_worker.py"
+    script.write_text(THREAD_WORKER)
+    out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, WS_ROOT=ROOT), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

@@ -312,10 +312,12 @@ def test_msm_full_size_adversarial_closed_forms(bn, orc, g):
     assert out[:esz] == expect(sum(ss[i] * ks[i] for i in range(0, n, 2)))
 
 
-@pytest.mark.parametrize("logd", [10, 16])
-def test_prove_vs_toxic_waste_closed_form(bn, logd):
+@pytest.mark.parametrize("logd,style", [(10, "columns"), (16, "columns"), (16, "rows"), (20, "columns")])
+def test_prove_vs_toxic_waste_closed_form(bn, logd, style):
+    """(20, columns) is BASELINE config 4 at full size: the circuit SURVEY.md section 8d C4 specifies (1-3 non-zeros per
+    column, every variable present).  'rows' leaves ~40 % of the A / B key points at infinity: the plan-variant path."""
     from wasmsnark_amd import synth
-    circ = synth.make_circuit(logd, n_public=5, seed=logd)
+    circ = synth.make_circuit(logd, n_public=5, seed=logd, style=style)
     S = synth.setup(circ, seed=3)
     pkey, _ = synth.build_key(circ, S, bn.mul_base)
     key = bn.load_key(pkey)
@@ -323,6 +325,72 @@ def test_prove_vs_toxic_waste_closed_form(bn, logd):
     for r, s in ((b"\0" * 32, b"\0" * 32), (b"\xff" * 32, b"\xfe" + b"\xff" * 31), (os.urandom(32), os.urandom(32))):
         got = bn.groth16GenProof(wit, key, r=r, s=s)
         assert got == synth.expected_proof(circ, S, r, s, bn.mul_base)
+    # blinding left to the library (the reference's default path, src/bn128.js:642-661): read back what it drew
+    # (its _pr / _ps, :662-664) and check the proof against the closed form for exactly those values
+    got = bn.groth16GenProof(wit, key)
+    r, s = bn.last_blinding()
+    assert got == synth.expected_proof(circ, S, r, s, bn.mul_base)
+    got2 = bn.groth16GenProof(wit, key)
+    assert bn.last_blinding() != (r, s) and got2 != got
+    key.free()
+
+
+def test_sections_loader_2p18_equals_file_loader(bn):
+    """wsnark_pkey_load_sections (the container for keys beyond proving_key.bin's 4 GiB of u32 offsets: BASELINE
+    config 5) against wsnark_pkey_load on the same 2^18 key: same proofs, equal to the closed form; short
+    sections are refused."""
+    from wasmsnark_amd import WsnarkError, synth
+    circ = synth.make_circuit(18, n_public=5, seed=18)
+    S = synth.setup(circ, seed=4)
+    sec, _ = synth.build_sections(circ, S, bn.mul_base)
+    pkey, _ = synth.build_key(circ, S, bn.mul_base)
+    k_file, k_sec = bn.load_key(pkey), bn.load_key(sections=sec)
+    assert (k_sec.n_vars, k_sec.n_public, k_sec.domain) == (k_file.n_vars, k_file.n_public, k_file.domain)
+    wit = synth.witness_bin(circ)
+    r, s = os.urandom(32), os.urandom(32)
+    want = synth.expected_proof(circ, S, r, s, bn.mul_base)
+    assert bn.groth16GenProof(wit, k_sec, r=r, s=s) == want
+    assert bn.groth16GenProof(wit, k_file, r=r, s=s) == want
+    for name in ("pointsB2", "pointsH"):
+        short = dict(sec)
+        short[name] = sec[name][:-64]
+        with pytest.raises(WsnarkError):
+            bn.load_key(sections=short)
+    k_file.free(); k_sec.free()
+
+
+def test_two_proofs_in_flight_one_key_on_gpu(bn):
+    """Lanes: two host threads prove with ONE key handle at the same time (each call holds a lane: its own queues,
+    MSM plans, scratch, witness / h buffers), a third waits for a lane; every proof equals the closed form."""
+    import threading
+    from wasmsnark_amd import synth
+    circ = synth.make_circuit(16, n_public=5, seed=61)
+    S = synth.setup(circ, seed=6)
+    pkey, _ = synth.build_key(circ, S, bn.mul_base)
+    key = bn.load_key(pkey)
+    wit = synth.witness_bin(circ)
+    jobs = []
+    for i in range(3):
+        r, s = bytes([i + 1]) * 32, bytes([i + 101]) * 32
+        jobs.append((r, s, synth.expected_proof(circ, S, r, s, bn.mul_base)))
+    errors = []
+
+    def worker(r, s, want):
+        try:
+            for _ in range(8):
+                if bn.groth16GenProof(wit, key, r=r, s=s) != want:
+                    errors.append("proof mismatch")
+                if bn.last_blinding() != (r, s):
+                    errors.append("last_blinding is not per thread")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=j) for j in jobs]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:3]
 
 
 def test_concurrent_callers(bn, orc):

@@ -1,5 +1,5 @@
 """The Node.js drop-in (wasmsnark_amd/js: N-API addon + index.js) end to end.
-CPU: driven against the thread-emulator build of the kernel sources ($WSNARK_LIB), so the JS
+CPU: driven against the thread-emulator build of the kernel sources (passed explicitly to buildBn128), so the JS
 marshalling, Promise/callback shapes and decimal formatting are tested without a GPU.
 GPU (-m gpu): the same script against the real libwsnark.so."""
 import os
@@ -19,10 +19,9 @@ def _build_addon():
     subprocess.check_call(["make", "-C", JS, "-s"])
 
 
-def _run(env_extra):
-    env = dict(os.environ, **env_extra)
-    return subprocess.run(["node", os.path.join(ROOT, "tests", "node_dropin_check.js")], env=env,
-                          capture_output=True, text=True, timeout=900)
+def _run(lib=None):
+    cmd = ["node", os.path.join(ROOT, "tests", "node_dropin_check.js")] + ([lib] if lib else [])
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=900)
 
 
 @needs_node
@@ -30,7 +29,7 @@ def test_node_dropin_against_emulated_kernels():
     from emul_util import emul_bn128, SO
     emul_bn128()
     _build_addon()
-    out = _run({"WSNARK_LIB": SO})
+    out = _run(SO)
     assert out.returncode == 0 and "NODE_DROPIN_OK" in out.stdout, out.stdout + out.stderr
 
 
@@ -41,8 +40,7 @@ def test_node_addon_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     _build_addon()
     code = "require('%s/index.js').buildBn128().then(()=>{console.log('UNEXPECTED_OK')},e=>{console.log('REJECTED',e.message)})" % JS
-    out = subprocess.run(["node", "-e", code], capture_output=True, text=True, timeout=120,
-                         env={k: v for k, v in os.environ.items() if k != "WSNARK_LIB"})
+    out = subprocess.run(["node", "-e", code], capture_output=True, text=True, timeout=120)
     assert "REJECTED" in out.stdout and "no CPU fallback" in out.stdout, out.stdout + out.stderr
 
 
@@ -52,5 +50,5 @@ def test_node_dropin_on_gpu():
     import __graft_entry__
     __graft_entry__.ensure_built()
     _build_addon()
-    out = _run({})
+    out = _run()
     assert out.returncode == 0 and "NODE_DROPIN_OK" in out.stdout, out.stdout + out.stderr

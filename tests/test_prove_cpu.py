@@ -42,7 +42,7 @@ def test_oracle_prover_matches_reference(orc, name):
 @pytest.mark.parametrize("name", NAMES)
 def test_toxic_waste_closed_form_matches_reference(name):
     _, _, meta = _key(name)
-    circ = synth.make_circuit(meta["log_domain"], n_public=meta["n_public"], seed=meta["circuit_seed"])
+    circ = synth.make_circuit(meta["log_domain"], n_public=meta["n_public"], seed=meta["circuit_seed"], style=meta.get("style", "rows"))
     S = synth.setup(circ, seed=meta["setup_seed"])
     for c in load_golden("proofs.json")[name]:
         exp = synth.expected_proof(circ, S, bytes.fromhex(c["r"]), bytes.fromhex(c["s"]), oracle_mul_base)
@@ -129,3 +129,64 @@ def test_partial_finish_and_sections_loader():
     bad["n_public"] = 0xFFFFFFFF                       # nPublic + 1 must not wrap around
     with pytest.raises(WsnarkError):
         bn.load_key(sections=bad)
+
+
+def test_two_proofs_in_flight_on_one_key():
+    """Lanes: several host threads prove with ONE key handle at once (each call takes a lane: its own queues, MSM plans,
+    scratch, witness / h buffers); a third caller waits for a lane.  Every proof must equal the reference's."""
+    import threading
+    bn = emul_bn128()
+    pkey, wit, _ = _key("t6")
+    key = bn.load_key(pkey)
+    cases = load_golden("proofs.json")["t6"]
+    errors = []
+
+    def worker(c):
+        try:
+            for _ in range(2):
+                got = bn.groth16GenProof(wit, key, r=bytes.fromhex(c["r"]), s=bytes.fromhex(c["s"]))
+                if got != c["proof"]:
+                    errors.append("mismatch")
+                if bn.last_blinding() != (bytes.fromhex(c["r"]), bytes.fromhex(c["s"])):
+                    errors.append("last_blinding is not per thread")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(c,)) for c in cases[:3]]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:3]
+
+
+def test_default_blinding_is_exposed_and_consistent(orc):
+    """r, s left to the library (OS CSPRNG): the values it drew are readable like the reference's _pr / _ps
+    (src/bn128.js:662-664) and reproduce the same proof when injected."""
+    bn = emul_bn128()
+    pkey, wit, _ = _key("t3")
+    p1 = bn.groth16GenProof(wit, pkey)
+    r1, s1 = bn.last_blinding()
+    p2 = bn.groth16GenProof(wit, pkey)
+    r2, s2 = bn.last_blinding()
+    assert (r1, s1) != (r2, s2) and p1 != p2                       # fresh randomness per proof
+    assert bn.groth16GenProof(wit, pkey, r=r1, s=s1) == p1
+    assert bn.groth16GenProof(wit, pkey, r=r2, s=s2) == p2
+    assert orc.groth16_prove(wit, pkey, r1, s1) == p1              # and it is the proof the reference algorithm gives for them
+
+
+def test_column_style_circuit_closed_form_and_oracle(orc):
+    """The benchmark's circuit shape (1-3 non-zeros per COLUMN, every variable present):
+    witness valid, every key point of A / B1 / B2 real (but the last variable's), and three provers agree:
+    toxic-waste closed form == oracle (reference algorithm) == emulated kernels."""
+    bn = emul_bn128()
+    circ = synth.make_circuit(5, n_public=2, seed=123, style="columns")
+    assert sum(1 for c in circ.A if not c) <= 1 and sum(1 for c in circ.B if not c) <= 1
+    assert all(1 <= len(c) <= 4 for c in circ.B[:-1])
+    S = synth.setup(circ, seed=9)
+    pkey, _ = synth.build_key(circ, S, oracle_mul_base)
+    wit = synth.witness_bin(circ)
+    r, s = bytes(range(1, 33)), bytes(range(100, 132))
+    want = synth.expected_proof(circ, S, r, s, oracle_mul_base)
+    assert orc.groth16_prove(wit, pkey, r, s) == want
+    assert bn.groth16GenProof(wit, pkey, r=r, s=s) == want

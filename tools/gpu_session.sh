@@ -1,24 +1,39 @@
 #!/bin/bash
-# One gpurun call: environment probe, instruction-rate microbench, GPU parity tests, bench, rocprof.
+# One gpurun call: environment probe, GPU parity tests, bench, rocprof kernel stats, PMC traffic.
+#   TAG=r02_s1 [SKIP="tests pmc"] [PYTEST_ARGS="-k ..."] tools/gpu_session.sh
 cd "$GRAFT_REPO_ROOT" || exit 1
-mkdir -p gpurun_out
+TAG=${TAG:-r02}
+O=gpurun_out/$TAG
+mkdir -p "$O"
+export HSA_ENABLE_IPC_MODE_LEGACY=0
 {
   echo "== env"; rocminfo 2>/dev/null | grep -E "Marketing Name|gfx9|Compute Unit" | head -6
-  nproc; free -g | head -2; node --version 2>&1; python --version
-} > gpurun_out/env.log 2>&1
-timeout 300 ./tools/microbench > gpurun_out/microbench.jsonl 2>&1
-echo "microbench rc=$?" >> gpurun_out/env.log
-timeout 2400 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
-echo "pytest rc=$?" >> gpurun_out/env.log
-timeout 1200 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err
-echo "bench rc=$?" >> gpurun_out/env.log
-( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o r01 -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --extras ntt ) > gpurun_out/prof.log 2>&1
-echo "rocprof rc=$?" >> gpurun_out/env.log
+  nproc; free -g | head -2; node --version 2>&1; python --version; rocm-smi --showid 2>/dev/null | grep -c "GPU\[" 
+} > "$O/env.log" 2>&1
+skip() { [[ " $SKIP " == *" $1 "* ]]; }
+if ! skip tests; then
+  timeout 2400 python -m pytest tests -m gpu -q --timeout 1200 -p no:cacheprovider --durations=12 $PYTEST_ARGS > "$O/pytest_gpu.txt" 2>&1
+  echo "pytest rc=$?" >> "$O/env.log"
+fi
+if ! skip bench; then
+  timeout 1500 python bench.py $BENCH_ARGS > "$O/bench.json" 2> "$O/bench.err"
+  echo "bench rc=$?" >> "$O/env.log"
+fi
+PROF_CMD="python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --extras msm,ntt"
+if ! skip prof; then
+  ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$O/prof" -o prof -- $PROF_CMD ) > "$O/prof.log" 2>&1
+  echo "rocprof rc=$?" >> "$O/env.log"
+  find "$O/prof" -name "*kernel_stats.csv" -exec cp {} "$O/kernel_stats.csv" \; 2>/dev/null
+  find "$O/prof" -name "*kernel_trace.csv" -size +8M -delete 2>/dev/null
+fi
 # HBM traffic counters: separate --pmc passes, kernel-trace only (never combined with sys/hip/hsa traces)
-for CTR in FETCH_SIZE WRITE_SIZE; do
-  ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_$CTR" -o pmc -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --extras ntt ) > gpurun_out/pmc_$CTR.log 2>&1
-  echo "pmc $CTR rc=$?" >> gpurun_out/env.log
-done
-python tools/pmc_summary.py gpurun_out > gpurun_out/pmc_summary.json 2>> gpurun_out/env.log
-find gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE -name "*.csv" -size +2M -delete 2>/dev/null
-tail -5 gpurun_out/pytest_gpu.log; cat gpurun_out/bench.json | head -c 3000; cat gpurun_out/env.log
+if ! skip pmc; then
+  for CTR in FETCH_SIZE WRITE_SIZE; do
+    ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/$O/pmc_$CTR" -o pmc -- python "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --extras msm,ntt ) > "$O/pmc_$CTR.log" 2>&1
+    echo "pmc $CTR rc=$?" >> "$O/env.log"
+  done
+  python tools/pmc_summary.py "$O" > "$O/pmc_traffic.json" 2>> "$O/env.log"
+  find "$O/pmc_FETCH_SIZE" "$O/pmc_WRITE_SIZE" -name "*.csv" -size +2M -delete 2>/dev/null
+fi
+[ -n "$EXTRA_CMD" ] && ( eval "$EXTRA_CMD" ) > "$O/extra.log" 2>&1
+tail -15 "$O/pytest_gpu.txt" 2>/dev/null; head -c 6000 "$O/bench.json" 2>/dev/null; echo; tail -3 "$O/bench.err" 2>/dev/null; cat "$O/env.log"

@@ -1,18 +1,23 @@
 #!/usr/bin/env python3
 """Per-kernel mean FETCH_SIZE / WRITE_SIZE from the two rocprofv3 --pmc passes of tools/gpu_session.sh
-(counter_collection CSVs).  Prints JSON: {kernel: {"launches": n, "FETCH_SIZE": mean, "WRITE_SIZE": mean}}.
-Units are the counters' own (KiB on gfx9 per rocprofv3's derived-metric definition); on gfx950
-FETCH_SIZE under-reports wide coalesced streams 2x (MI355X_MICROARCH.md) -- raw values are kept here."""
+(counter_collection CSVs) -> the JSON bench.py reads from profiles/r02_pmc_traffic.json:
+  {"how": ..., "kernels": {short kernel name: {"launches": n, "fetch_bytes": mean per launch, "write_bytes": ...}}}
+Counters are in KiB (rocprofv3's derived metrics on gfx9).  Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM):
+on gfx950 FETCH_SIZE reports exactly half the bytes of wide coalesced streaming reads (128-B requests tallied at 64 B);
+other access widths (the 64-B point gathers of msm_accumulate) and WRITE_SIZE are uncalibrated.  Both the raw value
+and, for the streaming kernels listed in STREAMING, the doubled one are kept."""
 import csv
 import glob
 import json
 import os
+import re
 import sys
 from collections import defaultdict
 
+STREAMING = ("ntt_pass_kernel", "fr_mul_kernel", "fr_map_kernel", "calch_combine_kernel", "presort_count", "msm_convert_points")
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
 out = defaultdict(lambda: {"launches": 0})
-for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+for ctr, key in (("FETCH_SIZE", "fetch_bytes"), ("WRITE_SIZE", "write_bytes")):
     acc = defaultdict(list)
     for f in glob.glob(os.path.join(root, "pmc_" + ctr, "**", "*counter_collection.csv"), recursive=True):
         with open(f, newline="") as fh:
@@ -20,12 +25,30 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
                 name = row.get("Kernel_Name") or row.get("Kernel Name") or ""
                 if row.get("Counter_Name") != ctr:
                     continue
-                short = name.split("(")[0].replace("void ", "").strip()[:70]
+                m = re.search(r"wsnark::([A-Za-z0-9_]+)", name)
+                short = m.group(1) if m else name.split("(")[0].replace("void ", "").strip()[:60]
+                # distinguish the G1 / G2 instantiations of the templated MSM kernels
+                if m and ("Fp2T" in name or "Fe2T" in name):
+                    short += "_g2"
                 try:
-                    acc[short].append(float(row["Counter_Value"]))
+                    acc[short].append(float(row["Counter_Value"]) * 1024.0)
                 except (KeyError, ValueError):
                     pass
     for k, v in acc.items():
-        out[k][ctr] = sum(v) / len(v)
+        out[k][key] = int(sum(v) / len(v))
         out[k]["launches"] = max(out[k]["launches"], len(v))
-print(json.dumps({k: v for k, v in out.items() if "wsnark" in k or "radix" in k}, indent=1))
+kern = {}
+for k, v in sorted(out.items()):
+    v.setdefault("fetch_bytes", 0); v.setdefault("write_bytes", 0)
+    if any(k.startswith(s) for s in STREAMING):
+        v["fetch_bytes_corrected_x2"] = 2 * v["fetch_bytes"]
+    kern[k] = v
+# bench.py keys: the timer's names
+alias = {"msm_accumulate_g1": "msm_accumulate", "msm_accumulate_g2": "msm_accumulate_g2"}
+for a, k in alias.items():
+    if k in kern:
+        kern[a] = kern[k]
+print(json.dumps({"how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes (--kernel-trace only) around "
+                         "`python bench.py --steps 2 --warmup 1 --no-cpu-baseline --extras msm,ntt`; mean bytes per launch = counter (KiB) x 1024; "
+                         "FETCH_SIZE raw except *_corrected_x2 (gfx950 tallies wide coalesced 128-B requests at 64 B)",
+                  "kernels": kern}, indent=1))

@@ -24,37 +24,67 @@ function proofFromBytes(ab) {       // bin2g1 / bin2g2, src/bn128.js:329-351, 71
     return { pi_a: [v[0], v[1], v[2]], pi_b: [[v[3], v[4]], [v[5], v[6]], [v[7], v[8]]], pi_c: [v[9], v[10], v[11]] };
 }
 
+/* cheap fingerprint of a key buffer: its length, its fixed header (10 x u32 + alfa1 .. delta2) and 64 words spread over
+ * the rest -- enough to notice that a cached handle no longer describes the bytes the caller is holding */
+function fingerprint(u8) {
+    let h = 0x811c9dc5 ^ u8.length;
+    const mix = (b) => { h = Math.imul(h ^ b, 0x01000193) >>> 0; };
+    const head = Math.min(u8.length, 488);
+    for (let i = 0; i < head; i++) mix(u8[i]);
+    const step = Math.max(1, Math.floor((u8.length - head) / 64));
+    for (let o = head; o + 4 <= u8.length; o += step) { mix(u8[o]); mix(u8[o + 1]); mix(u8[o + 2]); mix(u8[o + 3]); }
+    return h;
+}
+function asBytes(x) {
+    if (x instanceof ArrayBuffer) return new Uint8Array(x);
+    if (ArrayBuffer.isView(x)) return new Uint8Array(x.buffer, x.byteOffset, x.byteLength);
+    throw new TypeError("expected an ArrayBuffer, Buffer or TypedArray");
+}
+
 class Bn128 {
     constructor(deviceInfo) {
         this.deviceInfo = deviceInfo;
-        this._keys = new WeakMap();  // proving-key buffer -> device-resident handle (stays in HBM across proofs)
+        // proving-key OBJECT (the exact ArrayBuffer / view the caller passed) -> {handle, byteOffset, byteLength, fp}.
+        // Two views of one ArrayBuffer (sub-arrays of a bundle, Node's pooled small Buffers) are different keys here,
+        // and a cached handle is only reused while offset, length and fingerprint still match; the reference re-reads
+        // pkey on every call (src/bn128.js:581-604) -- callers that want no check at all hold the handle of loadKey().
+        this._keys = new WeakMap();
+        this._pr = null;     // blinding values of the last proof, "for tests" like the reference (src/bn128.js:662-664)
+        this._ps = null;
     }
     g1_multiexp(scalars, points) { return addon.g1Multiexp(scalars, points); }
     g2_multiexp(scalars, points) { return addon.g2Multiexp(scalars, points); }
     calcH(signals, polsA, polsB, nSignals, domainSize) { return addon.calcH(signals, polsA, polsB, nSignals, domainSize); }
     fft(buf, odd) { return addon.fft(buf, odd | 0, false); }
     ifft(buf, odd) { return addon.fft(buf, odd | 0, true); }
+    /* pkey bytes -> device-resident key handle (stays in HBM across proofs; freed by the GC) */
     async loadKey(pkey) {
-        const id = (pkey && pkey.buffer instanceof ArrayBuffer && !(pkey instanceof ArrayBuffer)) ? pkey.buffer : pkey;
-        let h = (typeof id === "object" && id !== null) ? this._keys.get(id) : undefined;
-        if (!h) {
-            h = await addon.loadKey(pkey);
-            if (typeof id === "object" && id !== null) this._keys.set(id, h);
-        }
-        return h;
+        if (pkey !== null && typeof pkey === "object" && !(pkey instanceof ArrayBuffer) && !ArrayBuffer.isView(pkey)) return pkey;   // already a handle
+        const u8 = asBytes(pkey);
+        const fp = fingerprint(u8);
+        const hit = this._keys.get(pkey);
+        if (hit && hit.byteOffset === u8.byteOffset && hit.byteLength === u8.byteLength && hit.fp === fp) return hit.handle;
+        const handle = await addon.loadKey(pkey);
+        this._keys.set(pkey, { handle, byteOffset: u8.byteOffset, byteLength: u8.byteLength, fp });
+        return handle;
     }
-    /* opts.r / opts.s: optional 32-byte blinding values (the reference draws them from crypto.randomBytes) */
+    /* pkey: proving_key.bin bytes, or a handle from loadKey().
+     * opts.r / opts.s: optional 32-byte blinding values (the reference draws them from crypto.randomBytes) */
     async groth16GenProof(signals, pkey, opts) {
         const h = await this.loadKey(pkey);
         const out = await addon.prove(h, signals, opts && opts.r ? opts.r : null, opts && opts.s ? opts.s : null);
-        return proofFromBytes(out);
+        this._pr = new Uint8Array(out.slice(384, 416));
+        this._ps = new Uint8Array(out.slice(416, 448));
+        return proofFromBytes(out.slice(0, 384));
     }
     terminate() { addon.shutdown(); }
 }
 
 let singleton = null;
-async function buildBn128(device) {
-    const info = addon.init(device === undefined ? -1 : device);
+/* opts.lib: load this build of the C ABI instead of the in-tree libwsnark.so.  The test-suite passes the CPU
+ * thread-emulator build; nothing else should: there is no CPU path in the product. */
+async function buildBn128(device, opts) {
+    const info = addon.init(device === undefined || device === null ? -1 : device, opts && opts.lib ? String(opts.lib) : undefined);
     return new Bn128(info);
 }
 function groth16GenProof(witness, provingKey, cb) {   // main_bn128.js:26-39

@@ -5,8 +5,10 @@
  * function maps 1:1 to one C entry point and returns a Promise (napi async work, so the event
  * loop is never blocked), with the reference's byte layouts (Jacobian-Montgomery 96/192 B,
  * plain-form h, ...).  Reference seam: src/bn128.js:102-166 (worker commands), :353-415, :569-720.
- * libwsnark.so is dlopen'ed at load time ($WSNARK_LIB or ../libwsnark.so next to this addon);
- * there is no fallback: if it cannot be loaded, requiring the addon throws.
+ * libwsnark.so (../libwsnark.so next to this addon: the in-tree hipcc build) is dlopen'ed by init();
+ * there is no fallback and no environment override: if it cannot be loaded or finds no GPU, init() throws.
+ * (init's optional second argument names another build of the same ABI explicitly; only the test-suite
+ * passes one: the CPU thread-emulator build of the kernel sources.)
  */
 #define NAPI_VERSION 4
 #define _GNU_SOURCE
@@ -32,6 +34,8 @@ static struct {
     void (*pkey_free)(wsnark_pkey_t*);
     int (*pkey_info)(const wsnark_pkey_t*, uint32_t*, uint32_t*, uint32_t*);
     int (*prove)(wsnark_pkey_t*, const void*, size_t, const void*, const void*, void*);
+    int (*last_blinding)(void*, void*);
+    char dir[4096];
 } L;
 
 #define CHECK(env, call)                                                        \
@@ -42,11 +46,11 @@ static struct {
         }                                                                       \
     } while (0)
 
-static int load_lib(const char* addon_dir, char* err, size_t errlen) {
-    char path[4096];
-    const char* envp = getenv("WSNARK_LIB");
-    if (envp && *envp) snprintf(path, sizeof path, "%s", envp);
-    else snprintf(path, sizeof path, "%s/../../libwsnark.so", addon_dir);
+static int load_lib(const char* explicit_path, char* err, size_t errlen) {
+    char path[4200];
+    if (L.h) return 0;
+    if (explicit_path && *explicit_path) snprintf(path, sizeof path, "%s", explicit_path);
+    else snprintf(path, sizeof path, "%s/../../libwsnark.so", L.dir);
     L.h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
     if (!L.h) { snprintf(err, errlen, "cannot load %s: %s", path, dlerror()); return -1; }
 #define SYM(field, name)                                                            \
@@ -56,6 +60,7 @@ static int load_lib(const char* addon_dir, char* err, size_t errlen) {
     SYM(device_info, "wsnark_device_info") SYM(g1_msm, "wsnark_g1_msm") SYM(g2_msm, "wsnark_g2_msm")
     SYM(fr_ntt, "wsnark_fr_ntt") SYM(calc_h, "wsnark_calc_h") SYM(pkey_load, "wsnark_pkey_load")
     SYM(pkey_free, "wsnark_pkey_free") SYM(pkey_info, "wsnark_pkey_info") SYM(prove, "wsnark_groth16_prove")
+    SYM(last_blinding, "wsnark_last_blinding")
 #undef SYM
     return 0;
 }
@@ -106,7 +111,10 @@ static void job_execute(napi_env env, void* data) {
     case OP_G2: j->rc = L.g2_msm(j->a, j->b, j->na / 32, j->out); break;
     case OP_NTT: memcpy(j->out, j->a, j->na); j->rc = L.fr_ntt(j->out, j->na / 32, j->i0, j->i1); break;
     case OP_CALCH: j->rc = L.calc_h(j->a, j->b, j->nb, j->c, j->nc, j->u0, j->u1, j->out); break;
-    case OP_PROVE: j->rc = L.prove(j->key, j->a, j->na, j->r32, j->s32, j->out); break;
+    case OP_PROVE:   /* out = proof (384 B) | r | s actually used (same pool thread: wsnark_last_blinding is per thread) */
+        j->rc = L.prove(j->key, j->a, j->na, j->r32, j->s32, j->out);
+        if (!j->rc) j->rc = L.last_blinding(j->out + 384, j->out + 416);
+        break;
     case OP_LOADKEY: j->rc = L.pkey_load(j->a, j->na, &j->key); break;
     }
     if (j->rc) snprintf(j->err, sizeof j->err, "wsnark error %d: %s", j->rc, L.last_error());
@@ -142,6 +150,7 @@ static void job_complete(napi_env env, napi_status status, void* data) {
 
 static napi_value start_job(napi_env env, job_t* j, const char* name) {
     napi_value promise, rname;
+    if (!L.h) { free(j->out); free(j); napi_throw_error(env, NULL, "wsnark_napi: init() has not been called (use buildBn128())"); return NULL; }
     CHECK(env, napi_create_promise(env, &j->deferred, &promise));
     CHECK(env, napi_create_string_utf8(env, name, NAPI_AUTO_LENGTH, &rname));
     CHECK(env, napi_create_async_work(env, NULL, rname, job_execute, job_complete, j, &j->work));
@@ -209,12 +218,12 @@ static napi_value js_loadkey(napi_env env, napi_callback_info info) {
     return start_job(env, j, "wsnark_pkey_load");
 }
 
-/* prove(keyHandle, witness, r32|null, s32|null) -> Promise<ArrayBuffer 384> */
+/* prove(keyHandle, witness, r32|null, s32|null) -> Promise<ArrayBuffer 448>: proof (384 B) | r | s used */
 static napi_value js_prove(napi_env env, napi_callback_info info) {
     size_t argc = 4; napi_value argv[4];
     CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     job_t* j = (job_t*)calloc(1, sizeof *j);
-    j->op = OP_PROVE; j->nout = 384; j->out = (uint8_t*)malloc(384);
+    j->op = OP_PROVE; j->nout = 448; j->out = (uint8_t*)malloc(448);
     if (argc < 2 || napi_get_value_external(env, argv[0], (void**)&j->key) != napi_ok || !j->key ||
         !get_bytes(env, argv[1], &j->a, &j->na))
         FAIL(env, j, "expected (keyHandle, witness[, r32, s32])");
@@ -246,11 +255,15 @@ static napi_value js_keyinfo(napi_env env, napi_callback_info info) {
     return o;
 }
 
+/* init(device[, libPath]) -> device info string */
 static napi_value js_init(napi_env env, napi_callback_info info) {
-    size_t argc = 1; napi_value argv[1], s;
+    size_t argc = 2; napi_value argv[2], s;
     int32_t dev = -1;
+    char lib[4096] = "", err[4600];
     CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     if (argc > 0) napi_get_value_int32(env, argv[0], &dev);
+    if (argc > 1) { size_t n = 0; napi_valuetype t; if (napi_typeof(env, argv[1], &t) == napi_ok && t == napi_string) napi_get_value_string_utf8(env, argv[1], lib, sizeof lib, &n); }
+    if (load_lib(lib, err, sizeof err)) { napi_throw_error(env, NULL, err); return NULL; }
     int rc = L.init(dev);
     if (rc) {
         char msg[600];
@@ -263,21 +276,19 @@ static napi_value js_init(napi_env env, napi_callback_info info) {
 }
 static napi_value js_shutdown(napi_env env, napi_callback_info info) {
     (void)info;
-    L.shutdown();
+    if (L.h) L.shutdown();
     napi_value u; napi_get_undefined(env, &u);
     return u;
 }
 
 static napi_value module_init(napi_env env, napi_value exports) {
     Dl_info di;
-    char dir[4096] = ".";
+    snprintf(L.dir, sizeof L.dir, ".");
     if (dladdr((void*)module_init, &di) && di.dli_fname) {
-        snprintf(dir, sizeof dir, "%s", di.dli_fname);
-        char* sl = strrchr(dir, '/');
+        snprintf(L.dir, sizeof L.dir, "%s", di.dli_fname);
+        char* sl = strrchr(L.dir, '/');
         if (sl) *sl = 0;
     }
-    char err[4600];
-    if (load_lib(dir, err, sizeof err)) { napi_throw_error(env, NULL, err); return NULL; }
     napi_property_descriptor props[] = {
         {"init", NULL, js_init, NULL, NULL, NULL, napi_default, NULL},
         {"shutdown", NULL, js_shutdown, NULL, NULL, NULL, napi_default, NULL},

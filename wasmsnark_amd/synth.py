@@ -43,11 +43,17 @@ class Circuit:
         self.witness = witness
 
 
-def make_circuit(log_domain, n_public=2, seed=1, nnz_extra=0.5):
+def make_circuit(log_domain, n_public=2, seed=1, nnz_extra=0.5, style="columns"):
     """Multiplication-chain circuit with domainSize = 2^log_domain exactly:
     nConstraints = domain - nPublic - 1 'real' rows, then the nPublic+1 input-binding rows
     (w_i * 0 = 0) old snarkjs appends.  Every constraint defines one
-    fresh variable: w[out] = (sum A w)(sum B w), so the witness is computed on the fly."""
+    fresh variable: w[out] = (sum A w)(sum B w), so the witness is computed on the fly.
+
+    style="columns" (default; the shape SURVEY.md section 8d C4 specifies): every variable occurs in 1-3 rows
+    of A and in 1-3 rows of B (rows that come after its own definition; a row left empty gets one fill-in term),
+    so every key point of A, B1, B2 is a real point -- except for the very last variable, which no later row can use.
+    style="rows" (round 1): 1-2 terms per ROW drawn among the earlier variables; ~40 % of the variables then
+    never occur in A (resp. B) and their key points are infinity -- the sparse case the plan variants exploit."""
     rnd = random.Random(seed)
     domain = 1 << log_domain
     n_cons = domain - n_public - 1
@@ -62,27 +68,56 @@ def make_circuit(log_domain, n_public=2, seed=1, nnz_extra=0.5):
     A = [dict() for _ in range(n_vars)]
     B = [dict() for _ in range(n_vars)]
     Cm = [dict() for _ in range(n_vars)]
-    for c in range(n_cons):
-        out = 1 + n_free + c
-        lhs = rhs = 0
-        for M, acc in ((A, 0), (B, 1)):
-            k = 1 + (1 if rnd.random() < nnz_extra else 0)
-            tot = 0
-            used = set()
-            for _ in range(k):
-                s = rnd.randrange(0, out)
-                if s in used:
+    coef_of = lambda: rnd.randrange(1, R) if rnd.random() < 0.5 else rnd.randrange(1, 8)
+    if style == "columns":
+        rows = {id(A): [[] for _ in range(n_cons)], id(B): [[] for _ in range(n_cons)]}
+        for M in (A, B):
+            rw = rows[id(M)]
+            for s in range(n_vars):
+                c_min = max(0, s - n_free)          # first row whose output variable comes after s
+                if c_min >= n_cons:
                     continue
-                used.add(s)
-                coef = rnd.randrange(1, R) if rnd.random() < 0.5 else rnd.randrange(1, 8)
-                M[s][c] = coef
-                tot = (tot + coef * w[s]) % R
-            if acc == 0:
-                lhs = tot
-            else:
-                rhs = tot
-        Cm[out][c] = 1
-        w[out] = lhs * rhs % R
+                for _ in range(rnd.randrange(1, 4)):
+                    c = rnd.randrange(c_min, n_cons)
+                    if c not in M[s]:
+                        M[s][c] = cf = coef_of()
+                        rw[c].append((s, cf))
+            for c in range(n_cons):
+                if not rw[c]:
+                    s = rnd.randrange(0, 1 + n_free + c)
+                    M[s][c] = cf = coef_of()
+                    rw[c].append((s, cf))
+        rA, rB = rows[id(A)], rows[id(B)]
+        for c in range(n_cons):
+            out = 1 + n_free + c
+            lhs = sum(cf * w[s] for s, cf in rA[c]) % R
+            rhs = sum(cf * w[s] for s, cf in rB[c]) % R
+            Cm[out][c] = 1
+            w[out] = lhs * rhs % R
+    elif style == "rows":
+        for c in range(n_cons):
+            out = 1 + n_free + c
+            lhs = rhs = 0
+            for M, acc in ((A, 0), (B, 1)):
+                k = 1 + (1 if rnd.random() < nnz_extra else 0)
+                tot = 0
+                used = set()
+                for _ in range(k):
+                    s = rnd.randrange(0, out)
+                    if s in used:
+                        continue
+                    used.add(s)
+                    coef = coef_of()
+                    M[s][c] = coef
+                    tot = (tot + coef * w[s]) % R
+                if acc == 0:
+                    lhs = tot
+                else:
+                    rhs = tot
+            Cm[out][c] = 1
+            w[out] = lhs * rhs % R
+    else:
+        raise ValueError("style must be 'columns' or 'rows'")
     for i in range(n_public + 1):              # input-binding rows: A = w_i, B = 0, C = 0
         A[i][n_cons + i] = 1
     return Circuit(n_vars, n_public, domain, A, B, Cm, w)
