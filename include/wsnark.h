@@ -94,6 +94,17 @@ int wsnark_g2_msm_windows_dev(const void* d_scalars, const void* d_points_affine
  * inverse with n == 1 is rejected (the reference never returns, :575-583). */
 int wsnark_fr_ntt(void* buf, uint64_t n, int odd, int inverse);
 int wsnark_fr_ntt_dev(void* d_buf, uint64_t n, int odd, int inverse, void* stream);
+/* Building blocks of the DISTRIBUTED transform (four-step, n = n1 * n2 over the ranks of one node; orchestrated by
+ * wasmsnark_amd/dist.py: dist_ntt -- the reference never parallelises a transform, src/bn128.js:126-166 runs CALC_H
+ * on one worker).  batch: `count` independent length-n transforms stored back to back (the column step and the row
+ * step), same semantics per transform as wsnark_fr_ntt_dev with odd = 0.  dist_scale: element (r, c) of a rank's
+ * rows x cols row-major block stands at global position t = (row0 + r) + 2^log_n1 * c of the length-2^log_n vector
+ * (cols must be 2^(log_n - log_n1)) and is multiplied by
+ *   mode 0: w_n^((row0 + r) * c)  -- the twiddle between the two steps (inverse != 0: the inverse root)
+ *   mode 1: w_2n^t                -- the coset pre-scale of odd = 1 (src/build_fft.js:159-187) */
+int wsnark_fr_ntt_batch_dev(void* d_buf, uint64_t n, uint64_t count, int inverse, void* stream);
+int wsnark_fr_dist_scale_dev(void* d_buf, uint64_t rows, uint64_t cols, uint64_t row0, uint32_t log_n1, uint32_t log_n, int mode,
+                             int inverse, void* stream);
 /* fft_toMontgomeryN / fft_fromMontgomeryN (src/build_fft.js:418-458, 507-547) */
 int wsnark_fr_to_montgomery(const void* in, void* out, uint64_t n);
 int wsnark_fr_from_montgomery(const void* in, void* out, uint64_t n);
@@ -142,6 +153,17 @@ int wsnark_groth16_prove(wsnark_pkey_t* handle, const void* witness, size_t witn
 /* same, witness already on the device */
 int wsnark_groth16_prove_dev(wsnark_pkey_t* handle, const void* d_witness, size_t witness_len, const void* r32,
                              const void* s32, void* out384_host, void* stream);
+
+/* Bn128.groth16Verify (src/bn128.js:722-791; pairing bn128_pairingEq4, src/bn128/build_bn128.js:265-1374): native host
+ * arithmetic, no GPU and no wsnark_init needed.  Checks e(A,B) e(-IC(inputs),gamma2) e(-C,delta2) e(-alfa1,beta2) == 1.
+ *   vk     : alfa1 (64 B) | beta2 (128 B) | gamma2 (128 B) | delta2 (128 B) | IC[0 .. n_inputs] (64 B each) -- the points
+ *            of verification_key.json as affine PLAIN (non-Montgomery) little-endian integers, G2 as (x.c0, x.c1, y.c0, y.c1)
+ *   inputs : n_inputs x 32 B plain little-endian public signals; one >= r gives *valid = 0 like the reference (:772)
+ *   proof384: what wsnark_groth16_prove writes (pi_a | pi_b | pi_c with their z coordinates; z == 0 = infinity)
+ * Returns WSNARK_OK with *valid = 1 / 0; WSNARK_ERR_FORMAT if a coordinate is not a reduced field element,
+ * WSNARK_ERR_SIZE if vk holds fewer than n_inputs + 1 IC points.  Like the reference it does not test curve or
+ * subgroup membership of the proof points. */
+int wsnark_groth16_verify(const void* vk, size_t vk_len, const void* inputs, uint64_t n_inputs, const void* proof384, int* valid);
 
 /* The two 32-byte blinding values of the last proof assembled by the CALLING THREAD (wsnark_groth16_prove[_dev] or
  * _prove_finish), whether injected or drawn from the OS CSPRNG: the reference keeps them the same way, "for tests",

@@ -1,0 +1,75 @@
+"""Distributed four-step NTT (wasmsnark_amd/dist.py: dist_ntt) on CPU: two processes on gloo, kernel sources under the
+thread emulator, against the pinned oracle's fft / ifft (reference semantics, src/build_fft.js:159-221): bit-exact for
+2^4 .. 2^14, odd 0/1, forward and inverse; plus a chain (inverse, coset forward) without any re-layout in between."""
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+WORKER = r'''
+import os, sys, random
+sys.path.insert(0, os.environ["WS_ROOT"]); sys.path.insert(0, os.path.join(os.environ["WS_ROOT"], "tests"))
+import torch, torch.distributed as dist
+from emul_util import emul_bn128
+from oracle import pyoracle as orc
+from wasmsnark_amd import dist as wd
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+bn = emul_bn128()
+def gather(y):
+    parts = [torch.empty_like(y) for _ in range(world)]
+    dist.all_gather(parts, y)
+    return torch.cat(parts)
+for bits in (4, 5, 10, 11, 14):
+    n = 1 << bits
+    rnd = random.Random(bits)
+    x = orc.to_mont_n(b"".join(rnd.randrange(orc.R).to_bytes(32, "little") for _ in range(n)))
+    full = torch.frombuffer(bytearray(x), dtype=torch.uint8)
+    l1, l2 = wd.ntt_layout_split(bits, world)
+    for odd in (0, 1):
+        for inverse in (False, True):
+            loc = wd.to_interleaved(full, l1, rank, world).clone()
+            y = wd.dist_ntt(bn, loc, bits, odd=odd, inverse=inverse)
+            got = wd.from_interleaved(gather(y), l2).numpy().tobytes()
+            assert got == orc.fft(x, n, odd, inverse=inverse), (bits, odd, inverse, rank)
+# a chain as in CALC_H (src/bn128.js:150-153): coefficients = ifft(x), then evaluations on the odd coset = fft(., odd=1);
+# with n1 == n2 the output layout of one transform is the input layout of the next
+bits = 10
+n = 1 << bits
+rnd = random.Random(99)
+x = orc.to_mont_n(b"".join(rnd.randrange(orc.R).to_bytes(32, "little") for _ in range(n)))
+l1, l2 = wd.ntt_layout_split(bits, world)
+assert l1 == l2
+loc = wd.to_interleaved(torch.frombuffer(bytearray(x), dtype=torch.uint8), l1, rank, world).clone()
+y = wd.dist_ntt(bn, wd.dist_ntt(bn, loc, bits, inverse=True), bits, odd=1)
+want = orc.fft(orc.fft(x, n, 0, inverse=True), n, 1)
+assert wd.from_interleaved(gather(y), l2).numpy().tobytes() == want
+dist.barrier()
+open(os.path.join(os.environ["WS_OUT"], "rank%d.ok" % rank), "w").write("ok")
+'''
+
+
+def test_dist_ntt_world2(tmp_path):
+    from emul_util import emul_bn128
+    emul_bn128()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, WS_ROOT=ROOT, WS_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29641", str(script)],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
+
+
+def test_layout_helpers_roundtrip():
+    import torch
+    from wasmsnark_amd import dist as wd
+    n, log_m, world = 64, 3, 4
+    x = torch.arange(n * 32, dtype=torch.int64).to(torch.uint8)
+    parts = torch.cat([wd.to_interleaved(x, log_m, r, world) for r in range(world)])
+    assert torch.equal(wd.from_interleaved(parts, log_m), x)
+    # rank 1 of 4 with m = 8 holds residues 2, 3: first row = elements 2, 10, 18, ...
+    row0 = wd.to_interleaved(x, log_m, 1, world)[:32 * 8].view(8, 32)
+    assert torch.equal(row0[1], x.view(n, 32)[10])

@@ -21,7 +21,7 @@ if ! skip bench; then
 fi
 PROF_CMD="python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --extras msm,ntt"
 if ! skip prof; then
-  ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$O/prof" -o prof -- $PROF_CMD ) > "$O/prof.log" 2>&1
+  ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$O/prof" -o prof -- $PROF_CMD ) > "$O/prof.log" 2>&1
   echo "rocprof rc=$?" >> "$O/env.log"
   find "$O/prof" -name "*kernel_stats.csv" -exec cp {} "$O/kernel_stats.csv" \; 2>/dev/null
   find "$O/prof" -name "*kernel_trace.csv" -size +8M -delete 2>/dev/null

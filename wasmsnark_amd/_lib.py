@@ -18,9 +18,9 @@ SYMBOLS = [
     "wsnark_g1_msm", "wsnark_g2_msm", "wsnark_g1_msm_dev", "wsnark_g2_msm_dev",
     "wsnark_g1_msm_windows", "wsnark_g2_msm_windows", "wsnark_g1_msm_windows_dev", "wsnark_g2_msm_windows_dev",
     "wsnark_g1_sum", "wsnark_g2_sum",
-    "wsnark_fr_ntt", "wsnark_fr_ntt_dev", "wsnark_fr_to_montgomery", "wsnark_fr_from_montgomery",
+    "wsnark_fr_ntt", "wsnark_fr_ntt_dev", "wsnark_fr_ntt_batch_dev", "wsnark_fr_dist_scale_dev", "wsnark_fr_to_montgomery", "wsnark_fr_from_montgomery",
     "wsnark_calc_h", "wsnark_pkey_load", "wsnark_pkey_free", "wsnark_pkey_info",
-    "wsnark_groth16_prove", "wsnark_groth16_prove_dev", "wsnark_pkey_load_sections", "wsnark_last_blinding",
+    "wsnark_groth16_prove", "wsnark_groth16_prove_dev", "wsnark_pkey_load_sections", "wsnark_last_blinding", "wsnark_groth16_verify",
     "wsnark_groth16_prove_partial", "wsnark_groth16_prove_partial_dev", "wsnark_groth16_prove_finish",
     "wsnark_g1_mul_base_batch", "wsnark_g2_mul_base_batch",
     "wsnark_selftest_field", "wsnark_selftest_curve",
@@ -63,6 +63,8 @@ class Lib:
         c.wsnark_g2_sum.argtypes = [vp, u64, vp]
         c.wsnark_fr_ntt.argtypes = [vp, u64, C.c_int, C.c_int]
         c.wsnark_fr_ntt_dev.argtypes = [vp, u64, C.c_int, C.c_int, vp]
+        c.wsnark_fr_ntt_batch_dev.argtypes = [vp, u64, u64, C.c_int, vp]
+        c.wsnark_fr_dist_scale_dev.argtypes = [vp, u64, u64, u64, u32, u32, C.c_int, C.c_int, vp]
         c.wsnark_fr_to_montgomery.argtypes = [vp, vp, u64]
         c.wsnark_fr_from_montgomery.argtypes = [vp, vp, u64]
         c.wsnark_calc_h.argtypes = [vp, vp, sz, vp, sz, u32, u32, vp]
@@ -76,6 +78,7 @@ class Lib:
         c.wsnark_groth16_prove_partial.argtypes = [vp, vp, sz, u32, u32, vp]
         c.wsnark_groth16_prove_partial_dev.argtypes = [vp, vp, sz, u32, u32, vp, vp]
         c.wsnark_last_blinding.argtypes = [vp, vp]
+        c.wsnark_groth16_verify.argtypes = [vp, sz, vp, u64, vp, C.POINTER(C.c_int)]
         c.wsnark_selftest_field.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, u64]
         c.wsnark_selftest_curve.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, u64]
         c.wsnark_groth16_prove_finish.argtypes = [vp, vp, u64, vp, vp, vp]

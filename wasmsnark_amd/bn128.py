@@ -247,6 +247,13 @@ class Bn128:
             key.free()
         return proof_from_bytes(bytes(out))
 
+    # --- src/bn128.js:722-791 ---
+    def groth16Verify(self, verificationKey, input, proof):
+        """verificationKey: the snarkjs "groth" verification_key.json object (vk_alfa_1, vk_beta_2, vk_gamma_2, vk_delta_2,
+        IC; vk_alfabeta_12 is not needed); input: public signals (decimal strings / ints, a single value is wrapped like
+        the reference does, :724-728); proof: {pi_a, pi_b, pi_c} of decimal strings.  Returns True / False."""
+        return groth16_verify(self.lib, verificationKey, input, proof)
+
     def terminate(self):  # src/bn128.js:562-566
         self.lib.shutdown()
 
@@ -255,6 +262,39 @@ def proof_from_bytes(b):
     """bin2g1 / bin2g2 of the reference (src/bn128.js:319-351, 714-718)."""
     v = [str(int.from_bytes(b[i:i + 32], "little")) for i in range(0, 384, 32)]
     return {"pi_a": v[0:3], "pi_b": [v[3:5], v[5:7], v[7:9]], "pi_c": v[9:12]}
+
+
+def proof_to_bytes(proof):
+    """Inverse of proof_from_bytes: {pi_a, pi_b, pi_c} of decimal strings -> the 384 bytes wsnark_groth16_prove writes."""
+    le = lambda v: int(v).to_bytes(32, "little")
+    a, b, c = proof["pi_a"], proof["pi_b"], proof["pi_c"]
+    return (b"".join(le(x) for x in a) + b"".join(le(x) for pair in b for x in pair) + b"".join(le(x) for x in c))
+
+
+def vk_to_bytes(vk, n_inputs):
+    le = lambda v: int(v).to_bytes(32, "little")
+    g1 = lambda p: le(p[0]) + le(p[1])
+    g2 = lambda p: le(p[0][0]) + le(p[0][1]) + le(p[1][0]) + le(p[1][1])
+    if len(vk["IC"]) < n_inputs + 1:
+        raise ValueError("verification key has %d IC points, %d inputs given" % (len(vk["IC"]), n_inputs))
+    return (g1(vk["vk_alfa_1"]) + g2(vk["vk_beta_2"]) + g2(vk["vk_gamma_2"]) + g2(vk["vk_delta_2"])
+            + b"".join(g1(p) for p in vk["IC"][:n_inputs + 1]))
+
+
+def groth16_verify(lib, verificationKey, input, proof):
+    """Bn128.groth16Verify (src/bn128.js:722-791) over wsnark_groth16_verify: host arithmetic, no GPU needed."""
+    if input is None:
+        input = []
+    elif not isinstance(input, (list, tuple)):
+        input = [input]
+    vals = [int(x) for x in input]
+    if any(v < 0 or v >= 1 << 256 for v in vals):
+        return False
+    vkb = vk_to_bytes(verificationKey, len(vals))
+    inp = b"".join(v.to_bytes(32, "little") for v in vals)
+    valid = C.c_int(0)
+    lib.check(lib.c.wsnark_groth16_verify(vkb, len(vkb), inp if vals else None, len(vals), proof_to_bytes(proof), C.byref(valid)))
+    return bool(valid.value)
 
 
 def build(lib=None, device=-1):

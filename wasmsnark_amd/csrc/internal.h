@@ -114,7 +114,9 @@ Context* ctx();   // nullptr before wsnark_init
 //   forward: y[k] = sum_i x[i] * w_{2n}^{(2k+odd) i}       (natural order in and out)
 //   inverse: rawfft, then y[i] = raw[(n-i) mod n] / n
 // The multi-pass scratch comes from lane L (the caller holds it).
-int ntt_dev(Lane& L, Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s);
+// count > 1: that many independent transforms stored back to back (the row / column steps of the four-step transform)
+int ntt_dev(Lane& L, Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s, uint64_t count = 1);
+int ntt_twiddle_tables(int bits, int inverse, const Fe** lo, const Fe** hi, int* h, hipStream_t s);
 
 int ntt_coset_tables(int bits, const Fe** lo, const Fe** hi, int* hc, Fe* n_inv, hipStream_t s);
 

@@ -86,6 +86,9 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
     LdsTile<F> tile(sm, LT);
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     const uint32_t w = blockIdx.x;
+    // batched form: blockIdx.y selects one of several independent transforms stored back to back
+    const Fe* __restrict__ src = A.in + ((uint64_t)blockIdx.y << A.log_n);
+    Fe* __restrict__ dst = A.out + ((uint64_t)blockIdx.y << A.log_n);
 
     // ---- tile coordinates ----
     uint64_t base = 0;       // non-last: hi*L*S + lo0
@@ -113,13 +116,13 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
             j = idx & (L - 1); t = idx >> log_L;
             g = ((uint64_t)(a0 + t) << A.log_S0) + ((uint64_t)mid << log_L) + j;
         }
-        El v = F::unpack(A.in[g]);
+        El v = F::unpack(src[g]);
         if (A.prescale) {   // only ever set for pass 0, where storage index == input index
             const uint32_t e = (uint32_t)g;
             El f = F::mul(F::unpack(A.cs_hi[e >> A.hc]), F::unpack(A.cs_lo[e & ((1u << A.hc) - 1)]));
             v = F::mul(v, f);          // (radix-2^29: cs_lo carries the extra 2^5 => also converts the domain)
         } else if (F::kInternalDomain && A.first && !A.fold_in) {
-            v = F::to_internal(A.in[g]);
+            v = F::to_internal(src[g]);
         }
         tile.put((j << log_T) + t, v);
     }
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
                 El f = F::mul(F::unpack(A.tw_hi[e >> A.h]), F::unpack(A.tw_lo[e & ((1u << A.h) - 1)]));
                 v = F::mul(v, f);
             }
-            A.out[base + ((uint64_t)kk << A.log_S) + t] = F::pack(v);
+            dst[base + ((uint64_t)kk << A.log_S) + t] = F::pack(v);
         }
     } else {
         // digit-reverse the middle digits k_1..k_{np-2} of this tile
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
                 if (A.scale) v = F::mul(v, F::unpack(A.out_scale));
                 o = F::pack(v);
             }
-            A.out[((uint64_t)kk << log_rest) + revmid + a0 + t] = o;
+            dst[((uint64_t)kk << log_rest) + revmid + a0 + t] = o;
         }
     }
 }
@@ -249,6 +252,7 @@ struct NttPlan {
     DevBuf tw_small[2], tw_lo[2], tw_hi[2];   // [0] forward root, [1] inverse root
     DevBuf cs_lo, cs_hi;                      // coset w_{2n}^i (forward root), format of the NTT kernel
     DevBuf cs_lo_ref, cs_hi_ref;              // the same in the reference Montgomery form (calch.hip)
+    DevBuf tw_lo_ref[2], tw_hi_ref[2];        // w_n^e two-level in the reference form (dist_scale: four-step inter-digit twiddle)
     DevBuf tw_full[2][4][2];                  // [dir][pass][fold_in]: full per-pass twiddles (radix-2^29, np >= 2)
     Fe n_inv;                                 // reference Montgomery form of 1/n
 };
@@ -297,9 +301,11 @@ static int build_plan(int bits, NttPlan& P, hipStream_t s) {
         if (f29) scale32(tmp);
         int rc = upload(P.tw_small[dir], tmp, s); if (rc) return rc;
         powers(wn, (size_t)1 << P.h, tmp);
+        rc = upload(P.tw_lo_ref[dir], tmp, s); if (rc) return rc;
         if (f29) scale32(tmp);
         rc = upload(P.tw_lo[dir], tmp, s); if (rc) return rc;
         powers(Fr::pow_u64(wn, (uint64_t)1 << P.h), (size_t)1 << (bits - P.h), tmp);
+        rc = upload(P.tw_hi_ref[dir], tmp, s); if (rc) return rc;
         if (f29) scale32(tmp);
         rc = upload(P.tw_hi[dir], tmp, s); if (rc) return rc;
     }
@@ -348,7 +354,19 @@ int ntt_coset_tables(int bits, const Fe** lo, const Fe** hi, int* hc, Fe* n_inv,
     return WS_OK;
 }
 
-int ntt_dev(Lane& L, Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s) {
+// w_n^(+-e), e < n = 2^bits, two-level in the reference Montgomery form: value = hi[e >> h] * lo[e & mask]
+int ntt_twiddle_tables(int bits, int inverse, const Fe** lo, const Fe** hi, int* h, hipStream_t s) {
+    Context* C = ctx();
+    if (!C) return WS_ERR_NOINIT;
+    if (bits < 1 || bits > 28) return WS_ERR_SIZE;
+    std::shared_ptr<NttPlan> P;
+    int rc = get_plan(C, bits, P, s);
+    if (rc) return rc;
+    *lo = P->tw_lo_ref[inverse ? 1 : 0].as<Fe>(); *hi = P->tw_hi_ref[inverse ? 1 : 0].as<Fe>(); *h = P->h;
+    return WS_OK;
+}
+
+int ntt_dev(Lane& L, Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s, uint64_t count) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
     if (!d_data) return WS_ERR_ARG;
@@ -358,6 +376,8 @@ int ntt_dev(Lane& L, Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s
     int bits = 0;
     while (((uint64_t)1 << bits) < n) bits++;
     if (odd && bits >= 28) return WS_ERR_SIZE;   // needs w_{2^29}, which does not exist
+    if (count == 0) return WS_OK;
+    if (count > 65535 || n * count > ((uint64_t)1 << 30)) return WS_ERR_SIZE;
     if (bits == 0) {
         // fft(n=1) is the identity; ifft(n=1) never terminates in the reference
         // (src/build_fft.js:575-583) -> reported as a size error here
@@ -368,7 +388,7 @@ int ntt_dev(Lane& L, Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s
     {
         int rc = get_plan(C, bits, P, s);
         if (rc) return rc;
-        if (P->np > 1) WS_HIP_CHECK(L.ntt_scratch.reserve(n * sizeof(Fe)));
+        if (P->np > 1) WS_HIP_CHECK(L.ntt_scratch.reserve(n * count * sizeof(Fe)));
     }
     Fe* scratch = L.ntt_scratch.as<Fe>();
     // inverse (reference semantics): raw forward transform, then y[i] = raw[(n-i) mod n]/n
@@ -444,10 +464,10 @@ int ntt_dev(Lane& L, Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * 36));
                 attr_set = true;
             }
-            hipLaunchKernelGGL(ntt_pass_kernel<Fr29>, dim3(grid), dim3(512 >> (11 - tile_log)), smem, s, A);
+            hipLaunchKernelGGL(ntt_pass_kernel<Fr29>, dim3(grid, (uint32_t)count), dim3(512 >> (11 - tile_log)), smem, s, A);
         } else {
             const size_t smem = elems * LdsTile<Fr>::kBytes;
-            hipLaunchKernelGGL(ntt_pass_kernel<Fr>, dim3(grid), dim3(512), smem, s, A);
+            hipLaunchKernelGGL(ntt_pass_kernel<Fr>, dim3(grid, (uint32_t)count), dim3(512), smem, s, A);
         }
         C->timer.end(s);
         WS_HIP_CHECK(hipGetLastError());
