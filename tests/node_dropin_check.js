@@ -74,6 +74,23 @@ const toAB = (b) => b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength);
         a3[100] ^= 0xff;
         if ((await bn.loadKey(a3)) === hk) throw new Error("stale key handle returned for changed bytes");
     }
+    // groth16Verify (main_bn128.js:41-55, src/bn128.js:722-791): the proofs just produced verify natively, a wrong input does not
+    {
+        const vk = JSON.parse(fs.readFileSync(path.join(gold, "keys", "t6.vk.json"), "utf8"));
+        const pub = JSON.parse(fs.readFileSync(path.join(gold, "keys", "t6.public.json"), "utf8"));
+        const w6 = fs.readFileSync(path.join(gold, "keys", "t6.witness.bin")), k6 = fs.readFileSync(path.join(gold, "keys", "t6.pkey.bin"));
+        const fresh = await bn.groth16GenProof(w6, k6);                       // library-drawn blinding
+        if ((await bn.groth16Verify(vk, pub, fresh)) !== true) throw new Error("fresh proof does not verify");
+        const wrong = pub.slice(); wrong[0] = (BigInt(wrong[0]) + 1n).toString();
+        if ((await bn.groth16Verify(vk, wrong, fresh)) !== false) throw new Error("wrong public input accepted");
+        const viaCb = await new Promise((res, rej) => ws.groth16Verify(vk, pub, fresh, (e, ok) => e ? rej(e) : res(ok)));
+        if (viaCb !== true) throw new Error("callback form of groth16Verify");
+        const ref = JSON.parse(fs.readFileSync(path.join(gold, "verify.json"), "utf8"));
+        for (const c of ref.cases) {
+            if ((await bn.groth16Verify(ref.verification_key, c.inputs, c.proof)) !== c.reference_verdict) throw new Error("verdict differs from the reference: " + c.label);
+            checked++;
+        }
+    }
     // error path: rejected Promise, not a hang (the reference hangs: SURVEY section 5)
     let rejected = false;
     try { await bn.fft(new Uint8Array(96), 0); } catch (e) { rejected = true; }

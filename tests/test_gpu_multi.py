@@ -50,6 +50,21 @@ for c in json.load(open(os.path.join(gold, "proofs.json")))["t6"]:
     r, s = bytes.fromhex(c["r"]), bytes.fromhex(c["s"])
     assert wd.sharded_prove(bn, key, wit, r=r, s=s, device=dev) == c["proof"], ("sharded prove", rank)
     assert wd.sharded_prove(bn, key, None, r=r, s=s, device=dev, d_witness=(d_w.data_ptr(), len(wit))) == c["proof"]
+# distributed four-step NTT over RCCL (one all_to_all_single per transform) against the single-GPU transform
+for bits in (10, 16, 20):
+    n = 1 << bits
+    g = torch.Generator(device="cpu").manual_seed(bits)
+    x = torch.randint(0, 256, (n * 32,), dtype=torch.uint8, generator=g)
+    x[31::32] &= 0x1F
+    d = x.to(dev)
+    l1, l2 = wd.ntt_layout_split(bits, world)
+    for odd, inverse in ((0, False), (1, False), (0, True), (1, True)):
+        ref = d.clone(); torch.cuda.synchronize()
+        bn.fft_dev(ref.data_ptr(), n, odd, inverse=inverse); torch.cuda.synchronize()
+        y = wd.dist_ntt(bn, wd.to_interleaved(d, l1, rank, world).clone(), bits, odd=odd, inverse=inverse)
+        parts = [torch.empty_like(y) for _ in range(world)]
+        dist.all_gather(parts, y)
+        assert torch.equal(wd.from_interleaved(torch.cat(parts), l2), ref), ("dist_ntt", bits, odd, inverse, rank)
 got = wd.sharded_prove(bn, key, wit, device=dev)                  # rank 0 draws r, s: all ranks, one proof
 r_used, s_used = bn.last_blinding()
 assert got == bn.groth16GenProof(wit, key, r=r_used, s=s_used)

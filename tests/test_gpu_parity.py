@@ -531,3 +531,47 @@ def test_ntt_2p25_four_pass_roundtrip_and_linearity(bn):
     sync()
     assert torch.equal(z, d)                        # ifft(fft(x)) == x
     assert not torch.equal(y, d)
+
+
+@pytest.mark.parametrize("bits", [6, 11, 16, 20, 22])
+def test_four_step_ntt_building_blocks_on_gpu(bn, orc, bits):
+    """wsnark_fr_ntt_batch_dev + wsnark_fr_dist_scale_dev through dist_ntt with a world of one (column step, twiddle,
+    transpose, row step on ONE GPU): bit-identical to the single-kernel-chain transform wsnark_fr_ntt_dev for odd 0/1,
+    forward and inverse (and to the oracle where it is fast).  The N > 1 exchange itself is in tests/test_gpu_multi.py
+    (nccl) and tests/test_dist_ntt_gloo.py (CPU)."""
+    import torch
+    from wasmsnark_amd import dist as wd
+    n = 1 << bits
+    g = torch.Generator(device="cpu").manual_seed(bits)
+    x = torch.randint(0, 256, (n * 32,), dtype=torch.uint8, generator=g)
+    x[31::32] &= 0x1F
+    d = x.cuda()
+    l1, l2 = wd.ntt_layout_split(bits, 1)
+    for odd in (0, 1):
+        for inverse in (False, True):
+            ref = d.clone()
+            torch.cuda.synchronize()
+            bn.fft_dev(ref.data_ptr(), n, odd, inverse=inverse)
+            torch.cuda.synchronize()
+            loc = wd.to_interleaved(d, l1, 0, 1).clone()
+            y = wd.from_interleaved(wd.dist_ntt(bn, loc, bits, odd=odd, inverse=inverse), l2)
+            assert torch.equal(y, ref), (bits, odd, inverse)
+            if bits <= 16:
+                assert ref.cpu().numpy().tobytes() == orc.fft(x.numpy().tobytes(), n, odd, inverse=inverse)
+
+
+def test_native_verifier_accepts_gpu_proofs(bn):
+    """wsnark_groth16_verify (host pairing) on proofs the GPU just produced -- with library-drawn blinding, so that nothing
+    but the verifier vouches for them -- and rejects them for a wrong public input."""
+    from wasmsnark_amd import synth
+    circ = synth.make_circuit(14, n_public=4, seed=141)
+    S = synth.setup(circ, seed=14)
+    pkey, vk = synth.build_key(circ, S, bn.mul_base)
+    key = bn.load_key(pkey)
+    wit = synth.witness_bin(circ)
+    pub = synth.public_signals(circ)
+    for _ in range(2):
+        proof = bn.groth16GenProof(wit, key)
+        assert bn.groth16Verify(vk, pub, proof) is True
+        assert bn.groth16Verify(vk, [str(int(pub[0]) + 1)] + pub[1:], proof) is False
+    key.free()

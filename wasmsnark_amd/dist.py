@@ -134,7 +134,10 @@ def dist_ntt(bn, x_local, log_n, odd=0, inverse=False, group=None):
     ranks.  x_local: this rank's uint8 tensor in the n1-interleaved layout (to_interleaved(x, log_n1, ...)) on the
     device the library runs on; it is overwritten.  Returns the rank's slice of the result in the n2-interleaved layout
     (from_interleaved(all slices, log_n2) is the natural-order vector).  One all-to-all."""
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if dist.is_available() and dist.is_initialized():
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    else:
+        world, rank = 1, 0            # a world of one: the same four steps, the exchange is the identity
     log_n1, log_n2 = ntt_layout_split(log_n, world)
     n1, n2 = 1 << log_n1, 1 << log_n2
     r1, r2 = n1 // world, n2 // world
@@ -152,8 +155,11 @@ def dist_ntt(bn, x_local, log_n, odd=0, inverse=False, group=None):
     bn.lib.c.wsnark_timing_report(None, 0)                                        # the library's queues have drained
     sync()
     send = x_local.view(r1, world, r2, 32).permute(1, 0, 2, 3).contiguous().view(-1)   # block q = my rows x rank q's columns
-    recv = torch.empty_like(send)
-    _all_to_all(recv, send, group)
+    if world == 1:
+        recv = send
+    else:
+        recv = torch.empty_like(send)
+        _all_to_all(recv, send, group)
     # received block q = rank q's rows (its i1 range) x my columns  ->  (my k2) x (all i1)
     y = recv.view(world, r1, r2, 32).permute(2, 0, 1, 3).contiguous().view(-1)
     sync()

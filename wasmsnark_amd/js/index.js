@@ -77,7 +77,27 @@ class Bn128 {
         this._ps = new Uint8Array(out.slice(416, 448));
         return proofFromBytes(out.slice(0, 384));
     }
+    /* src/bn128.js:722-791: verificationKey = snarkjs "groth" verification_key.json object, input = public signals
+     * (one value is wrapped like the reference does), proof = {pi_a, pi_b, pi_c}.  Native host arithmetic, no GPU. */
+    async groth16Verify(verificationKey, input, proof) {
+        if (input === undefined || input === null) input = [];
+        else if (!Array.isArray(input)) input = [input];
+        const vals = input.map((x) => BigInt(x));
+        if (vals.some((v) => v < 0n || v >= (1n << 256n))) return false;
+        const IC = verificationKey.IC;
+        if (!IC || IC.length < vals.length + 1) throw new Error("verification key has fewer IC points than inputs + 1");
+        const g1 = (p) => [p[0], p[1]], g2 = (p) => [p[0][0], p[0][1], p[1][0], p[1][1]];
+        const vk = le32cat([].concat(g1(verificationKey.vk_alfa_1), g2(verificationKey.vk_beta_2), g2(verificationKey.vk_gamma_2),
+            g2(verificationKey.vk_delta_2), ...IC.slice(0, vals.length + 1).map(g1)));
+        const pf = le32cat([].concat(proof.pi_a, proof.pi_b[0], proof.pi_b[1], proof.pi_b[2], proof.pi_c));
+        return addon.verify(vk, le32cat(vals), pf);
+    }
     terminate() { addon.shutdown(); }
+}
+function le32cat(list) {            // decimal strings / BigInts -> concatenated 32-byte little-endian integers
+    const out = new Uint8Array(32 * list.length);
+    list.forEach((x, k) => { let v = BigInt(x); for (let i = 0; i < 32; i++) { out[32 * k + i] = Number(v & 0xffn); v >>= 8n; } });
+    return out;
 }
 
 let singleton = null;
@@ -96,6 +116,15 @@ function groth16GenProof(witness, provingKey, cb) {   // main_bn128.js:26-39
     return p;
 }
 
+function groth16Verify(verificationKey, input, proof, cb) {   // main_bn128.js:41-55
+    const p = (async () => {
+        if (!singleton) singleton = await buildBn128();
+        return singleton.groth16Verify(verificationKey, input, proof);
+    })();
+    if (cb) { p.then((ok) => cb(null, ok), (err) => cb(err)); return undefined; }
+    return p;
+}
+
 const formats = require("./formats.js");     // snarkjs JSON -> proving_key.bin / witness.bin (reference tools/build*.js)
-module.exports = { buildBn128, groth16GenProof, genZKSnarkProof: groth16GenProof, Bn128, proofFromBytes,
+module.exports = { buildBn128, groth16GenProof, genZKSnarkProof: groth16GenProof, groth16Verify, Bn128, proofFromBytes,
     pkeyJsonToBin: formats.pkeyJsonToBin, witnessJsonToBin: formats.witnessJsonToBin };

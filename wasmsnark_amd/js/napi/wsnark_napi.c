@@ -35,6 +35,7 @@ static struct {
     int (*pkey_info)(const wsnark_pkey_t*, uint32_t*, uint32_t*, uint32_t*);
     int (*prove)(wsnark_pkey_t*, const void*, size_t, const void*, const void*, void*);
     int (*last_blinding)(void*, void*);
+    int (*verify)(const void*, size_t, const void*, uint64_t, const void*, int*);
     char dir[4096];
 } L;
 
@@ -60,7 +61,7 @@ static int load_lib(const char* explicit_path, char* err, size_t errlen) {
     SYM(device_info, "wsnark_device_info") SYM(g1_msm, "wsnark_g1_msm") SYM(g2_msm, "wsnark_g2_msm")
     SYM(fr_ntt, "wsnark_fr_ntt") SYM(calc_h, "wsnark_calc_h") SYM(pkey_load, "wsnark_pkey_load")
     SYM(pkey_free, "wsnark_pkey_free") SYM(pkey_info, "wsnark_pkey_info") SYM(prove, "wsnark_groth16_prove")
-    SYM(last_blinding, "wsnark_last_blinding")
+    SYM(last_blinding, "wsnark_last_blinding") SYM(verify, "wsnark_groth16_verify")
 #undef SYM
     return 0;
 }
@@ -86,7 +87,7 @@ static int get_bytes(napi_env env, napi_value v, uint8_t** p, size_t* n) {
     return 0;
 }
 
-enum { OP_G1, OP_G2, OP_NTT, OP_CALCH, OP_PROVE, OP_LOADKEY };
+enum { OP_G1, OP_G2, OP_NTT, OP_CALCH, OP_PROVE, OP_LOADKEY, OP_VERIFY };
 typedef struct {
     int op, rc;
     napi_async_work work;
@@ -116,6 +117,7 @@ static void job_execute(napi_env env, void* data) {
         if (!j->rc) j->rc = L.last_blinding(j->out + 384, j->out + 416);
         break;
     case OP_LOADKEY: j->rc = L.pkey_load(j->a, j->na, &j->key); break;
+    case OP_VERIFY: j->rc = L.verify(j->a, j->na, j->b, j->nb / 32, j->c, &j->i0); break;
     }
     if (j->rc) snprintf(j->err, sizeof j->err, "wsnark error %d: %s", j->rc, L.last_error());
 }
@@ -133,6 +135,9 @@ static void job_complete(napi_env env, napi_status status, void* data) {
         napi_create_string_utf8(env, j->rc ? j->err : "async work cancelled", NAPI_AUTO_LENGTH, &msg);
         napi_create_error(env, NULL, msg, &e);
         napi_reject_deferred(env, j->deferred, e);
+    } else if (j->op == OP_VERIFY) {
+        napi_get_boolean(env, j->i0 != 0, &res);
+        napi_resolve_deferred(env, j->deferred, res);
     } else if (j->op == OP_LOADKEY) {
         napi_create_external(env, j->key, key_finalize, NULL, &res);
         napi_resolve_deferred(env, j->deferred, res);
@@ -241,6 +246,19 @@ static napi_value js_prove(napi_env env, napi_callback_info info) {
     return start_job(env, j, "wsnark_groth16_prove");
 }
 
+/* verify(vkBytes, inputBytes, proof384) -> Promise<boolean>   (layouts: include/wsnark.h, wsnark_groth16_verify) */
+static napi_value js_verify(napi_env env, napi_callback_info info) {
+    size_t argc = 3; napi_value argv[3];
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    job_t* j = (job_t*)calloc(1, sizeof *j);
+    j->op = OP_VERIFY;
+    if (argc < 3 || !get_bytes(env, argv[0], &j->a, &j->na) || !get_bytes(env, argv[1], &j->b, &j->nb) ||
+        !get_bytes(env, argv[2], &j->c, &j->nc) || j->nc != 384 || j->nb % 32)
+        FAIL(env, j, "expected (vkBytes, inputBytes (n x 32), proof384)");
+    keep(env, j, argv[0]); keep(env, j, argv[1]); keep(env, j, argv[2]);
+    return start_job(env, j, "wsnark_groth16_verify");
+}
+
 static napi_value js_keyinfo(napi_env env, napi_callback_info info) {
     size_t argc = 1; napi_value argv[1], o, v;
     wsnark_pkey_t* k = NULL;
@@ -299,6 +317,7 @@ static napi_value module_init(napi_env env, napi_value exports) {
         {"loadKey", NULL, js_loadkey, NULL, NULL, NULL, napi_default, NULL},
         {"keyInfo", NULL, js_keyinfo, NULL, NULL, NULL, napi_default, NULL},
         {"prove", NULL, js_prove, NULL, NULL, NULL, napi_default, NULL},
+        {"verify", NULL, js_verify, NULL, NULL, NULL, napi_default, NULL},
     };
     CHECK(env, napi_define_properties(env, exports, sizeof props / sizeof props[0], props));
     return exports;
