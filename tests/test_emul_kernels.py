@@ -130,3 +130,25 @@ def test_calc_h_golden(bn):
     for c in load_golden("calch.json"):
         h = bn.calcH(B64(c["signals"]), B64(c["polsA"]), B64(c["polsB"]), c["nSignals"], c["domain"])
         assert h == B64(c["h"]), (c["nSignals"], c["domain"])
+
+
+def test_calc_h_fused_passes_vs_oracle(bn, orc):
+    """CALC_H with the pointwise products formed by the first pass of the following inverse transform and h stored by the
+    last pass of the final one (calch.hip / ntt.hip): two-pass size (per-pass folding tables) against the oracle's
+    step-by-step reference sequence (src/bn128.js:139-164)."""
+    import struct
+    rnd = random.Random(4096)
+    nS, dom = 700, 4096
+    sig = b"".join(rnd.randrange(orc.R).to_bytes(32, "little") for _ in range(nS))
+
+    def pols():
+        out = bytearray()
+        for s in range(nS):
+            k = rnd.randrange(0, 4)
+            out += struct.pack("<I", k)
+            for idx in rnd.sample(range(dom), k):
+                out += struct.pack("<I", idx) + rnd.randrange(orc.R).to_bytes(32, "little")
+        return bytes(out)
+
+    A, B = pols(), pols()
+    assert bn.calcH(sig, A, B, nS, dom) == orc.calc_h(sig, A, B, nS, dom)

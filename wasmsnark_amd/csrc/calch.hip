@@ -185,6 +185,22 @@ int calc_h_dev(Lane& L, const Fe* d_signals_plain, uint32_t n_signals, const Csr
     hipLaunchKernelGGL(lc_spmv_kernel, grd, blk, 0, s, A.row_ptr.as<uint32_t>(), A.col.as<uint32_t>(), A.coef.as<Fe>(), sigM, domain, a);
     hipLaunchKernelGGL(lc_spmv_kernel, grd, blk, 0, s, B.row_ptr.as<uint32_t>(), B.col.as<uint32_t>(), B.coef.as<Fe>(), sigM, domain, b);
     T.end(s);
+    // The pointwise products and the final combination are fused into the transforms next to them (WSNARK_CALCH_FUSE=0:
+    // separate kernels, for A/B runs): E = A.B is formed by the FIRST pass of its inverse transform while it loads,
+    // O = A.B on the coset likewise, and the last pass of that second transform stores h directly.  Saves three
+    // element-wise kernels (4 x 32 B x domain of traffic each) and their slow saturated-field products.
+    static const bool fuse = [] { const char* e = getenv("WSNARK_CALCH_FUSE"); return !(e && atoi(e) == 0); }();
+    const Fe *cs_lo, *cs_hi;
+    int hc;
+    Fe n_inv;
+    if (fuse) {
+        if ((rc = ntt_run(L, a, b, e, nullptr, domain, 0, 1, s))) return rc;   // e = iNTT(A.B)            (bn128.js:148, 160)
+        if ((rc = ntt_dev(L, a, domain, 0, 1, s))) return rc;                  // bn128.js:150-151  evaluations -> coefficients
+        if ((rc = ntt_dev(L, b, domain, 0, 1, s))) return rc;
+        if ((rc = ntt_dev(L, a, domain, 1, 0, s))) return rc;                  // bn128.js:152-153  -> odd-coset evaluations
+        if ((rc = ntt_dev(L, b, domain, 1, 0, s))) return rc;
+        return ntt_run(L, a, b, d_h_out, e, domain, 0, 1, s);                  // o = iNTT(A.B on the coset), h = combine(e, o)   (:158-164)
+    }
     T.begin("fr_pointwise", s);
     hipLaunchKernelGGL(fr_mul_kernel, grd, blk, 0, s, a, b, e, (uint64_t)domain);   // E = A.B on the domain
     T.end(s);
@@ -198,9 +214,6 @@ int calc_h_dev(Lane& L, const Fe* d_signals_plain, uint32_t n_signals, const Csr
     T.end(s);
     if ((rc = ntt_dev(L, e, domain, 0, 1, s))) return rc;               // bn128.js:160, split in two halves
     if ((rc = ntt_dev(L, a, domain, 0, 1, s))) return rc;
-    const Fe *cs_lo, *cs_hi;
-    int hc;
-    Fe n_inv;
     if ((rc = ntt_coset_tables(bits, &cs_lo, &cs_hi, &hc, &n_inv, s))) return rc;
     Fe half = Fr::inv(Fr::add(Fr::one(), Fr::one()));
     T.begin("calch_combine", s);                                     // bn128.js:162-164 (+ the upper-half selection)

@@ -116,6 +116,10 @@ Context* ctx();   // nullptr before wsnark_init
 // The multi-pass scratch comes from lane L (the caller holds it).
 // count > 1: that many independent transforms stored back to back (the row / column steps of the four-step transform)
 int ntt_dev(Lane& L, Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s, uint64_t count = 1);
+// the general form: reads d_src (times d_in2 element-wise, if given), writes d_dst; combine_e (inverse only): the last
+// pass stores CALC_H's h[t] = fromMontgomery((e[t] - w_2n^-t v[t]) / 2) instead of the transform v (calch.hip)
+int ntt_run(Lane& L, const Fe* d_src, const Fe* d_in2, Fe* d_dst, const Fe* combine_e, uint64_t n, int odd, int inverse,
+            hipStream_t s, uint64_t count = 1);
 int ntt_twiddle_tables(int bits, int inverse, const Fe** lo, const Fe** hi, int* h, hipStream_t s);
 
 int ntt_coset_tables(int bits, const Fe** lo, const Fe** hi, int* hc, Fe* n_inv, hipStream_t s);

@@ -44,6 +44,48 @@ struct PassArgs {
     // x2^-5 [and 1/n] in the second-to-last pass (fold_out: the last pass stores without a product)
     const Fe* tw_full;
     uint32_t fold_in, out_plain;
+    // CALC_H fusions (calch.hip): first pass loads in[g] * in2[g] (the pointwise product of two evaluation vectors);
+    // last pass stores h[t] = fromMontgomery((e[t] - w_2n^-t * v) / 2) instead of v.  fold_in == 2: the loaded product is
+    // 2^-5 short of the reference form AND 2^5 short of the internal one: the pass-0 table carries 2^10.
+    const Fe* in2;
+    const Fe* comb_e; const Fe* comb_lo; const Fe* comb_hi; uint32_t comb_hc;
+    Fe k271;        // 2^10 in the internal domain (raw 2^271 mod r): product-on-load without a folding table
+    Fe comb_c;      // epilogue constant: radix-2^29 path raw 16 (x 2^-257 = halve + leave Montgomery), 4x64 path 1/2 (Montgomery)
+};
+
+// h[t] from the inverse transform's value v (reference Montgomery form, canonical) and e[t]: the CALC_H epilogue
+//   h[t] = fromMontgomery((e[t] - w_2n^-t o[t]) / 2),   w_2n^-t = -w_2n^(n-t) for t >= 1   (derivation: calch.hip header)
+template <class F> struct CombineEpilogue;
+template <class P> struct CombineEpilogue<Field<P>> {
+    __device__ static __forceinline__ Fe run(const PassArgs& A, const Fe& v, uint64_t t) {
+        typedef Field<P> F;
+        const Fe e = A.comb_e[t];
+        Fe x;
+        if (t == 0) {
+            x = F::sub(e, v);
+        } else {
+            const uint64_t k = ((uint64_t)1 << A.log_n) - t;
+            x = F::add(e, F::mul(F::mul(A.comb_hi[k >> A.comb_hc], A.comb_lo[k & (((uint64_t)1 << A.comb_hc) - 1)]), v));
+        }
+        return F::from_mont(F::mul(x, A.comb_c));
+    }
+};
+template <class P> struct CombineEpilogue<Field29<P>> {
+    // v: canonical reference-form value held in limbs.  comb_hi / comb_lo: w_2n^k two-level, both in the INTERNAL form
+    // (x 2^261), so mul(mul(hi, lo), v) is w_2n^k * v in the reference form again; comb_c = 16: x 2^-257.
+    __device__ static __forceinline__ Fe run(const PassArgs& A, const F29& v, uint64_t t) {
+        typedef Field29<P> F;
+        const F29 e = F::unpack(A.comb_e[t]);
+        F29 x;
+        if (t == 0) {
+            x = F::sub(e, v);
+        } else {
+            const uint64_t k = ((uint64_t)1 << A.log_n) - t;
+            const F29 f = F::mul(F::unpack(A.comb_hi[k >> A.comb_hc]), F::unpack(A.comb_lo[k & (((uint64_t)1 << A.comb_hc) - 1)]));
+            x = F::add(e, F::mul(f, v));
+        }
+        return F::pack(F::canonical(F::mul(x, F::unpack(A.comb_c))));
+    }
 };
 
 // LDS tile storage: 16-byte planes so that consecutive lanes read consecutive 16-byte slots.
@@ -117,7 +159,10 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
             g = ((uint64_t)(a0 + t) << A.log_S0) + ((uint64_t)mid << log_L) + j;
         }
         El v = F::unpack(src[g]);
-        if (A.prescale) {   // only ever set for pass 0, where storage index == input index
+        if (A.in2) {        // pass 0 of a product transform: v = in[g] * in2[g] (Montgomery product of the reference format)
+            v = F::mul(v, F::unpack(A.in2[g]));
+            if (F::kInternalDomain && A.fold_in != 2) v = F::mul(v, F::unpack(A.k271));
+        } else if (A.prescale) {   // only ever set for pass 0, where storage index == input index
             const uint32_t e = (uint32_t)g;
             El f = F::mul(F::unpack(A.cs_hi[e >> A.hc]), F::unpack(A.cs_lo[e & ((1u << A.hc) - 1)]));
             v = F::mul(v, f);          // (radix-2^29: cs_lo carries the extra 2^5 => also converts the domain)
@@ -209,17 +254,18 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
             const uint32_t r = (log_L == 0) ? 0 : (__brev(kk) >> (32 - log_L));
             El v = tile.get((r << log_T) + t);
             Fe o;
+            const uint64_t at = ((uint64_t)kk << log_rest) + revmid + a0 + t;
             if (F::kInternalDomain && A.out_plain) {
-                o = F::pack(F::canonical(v));   // already in the reference domain (folded upstream)
+                v = F::canonical(v);            // already in the reference domain (folded upstream)
             } else if (F::kInternalDomain) {
                 // out_scale = 1 or 1/n in the REFERENCE Montgomery form: as an internal-domain operand it is
                 // (2^-5) or (2^-5 / n), so this one product also converts back; then canonicalise
-                o = F::pack(F::canonical(F::mul(v, F::unpack(A.out_scale))));
+                v = F::canonical(F::mul(v, F::unpack(A.out_scale)));
             } else {
                 if (A.scale) v = F::mul(v, F::unpack(A.out_scale));
-                o = F::pack(v);
             }
-            dst[((uint64_t)kk << log_rest) + revmid + a0 + t] = o;
+            o = A.comb_e ? CombineEpilogue<F>::run(A, v, at) : F::pack(v);
+            dst[at] = o;
         }
     }
 }
@@ -253,7 +299,8 @@ struct NttPlan {
     DevBuf cs_lo, cs_hi;                      // coset w_{2n}^i (forward root), format of the NTT kernel
     DevBuf cs_lo_ref, cs_hi_ref;              // the same in the reference Montgomery form (calch.hip)
     DevBuf tw_lo_ref[2], tw_hi_ref[2];        // w_n^e two-level in the reference form (dist_scale: four-step inter-digit twiddle)
-    DevBuf tw_full[2][4][2];                  // [dir][pass][fold_in]: full per-pass twiddles (radix-2^29, np >= 2)
+    DevBuf tw_full[2][4][3];                  // [dir][pass][fold_in]: full per-pass twiddles (radix-2^29, np >= 2); fold_in 2 = x 2^10
+    DevBuf cs_lo_int;                         // coset factors' low table in the internal form (x 2^5 once): CALC_H epilogue
     Fe n_inv;                                 // reference Montgomery form of 1/n
 };
 
@@ -313,7 +360,7 @@ static int build_plan(int bits, NttPlan& P, hipStream_t s) {
         Fe g = root_of_unity(bits + 1);
         powers(g, (size_t)1 << P.hc, tmp);
         int rc = upload(P.cs_lo_ref, tmp, s); if (rc) return rc;
-        if (f29) { scale32(tmp); scale32(tmp); }   // carries the 2^5 of the entry AND the 2^5 that converts the loaded value
+        if (f29) { scale32(tmp); rc = upload(P.cs_lo_int, tmp, s); if (rc) return rc; scale32(tmp); }   // cs_lo carries the 2^5 of the entry AND the 2^5 that converts the loaded value
         rc = upload(P.cs_lo, tmp, s); if (rc) return rc;
         powers(Fr::pow_u64(g, (uint64_t)1 << P.hc), (size_t)1 << (bits - P.hc), tmp);
         rc = upload(P.cs_hi_ref, tmp, s); if (rc) return rc;
@@ -367,9 +414,16 @@ int ntt_twiddle_tables(int bits, int inverse, const Fe** lo, const Fe** hi, int*
 }
 
 int ntt_dev(Lane& L, Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s, uint64_t count) {
+    return ntt_run(L, d_data, nullptr, d_data, nullptr, n, odd, inverse, s, count);
+}
+
+// src (x in2) -> dst; combine_e != nullptr: the last pass stores CALC_H's h instead of the transform (inverse only)
+int ntt_run(Lane& L, const Fe* d_src, const Fe* d_in2, Fe* d_data, const Fe* combine_e, uint64_t n, int odd, int inverse,
+            hipStream_t s, uint64_t count) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
-    if (!d_data) return WS_ERR_ARG;
+    if (!d_data || !d_src) return WS_ERR_ARG;
+    if ((d_in2 && odd) || (combine_e && (!inverse || count != 1))) return WS_ERR_ARG;
     if (!s) s = L.stream;
     // src/build_fft.js:92-157: n must be a power of two <= 2^28 (the reference traps otherwise)
     if (n == 0 || (n & (n - 1)) || n > ((uint64_t)1 << 28)) return WS_ERR_SIZE;
@@ -400,8 +454,17 @@ int ntt_dev(Lane& L, Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s
         PassArgs A;
         const bool last = (p == P->np - 1);
         sum_after -= P->k[p];
-        A.in = (p == 0) ? d_data : scratch;
+        A.in = (p == 0) ? d_src : scratch;
         A.out = last ? d_data : scratch;
+        A.in2 = (p == 0) ? d_in2 : nullptr;
+        A.comb_e = last ? combine_e : nullptr;
+        A.comb_lo = P->field29 ? P->cs_lo_int.as<Fe>() : P->cs_lo_ref.as<Fe>();
+        A.comb_hi = P->field29 ? P->cs_hi.as<Fe>() : P->cs_hi_ref.as<Fe>();
+        A.comb_hc = (uint32_t)P->hc;
+        // 2^271 mod r (raw): as an internal-domain operand it multiplies by 2^10
+        A.k271 = Fr::to_mont(Fe{{(uint64_t)1 << 15, 0, 0, 0}});
+        // epilogue constant: internal path raw 16 (mul: x 16 x 2^-261 = halve and leave the Montgomery form); 4x64 path 1/2
+        A.comb_c = P->field29 ? Fe{{16, 0, 0, 0}} : Fr::inv(Fr::add(Fr::one(), Fr::one()));
         A.log_n = bits; A.log_L = P->k[p]; A.log_S = sum_after;
         A.is_last = last ? 1 : 0;
         A.log_L0 = P->k[0]; A.log_S0 = bits - P->k[0];
@@ -417,18 +480,18 @@ int ntt_dev(Lane& L, Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s
         A.out_scale = A.scale ? P->n_inv : Fr::one();
         A.tw_full = nullptr; A.fold_in = 0; A.out_plain = 0;
         if (P->field29 && P->np >= 2) {
-            const bool fold_in = (p == 0) && !odd;            // odd: the coset product already converts
+            const int fold_in = (p == 0 && !odd) ? (d_in2 ? 2 : 1) : 0;   // odd: the coset product already converts; 2: product on load
             const bool fold_out = (p == P->np - 2);
-            A.fold_in = fold_in ? 1 : 0;
+            A.fold_in = (uint32_t)fold_in;
             A.out_plain = last ? 1 : 0;
             if (!last) {
-                DevBuf& tb = P->tw_full[dir][p][fold_in ? 1 : 0];
+                DevBuf& tb = P->tw_full[dir][p][fold_in];
                 const uint64_t count = (uint64_t)1 << (A.log_L + A.log_S);
                 if (!tb.p) {
-                    // factor (plain field element): 2^5 (in), 2^-5 (out), times 1/n on the inverse's out pass
+                    // factor (plain field element): 2^5 (in; 2^10 after a product on load), 2^-5 (out), times 1/n on the inverse's out pass
                     Fe f = Fr::one();                                           // Montgomery-R form of 1
                     const Fe m32 = Fr::to_mont(Fe{{32, 0, 0, 0}});
-                    if (fold_in) f = Fr::mul(f, m32);
+                    for (int k = 0; k < fold_in; k++) f = Fr::mul(f, m32);
                     if (fold_out) { f = Fr::mul(f, Fr::inv(m32)); if (inverse) f = Fr::mul(f, P->n_inv); }
                     f = Fr::mul(f, m32);                                        // -> internal form (x 2^5)
                     WS_HIP_CHECK(tb.alloc(count * sizeof(Fe)));
