@@ -217,7 +217,9 @@ int wsnark_selftest_field(int which, int impl, int op, const void* a, const void
  *   p, q: n Jacobian-Montgomery points (96 / 192 B, any z; z == 0 = infinity); out: n affine-normalised
  *   Jacobian-Montgomery points ((x, y, 1) or (0, 1, 0)) like every group element this ABI returns.
  *   op: 0 = p + q (full addition), 1 = 2p, 2 = -p, 3 = p (normalisation only), 4 = p + q as a MIXED addition
- *   (q must be affine: z == 1, or infinity), 5 = p - q as a mixed addition with the negate flag. */
+ *   (q must be affine: z == 1, or infinity), 5 = p - q as a mixed addition with the negate flag,
+ *   6 = p + q + q and 7 = p + q - q as two mixed additions of the ACCUMULATION LOOP's lazy form (x kept "wide" between
+ *   them, field29.h) followed by its narrowing. */
 int wsnark_selftest_curve(int g, int impl, int op, const void* p, const void* q, void* out, uint64_t n);
 
 /* ---- measurement hooks (bench.py) ---- */

@@ -139,6 +139,9 @@ def check_group(bn, orc, g, impl):
     got = st_curve(bn, g, impl, 4, p, qa)
     assert got == [H(c["add_affine"]) for c in cs], [l for l, x, c in zip(labels, got, cs) if x != H(c["add_affine"])]
     assert st_curve(bn, g, impl, 5, p, qa) == [orc.g_affine(g, orc.g_add(g, x, orc.g_neg(g, y))) for x, y in zip(p, q)]
+    # the accumulation loop's lazy form: two mixed additions with x kept wide in between, then narrowed
+    assert st_curve(bn, g, impl, 6, p, qa) == [orc.g_affine(g, orc.g_add(g, orc.g_add(g, x, y), y)) for x, y in zip(p, q)]
+    assert st_curve(bn, g, impl, 7, p, qa) == [orc.g_affine(g, x) for x in p]
     # infinity is always written as (0, 1, 0) and P + (-P) lands there
     zero = orc.g_affine(g, orc.g_zero(g))
     assert st_curve(bn, g, impl, 0, p, [orc.g_neg(g, x) for x in p]) == [zero] * len(p)
@@ -169,3 +172,7 @@ def check_group(bn, orc, g, impl):
     Qa = [orc.g_affine(g, y) for y in Q]
     assert st_curve(bn, g, impl, 4, P, Qa) == [orc.g_affine(g, orc.g_add(g, x, y)) for x, y in zip(P, Q)]
     assert st_curve(bn, g, impl, 4, P, [orc.g_affine(g, x) for x in P]) == [orc.g_affine(g, orc.g_double(g, x)) for x in P]
+    assert st_curve(bn, g, impl, 6, P, Qa) == [orc.g_affine(g, orc.g_add(g, orc.g_add(g, x, y), y)) for x, y in zip(P, Q)]
+    assert st_curve(bn, g, impl, 7, P, Qa) == [orc.g_affine(g, x) for x in P]
+    # p + q + q with p = -q: the first lazy addition lands on infinity, the second restarts from the affine point
+    assert st_curve(bn, g, impl, 6, [orc.g_neg(g, y) for y in Qa], Qa) == Qa

@@ -182,6 +182,11 @@ struct Field {
     WS_HD static bool is_zero_weak(const Fe& a) { return is_zero(a); }
     WS_HD static Fe mulsub2(const Fe& a, const Fe& b, const Fe& c, const Fe& d) { return sub(mul(a, b), mul(c, d)); }
     WS_HD static Fe mul_inl(const Fe& a, const Fe& b) { return mul(a, b); }
+    // (the "wide" forms of the radix-2^29 field, field29.h: strict here)
+    WS_HD static Fe x3_wide(const Fe& rr, const Fe& ppp, const Fe& q) { return sub(sub(rr, ppp), dbl(q)); }
+    WS_HD static Fe sub_wide(const Fe& a, const Fe& b) { return sub(a, b); }
+    WS_HD static bool is_zero_wide(const Fe& a) { return is_zero(a); }
+    WS_HD static Fe narrow(const Fe& a) { return a; }
 
     // build_f1m.js:86-100
     WS_HD static Fe sub(const Fe& a, const Fe& b) {

@@ -77,6 +77,16 @@ struct Field29 {
         return ws_limb29(P::P0 << 1, (P::P1 << 1) | (P::P0 >> 63), (P::P2 << 1) | (P::P1 >> 63), (P::P3 << 1) | (P::P2 >> 63), i);
     }
     static constexpr uint32_t NP29 = (uint32_t)(P::NP & WS_M29);
+    // limb i of k*p for a small k (the top limb takes the rest: 10p < 2^257 still fits)
+    WS_HD static constexpr uint32_t kp_limb(uint32_t k, int i) {
+        uint64_t carry = 0, t = 0;
+        for (int j = 0; j <= i; j++) {
+            t = (uint64_t)p_limb(j) * k + carry;
+            carry = t >> 29;
+            if (j < 8) t &= WS_M29;
+        }
+        return (uint32_t)t;
+    }
 
     WS_HD static F29 from_words(uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3) {
         F29 r;
@@ -188,6 +198,73 @@ struct Field29 {
         F29 t = cond_sub_2p(a);        // now in [0, 2p)
         return is_zero(t);
     }
+    // ---- "wide" values: in (0, 8p) or (0, 10p), tight limbs (the top one holds up to 25 bits).  They save the correction
+    // passes of the strict forms and are valid ONLY as operands of mul / sqr / mulsub2's first pair / sub_wide / is_zero_wide,
+    // and as the stored x of a lazily accumulated point (Curve::madd_wide); narrow() brings one back to [0, 2p).
+    // (a * b + m * p) / 2^261 with a, b < 10p is < (100 * 2^-7.4 + 1) p < 1.6p: products of wide operands stay below 2p. ----
+    // rr - ppp - 2q + 6p for strict rr, ppp, q: the X3 of an addition in ONE carry pass; in (0, 8p)
+    WS_HD static F29 x3_wide(const F29& rr, const F29& ppp, const F29& q) {
+        F29 d;
+        int32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int32_t t = (int32_t)rr.v[i] - (int32_t)ppp.v[i] - 2 * (int32_t)q.v[i] + (int32_t)kp_limb(6, i) + c;   // > -2^31
+            d.v[i] = (uint32_t)t & WS_M29;
+            c = t >> 29;
+        }
+        d.v[8] = (uint32_t)((int32_t)rr.v[8] - (int32_t)ppp.v[8] - 2 * (int32_t)q.v[8] + (int32_t)kp_limb(6, 8) + c);
+        return d;
+    }
+    // a - b + 8p for strict a and wide b (< 8p): in (0, 10p)
+    WS_HD static F29 sub_wide(const F29& a, const F29& b) {
+        F29 d;
+        int32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int32_t t = (int32_t)a.v[i] - (int32_t)b.v[i] + (int32_t)kp_limb(8, i) + c;
+            d.v[i] = (uint32_t)t & WS_M29;
+            c = t >> 29;
+        }
+        d.v[8] = (uint32_t)((int32_t)a.v[8] - (int32_t)b.v[8] + (int32_t)kp_limb(8, 8) + c);
+        return d;
+    }
+    // zero test for a sub_wide result (value in (0, 10p)): zero iff k*p, k = 1..9
+    WS_HD static bool is_zero_wide(const F29& a) {
+        const uint32_t l0 = a.v[0];
+        bool hit = false;
+#pragma unroll
+        for (uint32_t k = 1; k <= 9; k++) hit = hit || l0 == kp_limb(k, 0);
+        if (!hit) return false;                 // (the low limbs of p, 2p, ..., 9p differ: p is odd)
+#pragma unroll
+        for (uint32_t k = 1; k <= 9; k++) {
+            uint32_t d = 0;
+#pragma unroll
+            for (int i = 0; i < 9; i++) d |= a.v[i] ^ kp_limb(k, i);
+            if (d == 0) return true;
+        }
+        return false;
+    }
+    // r = s - k*p if s >= k*p else s (tight limbs in and out)
+    WS_HD static F29 cond_sub_kp(const F29& s, uint32_t k) {
+        F29 d;
+        int32_t bw = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int32_t t = (int32_t)s.v[i] - (int32_t)kp_limb(k, i) + bw;
+            d.v[i] = (uint32_t)t & WS_M29;
+            bw = t >> 29;
+        }
+        const int32_t t8 = (int32_t)s.v[8] - (int32_t)kp_limb(k, 8) + bw;
+        d.v[8] = (uint32_t)t8;
+        const bool neg = t8 < 0;
+        F29 r;
+#pragma unroll
+        for (int i = 0; i < 9; i++) r.v[i] = neg ? s.v[i] : d.v[i];
+        return r;
+    }
+    // wide (< 8p) -> [0, 2p)
+    WS_HD static F29 narrow(const F29& a) { return cond_sub_kp(cond_sub_kp(a, 4), 2); }
+
     WS_HD static F29 neg(const F29& a) {
         uint32_t o = 0;
 #pragma unroll

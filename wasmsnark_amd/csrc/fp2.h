@@ -46,6 +46,11 @@ struct Fp2T {
     // (the quadratic extension keeps strict operands: its products negate and re-add components)
     WS_HD static El sub_weak(const El& a, const El& b) { return sub(a, b); }
     WS_HD static bool is_zero_weak(const El& a) { return is_zero(a); }
+    // (the quadratic extension's products negate and re-add components: no wide operands; strict fall-backs)
+    WS_HD static El x3_wide(const El& rr, const El& ppp, const El& q) { return sub(sub(rr, ppp), dbl(q)); }
+    WS_HD static El sub_wide(const El& a, const El& b) { return sub(a, b); }
+    WS_HD static bool is_zero_wide(const El& a) { return is_zero(a); }
+    WS_HD static El narrow(const El& a) { return a; }
     WS_HD static El neg(const El& a) { return El{B::neg(a.c0), B::neg(a.c1)}; }
     WS_HD static El cneg(const El& a, bool s) { return s ? neg(a) : a; }
     // (a0 + a1 u)(b0 + b1 u) = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u.  The reference uses Karatsuba with 3

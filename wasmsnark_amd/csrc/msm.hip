@@ -45,6 +45,9 @@ namespace wsnark {
 #ifndef WS_G2_PREFETCH
 #define WS_G2_PREFETCH 0
 #endif
+#ifndef WS_MADD_WIDE
+#define WS_MADD_WIDE 1     // accumulation loop keeps X wide between additions (curve.h: madd_wide); 0 = strict madd, for A/B builds
+#endif
 static const uint32_t CHUNK = 8;          // buckets per msm_chunks lane
 
 struct MsmScratch {
@@ -360,8 +363,13 @@ __device__ __forceinline__ typename C::Pt accumulate_range(const typename C::Aff
         for (uint32_t k = 0; k < len; k++) {
             const uint32_t v = vals[s + k];
             const typename C::Aff cur = C::unpack_aff(points[v & 0x7FFFFFFFu]);
+#if WS_MADD_WIDE
+            C::madd_wide(acc, cur, (v >> 31) != 0);
+#else
             C::madd(acc, cur, (v >> 31) != 0);
+#endif
         }
+        C::narrow_x(acc);
         return acc;
     }
     // software pipeline: the next point's gather is in flight while the current one is added
@@ -374,8 +382,13 @@ __device__ __forceinline__ typename C::Pt accumulate_range(const typename C::Aff
             v = vals[s + k + 1];
             nxt = points[v & 0x7FFFFFFFu];
         }
+#if WS_MADD_WIDE
+        C::madd_wide(acc, cur, neg);
+#else
         C::madd(acc, cur, neg);
+#endif
     }
+    C::narrow_x(acc);
     return acc;
 }
 

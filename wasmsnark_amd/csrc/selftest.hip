@@ -223,6 +223,8 @@ __host__ __device__ inline typename C::PtP st_curve_op(int op, const typename C:
         case 3: r = from_jac(pj); break;
         case 4: r = from_jac(pj); C::madd(r, affine_of(qj), false); break;
         case 5: r = from_jac(pj); C::madd(r, affine_of(qj), true); break;
+        case 6: r = from_jac(pj); C::madd_wide(r, affine_of(qj), false); C::madd_wide(r, affine_of(qj), false); C::narrow_x(r); break;
+        case 7: r = from_jac(pj); C::madd_wide(r, affine_of(qj), false); C::madd_wide(r, affine_of(qj), true); C::narrow_x(r); break;
         default: *ok = false; break;
     }
     return C::pt_from_internal(r);
@@ -277,7 +279,7 @@ int selftest_curve(int g, int impl, int op, const uint8_t* p, const uint8_t* q, 
     Context* X = ctx();
     if (!X) return WS_ERR_NOINIT;
     if (n == 0) return WS_OK;
-    if (n > (1u << 20) || op < 0 || op > 5) return WS_ERR_ARG;
+    if (n > (1u << 20) || op < 0 || op > 7) return WS_ERR_ARG;
     hipStream_t s = X->stream;
     if (g == 1) {
         if (impl == 0) return st_curve_dev<G1R29, G1>(op, p, q, out, n, s);
