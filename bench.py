@@ -43,7 +43,7 @@ def kernel_ms(report, per=1):
     return {k: round(v[0] / max(per, 1), 4) for k, v in sorted(report.items())}
 
 
-def build_prover(bn, logd, style, seed=1):
+def build_prover(bn, logd, style, seed=1, keep_h=False):
     """Synthetic circuit + key (device-resident) + witness bytes.  Keys past the 4 GiB of proving_key.bin's u32 offsets
     (2^23 constraints and up) go through the sections loader."""
     from wasmsnark_amd import synth
@@ -54,15 +54,20 @@ def build_prover(bn, logd, style, seed=1):
         sec, _ = synth.build_sections(circ, S, bn.mul_base)
         key = bn.load_key(sections=sec)
         key_bytes = sum(len(v) for v in sec.values() if isinstance(v, (bytes, bytearray)))
+        h_points = sec["pointsH"] if keep_h else None
     else:
         pkey, _ = synth.build_key(circ, S, bn.mul_base)
         key = bn.load_key(pkey)
         key_bytes = len(pkey)
+        import struct
+        h_points = pkey[struct.unpack_from("<I", pkey, 36)[0]:] if keep_h else None
     wit = synth.witness_bin(circ)
     nnz = sum(len(c) for c in circ.A) + sum(len(c) for c in circ.B)
     absent = (sum(1 for c in circ.A if not c), sum(1 for c in circ.B if not c))
     info = {"log_domain": logd, "n_vars": circ.n_vars, "n_public": circ.n_public, "nnz_A_plus_B": nnz, "style": style,
             "vars_absent_from_A_B": absent, "key_bytes": key_bytes, "setup_s": round(time.perf_counter() - t0, 1)}
+    if keep_h:
+        info["h_points"] = h_points
     return circ, S, key, wit, info
 
 
@@ -79,6 +84,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shard", choices=["points", "windows"], default="points", help="--workload msm, N>1")
+    ap.add_argument("--calc-h", choices=["replicated", "dist"], default="dist",
+                    help="N>1: 'dist' = CALC_H on the distributed four-step transform + points-sharded H sum (DistProver); "
+                         "'replicated' = every rank repeats the whole CALC_H (round 1)")
     args = ap.parse_args()
 
     import torch
@@ -176,13 +184,22 @@ def bench_prove(ctx):
     args, bn, rank, world, dev, torch = ctx["args"], ctx["bn"], ctx["rank"], ctx["world"], ctx["dev"], ctx["torch"]
     from wasmsnark_amd import dist as wdist, synth
     logd = args.prove_log_domain
-    circ, S, key, wit, info = build_prover(bn, logd, args.circuit)
+    circ, S, key, wit, info = build_prover(bn, logd, args.circuit, keep_h=(world > 1 and args.calc_h == "dist"))
+    pkey_h_points = info.pop("h_points", None)
     d_w = torch.frombuffer(bytearray(wit), dtype=torch.uint8).to(dev)
     torch.cuda.synchronize()
     r32, s32 = bytes(range(32)), bytes(range(32, 64))
     want = synth.expected_proof(circ, S, r32, s32, bn.mul_base)
 
+    dprover = None
+    if world > 1 and args.calc_h == "dist":
+        import struct as _st
+        ph = pkey_h_points if pkey_h_points is not None else None
+        dprover = wdist.DistProver(bn, key, ph, device=dev)
+
     def step():
+        if dprover is not None:
+            return dprover.prove(d_w.data_ptr(), len(wit), r=r32, s=s32)
         if world > 1:
             return wdist.sharded_prove(bn, key, None, r=r32, s=s32, device=dev, d_witness=(d_w.data_ptr(), len(wit)))
         return bn.groth16GenProof_dev(d_w.data_ptr(), len(wit), key, r=r32, s=s32)
@@ -217,7 +234,10 @@ def bench_prove(ctx):
                                   "every variable present), key and witness resident in HBM, r and s injected" % logd
                                   if args.circuit == "columns" else
                                   "BN128 full Groth16 prove, synthetic 2^%d-constraint R1CS, round-1 sparse generator (1-2 terms per row)" % logd,
-                      "circuit": info, "parallelism": ("MSM windows sharded w %% %d == rank, 1 all_gather of 576 B records per proof" % world)
+                      "circuit": info, "parallelism": (("MSM windows sharded w %% %d == rank, " % world)
+                                                       + ("CALC_H on the distributed four-step NTT (7 all-to-alls of %d B per rank), H sum points-sharded, "
+                                                          % ((world - 1) * (circ.domain // world // world) * 32) if args.calc_h == "dist" else "CALC_H replicated, ")
+                                                       + "1 all_gather of 576 B records per proof")
                       if world > 1 else "1 GPU, no collective", "lanes": int(os.environ.get("WSNARK_LANES", "2")), "device": bn.device_info},
            "proofs_match_toxic_waste_closed_form": ok,
            "proofs_per_s": round(1e3 / ms, 2),

@@ -103,6 +103,16 @@ int wsnark_fr_ntt_dev(void* d_buf, uint64_t n, int odd, int inverse, void* strea
  *   mode 0: w_n^((row0 + r) * c)  -- the twiddle between the two steps (inverse != 0: the inverse root)
  *   mode 1: w_2n^t                -- the coset pre-scale of odd = 1 (src/build_fft.js:159-187) */
 int wsnark_fr_ntt_batch_dev(void* d_buf, uint64_t n, uint64_t count, int inverse, void* stream);
+/* The other pieces of a distributed CALC_H (src/bn128.js:126-166), all on device arrays:
+ *   pkey_eval_ab : a = A w, b = B w -- the two pol_constructLC calls (src/build_pol.js:62-144, bn128.js:139-145) from a
+ *                  device-resident plain witness; `domain` Montgomery elements each
+ *   fr_mul       : fft_mulN (src/build_fft.js:461-505), out[i] = a[i] * b[i]
+ *   dist_combine : h[t] = fromMontgomery((e[t] - w_2n^-t o[t]) / 2) on a rank's block, t as in dist_scale (the upper
+ *                  half of the reference's size-2n inverse transform, bn128.js:160-164; derivation in csrc/calch.hip) */
+int wsnark_pkey_eval_ab_dev(wsnark_pkey_t* handle, const void* d_witness, size_t witness_len, void* d_a_out, void* d_b_out, void* stream);
+int wsnark_fr_mul_dev(const void* d_a, const void* d_b, void* d_out, uint64_t n, void* stream);
+int wsnark_fr_dist_combine_dev(const void* d_e, const void* d_o, void* d_h_out, uint64_t rows, uint64_t cols, uint64_t row0,
+                               uint32_t log_n1, uint32_t log_n, void* stream);
 int wsnark_fr_dist_scale_dev(void* d_buf, uint64_t rows, uint64_t cols, uint64_t row0, uint32_t log_n1, uint32_t log_n, int mode,
                              int inverse, void* stream);
 /* fft_toMontgomeryN / fft_fromMontgomeryN (src/build_fft.js:418-458, 507-547) */
@@ -175,11 +185,15 @@ int wsnark_last_blinding(void* r32_out, void* s32_out);
  * A | B1 | C | H (4 x 96 B G1) | B2 (192 B G2), Jacobian-Montgomery -- the reference's per-worker
  * partial results (src/bn128.js:374-382, 406-414) for all five sums at once.  After a single
  * all_gather of these records, prove_finish (host arithmetic only) sums them and assembles the proof
- * exactly as wsnark_groth16_prove does (src/bn128.js:671-718). */
+ * exactly as wsnark_groth16_prove does (src/bn128.js:671-718).
+ * flags: WSNARK_PARTIAL_SKIP_H leaves CALC_H and the H sum to the caller (the record's H slot is infinity): the ranks then
+ * compute h with the distributed four-step transform and each sums its own slice of h against its slice of the H points
+ * (wasmsnark_amd/dist.py: DistProver) instead of every rank repeating the whole CALC_H. */
+#define WSNARK_PARTIAL_SKIP_H 1u
 int wsnark_groth16_prove_partial(wsnark_pkey_t* handle, const void* witness, size_t witness_len, uint32_t rank,
-                                 uint32_t world, void* out576);
+                                 uint32_t world, uint32_t flags, void* out576);
 int wsnark_groth16_prove_partial_dev(wsnark_pkey_t* handle, const void* d_witness, size_t witness_len, uint32_t rank,
-                                     uint32_t world, void* out576_host, void* stream);
+                                     uint32_t world, uint32_t flags, void* out576_host, void* stream);
 int wsnark_groth16_prove_finish(wsnark_pkey_t* handle, const void* partials, uint64_t n_ranks, const void* r32,
                                 const void* s32, void* out384);
 

@@ -1,6 +1,8 @@
 """Distributed four-step NTT (wasmsnark_amd/dist.py: dist_ntt) on CPU: two processes on gloo, kernel sources under the
 thread emulator, against the pinned oracle's fft / ifft (reference semantics, src/build_fft.js:159-221): bit-exact for
-2^4 .. 2^14, odd 0/1, forward and inverse; plus a chain (inverse, coset forward) without any re-layout in between."""
+2^4 .. 2^14, odd 0/1, forward and inverse; a chain (inverse, coset forward) without any re-layout in between; and whole
+proofs through DistProver (distributed CALC_H + points-sharded H sum + window-sharded sums) against the reference's
+golden proofs."""
 import os
 import subprocess
 import sys
@@ -45,6 +47,22 @@ loc = wd.to_interleaved(torch.frombuffer(bytearray(x), dtype=torch.uint8), l1, r
 y = wd.dist_ntt(bn, wd.dist_ntt(bn, loc, bits, inverse=True), bits, odd=1)
 want = orc.fft(orc.fft(x, n, 0, inverse=True), n, 1)
 assert wd.from_interleaved(gather(y), l2).numpy().tobytes() == want
+# whole proofs with the distributed CALC_H: window-sharded sums (SKIP_H) + the ranks' slices of h against their slices of the
+# H points; t3 has an odd log2(domain) (the chain alternates the two splits), t6 an even one
+import json, struct
+gold = os.path.join(os.environ["WS_ROOT"], "tests", "golden")
+for name in ("t3", "t6"):
+    pkey = open(os.path.join(gold, "keys", name + ".pkey.bin"), "rb").read()
+    wit = open(os.path.join(gold, "keys", name + ".witness.bin"), "rb").read()
+    key = bn.load_key(pkey)
+    dp = wd.DistProver(bn, key, pkey[struct.unpack_from("<I", pkey, 36)[0]:])
+    w = torch.frombuffer(bytearray(wit), dtype=torch.uint8)
+    for c in json.load(open(os.path.join(gold, "proofs.json")))[name]:
+        got = dp.prove(w.data_ptr(), len(wit), r=bytes.fromhex(c["r"]), s=bytes.fromhex(c["s"]))
+        assert got == c["proof"], ("DistProver", name, rank)
+    got = dp.prove(w.data_ptr(), len(wit))                     # rank 0 draws r, s
+    r_used, s_used = bn.last_blinding()
+    assert got == bn.groth16GenProof(wit, key, r=r_used, s=s_used), ("DistProver default blinding", name, rank)
 dist.barrier()
 open(os.path.join(os.environ["WS_OUT"], "rank%d.ok" % rank), "w").write("ok")
 '''

@@ -65,6 +65,21 @@ for bits in (10, 16, 20):
         parts = [torch.empty_like(y) for _ in range(world)]
         dist.all_gather(parts, y)
         assert torch.equal(wd.from_interleaved(torch.cat(parts), l2), ref), ("dist_ntt", bits, odd, inverse, rank)
+# whole proofs with the distributed CALC_H (DistProver): 2^14 synthetic circuit against the toxic-waste closed form
+import struct
+from wasmsnark_amd import synth
+circ = synth.make_circuit(14, n_public=5, seed=314)
+S = synth.setup(circ, seed=15)
+pk14, _ = synth.build_key(circ, S, bn.mul_base)
+key14 = bn.load_key(pk14)
+w14 = synth.witness_bin(circ)
+d_w14 = torch.frombuffer(bytearray(w14), dtype=torch.uint8).to(dev)
+torch.cuda.synchronize()
+dp = wd.DistProver(bn, key14, pk14[struct.unpack_from("<I", pk14, 36)[0]:], device=dev)
+r14, s14 = bytes(range(32)), bytes(range(64, 96))
+want14 = synth.expected_proof(circ, S, r14, s14, bn.mul_base)
+assert dp.prove(d_w14.data_ptr(), len(w14), r=r14, s=s14) == want14, ("DistProver", rank)
+assert wd.sharded_prove(bn, key14, w14, r=r14, s=s14, device=dev) == want14, ("sharded_prove 2^14", rank)
 got = wd.sharded_prove(bn, key, wit, device=dev)                  # rank 0 draws r, s: all ranks, one proof
 r_used, s_used = bn.last_blinding()
 assert got == bn.groth16GenProof(wit, key, r=r_used, s=s_used)

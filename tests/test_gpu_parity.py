@@ -575,3 +575,26 @@ def test_native_verifier_accepts_gpu_proofs(bn):
         assert bn.groth16Verify(vk, pub, proof) is True
         assert bn.groth16Verify(vk, [str(int(pub[0]) + 1)] + pub[1:], proof) is False
     key.free()
+
+
+@pytest.mark.parametrize("logd", [13, 16])
+def test_dist_prover_world_of_one_on_gpu(bn, logd):
+    """wasmsnark_amd.dist.DistProver with a world of one: CALC_H through the four-step building blocks (eval_ab, fr_mul,
+    batched transforms, dist_scale, dist_combine: odd and even log2(domain)), the H sum from the caller's h and H points,
+    the other four sums with WSNARK_PARTIAL_SKIP_H -- equal to the closed form and to the one-call prover."""
+    import struct
+    import torch
+    from wasmsnark_amd import dist as wd, synth
+    circ = synth.make_circuit(logd, n_public=5, seed=200 + logd)
+    S = synth.setup(circ, seed=20)
+    pkey, _ = synth.build_key(circ, S, bn.mul_base)
+    key = bn.load_key(pkey)
+    wit = synth.witness_bin(circ)
+    d_w = torch.frombuffer(bytearray(wit), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    dp = wd.DistProver(bn, key, pkey[struct.unpack_from("<I", pkey, 36)[0]:], device=torch.device("cuda", 0))
+    r, s = os.urandom(32), os.urandom(32)
+    want = synth.expected_proof(circ, S, r, s, bn.mul_base)
+    assert dp.prove(d_w.data_ptr(), len(wit), r=r, s=s) == want
+    assert bn.groth16GenProof(wit, key, r=r, s=s) == want
+    key.free()

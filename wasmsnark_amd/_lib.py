@@ -18,7 +18,8 @@ SYMBOLS = [
     "wsnark_g1_msm", "wsnark_g2_msm", "wsnark_g1_msm_dev", "wsnark_g2_msm_dev",
     "wsnark_g1_msm_windows", "wsnark_g2_msm_windows", "wsnark_g1_msm_windows_dev", "wsnark_g2_msm_windows_dev",
     "wsnark_g1_sum", "wsnark_g2_sum",
-    "wsnark_fr_ntt", "wsnark_fr_ntt_dev", "wsnark_fr_ntt_batch_dev", "wsnark_fr_dist_scale_dev", "wsnark_fr_to_montgomery", "wsnark_fr_from_montgomery",
+    "wsnark_fr_ntt", "wsnark_fr_ntt_dev", "wsnark_fr_ntt_batch_dev", "wsnark_fr_dist_scale_dev",
+    "wsnark_pkey_eval_ab_dev", "wsnark_fr_mul_dev", "wsnark_fr_dist_combine_dev", "wsnark_fr_to_montgomery", "wsnark_fr_from_montgomery",
     "wsnark_calc_h", "wsnark_pkey_load", "wsnark_pkey_free", "wsnark_pkey_info",
     "wsnark_groth16_prove", "wsnark_groth16_prove_dev", "wsnark_pkey_load_sections", "wsnark_last_blinding", "wsnark_groth16_verify",
     "wsnark_groth16_prove_partial", "wsnark_groth16_prove_partial_dev", "wsnark_groth16_prove_finish",
@@ -75,8 +76,11 @@ class Lib:
         c.wsnark_groth16_prove.argtypes = [vp, vp, sz, vp, vp, vp]
         c.wsnark_groth16_prove_dev.argtypes = [vp, vp, sz, vp, vp, vp, vp]
         c.wsnark_pkey_load_sections.argtypes = [vp, C.POINTER(vp)]
-        c.wsnark_groth16_prove_partial.argtypes = [vp, vp, sz, u32, u32, vp]
-        c.wsnark_groth16_prove_partial_dev.argtypes = [vp, vp, sz, u32, u32, vp, vp]
+        c.wsnark_groth16_prove_partial.argtypes = [vp, vp, sz, u32, u32, u32, vp]
+        c.wsnark_groth16_prove_partial_dev.argtypes = [vp, vp, sz, u32, u32, u32, vp, vp]
+        c.wsnark_pkey_eval_ab_dev.argtypes = [vp, vp, sz, vp, vp, vp]
+        c.wsnark_fr_mul_dev.argtypes = [vp, vp, vp, u64, vp]
+        c.wsnark_fr_dist_combine_dev.argtypes = [vp, vp, vp, u64, u64, u64, u32, u32, vp]
         c.wsnark_last_blinding.argtypes = [vp, vp]
         c.wsnark_groth16_verify.argtypes = [vp, sz, vp, u64, vp, C.POINTER(C.c_int)]
         c.wsnark_selftest_field.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, u64]

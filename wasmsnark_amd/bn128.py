@@ -204,16 +204,18 @@ class Bn128:
         return ProvingKey(self.lib, pkey, sections)
 
     # --- multi-GPU proving: per-rank partial sums + host-side finish (include/wsnark.h) ---
-    def groth16_prove_partial(self, signals, key, shard=(0, 1)):
-        """shard=(rank, world): this rank's 576-byte record of partial sums (windows w % world == rank)."""
+    def groth16_prove_partial(self, signals, key, shard=(0, 1), skip_h=False):
+        """shard=(rank, world): this rank's 576-byte record of partial sums (windows w % world == rank).
+        skip_h: leave CALC_H and the H sum to the caller (WSNARK_PARTIAL_SKIP_H; the H slot is infinity)."""
         w, nw = _ro(signals)
         out = (C.c_uint8 * 576)()
-        self.lib.check(self.lib.c.wsnark_groth16_prove_partial(key._h, w, nw, shard[0], shard[1], out))
+        self.lib.check(self.lib.c.wsnark_groth16_prove_partial(key._h, w, nw, shard[0], shard[1], 1 if skip_h else 0, out))
         return bytes(out)
 
-    def groth16_prove_partial_dev(self, d_witness, witness_len, key, shard=(0, 1), stream=None):
+    def groth16_prove_partial_dev(self, d_witness, witness_len, key, shard=(0, 1), stream=None, skip_h=False):
         out = (C.c_uint8 * 576)()
-        self.lib.check(self.lib.c.wsnark_groth16_prove_partial_dev(key._h, d_witness, witness_len, shard[0], shard[1], out, stream))
+        self.lib.check(self.lib.c.wsnark_groth16_prove_partial_dev(key._h, d_witness, witness_len, shard[0], shard[1],
+                                                                    1 if skip_h else 0, out, stream))
         return bytes(out)
 
     def last_blinding(self):

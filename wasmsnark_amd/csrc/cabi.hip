@@ -24,8 +24,9 @@ struct KeySections {
     uint64_t lenPA, lenPB1, lenPB2, lenPC, lenPH;
 };
 int pkey_load_sections(const KeySections& S, ProvingKey** out);
-int groth16_prove_partial(ProvingKey* K, const uint8_t* witness, size_t witness_len, WindowShard sh, uint8_t* out576);
-int groth16_prove_partial_dev(ProvingKey* K, const Fe* d_witness, size_t witness_len, WindowShard sh, uint8_t* out576, hipStream_t s);
+int groth16_prove_partial(ProvingKey* K, const uint8_t* witness, size_t witness_len, WindowShard sh, uint8_t* out576, bool skip_h);
+int groth16_prove_partial_dev(ProvingKey* K, const Fe* d_witness, size_t witness_len, WindowShard sh, uint8_t* out576, hipStream_t s, bool skip_h);
+int pkey_eval_ab_dev(ProvingKey* K, const Fe* d_witness, size_t witness_len, Fe* d_a, Fe* d_b, hipStream_t s);
 int groth16_prove_finish(ProvingKey* K, const uint8_t* partials, uint64_t n_ranks, const uint8_t* r32,
                          const uint8_t* s32, uint8_t* out384);
 int groth16_prove_dev_witness(ProvingKey* K, const Fe* d_witness, size_t witness_len, const uint8_t* r32,
@@ -252,18 +253,32 @@ int wsnark_pkey_load_sections(const wsnark_key_sections_t* ks, wsnark_pkey_t** o
     return WSNARK_OK;
 }
 int wsnark_groth16_prove_partial(wsnark_pkey_t* h, const void* witness, size_t witness_len, uint32_t rank, uint32_t world,
-                                 void* out576) {
+                                 uint32_t flags, void* out576) {
     REQUIRE_CTX();
-    if (!h || !witness || !out576 || !shard_ok(rank, world)) return WSNARK_ERR_ARG;
+    if (!h || !witness || !out576 || !shard_ok(rank, world) || (flags & ~(uint32_t)WSNARK_PARTIAL_SKIP_H)) return WSNARK_ERR_ARG;
     return groth16_prove_partial(reinterpret_cast<ProvingKey*>(h), (const uint8_t*)witness, witness_len, WindowShard{rank, world},
-                                 (uint8_t*)out576);
+                                 (uint8_t*)out576, (flags & WSNARK_PARTIAL_SKIP_H) != 0);
 }
 int wsnark_groth16_prove_partial_dev(wsnark_pkey_t* h, const void* d_witness, size_t witness_len, uint32_t rank, uint32_t world,
-                                     void* out576_host, void* stream) {
+                                     uint32_t flags, void* out576_host, void* stream) {
     REQUIRE_CTX();
-    if (!h || !d_witness || !out576_host || !shard_ok(rank, world)) return WSNARK_ERR_ARG;
+    if (!h || !d_witness || !out576_host || !shard_ok(rank, world) || (flags & ~(uint32_t)WSNARK_PARTIAL_SKIP_H)) return WSNARK_ERR_ARG;
     return groth16_prove_partial_dev(reinterpret_cast<ProvingKey*>(h), (const Fe*)d_witness, witness_len, WindowShard{rank, world},
-                                     (uint8_t*)out576_host, (hipStream_t)stream);
+                                     (uint8_t*)out576_host, (hipStream_t)stream, (flags & WSNARK_PARTIAL_SKIP_H) != 0);
+}
+int wsnark_pkey_eval_ab_dev(wsnark_pkey_t* h, const void* d_witness, size_t witness_len, void* d_a_out, void* d_b_out, void* stream) {
+    REQUIRE_CTX();
+    if (!h || !d_witness || !d_a_out || !d_b_out) return WSNARK_ERR_ARG;
+    return pkey_eval_ab_dev(reinterpret_cast<ProvingKey*>(h), (const Fe*)d_witness, witness_len, (Fe*)d_a_out, (Fe*)d_b_out, (hipStream_t)stream);
+}
+int wsnark_fr_mul_dev(const void* d_a, const void* d_b, void* d_out, uint64_t n, void* stream) {
+    REQUIRE_CTX();
+    return fr_mul_dev((const Fe*)d_a, (const Fe*)d_b, (Fe*)d_out, n, (hipStream_t)stream);
+}
+int wsnark_fr_dist_combine_dev(const void* d_e, const void* d_o, void* d_h_out, uint64_t rows, uint64_t cols, uint64_t row0, uint32_t log_n1,
+                               uint32_t log_n, void* stream) {
+    REQUIRE_CTX();
+    return dist_combine_dev((const Fe*)d_e, (const Fe*)d_o, (Fe*)d_h_out, rows, cols, row0, log_n1, log_n, (hipStream_t)stream);
 }
 int wsnark_groth16_verify(const void* vk, size_t vk_len, const void* inputs, uint64_t n_inputs, const void* proof384, int* valid) {
     if (!vk || !proof384 || !valid || (n_inputs && !inputs)) return WSNARK_ERR_ARG;

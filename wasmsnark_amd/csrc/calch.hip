@@ -98,6 +98,71 @@ int dist_scale_dev(Fe* d_data, uint64_t rows, uint64_t cols, uint64_t row0, uint
     return WS_OK;
 }
 
+// the last step of CALC_H on a rank's block of the interleaved layout: h[t] = fromMontgomery((e[t] - w_2n^-t o[t]) / 2),
+// t = (row0 + r) + n1 * c   (same formula as calch_combine_kernel, which is the single-GPU case rows = 1... n)
+__global__ __launch_bounds__(256) void dist_combine_kernel(const Fe* __restrict__ e, const Fe* __restrict__ o, Fe* __restrict__ h,
+                                                             uint64_t rows, uint64_t cols, uint64_t row0, uint32_t log_n1, uint32_t log_n,
+                                                             const Fe* __restrict__ cs_lo, const Fe* __restrict__ cs_hi, uint32_t hc, Fe half) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const uint64_t r = idx / cols, c = idx - r * cols;
+    const uint64_t t = (row0 + r) + (c << log_n1);
+    Fe v;
+    if (t == 0) {
+        v = Fr::sub(e[idx], o[idx]);
+    } else {
+        const uint64_t x = ((uint64_t)1 << log_n) - t;
+        v = Fr::add(e[idx], Fr::mul(Fr::mul(cs_hi[x >> hc], cs_lo[x & (((uint64_t)1 << hc) - 1)]), o[idx]));
+    }
+    h[idx] = Fr::from_mont(Fr::mul(v, half));
+}
+int dist_combine_dev(const Fe* d_e, const Fe* d_o, Fe* d_h, uint64_t rows, uint64_t cols, uint64_t row0, uint32_t log_n1, uint32_t log_n, hipStream_t s) {
+    Context* C = ctx();
+    if (!C) return WS_ERR_NOINIT;
+    if (!s) s = C->stream;
+    if (rows == 0 || cols == 0) return WS_OK;
+    if (!d_e || !d_o || !d_h) return WS_ERR_ARG;
+    if (log_n < 1 || log_n > 27 || log_n1 > log_n || cols != ((uint64_t)1 << (log_n - log_n1)) || row0 + rows > ((uint64_t)1 << log_n1)) return WS_ERR_SIZE;
+    const Fe *lo, *hi;
+    int hc;
+    Fe n_inv;
+    int rc = ntt_coset_tables((int)log_n, &lo, &hi, &hc, &n_inv, s);
+    if (rc) return rc;
+    const Fe half = Fr::inv(Fr::add(Fr::one(), Fr::one()));
+    hipLaunchKernelGGL(dist_combine_kernel, dim3(ceil_div_u64(rows * cols, 256)), dim3(256), 0, s, d_e, d_o, d_h, rows, cols, row0, log_n1, log_n,
+                       lo, hi, (uint32_t)hc, half);
+    WS_HIP_CHECK(hipGetLastError());
+    return WS_OK;
+}
+int fr_mul_dev(const Fe* d_a, const Fe* d_b, Fe* d_out, uint64_t n, hipStream_t s) {
+    Context* C = ctx();
+    if (!C) return WS_ERR_NOINIT;
+    if (n == 0) return WS_OK;
+    if (!d_a || !d_b || !d_out) return WS_ERR_ARG;
+    if (!s) s = C->stream;
+    hipLaunchKernelGGL(fr_mul_kernel, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s, d_a, d_b, d_out, n);
+    WS_HIP_CHECK(hipGetLastError());
+    return WS_OK;
+}
+// a = A w, b = B w (pol_constructLC twice, bn128.js:139-145) from a device-resident plain witness; Montgomery outputs
+int eval_ab_dev(Lane& L, const Fe* d_signals_plain, uint32_t n_signals, const CsrMatrix& A, const CsrMatrix& B, uint32_t domain,
+                Fe* d_a, Fe* d_b, hipStream_t s) {
+    Context* C = ctx();
+    if (!C) return WS_ERR_NOINIT;
+    if (!s) s = L.stream;
+    if (A.n_rows != domain || B.n_rows != domain || A.n_cols != n_signals || B.n_cols != n_signals || !d_a || !d_b) return WS_ERR_ARG;
+    ScratchGuard scratch_turn(L.calch_chain, s);
+    WS_HIP_CHECK(L.calch_buf[0].reserve((size_t)n_signals * sizeof(Fe)));
+    Fe* sigM = L.calch_buf[0].as<Fe>();
+    int rc = fr_map_dev(d_signals_plain, sigM, n_signals, 1, s);
+    if (rc) return rc;
+    const dim3 blk(256), grd(ceil_div_u64(domain, 256));
+    hipLaunchKernelGGL(lc_spmv_kernel, grd, blk, 0, s, A.row_ptr.as<uint32_t>(), A.col.as<uint32_t>(), A.coef.as<Fe>(), sigM, domain, d_a);
+    hipLaunchKernelGGL(lc_spmv_kernel, grd, blk, 0, s, B.row_ptr.as<uint32_t>(), B.col.as<uint32_t>(), B.coef.as<Fe>(), sigM, domain, d_b);
+    WS_HIP_CHECK(hipGetLastError());
+    return WS_OK;
+}
+
 int fr_map_dev(const Fe* d_in, Fe* d_out, uint64_t n, int to_mont, hipStream_t s) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;

@@ -180,5 +180,9 @@ int pols_to_csr(const uint8_t* pols, size_t len, uint32_t n_signals, uint32_t do
 int calc_h_dev(Lane& L, const Fe* d_signals_plain, uint32_t n_signals, const CsrMatrix& A, const CsrMatrix& B,
                uint32_t domain, Fe* d_h_out, hipStream_t s);
 int fr_map_dev(const Fe* d_in, Fe* d_out, uint64_t n, int to_mont, hipStream_t s);
+int fr_mul_dev(const Fe* d_a, const Fe* d_b, Fe* d_out, uint64_t n, hipStream_t s);
+int eval_ab_dev(Lane& L, const Fe* d_signals_plain, uint32_t n_signals, const CsrMatrix& A, const CsrMatrix& B, uint32_t domain,
+                Fe* d_a, Fe* d_b, hipStream_t s);
+int dist_combine_dev(const Fe* d_e, const Fe* d_o, Fe* d_h, uint64_t rows, uint64_t cols, uint64_t row0, uint32_t log_n1, uint32_t log_n, hipStream_t s);
 
 }  // namespace wsnark

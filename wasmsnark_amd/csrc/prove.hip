@@ -203,7 +203,7 @@ struct MsmSums {
 // The host finishes each sum while the GPU works on the next ones; `after_ab1` (optional) runs on the host as soon
 // as A and B1 are known.
 static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard sh, MsmSums* out, hipStream_t s,
-                      const std::function<void(const MsmSums&)>& after_ab1 = nullptr) {
+                      const std::function<void(const MsmSums&)>& after_ab1 = nullptr, bool skip_h = false) {
     Trace tr;
     const uint32_t nv = K->n_vars, dom = K->domain;
     int rc;
@@ -242,6 +242,17 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
     msm_select_plan(L, 0);
     if (rc) return rc;
     tr.mark("launch B2");
+    if (skip_h) {
+        // distributed proving with the four-step CALC_H (wasmsnark_amd/dist.py): h and the H sum are the caller's
+        if ((rc = msm_g1_finish(L, hA, &out->A))) return rc;
+        if ((rc = msm_g1_finish(L, hB1, &out->B1))) return rc;
+        if (after_ab1) after_ab1(*out);
+        if ((rc = msm_g1_finish(L, hC, &out->C))) return rc;
+        if ((rc = msm_g2_finish(L, hB2, &out->B2))) return rc;
+        out->H = G1::infinity();
+        guard.armed = false;
+        return WS_OK;
+    }
     // CALC_H, then the H MSM over domainSize pairs (src/bn128.js:607-615)
     if (s2 != s) WS_HIP_CHECK(hipStreamWaitEvent(s2, overlap == 2 ? L.ev_start : L.ev_tail, 0));
     WS_HIP_CHECK(L.h.reserve((size_t)dom * 32));
@@ -387,9 +398,9 @@ static int upload_witness(ProvingKey* K, Lane& L, const uint8_t* witness) {
 
 // ---- multi-GPU proving: per-rank partial sums, then one 576-byte record per rank to combine ----
 // record = A | B1 | C | H (4 x 96 B G1) | B2 (192 B G2), Jacobian-Montgomery, affine-normalised
-static int prove_partial_on(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard sh, uint8_t* out576, hipStream_t s) {
+static int prove_partial_on(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard sh, uint8_t* out576, hipStream_t s, bool skip_h) {
     MsmSums M;
-    int rc = prove_msms(K, L, d_witness, sh, &M, s ? s : L.stream);
+    int rc = prove_msms(K, L, d_witness, sh, &M, s ? s : L.stream, nullptr, skip_h);
     if (rc) return rc;
     Jac<Fq> j;
     j = G1::to_affine_jac(M.A); memcpy(out576, &j, 96);
@@ -399,22 +410,30 @@ static int prove_partial_on(ProvingKey* K, Lane& L, const Fe* d_witness, WindowS
     Jac<Fq2> j2 = G2::to_affine_jac(M.B2); memcpy(out576 + 384, &j2, 192);
     return WS_OK;
 }
-int groth16_prove_partial(ProvingKey* K, const uint8_t* witness, size_t witness_len, WindowShard sh, uint8_t* out576) {
+int groth16_prove_partial(ProvingKey* K, const uint8_t* witness, size_t witness_len, WindowShard sh, uint8_t* out576, bool skip_h) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
     int rc = check_witness_len(K, witness_len);
     if (rc) return rc;
     LaneLock L = acquire_lane(C);
     if ((rc = upload_witness(K, *L, witness))) return rc;
-    return prove_partial_on(K, *L, L->witness.as<Fe>(), sh, out576, L->stream);
+    return prove_partial_on(K, *L, L->witness.as<Fe>(), sh, out576, L->stream, skip_h);
 }
-int groth16_prove_partial_dev(ProvingKey* K, const Fe* d_witness, size_t witness_len, WindowShard sh, uint8_t* out576, hipStream_t s) {
+int groth16_prove_partial_dev(ProvingKey* K, const Fe* d_witness, size_t witness_len, WindowShard sh, uint8_t* out576, hipStream_t s, bool skip_h) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
     int rc = check_witness_len(K, witness_len);
     if (rc) return rc;
     LaneLock L = acquire_lane(C);
-    return prove_partial_on(K, *L, d_witness, sh, out576, s);
+    return prove_partial_on(K, *L, d_witness, sh, out576, s, skip_h);
+}
+int pkey_eval_ab_dev(ProvingKey* K, const Fe* d_witness, size_t witness_len, Fe* d_a, Fe* d_b, hipStream_t s) {
+    Context* C = ctx();
+    if (!C) return WS_ERR_NOINIT;
+    int rc = check_witness_len(K, witness_len);
+    if (rc) return rc;
+    LaneLock L = acquire_lane(C);
+    return eval_ab_dev(*L, d_witness, K->n_vars, K->polsA, K->polsB, K->domain, d_a, d_b, s);
 }
 int groth16_prove_finish(ProvingKey* K, const uint8_t* partials, uint64_t n_ranks, const uint8_t* r32,
                          const uint8_t* s32, uint8_t* out384) {

@@ -91,30 +91,32 @@ def sharded_prove(bn, key, witness, r=None, s=None, device=None, d_witness=None)
 # GPUs; the CPU tests run the same code on gloo with the thread-emulator build, where all_to_all falls back to
 # all_gather when the backend lacks it).  All arithmetic is exact: results are bit-identical to wsnark_fr_ntt.
 # ---------------------------------------------------------------------------------------------------------------
-def ntt_layout_split(log_n, world):
-    """(log_n1, log_n2) of the four-step split used by dist_ntt: n1 >= n2, both divisible by the world size."""
+def ntt_layout_split(log_n, world, flip=False):
+    """(log_n1, log_n2) of the four-step split used by dist_ntt: n1 >= n2 (flip: n1 <= n2), both divisible by the world
+    size.  A transform maps the n1-interleaved layout to the n2-interleaved one, so a chain of transforms alternates
+    flip = False, True, False, ... (for even log_n both are the same split and nothing alternates)."""
     log_n1 = (log_n + 1) // 2
     log_n2 = log_n - log_n1
     if world & (world - 1) or (1 << log_n2) < world:
         raise ValueError("dist_ntt needs a power-of-two world size <= n2 = 2^%d" % log_n2)
-    return log_n1, log_n2
+    return (log_n2, log_n1) if flip else (log_n1, log_n2)
 
 
-def to_interleaved(x_full, log_m, rank, world):
-    """Slice of a full vector (uint8 tensor of n*32 bytes, any device) in the m-interleaved layout (m = 2^log_m):
+def to_interleaved(x_full, log_m, rank, world, elem=32):
+    """Slice of a full vector (uint8 tensor of n*elem bytes, any device) in the m-interleaved layout (m = 2^log_m):
     rows = the rank's residues i mod m, each row the complete sub-sequence x[res + m*j], j = 0 .. n/m - 1."""
     m = 1 << log_m
-    n = x_full.numel() // 32
+    n = x_full.numel() // elem
     per = m // world
-    v = x_full.view(n // m, m, 32)[:, rank * per:(rank + 1) * per, :]
+    v = x_full.view(n // m, m, elem)[:, rank * per:(rank + 1) * per, :]
     return v.permute(1, 0, 2).contiguous().view(-1)
 
 
-def from_interleaved(parts, log_m):
+def from_interleaved(parts, log_m, elem=32):
     """Inverse of to_interleaved for the concatenation (rank order) of all ranks' slices."""
     m = 1 << log_m
-    n = parts.numel() // 32
-    return parts.view(m, n // m, 32).permute(1, 0, 2).contiguous().view(-1)
+    n = parts.numel() // elem
+    return parts.view(m, n // m, elem).permute(1, 0, 2).contiguous().view(-1)
 
 
 def _all_to_all(out, inp, group=None):
@@ -129,7 +131,7 @@ def _all_to_all(out, inp, group=None):
             out[q * chunk:(q + 1) * chunk] = parts[q][rank * chunk:(rank + 1) * chunk]
 
 
-def dist_ntt(bn, x_local, log_n, odd=0, inverse=False, group=None):
+def dist_ntt(bn, x_local, log_n, odd=0, inverse=False, group=None, flip=False):
     """fft_fft / fft_ifft (src/build_fft.js:159-221) of a length-2^log_n vector of Montgomery Fr elements spread over the
     ranks.  x_local: this rank's uint8 tensor in the n1-interleaved layout (to_interleaved(x, log_n1, ...)) on the
     device the library runs on; it is overwritten.  Returns the rank's slice of the result in the n2-interleaved layout
@@ -138,22 +140,22 @@ def dist_ntt(bn, x_local, log_n, odd=0, inverse=False, group=None):
         world, rank = dist.get_world_size(group), dist.get_rank(group)
     else:
         world, rank = 1, 0            # a world of one: the same four steps, the exchange is the identity
-    log_n1, log_n2 = ntt_layout_split(log_n, world)
+    log_n1, log_n2 = ntt_layout_split(log_n, world, flip)
     n1, n2 = 1 << log_n1, 1 << log_n2
     r1, r2 = n1 // world, n2 // world
     if x_local.numel() != r1 * n2 * 32 or not x_local.is_contiguous():
         raise ValueError("x_local must be the rank's contiguous (n1/P) x n2 block")
     c = bn.lib.c
     inv = 1 if inverse else 0
-    sync = (lambda: torch.cuda.synchronize()) if x_local.is_cuda else (lambda: None)
+    # everything is enqueued on torch's current stream: the library kernels (stream argument), the layout permutes and the
+    # collective are then ordered by the stream itself -- no host synchronisation inside a transform
+    st = torch.cuda.current_stream(x_local.device).cuda_stream if x_local.is_cuda else None
     ptr = x_local.data_ptr()
     if odd:      # x[t] *= w_2n^t (also for the inverse: the reference's rawfft scales before its index flip)
-        bn.lib.check(c.wsnark_fr_dist_scale_dev(ptr, r1, n2, rank * r1, log_n1, log_n, 1, 0, None))
+        bn.lib.check(c.wsnark_fr_dist_scale_dev(ptr, r1, n2, rank * r1, log_n1, log_n, 1, 0, st))
     if log_n2 >= 1:
-        bn.lib.check(c.wsnark_fr_ntt_batch_dev(ptr, n2, r1, inv, None))          # column step: r1 transforms over i2
-    bn.lib.check(c.wsnark_fr_dist_scale_dev(ptr, r1, n2, rank * r1, log_n1, log_n, 0, inv, None))
-    bn.lib.c.wsnark_timing_report(None, 0)                                        # the library's queues have drained
-    sync()
+        bn.lib.check(c.wsnark_fr_ntt_batch_dev(ptr, n2, r1, inv, st))            # column step: r1 transforms over i2
+    bn.lib.check(c.wsnark_fr_dist_scale_dev(ptr, r1, n2, rank * r1, log_n1, log_n, 0, inv, st))
     send = x_local.view(r1, world, r2, 32).permute(1, 0, 2, 3).contiguous().view(-1)   # block q = my rows x rank q's columns
     if world == 1:
         recv = send
@@ -162,8 +164,94 @@ def dist_ntt(bn, x_local, log_n, odd=0, inverse=False, group=None):
         _all_to_all(recv, send, group)
     # received block q = rank q's rows (its i1 range) x my columns  ->  (my k2) x (all i1)
     y = recv.view(world, r1, r2, 32).permute(2, 0, 1, 3).contiguous().view(-1)
-    sync()
-    bn.lib.check(c.wsnark_fr_ntt_batch_dev(y.data_ptr(), n1, r2, inv, None))       # row step: r2 transforms over i1
-    bn.lib.c.wsnark_timing_report(None, 0)
-    sync()
+    bn.lib.check(c.wsnark_fr_ntt_batch_dev(y.data_ptr(), n1, r2, inv, st))         # row step: r2 transforms over i1
     return y
+
+
+class DistProver:
+    """Groth16 proving over the ranks of one node with NOTHING replicated but the cheap parts: the four sums over the
+    witness are window-sharded (wsnark_groth16_prove_partial, WSNARK_PARTIAL_SKIP_H), CALC_H runs on the distributed
+    four-step transform (seven transforms, one all-to-all each), and every rank sums ITS slice of h against ITS slice of
+    the key's H points -- a points-sharded partial sum that goes into the H slot of the rank's 576-byte record.  One
+    all_gather of the records and the host-side finish as in sharded_prove.  The two linear combinations a = A w, b = B w
+    are still evaluated in full on every rank (0.3 ms at 2^20: one sparse product each), then sliced.
+    Reference shape: src/bn128.js:126-166 (CALC_H on one worker) + :353-415 (sums split over workers)."""
+
+    def __init__(self, bn, key, points_h, device=None, group=None):
+        """points_h: the key's hExps section (domain x 64 B, reference format: proving_key.bin from offset pHExps)."""
+        self.bn, self.key, self.group, self.device = bn, key, group, device
+        if dist.is_available() and dist.is_initialized():
+            self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        else:
+            self.world, self.rank = 1, 0
+        dom = key.domain
+        self.log_n = dom.bit_length() - 1
+        if len(points_h) < dom * 64:
+            raise ValueError("points_h shorter than domain * 64 bytes")
+        # h comes out of three chained transforms (l1 -> l2 -> l1 -> l2): it is n2-interleaved, n2 of the UNflipped split
+        self.l1, self.l2 = ntt_layout_split(self.log_n, self.world)
+        full = torch.frombuffer(bytearray(points_h[:dom * 64]), dtype=torch.uint8)
+        mine = to_interleaved(full, self.l2, self.rank, self.world, elem=64).clone()
+        self.h_points = mine.to(device) if device is not None else mine
+        self.n_local = dom // self.world
+
+    def _calc_h_local(self, d_witness, witness_len):
+        """This rank's slice of h (plain form, n2-interleaved), computed with the distributed transform."""
+        bn, c, dom = self.bn, self.bn.lib.c, self.key.domain
+        dev = self.h_points.device
+        st = torch.cuda.current_stream(dev).cuda_stream if self.h_points.is_cuda else None
+        a = torch.empty(dom * 32, dtype=torch.uint8, device=dev)
+        b = torch.empty(dom * 32, dtype=torch.uint8, device=dev)
+        bn.lib.check(c.wsnark_pkey_eval_ab_dev(self.key._h, d_witness, witness_len, a.data_ptr(), b.data_ptr(), st))
+        a = to_interleaved(a, self.l1, self.rank, self.world)
+        b = to_interleaved(b, self.l1, self.rank, self.world)
+        n_loc = a.numel() // 32
+        e = torch.empty_like(a)
+        bn.lib.check(c.wsnark_fr_mul_dev(a.data_ptr(), b.data_ptr(), e.data_ptr(), n_loc, st))          # E = A.B on the domain
+        nt = lambda x, flip, **kw: dist_ntt(bn, x, self.log_n, group=self.group, flip=flip, **kw)
+        a, b = nt(a, False, inverse=True), nt(b, False, inverse=True)                                    # coefficients (l2-interleaved)
+        a, b = nt(a, True, odd=1), nt(b, True, odd=1)                                                    # odd-coset evaluations (l1)
+        o = torch.empty_like(a)
+        bn.lib.check(c.wsnark_fr_mul_dev(a.data_ptr(), b.data_ptr(), o.data_ptr(), n_loc, st))          # O = A.B on the coset
+        e, o = nt(e, False, inverse=True), nt(o, False, inverse=True)                                    # both l2-interleaved
+        rows = (1 << self.l2) // self.world
+        h = torch.empty_like(e)
+        bn.lib.check(c.wsnark_fr_dist_combine_dev(e.data_ptr(), o.data_ptr(), h.data_ptr(), rows, 1 << (self.log_n - self.l2),
+                                                  self.rank * rows, self.l2, self.log_n, st))
+        if h.is_cuda:
+            torch.cuda.current_stream(dev).synchronize()      # the H sum below runs on the library's own queue
+        return h
+
+    def prove(self, d_witness, witness_len, r=None, s=None):
+        """d_witness: device pointer of the plain witness on this rank's GPU.  r, s: as in sharded_prove."""
+        import os
+        import threading
+        bn, rank, world = self.bn, self.rank, self.world
+        box = {}
+
+        def sums():      # A, B1, C, B2 on this rank's windows: a blocking call, so it gets its own host thread (and lane)
+            try:
+                box["rec"] = bn.groth16_prove_partial_dev(d_witness, witness_len, self.key, shard=(rank, world), skip_h=True)
+            except Exception as ex:  # noqa: BLE001
+                box["err"] = ex
+
+        th = threading.Thread(target=sums)
+        th.start()
+        try:
+            h = self._calc_h_local(d_witness, witness_len)
+            hpart = bn.g1_multiexp_dev(h.data_ptr(), self.h_points.data_ptr(), self.n_local)    # points-sharded partial of the H sum
+        finally:
+            th.join()
+        if "err" in box:
+            raise box["err"]
+        part = box["rec"][:288] + hpart + box["rec"][384:]
+        draw = r is None or s is None
+        if draw:
+            part += (os.urandom(64) if rank == 0 else bytes(64))
+        allp = allgather_partials(part, self.device) if world > 1 else part
+        if draw:
+            rec = len(part)
+            r0, s0 = allp[576:608], allp[608:640]
+            r, s = (r if r is not None else r0), (s if s is not None else s0)
+            allp = b"".join(allp[i * rec:i * rec + 576] for i in range(world))
+        return bn.groth16_prove_finish(self.key, allp, r=r, s=s)
