@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call: environment probe, GPU parity tests, bench, rocprof kernel stats, PMC traffic.
-#   TAG=r02_s1 [SKIP="tests pmc"] [PYTEST_ARGS="-k ..."] tools/gpu_session.sh
+#   TAG=r02_s1 [SKIP="tests pmc"] [PYTEST_K="expr for -k"] tools/gpu_session.sh
 cd "$GRAFT_REPO_ROOT" || exit 1
 TAG=${TAG:-r02}
 O=gpurun_out/$TAG
@@ -12,7 +12,7 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 } > "$O/env.log" 2>&1
 skip() { [[ " $SKIP " == *" $1 "* ]]; }
 if ! skip tests; then
-  timeout 2400 python -m pytest tests -m gpu -q --timeout 1200 -p no:cacheprovider --durations=12 $PYTEST_ARGS > "$O/pytest_gpu.txt" 2>&1
+  timeout 2400 python -m pytest tests -m gpu -q --timeout 1200 -p no:cacheprovider --durations=12 ${PYTEST_K:+-k "$PYTEST_K"} > "$O/pytest_gpu.txt" 2>&1
   echo "pytest rc=$?" >> "$O/env.log"
 fi
 if ! skip bench; then
