@@ -131,7 +131,53 @@ def _all_to_all(out, inp, group=None):
             out[q * chunk:(q + 1) * chunk] = parts[q][rank * chunk:(rank + 1) * chunk]
 
 
+_side_streams = {}
+
+
+class _on_side_stream:
+    """Runs a block on a dedicated (non-default) torch stream of the tensor's device and hands that stream's handle to the
+    library: torch's default stream is the NULL stream, which the C ABI reads as "use the library's own queue" -- the kernels
+    would then not be ordered with the torch ops around them.  Entry and exit are ordered with the caller's current
+    stream by events (wait_stream), not by host synchronisation.  CPU tensors (emulator tests): a no-op."""
+
+    def __init__(self, t):
+        self.cuda = t.is_cuda
+        self.handle = None
+        if self.cuda:
+            dev = t.device
+            if dev not in _side_streams:
+                _side_streams[dev] = torch.cuda.Stream(device=dev)
+            self.side = _side_streams[dev]
+            self.cur = torch.cuda.current_stream(dev)
+
+    def __enter__(self):
+        if self.cuda and self.cur.cuda_stream != self.side.cuda_stream:
+            self.side.wait_stream(self.cur)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+            self.handle = self.side.cuda_stream
+        elif self.cuda:
+            self.ctx = None
+            self.handle = self.side.cuda_stream
+        return self
+
+    def __exit__(self, *exc):
+        if self.cuda and self.ctx is not None:
+            self.ctx.__exit__(*exc)
+            self.cur.wait_stream(self.side)
+        return False
+
+
 def dist_ntt(bn, x_local, log_n, odd=0, inverse=False, group=None, flip=False):
+    with _on_side_stream(x_local) as ss:
+        y = _dist_ntt(bn, x_local, log_n, odd, inverse, group, flip, ss.handle)
+        if x_local.is_cuda:
+            x_local.record_stream(torch.cuda.current_stream(x_local.device))
+            y.record_stream(torch.cuda.current_stream(x_local.device))
+    return y
+
+
+def _dist_ntt(bn, x_local, log_n, odd, inverse, group, flip, st):
     """fft_fft / fft_ifft (src/build_fft.js:159-221) of a length-2^log_n vector of Montgomery Fr elements spread over the
     ranks.  x_local: this rank's uint8 tensor in the n1-interleaved layout (to_interleaved(x, log_n1, ...)) on the
     device the library runs on; it is overwritten.  Returns the rank's slice of the result in the n2-interleaved layout
@@ -147,9 +193,8 @@ def dist_ntt(bn, x_local, log_n, odd=0, inverse=False, group=None, flip=False):
         raise ValueError("x_local must be the rank's contiguous (n1/P) x n2 block")
     c = bn.lib.c
     inv = 1 if inverse else 0
-    # everything is enqueued on torch's current stream: the library kernels (stream argument), the layout permutes and the
-    # collective are then ordered by the stream itself -- no host synchronisation inside a transform
-    st = torch.cuda.current_stream(x_local.device).cuda_stream if x_local.is_cuda else None
+    # everything is enqueued on ONE (non-default) torch stream: the library kernels (stream argument `st`), the layout
+    # permutes and the collective are ordered by the stream itself -- no host synchronisation inside a transform
     ptr = x_local.data_ptr()
     if odd:      # x[t] *= w_2n^t (also for the inverse: the reference's rawfft scales before its index flip)
         bn.lib.check(c.wsnark_fr_dist_scale_dev(ptr, r1, n2, rank * r1, log_n1, log_n, 1, 0, st))
@@ -197,9 +242,15 @@ class DistProver:
 
     def _calc_h_local(self, d_witness, witness_len):
         """This rank's slice of h (plain form, n2-interleaved), computed with the distributed transform."""
+        with _on_side_stream(self.h_points) as ss:
+            h = self._calc_h_on(d_witness, witness_len, ss.handle)
+            if h.is_cuda:
+                torch.cuda.current_stream(h.device).synchronize()      # the H sum runs on the library's own queue
+        return h
+
+    def _calc_h_on(self, d_witness, witness_len, st):
         bn, c, dom = self.bn, self.bn.lib.c, self.key.domain
         dev = self.h_points.device
-        st = torch.cuda.current_stream(dev).cuda_stream if self.h_points.is_cuda else None
         a = torch.empty(dom * 32, dtype=torch.uint8, device=dev)
         b = torch.empty(dom * 32, dtype=torch.uint8, device=dev)
         bn.lib.check(c.wsnark_pkey_eval_ab_dev(self.key._h, d_witness, witness_len, a.data_ptr(), b.data_ptr(), st))
@@ -208,7 +259,7 @@ class DistProver:
         n_loc = a.numel() // 32
         e = torch.empty_like(a)
         bn.lib.check(c.wsnark_fr_mul_dev(a.data_ptr(), b.data_ptr(), e.data_ptr(), n_loc, st))          # E = A.B on the domain
-        nt = lambda x, flip, **kw: dist_ntt(bn, x, self.log_n, group=self.group, flip=flip, **kw)
+        nt = lambda x, flip, **kw: _dist_ntt(bn, x, self.log_n, kw.get("odd", 0), kw.get("inverse", False), self.group, flip, st)
         a, b = nt(a, False, inverse=True), nt(b, False, inverse=True)                                    # coefficients (l2-interleaved)
         a, b = nt(a, True, odd=1), nt(b, True, odd=1)                                                    # odd-coset evaluations (l1)
         o = torch.empty_like(a)
@@ -218,8 +269,6 @@ class DistProver:
         h = torch.empty_like(e)
         bn.lib.check(c.wsnark_fr_dist_combine_dev(e.data_ptr(), o.data_ptr(), h.data_ptr(), rows, 1 << (self.log_n - self.l2),
                                                   self.rank * rows, self.l2, self.log_n, st))
-        if h.is_cuda:
-            torch.cuda.current_stream(dev).synchronize()      # the H sum below runs on the library's own queue
         return h
 
     def prove(self, d_witness, witness_len, r=None, s=None):
