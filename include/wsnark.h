@@ -223,7 +223,10 @@ enum {
     WSNARK_ST_MULSUB2 = 11,      /* (a - b)*a - b*a: fused, first operand an uncorrected difference   */
     WSNARK_ST_EQ = 12,           /* out = 1 if a == b else 0 (zero test of the strict difference)    */
     WSNARK_ST_EQ_WEAK = 13,      /* the same through the uncorrected difference                      */
-    WSNARK_ST_INVERSE = 14       /* 1/a (a != 0); host field only (impl 2): f1m_inverse is per-proof host work */
+    WSNARK_ST_INVERSE = 14,      /* 1/a (a != 0); host field only (impl 2): f1m_inverse is per-proof host work */
+    WSNARK_ST_SQR_WEAK = 15,     /* (a - b)^2 with the uncorrected difference as the operand of the squaring        */
+    WSNARK_ST_MUL_WEAK_A = 16,   /* (a - b) * b with the uncorrected difference as the FIRST operand of the product */
+    WSNARK_ST_MULSUB2_WEAK_B = 17 /* a*(a - b) - b*a: fused, second operand an uncorrected difference              */
 };
 int wsnark_selftest_field(int which, int impl, int op, const void* a, const void* b, void* out, uint64_t n);
 /*   g: 1 or 2; impl: 0 = radix-2^29 curve of the accumulation kernels, 1 = saturated-field curve on the device,

@@ -11,7 +11,7 @@ from conftest import load_golden
 
 H = bytes.fromhex
 
-MUL, SQR, ADD, SUB, NEG, TOMONT, FROMMONT, SUB_WEAK, ADD_LAZY_MUL, NEG_WEAK_MUL, MUL2ADD, MULSUB2, EQ, EQ_WEAK, INVERSE = range(15)
+MUL, SQR, ADD, SUB, NEG, TOMONT, FROMMONT, SUB_WEAK, ADD_LAZY_MUL, NEG_WEAK_MUL, MUL2ADD, MULSUB2, EQ, EQ_WEAK, INVERSE, SQR_WEAK, MUL_WEAK_A, MULSUB2_WEAK_B = range(18)
 FIELD_IMPLS = {0: "radix-2^29 device field", 1: "saturated device field", 2: "host field"}
 CURVE_IMPLS = {1: (0, 1, 2, 3), 2: (0, 1, 2)}
 
@@ -83,6 +83,9 @@ def check_base_field(bn, fname, which, impl):
     assert st_field(bn, which, impl, NEG_WEAK_MUL, pa, pb) == [_le((p - x) * y * rinv % p) for x, y in pairs]
     assert st_field(bn, which, impl, MUL2ADD, pa, pb) == [_le((x * x + y * y) * rinv % p) for x, y in pairs]
     assert st_field(bn, which, impl, MULSUB2, pa, pb) == [_le(((x - y) * x - y * x) * rinv % p) for x, y in pairs]
+    assert st_field(bn, which, impl, SQR_WEAK, pa, pb) == [_le((x - y) * (x - y) * rinv % p) for x, y in pairs]
+    assert st_field(bn, which, impl, MUL_WEAK_A, pa, pb) == [_le((x - y) * y * rinv % p) for x, y in pairs]
+    assert st_field(bn, which, impl, MULSUB2_WEAK_B, pa, pb) == [_le((x * (x - y) - y * x) * rinv % p) for x, y in pairs]
     flags = [_le(1 if x == y else 0) for x, y in pairs]
     assert st_field(bn, which, impl, EQ, pa, pb) == flags
     assert st_field(bn, which, impl, EQ_WEAK, pa, pb) == flags
@@ -117,6 +120,12 @@ def check_fq2(bn, impl):
     assert st_field(bn, 2, impl, NEG, pa, pa) == [enc(((-x[0]) % q, (-x[1]) % q)) for x, _ in pairs]
     want = [enc(sub(mul(sub(x, y), x), mul(y, x))) for x, y in pairs]
     assert st_field(bn, 2, impl, MULSUB2, pa, pb) == want
+    # uncorrected differences where the G2 formulas put them: operand of the squaring, first operand of the product,
+    # second operand of the fused a*b - c*d
+    assert st_field(bn, 2, impl, SUB_WEAK, pa, pb) == [enc(sub(x, y)) for x, y in pairs]
+    assert st_field(bn, 2, impl, SQR_WEAK, pa, pb) == [enc(mul(sub(x, y), sub(x, y))) for x, y in pairs]
+    assert st_field(bn, 2, impl, MUL_WEAK_A, pa, pb) == [enc(mul(sub(x, y), y)) for x, y in pairs]
+    assert st_field(bn, 2, impl, MULSUB2_WEAK_B, pa, pb) == [enc(sub(mul(x, sub(x, y)), mul(y, x))) for x, y in pairs]
     flag = lambda v: _le(v) + bytes(32)
     assert st_field(bn, 2, impl, EQ, pa, pb) == [flag(1 if x == y else 0) for x, y in pairs]
     assert st_field(bn, 2, impl, EQ_WEAK, pa, pb) == [flag(1 if x == y else 0) for x, y in pairs]

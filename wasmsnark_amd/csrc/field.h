@@ -187,6 +187,9 @@ struct Field {
     WS_HD static Fe sub_wide(const Fe& a, const Fe& b) { return sub(a, b); }
     WS_HD static bool is_zero_wide(const Fe& a) { return is_zero(a); }
     WS_HD static Fe narrow(const Fe& a) { return a; }
+    WS_HD static Fe sub_weak4(const Fe& a, const Fe& b) { return sub(a, b); }
+    WS_HD static Fe neg_weak(const Fe& a) { return neg(a); }
+    WS_HD static Fe neg_weak4(const Fe& a) { return neg(a); }
 
     // build_f1m.js:86-100
     WS_HD static Fe sub(const Fe& a, const Fe& b) {

@@ -190,6 +190,32 @@ struct Field29 {
         d.v[8] = (uint32_t)((int32_t)a.v[8] - (int32_t)b.v[8] + (int32_t)p2_limb(8) + c);
         return d;
     }
+    // a - b + 4p for a, b < 4p (uncorrected differences themselves): in (0, 8p), tight limbs.  Operand of a product only.
+    WS_HD static F29 sub_weak4(const F29& a, const F29& b) {
+        F29 d;
+        int32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int32_t t = (int32_t)a.v[i] - (int32_t)b.v[i] + (int32_t)kp_limb(4, i) + c;
+            d.v[i] = (uint32_t)t & WS_M29;
+            c = t >> 29;
+        }
+        d.v[8] = (uint32_t)((int32_t)a.v[8] - (int32_t)b.v[8] + (int32_t)kp_limb(4, 8) + c);
+        return d;
+    }
+    // 4p - c for c in [0, 4p): in (0, 4p]; only ever an operand of a product
+    WS_HD static F29 neg_weak4(const F29& c) {
+        F29 n;
+        int32_t cy = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int32_t t = (int32_t)kp_limb(4, i) - (int32_t)c.v[i] + cy;
+            n.v[i] = (uint32_t)t & WS_M29;
+            cy = t >> 29;
+        }
+        n.v[8] = (uint32_t)((int32_t)kp_limb(4, 8) - (int32_t)c.v[8] + cy);
+        return n;
+    }
     // zero test for a sub_weak result (value in (0, 4p)): zero iff p, 2p or 3p
     WS_HD static bool is_zero_weak(const F29& a) {
         // cheap filter on the lowest limb first (a multiple of p matches one of three constants)

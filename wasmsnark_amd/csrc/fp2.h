@@ -13,6 +13,10 @@
 #define WS_FP2_INLINE 1   // products of the quadratic extension as inlined bodies (G2 accumulate 4.15 -> 3.93 ms)
 #endif
 
+#ifndef WS_FP2_WEAK
+#define WS_FP2_WEAK 1   // uncorrected differences as operands of the extension's products + one-pass X3 (0: round-1 strict forms, for A/B builds)
+#endif
+
 #ifndef WS_FP2_SQR_INLINE
 #define WS_FP2_SQR_INLINE 1   // (G2 accumulate 3.76 -> 3.65 ms)
 #endif
@@ -43,13 +47,24 @@ struct Fp2T {
     WS_HD static El add(const El& a, const El& b) { return El{B::add(a.c0, b.c0), B::add(a.c1, b.c1)}; }
     WS_HD static El dbl(const El& a) { return El{B::dbl(a.c0), B::dbl(a.c1)}; }
     WS_HD static El sub(const El& a, const El& b) { return El{B::sub(a.c0, b.c0), B::sub(a.c1, b.c1)}; }
-    // (the quadratic extension keeps strict operands: its products negate and re-add components)
+    // Uncorrected differences (components in (0, 4p), base field's sub_weak) are allowed where the curve formulas put them:
+    // as the FIRST operand of mul, as the operand of sqr, and as the first two operands of mulsub2.  The second operand of
+    // mul and the last two of mulsub2 stay strict (< 2p): their components are negated with the 2p form.
+    // (For the saturated base field every weak form is the strict one.)
+#if WS_FP2_WEAK
+    WS_HD static El sub_weak(const El& a, const El& b) { return El{B::sub_weak(a.c0, b.c0), B::sub_weak(a.c1, b.c1)}; }
+    WS_HD static bool is_zero_weak(const El& a) { return B::is_zero_weak(a.c0) && B::is_zero_weak(a.c1); }
+    // X of an addition: one carry pass per component, then narrowed (the extension keeps its stored coordinates strict)
+    WS_HD static El x3_wide(const El& rr, const El& ppp, const El& q) {
+        return El{B::narrow(B::x3_wide(rr.c0, ppp.c0, q.c0)), B::narrow(B::x3_wide(rr.c1, ppp.c1, q.c1))};
+    }
+#else
     WS_HD static El sub_weak(const El& a, const El& b) { return sub(a, b); }
     WS_HD static bool is_zero_weak(const El& a) { return is_zero(a); }
-    // (the quadratic extension's products negate and re-add components: no wide operands; strict fall-backs)
     WS_HD static El x3_wide(const El& rr, const El& ppp, const El& q) { return sub(sub(rr, ppp), dbl(q)); }
-    WS_HD static El sub_wide(const El& a, const El& b) { return sub(a, b); }
-    WS_HD static bool is_zero_wide(const El& a) { return is_zero(a); }
+#endif
+    WS_HD static El sub_wide(const El& a, const El& b) { return sub_weak(a, b); }
+    WS_HD static bool is_zero_wide(const El& a) { return is_zero_weak(a); }
     WS_HD static El narrow(const El& a) { return a; }
     WS_HD static El neg(const El& a) { return El{B::neg(a.c0), B::neg(a.c1)}; }
     WS_HD static El cneg(const El& a, bool s) { return s ? neg(a) : a; }
@@ -58,7 +73,7 @@ struct Fp2T {
     // component) the radix-2^29 field does it in two calls and one negation: ~30 % fewer instructions.
     template <class BB = B>
     WS_HD static typename std::enable_if<BB::kHasMul2Add, El>::type mul(const El& a, const El& b) {
-        const BE nb1 = B::neg(b.c1);
+        const BE nb1 = B::neg_weak(b.c1);     // a: components < 4p allowed; b: strict.  (4p*2p)*2 = 16 p^2: < 1.1p after reduction
 #if WS_FP2_INLINE
         return El{B::mul2add_inl(a.c0, b.c0, a.c1, nb1), B::mul2add_inl(a.c0, b.c1, a.c1, b.c0)};
 #else
@@ -75,7 +90,8 @@ struct Fp2T {
     // a*b - c*d: with the fused four-product reduction two Montgomery passes instead of four products + a correction
     template <class BB = B>
     WS_HD static typename std::enable_if<BB::kHasMul2Add, El>::type mulsub2(const El& a, const El& b, const El& c, const El& d) {
-        const BE nb1 = B::neg_weak(b.c1), nc0 = B::neg_weak(c.c0), nc1 = B::neg_weak(c.c1);
+        // a, b: components < 4p allowed (b.c1 is negated with the 4p form); c, d strict.  32 p^2 + 8 p^2 = 40 p^2: < 1.3p
+        const BE nb1 = B::neg_weak4(b.c1), nc0 = B::neg_weak(c.c0), nc1 = B::neg_weak(c.c1);
         return El{B::mul4add(a.c0, b.c0, a.c1, nb1, nc0, d.c0, c.c1, d.c1),
                   B::mul4add(a.c0, b.c1, a.c1, b.c0, nc0, d.c1, nc1, d.c0)};
     }
@@ -86,11 +102,11 @@ struct Fp2T {
     // complex squaring, 2 base-field products (build_f2m.js:186-227)
     WS_HD static El sqr(const El& a) {
 #if WS_FP2_SQR_INLINE
-        BE AB = B::mul_inl(a.c0, a.c1);
-        BE t = B::mul_inl(B::add_lazy(a.c0, a.c1), B::sub(a.c0, a.c1));
+        BE AB = B::mul_inl(a.c0, a.c1);      // a: components < 4p allowed: (a0 + a1) < 8p, (a0 - a1 + 4p) < 8p, 64 p^2: < 1.4p
+        BE t = B::mul_inl(B::add_lazy(a.c0, a.c1), B::sub_weak4(a.c0, a.c1));
 #else
         BE AB = B::mul(a.c0, a.c1);
-        BE t = B::mul(B::add_lazy(a.c0, a.c1), B::sub(a.c0, a.c1));
+        BE t = B::mul(B::add_lazy(a.c0, a.c1), B::sub_weak4(a.c0, a.c1));
 #endif
         return El{t, B::dbl(AB)};
     }

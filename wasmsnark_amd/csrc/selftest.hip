@@ -43,6 +43,9 @@ __host__ __device__ inline Fe st_base_op(int op, const Fe& ap, const Fe& bp, con
         case WSNARK_ST_SUB_WEAK: return F::from_internal(F::sub_weak(a, b));
         case WSNARK_ST_ADD_LAZY_MUL: return F::from_internal(F::mul(F::add_lazy(a, b), b));
         case WSNARK_ST_MULSUB2: return F::from_internal(F::mulsub2(F::sub_weak(a, b), a, b, a));
+        case WSNARK_ST_SQR_WEAK: return F::from_internal(F::sqr(F::sub_weak(a, b)));
+        case WSNARK_ST_MUL_WEAK_A: return F::from_internal(F::mul(F::sub_weak(a, b), b));
+        case WSNARK_ST_MULSUB2_WEAK_B: return F::from_internal(F::mulsub2(a, F::sub_weak(a, b), b, a));
         case WSNARK_ST_EQ: return st_flag<Fe>(F::is_zero(F::sub(a, b)));
         case WSNARK_ST_EQ_WEAK: return st_flag<Fe>(F::is_zero_weak(F::sub_weak(a, b)));
         default: break;
@@ -73,6 +76,9 @@ __host__ __device__ inline typename F2::Packed st_ext_op(int op, const typename 
         case WSNARK_ST_NEG: return F2::from_internal(F2::neg(a));
         case WSNARK_ST_SUB_WEAK: return F2::from_internal(F2::sub_weak(a, b));
         case WSNARK_ST_MULSUB2: return F2::from_internal(F2::mulsub2(F2::sub_weak(a, b), a, b, a));
+        case WSNARK_ST_SQR_WEAK: return F2::from_internal(F2::sqr(F2::sub_weak(a, b)));
+        case WSNARK_ST_MUL_WEAK_A: return F2::from_internal(F2::mul(F2::sub_weak(a, b), b));
+        case WSNARK_ST_MULSUB2_WEAK_B: return F2::from_internal(F2::mulsub2(a, F2::sub_weak(a, b), b, a));
         case WSNARK_ST_EQ: return st_flag<Pk>(F2::is_zero(F2::sub(a, b)));
         case WSNARK_ST_EQ_WEAK: return st_flag<Pk>(F2::is_zero_weak(F2::sub_weak(a, b)));
         default: break;
