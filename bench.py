@@ -43,14 +43,14 @@ def kernel_ms(report, per=1):
     return {k: round(v[0] / max(per, 1), 4) for k, v in sorted(report.items())}
 
 
-def build_prover(bn, logd, style, seed=1, keep_h=False):
+def build_prover(bn, logd, style, seed=1, keep_h=False, container="auto"):
     """Synthetic circuit + key (device-resident) + witness bytes.  Keys past the 4 GiB of proving_key.bin's u32 offsets
     (2^23 constraints and up) go through the sections loader."""
     from wasmsnark_amd import synth
     t0 = time.perf_counter()
     circ = synth.make_circuit(logd, n_public=5, seed=seed, style=style)
     S = synth.setup(circ, seed=seed + 1)
-    if logd >= 23:
+    if container == "sections" or (container == "auto" and logd >= 23):
         sec, _ = synth.build_sections(circ, S, bn.mul_base)
         key = bn.load_key(sections=sec)
         key_bytes = sum(len(v) for v in sec.values() if isinstance(v, (bytes, bytearray)))
@@ -65,7 +65,8 @@ def build_prover(bn, logd, style, seed=1, keep_h=False):
     nnz = sum(len(c) for c in circ.A) + sum(len(c) for c in circ.B)
     absent = (sum(1 for c in circ.A if not c), sum(1 for c in circ.B if not c))
     info = {"log_domain": logd, "n_vars": circ.n_vars, "n_public": circ.n_public, "nnz_A_plus_B": nnz, "style": style,
-            "vars_absent_from_A_B": absent, "key_bytes": key_bytes, "setup_s": round(time.perf_counter() - t0, 1)}
+            "vars_absent_from_A_B": absent, "key_bytes": key_bytes, "key_container": "sections" if (container == "sections" or (container == "auto" and logd >= 23)) else "proving_key.bin",
+            "setup_s": round(time.perf_counter() - t0, 1)}
     if keep_h:
         info["h_points"] = h_points
     return circ, S, key, wit, info
@@ -79,6 +80,8 @@ def main():
     ap.add_argument("--workload", choices=["prove", "msm"], default="prove")
     ap.add_argument("--prove-log-domain", type=int, default=20, help="20 = BASELINE config 4; 24 = config 5 (sections loader)")
     ap.add_argument("--circuit", choices=["columns", "rows"], default="columns")
+    ap.add_argument("--key-container", choices=["auto", "file", "sections"], default="auto",
+                    help="proving_key.bin (u32 offsets: up to 4 GiB) or the section container (wsnark_pkey_load_sections); auto = sections from 2^23")
     ap.add_argument("--log-n", type=int, default=20, help="--workload msm / extras: pairs per MSM")
     ap.add_argument("--extras", default="msm,ntt,cold,inflight,sparse", help="comma list (N=1 only): msm, ntt, cold, inflight, sparse")
     ap.add_argument("--no-extras", action="store_true")
@@ -184,7 +187,7 @@ def bench_prove(ctx):
     args, bn, rank, world, dev, torch = ctx["args"], ctx["bn"], ctx["rank"], ctx["world"], ctx["dev"], ctx["torch"]
     from wasmsnark_amd import dist as wdist, synth
     logd = args.prove_log_domain
-    circ, S, key, wit, info = build_prover(bn, logd, args.circuit, keep_h=(world > 1 and args.calc_h == "dist"))
+    circ, S, key, wit, info = build_prover(bn, logd, args.circuit, keep_h=(world > 1 and args.calc_h == "dist"), container=args.key_container)
     pkey_h_points = info.pop("h_points", None)
     d_w = torch.frombuffer(bytearray(wit), dtype=torch.uint8).to(dev)
     torch.cuda.synchronize()

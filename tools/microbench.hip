@@ -153,6 +153,30 @@ __global__ void k_r29(uint32_t* out, const uint32_t* in, int iters) {
     out[t] = r;
 }
 
+// One Fermat inversion per lane (x^(p-2): 253 squarings + the multiplications of the exponent's set bits), every lane
+// active: what a LANE-PARALLEL batch inversion costs per batch (the batch-affine accumulation analysis in DESIGN.md).
+__global__ void k_inv29(uint32_t* out, const uint32_t* in, int iters) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t e[4] = {0x3c208c16d87cfd45ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull};   // q - 2
+    uint32_t x[9], acc[9], base[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) x[j] = (in[t * 8 + (j & 7)] | 1) & M29;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int j = 0; j < 9; j++) { acc[j] = x[j]; base[j] = x[j]; }
+        for (int i = 1; i < 254; i++) {
+            mul_r29(base, base, base);
+            if ((e[i >> 6] >> (i & 63)) & 1) mul_r29(acc, base, acc);
+        }
+#pragma unroll
+        for (int j = 0; j < 9; j++) x[j] = acc[j] & M29;
+    }
+    uint32_t r = 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) r ^= x[j];
+    out[t] = r;
+}
+
 template <class F>
 static int run(const char* name, F launch, double ops_per_thread_iter, int iters, int threads_total) {
     hipEvent_t a, b;
@@ -197,5 +221,6 @@ int main() {
     run("mont_mul32 x1 chain, 2 blocks/CU", [&](int n) { hipLaunchKernelGGL(k_modmul<1>, dim3(prop.multiProcessorCount * 2), dim3(threads), 0, 0, (Fe*)buf, in, n); }, 1, im, prop.multiProcessorCount * 2 * threads);
     run("radix29 x1 chain, 2 blocks/CU", [&](int n) { hipLaunchKernelGGL((k_r29<0, 1>), dim3(prop.multiProcessorCount * 2), dim3(threads), 0, 0, (uint32_t*)buf, (const uint32_t*)in, n); }, 1, im, prop.multiProcessorCount * 2 * threads);
     run("radix29 x1 chain, 4 blocks/CU", [&](int n) { hipLaunchKernelGGL((k_r29<0, 1>), dim3(prop.multiProcessorCount * 4), dim3(threads), 0, 0, (uint32_t*)buf, (const uint32_t*)in, n); }, 1, im, prop.multiProcessorCount * 4 * threads);
+    run("Fermat inversion radix29, every lane active (inversions/s)", [&](int n) { hipLaunchKernelGGL(k_inv29, dim3(blocks), dim3(threads), 0, 0, (uint32_t*)buf, (const uint32_t*)in, n < 1 ? 1 : n); }, 1, 20, total);
     return 0;
 }
