@@ -168,7 +168,8 @@ def rooflines(kt, kernel, pairs_per_launch, windows_owned, bytes_per_pair, modmu
     avg_s = ms / cnt / 1e3
     alg = bytes_per_pair * pairs_per_launch
     achieved = alg / avg_s / 1e9
-    traffic, src = pmc_traffic(kernel)
+    # the committed PMC summary was taken at 2^20 pairs per launch with all 16 windows: only quoted for that shape
+    traffic, src = pmc_traffic(kernel) if (abs(pairs_per_launch - (1 << 20)) < 8 and windows_owned == 16) else (None, None)
     modmul = modmul_per_add * windows_owned * pairs_per_launch
     g = modmul / avg_s / 1e9
     hbm = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
