@@ -152,3 +152,31 @@ def test_calc_h_fused_passes_vs_oracle(bn, orc):
 
     A, B = pols(), pols()
     assert bn.calcH(sig, A, B, nS, dom) == orc.calc_h(sig, A, B, nS, dom)
+
+
+def test_new_entry_points_reject_bad_arguments(bn):
+    """Round-2 entry points return status codes, never crash: shard out of range, unknown partial flags, layouts that do not
+    match the transform size, short witnesses."""
+    import ctypes as C
+    c = bn.lib.c
+    buf = (C.c_uint8 * (64 * 32))()
+    out = (C.c_uint8 * 576)()
+    assert c.wsnark_g1_msm_windows(buf, buf, 4, 2, 2, out) == 4                 # rank >= world: WSNARK_ERR_ARG
+    assert c.wsnark_g1_msm_windows(buf, buf, 4, 0, 0, out) == 4
+    assert c.wsnark_fr_dist_scale_dev(buf, 4, 8, 0, 3, 6, 0, 0, None) == 0      # rows 4 of n1 = 8, cols n2 = 8: fine
+    assert c.wsnark_fr_dist_scale_dev(buf, 4, 4, 0, 3, 6, 0, 0, None) == 1      # cols != 2^(log_n - log_n1): WSNARK_ERR_SIZE
+    assert c.wsnark_fr_dist_scale_dev(buf, 4, 8, 6, 3, 6, 0, 0, None) == 1      # row0 + rows > n1
+    assert c.wsnark_fr_dist_scale_dev(buf, 4, 8, 0, 3, 6, 7, 0, None) == 1      # unknown mode
+    assert c.wsnark_fr_ntt_batch_dev(buf, 8, 0, 0, None) == 0                   # count 0: nothing to do
+    assert c.wsnark_fr_ntt_batch_dev(buf, 6, 2, 0, None) == 1                   # not a power of two
+    assert c.wsnark_fr_dist_combine_dev(buf, buf, buf, 4, 4, 0, 3, 6, None) == 1
+    from conftest import GOLDEN
+    import os
+    key = bn.load_key(open(os.path.join(GOLDEN, "keys", "t3.pkey.bin"), "rb").read())
+    wit = open(os.path.join(GOLDEN, "keys", "t3.witness.bin"), "rb").read()
+    assert c.wsnark_groth16_prove_partial(key._h, wit, len(wit), 0, 1, 2, out) == 4        # unknown flag bit
+    assert c.wsnark_groth16_prove_partial(key._h, wit, 32, 0, 1, 0, out) == 1              # witness too short
+    a = (C.c_uint8 * (key.domain * 32))()
+    assert c.wsnark_pkey_eval_ab_dev(key._h, wit, 32, a, a, None) == 1
+    r = (C.c_uint8 * 32)()
+    assert c.wsnark_groth16_verify(None, 0, None, 0, out, C.byref(C.c_int())) == 4

@@ -163,6 +163,7 @@ static hipEvent_t timer_event(std::vector<hipEvent_t>& pool) {
     return e;
 }
 static thread_local long t_rec = -1;      // this thread's open bracket (index into recs), -1 = none / filtered out
+static thread_local unsigned long t_gen = 0;   // ... valid only while recs has not been folded away by collect()
 void KernelTimer::begin(const char* name, hipStream_t s) {
     if (!enabled) return;
     t_rec = -1;
@@ -175,11 +176,12 @@ void KernelTimer::begin(const char* name, hipStream_t s) {
     (void)hipEventRecord(r.a, s);
     recs.push_back(r);
     t_rec = (long)recs.size() - 1;
+    t_gen = generation;
 }
 void KernelTimer::end(hipStream_t s) {
     if (!enabled || t_rec < 0) return;
     std::lock_guard<std::mutex> lk(mu);
-    if ((size_t)t_rec < recs.size()) (void)hipEventRecord(recs[(size_t)t_rec].b, s);
+    if (t_gen == generation && (size_t)t_rec < recs.size()) (void)hipEventRecord(recs[(size_t)t_rec].b, s);
     t_rec = -1;
 }
 void KernelTimer::collect() {
@@ -202,6 +204,7 @@ void KernelTimer::collect() {
         pool.push_back(r.b);
     }
     recs.clear();
+    generation++;
 }
 void KernelTimer::reset() {
     collect();

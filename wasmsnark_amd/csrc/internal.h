@@ -15,6 +15,7 @@ struct KernelTimer {
     bool enabled = false;
     bool dominant_only = false;   // mode 2: bracket only the kernel the roofline is quoted on (msm_accumulate_*)
     std::mutex mu;                // callers on several lanes bracket concurrently
+    unsigned long generation = 0; // bumped by collect(): a bracket opened before it must not touch the new record list
     struct Rec { const char* name; hipEvent_t a, b; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;   // events are recycled: creating them costs more than recording them
