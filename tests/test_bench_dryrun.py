@@ -1,0 +1,47 @@
+"""bench.py's control flow on CPU (tools/bench_dryrun.py: the thread-emulator build at toy sizes, gloo instead of nccl):
+the N = 1 line with every extra, and the N = 2 launch the driver uses for the scaling run -- window-sharded sums, the
+distributed CALC_H and the points-sharded H sum through DistProver, the max-over-ranks timing, one JSON line from rank 0
+with the contract's fields.  Not a measurement: a guard against Python-side mistakes in a path that only runs on GPUs."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+FIELDS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+          "dtype", "data", "config", "roofline", "roofline_int_alu")
+
+
+def _line(out):
+    rows = [l for l in out.stdout.splitlines() if l.startswith("{\"metric\"")]
+    assert out.returncode == 0 and len(rows) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    return json.loads(rows[0])
+
+
+def test_bench_single_gpu_line():
+    from emul_util import emul_bn128
+    emul_bn128()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_dryrun.py"), "--prove-log-domain", "6", "--log-n", "8",
+                          "--steps", "2", "--warmup", "1", "--extras", "msm,inflight"],
+                         capture_output=True, text=True, timeout=900)
+    d = _line(out)
+    assert all(k in d for k in FIELDS) and d["n_gpus"] == 1 and d["higher_is_better"] is False and d["unit"] == "ms"
+    assert d["proofs_match_toxic_waste_closed_form"] is True
+    assert d["config"]["workload"].startswith("BN128 full Groth16 prove") and "model" not in d["config"]
+    ex = d["extras"]
+    assert ex["two_proofs_in_flight"]["all_proofs_identical_to_closed_form"]
+    assert ex["g1_msm_2p8"]["two_in_flight"]["same_results"]
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["gpu_result_matches"] is True
+
+
+def test_bench_two_ranks_line():
+    from emul_util import emul_bn128
+    emul_bn128()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29657", os.path.join(ROOT, "tools", "bench_dryrun.py"), "--gpus", "2", "--prove-log-domain", "6",
+                          "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    d = _line(out)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["proofs_match_toxic_waste_closed_form"] is True
+    assert "distributed four-step NTT" in d["config"]["parallelism"] and "extras" not in d

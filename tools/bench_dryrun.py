@@ -13,6 +13,10 @@ torch.cuda.set_device = lambda *_: None
 torch.cuda.synchronize = lambda *_: None
 _real_device = torch.device
 torch.device = lambda *a, **k: _real_device("cpu")
+import torch.distributed as _dist
+
+_real_init = _dist.init_process_group
+_dist.init_process_group = lambda backend=None, **kw: _real_init("gloo")      # N > 1 dry run: gloo instead of nccl
 import __graft_entry__
 
 __graft_entry__.ensure_built = lambda: None

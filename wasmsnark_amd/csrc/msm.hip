@@ -45,9 +45,6 @@ namespace wsnark {
 #ifndef WS_G2_PREFETCH
 #define WS_G2_PREFETCH 0
 #endif
-#ifndef WS_G2_TOUCH
-#define WS_G2_TOUCH 0      // G2 accumulation: touch the next point's cache line one addition ahead (A/B: tools/build_variant.sh)
-#endif
 #ifndef WS_MADD_WIDE
 #define WS_MADD_WIDE 1     // accumulation loop keeps X wide between additions (curve.h: madd_wide); 0 = strict madd, for A/B builds
 #endif
@@ -362,28 +359,8 @@ __device__ __forceinline__ typename C::Pt accumulate_range(const typename C::Aff
     if (len == 0) return acc;
     if (sizeof(typename C::AffP) > 64 && !WS_G2_PREFETCH) {
         // G2: the accumulator alone is 72 VGPRs; holding a prefetched 128-byte point as well costs a
-        // wavefront of occupancy, so the gather is issued just before use
-#if WS_G2_TOUCH
-        // ... but its cache line can be pulled towards the CU one addition ahead for the price of ONE register: a 4-byte
-        // load of the next point, consumed (so that it is not optimised away) only after the current addition
-        uint32_t v = vals[s];
-        for (uint32_t k = 0; k < len; k++) {
-            const uint32_t vn = k + 1 < len ? vals[s + k + 1] : v;
-            const uint32_t touch = *reinterpret_cast<const volatile uint32_t*>(&points[vn & 0x7FFFFFFFu]);
-            const typename C::Aff cur = C::unpack_aff(points[v & 0x7FFFFFFFu]);
-#if WS_MADD_WIDE
-            C::madd_wide(acc, cur, (v >> 31) != 0);
-#else
-            C::madd(acc, cur, (v >> 31) != 0);
-#endif
-#ifndef WSNARK_EMUL
-            asm volatile("" ::"v"(touch));
-#else
-            (void)touch;
-#endif
-            v = vn;
-        }
-#else
+        // wavefront of occupancy, so the gather is issued just before use (touching only the next point's cache line one
+        // addition ahead was measured too: +4 %, profiles/r02_ab_g2_variants.txt -- the kernel is issue-bound, not latency-bound)
         for (uint32_t k = 0; k < len; k++) {
             const uint32_t v = vals[s + k];
             const typename C::Aff cur = C::unpack_aff(points[v & 0x7FFFFFFFu]);
@@ -393,7 +370,6 @@ __device__ __forceinline__ typename C::Pt accumulate_range(const typename C::Aff
             C::madd(acc, cur, (v >> 31) != 0);
 #endif
         }
-#endif
         C::narrow_x(acc);
         return acc;
     }
