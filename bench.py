@@ -76,7 +76,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=["prove", "msm"], default="prove")
     ap.add_argument("--prove-log-domain", type=int, default=20, help="20 = BASELINE config 4; 24 = config 5 (sections loader)")
     ap.add_argument("--circuit", choices=["columns", "rows"], default="columns")
@@ -359,7 +359,7 @@ def extra_msm(ctx, cold):
     bn, torch, args = ctx["bn"], ctx["torch"], ctx["args"]
     n, rng, sc, pts, d_s, d_p = msm_inputs(ctx, args.log_n, 1234)
     call = lambda: bn.g1_multiexp_dev(d_s.data_ptr(), d_p.data_ptr(), n)
-    for _ in range(3):
+    for _ in range(10):
         ref = call()
     bn.lib.c.wsnark_timing_reset(); bn.lib.c.wsnark_timing_enable(2)
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -431,10 +431,11 @@ def extra_ntt(ctx):
     x = torch.from_numpy(np.random.default_rng(7).integers(0, 256, size=(m, 32), dtype=np.uint8))
     x[:, 31] &= 0x1F
     dx = x.reshape(-1).to(dev)
-    for odd, inv in ((0, False), (1, False), (0, True)):
-        bn.fft_dev(dx.data_ptr(), m, odd, inverse=inv)
+    for _ in range(12):      # tables + clocks: the first ~40 transforms after an idle gap run 15-20 % slower (tools/ntt_probe.py)
+        for odd, inv in ((0, False), (1, False), (0, True)):
+            bn.fft_dev(dx.data_ptr(), m, odd, inverse=inv)
     bn.lib.c.wsnark_timing_report(None, 0)
-    res, reps = {}, 6
+    res, reps = {}, 20
     for name, odd, inv in (("fwd_odd0_ms", 0, False), ("fwd_odd1_ms", 1, False), ("inv_ms", 0, True)):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(reps):
