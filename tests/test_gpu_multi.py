@@ -1,5 +1,7 @@
-"""-m gpu tests that need MORE THAN ONE visible GPU; each skips itself otherwise (the build's gpurun boxes have one;
-the driver's 8-GPU node, when there is one, runs them).  One process per GPU, torch.distributed backend "nccl"
+"""-m gpu tests of the N > 1 code.  Two of them need MORE THAN ONE visible GPU and skip themselves otherwise (the build's gpurun
+boxes have one; the driver's 8-GPU node, when there is one, runs them).  The third runs everywhere: TWO ranks sharing ONE
+GPU over gloo (RCCL refuses two ranks on one device) -- the real kernels, real asynchronous streams and a real exchange
+between two processes, only the transport differs from the multi-GPU case.  One process per GPU, torch.distributed backend "nccl"
 (= RCCL over xGMI), the same code path bench.py --gpus N uses: window-sharded MSM and whole sharded proofs against
 the reference's golden proofs, and an entry point called from a thread other than the one that initialised a
 context on device 1."""
@@ -62,9 +64,7 @@ for bits in (10, 16, 20):
         ref = d.clone(); torch.cuda.synchronize()
         bn.fft_dev(ref.data_ptr(), n, odd, inverse=inverse); torch.cuda.synchronize()
         y = wd.dist_ntt(bn, wd.to_interleaved(d, l1, rank, world).clone(), bits, odd=odd, inverse=inverse)
-        parts = [torch.empty_like(y) for _ in range(world)]
-        dist.all_gather(parts, y)
-        assert torch.equal(wd.from_interleaved(torch.cat(parts), l2), ref), ("dist_ntt", bits, odd, inverse, rank)
+        assert torch.equal(wd.from_interleaved(wd.gather_all(y), l2), ref), ("dist_ntt", bits, odd, inverse, rank)
 # whole proofs with the distributed CALC_H (DistProver): 2^14 synthetic circuit against the toxic-waste closed form
 import struct
 from wasmsnark_amd import synth
@@ -133,3 +133,25 @@ def test_entry_points_from_another_thread_on_device_1(tmp_path):
     script.write_text(THREAD_WORKER)
     out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, WS_ROOT=ROOT), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+ONE_GPU_WORKER = WORKER.replace('dist.init_process_group("nccl", device_id=dev)', 'dist.init_process_group("gloo")') \
+    .replace('rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])',
+             'rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), 0')
+
+
+def test_two_ranks_sharing_one_gpu_over_gloo(tmp_path):
+    """The whole N > 1 surface with 2 processes on GPU 0: points split, window split, sharded_prove (host and device
+    witness, injected and rank-0-drawn blinding), dist_ntt up to 2^20 against the single-GPU transform, DistProver against
+    the closed form."""
+    if _gpus() < 1:
+        pytest.skip("needs a GPU")
+    assert 'init_process_group("gloo")' in ONE_GPU_WORKER and ", 0\n" in ONE_GPU_WORKER
+    script = tmp_path / "worker_one_gpu.py"
+    script.write_text(ONE_GPU_WORKER)
+    env = dict(os.environ, WS_ROOT=ROOT, WS_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29633", str(script)],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert all((tmp_path / ("rank%d.ok" % r)).exists() for r in range(2))

@@ -32,7 +32,7 @@ def allgather_partials(partial, device=None):
     bench adds to every MSM."""
     world = dist.get_world_size()
     t = torch.frombuffer(bytearray(partial), dtype=torch.uint8)
-    if device is not None:
+    if device is not None and dist.get_backend() != "gloo":      # (gloo moves host memory only)
         t = t.to(device)
     out = torch.empty(world * t.numel(), dtype=torch.uint8, device=t.device)
     try:
@@ -119,16 +119,42 @@ def from_interleaved(parts, log_m, elem=32):
     return parts.view(m, n // m, elem).permute(1, 0, 2).contiguous().view(-1)
 
 
+def gather_all(t, group=None):
+    """Concatenation (rank order) of every rank's tensor `t`, on t's device; staged through the host on gloo."""
+    world = dist.get_world_size(group)
+    src = t.cpu() if (t.is_cuda and dist.get_backend(group) == "gloo") else t
+    parts = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(parts, src.contiguous(), group=group)
+    return torch.cat(parts).to(t.device)
+
+
+_a2a_native = {}
+
+
 def _all_to_all(out, inp, group=None):
-    try:
-        dist.all_to_all_single(out, inp, group=group)
-    except (RuntimeError, NotImplementedError):      # backend without all-to-all (older gloo): emulate with all_gather
-        world, rank = dist.get_world_size(group), dist.get_rank(group)
-        parts = [torch.empty_like(inp) for _ in range(world)]
-        dist.all_gather(parts, inp, group=group)
-        chunk = inp.numel() // world
-        for q in range(world):
-            out[q * chunk:(q + 1) * chunk] = parts[q][rank * chunk:(rank + 1) * chunk]
+    """all_to_all_single where the backend has it (nccl = RCCL always; gloo in recent torch builds); otherwise -- decided ONCE
+    per backend, on the first call -- the same exchange through all_gather (CPU tests only)."""
+    backend = dist.get_backend(group)
+    if backend == "gloo" and inp.is_cuda:       # gloo moves host memory only: stage through the host (tests: two ranks on one GPU)
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        _all_to_all(h_out, inp.cpu(), group)
+        out.copy_(h_out)
+        return
+    if _a2a_native.get(backend, True):
+        try:
+            dist.all_to_all_single(out, inp, group=group)
+            _a2a_native[backend] = True
+            return
+        except (RuntimeError, NotImplementedError):
+            if backend == "nccl" or _a2a_native.get(backend):
+                raise                                   # a real failure, not a missing feature
+            _a2a_native[backend] = False
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    parts = [torch.empty_like(inp) for _ in range(world)]
+    dist.all_gather(parts, inp, group=group)
+    chunk = inp.numel() // world
+    for q in range(world):
+        out[q * chunk:(q + 1) * chunk] = parts[q][rank * chunk:(rank + 1) * chunk]
 
 
 _side_streams = {}
