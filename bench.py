@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shard", choices=["points", "windows"], default="points", help="--workload msm, N>1")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="N>1 transport: nccl (= RCCL over xGMI; one GPU per rank) or gloo with host staging -- the latter lets "
+                         "several ranks SHARE one GPU (functional check of the N>1 path on a one-GPU box; not a scaling measurement)")
     ap.add_argument("--calc-h", choices=["replicated", "dist"], default="dist",
                     help="N>1: 'dist' = CALC_H on the distributed four-step transform + points-sharded H sum (DistProver); "
                          "'replicated' = every rank repeats the whole CALC_H (round 1)")
@@ -98,13 +101,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    if args.backend == "gloo":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)      # ranks may share a GPU
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if local_rank == 0:
+    if rank == 0:
         import __graft_entry__
         __graft_entry__.ensure_built()      # in-tree hipcc build if the library is not there yet
     if world > 1:
@@ -142,7 +150,7 @@ def timed(ctx, step, steps, warmup):
     lib.c.wsnark_timing_enable(0)
     kt = lib.timing_report()
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=(dev if dist.get_backend() == "nccl" else "cpu"))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt, kt, res
@@ -219,7 +227,7 @@ def bench_prove(ctx):
             why = "" if ok_here else "proof != closed form"
         except Exception as ex:  # noqa: BLE001
             ok_here, why = 0, repr(ex)
-        flag = torch.tensor([ok_here], dtype=torch.int32, device=dev)
+        flag = torch.tensor([ok_here], dtype=torch.int32, device=(dev if ctx["dist"].get_backend() == "nccl" else "cpu"))
         ctx["dist"].all_reduce(flag, op=ctx["dist"].ReduceOp.MIN)
         if int(flag.item()) == 0:
             dprover = None
@@ -258,6 +266,7 @@ def bench_prove(ctx):
                                                        + ("CALC_H on the distributed four-step NTT (7 all-to-alls of %d B per rank), H sum points-sharded, "
                                                           % ((world - 1) * (circ.domain // world // world) * 32) if calc_h_mode == "dist" else "CALC_H %s, " % calc_h_mode)
                                                        + "1 all_gather of 576 B records per proof")
+                      + ("" if args.backend == "nccl" else " [transport gloo with host staging: ranks may share a GPU -- functional check, not a scaling figure]")
                       if world > 1 else "1 GPU, no collective", "lanes": int(os.environ.get("WSNARK_LANES", "2")), "device": bn.device_info},
            "proofs_match_toxic_waste_closed_form": ok,
            "proofs_per_s": round(1e3 / ms, 2),
