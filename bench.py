@@ -263,7 +263,7 @@ def bench_prove(ctx):
                                   if args.circuit == "columns" else
                                   "BN128 full Groth16 prove, synthetic 2^%d-constraint R1CS, round-1 sparse generator (1-2 terms per row)" % logd,
                       "circuit": info, "parallelism": (("MSM windows sharded w %% %d == rank, " % world)
-                                                       + ("CALC_H on the distributed four-step NTT (7 all-to-alls of %d B per rank), H sum points-sharded, "
+                                                       + ("CALC_H on the distributed four-step NTT (3 all-to-alls per proof: 3 + 2 + 1 vectors of %d B per rank each), H sum points-sharded, "
                                                           % ((world - 1) * (circ.domain // world // world) * 32) if calc_h_mode == "dist" else "CALC_H %s, " % calc_h_mode)
                                                        + "1 all_gather of 576 B records per proof")
                       + ("" if args.backend == "nccl" else " [transport gloo with host staging: ranks may share a GPU -- functional check, not a scaling figure]")

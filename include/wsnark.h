@@ -99,7 +99,8 @@ int wsnark_fr_ntt_dev(void* d_buf, uint64_t n, int odd, int inverse, void* strea
  * on one worker).  batch: `count` independent length-n transforms stored back to back (the column step and the row
  * step), same semantics per transform as wsnark_fr_ntt_dev with odd = 0.  dist_scale: element (r, c) of a rank's
  * rows x cols row-major block stands at global position t = (row0 + r) + 2^log_n1 * c of the length-2^log_n vector
- * (cols must be 2^(log_n - log_n1)) and is multiplied by
+ * (cols must be 2^(log_n - log_n1)); `stack` such blocks -- the slices of several vectors that go through the same
+ * transform together, one exchange for all of them -- lie one after the other; every element is multiplied by
  *   mode 0: w_n^((row0 + r) * c)  -- the twiddle between the two steps (inverse != 0: the inverse root)
  *   mode 1: w_2n^t                -- the coset pre-scale of odd = 1 (src/build_fft.js:159-187) */
 int wsnark_fr_ntt_batch_dev(void* d_buf, uint64_t n, uint64_t count, int inverse, void* stream);
@@ -113,8 +114,8 @@ int wsnark_pkey_eval_ab_dev(wsnark_pkey_t* handle, const void* d_witness, size_t
 int wsnark_fr_mul_dev(const void* d_a, const void* d_b, void* d_out, uint64_t n, void* stream);
 int wsnark_fr_dist_combine_dev(const void* d_e, const void* d_o, void* d_h_out, uint64_t rows, uint64_t cols, uint64_t row0,
                                uint32_t log_n1, uint32_t log_n, void* stream);
-int wsnark_fr_dist_scale_dev(void* d_buf, uint64_t rows, uint64_t cols, uint64_t row0, uint32_t log_n1, uint32_t log_n, int mode,
-                             int inverse, void* stream);
+int wsnark_fr_dist_scale_dev(void* d_buf, uint64_t stack, uint64_t rows, uint64_t cols, uint64_t row0, uint32_t log_n1, uint32_t log_n,
+                             int mode, int inverse, void* stream);
 /* fft_toMontgomeryN / fft_fromMontgomeryN (src/build_fft.js:418-458, 507-547) */
 int wsnark_fr_to_montgomery(const void* in, void* out, uint64_t n);
 int wsnark_fr_from_montgomery(const void* in, void* out, uint64_t n);

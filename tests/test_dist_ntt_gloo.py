@@ -35,6 +35,18 @@ for bits in (4, 5, 10, 11, 14):
             y = wd.dist_ntt(bn, loc, bits, odd=odd, inverse=inverse)
             got = wd.from_interleaved(gather(y), l2).numpy().tobytes()
             assert got == orc.fft(x, n, odd, inverse=inverse), (bits, odd, inverse, rank)
+# three vectors through ONE transform / one exchange (dist_ntt(stack=3)) == three separate transforms
+bits = 8
+n = 1 << bits
+l1, l2 = wd.ntt_layout_split(bits, world)
+vs = [orc.to_mont_n(b"".join(random.Random(70 + j).randrange(orc.R).to_bytes(32, "little") for _ in range(n))) for j in range(3)]
+stack = torch.cat([wd.to_interleaved(torch.frombuffer(bytearray(v), dtype=torch.uint8), l1, rank, world) for v in vs]).clone()
+for odd, inverse in ((1, False), (0, True)):
+    y = wd.dist_ntt(bn, stack.clone(), bits, odd=odd, inverse=inverse, stack=3)
+    per = y.numel() // 3
+    for j in range(3):
+        got = wd.from_interleaved(gather(y[j * per:(j + 1) * per].contiguous()), l2).numpy().tobytes()
+        assert got == orc.fft(vs[j], n, odd, inverse=inverse), ("stack", j, odd, inverse, rank)
 # a chain as in CALC_H (src/bn128.js:150-153): coefficients = ifft(x), then evaluations on the odd coset = fft(., odd=1);
 # with n1 == n2 the output layout of one transform is the input layout of the next
 bits = 10

@@ -163,10 +163,11 @@ def test_new_entry_points_reject_bad_arguments(bn):
     out = (C.c_uint8 * 576)()
     assert c.wsnark_g1_msm_windows(buf, buf, 4, 2, 2, out) == 4                 # rank >= world: WSNARK_ERR_ARG
     assert c.wsnark_g1_msm_windows(buf, buf, 4, 0, 0, out) == 4
-    assert c.wsnark_fr_dist_scale_dev(buf, 4, 8, 0, 3, 6, 0, 0, None) == 0      # rows 4 of n1 = 8, cols n2 = 8: fine
-    assert c.wsnark_fr_dist_scale_dev(buf, 4, 4, 0, 3, 6, 0, 0, None) == 1      # cols != 2^(log_n - log_n1): WSNARK_ERR_SIZE
-    assert c.wsnark_fr_dist_scale_dev(buf, 4, 8, 6, 3, 6, 0, 0, None) == 1      # row0 + rows > n1
-    assert c.wsnark_fr_dist_scale_dev(buf, 4, 8, 0, 3, 6, 7, 0, None) == 1      # unknown mode
+    assert c.wsnark_fr_dist_scale_dev(buf, 1, 4, 8, 0, 3, 6, 0, 0, None) == 0      # rows 4 of n1 = 8, cols n2 = 8: fine
+    assert c.wsnark_fr_dist_scale_dev(buf, 2, 4, 8, 0, 3, 6, 0, 0, None) == 0      # two stacked blocks (2 x 4 x 8 = 64 elements)
+    assert c.wsnark_fr_dist_scale_dev(buf, 1, 4, 4, 0, 3, 6, 0, 0, None) == 1      # cols != 2^(log_n - log_n1): WSNARK_ERR_SIZE
+    assert c.wsnark_fr_dist_scale_dev(buf, 1, 4, 8, 6, 3, 6, 0, 0, None) == 1      # row0 + rows > n1
+    assert c.wsnark_fr_dist_scale_dev(buf, 1, 4, 8, 0, 3, 6, 7, 0, None) == 1      # unknown mode
     assert c.wsnark_fr_ntt_batch_dev(buf, 8, 0, 0, None) == 0                   # count 0: nothing to do
     assert c.wsnark_fr_ntt_batch_dev(buf, 6, 2, 0, None) == 1                   # not a power of two
     assert c.wsnark_fr_dist_combine_dev(buf, buf, buf, 4, 4, 0, 3, 6, None) == 1

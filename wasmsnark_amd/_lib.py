@@ -65,7 +65,7 @@ class Lib:
         c.wsnark_fr_ntt.argtypes = [vp, u64, C.c_int, C.c_int]
         c.wsnark_fr_ntt_dev.argtypes = [vp, u64, C.c_int, C.c_int, vp]
         c.wsnark_fr_ntt_batch_dev.argtypes = [vp, u64, u64, C.c_int, vp]
-        c.wsnark_fr_dist_scale_dev.argtypes = [vp, u64, u64, u64, u32, u32, C.c_int, C.c_int, vp]
+        c.wsnark_fr_dist_scale_dev.argtypes = [vp, u64, u64, u64, u64, u32, u32, C.c_int, C.c_int, vp]
         c.wsnark_fr_to_montgomery.argtypes = [vp, vp, u64]
         c.wsnark_fr_from_montgomery.argtypes = [vp, vp, u64]
         c.wsnark_calc_h.argtypes = [vp, vp, sz, vp, sz, u32, u32, vp]

@@ -33,7 +33,7 @@ int groth16_prove_dev_witness(ProvingKey* K, const Fe* d_witness, size_t witness
                               const uint8_t* s32, uint8_t* out384, hipStream_t s);
 bool last_blinding(uint8_t* r32, uint8_t* s32);
 int groth16_verify(const uint8_t* vk, size_t vk_len, const uint8_t* inputs, uint64_t n_inputs, const uint8_t* proof384, int* valid);
-int dist_scale_dev(Fe* d_data, uint64_t rows, uint64_t cols, uint64_t row0, uint32_t log_n1, uint32_t log_n, int mode, int inverse, hipStream_t s);
+int dist_scale_dev(Fe* d_data, uint64_t stack, uint64_t rows, uint64_t cols, uint64_t row0, uint32_t log_n1, uint32_t log_n, int mode, int inverse, hipStream_t s);
 void g1_sum_host(const uint8_t* pts, uint64_t count, uint8_t* out96);
 void g2_sum_host(const uint8_t* pts, uint64_t count, uint8_t* out192);
 int g1_mul_base_batch(const void* base, const void* scalars, uint64_t n, void* out);
@@ -139,10 +139,10 @@ int wsnark_fr_ntt_batch_dev(void* d_buf, uint64_t n, uint64_t count, int inverse
     LaneLock L = acquire_lane(C);
     return ntt_dev(*L, (Fe*)d_buf, n, 0, inverse, (hipStream_t)stream, count);
 }
-int wsnark_fr_dist_scale_dev(void* d_buf, uint64_t rows, uint64_t cols, uint64_t row0, uint32_t log_n1, uint32_t log_n, int mode,
+int wsnark_fr_dist_scale_dev(void* d_buf, uint64_t stack, uint64_t rows, uint64_t cols, uint64_t row0, uint32_t log_n1, uint32_t log_n, int mode,
                              int inverse, void* stream) {
     REQUIRE_CTX();
-    return dist_scale_dev((Fe*)d_buf, rows, cols, row0, log_n1, log_n, mode, inverse, (hipStream_t)stream);
+    return dist_scale_dev((Fe*)d_buf, stack, rows, cols, row0, log_n1, log_n, mode, inverse, (hipStream_t)stream);
 }
 int wsnark_fr_ntt(void* buf, uint64_t n, int odd, int inverse) {
     REQUIRE_CTX();

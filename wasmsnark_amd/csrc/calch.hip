@@ -65,20 +65,21 @@ __global__ __launch_bounds__(256) void calch_combine_kernel(const Fe* __restrict
 // global position t = (row0 + r) + n1 * c of the length-n vector (wasmsnark_amd/dist.py: dist_ntt) ----
 //   mode 0: *= w_n^((row0 + r) * c)   the twiddle between the column step and the row step (inverse: w_n^-1)
 //   mode 1: *= w_2n^t                 the coset pre-scale of fft_fft's odd = 1 (src/build_fft.js:159-187)
-__global__ __launch_bounds__(256) void dist_scale_kernel(Fe* __restrict__ data, uint64_t rows, uint64_t cols, uint64_t row0,
+__global__ __launch_bounds__(256) void dist_scale_kernel(Fe* __restrict__ data, uint64_t stack, uint64_t rows, uint64_t cols, uint64_t row0,
                                                            uint32_t log_n1, int mode, const Fe* __restrict__ lo, const Fe* __restrict__ hi, uint32_t h) {
     const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rows * cols) return;
-    const uint64_t r = idx / cols, c = idx - r * cols;
+    if (idx >= stack * rows * cols) return;
+    const uint64_t rr = idx / cols, c = idx - rr * cols, r = rr % rows;      // `stack` blocks of the same layout, one after the other
     const uint64_t e = mode == 0 ? (row0 + r) * c : (row0 + r) + (c << log_n1);
     const Fe f = Fr::mul(hi[e >> h], lo[e & (((uint64_t)1 << h) - 1)]);
     data[idx] = Fr::mul(data[idx], f);
 }
-int dist_scale_dev(Fe* d_data, uint64_t rows, uint64_t cols, uint64_t row0, uint32_t log_n1, uint32_t log_n, int mode, int inverse, hipStream_t s) {
+int dist_scale_dev(Fe* d_data, uint64_t stack, uint64_t rows, uint64_t cols, uint64_t row0, uint32_t log_n1, uint32_t log_n, int mode, int inverse, hipStream_t s) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
     if (!s) s = C->stream;
-    if (rows == 0 || cols == 0) return WS_OK;
+    if (stack == 0 || rows == 0 || cols == 0) return WS_OK;
+    if (stack > 64) return WS_ERR_SIZE;
     if (!d_data) return WS_ERR_ARG;
     if (log_n < 1 || log_n > 27 || log_n1 > log_n || cols != ((uint64_t)1 << (log_n - log_n1)) || row0 + rows > ((uint64_t)1 << log_n1) ||
         (mode != 0 && mode != 1))
@@ -93,7 +94,7 @@ int dist_scale_dev(Fe* d_data, uint64_t rows, uint64_t cols, uint64_t row0, uint
         rc = ntt_coset_tables((int)log_n, &lo, &hi, &h, &n_inv, s);
     }
     if (rc) return rc;
-    hipLaunchKernelGGL(dist_scale_kernel, dim3(ceil_div_u64(rows * cols, 256)), dim3(256), 0, s, d_data, rows, cols, row0, log_n1, mode, lo, hi, (uint32_t)h);
+    hipLaunchKernelGGL(dist_scale_kernel, dim3(ceil_div_u64(stack * rows * cols, 256)), dim3(256), 0, s, d_data, stack, rows, cols, row0, log_n1, mode, lo, hi, (uint32_t)h);
     WS_HIP_CHECK(hipGetLastError());
     return WS_OK;
 }

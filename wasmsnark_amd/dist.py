@@ -86,8 +86,8 @@ def sharded_prove(bn, key, witness, r=None, s=None, device=None, d_witness=None)
 # turns the (n1/P) x n2 blocks into (n2/P) x n1 blocks, and the row step (length-n1 transforms over i1) is local
 # again.  The result is n2-interleaved (rank p holds the k2 in its range, all k1): with n1 == n2 that IS the input
 # layout of the next transform, so chains of transforms (CALC_H: iNTT -> coset NTT -> iNTT) need no re-layout.
-# Bytes exchanged per transform: every rank sends and receives (P-1)/P * (n/P) * 32 B  (2^24, P = 8: 56 MiB per rank,
-# 8 MiB per xGMI link; 2^20: 3.5 MiB per rank).  Backend: torch.distributed all_to_all_single ("nccl" = RCCL on the
+# Bytes exchanged per vector and transform: every rank sends and receives (P-1)/P * (n/P) * 32 B  (2^24, P = 8: 56 MiB per
+# rank, 8 MiB per xGMI link; 2^20: 3.5 MiB per rank); `stack` vectors share one exchange.  Backend: torch.distributed all_to_all_single ("nccl" = RCCL on the
 # GPUs; the CPU tests run the same code on gloo with the thread-emulator build, where all_to_all falls back to
 # all_gather when the backend lacks it).  All arithmetic is exact: results are bit-identical to wsnark_fr_ntt.
 # ---------------------------------------------------------------------------------------------------------------
@@ -194,20 +194,22 @@ class _on_side_stream:
         return False
 
 
-def dist_ntt(bn, x_local, log_n, odd=0, inverse=False, group=None, flip=False):
+def dist_ntt(bn, x_local, log_n, odd=0, inverse=False, group=None, flip=False, stack=1):
     with _on_side_stream(x_local) as ss:
-        y = _dist_ntt(bn, x_local, log_n, odd, inverse, group, flip, ss.handle)
+        y = _dist_ntt(bn, x_local, log_n, odd, inverse, group, flip, ss.handle, stack)
         if x_local.is_cuda:
             x_local.record_stream(torch.cuda.current_stream(x_local.device))
             y.record_stream(torch.cuda.current_stream(x_local.device))
     return y
 
 
-def _dist_ntt(bn, x_local, log_n, odd, inverse, group, flip, st):
+def _dist_ntt(bn, x_local, log_n, odd, inverse, group, flip, st, stack=1):
     """fft_fft / fft_ifft (src/build_fft.js:159-221) of a length-2^log_n vector of Montgomery Fr elements spread over the
     ranks.  x_local: this rank's uint8 tensor in the n1-interleaved layout (to_interleaved(x, log_n1, ...)) on the
     device the library runs on; it is overwritten.  Returns the rank's slice of the result in the n2-interleaved layout
-    (from_interleaved(all slices, log_n2) is the natural-order vector).  One all-to-all."""
+    (from_interleaved(all slices, log_n2) is the natural-order vector).  One all-to-all.
+    stack = k: x_local holds the slices of k vectors one after the other; they go through the same transform together --
+    one set of kernel launches and ONE exchange for all of them (the exchanges are latency-bound at these sizes)."""
     if dist.is_available() and dist.is_initialized():
         world, rank = dist.get_world_size(group), dist.get_rank(group)
     else:
@@ -215,34 +217,35 @@ def _dist_ntt(bn, x_local, log_n, odd, inverse, group, flip, st):
     log_n1, log_n2 = ntt_layout_split(log_n, world, flip)
     n1, n2 = 1 << log_n1, 1 << log_n2
     r1, r2 = n1 // world, n2 // world
-    if x_local.numel() != r1 * n2 * 32 or not x_local.is_contiguous():
-        raise ValueError("x_local must be the rank's contiguous (n1/P) x n2 block")
+    k = int(stack)
+    if k < 1 or x_local.numel() != k * r1 * n2 * 32 or not x_local.is_contiguous():
+        raise ValueError("x_local must be `stack` contiguous (n1/P) x n2 blocks")
     c = bn.lib.c
     inv = 1 if inverse else 0
     # everything is enqueued on ONE (non-default) torch stream: the library kernels (stream argument `st`), the layout
     # permutes and the collective are ordered by the stream itself -- no host synchronisation inside a transform
     ptr = x_local.data_ptr()
     if odd:      # x[t] *= w_2n^t (also for the inverse: the reference's rawfft scales before its index flip)
-        bn.lib.check(c.wsnark_fr_dist_scale_dev(ptr, r1, n2, rank * r1, log_n1, log_n, 1, 0, st))
+        bn.lib.check(c.wsnark_fr_dist_scale_dev(ptr, k, r1, n2, rank * r1, log_n1, log_n, 1, 0, st))
     if log_n2 >= 1:
-        bn.lib.check(c.wsnark_fr_ntt_batch_dev(ptr, n2, r1, inv, st))            # column step: r1 transforms over i2
-    bn.lib.check(c.wsnark_fr_dist_scale_dev(ptr, r1, n2, rank * r1, log_n1, log_n, 0, inv, st))
-    send = x_local.view(r1, world, r2, 32).permute(1, 0, 2, 3).contiguous().view(-1)   # block q = my rows x rank q's columns
+        bn.lib.check(c.wsnark_fr_ntt_batch_dev(ptr, n2, k * r1, inv, st))        # column step: r1 transforms over i2 per vector
+    bn.lib.check(c.wsnark_fr_dist_scale_dev(ptr, k, r1, n2, rank * r1, log_n1, log_n, 0, inv, st))
+    send = x_local.view(k, r1, world, r2, 32).permute(2, 0, 1, 3, 4).contiguous().view(-1)   # block q = (all vectors) my rows x rank q's columns
     if world == 1:
         recv = send
     else:
         recv = torch.empty_like(send)
         _all_to_all(recv, send, group)
-    # received block q = rank q's rows (its i1 range) x my columns  ->  (my k2) x (all i1)
-    y = recv.view(world, r1, r2, 32).permute(2, 0, 1, 3).contiguous().view(-1)
-    bn.lib.check(c.wsnark_fr_ntt_batch_dev(y.data_ptr(), n1, r2, inv, st))         # row step: r2 transforms over i1
+    # received block q = rank q's rows (its i1 range) x my columns  ->  per vector (my k2) x (all i1)
+    y = recv.view(world, k, r1, r2, 32).permute(1, 3, 0, 2, 4).contiguous().view(-1)
+    bn.lib.check(c.wsnark_fr_ntt_batch_dev(y.data_ptr(), n1, k * r2, inv, st))     # row step: r2 transforms over i1 per vector
     return y
 
 
 class DistProver:
     """Groth16 proving over the ranks of one node with NOTHING replicated but the cheap parts: the four sums over the
     witness are window-sharded (wsnark_groth16_prove_partial, WSNARK_PARTIAL_SKIP_H), CALC_H runs on the distributed
-    four-step transform (seven transforms, one all-to-all each), and every rank sums ITS slice of h against ITS slice of
+    four-step transform (six transforms in three batches: three all-to-alls per proof), and every rank sums ITS slice of h against ITS slice of
     the key's H points -- a points-sharded partial sum that goes into the H slot of the rank's 576-byte record.  One
     all_gather of the records and the host-side finish as in sharded_prove.  The two linear combinations a = A w, b = B w
     are still evaluated in full on every rank (0.3 ms at 2^20: one sparse product each), then sliced.
@@ -275,24 +278,28 @@ class DistProver:
         return h
 
     def _calc_h_on(self, d_witness, witness_len, st):
+        """CALC_H (src/bn128.js:139-164) on this rank's slices with THREE exchanges: the inverse transforms of A, B and
+        E = A.B travel together, then the coset transforms of A and B, then the inverse transform of O."""
         bn, c, dom = self.bn, self.bn.lib.c, self.key.domain
         dev = self.h_points.device
-        a = torch.empty(dom * 32, dtype=torch.uint8, device=dev)
-        b = torch.empty(dom * 32, dtype=torch.uint8, device=dev)
-        bn.lib.check(c.wsnark_pkey_eval_ab_dev(self.key._h, d_witness, witness_len, a.data_ptr(), b.data_ptr(), st))
-        a = to_interleaved(a, self.l1, self.rank, self.world)
-        b = to_interleaved(b, self.l1, self.rank, self.world)
-        n_loc = a.numel() // 32
-        e = torch.empty_like(a)
-        bn.lib.check(c.wsnark_fr_mul_dev(a.data_ptr(), b.data_ptr(), e.data_ptr(), n_loc, st))          # E = A.B on the domain
-        nt = lambda x, flip, **kw: _dist_ntt(bn, x, self.log_n, kw.get("odd", 0), kw.get("inverse", False), self.group, flip, st)
-        a, b = nt(a, False, inverse=True), nt(b, False, inverse=True)                                    # coefficients (l2-interleaved)
-        a, b = nt(a, True, odd=1), nt(b, True, odd=1)                                                    # odd-coset evaluations (l1)
-        o = torch.empty_like(a)
-        bn.lib.check(c.wsnark_fr_mul_dev(a.data_ptr(), b.data_ptr(), o.data_ptr(), n_loc, st))          # O = A.B on the coset
-        e, o = nt(e, False, inverse=True), nt(o, False, inverse=True)                                    # both l2-interleaved
+        ab = torch.empty(2 * dom * 32, dtype=torch.uint8, device=dev)
+        bn.lib.check(c.wsnark_pkey_eval_ab_dev(self.key._h, d_witness, witness_len, ab.data_ptr(), ab.data_ptr() + dom * 32, st))
+        n_loc = dom // self.world
+        abe = torch.empty(3 * n_loc * 32, dtype=torch.uint8, device=dev)          # slices of A, B, E one after the other
+        abe[:n_loc * 32] = to_interleaved(ab[:dom * 32], self.l1, self.rank, self.world)
+        abe[n_loc * 32:2 * n_loc * 32] = to_interleaved(ab[dom * 32:], self.l1, self.rank, self.world)
+        p = abe.data_ptr()
+        bn.lib.check(c.wsnark_fr_mul_dev(p, p + n_loc * 32, p + 2 * n_loc * 32, n_loc, st))            # E = A.B on the domain
+        abe = _dist_ntt(bn, abe, self.log_n, 0, True, self.group, False, st, 3)                          # coefficients of A, B; e (l2-interleaved)
+        e = abe[2 * n_loc * 32:]
+        ab2 = _dist_ntt(bn, abe[:2 * n_loc * 32].contiguous(), self.log_n, 1, False, self.group, True, st, 2)   # odd-coset evaluations (l1)
+        q = ab2.data_ptr()
+        o = torch.empty(n_loc * 32, dtype=torch.uint8, device=dev)
+        bn.lib.check(c.wsnark_fr_mul_dev(q, q + n_loc * 32, o.data_ptr(), n_loc, st))                   # O = A.B on the coset
+        o = _dist_ntt(bn, o, self.log_n, 0, True, self.group, False, st, 1)                              # l2-interleaved, like e
         rows = (1 << self.l2) // self.world
-        h = torch.empty_like(e)
+        h = torch.empty(n_loc * 32, dtype=torch.uint8, device=dev)
+        e = e.contiguous()
         bn.lib.check(c.wsnark_fr_dist_combine_dev(e.data_ptr(), o.data_ptr(), h.data_ptr(), rows, 1 << (self.log_n - self.l2),
                                                   self.rank * rows, self.l2, self.log_n, st))
         return h
