@@ -28,6 +28,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 
 #include "internal.h"
 #ifndef WSNARK_EMUL
@@ -807,7 +808,10 @@ static int msm_finish_t(MsmPending& P, typename H::Pt* out_host) {
     const MsmPlanInfo& I = P.info;
     if (I.n == 0) { *out_host = H::infinity(); P.active = false; return WS_OK; }
     struct Done { MsmPending& p; ~Done() { p.active = false; } } done{P};   // the slot is free again whatever happens
+    static const bool trace = [] { const char* e = getenv("WSNARK_TRACE"); return e && atoi(e) == 1; }();
+    const auto t_wait = std::chrono::steady_clock::now();
     WS_HIP_CHECK(hipEventSynchronize(P.ev));
+    const auto t_tail = std::chrono::steady_clock::now();
     const HPt* sums = reinterpret_cast<const HPt*>(P.h_sums);
     // 8. host tail: result = sum_w 2^(c w) [ A_w + m * sum_q 2^q U_{w,q} ].  ONE Horner chain over the bit
     // positions of the whole scalar (MSB first): U_{w,q} sits at bit c*w + log2(m) + q, A_w at bit c*w, and
@@ -828,6 +832,10 @@ static int msm_finish_t(MsmPending& P, typename H::Pt* out_host) {
         }
     }
     *out_host = acc;
+    if (trace)
+        fprintf(stderr, "[wsnark trace]   msm finish (%s): waited %.3f ms for the GPU, host Horner %.3f ms\n", sizeof(HPt) > 128 ? "G2" : "G1",
+                std::chrono::duration<double, std::milli>(t_tail - t_wait).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_tail).count());
     return WS_OK;
 }
 
