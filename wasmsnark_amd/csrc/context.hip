@@ -44,11 +44,12 @@ int context_init(int device) {
         int nl = e ? atoi(e) : 2;
         C->n_lanes = nl < 1 ? 1 : nl > kMaxLanes ? kMaxLanes : nl;
     }
-    // every lane's second queue gets the device's highest priority (WSNARK_S2_PRIO=0 turns that off): its work is
-    // released at chosen points of the first queue's schedule and should then be dispatched ahead of what is still queued
+    // WSNARK_S2_PRIO=1 gives every lane's second queue the device's highest priority (round 1's default).  Since the prover
+    // finishes whichever sum is ready first, plain queues released at once are the best schedule on dense and sparse
+    // keys alike (profiles/r02_sweep_prove_overlap.txt: 11.26 ms against 11.30-11.68 ms for the other three combinations)
     const char* pe = getenv("WSNARK_S2_PRIO");
     int lo = 0, hi = 0;
-    const bool prio = !(pe && atoi(pe) == 0) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo;
+    const bool prio = (pe && atoi(pe) == 1) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo;
     for (int i = 0; i < C->n_lanes; i++) {
         Lane& L = C->lanes[i];
         L.id = i;

@@ -208,11 +208,10 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
     Trace tr;
     const uint32_t nv = K->n_vars, dom = K->domain;
     int rc;
-    // default: with plan variants (sparse keys) the second queue is the longer one and starts at once (2); with every pair in
-    // every sum the first queue is, and CALC_H waits for the first batched tail (1): 2^20 dense 11.83 / 12.03 / 12.08 ms
-    // against 11.96 / 12.43 / 12.37 ms on three boxes (profiles/r02_sweep_prove_overlap.txt)
-    static const int overlap_env = [] { const char* e = getenv("WSNARK_PROVE_OVERLAP"); return e ? atoi(e) : -1; }();
-    const int overlap = overlap_env >= 0 ? overlap_env : ((K->sparseA || K->sparseB) ? 2 : 1);
+    // WSNARK_PROVE_OVERLAP: 0 = one queue; 1 = the second queue (CALC_H, H) is released when the first batched tail starts;
+    // 2 (default) = released at once.  Round-2 sweep on the dense 2^20 key, after the finish-order fix below:
+    // 2: 11.26 ms, 1: 11.34 ms (plain queues); with a high-priority second queue 2: 11.6 ms, 1: 11.3 ms.
+    static const int overlap = [] { const char* e = getenv("WSNARK_PROVE_OVERLAP"); return e ? atoi(e) : 2; }();
     hipStream_t s2 = overlap ? L.stream2 : s;
     // launch slots: A, B1, C, B2, H.  On an error path the launches of THIS proof are forgotten (other lanes' are not touched)
     int slots[5] = {-1, -1, -1, -1, -1};
