@@ -195,12 +195,11 @@ struct MsmSums {
 // this rank's partial sums.
 //
 // Two in-order queues.  Stream s: the witness plan (+ its variants), A, B1, C (one batched tail), B2.  The lane's
-// second queue (highest priority): CALC_H, the H plan and the H sum.  The reduction tails are chains of ~30 dependent
+// second queue: CALC_H, the H plan and the H sum.  The reduction tails are chains of ~30 dependent
 // point additions on a few hundred wavefronts; the other queue's full-width kernels take the SIMDs they leave idle.
-// Measured on MI355X, prove 2^20: one queue (WSNARK_PROVE_OVERLAP=0) 14.5 ms -> two queues 13.2 ms (session 16);
-// with the sums on plan variants the second queue is the longer one and is released at once (=2, default:
-// 10.3 ms) rather than when the first tail starts (=1: 10.5 ms).  Stricter gating does not help: a tail that
-// shares its SIMDs with a full-width kernel just runs 2-3x slower (profiles/r01_sweep_prove_overlap.txt).
+// Measured on MI355X, prove 2^20: round 1 one queue (WSNARK_PROVE_OVERLAP=0) 14.5 ms -> two queues 13.2 ms; round 2 (dense
+// key) one queue 12.8 ms -> two queues 11.2 ms, see the sweep notes at `overlap` below.  A tail that shares its SIMDs
+// with a full-width kernel runs 2-3x slower (the kernel timeline of one proof: profiles/r02_session25_prove_timeline.txt).
 // The host finishes each sum while the GPU works on the next ones; `after_ab1` (optional) runs on the host as soon
 // as A and B1 are known.
 static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard sh, MsmSums* out, hipStream_t s,
