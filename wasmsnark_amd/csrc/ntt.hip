@@ -34,6 +34,7 @@ struct PassArgs {
     uint32_t is_last, log_S0, log_L0;         // last pass: stride and size of digit 0
     uint32_t np, kdig[4];
     const Fe* tw_small; uint32_t log_lmax;    // w_Lmax^j, j < Lmax/2 (direction-specific)
+    const struct TwLimbs* tw_small29;         // the same table as nine 29-bit limbs per entry (radix-2^29 path: no unpacking per butterfly)
     const Fe* tw_lo; const Fe* tw_hi; uint32_t h;   // two-level w_N^e = tw_hi[e>>h] * tw_lo[e & mask]
     uint32_t apply_twiddle;
     const Fe* cs_lo; const Fe* cs_hi; uint32_t hc; uint32_t prescale;   // coset factors w_2N^i
@@ -85,6 +86,19 @@ template <class P> struct CombineEpilogue<Field29<P>> {
             x = F::add(e, F::mul(f, v));
         }
         return F::pack(F::canonical(F::mul(x, F::unpack(A.comb_c))));
+    }
+};
+
+// A small-twiddle entry of the radix-2^29 path: the nine limbs as they are used, 48-byte stride (three 16-byte loads)
+struct alignas(16) TwLimbs { uint32_t v[12]; };
+template <class F> struct SmallTw;
+template <class P> struct SmallTw<Field<P>> {
+    __device__ static __forceinline__ Fe get(const PassArgs& A, uint32_t i) { return A.tw_small[i]; }
+};
+template <class P> struct SmallTw<Field29<P>> {
+    __device__ static __forceinline__ F29 get(const PassArgs& A, uint32_t i) {
+        const TwLimbs t = A.tw_small29[i];
+        return F29{{t.v[0], t.v[1], t.v[2], t.v[3], t.v[4], t.v[5], t.v[6], t.v[7], t.v[8]}};
     }
 };
 
@@ -189,12 +203,12 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
             const uint32_t i0 = (j0 << log_T) + t;
             El x0 = tile.get(i0), x1 = tile.get(i0 + q), x2 = tile.get(i0 + 2 * q), x3 = tile.get(i0 + 3 * q);
             // stage hs: (j0, j0+h) with w_{2h}^{jl}, (j0+h/2, j0+3h/2) with w_{2h}^{jl+h/2}
-            El s0 = F::add(x0, x2), d0 = F::mul(F::sub_weak(x0, x2), F::unpack(A.tw_small[jl << sh_hi]));
-            El s1 = F::add(x1, x3), d1 = F::mul(F::sub_weak(x1, x3), F::unpack(A.tw_small[(jl + (1u << (hs - 1))) << sh_hi]));
+            El s0 = F::add(x0, x2), d0 = F::mul(F::sub_weak(x0, x2), SmallTw<F>::get(A, jl << sh_hi));
+            El s1 = F::add(x1, x3), d1 = F::mul(F::sub_weak(x1, x3), SmallTw<F>::get(A, (jl + (1u << (hs - 1))) << sh_hi));
             // stage hs-1: (j0, j0+h/2) and (j0+h, j0+3h/2), both with w_{h}^{jl}
             El y0 = F::add(s0, s1), y2 = F::add(d0, d1), y1, y3;
             if (hs > 1) {
-                const El w = F::unpack(A.tw_small[jl << (sh_hi + 1)]);
+                const El w = SmallTw<F>::get(A, jl << (sh_hi + 1));
                 y1 = F::mul(F::sub_weak(s0, s1), w);
                 y3 = F::mul(F::sub_weak(d0, d1), w);
             } else {
@@ -296,6 +310,7 @@ struct NttPlan {
     int h = 0, hc = 0;
     bool field29 = false;                     // table format: internal domain of Field29 (entries x 2^5)
     DevBuf tw_small[2], tw_lo[2], tw_hi[2];   // [0] forward root, [1] inverse root
+    DevBuf tw_small29[2];                     // tw_small as limbs (TwLimbs), radix-2^29 path
     DevBuf cs_lo, cs_hi;                      // coset w_{2n}^i (forward root), format of the NTT kernel
     DevBuf cs_lo_ref, cs_hi_ref;              // the same in the reference Montgomery form (calch.hip)
     DevBuf tw_lo_ref[2], tw_hi_ref[2];        // w_n^e two-level in the reference form (dist_scale: four-step inter-digit twiddle)
@@ -347,6 +362,16 @@ static int build_plan(int bits, NttPlan& P, hipStream_t s) {
         powers(wl, (size_t)1 << (LOG_LMAX - 1), tmp);
         if (f29) scale32(tmp);
         int rc = upload(P.tw_small[dir], tmp, s); if (rc) return rc;
+        if (f29) {
+            std::vector<TwLimbs> limbs(tmp.size());
+            for (size_t i = 0; i < tmp.size(); i++) {
+                const F29 u = Fr29::unpack(tmp[i]);
+                for (int k = 0; k < 12; k++) limbs[i].v[k] = k < 9 ? u.v[k] : 0;
+            }
+            WS_HIP_CHECK(P.tw_small29[dir].alloc(limbs.size() * sizeof(TwLimbs)));
+            WS_HIP_CHECK(hipMemcpyAsync(P.tw_small29[dir].p, limbs.data(), limbs.size() * sizeof(TwLimbs), hipMemcpyHostToDevice, s));
+            WS_HIP_CHECK(hipStreamSynchronize(s));
+        }
         powers(wn, (size_t)1 << P.h, tmp);
         rc = upload(P.tw_lo_ref[dir], tmp, s); if (rc) return rc;
         if (f29) scale32(tmp);
@@ -471,6 +496,7 @@ int ntt_run(Lane& L, const Fe* d_src, const Fe* d_in2, Fe* d_data, const Fe* com
         A.np = P->np;
         for (int d = 0; d < 4; d++) A.kdig[d] = P->k[d];
         A.tw_small = P->tw_small[dir].as<Fe>(); A.log_lmax = LOG_LMAX;
+        A.tw_small29 = P->tw_small29[dir].as<TwLimbs>();
         A.tw_lo = P->tw_lo[dir].as<Fe>(); A.tw_hi = P->tw_hi[dir].as<Fe>(); A.h = P->h;
         A.apply_twiddle = last ? 0 : 1;
         A.cs_lo = P->cs_lo.as<Fe>(); A.cs_hi = P->cs_hi.as<Fe>(); A.hc = P->hc;
