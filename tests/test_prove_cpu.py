@@ -75,6 +75,31 @@ def test_emulated_prove_sparse_b_plan(monkeypatch, name):
         assert bn.groth16GenProof(wit, key, r=bytes.fromhex(c["r"]), s=bytes.fromhex(c["s"])) == c["proof"]
 
 
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("mode", ["plain", "pieces", "pieces-sparse", "wide", "round1-order"])
+def test_emulated_prove_key_table_modes(monkeypatch, name, mode):
+    """Resident keys are fixed-base window tables by default (row w = 2^(c w) * section; one bucket set per sum).
+    `plain` switches them off (the per-window path the MSM entry points use); `pieces` forces a table whose bucket set
+    is cut into several tail pieces (the sum_v v T_v term of the host tail), also together with the masked plan
+    variants; `wide` a window wider than the pair count suggests.  Same proofs, bit for bit."""
+    if mode == "plain":
+        monkeypatch.setenv("WSNARK_KEY_TABLE", "0")
+    elif mode.startswith("pieces"):
+        monkeypatch.setenv("WSNARK_TABLE_C", "9")
+        monkeypatch.setenv("WSNARK_TAIL_BITS", "6")
+        if mode.endswith("sparse"):
+            monkeypatch.setenv("WSNARK_PROVE_SPARSE", "2")
+    elif mode == "wide":
+        monkeypatch.setenv("WSNARK_TABLE_C", "13")
+    else:
+        monkeypatch.setenv("WSNARK_PROVE_ORDER", "0")     # A, B1, C, B2 on the first queue (default: B2, A, B1, C)
+    bn = emul_bn128()
+    pkey, wit, _ = _key(name)
+    key = bn.load_key(pkey)
+    for c in load_golden("proofs.json")[name]:
+        assert bn.groth16GenProof(wit, key, r=bytes.fromhex(c["r"]), s=bytes.fromhex(c["s"])) == c["proof"]
+
+
 def test_emulated_mul_base_matches_oracle(orc):
     bn = emul_bn128()
     sc = b"".join(v.to_bytes(32, "little") for v in (0, 1, 2, 12345, orc.R - 1, orc.R, (1 << 256) - 1))

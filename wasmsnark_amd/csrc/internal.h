@@ -137,7 +137,11 @@ int msm_g1_host(Lane& L, const void* h_scalars, const void* h_points, uint64_t n
 int msm_g2_host(Lane& L, const void* h_scalars, const void* h_points, uint64_t n, WindowShard sh, Jac<Fq2>* out_host);
 // two-phase form: one digit/sort/task plan per scalar vector, then any number of point sets of the
 // same length against it (the prover's A, B1, B2 and C sums all use the witness as scalars).
-int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipStream_t s);
+// table_c != 0: plan for fixed-base window tables of that window width (msm_build_table; the launches then take the table)
+int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipStream_t s, uint32_t table_c = 0);
+uint32_t msm_table_rows(uint32_t table_c);
+uint32_t msm_table_window(uint64_t n);
+int msm_build_table(int which, void* d_table, uint64_t n, uint32_t table_c, hipStream_t s);   // rows 1.. from row 0 (reference format)
 // mask[i] = 0 where the point is infinity (x == 0, reference format) in every given set; *skipped_host = how many
 int msm_points_mask(const Affine<Fq>* d_g1, const Affine<Fq2>* d_g2, uint64_t n, uint8_t* d_mask, uint32_t* skipped_host, hipStream_t s);
 // asynchronous form: launch enqueues the kernels and the copy of the window sums, finish waits

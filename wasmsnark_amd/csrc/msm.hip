@@ -130,7 +130,11 @@ struct PresortArgs {
     uint32_t tile;                     // scalars per workgroup
     uint32_t idx_bits;                 // packed 4-byte entries: idx | neg << idx_bits | lo << (idx_bits+1)
     const uint8_t* mask;               // optional: pairs with mask[i] == 0 are left out (their point is infinity)
+    uint32_t flat;                     // fixed-base table plans: ONE bucket set, bin = (d-1) >> lo_bits, entries index the table (window * n + i)
 };
+__device__ __forceinline__ uint32_t presort_bin(const PresortArgs& A, uint32_t k, uint32_t d) {
+    return (A.flat ? 0u : k * A.HB) + ((d - 1) >> A.lo_bits);
+}
 
 // 8-byte entry = (low bucket bits << 32) | (index | sign << 31); 4-byte entries when bits(n)+1+lo_bits <= 32
 template <class E> struct PresortEntry;
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(1024) void presort_count(PresortArgs A, uint32_t* _
     for (uint32_t i = base + threadIdx.x; i < base + A.tile && i < A.n; i += blockDim.x) {
         if (A.mask && !A.mask[i]) continue;
         for_each_digit(A.scalars[i], A.c, A.Wall, A.w_off, A.w_stride, [&](uint32_t k, uint32_t d, uint32_t) {
-            atomicAdd(&cnt[k * A.HB + ((d - 1) >> A.lo_bits)], 1u);
+            atomicAdd(&cnt[presort_bin(A, k, d)], 1u);
         });
     }
     __syncthreads();
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(1024) void presort_scatter(PresortArgs A, uint32_t*
     for (uint32_t i = base + threadIdx.x; i < base + A.tile && i < A.n; i += blockDim.x) {
         if (A.mask && !A.mask[i]) continue;
         for_each_digit(A.scalars[i], A.c, A.Wall, A.w_off, A.w_stride, [&](uint32_t k, uint32_t d, uint32_t) {
-            atomicAdd(&cnt[k * A.HB + ((d - 1) >> A.lo_bits)], 1u);
+            atomicAdd(&cnt[presort_bin(A, k, d)], 1u);
         });
     }
     __syncthreads();
@@ -215,9 +219,10 @@ __global__ __launch_bounds__(1024) void presort_scatter(PresortArgs A, uint32_t*
     for (uint32_t i = base + threadIdx.x; i < base + A.tile && i < A.n; i += blockDim.x) {
         if (A.mask && !A.mask[i]) continue;
         for_each_digit(A.scalars[i], A.c, A.Wall, A.w_off, A.w_stride, [&](uint32_t k, uint32_t d, uint32_t neg) {
-            const uint32_t b = k * A.HB + ((d - 1) >> A.lo_bits);
+            const uint32_t b = presort_bin(A, k, d);
             const uint32_t r = atomicAdd(&cnt[b], 1u);
-            entries[gbase[b] + r] = PresortEntry<E>::make(i, neg, (d - 1) & lo_mask, A.idx_bits);
+            const uint32_t idx = A.flat ? (A.w_off + k * A.w_stride) * A.n + i : i;
+            entries[gbase[b] + r] = PresortEntry<E>::make(idx, neg, (d - 1) & lo_mask, A.idx_bits);
         });
     }
 }
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(1024) void presort_bins(const E* __restrict__ entri
                                                        uint32_t lo_bits, uint32_t idx_bits, uint32_t* __restrict__ vals_out,
                                                        uint32_t* __restrict__ bstart, uint32_t* __restrict__ bend,
                                                        uint32_t lmax, uint32_t* __restrict__ hist,
-                                                       const uint8_t* __restrict__ mask) {
+                                                       const uint8_t* __restrict__ mask, uint32_t mask_mod) {
     __shared__ uint32_t sub[1u << PRESORT_MAX_LO];
     __shared__ uint32_t off[1u << PRESORT_MAX_LO];
     __shared__ uint32_t part[1024];
@@ -283,7 +288,10 @@ __global__ __launch_bounds__(1024) void presort_bins(const E* __restrict__ entri
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) {
             bool active = i + u * blockDim.x < e;
-            if (mask && active) active = mask[PresortEntry<E>::val(v[u], idx_bits) & 0x7FFFFFFFu] != 0;   // plan variant: pair left out
+            if (mask && active) {                                                                           // plan variant: pair left out
+                const uint32_t idx = PresortEntry<E>::val(v[u], idx_bits) & 0x7FFFFFFFu;
+                active = mask[mask_mod ? idx % mask_mod : idx] != 0;                                        // (table plans: idx = window * n + i)
+            }
             (void)wave_rank_add(sub, PresortEntry<E>::lo(v[u], idx_bits), active);
         }
     }
@@ -329,7 +337,10 @@ __global__ __launch_bounds__(1024) void presort_bins(const E* __restrict__ entri
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) {
             bool active = i + u * blockDim.x < e;
-            if (mask && active) active = mask[PresortEntry<E>::val(v[u], idx_bits) & 0x7FFFFFFFu] != 0;
+            if (mask && active) {
+                const uint32_t idx = PresortEntry<E>::val(v[u], idx_bits) & 0x7FFFFFFFu;
+                active = mask[mask_mod ? idx % mask_mod : idx] != 0;
+            }
             const uint32_t lo = PresortEntry<E>::lo(v[u], idx_bits);
             const uint32_t r = wave_rank_add(sub, lo, active);
             if (active) vals_out[off[lo] + r] = PresortEntry<E>::val(v[u], idx_bits);
@@ -655,7 +666,7 @@ __global__ __launch_bounds__(256) void msm_chunks(TailSets<C> ts, uint32_t nchun
 
 // ---------------------------------------------------------------------------
 // 7. masked tree sums per window: blockIdx.y = window, blockIdx.x = q
-//    q < logJ : U_q = sum_{j : bit q of j set} S_j ;  q == logJ : sum_j A_j
+//    q < logJ : U_q = sum_{j : bit q of j set} S_j ;  q == logJ : sum_j A_j ;  q == logJ + 1 (table plans) : sum_j S_j
 // ---------------------------------------------------------------------------
 template <class C>
 __global__ __launch_bounds__(sizeof(typename C::PtP) > 128 ? 256 : 512) void msm_tree(TailSets<C> ts, uint32_t J,
@@ -668,7 +679,7 @@ __global__ __launch_bounds__(sizeof(typename C::PtP) > 128 ? 256 : 512) void msm
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     const typename C::PtP* src = (q == logJ ? chunkA : chunkS) + (uint64_t)w * J;
     typename C::Pt acc = C::infinity();
-    if (q == logJ) {
+    if (q >= logJ) {
         for (uint32_t j = tid; j < J; j += nthr) acc = C::add(acc, C::unpack_pt(src[j]));
     } else {
         // enumerate only the J/2 indices whose bit q is set (insert a 1 at bit q): every lane stays busy
@@ -685,7 +696,7 @@ __global__ __launch_bounds__(sizeof(typename C::PtP) > 128 ? 256 : 512) void msm
         __syncthreads();
     }
     // results leave the device in the reference format (canonical, Montgomery R = 2^256)
-    if (tid == 0) sums[(uint64_t)w * (logJ + 1) + q] = C::pt_from_internal(C::unpack_pt(sh[0]));
+    if (tid == 0) sums[(uint64_t)w * gridDim.x + q] = C::pt_from_internal(C::unpack_pt(sh[0]));
 }
 
 
@@ -740,6 +751,11 @@ struct MsmPlanInfo {
     uint32_t ps_lo_bits = 0, ps_idx_bits = 0, ps_nbins = 0, ps_bthr = 0;   // grouping pass geometry (presort plans)
     bool ps_valid = false, ps_e32 = false;
     uint32_t Wall = 0, w_off = 0, w_stride = 1;   // W = owned windows; Wall = windows of the whole scalar
+    // fixed-base table plans (flat): the points array holds Wall rows of n points, row w = 2^(c w) * row 0, so every window's
+    // digits go into ONE set of NB buckets and no doubling is left for the tail.  For the reduction tail the bucket set is
+    // cut into tW pieces of tNB buckets ("windows" of the chunk/tree kernels; classic plans: tW = W, tNB = NB).
+    bool flat = false;
+    uint32_t tW = 0, tNB = 0;
     uint32_t ntasks = 0, nmulti = 0;
     bool valid = false;
 };
@@ -813,6 +829,36 @@ static int msm_finish_t(MsmPending& P, typename H::Pt* out_host) {
     WS_HIP_CHECK(hipEventSynchronize(P.ev));
     const auto t_tail = std::chrono::steady_clock::now();
     const HPt* sums = reinterpret_cast<const HPt*>(P.h_sums);
+    if (I.flat) {
+        // table plans: sum_b (b+1) B_b over ONE bucket set, b = v*tNB + u:  sum_v [ A_v + m sum_q 2^q U_{v,q} ] + tNB sum_v v T_v
+        // (rows per piece v: U_{v,0..logJ-1}, A_v, T_v = sum of the piece's buckets).  The pieces are summed row-wise first,
+        // so the doubling chain is c - 1 long whatever the number of pieces.
+        uint32_t logm = 0, logt = 0;
+        while ((1u << logm) < I.m) logm++;
+        while ((1u << logt) < I.tNB) logt++;
+        HPt acc = H::infinity();
+        for (int q = (int)I.logJ - 1; q >= 0; q--) {
+            acc = H::dbl(acc);
+            for (uint32_t v = 0; v < I.tW; v++) acc = H::add(acc, sums[(size_t)v * I.nsum + q]);
+        }
+        for (uint32_t k = 0; k < logm; k++) acc = H::dbl(acc);
+        for (uint32_t v = 0; v < I.tW; v++) acc = H::add(acc, sums[(size_t)v * I.nsum + I.logJ]);
+        if (I.tW > 1) {
+            HPt run = H::infinity(), tot = H::infinity();
+            for (uint32_t v = I.tW - 1; v >= 1; v--) {
+                run = H::add(run, sums[(size_t)v * I.nsum + I.logJ + 1]);
+                tot = H::add(tot, run);
+            }
+            for (uint32_t k = 0; k < logt; k++) tot = H::dbl(tot);
+            acc = H::add(acc, tot);
+        }
+        *out_host = acc;
+        if (trace)
+            fprintf(stderr, "[wsnark trace]   msm finish (%s, table): waited %.3f ms for the GPU, host tail %.3f ms\n", sizeof(HPt) > 128 ? "G2" : "G1",
+                    std::chrono::duration<double, std::milli>(t_tail - t_wait).count(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_tail).count());
+        return WS_OK;
+    }
     // 8. host tail: result = sum_w 2^(c w) [ A_w + m * sum_q 2^q U_{w,q} ].  ONE Horner chain over the bit
     // positions of the whole scalar (MSB first): U_{w,q} sits at bit c*w + log2(m) + q, A_w at bit c*w, and
     // log2(m) + logJ = c - 1, so every window's terms fall inside its own c positions: c*Wall doublings and
@@ -846,7 +892,25 @@ static int wait_plan_users(MsmWorkspace& M, int plan_id, hipStream_t s) {
     return WS_OK;
 }
 
-int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipStream_t s) {
+uint32_t msm_table_rows(uint32_t tc) { return tc ? (255 + tc - 1) / tc : 1; }
+
+// window width of the fixed-base tables for n pairs: c = log2 n, so that a bucket of the ONE bucket set receives about
+// 2 * rows entries (26 at 2^20: 13 rows, 2^19 buckets) -- the same load per lane as the per-window method has, with
+// 13 passes over the points instead of 16.  Narrower windows were measured at 2^20 (profiles/r02_sweep_key_table.txt):
+// their few, heavily loaded buckets must be cut into several tasks each and the partial sums folded again, which costs
+// more than the shorter tail saves (c = 18: 12.5 ms per proof, c = 20: 10.2-10.5 ms, plain sections 11.25 ms).
+// Capped at 20: 2^21 buckets would need 8-byte grouping entries.  WSNARK_TABLE_C overrides.
+uint32_t msm_table_window(uint64_t n) {
+    if (const char* e = getenv("WSNARK_TABLE_C")) { int c = atoi(e); if (c >= 4 && c <= 22) return (uint32_t)c; }
+    int lg = 0;
+    while (((uint64_t)1 << (lg + 1)) <= n) lg++;
+    int c = lg;
+    if (c < 4) c = 4;
+    if (c > 20) c = 20;
+    return (uint32_t)c;
+}
+
+int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipStream_t s, uint32_t table_c) {
     Context* X = ctx();
     if (!X) return WS_ERR_NOINIT;
     if (!s) s = L.stream;
@@ -858,26 +922,46 @@ int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipSt
     if (n > ((uint64_t)1 << 28)) return WS_ERR_SIZE;
     if (sh.stride == 0) return WS_ERR_ARG;
     I.n = n;
-    I.c = pick_window(n);
+    I.flat = table_c != 0;
+    I.c = I.flat ? table_c : pick_window(n);
+    if (I.c < 2 || I.c > 22) return WS_ERR_ARG;
     I.Wall = (255 + I.c - 1) / I.c;
+    if (I.flat && (uint64_t)I.Wall * n >= ((uint64_t)1 << 31)) return WS_ERR_SIZE;   // entries index the table, sign in bit 31
     I.w_off = sh.off;
     I.w_stride = sh.stride;
     I.W = I.w_off < I.Wall ? (I.Wall - I.w_off + I.w_stride - 1) / I.w_stride : 0;
     if (I.W == 0) { I.n = 0; I.valid = true; return WS_OK; }   // this rank owns no window: partial = infinity
     I.NB = 1u << (I.c - 1);
-    I.nbuckets = I.W * I.NB;
+    I.nbuckets = I.flat ? I.NB : I.W * I.NB;
     const uint64_t total = n * I.W;
     if (total >= ((uint64_t)1 << 32)) return WS_ERR_SIZE;
     uint32_t chunk = CHUNK;
     if (const char* e = getenv("WSNARK_MSM_CHUNK")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32) chunk = (uint32_t)v; }
-    I.m = I.NB < chunk ? I.NB : chunk;
-    I.J = I.NB / I.m;
+    if (I.flat) {
+        uint32_t tbits = 15;       // buckets per tail piece (WSNARK_TAIL_BITS): shorter pieces = shallower trees, more rows for the host
+        if (const char* e = getenv("WSNARK_TAIL_BITS")) { int v = atoi(e); if (v >= 6 && v <= 20) tbits = (uint32_t)v; }
+        I.tNB = I.NB < (1u << tbits) ? I.NB : (1u << tbits);
+        I.tW = I.NB / I.tNB;
+    } else {
+        I.tNB = I.NB;
+        I.tW = I.W;
+    }
+    I.m = I.tNB < chunk ? I.tNB : chunk;
+    I.J = I.tNB / I.m;
     while ((1u << I.logJ) < I.J) I.logJ++;
-    I.nsum = I.logJ + 1;
+    I.nsum = I.logJ + 1 + (I.flat ? 1 : 0);
     // task length cap: a multiple of the mean bucket load (default 2x); WSNARK_MSM_LMAX_X4 = multiplier * 4 for tuning
     uint32_t mult4 = 8;
     if (const char* e = getenv("WSNARK_MSM_LMAX_X4")) { int v = atoi(e); if (v >= 1 && v <= 64) mult4 = (uint32_t)v; }
-    I.lmax = (uint32_t)((mult4 * ((n + I.NB - 1) / I.NB) + 3) / 4);
+    I.lmax = (uint32_t)((mult4 * (((I.flat ? total : n) + I.NB - 1) / I.NB) + 3) / 4);
+    if (I.flat && I.NB < (1u << 19) && total >= ((uint64_t)1 << 22)) {
+        // one SMALL bucket set under many entries (a forced narrow window): a lane per bucket would leave most of the chip
+        // idle (2^15 buckets at 2^20 pairs = 2 wavefronts per CU: measured 4.0 ms instead of 1.26 ms), so the buckets
+        // are cut until about 2^19 tasks exist
+        const uint32_t by_tasks = (uint32_t)((total + (1u << 19) - 1) >> 19);
+        if (I.lmax > by_tasks) I.lmax = by_tasks;
+    }
+    if (const char* e = getenv("WSNARK_MSM_LMAX")) { int v = atoi(e); if (v >= 4 && v <= 65536) I.lmax = (uint32_t)v; }
     if (I.lmax < 32) I.lmax = 32;
     I.hot_cap = (uint32_t)(total / I.lmax) + I.nbuckets + 16;
     const uint32_t c = I.c, W = I.W, nbuckets = I.nbuckets, lmax = I.lmax;
@@ -909,12 +993,16 @@ int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipSt
     const bool env_e64 = [] { const char* e = getenv("WSNARK_MSM_ENTRY64"); return e && atoi(e) != 0; }();
     uint32_t lo_bits = env_lo > PRESORT_MAX_LO ? PRESORT_MAX_LO : env_lo;
     if (lo_bits > c - 1) lo_bits = c - 1;
-    while ((uint64_t)W * (I.NB >> lo_bits) > PRESORT_MAX_BINS && lo_bits < c - 1 && lo_bits < PRESORT_MAX_LO) lo_bits++;
+    const uint32_t Wb = I.flat ? 1 : W;        // bucket sets the bins are spread over
+    while ((uint64_t)Wb * (I.NB >> lo_bits) > PRESORT_MAX_BINS && lo_bits < c - 1 && lo_bits < PRESORT_MAX_LO) lo_bits++;
+    // one bucket set: keep about as many bins (= workgroups of the per-bin sort) as the 16-window plans have
+    // (not below 7 low bits: with 64 LDS counters per bin the counting sort's atomics collide -- 0.94 ms instead of 0.15-0.22 ms)
+    while (I.flat && (I.NB >> lo_bits) < 2048 && lo_bits > 7) lo_bits--;
     uint32_t idx_bits = 1;
-    while (((uint64_t)1 << idx_bits) < n) idx_bits++;
+    while (((uint64_t)1 << idx_bits) < (I.flat ? (uint64_t)I.Wall * n : n)) idx_bits++;
     // large inputs (2^24 pairs): give up low bucket bits while that keeps the entries at 4 bytes and the bin count in range
-    while (!env_e64 && idx_bits + 1 + lo_bits > 32 && lo_bits > 1 && (uint64_t)W * (I.NB >> (lo_bits - 1)) <= PRESORT_MAX_BINS) lo_bits--;
-    const uint32_t HB = I.NB >> lo_bits, nbins = W * HB;
+    while (!env_e64 && idx_bits + 1 + lo_bits > 32 && lo_bits > 1 && (uint64_t)Wb * (I.NB >> (lo_bits - 1)) <= PRESORT_MAX_BINS) lo_bits--;
+    const uint32_t HB = I.NB >> lo_bits, nbins = Wb * HB;
     if (!use_cub && nbins <= PRESORT_MAX_BINS) {
         // ---- grouping by coarse bins + per-bin LDS counting sort (hand-written; see the kernels above) ----
         const bool e32 = !env_e64 && idx_bits + 1 + lo_bits <= 32;
@@ -923,7 +1011,7 @@ int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipSt
         uint32_t* bin_start = bin_count + (nbins + 1);
         uint32_t* bin_cursor = bin_start + (nbins + 1);
         WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, (1024 + (size_t)nbins + 1) * 4, s));
-        PresortArgs PA{d_scalars, (uint32_t)n, c, I.Wall, I.w_off, I.w_stride, lo_bits, HB, nbins, env_tile, idx_bits, nullptr};
+        PresortArgs PA{d_scalars, (uint32_t)n, c, I.Wall, I.w_off, I.w_stride, lo_bits, HB, nbins, env_tile, idx_bits, nullptr, I.flat ? 1u : 0u};
         const dim3 grid(ceil_div_u64(n, env_tile)), blk(env_thr);
         T.begin("msm_presort_count", s);
         hipLaunchKernelGGL(presort_count, grid, blk, 0, s, PA, bin_count);
@@ -941,16 +1029,17 @@ int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipSt
         T.begin("msm_presort_bins", s);
         if (e32)
             hipLaunchKernelGGL(presort_bins<uint32_t>, dim3(nbins), bblk, 0, s, S.entries.as<uint32_t>(), bin_start, lo_bits,
-                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(), lmax, d_cnt + 16, nullptr);
+                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(), lmax, d_cnt + 16, nullptr, 0u);
         else
             hipLaunchKernelGGL(presort_bins<uint64_t>, dim3(nbins), bblk, 0, s, S.entries.as<uint64_t>(), bin_start, lo_bits,
-                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(), lmax, d_cnt + 16, nullptr);
+                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(), lmax, d_cnt + 16, nullptr, 0u);
         T.end(s);
         WS_HIP_CHECK(hipGetLastError());
         have_hist = true;
         I.ps_valid = true;
         I.ps_lo_bits = lo_bits; I.ps_idx_bits = idx_bits; I.ps_nbins = nbins; I.ps_bthr = bthr; I.ps_e32 = e32;
     } else {
+        if (I.flat) { set_last_error("msm: table plans need the grouping pass (WSNARK_MSM_SORT=cub or too many bins)"); return WS_ERR_ARG; }
         WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, 4096, s));
         // ---- reference pipeline: explicit digit arrays + hipCUB radix sort (WSNARK_MSM_SORT=cub) ----
         WS_HIP_CHECK(S.keys.reserve(total * 4));
@@ -1024,11 +1113,11 @@ int msm_plan_variant(Lane& L, int src_id, int dst_id, const uint8_t* d_mask, hip
     if (src.ps_e32)
         hipLaunchKernelGGL(presort_bins<uint32_t>, dim3(src.ps_nbins), dim3(src.ps_bthr), 0, s, SS.entries.as<uint32_t>(), bin_start,
                            src.ps_lo_bits, src.ps_idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(),
-                           src.lmax, d_cnt + 16, d_mask);
+                           src.lmax, d_cnt + 16, d_mask, src.flat ? (uint32_t)src.n : 0u);
     else
         hipLaunchKernelGGL(presort_bins<uint64_t>, dim3(src.ps_nbins), dim3(src.ps_bthr), 0, s, SS.entries.as<uint64_t>(), bin_start,
                            src.ps_lo_bits, src.ps_idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(),
-                           src.lmax, d_cnt + 16, d_mask);
+                           src.lmax, d_cnt + 16, d_mask, src.flat ? (uint32_t)src.n : 0u);
     T.end(s);
     T.begin("msm_plan", s);
     hipLaunchKernelGGL(msm_plan_emit, dim3(ceil_div_u64(src.nbuckets, 256)), dim3(256), 0, s, S.bstart.as<uint32_t>(),
@@ -1065,7 +1154,7 @@ static int msm_launch_acc(Lane& L, int which, const typename H::Aff* d_points_re
     if (I.n == 0) { P.active = true; *slot_out = slot; return WS_OK; }   // multiexp with n=0 leaves pr unchanged
     const typename C::AffP* d_points = reinterpret_cast<const typename C::AffP*>(d_points_ref);
     const uint64_t n = I.n;
-    const uint32_t W = I.W, nbuckets = I.nbuckets, J = I.J, nsum = I.nsum;
+    const uint32_t W = I.tW, nbuckets = I.nbuckets, J = I.J, nsum = I.nsum;
     const uint32_t ntasks = I.ntasks;
 
     MsmScratch& PS = M.plan[M.cur].S;           // plan buffers (read-only here)
@@ -1090,6 +1179,7 @@ static int msm_launch_acc(Lane& L, int which, const typename H::Aff* d_points_re
     WS_HIP_CHECK(S.hot_sums.reserve(((size_t)I.hot_cap / HOT_SLICE + (size_t)I.hot_cap / I.hot_min + 32) * sizeof(Pt)));
 
     KernelTimer& T = X->timer;
+    if (I.flat && !prepared) { set_last_error("msm: a table plan needs a prepared fixed-base table"); return WS_ERR_ARG; }
     if (C::Field::kInternalDomain && !prepared) {
         WS_HIP_CHECK(S.points_conv.reserve((size_t)n * sizeof(typename C::AffP)));
         T.begin("msm_convert_points", s);
@@ -1149,7 +1239,7 @@ static int msm_launch_tail(Lane& L, const int* slot_ids, int nslots, hipStream_t
         ts.chunkA[k] = P.S.chunkA.template as<Pt>();
         ts.sums[k] = P.d_sums.template as<Pt>();
     }
-    const uint32_t W = I.W, J = I.J, logJ = I.logJ, nsum = I.nsum, m = I.m;
+    const uint32_t W = I.tW, J = I.J, logJ = I.logJ, nsum = I.nsum, m = I.m;
     KernelTimer& T = X->timer;
     T.begin("msm_chunks", s);
     hipLaunchKernelGGL(msm_chunks<C>, dim3(ceil_div_u64((uint64_t)W * J, 256), nslots), dim3(256), 0, s, ts, W * J, m);
@@ -1280,6 +1370,57 @@ int msm_prepare_points(int which, void* d_points, uint64_t n, hipStream_t s) {
     return WS_OK;
 }
 
+// ---- fixed-base window tables (resident proving keys) ----
+// table = rows x n affine points, reference format, row 0 given: row w = 2^(c w) * row 0.  One lane per point walks
+// the rows with c doublings each (XYZZ, never normalised in between) and normalises TABLE_GROUP rows with one shared
+// inversion (Montgomery's trick on the ZZZ coordinates; 1/ZZ = ZZ^2 / ZZZ^2).  Key-load time only.
+static const uint32_t TABLE_GROUP = 8;
+template <class C>
+__global__ __launch_bounds__(256) void msm_table_kernel(typename C::Aff* __restrict__ table, uint64_t n, uint32_t c, uint32_t rows) {
+    typedef typename C::Field F;
+    typedef typename F::El El;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const typename C::Aff p0 = table[i];
+    if (C::aff_is_inf(p0)) {
+        for (uint32_t w = 1; w < rows; w++) table[(uint64_t)w * n + i] = p0;     // x == 0: infinity in every row
+        return;
+    }
+    typename C::Pt P = C::from_affine(p0);
+    typename C::Pt pts[TABLE_GROUP];
+    El pre[TABLE_GROUP];
+    for (uint32_t w0 = 1; w0 < rows; w0 += TABLE_GROUP) {
+        const uint32_t g = rows - w0 < TABLE_GROUP ? rows - w0 : TABLE_GROUP;
+        El run = F::one();
+        for (uint32_t k = 0; k < g; k++) {
+            for (uint32_t d = 0; d < c; d++) P = C::dbl(P);       // (a point of odd prime order never doubles to infinity)
+            pts[k] = P;
+            pre[k] = run;
+            run = F::mul(run, P.zzz);
+        }
+        El inv = F::inv(run);
+        for (int k = (int)g - 1; k >= 0; k--) {
+            const El izzz = F::mul(inv, pre[k]);
+            inv = F::mul(inv, pts[k].zzz);
+            const El izz = F::mul(F::sqr(izzz), F::sqr(pts[k].zz));
+            table[(uint64_t)(w0 + k) * n + i] = typename C::Aff{F::mul(pts[k].x, izz), F::mul(pts[k].y, izzz)};
+        }
+    }
+}
+int msm_build_table(int which, void* d_table, uint64_t n, uint32_t tc, hipStream_t s) {
+    Context* X = ctx();
+    if (!X) return WS_ERR_NOINIT;
+    if (!s) s = X->stream;
+    const uint32_t rows = msm_table_rows(tc);
+    if (n == 0 || rows < 2) return WS_OK;
+    if (which == 0)
+        hipLaunchKernelGGL(msm_table_kernel<G1>, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s, (G1::Aff*)d_table, n, tc, rows);
+    else
+        hipLaunchKernelGGL(msm_table_kernel<G2>, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s, (G2::Aff*)d_table, n, tc, rows);
+    WS_HIP_CHECK(hipGetLastError());
+    return WS_OK;
+}
+
 // The conversion of caller points to the device field's internal domain does not depend on the plan: it runs on
 // the lane's second queue while the first one groups the digits (returns the array the accumulation should read).
 template <class CD, class AffT>
@@ -1314,7 +1455,7 @@ static int msm_dev_t(Lane& L, int which, const Fe* d_scalars, const typename H::
     msm_select_plan(L, 0);
     int rc = convert_beside_plan<CD>(L, d_points, n, s, &pts, &prepared);
     if (rc) return rc;
-    if ((rc = msm_plan_dev(L, d_scalars, n, sh, s))) return rc;
+    if ((rc = msm_plan_dev(L, d_scalars, n, sh, s, 0))) return rc;
     if (prepared) WS_HIP_CHECK(hipStreamWaitEvent(s, ws(L).conv_ev[1], 0));
     int slot = -1;
     rc = which == 0 ? msm_g1_launch(L, reinterpret_cast<const Affine<Fq>*>(pts), prepared, &slot, s)
@@ -1351,7 +1492,7 @@ static int msm_host_t(Lane& L, int which, const void* h_scalars, const void* h_p
     int rc = upload_staged(L.host_in[0].p, h_scalars, (size_t)n * 32, s);
     if (rc) return rc;
     msm_select_plan(L, 0);
-    if ((rc = msm_plan_dev(L, L.host_in[0].as<Fe>(), n, sh, s))) return rc;
+    if ((rc = msm_plan_dev(L, L.host_in[0].as<Fe>(), n, sh, s, 0))) return rc;
     if ((rc = upload_staged(L.host_in[1].p, h_points, (size_t)n * sizeof(typename H::Aff), s2))) return rc;
     WS_HIP_CHECK(hipEventRecord(M.host_ev, s2));
     WS_HIP_CHECK(hipStreamWaitEvent(s, M.host_ev, 0));

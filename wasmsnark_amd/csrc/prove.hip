@@ -27,6 +27,11 @@ struct ProvingKey {
     DevBuf maskA, maskB;        // 1 byte per signal: 0 where A (resp. B1 and B2) is infinity: the variable is not in that matrix
     uint32_t infA = 0, infB = 0;   // how many of those there are
     bool sparseA = false, sparseB = false;   // enough of them to give those sums a plan variant that leaves them out
+    // Fixed-base window tables: the key's points never change, so each section is kept as rows x n points, row w =
+    // 2^(c w) * (the section) -- 15 rows at c = 18 for 2^20 pairs, 6 GB for the five sections.  Every window of a scalar
+    // then adds into ONE bucket set: fewer, wider windows (15 instead of 16 passes over the points at 2^20), one
+    // reduction tail per sum instead of one per window, no doubling chain on the host.  0 = plain sections.
+    uint32_t table_cw = 0, table_ch = 0;     // window width of the A/B1/B2/C tables (n_vars pairs) and of the H table (domain pairs)
     // Read-only after load: any number of proofs may use one handle at once (each on its own lane, which holds the
     // per-proof buffers and events).
 };
@@ -63,6 +68,25 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out) {
     memcpy(&K->delta2, S.delta2, 128);
     hipStream_t s = C->stream;
     size_t used = 0;
+    // WSNARK_KEY_TABLE=0: plain sections.  Otherwise tables, when they fit: at most WSNARK_TABLE_MAX_GB (default 160) and
+    // half of the memory that is free now
+    {
+        const char* e = getenv("WSNARK_KEY_TABLE");
+        if ((!e || atoi(e) != 0) && msm_uses_field29() && !(getenv("WSNARK_MSM_SORT") && !strcmp(getenv("WSNARK_MSM_SORT"), "cub"))) {
+            const uint32_t cw = msm_table_window(nv), ch = msm_table_window(dom);
+            const uint64_t bytes = (uint64_t)nv * 320 * msm_table_rows(cw) + (uint64_t)dom * 64 * msm_table_rows(ch);
+            const char* g = getenv("WSNARK_TABLE_MAX_GB");
+            const uint64_t cap = (uint64_t)((g ? atof(g) : 160.0) * 1073741824.0);
+            size_t free_b = 0, total_b = 0;
+            WS_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+            if (bytes <= cap && bytes <= free_b / 2 && (uint64_t)msm_table_rows(cw) * nv < ((uint64_t)1 << 31) &&
+                (uint64_t)msm_table_rows(ch) * dom < ((uint64_t)1 << 31)) {
+                K->table_cw = cw;
+                K->table_ch = ch;
+            }
+        }
+    }
+    const uint64_t rowsW = msm_table_rows(K->table_cw), rowsH = msm_table_rows(K->table_ch);
     int rc = pols_to_csr(S.polsA, (size_t)S.lenA, nv, dom, &K->polsA, &used, s);
     if (rc) return rc;
     rc = pols_to_csr(S.polsB, (size_t)S.lenB, nv, dom, &K->polsB, &used, s);
@@ -75,12 +99,12 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out) {
             // C holds points for signals nPublic+1.. only (src/bn128.js:620 slices the scalars instead).
             // Resident copy: padded in front with nPublic+1 points at infinity (x == 0), so that the C sum
             // uses the SAME scalar vector -- and the same digit/sort plan -- as A, B1 and B2.
-            WS_HIP_CHECK(sc.d->alloc((size_t)nv * 64));
+            WS_HIP_CHECK(sc.d->alloc((size_t)nv * 64 * rowsW));
             WS_HIP_CHECK(hipMemsetAsync(sc.d->p, 0, (size_t)(np + 1) * 64, s));
             if (sc.bytes && (rc = upload_staged((uint8_t*)sc.d->p + (size_t)(np + 1) * 64, sc.src, (size_t)sc.bytes, s))) return rc;
             continue;
         }
-        WS_HIP_CHECK(sc.d->alloc((size_t)sc.bytes));
+        WS_HIP_CHECK(sc.d->alloc((size_t)sc.bytes * (sc.d == &K->pointsH ? rowsH : rowsW)));
         if (sc.bytes && (rc = upload_staged(sc.d->p, sc.src, (size_t)sc.bytes, s))) return rc;
     }
     // Variables that do not occur in matrix A (resp. B) have A (resp. B1 = B2) = infinity -- common: real circuits put
@@ -99,12 +123,19 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out) {
         K->sparseA = mode == 2 || (mode == 1 && big && (uint64_t)K->infA * 100 >= (uint64_t)nv * 15);   // saves a share of one G1 sum
         K->sparseB = mode == 2 || (mode == 1 && big && (uint64_t)K->infB * 100 >= (uint64_t)nv * 5);    // ... of a G1 and a G2 sum
     }
+    if (K->table_cw) {
+        if ((rc = msm_build_table(0, K->pointsA.p, nv, K->table_cw, s))) return rc;
+        if ((rc = msm_build_table(0, K->pointsB1.p, nv, K->table_cw, s))) return rc;
+        if ((rc = msm_build_table(1, K->pointsB2.p, nv, K->table_cw, s))) return rc;
+        if ((rc = msm_build_table(0, K->pointsC.p, nv, K->table_cw, s))) return rc;
+        if ((rc = msm_build_table(0, K->pointsH.p, dom, K->table_ch, s))) return rc;
+    }
     // resident keys are kept in the device field's internal domain: no per-proof conversion pass
-    if ((rc = msm_prepare_points(0, K->pointsA.p, nv, s))) return rc;
-    if ((rc = msm_prepare_points(0, K->pointsB1.p, nv, s))) return rc;
-    if ((rc = msm_prepare_points(1, K->pointsB2.p, nv, s))) return rc;
-    if ((rc = msm_prepare_points(0, K->pointsC.p, nv, s))) return rc;
-    if ((rc = msm_prepare_points(0, K->pointsH.p, dom, s))) return rc;
+    if ((rc = msm_prepare_points(0, K->pointsA.p, nv * rowsW, s))) return rc;
+    if ((rc = msm_prepare_points(0, K->pointsB1.p, nv * rowsW, s))) return rc;
+    if ((rc = msm_prepare_points(1, K->pointsB2.p, nv * rowsW, s))) return rc;
+    if ((rc = msm_prepare_points(0, K->pointsC.p, nv * rowsW, s))) return rc;
+    if ((rc = msm_prepare_points(0, K->pointsH.p, dom * rowsH, s))) return rc;
     WS_HIP_CHECK(hipStreamSynchronize(s));
     *out = K.release();
     return WS_OK;
@@ -224,14 +255,38 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
     WS_HIP_CHECK(hipEventRecord(L.ev_start, s));          // the witness is ready on s
     // the four sums whose scalars are the witness (:617-620)
     msm_select_plan(L, 0);
-    if ((rc = msm_plan_dev(L, d_witness, nv, sh, s))) return rc;
+    if ((rc = msm_plan_dev(L, d_witness, nv, sh, s, K->table_cw))) return rc;
     // one grouping pass for all four; A and B1/B2 may run on variants of the plan that leave out the variables
     // absent from their matrix (plan 0 = full, 2 = without B's absentees, 3 = without A's).  A, B1 and C: three
     // accumulations back to back, then ONE batched reduction tail
     int planA = 0, planB = 0;
     if (K->sparseB && msm_plan_variant(L, 0, 2, K->maskB.as<uint8_t>(), s) == WS_OK) planB = 2;   // (hipCUB pipeline: no variants,
     if (K->sparseA && msm_plan_variant(L, 0, 3, K->maskA.as<uint8_t>(), s) == WS_OK) planA = 3;   //  everything on the full plan)
-    {
+    // Order on this queue: B2 first, then A and B1 (accumulations back to back, ONE batched tail), C last.  The G2 tail is
+    // the slowest chain of the proof (a G2 addition on a lone wavefront: ~23 us, G1: ~7 us); early in the queue it runs
+    // beside CALC_H's full-width kernels instead of at the end of the proof, where nothing is left to fill the SIMDs
+    // (WSNARK_PROVE_ORDER=0: the round-1 order A, B1, C, B2).  A and B1 reach the host before C's accumulation ends,
+    // so the host's share of pi_c (after_ab1) still overlaps GPU work.
+    static const bool g2_first = [] { const char* e = getenv("WSNARK_PROVE_ORDER"); return !e || atoi(e) != 0; }();
+    auto launch_b2 = [&]() -> int {
+        msm_select_plan(L, planB);
+        int r = msm_g2_launch(L, K->pointsB2.as<Affine<Fq2>>(), true, &hB2, s);                           // :619
+        msm_select_plan(L, 0);
+        return r;
+    };
+    if (g2_first) {
+        if ((rc = launch_b2())) return rc;
+        tr.mark("plan(w) [+ variants] + launch B2");
+        const Affine<Fq>* g1sets[2] = {K->pointsA.as<Affine<Fq>>(), K->pointsB1.as<Affine<Fq>>()};
+        const int plans[2] = {planA, planB};
+        int g1slots[2] = {-1, -1};
+        rc = msm_g1_launch_batch(L, g1sets, 2, true, g1slots, s, L.ev_tail, plans);                       // :617, :618
+        hA = g1slots[0]; hB1 = g1slots[1];
+        if (rc) return rc;
+        msm_select_plan(L, 0);
+        if ((rc = msm_g1_launch(L, K->pointsC.as<Affine<Fq>>(), true, &hC, s))) return rc;                // :620 (padded)
+        tr.mark("launch A, B1, C");
+    } else {
         const Affine<Fq>* g1sets[3] = {K->pointsA.as<Affine<Fq>>(), K->pointsB1.as<Affine<Fq>>(), K->pointsC.as<Affine<Fq>>()};
         const int plans[3] = {planA, planB, 0};
         int g1slots[3] = {-1, -1, -1};
@@ -239,12 +294,9 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
         hA = g1slots[0]; hB1 = g1slots[1]; hC = g1slots[2];
         if (rc) return rc;
         tr.mark("plan(w) [+ variants] + launch A,B1,C");
+        if ((rc = launch_b2())) return rc;
+        tr.mark("launch B2");
     }
-    msm_select_plan(L, planB);
-    rc = msm_g2_launch(L, K->pointsB2.as<Affine<Fq2>>(), true, &hB2, s);                                  // :619
-    msm_select_plan(L, 0);
-    if (rc) return rc;
-    tr.mark("launch B2");
     if (skip_h) {
         // distributed proving with the four-step CALC_H (wasmsnark_amd/dist.py): h and the H sum are the caller's
         if ((rc = msm_g1_finish(L, hA, &out->A))) return rc;
@@ -263,33 +315,36 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
     if ((rc = calc_h_dev(L, d_witness, nv, K->polsA, K->polsB, dom, d_h, s2))) return rc;
     tr.mark("calc_h enqueued");
     msm_select_plan(L, s2 != s ? 1 : 0);
-    rc = msm_plan_dev(L, d_h, dom, sh, s2);
+    rc = msm_plan_dev(L, d_h, dom, sh, s2, K->table_ch);
     if (!rc) rc = msm_g1_launch(L, K->pointsH.as<Affine<Fq>>(), true, &hH, s2);                           // :614
     msm_select_plan(L, 0);
     if (rc) return rc;
     if (s2 != s) { WS_HIP_CHECK(hipEventRecord(L.ev_h, s2)); WS_HIP_CHECK(hipStreamWaitEvent(s, L.ev_h, 0)); }   // s stays the caller's ordering point
     tr.mark("plan(h) + launch H");
+    if (g2_first && (rc = msm_g2_finish(L, hB2, &out->B2))) return rc;
     if ((rc = msm_g1_finish(L, hA, &out->A))) return rc;
     if ((rc = msm_g1_finish(L, hB1, &out->B1))) return rc;
-    tr.mark("finish A, B1");
+    tr.mark(g2_first ? "finish B2, A, B1" : "finish A, B1");
     if (after_ab1) after_ab1(*out);
-    if ((rc = msm_g1_finish(L, hC, &out->C))) return rc;
-    tr.mark("host work on A, B1; finish C");
-    // the two queues end independently: finish whichever sum reaches the host first (its serial host tail -- 0.24 ms for
-    // the G2 sum -- then runs while the GPU still works on the other one), so poll both instead of blocking on one
+    if (!g2_first && (rc = msm_g1_finish(L, hC, &out->C))) return rc;
+    tr.mark(g2_first ? "host work on A, B1" : "host work on A, B1; finish C");
+    // the two queues end independently: finish whichever sum reaches the host first (its serial host tail then runs while
+    // the GPU still works on the other one), so poll both instead of blocking on one
     {
-        bool doneB2 = false, doneH = false;
-        for (unsigned spins = 0; !(doneB2 && doneH); spins++) {
-            if (!doneB2 && (doneH || msm_ready(L, hB2))) { if ((rc = msm_g2_finish(L, hB2, &out->B2))) return rc; doneB2 = true; continue; }
-            if (!doneH && (doneB2 || msm_ready(L, hH))) { if ((rc = msm_g1_finish(L, hH, &out->H))) return rc; doneH = true; continue; }
+        const int hX = g2_first ? hC : hB2;                 // the first queue's last sum
+        auto finish_x = [&]() -> int { return g2_first ? msm_g1_finish(L, hC, &out->C) : msm_g2_finish(L, hB2, &out->B2); };
+        bool doneX = false, doneH = false;
+        for (unsigned spins = 0; !(doneX && doneH); spins++) {
+            if (!doneX && (doneH || msm_ready(L, hX))) { if ((rc = finish_x())) return rc; doneX = true; continue; }
+            if (!doneH && (doneX || msm_ready(L, hH))) { if ((rc = msm_g1_finish(L, hH, &out->H))) return rc; doneH = true; continue; }
             if (spins > 64) std::this_thread::yield();
             if (spins > (1u << 22)) {       // (never observed: an event that does not report ready -- block on the sums in turn)
                 if (!doneH) { if ((rc = msm_g1_finish(L, hH, &out->H))) return rc; doneH = true; }
-                if (!doneB2) { if ((rc = msm_g2_finish(L, hB2, &out->B2))) return rc; doneB2 = true; }
+                if (!doneX) { if ((rc = finish_x())) return rc; doneX = true; }
             }
         }
     }
-    tr.mark("finish H, B2");
+    tr.mark(g2_first ? "finish H, C" : "finish H, B2");
     guard.armed = false;
     return WS_OK;
 }
