@@ -156,13 +156,16 @@ def timed(ctx, step, steps, warmup):
     return dt, kt, res
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, pairs_per_launch, windows):
     """HBM-side bytes per launch of `kernel`, measured out of band by tools/gpu_session.sh (rocprofv3 cannot wrap
     itself): two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) over this same command, summary committed."""
     for name in ("r02_pmc_traffic.json",):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
             k = pm["kernels"][kernel]
+            shape = pm.get("msm_accumulate_shape") or {"pairs_per_launch": 1 << 20, "windows_per_launch": 16}
+            if abs(pairs_per_launch - shape["pairs_per_launch"]) > 16 or windows != shape["windows_per_launch"]:
+                continue        # the committed summary was taken on another launch shape: not quoted
             return k["fetch_bytes"] + k["write_bytes"], "profiles/%s: %s" % (name, pm.get("how", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bytes per launch"))
         except Exception:  # noqa: BLE001
             continue
@@ -176,8 +179,8 @@ def rooflines(kt, kernel, pairs_per_launch, windows_owned, bytes_per_pair, modmu
     avg_s = ms / cnt / 1e3
     alg = bytes_per_pair * pairs_per_launch
     achieved = alg / avg_s / 1e9
-    # the committed PMC summary was taken at 2^20 pairs per launch with all 16 windows: only quoted for that shape
-    traffic, src = pmc_traffic(kernel) if (abs(pairs_per_launch - (1 << 20)) < 8 and windows_owned == 16) else (None, None)
+    # the committed PMC summary names the launch shape it was taken on: only quoted for that shape
+    traffic, src = pmc_traffic(kernel, pairs_per_launch, windows_owned)
     modmul = modmul_per_add * windows_owned * pairs_per_launch
     g = modmul / avg_s / 1e9
     hbm = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -186,7 +189,7 @@ def rooflines(kt, kernel, pairs_per_launch, windows_owned, bytes_per_pair, modmu
            "note": "reported because the contract asks for it; the kernel is integer-ALU bound (see roofline_int_alu): "
                    "~%d modmul per %d bytes" % (modmul_per_add * windows_owned, bytes_per_pair)}
     alu = {"bound": "int-alu", "kernel": kernel, "achieved": round(g, 1), "peak": MODMUL_PEAK_G, "unit": "Gmodmul/s",
-           "frac": round(g / MODMUL_PEAK_G, 4), "modmul_per_launch": int(modmul),
+           "frac": round(g / MODMUL_PEAK_G, 4), "modmul_per_launch": int(modmul), "windows_per_launch": windows_owned,
            "peak_source": "tools/microbench.hip on MI355X: dependent chain of radix-2^29 Montgomery products, "
                           "162 v_mad_u64_u32 each (27.8 T mad/s chip-wide)"}
     return hbm, alu
@@ -247,8 +250,12 @@ def bench_prove(ctx):
         return None
     ms = dt / args.steps * 1e3
     nv, dom = circ.n_vars, circ.domain
-    c_win = 16 if logd >= 20 else max(4, logd - 4)
-    W_all = (255 + c_win - 1) // c_win
+    # passes over the points per sum: the rows of the key's fixed-base tables (13 at 2^20), or the windows of the plain method
+    if key.table["rows_w"] > 1:
+        W_all = key.table["rows_w"]
+    else:
+        c_win = 16 if logd >= 20 else max(4, logd - 4)
+        W_all = (255 + c_win - 1) // c_win
     W_own = len(range(rank, W_all, world))
     pairs = (3 * nv + dom) / 4.0                       # msm_accumulate_g1 launches per proof: A, B1, C (nVars pairs) and H (domain pairs)
     hbm, alu = rooflines(kt, "msm_accumulate_g1", pairs, W_own, 96, 10)

@@ -132,6 +132,14 @@ int wsnark_calc_h(const void* signals, const void* polsA, size_t lenA, const voi
 int wsnark_pkey_load(const void* pkey, size_t len, wsnark_pkey_t** out_handle);
 void wsnark_pkey_free(wsnark_pkey_t* handle);
 int wsnark_pkey_info(const wsnark_pkey_t* handle, uint32_t* n_vars, uint32_t* n_public, uint32_t* domain);
+/* How the key's five point sections are resident (no counterpart in the reference, which reads the sections in place:
+ * src/bn128.js:592-604).  By default each section is kept as a fixed-base window table -- rows x n points, row w =
+ * 2^(c w) * section -- so that a sum is `rows` passes into one bucket set (13 rows, c = 20, at 2^20 pairs; about 6 GB
+ * for the five sections).  c_w / rows_w: the A, B1, B2, C tables (nVars pairs); c_h / rows_h: the hExps table
+ * (domainSize pairs); bytes: device memory of all five.  Plain sections (WSNARK_KEY_TABLE=0, or tables that do not
+ * fit: WSNARK_TABLE_MAX_GB, half of the free memory): c = 0, rows = 1.  Any out pointer may be NULL. */
+int wsnark_pkey_table_info(const wsnark_pkey_t* handle, uint32_t* c_w, uint32_t* rows_w, uint32_t* c_h, uint32_t* rows_h,
+                           uint64_t* bytes);
 
 /* The same key given as separate host buffers with 64-bit lengths: proving_key.bin addresses its
  * sections with u32 byte offsets (tools/buildpkey.js:133-139), which caps a key at 4 GiB (~2^23

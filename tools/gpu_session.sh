@@ -29,7 +29,7 @@ fi
 # HBM traffic counters: separate --pmc passes, kernel-trace only (never combined with sys/hip/hsa traces)
 if ! skip pmc; then
   for CTR in FETCH_SIZE WRITE_SIZE; do
-    ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/$O/pmc_$CTR" -o pmc -- python "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --extras msm,ntt ) > "$O/pmc_$CTR.log" 2>&1
+    ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/$O/pmc_$CTR" -o pmc -- python "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extras ) > "$O/pmc_$CTR.log" 2>&1
     echo "pmc $CTR rc=$?" >> "$O/env.log"
   done
   python tools/pmc_summary.py "$O" > "$O/pmc_traffic.json" 2>> "$O/env.log"

@@ -48,7 +48,18 @@ alias = {"msm_accumulate_g1": "msm_accumulate", "msm_accumulate_g2": "msm_accumu
 for a, k in alias.items():
     if k in kern:
         kern[a] = kern[k]
+# the shape of the msm_accumulate launches the means were taken over: from the bench line of the same pass
+shape = None
+try:
+    for line in open(os.path.join(root, "pmc_FETCH_SIZE.log")):
+        if line.startswith("{") and '"roofline_int_alu"' in line:
+            d = json.loads(line)
+            shape = {"pairs_per_launch": d["roofline"]["algorithmic_bytes_per_launch"] // 96,
+                     "windows_per_launch": d["roofline_int_alu"].get("windows_per_launch")}
+except Exception:  # noqa: BLE001
+    pass
 print(json.dumps({"how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes (--kernel-trace only) around "
-                         "`python bench.py --steps 2 --warmup 1 --no-cpu-baseline --extras msm,ntt`; mean bytes per launch = counter (KiB) x 1024; "
+                         "`python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras` (proofs only: every msm_accumulate launch has "
+                         "the shape below); mean bytes per launch = counter (KiB) x 1024; "
                          "FETCH_SIZE raw except *_corrected_x2 (gfx950 tallies wide coalesced 128-B requests at 64 B)",
-                  "kernels": kern}, indent=1))
+                  "msm_accumulate_shape": shape, "kernels": kern}, indent=1))

@@ -20,7 +20,7 @@ SYMBOLS = [
     "wsnark_g1_sum", "wsnark_g2_sum",
     "wsnark_fr_ntt", "wsnark_fr_ntt_dev", "wsnark_fr_ntt_batch_dev", "wsnark_fr_dist_scale_dev",
     "wsnark_pkey_eval_ab_dev", "wsnark_fr_mul_dev", "wsnark_fr_dist_combine_dev", "wsnark_fr_to_montgomery", "wsnark_fr_from_montgomery",
-    "wsnark_calc_h", "wsnark_pkey_load", "wsnark_pkey_free", "wsnark_pkey_info",
+    "wsnark_calc_h", "wsnark_pkey_load", "wsnark_pkey_free", "wsnark_pkey_info", "wsnark_pkey_table_info",
     "wsnark_groth16_prove", "wsnark_groth16_prove_dev", "wsnark_pkey_load_sections", "wsnark_last_blinding", "wsnark_groth16_verify",
     "wsnark_groth16_prove_partial", "wsnark_groth16_prove_partial_dev", "wsnark_groth16_prove_finish",
     "wsnark_g1_mul_base_batch", "wsnark_g2_mul_base_batch",
@@ -73,6 +73,7 @@ class Lib:
         c.wsnark_pkey_free.argtypes = [vp]
         c.wsnark_pkey_free.restype = None
         c.wsnark_pkey_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+        c.wsnark_pkey_table_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_uint64)]
         c.wsnark_groth16_prove.argtypes = [vp, vp, sz, vp, vp, vp]
         c.wsnark_groth16_prove_dev.argtypes = [vp, vp, sz, vp, vp, vp, vp]
         c.wsnark_pkey_load_sections.argtypes = [vp, C.POINTER(vp)]

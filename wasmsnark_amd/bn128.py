@@ -82,6 +82,10 @@ class ProvingKey:
         nv, npub, dom = C.c_uint32(), C.c_uint32(), C.c_uint32()
         lib.check(lib.c.wsnark_pkey_info(self._h, C.byref(nv), C.byref(npub), C.byref(dom)))
         self.n_vars, self.n_public, self.domain = nv.value, npub.value, dom.value
+        cw, rw, ch, rh, nb = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
+        lib.check(lib.c.wsnark_pkey_table_info(self._h, C.byref(cw), C.byref(rw), C.byref(ch), C.byref(rh), C.byref(nb)))
+        # how the point sections are resident: fixed-base window tables (rows > 1) or the plain sections
+        self.table = {"c_w": cw.value, "rows_w": rw.value, "c_h": ch.value, "rows_h": rh.value, "bytes": nb.value}
 
     def free(self):
         if self._h:

@@ -13,6 +13,7 @@ struct ProvingKey;
 int pkey_load(const uint8_t* buf, size_t len, ProvingKey** out);
 void pkey_free(ProvingKey* K);
 void pkey_info(const ProvingKey* K, uint32_t* nv, uint32_t* np, uint32_t* dom);
+void pkey_table_info(const ProvingKey* K, uint32_t* cw, uint32_t* rw, uint32_t* ch, uint32_t* rh, uint64_t* bytes);
 int groth16_prove_host_witness(ProvingKey* K, const uint8_t* witness, size_t witness_len, const uint8_t* r32,
                                const uint8_t* s32, uint8_t* out384);
 struct KeySections {
@@ -217,6 +218,11 @@ void wsnark_pkey_free(wsnark_pkey_t* h) {
 int wsnark_pkey_info(const wsnark_pkey_t* h, uint32_t* nv, uint32_t* np, uint32_t* dom) {
     if (!h) return WSNARK_ERR_ARG;
     pkey_info(reinterpret_cast<const ProvingKey*>(h), nv, np, dom);
+    return WSNARK_OK;
+}
+int wsnark_pkey_table_info(const wsnark_pkey_t* h, uint32_t* cw, uint32_t* rw, uint32_t* ch, uint32_t* rh, uint64_t* bytes) {
+    if (!h) return WSNARK_ERR_ARG;
+    pkey_table_info(reinterpret_cast<const ProvingKey*>(h), cw, rw, ch, rh, bytes);
     return WSNARK_OK;
 }
 int wsnark_groth16_prove(wsnark_pkey_t* h, const void* witness, size_t witness_len, const void* r32, const void* s32,

@@ -173,6 +173,14 @@ void pkey_info(const ProvingKey* K, uint32_t* nv, uint32_t* np, uint32_t* dom) {
     if (dom) *dom = K->domain;
 }
 
+void pkey_table_info(const ProvingKey* K, uint32_t* cw, uint32_t* rw, uint32_t* ch, uint32_t* rh, uint64_t* bytes) {
+    if (cw) *cw = K->table_cw;
+    if (rw) *rw = msm_table_rows(K->table_cw);
+    if (ch) *ch = K->table_ch;
+    if (rh) *rh = msm_table_rows(K->table_ch);
+    if (bytes) *bytes = (uint64_t)K->n_vars * 320 * msm_table_rows(K->table_cw) + (uint64_t)K->domain * 64 * msm_table_rows(K->table_ch);
+}
+
 // serial EC sum of Jacobian-Montgomery partials: the main-thread gather loop of the reference
 // (src/bn128.js:374-382 g1m_add over the workers' results; :406-414 for G2).  Host arithmetic.
 template <class C, class F>
@@ -267,7 +275,8 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
     // beside CALC_H's full-width kernels instead of at the end of the proof, where nothing is left to fill the SIMDs
     // (WSNARK_PROVE_ORDER=0: the round-1 order A, B1, C, B2).  A and B1 reach the host before C's accumulation ends,
     // so the host's share of pi_c (after_ab1) still overlaps GPU work.
-    static const bool g2_first = [] { const char* e = getenv("WSNARK_PROVE_ORDER"); return !e || atoi(e) != 0; }();
+    static const int order = [] { const char* e = getenv("WSNARK_PROVE_ORDER"); return e ? atoi(e) : 1; }();
+    const bool g2_first = order != 0;
     auto launch_b2 = [&]() -> int {
         msm_select_plan(L, planB);
         int r = msm_g2_launch(L, K->pointsB2.as<Affine<Fq2>>(), true, &hB2, s);                           // :619
@@ -277,14 +286,20 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
     if (g2_first) {
         if ((rc = launch_b2())) return rc;
         tr.mark("plan(w) [+ variants] + launch B2");
-        const Affine<Fq>* g1sets[2] = {K->pointsA.as<Affine<Fq>>(), K->pointsB1.as<Affine<Fq>>()};
-        const int plans[2] = {planA, planB};
-        int g1slots[2] = {-1, -1};
-        rc = msm_g1_launch_batch(L, g1sets, 2, true, g1slots, s, L.ev_tail, plans);                       // :617, :618
-        hA = g1slots[0]; hB1 = g1slots[1];
-        if (rc) return rc;
-        msm_select_plan(L, 0);
-        if ((rc = msm_g1_launch(L, K->pointsC.as<Affine<Fq>>(), true, &hC, s))) return rc;                // :620 (padded)
+        const Affine<Fq>* g1sets[3] = {K->pointsA.as<Affine<Fq>>(), K->pointsB1.as<Affine<Fq>>(), K->pointsC.as<Affine<Fq>>()};
+        const int plans[3] = {planA, planB, 0};
+        int g1slots[3] = {-1, -1, -1};
+        if (order == 2) {        // (A, B1 and C under one batched tail: one chain fewer, but A and B1 reach the host last)
+            rc = msm_g1_launch_batch(L, g1sets, 3, true, g1slots, s, L.ev_tail, plans);
+            hA = g1slots[0]; hB1 = g1slots[1]; hC = g1slots[2];
+            if (rc) return rc;
+        } else {
+            rc = msm_g1_launch_batch(L, g1sets, 2, true, g1slots, s, L.ev_tail, plans);                   // :617, :618
+            hA = g1slots[0]; hB1 = g1slots[1];
+            if (rc) return rc;
+            msm_select_plan(L, 0);
+            if ((rc = msm_g1_launch(L, K->pointsC.as<Affine<Fq>>(), true, &hC, s))) return rc;            // :620 (padded)
+        }
         tr.mark("launch A, B1, C");
     } else {
         const Affine<Fq>* g1sets[3] = {K->pointsA.as<Affine<Fq>>(), K->pointsB1.as<Affine<Fq>>(), K->pointsC.as<Affine<Fq>>()};
