@@ -76,7 +76,7 @@ def test_emulated_prove_sparse_b_plan(monkeypatch, name):
 
 
 @pytest.mark.parametrize("name", NAMES)
-@pytest.mark.parametrize("mode", ["plain", "pieces", "pieces-sparse", "wide", "round1-order"])
+@pytest.mark.parametrize("mode", ["plain", "pieces", "pieces-sparse", "wide", "round1-order", "entry64"])
 def test_emulated_prove_key_table_modes(monkeypatch, name, mode):
     """Resident keys are fixed-base window tables by default (row w = 2^(c w) * section; one bucket set per sum).
     `plain` switches them off (the per-window path the MSM entry points use); `pieces` forces a table whose bucket set
@@ -91,6 +91,9 @@ def test_emulated_prove_key_table_modes(monkeypatch, name, mode):
             monkeypatch.setenv("WSNARK_PROVE_SPARSE", "2")
     elif mode == "wide":
         monkeypatch.setenv("WSNARK_TABLE_C", "13")
+    elif mode == "entry64":
+        monkeypatch.setenv("WSNARK_MSM_ENTRY64", "1")     # 8-byte grouping entries: what a 2^24 table key needs (28 index bits)
+        monkeypatch.setenv("WSNARK_PROVE_SPARSE", "2")
     else:
         monkeypatch.setenv("WSNARK_PROVE_ORDER", "0")     # A, B1, C, B2 on the first queue (default: B2, A, B1, C)
     bn = emul_bn128()
