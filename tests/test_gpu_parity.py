@@ -509,6 +509,38 @@ def test_sharded_prove_records_on_gpu(bn):
     assert bn.groth16_prove_finish(key, parts, r=r, s=s) == want
 
 
+@pytest.mark.parametrize("logd", [12, 16])
+def test_key_tables_and_plain_sections_give_the_same_proofs_on_gpu(bn, monkeypatch, logd):
+    """Resident keys are fixed-base window tables by default (wsnark_pkey_table_info: rows x n points per section, one
+    bucket set per sum); WSNARK_KEY_TABLE=0 keeps the plain sections and the per-window plans.  Same proofs from both,
+    equal to the closed form; also with the table's bucket set cut into several reduction pieces, with the masked plan
+    variants, and through the window shards of a world of 3."""
+    from wasmsnark_amd import synth
+    circ = synth.make_circuit(logd, n_public=4, seed=100 + logd, style="rows")
+    S = synth.setup(circ, seed=5)
+    pkey, _ = synth.build_key(circ, S, bn.mul_base)
+    wit = synth.witness_bin(circ)
+    r, s = os.urandom(32), os.urandom(32)
+    want = synth.expected_proof(circ, S, r, s, bn.mul_base)
+    key = bn.load_key(pkey)
+    assert key.table["rows_w"] == -(-255 // key.table["c_w"]) > 1 and key.table["c_w"] == min(20, circ.n_vars.bit_length() - 1)
+    assert key.table["bytes"] == circ.n_vars * 320 * key.table["rows_w"] + circ.domain * 64 * key.table["rows_h"]
+    assert bn.groth16GenProof(wit, key, r=r, s=s) == want
+    parts = b"".join(bn.groth16_prove_partial(wit, key, shard=(rank, 3)) for rank in range(3))
+    assert bn.groth16_prove_finish(key, parts, r=r, s=s) == want
+    key.free()
+    for env in ({"WSNARK_KEY_TABLE": "0"}, {"WSNARK_TABLE_C": "10", "WSNARK_TAIL_BITS": "6", "WSNARK_PROVE_SPARSE": "2"},
+                {"WSNARK_TABLE_C": "13", "WSNARK_MSM_ENTRY64": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        key = bn.load_key(pkey)
+        assert (key.table["rows_w"] == 1) == ("WSNARK_KEY_TABLE" in env)
+        assert bn.groth16GenProof(wit, key, r=r, s=s) == want, env
+        key.free()
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_ntt_2p25_four_pass_roundtrip_and_linearity(bn):
     """2^25 needs four digit passes (middle-digit reversal): round trip, and F(x + y) == F(x) + F(y)
     checked through the evaluation at one point: sum_k F(x)[k] == n * x[0] (DFT of the constant-one vector)."""

@@ -99,6 +99,10 @@ def test_emulated_prove_key_table_modes(monkeypatch, name, mode):
     bn = emul_bn128()
     pkey, wit, _ = _key(name)
     key = bn.load_key(pkey)
+    # wsnark_pkey_table_info: plain sections report one row; tables ceil(255 / c) rows of the window the mode asks for
+    t = key.table
+    assert (t["rows_w"], t["c_w"]) == ((1, 0) if mode == "plain" else (-(-255 // t["c_w"]), {"pieces": 9, "pieces-sparse": 9, "wide": 13}.get(mode, t["c_w"])))
+    assert t["bytes"] == key.n_vars * 320 * t["rows_w"] + key.domain * 64 * t["rows_h"]
     for c in load_golden("proofs.json")[name]:
         assert bn.groth16GenProof(wit, key, r=bytes.fromhex(c["r"]), s=bytes.fromhex(c["s"])) == c["proof"]
 
