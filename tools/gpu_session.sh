@@ -19,7 +19,8 @@ if ! skip bench; then
   timeout 1500 python bench.py $BENCH_ARGS > "$O/bench.json" 2> "$O/bench.err"
   echo "bench rc=$?" >> "$O/env.log"
 fi
-PROF_CMD="python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --extras msm,ntt"
+# (proofs only: every msm_accumulate launch then has the shape bench.py's roofline is quoted on)
+PROF_CMD="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras"
 if ! skip prof; then
   ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$O/prof" -o prof -- $PROF_CMD ) > "$O/prof.log" 2>&1
   echo "rocprof rc=$?" >> "$O/env.log"
