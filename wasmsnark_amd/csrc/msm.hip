@@ -899,12 +899,14 @@ uint32_t msm_table_rows(uint32_t tc) { return tc ? (255 + tc - 1) / tc : 1; }
 // 13 passes over the points instead of 16.  Narrower windows were measured at 2^20 (profiles/r02_sweep_key_table.txt):
 // their few, heavily loaded buckets must be cut into several tasks each and the partial sums folded again, which costs
 // more than the shorter tail saves (c = 18: 12.5 ms per proof, c = 20: 10.2-10.5 ms, plain sections 11.25 ms).
+// Between powers of two the width goes up at n = 1.25 * 2^k: there rows(c) * n + ~3 * 2^(c-1) additions (passes + bucket
+// reduction) break even, and the wider window keeps one task per bucket (14-32 entries each).
 // Capped at 20: 2^21 buckets would need 8-byte grouping entries.  WSNARK_TABLE_C overrides.
 uint32_t msm_table_window(uint64_t n) {
     if (const char* e = getenv("WSNARK_TABLE_C")) { int c = atoi(e); if (c >= 4 && c <= 22) return (uint32_t)c; }
     int lg = 0;
     while (((uint64_t)1 << (lg + 1)) <= n) lg++;
-    int c = lg;
+    int c = (n * 4 >= ((uint64_t)5 << lg)) ? lg + 1 : lg;
     if (c < 4) c = 4;
     if (c > 20) c = 20;
     return (uint32_t)c;
@@ -954,10 +956,10 @@ int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipSt
     uint32_t mult4 = 8;
     if (const char* e = getenv("WSNARK_MSM_LMAX_X4")) { int v = atoi(e); if (v >= 1 && v <= 64) mult4 = (uint32_t)v; }
     I.lmax = (uint32_t)((mult4 * (((I.flat ? total : n) + I.NB - 1) / I.NB) + 3) / 4);
-    if (I.flat && I.NB < (1u << 19) && total >= ((uint64_t)1 << 22)) {
-        // one SMALL bucket set under many entries (a forced narrow window): a lane per bucket would leave most of the chip
-        // idle (2^15 buckets at 2^20 pairs = 2 wavefronts per CU: measured 4.0 ms instead of 1.26 ms), so the buckets
-        // are cut until about 2^19 tasks exist
+    if (I.flat && I.NB < (1u << 19) && total >= ((uint64_t)1 << 22) && total / I.NB > 64) {
+        // one SMALL bucket set under many entries (a forced narrow window; the default width keeps 14-32 entries per
+        // bucket): a lane per bucket would leave most of the chip idle (2^15 buckets at 2^20 pairs = 2 wavefronts per CU:
+        // measured 4.0 ms instead of 1.26 ms), so the buckets are cut until about 2^19 tasks exist
         const uint32_t by_tasks = (uint32_t)((total + (1u << 19) - 1) >> 19);
         if (I.lmax > by_tasks) I.lmax = by_tasks;
     }
