@@ -141,7 +141,7 @@ int msm_g2_host(Lane& L, const void* h_scalars, const void* h_points, uint64_t n
 int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipStream_t s, uint32_t table_c = 0);
 uint32_t msm_table_rows(uint32_t table_c);
 uint32_t msm_table_window(uint64_t n);
-int msm_build_table(int which, void* d_table, uint64_t n, uint32_t table_c, hipStream_t s);   // rows 1.. from row 0 (reference format)
+int msm_build_table(int which, void* d_table, uint64_t n, uint32_t table_c, hipStream_t s);   // rows 1.. from row 0 (device domain: after msm_prepare_points)
 // mask[i] = 0 where the point is infinity (x == 0, reference format) in every given set; *skipped_host = how many
 int msm_points_mask(const Affine<Fq>* d_g1, const Affine<Fq2>* d_g2, uint64_t n, uint8_t* d_mask, uint32_t* skipped_host, hipStream_t s);
 // asynchronous form: launch enqueues the kernels and the copy of the window sums, finish waits

@@ -1373,19 +1373,21 @@ int msm_prepare_points(int which, void* d_points, uint64_t n, hipStream_t s) {
 }
 
 // ---- fixed-base window tables (resident proving keys) ----
-// table = rows x n affine points, reference format, row 0 given: row w = 2^(c w) * row 0.  One lane per point walks
-// the rows with c doublings each (XYZZ, never normalised in between) and normalises TABLE_GROUP rows with one shared
-// inversion (Montgomery's trick on the ZZZ coordinates; 1/ZZ = ZZ^2 / ZZZ^2).  Key-load time only.
+// table = rows x n affine points in the device field's domain (row 0 given, msm_prepare_points): row w = 2^(c w) * row 0.
+// One lane per point walks the rows with c doublings each (XYZZ, never normalised in between) and normalises
+// TABLE_GROUP rows with one shared inversion (Montgomery's trick on the ZZZ coordinates; 1/ZZ = ZZ^2 / ZZZ^2).
+// Key-load time only.
 static const uint32_t TABLE_GROUP = 8;
 template <class C>
-__global__ __launch_bounds__(256) void msm_table_kernel(typename C::Aff* __restrict__ table, uint64_t n, uint32_t c, uint32_t rows) {
+__global__ __launch_bounds__(256) void msm_table_kernel(typename C::AffP* __restrict__ table, uint64_t n, uint32_t c, uint32_t rows) {
     typedef typename C::Field F;
     typedef typename F::El El;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const typename C::Aff p0 = table[i];
+    const typename C::AffP p0p = table[i];
+    const typename C::Aff p0 = C::unpack_aff(p0p);
     if (C::aff_is_inf(p0)) {
-        for (uint32_t w = 1; w < rows; w++) table[(uint64_t)w * n + i] = p0;     // x == 0: infinity in every row
+        for (uint32_t w = 1; w < rows; w++) table[(uint64_t)w * n + i] = p0p;     // x == 0: infinity in every row
         return;
     }
     typename C::Pt P = C::from_affine(p0);
@@ -1405,20 +1407,22 @@ __global__ __launch_bounds__(256) void msm_table_kernel(typename C::Aff* __restr
             const El izzz = F::mul(inv, pre[k]);
             inv = F::mul(inv, pts[k].zzz);
             const El izz = F::mul(F::sqr(izzz), F::sqr(pts[k].zz));
-            table[(uint64_t)(w0 + k) * n + i] = typename C::Aff{F::mul(pts[k].x, izz), F::mul(pts[k].y, izzz)};
+            table[(uint64_t)(w0 + k) * n + i] = C::pack_aff(typename C::Aff{F::mul(pts[k].x, izz), F::mul(pts[k].y, izzz)});
         }
     }
 }
+// d_table: rows x n points, row 0 already in the device domain (msm_prepare_points)
 int msm_build_table(int which, void* d_table, uint64_t n, uint32_t tc, hipStream_t s) {
     Context* X = ctx();
     if (!X) return WS_ERR_NOINIT;
     if (!s) s = X->stream;
     const uint32_t rows = msm_table_rows(tc);
     if (n == 0 || rows < 2) return WS_OK;
+    if (!msm_uses_field29()) { set_last_error("msm: fixed-base tables are built on the radix-2^29 field"); return WS_ERR_ARG; }
     if (which == 0)
-        hipLaunchKernelGGL(msm_table_kernel<G1>, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s, (G1::Aff*)d_table, n, tc, rows);
+        hipLaunchKernelGGL(msm_table_kernel<G1R29>, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s, (G1R29::AffP*)d_table, n, tc, rows);
     else
-        hipLaunchKernelGGL(msm_table_kernel<G2>, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s, (G2::Aff*)d_table, n, tc, rows);
+        hipLaunchKernelGGL(msm_table_kernel<G2R29>, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s, (G2R29::AffP*)d_table, n, tc, rows);
     WS_HIP_CHECK(hipGetLastError());
     return WS_OK;
 }

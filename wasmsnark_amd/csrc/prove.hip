@@ -123,19 +123,19 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out) {
         K->sparseA = mode == 2 || (mode == 1 && big && (uint64_t)K->infA * 100 >= (uint64_t)nv * 15);   // saves a share of one G1 sum
         K->sparseB = mode == 2 || (mode == 1 && big && (uint64_t)K->infB * 100 >= (uint64_t)nv * 5);    // ... of a G1 and a G2 sum
     }
-    if (K->table_cw) {
+    // resident keys are kept in the device field's internal domain: no per-proof conversion pass
+    if ((rc = msm_prepare_points(0, K->pointsA.p, nv, s))) return rc;
+    if ((rc = msm_prepare_points(0, K->pointsB1.p, nv, s))) return rc;
+    if ((rc = msm_prepare_points(1, K->pointsB2.p, nv, s))) return rc;
+    if ((rc = msm_prepare_points(0, K->pointsC.p, nv, s))) return rc;
+    if ((rc = msm_prepare_points(0, K->pointsH.p, dom, s))) return rc;
+    if (K->table_cw) {      // rows 1.. of the tables, from row 0, in that domain
         if ((rc = msm_build_table(0, K->pointsA.p, nv, K->table_cw, s))) return rc;
         if ((rc = msm_build_table(0, K->pointsB1.p, nv, K->table_cw, s))) return rc;
         if ((rc = msm_build_table(1, K->pointsB2.p, nv, K->table_cw, s))) return rc;
         if ((rc = msm_build_table(0, K->pointsC.p, nv, K->table_cw, s))) return rc;
         if ((rc = msm_build_table(0, K->pointsH.p, dom, K->table_ch, s))) return rc;
     }
-    // resident keys are kept in the device field's internal domain: no per-proof conversion pass
-    if ((rc = msm_prepare_points(0, K->pointsA.p, nv * rowsW, s))) return rc;
-    if ((rc = msm_prepare_points(0, K->pointsB1.p, nv * rowsW, s))) return rc;
-    if ((rc = msm_prepare_points(1, K->pointsB2.p, nv * rowsW, s))) return rc;
-    if ((rc = msm_prepare_points(0, K->pointsC.p, nv * rowsW, s))) return rc;
-    if ((rc = msm_prepare_points(0, K->pointsH.p, dom * rowsH, s))) return rc;
     WS_HIP_CHECK(hipStreamSynchronize(s));
     *out = K.release();
     return WS_OK;
