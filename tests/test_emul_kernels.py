@@ -50,6 +50,23 @@ def test_fft_vs_oracle_multi_pass(bn, orc, bits):
         assert bn.ifft(x, odd) == orc.fft(x, n, odd, inverse=True), (bits, odd)
 
 
+@pytest.mark.parametrize("bits", [4, 9, 10, 12])
+def test_fft_extreme_values_keep_the_lazy_bounds(bn, orc, bits):
+    """The butterflies keep their sums uncorrected (values in [0, 4p) in LDS, folded back from [0, 16p)): vectors
+    made of the largest residues -- r - 1 everywhere, r - 1 / 0 / 1 patterns -- drive every sum to its bound."""
+    n = 1 << bits
+    top = (orc.R - 1).to_bytes(32, "little")
+    pats = [top * n,
+            b"".join(top if (i & 1) else (0).to_bytes(32, "little") for i in range(n)),
+            b"".join((orc.R - 1 - (i % 3)).to_bytes(32, "little") for i in range(n)),
+            b"".join(top if i < n // 2 else (1).to_bytes(32, "little") for i in range(n))]
+    for plain in pats:
+        for x in (plain, orc.to_mont_n(plain)):      # the same bytes read as Montgomery forms, and their Montgomery images
+            for odd in (0, 1):
+                assert bn.fft(x, odd) == orc.fft(x, n, odd), (bits, odd)
+                assert bn.ifft(x, odd) == orc.fft(x, n, odd, inverse=True), (bits, odd)
+
+
 def test_fft_three_pass(bn, orc):
     n = 1 << 17
     rnd = random.Random(17)

@@ -86,6 +86,21 @@ def test_ntt_vs_oracle(bn, orc, bits):
         assert bn.ifft(x, odd) == orc.fft(x, n, odd, inverse=True)
 
 
+@pytest.mark.parametrize("bits", [5, 10, 13, 17])
+def test_ntt_extreme_values_vs_oracle(bn, orc, bits):
+    """Vectors of the largest residues (r - 1 everywhere, r - 1 / 0 / 1 patterns): the butterflies keep sums
+    uncorrected in [0, 4p) and fold them back from [0, 16p), so these inputs drive every lazy bound to its limit."""
+    n = 1 << bits
+    top = (orc.R - 1).to_bytes(32, "little")
+    pats = [top * n,
+            b"".join(top if (i & 1) else (0).to_bytes(32, "little") for i in range(n)),
+            b"".join(top if i < n // 2 else (1).to_bytes(32, "little") for i in range(n))]
+    for x in pats:
+        for odd in (0, 1):
+            assert bn.fft(x, odd) == orc.fft(x, n, odd), (bits, odd)
+            assert bn.ifft(x, odd) == orc.fft(x, n, odd, inverse=True), (bits, odd)
+
+
 def test_montgomery_maps_vs_oracle(bn, orc):
     x = rand_fr(random.Random(9), 5000)
     xr = b"".join((int.from_bytes(x[i:i + 32], "little") % orc.R).to_bytes(32, "little") for i in range(0, len(x), 32))

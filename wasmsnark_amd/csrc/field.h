@@ -188,6 +188,12 @@ struct Field {
     WS_HD static bool is_zero_wide(const Fe& a) { return is_zero(a); }
     WS_HD static Fe narrow(const Fe& a) { return a; }
     WS_HD static Fe sub_weak4(const Fe& a, const Fe& b) { return sub(a, b); }
+    // (the lazily reduced butterfly sums of field29.h: strict here)
+    WS_HD static Fe add_nr(const Fe& a, const Fe& b) { return add(a, b); }
+    WS_HD static Fe sub_weak8(const Fe& a, const Fe& b) { return sub(a, b); }
+    WS_HD static Fe fold8(const Fe& a) { return a; }
+    WS_HD static Fe fold16(const Fe& a) { return a; }
+    WS_HD static Fe fold4to2(const Fe& a) { return a; }
     WS_HD static Fe neg_weak(const Fe& a) { return neg(a); }
     WS_HD static Fe neg_weak4(const Fe& a) { return neg(a); }
 

@@ -291,6 +291,39 @@ struct Field29 {
     // wide (< 8p) -> [0, 2p)
     WS_HD static F29 narrow(const F29& a) { return cond_sub_kp(cond_sub_kp(a, 4), 2); }
 
+    // ---- lazily reduced sums for the NTT butterflies: LDS-resident values live in [0, 4p) (tight limbs), sums are
+    // formed WITHOUT a correction pass and folded back only where the bound would pass 16p; differences go straight
+    // into a product ((a * b + m * p) / 2^261 < 1.2p for a < 16p, b < 2p).  Half the correction passes of add / sub. ----
+    // a + b, carries propagated, no reduction: the bound just adds up
+    WS_HD static F29 add_nr(const F29& a, const F29& b) {
+        F29 s;
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t t = a.v[i] + b.v[i] + c;
+            s.v[i] = t & WS_M29;
+            c = t >> 29;
+        }
+        s.v[8] = a.v[8] + b.v[8] + c;
+        return s;
+    }
+    // a - b + 8p for a, b < 8p: in (0, 16p), tight limbs
+    WS_HD static F29 sub_weak8(const F29& a, const F29& b) {
+        F29 d;
+        int32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int32_t t = (int32_t)a.v[i] - (int32_t)b.v[i] + (int32_t)kp_limb(8, i) + c;
+            d.v[i] = (uint32_t)t & WS_M29;
+            c = t >> 29;
+        }
+        d.v[8] = (uint32_t)((int32_t)a.v[8] - (int32_t)b.v[8] + (int32_t)kp_limb(8, 8) + c);
+        return d;
+    }
+    WS_HD static F29 fold8(const F29& a) { return cond_sub_kp(a, 4); }                        // [0, 8p)  -> [0, 4p)
+    WS_HD static F29 fold16(const F29& a) { return cond_sub_kp(cond_sub_kp(a, 8), 4); }       // [0, 16p) -> [0, 4p)
+    WS_HD static F29 fold4to2(const F29& a) { return cond_sub_2p(a); }                        // [0, 4p)  -> [0, 2p)
+
     WS_HD static F29 neg(const F29& a) {
         uint32_t o = 0;
 #pragma unroll

@@ -203,17 +203,19 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
             const uint32_t i0 = (j0 << log_T) + t;
             El x0 = tile.get(i0), x1 = tile.get(i0 + q), x2 = tile.get(i0 + 2 * q), x3 = tile.get(i0 + 3 * q);
             // stage hs: (j0, j0+h) with w_{2h}^{jl}, (j0+h/2, j0+3h/2) with w_{2h}^{jl+h/2}
-            El s0 = F::add(x0, x2), d0 = F::mul(F::sub_weak(x0, x2), SmallTw<F>::get(A, jl << sh_hi));
-            El s1 = F::add(x1, x3), d1 = F::mul(F::sub_weak(x1, x3), SmallTw<F>::get(A, (jl + (1u << (hs - 1))) << sh_hi));
+            // (radix-2^29 field: tile values live in [0, 4p); sums are not corrected, only y0 -- and y1 of the last pair
+            // of stages -- are folded back from [0, 16p); differences go into products uncorrected: field29.h add_nr)
+            El s0 = F::add_nr(x0, x2), d0 = F::mul(F::sub_weak4(x0, x2), SmallTw<F>::get(A, jl << sh_hi));
+            El s1 = F::add_nr(x1, x3), d1 = F::mul(F::sub_weak4(x1, x3), SmallTw<F>::get(A, (jl + (1u << (hs - 1))) << sh_hi));
             // stage hs-1: (j0, j0+h/2) and (j0+h, j0+3h/2), both with w_{h}^{jl}
-            El y0 = F::add(s0, s1), y2 = F::add(d0, d1), y1, y3;
+            El y0 = F::fold16(F::add_nr(s0, s1)), y2 = F::add_nr(d0, d1), y1, y3;
             if (hs > 1) {
                 const El w = SmallTw<F>::get(A, jl << (sh_hi + 1));
-                y1 = F::mul(F::sub_weak(s0, s1), w);
+                y1 = F::mul(F::sub_weak8(s0, s1), w);
                 y3 = F::mul(F::sub_weak(d0, d1), w);
             } else {
-                y1 = F::sub(s0, s1);
-                y3 = F::sub(d0, d1);
+                y1 = F::fold16(F::sub_weak8(s0, s1));
+                y3 = F::sub_weak(d0, d1);
             }
             tile.put(i0, y0);
             tile.put(i0 + q, y1);
@@ -227,8 +229,8 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
             const uint32_t t = idx & (T - 1), bb = idx >> log_T;
             const uint32_t i0 = ((bb << 1) << log_T) + t, i1 = i0 + T;
             El u = tile.get(i0), v = tile.get(i1);
-            tile.put(i0, F::add(u, v));
-            tile.put(i1, F::sub(u, v));
+            tile.put(i0, F::fold8(F::add_nr(u, v)));
+            tile.put(i1, F::fold8(F::sub_weak4(u, v)));
         }
         __syncthreads();
     }
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
             Fe o;
             const uint64_t at = ((uint64_t)kk << log_rest) + revmid + a0 + t;
             if (F::kInternalDomain && A.out_plain) {
-                v = F::canonical(v);            // already in the reference domain (folded upstream)
+                v = F::canonical(F::fold4to2(v));   // already in the reference domain (folded upstream)
             } else if (F::kInternalDomain) {
                 // out_scale = 1 or 1/n in the REFERENCE Montgomery form: as an internal-domain operand it is
                 // (2^-5) or (2^-5 / n), so this one product also converts back; then canonicalise
