@@ -100,9 +100,14 @@ static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; 
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     p->multiProcessorCount = 4; strcpy(p->name, "cpu-emulator"); strcpy(p->gcnArchName, "emul"); return hipSuccess;
 }
-static inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(64, (n + 63) & ~(size_t)63); return *p ? hipSuccess : hipErrorOutOfMemory; }
+// WSNARK_EMUL_MAX_ALLOC (bytes): larger requests fail like a full device would (tests of the out-of-memory paths)
+static inline hipError_t hipMalloc(void** p, size_t n) {
+    if (const char* e = getenv("WSNARK_EMUL_MAX_ALLOC")) { if (n > (size_t)strtoull(e, nullptr, 10)) { *p = nullptr; return hipErrorOutOfMemory; } }
+    *p = aligned_alloc(64, (n + 63) & ~(size_t)63);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
-static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = aligned_alloc(64, (n + 63) & ~(size_t)63); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }

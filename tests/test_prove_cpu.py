@@ -107,6 +107,20 @@ def test_emulated_prove_key_table_modes(monkeypatch, name, mode):
         assert bn.groth16GenProof(wit, key, r=bytes.fromhex(c["r"]), s=bytes.fromhex(c["s"])) == c["proof"]
 
 
+def test_key_falls_back_to_plain_sections_when_a_table_does_not_fit(monkeypatch):
+    """A table allocation the device refuses (emulator: WSNARK_EMUL_MAX_ALLOC) must not fail the load: the key keeps
+    its plain sections (one row) and proves the same."""
+    bn = emul_bn128()
+    pkey, wit, _ = _key("t6")
+    assert bn.load_key(pkey).table["rows_w"] > 1
+    monkeypatch.setenv("WSNARK_EMUL_MAX_ALLOC", str(96 * 1024))      # B2 table: 66 x 128 B x 43 rows = 363 KB; plain 8 KB
+    key = bn.load_key(pkey)
+    assert key.table["rows_w"] == 1 and key.table["c_w"] == 0
+    monkeypatch.delenv("WSNARK_EMUL_MAX_ALLOC")
+    for c in load_golden("proofs.json")["t6"]:
+        assert bn.groth16GenProof(wit, key, r=bytes.fromhex(c["r"]), s=bytes.fromhex(c["s"])) == c["proof"]
+
+
 def test_emulated_mul_base_matches_oracle(orc):
     bn = emul_bn128()
     sc = b"".join(v.to_bytes(32, "little") for v in (0, 1, 2, 12345, orc.R - 1, orc.R, (1 << 256) - 1))

@@ -86,7 +86,6 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out) {
             }
         }
     }
-    const uint64_t rowsW = msm_table_rows(K->table_cw), rowsH = msm_table_rows(K->table_ch);
     int rc = pols_to_csr(S.polsA, (size_t)S.lenA, nv, dom, &K->polsA, &used, s);
     if (rc) return rc;
     rc = pols_to_csr(S.polsB, (size_t)S.lenB, nv, dom, &K->polsB, &used, s);
@@ -94,18 +93,31 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out) {
     struct Sec { DevBuf* d; const uint8_t* src; uint64_t bytes; } secs[5] = {
         {&K->pointsA, S.A, (uint64_t)nv * 64}, {&K->pointsB1, S.B1, (uint64_t)nv * 64}, {&K->pointsB2, S.B2, (uint64_t)nv * 128},
         {&K->pointsC, S.Cpts, nC * 64}, {&K->pointsH, S.H, (uint64_t)dom * 64}};
-    for (auto& sc : secs) {
-        if (sc.d == &K->pointsC) {
-            // C holds points for signals nPublic+1.. only (src/bn128.js:620 slices the scalars instead).
-            // Resident copy: padded in front with nPublic+1 points at infinity (x == 0), so that the C sum
-            // uses the SAME scalar vector -- and the same digit/sort plan -- as A, B1 and B2.
-            WS_HIP_CHECK(sc.d->alloc((size_t)nv * 64 * rowsW));
-            WS_HIP_CHECK(hipMemsetAsync(sc.d->p, 0, (size_t)(np + 1) * 64, s));
-            if (sc.bytes && (rc = upload_staged((uint8_t*)sc.d->p + (size_t)(np + 1) * 64, sc.src, (size_t)sc.bytes, s))) return rc;
-            continue;
+    // the five buffers: rows x section.  Should the device refuse a table after all (fragmentation, another process), the
+    // key falls back to plain sections instead of failing
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const uint64_t rowsW = msm_table_rows(K->table_cw), rowsH = msm_table_rows(K->table_ch);
+        hipError_t err = hipSuccess;
+        for (auto& sc : secs) {
+            // C holds points for signals nPublic+1.. only (src/bn128.js:620 slices the scalars instead).  Resident copy:
+            // padded in front with nPublic+1 points at infinity (x == 0), so that the C sum uses the SAME scalar vector --
+            // and the same digit/sort plan -- as A, B1 and B2.
+            const uint64_t row_bytes = sc.d == &K->pointsC ? (uint64_t)nv * 64 : sc.bytes;
+            if ((err = sc.d->alloc((size_t)(row_bytes * (sc.d == &K->pointsH ? rowsH : rowsW)))) != hipSuccess) break;
         }
-        WS_HIP_CHECK(sc.d->alloc((size_t)sc.bytes * (sc.d == &K->pointsH ? rowsH : rowsW)));
-        if (sc.bytes && (rc = upload_staged(sc.d->p, sc.src, (size_t)sc.bytes, s))) return rc;
+        if (err == hipSuccess) break;
+        (void)hipGetLastError();
+        if (!K->table_cw) { set_last_error("proving key: device allocation of the point sections failed"); return WS_ERR_HIP; }
+        for (auto& sc : secs) sc.d->release();
+        K->table_cw = K->table_ch = 0;
+    }
+    for (auto& sc : secs) {
+        size_t front = 0;
+        if (sc.d == &K->pointsC) {
+            front = (size_t)(np + 1) * 64;
+            WS_HIP_CHECK(hipMemsetAsync(sc.d->p, 0, front, s));
+        }
+        if (sc.bytes && (rc = upload_staged((uint8_t*)sc.d->p + front, sc.src, (size_t)sc.bytes, s))) return rc;
     }
     // Variables that do not occur in matrix A (resp. B) have A (resp. B1 = B2) = infinity -- common: real circuits put
     // far fewer terms on the B side.  Their pairs cost a lane slot each in those sums, so when there are enough of
