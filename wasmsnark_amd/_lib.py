@@ -43,6 +43,16 @@ class Lib:
                 "libwsnark.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
         self.path = path
+        # One HIP runtime per process.  The Python host side keeps device buffers in PyTorch tensors (and uses
+        # torch.distributed for N > 1), and PyTorch-ROCm bundles its own libamdhip64: whichever library is loaded FIRST
+        # decides which runtime the soname resolves to.  If this library came first, its /opt/rocm runtime and PyTorch's
+        # bundled one would both open the device and the second to initialise fails ("no ROCm-capable device is
+        # detected" -- seen on the MI355X when build() loaded the library before smoke() imported torch).  So PyTorch's
+        # goes in first whenever PyTorch is installed; hosts without it (the Node addon) use /opt/rocm's alone.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # noqa: BLE001
+            pass
         self.c = C.CDLL(path)
         for s in SYMBOLS:
             getattr(self.c, s)  # AttributeError if the ABI is incomplete
