@@ -185,3 +185,34 @@ def check_group(bn, orc, g, impl):
     assert st_curve(bn, g, impl, 7, P, Qa) == [orc.g_affine(g, x) for x in P]
     # p + q + q with p = -q: the first lazy addition lands on infinity, the second restarts from the affine point
     assert st_curve(bn, g, impl, 6, [orc.g_neg(g, y) for y in Qa], Qa) == Qa
+
+
+def degenerate_key_and_witness(orc, pkey, wit):
+    """The t6 key with degenerate point sections (A, B1, B2, hExps): eight copies of one point, P / -P neighbours, points
+    at infinity (x = 0) -- and a witness with EQUAL scalars on the equal points, so that equal digits of equal points meet
+    in one bucket (the accumulation's doubling case, and sums that pass through infinity)."""
+    import struct
+    key = bytearray(pkey)
+    nv, npub, dom, pA_, pB_, pA, pB1, pB2, pC, pH = struct.unpack("<10I", pkey[:40])
+    Q = orc.Q
+
+    def neg_y(pt, fsz):               # (x, y) -> (x, -y) in the key's Montgomery encoding; fsz = 32 (G1) or 64 (G2: two components)
+        out = bytearray(pt)
+        for o in range(fsz, 2 * fsz, 32):
+            y = int.from_bytes(pt[o:o + 32], "little")
+            out[o:o + 32] = ((Q - y) % Q).to_bytes(32, "little")
+        return bytes(out)
+
+    for off, esz, n in ((pA, 64, nv), (pB1, 64, nv), (pB2, 128, nv), (pH, 64, dom)):
+        P = bytes(key[off + 5 * esz: off + 6 * esz])
+        for i in range(6, 14):                                   # eight copies of point 5
+            key[off + i * esz: off + (i + 1) * esz] = P
+        for i in range(14, 20, 2):                               # P, -P, P, -P, ...
+            key[off + i * esz: off + (i + 1) * esz] = P
+            key[off + (i + 1) * esz: off + (i + 2) * esz] = neg_y(P, esz // 2)
+        for i in range(20, 24):                                  # infinity: x == 0 whatever y is
+            key[off + i * esz: off + i * esz + esz // 2] = bytes(esz // 2)
+    w = bytearray(wit)
+    for i in range(6, 20):
+        w[i * 32:(i + 1) * 32] = w[5 * 32:6 * 32]
+    return bytes(key), bytes(w)

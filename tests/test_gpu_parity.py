@@ -556,6 +556,23 @@ def test_key_tables_and_plain_sections_give_the_same_proofs_on_gpu(bn, monkeypat
             monkeypatch.delenv(k)
 
 
+@pytest.mark.parametrize("mode", ["table", "plain"])
+def test_degenerate_key_points_against_the_oracle_prover_on_gpu(bn, orc, monkeypatch, mode):
+    """Equal points with equal scalars (doubling inside a bucket), P / -P neighbours, points at infinity in the A, B1, B2
+    and hExps sections of the t6 key: the GPU prover against the oracle's restatement of the reference prover, on the
+    fixed-base table key and on plain sections (tests/primitives_common.py: degenerate_key_and_witness)."""
+    from primitives_common import degenerate_key_and_witness
+    if mode == "plain":
+        monkeypatch.setenv("WSNARK_KEY_TABLE", "0")
+    rd = lambda ext: open(os.path.join(GOLDEN, "keys", "t6" + ext), "rb").read()
+    key, w = degenerate_key_and_witness(orc, rd(".pkey.bin"), rd(".witness.bin"))
+    k = bn.load_key(key)
+    assert (k.table["rows_w"] > 1) == (mode == "table")
+    for r, s in ((bytes(32), bytes(32)), (bytes(range(1, 33)), bytes(range(101, 133)))):
+        assert bn.groth16GenProof(w, k, r=r, s=s) == orc.groth16_prove(w, key, r, s, workers=8)
+    k.free()
+
+
 def test_ntt_2p25_four_pass_roundtrip_and_linearity(bn):
     """2^25 needs four digit passes (middle-digit reversal): round trip, and F(x + y) == F(x) + F(y)
     checked through the evaluation at one point: sum_k F(x)[k] == n * x[0] (DFT of the constant-one vector)."""

@@ -107,6 +107,24 @@ def test_emulated_prove_key_table_modes(monkeypatch, name, mode):
         assert bn.groth16GenProof(wit, key, r=bytes.fromhex(c["r"]), s=bytes.fromhex(c["s"])) == c["proof"]
 
 
+@pytest.mark.parametrize("mode", ["table", "plain"])
+def test_degenerate_key_points_against_the_oracle_prover(orc, monkeypatch, mode):
+    """The prover is a pure function of (witness, key, r, s) -- the key's points need not come from a setup.  Here the
+    point sections of the t6 key are made degenerate: runs of EQUAL points (the accumulation's doubling case: equal
+    digits of equal points meet in one bucket), P / -P neighbours (the sum that passes through infinity) and points at
+    infinity (x = 0), in A, B1, B2 and hExps.  The oracle's restatement of the reference prover is the judge, for the
+    fixed-base table key and for the plain sections."""
+    from primitives_common import degenerate_key_and_witness
+    if mode == "plain":
+        monkeypatch.setenv("WSNARK_KEY_TABLE", "0")
+    key, w = degenerate_key_and_witness(orc, *_key("t6")[:2])
+    bn = emul_bn128()
+    k = bn.load_key(key)
+    assert (k.table["rows_w"] > 1) == (mode == "table")
+    for r, s in ((bytes(32), bytes(32)), (bytes(range(1, 33)), bytes(range(101, 133)))):
+        assert bn.groth16GenProof(w, k, r=r, s=s) == orc.groth16_prove(w, key, r, s, workers=8)
+
+
 def test_key_falls_back_to_plain_sections_when_a_table_does_not_fit(monkeypatch):
     """A table allocation the device refuses (emulator: WSNARK_EMUL_MAX_ALLOC) must not fail the load: the key keeps
     its plain sections (one row) and proves the same."""
