@@ -213,6 +213,29 @@ int wsnark_groth16_prove_finish(wsnark_pkey_t* handle, const void* partials, uin
 int wsnark_g1_mul_base_batch(const void* base64, const void* scalars, uint64_t n, void* out_affine);
 int wsnark_g2_mul_base_batch(const void* base128, const void* scalars, uint64_t n, void* out_affine);
 
+/* A whole synthetic circuit + trusted setup from KNOWN toxic waste, on the host (csrc/synth.hip): the multiplication-chain
+ * R1CS SURVEY.md section 8d C4 specifies (style 0 = 1-3 non-zeros per COLUMN of A and B, every variable present; style 1 =
+ * 1-2 terms per ROW, ~40 % of the variables absent from A resp. B), its witness, its polsA / polsB record streams
+ * (tools/buildpkey.js:79-89), the discrete logarithm of every key point (feed them to wsnark_g{1,2}_mul_base_batch) and
+ * the discrete logarithms of the proof for given r, s -- the closed form the full-size parity tests compare against.
+ * key_scalars group 1: alfa1, beta1, delta1, A[nVars], B1[nVars], C[nVars-nPublic-1], hExps[domain], IC[nPublic+1];
+ * group 2: beta2, delta2, gamma2, B2[nVars]; 32-byte plain little-endian each.  expected: a | b | c, 32 B plain each. */
+typedef struct wsnark_synth wsnark_synth_t;
+typedef struct {
+    uint32_t n_vars, n_public, domain;
+    uint64_t nnz_a, nnz_b, absent_a, absent_b;   /* non-zeros; variables that never occur in A resp. B */
+    uint64_t pols_a_len, pols_b_len;             /* bytes of the record streams */
+    uint64_t n_g1_scalars, n_g2_scalars;
+} wsnark_synth_info_t;
+int wsnark_synth_new(uint32_t log_domain, uint32_t n_public, uint64_t circuit_seed, uint64_t setup_seed, int style,
+                     wsnark_synth_t** out);
+void wsnark_synth_free(wsnark_synth_t* h);
+int wsnark_synth_info(const wsnark_synth_t* h, wsnark_synth_info_t* out);
+int wsnark_synth_witness(const wsnark_synth_t* h, void* out_plain);
+int wsnark_synth_pols(const wsnark_synth_t* h, int which, void* out, uint64_t cap);
+int wsnark_synth_key_scalars(const wsnark_synth_t* h, int group, void* out);
+int wsnark_synth_expected(const wsnark_synth_t* h, const void* r32, const void* s32, void* out96);
+
 /* ---- device self-test hooks (tests/test_gpu_primitives.py): NO reference counterpart ----
  * The reference tests its field and group primitives directly (test/f1.js:296-400, test/bn128.js:84-185); here they
  * are __device__ code reached only through whole kernels, so these two entry points run ONE LANE PER VECTOR through

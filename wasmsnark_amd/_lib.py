@@ -24,6 +24,8 @@ SYMBOLS = [
     "wsnark_groth16_prove", "wsnark_groth16_prove_dev", "wsnark_pkey_load_sections", "wsnark_last_blinding", "wsnark_groth16_verify",
     "wsnark_groth16_prove_partial", "wsnark_groth16_prove_partial_dev", "wsnark_groth16_prove_finish",
     "wsnark_g1_mul_base_batch", "wsnark_g2_mul_base_batch",
+    "wsnark_synth_new", "wsnark_synth_free", "wsnark_synth_info", "wsnark_synth_witness", "wsnark_synth_pols",
+    "wsnark_synth_key_scalars", "wsnark_synth_expected",
     "wsnark_selftest_field", "wsnark_selftest_curve",
     "wsnark_timing_enable", "wsnark_timing_reset", "wsnark_timing_report",
 ]
@@ -99,6 +101,14 @@ class Lib:
         c.wsnark_groth16_prove_finish.argtypes = [vp, vp, u64, vp, vp, vp]
         c.wsnark_g1_mul_base_batch.argtypes = [vp, vp, u64, vp]
         c.wsnark_g2_mul_base_batch.argtypes = [vp, vp, u64, vp]
+        c.wsnark_synth_new.argtypes = [u32, u32, u64, u64, C.c_int, C.POINTER(vp)]
+        c.wsnark_synth_free.argtypes = [vp]
+        c.wsnark_synth_free.restype = None
+        c.wsnark_synth_info.argtypes = [vp, vp]
+        c.wsnark_synth_witness.argtypes = [vp, vp]
+        c.wsnark_synth_pols.argtypes = [vp, C.c_int, vp, u64]
+        c.wsnark_synth_key_scalars.argtypes = [vp, C.c_int, vp]
+        c.wsnark_synth_expected.argtypes = [vp, vp, vp, vp]
         self.initialised = False
 
     def check(self, rc):

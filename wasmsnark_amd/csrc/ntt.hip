@@ -18,6 +18,8 @@
 //
 // HBM traffic: np passes x (32 B read + 32 B write) per element, np = 3 at 2^22.
 // Arithmetic is exact, so outputs are bit-identical to the reference's.
+#include <atomic>
+
 #include "internal.h"
 #include "field29.h"
 
@@ -317,6 +319,11 @@ struct NttPlan {
     DevBuf cs_lo_ref, cs_hi_ref;              // the same in the reference Montgomery form (calch.hip)
     DevBuf tw_lo_ref[2], tw_hi_ref[2];        // w_n^e two-level in the reference form (dist_scale: four-step inter-digit twiddle)
     DevBuf tw_full[2][4][3];                  // [dir][pass][fold_in]: full per-pass twiddles (radix-2^29, np >= 2); fold_in 2 = x 2^10
+    // The full tables are generated lazily, by whichever caller needs one first.  Several lanes (host threads, streams)
+    // share one plan, so a table is built under tw_mu on the context's utility queue and the builder WAITS for the
+    // kernel before publishing the flag: a consumer on any stream then finds a finished table (no cross-stream event).
+    std::mutex tw_mu;
+    bool tw_ready[2][4][3] = {};
     DevBuf cs_lo_int;                         // coset factors' low table in the internal form (x 2^5 once): CALC_H epilogue
     Fe n_inv;                                 // reference Montgomery form of 1/n
 };
@@ -515,18 +522,23 @@ int ntt_run(Lane& L, const Fe* d_src, const Fe* d_in2, Fe* d_data, const Fe* com
             if (!last) {
                 DevBuf& tb = P->tw_full[dir][p][fold_in];
                 const uint64_t count = (uint64_t)1 << (A.log_L + A.log_S);
-                if (!tb.p) {
-                    // factor (plain field element): 2^5 (in; 2^10 after a product on load), 2^-5 (out), times 1/n on the inverse's out pass
-                    Fe f = Fr::one();                                           // Montgomery-R form of 1
-                    const Fe m32 = Fr::to_mont(Fe{{32, 0, 0, 0}});
-                    for (int k = 0; k < fold_in; k++) f = Fr::mul(f, m32);
-                    if (fold_out) { f = Fr::mul(f, Fr::inv(m32)); if (inverse) f = Fr::mul(f, P->n_inv); }
-                    f = Fr::mul(f, m32);                                        // -> internal form (x 2^5)
-                    WS_HIP_CHECK(tb.alloc(count * sizeof(Fe)));
-                    hipLaunchKernelGGL(ntt_build_twiddles<Fr29>, dim3(ceil_div_u64(count, 256)), dim3(256), 0, s,
-                                       P->tw_lo[dir].as<Fe>(), P->tw_hi[dir].as<Fe>(), (uint32_t)P->h,
-                                       (uint32_t)(bits - A.log_L - A.log_S), A.log_S, count, f, tb.as<Fe>());
-                    WS_HIP_CHECK(hipGetLastError());
+                {
+                    std::lock_guard<std::mutex> tw_lk(P->tw_mu);
+                    if (!P->tw_ready[dir][p][fold_in]) {
+                        // factor (plain field element): 2^5 (in; 2^10 after a product on load), 2^-5 (out), times 1/n on the inverse's out pass
+                        Fe f = Fr::one();                                           // Montgomery-R form of 1
+                        const Fe m32 = Fr::to_mont(Fe{{32, 0, 0, 0}});
+                        for (int k = 0; k < fold_in; k++) f = Fr::mul(f, m32);
+                        if (fold_out) { f = Fr::mul(f, Fr::inv(m32)); if (inverse) f = Fr::mul(f, P->n_inv); }
+                        f = Fr::mul(f, m32);                                        // -> internal form (x 2^5)
+                        WS_HIP_CHECK(tb.alloc(count * sizeof(Fe)));
+                        hipLaunchKernelGGL(ntt_build_twiddles<Fr29>, dim3(ceil_div_u64(count, 256)), dim3(256), 0, C->stream,
+                                           P->tw_lo[dir].as<Fe>(), P->tw_hi[dir].as<Fe>(), (uint32_t)P->h,
+                                           (uint32_t)(bits - A.log_L - A.log_S), A.log_S, count, f, tb.as<Fe>());
+                        WS_HIP_CHECK(hipGetLastError());
+                        WS_HIP_CHECK(hipStreamSynchronize(C->stream));
+                        P->tw_ready[dir][p][fold_in] = true;
+                    }
                 }
                 A.tw_full = tb.as<Fe>();
             }
@@ -549,7 +561,7 @@ int ntt_run(Lane& L, const Fe* d_src, const Fe* d_in2, Fe* d_data, const Fe* com
         C->timer.begin(last ? "ntt_pass_last" : "ntt_pass", s);
         if (P->field29) {
             const size_t smem = elems * LdsTile<Fr29>::kBytes;
-            static bool attr_set = false;
+            static std::atomic<bool> attr_set{false};   // (two lanes may both set it once: same value)
             if (!attr_set) {   // 2048-element tiles need 72 KiB of dynamic LDS (> the 64 KiB default cap)
                 WS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<Fr29>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * 36));

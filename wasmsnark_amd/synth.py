@@ -275,6 +275,147 @@ def expected_proof(circ, S, r32, s32, mul_base):
     return {"pi_a": pa, "pi_b": pb, "pi_c": pc}
 
 
+class _SynthInfo(__import__("ctypes").Structure):   # wsnark_synth_info_t
+    import ctypes as _C
+    _fields_ = [("n_vars", _C.c_uint32), ("n_public", _C.c_uint32), ("domain", _C.c_uint32),
+                ("nnz_a", _C.c_uint64), ("nnz_b", _C.c_uint64), ("absent_a", _C.c_uint64), ("absent_b", _C.c_uint64),
+                ("pols_a_len", _C.c_uint64), ("pols_b_len", _C.c_uint64), ("n_g1_scalars", _C.c_uint64), ("n_g2_scalars", _C.c_uint64)]
+
+
+class NativeCircuit:
+    """The same construction as make_circuit + setup + build_sections + expected_proof, done by the library's host-side
+    generator (csrc/synth.hip, wsnark_synth_*): seconds instead of minutes at 2^22-2^24, which is what lets BASELINE
+    config 5's size run under the GPU tests.  `lib` is the loaded C ABI (wasmsnark_amd._lib.Lib; the group scalar
+    multiplications go to its wsnark_g{1,2}_mul_base_batch).  Different random stream than the Python generator: the
+    circuits are not the same instances, only the same family (tests/test_synth_native.py pins this generator against
+    the oracle's prover and the native verifier)."""
+
+    def __init__(self, lib, log_domain, n_public=2, seed=1, setup_seed=None, style="columns"):
+        import ctypes as C
+        self._lib, self._h = lib, C.c_void_p()
+        st = {"columns": 0, "rows": 1}[style]
+        lib.check(lib.c.wsnark_synth_new(log_domain, n_public, seed, seed + 1 if setup_seed is None else setup_seed, st, C.byref(self._h)))
+        inf = _SynthInfo()
+        lib.check(lib.c.wsnark_synth_info(self._h, C.byref(inf)))
+        self.info = inf
+        self.n_vars, self.n_public, self.domain = inf.n_vars, inf.n_public, inf.domain
+        self.nnz = inf.nnz_a + inf.nnz_b
+        self.absent = (inf.absent_a, inf.absent_b)
+        self.style = style
+        self._wit = None
+
+    def free(self):
+        if self._h:
+            self._lib.c.wsnark_synth_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+    @staticmethod
+    def _cbuf(ba, off=0, n=None):
+        import ctypes as C
+        n = len(ba) - off if n is None else n
+        return (C.c_uint8 * max(n, 1)).from_buffer(ba, off) if n else None
+
+    def witness_bin(self):
+        if self._wit is None:
+            out = bytearray(self.n_vars * 32)
+            self._lib.check(self._lib.c.wsnark_synth_witness(self._h, self._cbuf(out)))
+            self._wit = bytes(out)
+        return self._wit
+
+    def public_signals(self):
+        w = self.witness_bin()
+        return [str(int.from_bytes(w[32 * i:32 * i + 32], "little")) for i in range(1, self.n_public + 1)]
+
+    def _mul(self, g, scalars, off, n, base=None):
+        """n points k_i * generator for the scalars at byte offset `off`, as a bytearray (no intermediate copies)."""
+        from .bn128 import G1_GEN, G2_GEN
+        sz = 64 if g == 1 else 128
+        out = bytearray(n * sz)
+        if n:
+            fn = self._lib.c.wsnark_g1_mul_base_batch if g == 1 else self._lib.c.wsnark_g2_mul_base_batch
+            self._lib.check(fn(G1_GEN if g == 1 else G2_GEN, self._cbuf(scalars, off, n * 32), n, self._cbuf(out)))
+        return out
+
+    def build_sections(self, mul_base=None):
+        """(sections dict for Bn128.load_key(sections=...), (IC points, gamma2 bytes)); `mul_base` is ignored (the
+        library's own fixed-base kernel is used), the parameter only mirrors synth.build_sections."""
+        inf, nv, npub, dom = self.info, self.n_vars, self.n_public, self.domain
+        s1 = bytearray(inf.n_g1_scalars * 32)
+        s2 = bytearray(inf.n_g2_scalars * 32)
+        self._lib.check(self._lib.c.wsnark_synth_key_scalars(self._h, 1, self._cbuf(s1)))
+        self._lib.check(self._lib.c.wsnark_synth_key_scalars(self._h, 2, self._cbuf(s2)))
+        nC = nv - npub - 1
+        o = 0
+        fixed1 = self._mul(1, s1, 0, 3); o += 3
+        ptsA = self._mul(1, s1, o * 32, nv); o += nv
+        ptsB1 = self._mul(1, s1, o * 32, nv); o += nv
+        ptsC = self._mul(1, s1, o * 32, nC); o += nC
+        ptsH = self._mul(1, s1, o * 32, dom); o += dom
+        ic = self._mul(1, s1, o * 32, npub + 1)
+        fixed2 = self._mul(2, s2, 0, 3)
+        ptsB2 = self._mul(2, s2, 96, nv)
+        polsA, polsB = bytearray(inf.pols_a_len), bytearray(inf.pols_b_len)
+        self._lib.check(self._lib.c.wsnark_synth_pols(self._h, 0, self._cbuf(polsA), len(polsA)))
+        self._lib.check(self._lib.c.wsnark_synth_pols(self._h, 1, self._cbuf(polsB), len(polsB)))
+        sec = {"n_vars": nv, "n_public": npub, "domain": dom,
+               "alfa1": bytes(fixed1[0:64]), "beta1": bytes(fixed1[64:128]), "delta1": bytes(fixed1[128:192]),
+               "beta2": bytes(fixed2[0:128]), "delta2": bytes(fixed2[128:256]), "polsA": polsA, "polsB": polsB,
+               "pointsA": ptsA, "pointsB1": ptsB1, "pointsB2": ptsB2, "pointsC": ptsC, "pointsH": ptsH}
+        return sec, ([bytes(ic[64 * i:64 * i + 64]) for i in range(npub + 1)], bytes(fixed2[256:384]))
+
+    def build_key(self, mul_base=None):
+        """(proving_key.bin bytes, verification key dict) -- only below the 4 GiB of the file format's u32 offsets."""
+        sec, (ic, gamma2) = self.build_sections()
+        return sections_to_pkey(sec), vk_from_points(self.n_public, sec, ic, gamma2)
+
+    def expected_scalars(self, r32, s32):
+        out = bytearray(96)
+        self._lib.check(self._lib.c.wsnark_synth_expected(self._h, bytes(r32), bytes(s32), self._cbuf(out)))
+        return tuple(int.from_bytes(out[32 * i:32 * i + 32], "little") for i in range(3))
+
+    def expected_proof(self, r32, s32, mul_base=None):
+        a, b, c = self.expected_scalars(r32, s32)
+        sc = bytearray(le32(a) + le32(c))
+        return proof_from_points(bytes(self._mul(1, sc, 0, 2)), bytes(self._mul(2, bytearray(le32(b)), 0, 1)))
+
+
+def sections_to_pkey(sec):
+    """tools/buildpkey.js:124-186 layout from the separate sections."""
+    fixed = bytes(sec["alfa1"]) + bytes(sec["beta1"]) + bytes(sec["delta1"]) + bytes(sec["beta2"]) + bytes(sec["delta2"])
+    parts = [sec["polsA"], sec["polsB"], sec["pointsA"], sec["pointsB1"], sec["pointsB2"], sec["pointsC"], sec["pointsH"]]
+    offs, o = [], 40 + len(fixed)
+    for part in parts:
+        offs.append(o)
+        o += len(part)
+    if o >= 1 << 32:
+        raise ValueError("key beyond the 4 GiB of proving_key.bin's u32 offsets: use the sections container")
+    return struct.pack("<10I", sec["n_vars"], sec["n_public"], sec["domain"], *offs) + fixed + b"".join(bytes(p) for p in parts)
+
+
+def _dec_q(bs):
+    return str(int.from_bytes(bs, "little") * pow(MONT, Q - 2, Q) % Q)
+
+
+def vk_from_points(npub, sec, ic, gamma2):
+    dec1 = lambda p: [_dec_q(p[:32]), _dec_q(p[32:64]), "1"]
+    dec2 = lambda p: [[_dec_q(p[0:32]), _dec_q(p[32:64])], [_dec_q(p[64:96]), _dec_q(p[96:128])], ["1", "0"]]
+    return {"protocol": "groth", "nPublic": npub, "vk_alfa_1": dec1(sec["alfa1"]), "vk_beta_2": dec2(sec["beta2"]),
+            "vk_gamma_2": dec2(gamma2), "vk_delta_2": dec2(sec["delta2"]), "IC": [dec1(p) for p in ic]}
+
+
+def proof_from_points(g1, g2):
+    """{pi_a, pi_c} = the two 64-byte affine Montgomery points of g1, pi_b = the 128-byte point g2, as the proof object."""
+    p1 = lambda p: ["0", "1", "0"] if p[:32] == b"\0" * 32 else [_dec_q(p[:32]), _dec_q(p[32:64]), "1"]
+    pb = [[_dec_q(g2[0:32]), _dec_q(g2[32:64])], [_dec_q(g2[64:96]), _dec_q(g2[96:128])], ["1", "0"]]
+    return {"pi_a": p1(g1[:64]), "pi_b": pb, "pi_c": p1(g1[64:128])}
+
+
 def pseudo_key(n_vars, n_public, domain, seed, mul_base):
     """A well-formed but NOT circuit-valid proving key with the given header: every point is
     k * G for seeded pseudo-random k, polsA/polsB have one pseudo-random coefficient per signal.
