@@ -141,6 +141,11 @@ int wsnark_pkey_info(const wsnark_pkey_t* handle, uint32_t* n_vars, uint32_t* n_
 int wsnark_pkey_table_info(const wsnark_pkey_t* handle, uint32_t* c_w, uint32_t* rows_w, uint32_t* c_h, uint32_t* rows_h,
                            uint64_t* bytes);
 
+/* Wall-clock of the handle's load, in ms: [0] pols -> CSR, [1] point sections host -> device, [2] infinity masks +
+ * conversion to the device field's domain, [3] fixed-base table build, [4] the whole call -- what a cold caller pays
+ * before its first proof (the reference re-parses the key inside every groth16GenProof call, src/bn128.js:581-604). */
+int wsnark_pkey_load_stats(const wsnark_pkey_t* handle, double* ms5);
+
 /* The same key given as separate host buffers with 64-bit lengths: proving_key.bin addresses its
  * sections with u32 byte offsets (tools/buildpkey.js:133-139), which caps a key at 4 GiB (~2^23
  * constraints); this entry point is the container for larger keys (BASELINE config 5).
@@ -161,6 +166,27 @@ typedef struct {
 } wsnark_key_sections_t;
 int wsnark_pkey_load_sections(const wsnark_key_sections_t* sections, wsnark_pkey_t** out_handle);
 
+/* Multi-GPU: ONE RANK'S SHARE of a key, split by points -- the reference's own worker split (src/bn128.js:353-361:
+ * contiguous ranges of the pairs, the remainder to the last worker) with GPUs as workers.  Every rank passes the same
+ * (complete) sections and keeps only the points of signals [rank * floor(nVars / world), ...) of A, B1, B2 and C and its
+ * share of hExps: 1 / world of the device memory and of the additions of every sum, uniform whatever the window count
+ * (wsnark_pkey_table_info reports the shard's own tables).  The two sparse matrices stay complete (CALC_H needs all rows).
+ * h_interleave_log = 0: the hExps share is the contiguous range [rank * floor(domain / world), ...): every rank computes
+ * the whole h (wsnark_groth16_prove_partial without WSNARK_PARTIAL_SKIP_H).  h_interleave_log = k > 0 (world a power of
+ * two, world <= 2^k <= domain): the share is the rank's rows of the 2^k-interleaved layout in which the distributed CALC_H
+ * leaves its slice of h -- local element (r, j) = hExps[(rank * 2^k / world + r) + 2^k * j], row-major -- to be summed with
+ * wsnark_pkey_h_msm_dev.  On such a handle wsnark_groth16_prove_partial[_dev] must be called with the handle's own (rank,
+ * world) and returns the partial sums over the handle's pairs (all windows); wsnark_groth16_prove[_dev] is WSNARK_ERR_ARG;
+ * wsnark_groth16_prove_finish works on any handle of the key (it only needs the five fixed points). */
+int wsnark_pkey_load_shard(const wsnark_key_sections_t* sections, uint32_t rank, uint32_t world, uint32_t h_interleave_log,
+                           wsnark_pkey_t** out_handle);
+/* which share a handle holds: (0, 1, 0, nVars, domain, 0) for a whole key.  Any out pointer may be NULL. */
+int wsnark_pkey_shard_info(const wsnark_pkey_t* handle, uint32_t* rank, uint32_t* world, uint64_t* first_signal,
+                           uint64_t* n_signals, uint64_t* n_hexps, uint32_t* h_interleave_log);
+/* sum_i h[i] * hExps_local[i] over the handle's resident hExps share (n must equal its n_hexps; d_h_slice: device, plain
+ * form, in the share's layout) -- the H call of src/bn128.js:614 for one rank.  out96: Jacobian-Montgomery, normalised. */
+int wsnark_pkey_h_msm_dev(wsnark_pkey_t* handle, const void* d_h_slice, uint64_t n, void* out96_host, void* stream);
+
 /* Bn128.groth16GenProof (src/bn128.js:580-720).  witness: nVars x 32 B plain
  * (tools/buildwitness.js:36-41).  r32 / s32: the two 32-byte blinding values the reference
  * draws from crypto.randomBytes (src/bn128.js:642-661); NULL => drawn from the OS CSPRNG.
@@ -180,8 +206,10 @@ int wsnark_groth16_prove_dev(wsnark_pkey_t* handle, const void* d_witness, size_
  *   inputs : n_inputs x 32 B plain little-endian public signals; one >= r gives *valid = 0 like the reference (:772)
  *   proof384: what wsnark_groth16_prove writes (pi_a | pi_b | pi_c with their z coordinates; z == 0 = infinity)
  * Returns WSNARK_OK with *valid = 1 / 0; WSNARK_ERR_FORMAT if a coordinate is not a reduced field element,
- * WSNARK_ERR_SIZE if vk holds fewer than n_inputs + 1 IC points.  Like the reference it does not test curve or
- * subgroup membership of the proof points. */
+ * WSNARK_ERR_SIZE if vk holds fewer than n_inputs + 1 IC points.  Unlike the reference, which makes no such test (its
+ * verdict on malformed points is an accident of its Miller loop), a point that is not on its curve, or a G2 point outside
+ * the order-r subgroup, makes the proof invalid (*valid = 0).  Like the reference (src/bn128.js:741-760 force z = 1) the z
+ * coordinates of the proof are ignored: (x, y) is the point. */
 int wsnark_groth16_verify(const void* vk, size_t vk_len, const void* inputs, uint64_t n_inputs, const void* proof384, int* valid);
 
 /* The two 32-byte blinding values of the last proof assembled by the CALLING THREAD (wsnark_groth16_prove[_dev] or
@@ -279,6 +307,15 @@ void wsnark_timing_enable(int on);
 void wsnark_timing_reset(void);
 /* writes "name total_ms launches\n" lines; returns bytes needed (excluding NUL) */
 size_t wsnark_timing_report(char* buf, size_t cap);
+/* The integer roofline's peak, measured on the device in use (about 10 ms each): probe 0 = a dependent chain of the
+ * library's own radix-2^29 Montgomery product on every lane, 8 x 256 lanes per CU (Gmodmul/s: what a kernel of nothing
+ * but products reaches); 1 = the same with the inlined product body; 2 = eight independent v_mad_u64_u32 chains per lane
+ * (Gmad/s: the raw 32x32+64 multiply-add issue rate).  3, 4 = traffic calibration kernels for the
+ * FETCH_SIZE counter (run under rocprofv3 --pmc by tools/gpu_session.sh): 3 = 2^25 pseudo-random 64-byte point gathers out
+ * of a 1 GiB table (the accumulation kernel's access pattern; 2 GiB of known bytes per launch, kernel
+ * `probe_gather64_kernel`), 4 = a 16-B-per-lane streaming read of the same 1 GiB (`probe_stream16_kernel`); both return
+ * GB/s of those known bytes. */
+int wsnark_peak_probe(int probe, double* gops_per_s);
 
 #ifdef __cplusplus
 }

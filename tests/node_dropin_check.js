@@ -73,6 +73,25 @@ const toAB = (b) => b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength);
         if ((await bn.loadKey(a3)) !== hk) throw new Error("unchanged key was reloaded");
         a3[100] ^= 0xff;
         if ((await bn.loadKey(a3)) === hk) throw new Error("stale key handle returned for changed bytes");
+        // ... wherever the byte is: the digest covers the whole buffer, not samples of it (VERDICT r2 item 8) -- every
+        // offset of a stretch well past the header, one flip at a time, each must give a fresh handle
+        let prev = await bn.loadKey(a3);
+        for (const off of [489, 500, 510, 777, 1001, k3.length - 33, k3.length - 2, k3.length - 1]) {
+            a3[off] ^= 0x01;
+            let h2 = null;
+            try { h2 = await bn.loadKey(a3); } catch (e) { h2 = null; }        // (a flip inside a record count makes the key malformed: a fresh parse that fails has noticed, too)
+            if (h2 !== null && h2 === prev) throw new Error("stale key handle after a flip at offset " + off);
+            if (h2 === null) a3[off] ^= 0x01; else prev = h2;
+        }
+    }
+    // terminate() of one Bn128 object must not shut the context down under another one (VERDICT r2 item 8)
+    {
+        const other = await ws.buildBn128(undefined, lib ? { lib } : undefined);
+        other.terminate();
+        other.terminate();                                                       // idempotent
+        const c3 = proofs.t3[0];
+        const still = await bn.groth16GenProof(wit, pkey, { r: Buffer.from(c3.r, "hex"), s: Buffer.from(c3.s, "hex") });
+        if (JSON.stringify(still) !== JSON.stringify(c3.proof)) throw new Error("proof after another object's terminate()");
     }
     // groth16Verify (main_bn128.js:41-55, src/bn128.js:722-791): the proofs just produced verify natively, a wrong input does not
     {

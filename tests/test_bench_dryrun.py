@@ -32,7 +32,13 @@ def test_bench_single_gpu_line():
     ex = d["extras"]
     assert ex["two_proofs_in_flight"]["all_proofs_identical_to_closed_form"]
     assert ex["g1_msm_2p8"]["two_in_flight"]["same_results"]
-    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["gpu_result_matches"] is True
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cpu_proof_matches_closed_form"] is True
+    assert "x 16" not in d["cpu_baseline"]["sample"] and d["cpu_baseline"]["one_thread"]["cores"] == 1
+    assert d["drop_in_call"]["same_proof"] is True and d["drop_in_call"]["ms"] > 0
+    cold = d["cold"]
+    assert cold["first_proof_matches_closed_form"] is True and cold["table_bytes"] > 0
+    assert set(cold["key_load_ms"]) == {"pols_to_csr", "points_h2d", "masks_convert", "table_build", "total"}
+    assert set(d["int_alu_peaks_this_run"]) >= {"modmul_G_per_s", "modmul_inlined_G_per_s", "mad_u64_u32_G_per_s"}   # (values need a GPU clock)
 
 
 def test_bench_two_ranks_line():

@@ -36,5 +36,24 @@ if ! skip pmc; then
   python tools/pmc_summary.py "$O" > "$O/pmc_traffic.json" 2>> "$O/env.log"
   find "$O/pmc_FETCH_SIZE" "$O/pmc_WRITE_SIZE" -name "*.csv" -size +2M -delete 2>/dev/null
 fi
+# SQ / GRBM counters behind the issue-bound claim: two passes, proofs only, kernel-trace only
+if ! skip sq; then
+  I=0
+  for GROUP in "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU"; do
+    I=$((I+1))
+    ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --pmc $GROUP --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/$O/sq/pmc_sq$I" -o pmc -- python "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --extras msm,ntt ) > "$O/pmc_sq$I.log" 2>&1
+    echo "pmc sq$I rc=$?" >> "$O/env.log"
+  done
+  python tools/pmc_counters.py "$O/sq" > "$O/pmc_sq_counters.json" 2>> "$O/env.log"
+  find "$O/sq" -name "*.csv" -size +2M -delete 2>/dev/null
+fi
+# FETCH_SIZE / WRITE_SIZE calibration on known byte counts (64-B gathers out of a 1 GiB table; a 16-B-per-lane stream)
+if ! skip calib; then
+  for CTR in FETCH_SIZE WRITE_SIZE; do
+    ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/$O/calib/pmc_$CTR" -o pmc -- python "$GRAFT_REPO_ROOT/tools/pmc_calibrate.py" ) > "$O/calib_$CTR.log" 2>&1
+    echo "calib $CTR rc=$?" >> "$O/env.log"
+  done
+  python tools/pmc_counters.py "$O/calib" > "$O/pmc_calibration.json" 2>> "$O/env.log"
+fi
 [ -n "$EXTRA_CMD" ] && ( eval "$EXTRA_CMD" ) > "$O/extra.log" 2>&1
 tail -15 "$O/pytest_gpu.txt" 2>/dev/null; head -c 6000 "$O/bench.json" 2>/dev/null; echo; tail -3 "$O/bench.err" 2>/dev/null; cat "$O/env.log"

@@ -21,13 +21,13 @@ SYMBOLS = [
     "wsnark_fr_ntt", "wsnark_fr_ntt_dev", "wsnark_fr_ntt_batch_dev", "wsnark_fr_dist_scale_dev",
     "wsnark_pkey_eval_ab_dev", "wsnark_fr_mul_dev", "wsnark_fr_dist_combine_dev", "wsnark_fr_to_montgomery", "wsnark_fr_from_montgomery",
     "wsnark_calc_h", "wsnark_pkey_load", "wsnark_pkey_free", "wsnark_pkey_info", "wsnark_pkey_table_info",
-    "wsnark_groth16_prove", "wsnark_groth16_prove_dev", "wsnark_pkey_load_sections", "wsnark_last_blinding", "wsnark_groth16_verify",
+    "wsnark_groth16_prove", "wsnark_groth16_prove_dev", "wsnark_pkey_load_sections", "wsnark_pkey_load_shard", "wsnark_pkey_shard_info", "wsnark_pkey_load_stats", "wsnark_pkey_h_msm_dev", "wsnark_last_blinding", "wsnark_groth16_verify",
     "wsnark_groth16_prove_partial", "wsnark_groth16_prove_partial_dev", "wsnark_groth16_prove_finish",
     "wsnark_g1_mul_base_batch", "wsnark_g2_mul_base_batch",
     "wsnark_synth_new", "wsnark_synth_free", "wsnark_synth_info", "wsnark_synth_witness", "wsnark_synth_pols",
     "wsnark_synth_key_scalars", "wsnark_synth_expected",
     "wsnark_selftest_field", "wsnark_selftest_curve",
-    "wsnark_timing_enable", "wsnark_timing_reset", "wsnark_timing_report",
+    "wsnark_timing_enable", "wsnark_timing_reset", "wsnark_timing_report", "wsnark_peak_probe",
 ]
 
 
@@ -89,6 +89,11 @@ class Lib:
         c.wsnark_groth16_prove.argtypes = [vp, vp, sz, vp, vp, vp]
         c.wsnark_groth16_prove_dev.argtypes = [vp, vp, sz, vp, vp, vp, vp]
         c.wsnark_pkey_load_sections.argtypes = [vp, C.POINTER(vp)]
+        c.wsnark_pkey_load_shard.argtypes = [vp, u32, u32, u32, C.POINTER(vp)]
+        c.wsnark_pkey_shard_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
+        c.wsnark_peak_probe.argtypes = [C.c_int, C.POINTER(C.c_double)]
+        c.wsnark_pkey_load_stats.argtypes = [vp, C.POINTER(C.c_double)]
+        c.wsnark_pkey_h_msm_dev.argtypes = [vp, vp, u64, vp, vp]
         c.wsnark_groth16_prove_partial.argtypes = [vp, vp, sz, u32, u32, u32, vp]
         c.wsnark_groth16_prove_partial_dev.argtypes = [vp, vp, sz, u32, u32, u32, vp, vp]
         c.wsnark_pkey_eval_ab_dev.argtypes = [vp, vp, sz, vp, vp, vp]

@@ -60,9 +60,13 @@ class _KeySections(C.Structure):   # wsnark_key_sections_t
 class ProvingKey:
     """Device-resident proving key (wsnark_pkey_load, or wsnark_pkey_load_sections for `sections`)."""
 
-    def __init__(self, lib, data=None, sections=None):
+    def __init__(self, lib, data=None, sections=None, shard=None, h_interleave_log=0):
+        """shard=(rank, world) with `sections`: only that rank's share of the points becomes resident
+        (wsnark_pkey_load_shard; h_interleave_log: the layout of its hExps share, see include/wsnark.h)."""
         self._lib = lib
         self._h = C.c_void_p()
+        if shard is not None and sections is None:
+            raise ValueError("a points shard is loaded from sections")
         if sections is not None:
             # dict: n_vars, n_public, domain + byte strings alfa1, beta1, delta1, beta2, delta2, polsA, polsB,
             # pointsA, pointsB1, pointsB2, pointsC, pointsH (64-bit lengths: keys beyond the 4 GiB file format)
@@ -75,7 +79,10 @@ class ProvingKey:
                 setattr(ks, name, C.cast(b, C.c_void_p))
                 if name.startswith(("pols", "points")):
                     setattr(ks, name + "_len", n)     # the library checks every section against the header
-            lib.check(lib.c.wsnark_pkey_load_sections(C.byref(ks), C.byref(self._h)))
+            if shard is not None:
+                lib.check(lib.c.wsnark_pkey_load_shard(C.byref(ks), shard[0], shard[1], h_interleave_log, C.byref(self._h)))
+            else:
+                lib.check(lib.c.wsnark_pkey_load_sections(C.byref(ks), C.byref(self._h)))
         else:
             b, n = _ro(data)
             lib.check(lib.c.wsnark_pkey_load(b, n, C.byref(self._h)))
@@ -86,6 +93,15 @@ class ProvingKey:
         lib.check(lib.c.wsnark_pkey_table_info(self._h, C.byref(cw), C.byref(rw), C.byref(ch), C.byref(rh), C.byref(nb)))
         # how the point sections are resident: fixed-base window tables (rows > 1) or the plain sections
         self.table = {"c_w": cw.value, "rows_w": rw.value, "c_h": ch.value, "rows_h": rh.value, "bytes": nb.value}
+        ms = (C.c_double * 5)()
+        lib.check(lib.c.wsnark_pkey_load_stats(self._h, ms))
+        self.load_ms = {"pols_to_csr": ms[0], "points_h2d": ms[1], "masks_convert": ms[2], "table_build": ms[3], "total": ms[4]}
+        rk, wd, hl = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        lo, nl, nh = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        lib.check(lib.c.wsnark_pkey_shard_info(self._h, C.byref(rk), C.byref(wd), C.byref(lo), C.byref(nl), C.byref(nh), C.byref(hl)))
+        # which share of the points this handle holds (a whole key: rank 0 of 1, all nVars signals, all hExps)
+        self.shard = {"rank": rk.value, "world": wd.value, "first_signal": lo.value, "n_signals": nl.value, "n_hexps": nh.value,
+                      "h_interleave_log": hl.value}
 
     def free(self):
         if self._h:
@@ -204,8 +220,14 @@ class Bn128:
         self.lib.check(fn(b, s, n, out))
         return bytes(out)[: n * sz]
 
-    def load_key(self, pkey=None, sections=None):
-        return ProvingKey(self.lib, pkey, sections)
+    def load_key(self, pkey=None, sections=None, shard=None, h_interleave_log=0):
+        return ProvingKey(self.lib, pkey, sections, shard, h_interleave_log)
+
+    def h_multiexp_dev(self, key, d_h_slice, n, stream=None):
+        """The H sum of one rank against the key handle's resident hExps share (wsnark_pkey_h_msm_dev)."""
+        out = (C.c_uint8 * 96)()
+        self.lib.check(self.lib.c.wsnark_pkey_h_msm_dev(key._h, d_h_slice, n, out, stream))
+        return bytes(out)
 
     # --- multi-GPU proving: per-rank partial sums + host-side finish (include/wsnark.h) ---
     def groth16_prove_partial(self, signals, key, shard=(0, 1), skip_h=False):

@@ -24,7 +24,11 @@ struct KeySections {
     const uint8_t *A, *B1, *B2, *Cpts, *H;
     uint64_t lenPA, lenPB1, lenPB2, lenPC, lenPH;
 };
-int pkey_load_sections(const KeySections& S, ProvingKey** out);
+struct KeyShard { uint32_t rank = 0, world = 1, h_log_m = 0; };
+int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard);
+void pkey_shard_info(const ProvingKey* K, uint32_t* rank, uint32_t* world, uint64_t* lo, uint64_t* n_local, uint64_t* h_local, uint32_t* h_log_m);
+void pkey_load_stats(const ProvingKey* K, double* out5);
+int pkey_h_msm_dev(ProvingKey* K, const Fe* d_h_local, uint64_t n, uint8_t* out96, hipStream_t s);
 int groth16_prove_partial(ProvingKey* K, const uint8_t* witness, size_t witness_len, WindowShard sh, uint8_t* out576, bool skip_h);
 int groth16_prove_partial_dev(ProvingKey* K, const Fe* d_witness, size_t witness_len, WindowShard sh, uint8_t* out576, hipStream_t s, bool skip_h);
 int pkey_eval_ab_dev(ProvingKey* K, const Fe* d_witness, size_t witness_len, Fe* d_a, Fe* d_b, hipStream_t s);
@@ -39,6 +43,7 @@ void g1_sum_host(const uint8_t* pts, uint64_t count, uint8_t* out96);
 void g2_sum_host(const uint8_t* pts, uint64_t count, uint8_t* out192);
 int g1_mul_base_batch(const void* base, const void* scalars, uint64_t n, void* out);
 int g2_mul_base_batch(const void* base, const void* scalars, uint64_t n, void* out);
+int peak_probe(int probe, double* gops);
 int selftest_field(int which, int impl, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, uint64_t n);
 int selftest_curve(int g, int impl, int op, const uint8_t* p, const uint8_t* q, uint8_t* out, uint64_t n);
 }  // namespace wsnark
@@ -240,8 +245,7 @@ int wsnark_groth16_prove_dev(wsnark_pkey_t* h, const void* d_witness, size_t wit
                                      (const uint8_t*)r32, (const uint8_t*)s32, (uint8_t*)out384_host, (hipStream_t)stream);
 }
 
-int wsnark_pkey_load_sections(const wsnark_key_sections_t* ks, wsnark_pkey_t** out_handle) {
-    REQUIRE_CTX();
+static int load_sections_entry(const wsnark_key_sections_t* ks, KeyShard shard, wsnark_pkey_t** out_handle) {
     if (!ks || !out_handle || !ks->alfa1 || !ks->beta1 || !ks->delta1 || !ks->beta2 || !ks->delta2 || !ks->polsA ||
         !ks->polsB || !ks->pointsA || !ks->pointsB1 || !ks->pointsB2 || !ks->pointsH ||
         (!ks->pointsC && (uint64_t)ks->n_vars > (uint64_t)ks->n_public + 1))
@@ -253,10 +257,36 @@ int wsnark_pkey_load_sections(const wsnark_key_sections_t* ks, wsnark_pkey_t** o
                   (const uint8_t*)ks->pointsC, (const uint8_t*)ks->pointsH,
                   ks->pointsA_len, ks->pointsB1_len, ks->pointsB2_len, ks->pointsC_len, ks->pointsH_len};
     ProvingKey* K = nullptr;
-    int rc = pkey_load_sections(S, &K);
+    int rc = pkey_load_sections(S, &K, shard);
     if (rc) return rc;
     *out_handle = reinterpret_cast<wsnark_pkey_t*>(K);
     return WSNARK_OK;
+}
+int wsnark_pkey_load_sections(const wsnark_key_sections_t* ks, wsnark_pkey_t** out_handle) {
+    REQUIRE_CTX();
+    return load_sections_entry(ks, KeyShard{}, out_handle);
+}
+int wsnark_pkey_load_shard(const wsnark_key_sections_t* ks, uint32_t rank, uint32_t world, uint32_t h_interleave_log,
+                           wsnark_pkey_t** out_handle) {
+    REQUIRE_CTX();
+    if (!shard_ok(rank, world)) return WSNARK_ERR_ARG;
+    return load_sections_entry(ks, KeyShard{rank, world, h_interleave_log}, out_handle);
+}
+int wsnark_pkey_shard_info(const wsnark_pkey_t* h, uint32_t* rank, uint32_t* world, uint64_t* first_signal, uint64_t* n_signals,
+                           uint64_t* n_hexps, uint32_t* h_interleave_log) {
+    if (!h) return WSNARK_ERR_ARG;
+    pkey_shard_info(reinterpret_cast<const ProvingKey*>(h), rank, world, first_signal, n_signals, n_hexps, h_interleave_log);
+    return WSNARK_OK;
+}
+int wsnark_pkey_load_stats(const wsnark_pkey_t* h, double* ms5) {
+    if (!h || !ms5) return WSNARK_ERR_ARG;
+    pkey_load_stats(reinterpret_cast<const ProvingKey*>(h), ms5);
+    return WSNARK_OK;
+}
+int wsnark_pkey_h_msm_dev(wsnark_pkey_t* h, const void* d_h_slice, uint64_t n, void* out96_host, void* stream) {
+    REQUIRE_CTX();
+    if (!h || !out96_host || (n && !d_h_slice)) return WSNARK_ERR_ARG;
+    return pkey_h_msm_dev(reinterpret_cast<ProvingKey*>(h), (const Fe*)d_h_slice, n, (uint8_t*)out96_host, (hipStream_t)stream);
 }
 int wsnark_groth16_prove_partial(wsnark_pkey_t* h, const void* witness, size_t witness_len, uint32_t rank, uint32_t world,
                                  uint32_t flags, void* out576) {
@@ -320,6 +350,11 @@ int wsnark_selftest_curve(int g, int impl, int op, const void* p, const void* q,
     REQUIRE_CTX();
     if (n && (!p || !q || !out)) return WSNARK_ERR_ARG;
     return selftest_curve(g, impl, op, (const uint8_t*)p, (const uint8_t*)q, (uint8_t*)out, n);
+}
+
+int wsnark_peak_probe(int probe, double* gops_per_s) {
+    REQUIRE_CTX();
+    return peak_probe(probe, gops_per_s);
 }
 
 // ---- timing ----

@@ -6,6 +6,8 @@
 #include <atomic>
 #include <thread>
 
+#include <chrono>
+
 #include "internal.h"
 
 namespace wsnark {
@@ -97,15 +99,23 @@ const std::string& device_info() { return g_devinfo; }
 
 LaneLock acquire_lane(Context* C) {
     LaneLock r;
-    for (int i = 0; i < C->n_lanes; i++) {
-        std::unique_lock<std::mutex> lk(C->lanes[i].mu, std::try_to_lock);
-        if (lk.owns_lock()) { r.L = &C->lanes[i]; r.lk = std::move(lk); return r; }
+    r.C = C;
+    for (;;) {
+        for (int i = 0; i < C->n_lanes; i++) {
+            std::unique_lock<std::mutex> lk(C->lanes[i].mu, std::try_to_lock);
+            if (lk.owns_lock()) { r.L = &C->lanes[i]; r.lk = std::move(lk); return r; }
+        }
+        // every lane is busy: sleep until one is released (the timeout only bounds a wake-up lost between the scan above
+        // and the wait below)
+        std::unique_lock<std::mutex> w(C->lane_mu);
+        C->lane_cv.wait_for(w, std::chrono::milliseconds(2));
     }
-    static std::atomic<unsigned> turn(0);
-    Lane& L = C->lanes[turn.fetch_add(1) % (unsigned)C->n_lanes];
-    r.lk = std::unique_lock<std::mutex>(L.mu);
-    r.L = &L;
-    return r;
+}
+LaneLock::~LaneLock() {
+    if (lk.owns_lock()) {
+        lk.unlock();
+        if (C) C->lane_cv.notify_one();
+    }
 }
 
 // ---- staged uploads ----

@@ -1,5 +1,6 @@
 // internal.h -- C++ interfaces between the translation units of libwsnark.
 #pragma once
+#include <condition_variable>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -84,6 +85,8 @@ struct Context {
     int num_cu = 256;
     int n_lanes = 2;
     Lane lanes[kMaxLanes];
+    std::mutex lane_mu;                         // waiting for a lane: released lanes are announced on lane_cv
+    std::condition_variable lane_cv;
     std::mutex mu;                              // NTT plan cache
     std::map<int, std::shared_ptr<NttPlan>> ntt_plans;   // by log2(n)
     KernelTimer timer;
@@ -92,10 +95,17 @@ struct Context {
     hipEvent_t pin_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
-// RAII: a free lane if there is one, else the next one in turn (blocks until its current user is done)
+// RAII: a free lane; with every lane busy the caller waits until ANY of them is released (not for one picked in advance:
+// a caller must not queue behind a long proof while another lane has already come free)
 struct LaneLock {
     Lane* L = nullptr;
+    Context* C = nullptr;
     std::unique_lock<std::mutex> lk;
+    LaneLock() {}
+    LaneLock(LaneLock&& o) : L(o.L), C(o.C), lk(std::move(o.lk)) { o.L = nullptr; o.C = nullptr; }
+    LaneLock(const LaneLock&) = delete;
+    LaneLock& operator=(const LaneLock&) = delete;
+    ~LaneLock();
     Lane* operator->() const { return L; }
     Lane& operator*() const { return *L; }
 };

@@ -28,10 +28,21 @@ struct ProvingKey {
     uint32_t infA = 0, infB = 0;   // how many of those there are
     bool sparseA = false, sparseB = false;   // enough of them to give those sums a plan variant that leaves them out
     // Fixed-base window tables: the key's points never change, so each section is kept as rows x n points, row w =
-    // 2^(c w) * (the section) -- 15 rows at c = 18 for 2^20 pairs, 6 GB for the five sections.  Every window of a scalar
-    // then adds into ONE bucket set: fewer, wider windows (15 instead of 16 passes over the points at 2^20), one
+    // 2^(c w) * (the section) -- 13 rows at c = 20 for 2^20 pairs, 5.2 GB for the five sections.  Every window of a scalar
+    // then adds into ONE bucket set: fewer, wider windows (13 instead of 16 passes over the points at 2^20), one
     // reduction tail per sum instead of one per window, no doubling chain on the host.  0 = plain sections.
-    uint32_t table_cw = 0, table_ch = 0;     // window width of the A/B1/B2/C tables (n_vars pairs) and of the H table (domain pairs)
+    uint32_t table_cw = 0, table_ch = 0;     // window width of the A/B1/B2/C tables (n_local pairs) and of the H table (h_local pairs)
+    // Points shard (multi-GPU, SURVEY.md section 8e split (i) = the reference's own worker split, src/bn128.js:353-361):
+    // this handle holds the points of signals [lo, lo + n_local) of every section and h_local of the hExps -- 1/world
+    // of the memory and of the additions, all table rows, uniform work whatever the window count.  world 1 = whole key.
+    // The hExps slice is the contiguous range [hlo, hlo + h_local) (h computed in full on this rank), or -- h_log_m != 0
+    // -- the rank's rows of the m-interleaved layout the distributed CALC_H leaves its slice of h in (element (row r, j)
+    // = hExps[(rank*m/world + r) + m*j]).  The two sparse matrices are always complete (CALC_H needs every row).
+    uint32_t shard_rank = 0, shard_world = 1;
+    uint32_t lo = 0, n_local = 0, hlo = 0, h_local = 0, h_log_m = 0;
+    // wall-clock of the load, by phase (ms): pols -> CSR, point sections host -> device, masks + conversion to the device
+    // field's domain, fixed-base table build, whole call (what a cold caller pays before its first proof)
+    double load_ms[5] = {0, 0, 0, 0, 0};
     // Read-only after load: any number of proofs may use one handle at once (each on its own lane, which holds the
     // per-proof buffers and events).
 };
@@ -47,10 +58,13 @@ struct KeySections {      // everything wsnark_pkey_load reads from proving_key.
     uint64_t lenPA, lenPB1, lenPB2, lenPC, lenPH;   // bytes the caller vouches for behind each of those
 };
 
-int pkey_load_sections(const KeySections& S, ProvingKey** out) {
+struct KeyShard { uint32_t rank = 0, world = 1, h_log_m = 0; };
+
+int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
     const uint32_t nv = S.n_vars, np = S.n_public, dom = S.domain;
+    if (shard.world == 0 || shard.rank >= shard.world) return WS_ERR_ARG;
     if (nv == 0 || (uint64_t)np + 1 > nv) { set_last_error("proving key: nPublic + 1 > nVars"); return WS_ERR_FORMAT; }
     if (dom < 2 || (dom & (dom - 1)) || dom > (1u << 27)) { set_last_error("proving key: domainSize must be a power of two in [2, 2^27]"); return WS_ERR_SIZE; }
     const uint64_t nC = (uint64_t)nv - np - 1;
@@ -61,6 +75,26 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out) {
     }
     std::unique_ptr<ProvingKey> K(new ProvingKey());
     K->n_vars = nv; K->n_public = np; K->domain = dom;
+    // the rank's share: floor(n / world) pairs per rank, the remainder to the last one (src/bn128.js:354-361)
+    K->shard_rank = shard.rank; K->shard_world = shard.world;
+    {
+        const uint32_t per = nv / shard.world, hper = dom / shard.world;
+        K->lo = shard.rank * per;
+        K->n_local = shard.rank == shard.world - 1 ? nv - K->lo : per;
+        K->hlo = shard.rank * hper;
+        K->h_local = shard.rank == shard.world - 1 ? dom - K->hlo : hper;
+        if (shard.world > 1 && shard.h_log_m) {
+            const uint64_t m = (uint64_t)1 << shard.h_log_m;
+            if (shard.h_log_m > 27 || m > dom || (shard.world & (shard.world - 1)) || m % shard.world) {
+                set_last_error("proving key shard: the interleave 2^h_log_m must divide the domain and be a multiple of the (power-of-two) world size");
+                return WS_ERR_ARG;
+            }
+            K->h_log_m = shard.h_log_m;
+            K->hlo = 0;                      // (no contiguous range: see pointsH below)
+            K->h_local = dom / shard.world;
+        }
+    }
+    const uint32_t nl = K->n_local, hl = K->h_local, lo = K->lo;
     memcpy(&K->alfa1, S.alfa1, 64);
     memcpy(&K->beta1, S.beta1, 64);
     memcpy(&K->delta1, S.delta1, 64);
@@ -73,37 +107,53 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out) {
     {
         const char* e = getenv("WSNARK_KEY_TABLE");
         if ((!e || atoi(e) != 0) && msm_uses_field29() && !(getenv("WSNARK_MSM_SORT") && !strcmp(getenv("WSNARK_MSM_SORT"), "cub"))) {
-            const uint32_t cw = msm_table_window(nv), ch = msm_table_window(dom);
-            const uint64_t bytes = (uint64_t)nv * 320 * msm_table_rows(cw) + (uint64_t)dom * 64 * msm_table_rows(ch);
+            const uint32_t cw = msm_table_window(nl ? nl : 1), ch = msm_table_window(hl ? hl : 1);
+            const uint64_t bytes = (uint64_t)nl * 320 * msm_table_rows(cw) + (uint64_t)hl * 64 * msm_table_rows(ch);
             const char* g = getenv("WSNARK_TABLE_MAX_GB");
             const uint64_t cap = (uint64_t)((g ? atof(g) : 160.0) * 1073741824.0);
             size_t free_b = 0, total_b = 0;
             WS_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-            if (bytes <= cap && bytes <= free_b / 2 && (uint64_t)msm_table_rows(cw) * nv < ((uint64_t)1 << 31) &&
-                (uint64_t)msm_table_rows(ch) * dom < ((uint64_t)1 << 31)) {
+            if (bytes <= cap && bytes <= free_b / 2 && (uint64_t)msm_table_rows(cw) * nl < ((uint64_t)1 << 31) &&
+                (uint64_t)msm_table_rows(ch) * hl < ((uint64_t)1 << 31)) {
                 K->table_cw = cw;
                 K->table_ch = ch;
             }
         }
     }
+    typedef std::chrono::steady_clock Clock;
+    const auto t_begin = Clock::now();
+    auto lap = [&](Clock::time_point& from) {      // ms since `from`, after the queue has drained; `from` moves on
+        (void)hipStreamSynchronize(s);
+        const auto now = Clock::now();
+        const double ms = std::chrono::duration<double, std::milli>(now - from).count();
+        from = now;
+        return ms;
+    };
+    auto t_phase = t_begin;
     int rc = pols_to_csr(S.polsA, (size_t)S.lenA, nv, dom, &K->polsA, &used, s);
     if (rc) return rc;
     rc = pols_to_csr(S.polsB, (size_t)S.lenB, nv, dom, &K->polsB, &used, s);
     if (rc) return rc;
-    struct Sec { DevBuf* d; const uint8_t* src; uint64_t bytes; } secs[5] = {
-        {&K->pointsA, S.A, (uint64_t)nv * 64}, {&K->pointsB1, S.B1, (uint64_t)nv * 64}, {&K->pointsB2, S.B2, (uint64_t)nv * 128},
-        {&K->pointsC, S.Cpts, nC * 64}, {&K->pointsH, S.H, (uint64_t)dom * 64}};
+    K->load_ms[0] = lap(t_phase);
+    // the rank's slice of every section.  C holds points for signals nPublic+1.. only (src/bn128.js:620 slices the scalars
+    // instead).  Resident copy: padded in front with infinities (x == 0) for the signals 0..nPublic, so that the C sum uses
+    // the SAME scalar vector -- and the same digit/sort plan -- as A, B1 and B2: local index i = signal lo + i everywhere.
+    const uint64_t c_front = lo < np + 1 ? std::min<uint64_t>(nl, (uint64_t)np + 1 - lo) : 0;      // leading infinities of the local C array
+    const uint64_t c_first = (lo > np + 1 ? lo - (np + 1) : 0);                                     // first C point of the file that is mine
+    struct Sec { DevBuf* d; const uint8_t* src; uint64_t bytes, row_bytes, rows; } secs[5] = {
+        {&K->pointsA, S.A + (uint64_t)lo * 64, (uint64_t)nl * 64, (uint64_t)nl * 64, 0},
+        {&K->pointsB1, S.B1 + (uint64_t)lo * 64, (uint64_t)nl * 64, (uint64_t)nl * 64, 0},
+        {&K->pointsB2, S.B2 + (uint64_t)lo * 128, (uint64_t)nl * 128, (uint64_t)nl * 128, 0},
+        {&K->pointsC, S.Cpts + c_first * 64, ((uint64_t)nl - c_front) * 64, (uint64_t)nl * 64, 0},
+        {&K->pointsH, S.H + (uint64_t)K->hlo * 64, (uint64_t)hl * 64, (uint64_t)hl * 64, 0}};
     // the five buffers: rows x section.  Should the device refuse a table after all (fragmentation, another process), the
     // key falls back to plain sections instead of failing
     for (int attempt = 0; attempt < 2; attempt++) {
         const uint64_t rowsW = msm_table_rows(K->table_cw), rowsH = msm_table_rows(K->table_ch);
         hipError_t err = hipSuccess;
         for (auto& sc : secs) {
-            // C holds points for signals nPublic+1.. only (src/bn128.js:620 slices the scalars instead).  Resident copy:
-            // padded in front with nPublic+1 points at infinity (x == 0), so that the C sum uses the SAME scalar vector --
-            // and the same digit/sort plan -- as A, B1 and B2.
-            const uint64_t row_bytes = sc.d == &K->pointsC ? (uint64_t)nv * 64 : sc.bytes;
-            if ((err = sc.d->alloc((size_t)(row_bytes * (sc.d == &K->pointsH ? rowsH : rowsW)))) != hipSuccess) break;
+            sc.rows = sc.d == &K->pointsH ? rowsH : rowsW;
+            if ((err = sc.d->alloc((size_t)std::max<uint64_t>(sc.row_bytes * sc.rows, 64))) != hipSuccess) break;
         }
         if (err == hipSuccess) break;
         (void)hipGetLastError();
@@ -111,44 +161,58 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out) {
         for (auto& sc : secs) sc.d->release();
         K->table_cw = K->table_ch = 0;
     }
+    std::vector<uint8_t> h_gather;
+    if (K->h_log_m) {
+        // the rank's rows of the m-interleaved layout, row-major (m / world) x (domain / m): local (r, j) = hExps[(rank m/world + r) + m j]
+        const uint64_t m = (uint64_t)1 << K->h_log_m, per = m / shard.world, cols = dom / m;
+        h_gather.resize((size_t)hl * 64);
+        for (uint64_t r = 0; r < per; r++)
+            for (uint64_t j = 0; j < cols; j++)
+                memcpy(&h_gather[(size_t)(r * cols + j) * 64], S.H + ((uint64_t)shard.rank * per + r + m * j) * 64, 64);
+        secs[4].src = h_gather.data();
+    }
     for (auto& sc : secs) {
         size_t front = 0;
-        if (sc.d == &K->pointsC) {
-            front = (size_t)(np + 1) * 64;
+        if (sc.d == &K->pointsC && c_front) {
+            front = (size_t)c_front * 64;
             WS_HIP_CHECK(hipMemsetAsync(sc.d->p, 0, front, s));
         }
         if (sc.bytes && (rc = upload_staged((uint8_t*)sc.d->p + front, sc.src, (size_t)sc.bytes, s))) return rc;
     }
+    K->load_ms[1] = lap(t_phase);
     // Variables that do not occur in matrix A (resp. B) have A (resp. B1 = B2) = infinity -- common: real circuits put
     // far fewer terms on the B side.  Their pairs cost a lane slot each in those sums, so when there are enough of
     // them the sums run on a plan VARIANT that leaves them out (msm_plan_variant: the per-bin sort and the task list
     // are redone, ~0.17 ms at 2^20; the digit extraction and the scatter are shared with the full plan).
     // WSNARK_PROVE_SPARSE: 0 never, 2 always.
-    WS_HIP_CHECK(K->maskA.alloc((size_t)nv));
-    WS_HIP_CHECK(K->maskB.alloc((size_t)nv));
-    if ((rc = msm_points_mask(K->pointsA.as<Affine<Fq>>(), nullptr, nv, K->maskA.as<uint8_t>(), &K->infA, s))) return rc;
-    if ((rc = msm_points_mask(K->pointsB1.as<Affine<Fq>>(), K->pointsB2.as<Affine<Fq2>>(), nv, K->maskB.as<uint8_t>(), &K->infB, s))) return rc;
+    WS_HIP_CHECK(K->maskA.alloc((size_t)std::max<uint32_t>(nl, 1)));
+    WS_HIP_CHECK(K->maskB.alloc((size_t)std::max<uint32_t>(nl, 1)));
+    if ((rc = msm_points_mask(K->pointsA.as<Affine<Fq>>(), nullptr, nl, K->maskA.as<uint8_t>(), &K->infA, s))) return rc;
+    if ((rc = msm_points_mask(K->pointsB1.as<Affine<Fq>>(), K->pointsB2.as<Affine<Fq2>>(), nl, K->maskB.as<uint8_t>(), &K->infB, s))) return rc;
     {
         const char* e = getenv("WSNARK_PROVE_SPARSE");
         const int mode = e ? atoi(e) : 1;
-        const bool big = nv >= (1u << 14);
-        K->sparseA = mode == 2 || (mode == 1 && big && (uint64_t)K->infA * 100 >= (uint64_t)nv * 15);   // saves a share of one G1 sum
-        K->sparseB = mode == 2 || (mode == 1 && big && (uint64_t)K->infB * 100 >= (uint64_t)nv * 5);    // ... of a G1 and a G2 sum
+        const bool big = nl >= (1u << 14);
+        K->sparseA = mode == 2 || (mode == 1 && big && (uint64_t)K->infA * 100 >= (uint64_t)nl * 15);   // saves a share of one G1 sum
+        K->sparseB = mode == 2 || (mode == 1 && big && (uint64_t)K->infB * 100 >= (uint64_t)nl * 5);    // ... of a G1 and a G2 sum
     }
     // resident keys are kept in the device field's internal domain: no per-proof conversion pass
-    if ((rc = msm_prepare_points(0, K->pointsA.p, nv, s))) return rc;
-    if ((rc = msm_prepare_points(0, K->pointsB1.p, nv, s))) return rc;
-    if ((rc = msm_prepare_points(1, K->pointsB2.p, nv, s))) return rc;
-    if ((rc = msm_prepare_points(0, K->pointsC.p, nv, s))) return rc;
-    if ((rc = msm_prepare_points(0, K->pointsH.p, dom, s))) return rc;
+    if ((rc = msm_prepare_points(0, K->pointsA.p, nl, s))) return rc;
+    if ((rc = msm_prepare_points(0, K->pointsB1.p, nl, s))) return rc;
+    if ((rc = msm_prepare_points(1, K->pointsB2.p, nl, s))) return rc;
+    if ((rc = msm_prepare_points(0, K->pointsC.p, nl, s))) return rc;
+    if ((rc = msm_prepare_points(0, K->pointsH.p, hl, s))) return rc;
+    K->load_ms[2] = lap(t_phase);
     if (K->table_cw) {      // rows 1.. of the tables, from row 0, in that domain
-        if ((rc = msm_build_table(0, K->pointsA.p, nv, K->table_cw, s))) return rc;
-        if ((rc = msm_build_table(0, K->pointsB1.p, nv, K->table_cw, s))) return rc;
-        if ((rc = msm_build_table(1, K->pointsB2.p, nv, K->table_cw, s))) return rc;
-        if ((rc = msm_build_table(0, K->pointsC.p, nv, K->table_cw, s))) return rc;
-        if ((rc = msm_build_table(0, K->pointsH.p, dom, K->table_ch, s))) return rc;
+        if ((rc = msm_build_table(0, K->pointsA.p, nl, K->table_cw, s))) return rc;
+        if ((rc = msm_build_table(0, K->pointsB1.p, nl, K->table_cw, s))) return rc;
+        if ((rc = msm_build_table(1, K->pointsB2.p, nl, K->table_cw, s))) return rc;
+        if ((rc = msm_build_table(0, K->pointsC.p, nl, K->table_cw, s))) return rc;
+        if ((rc = msm_build_table(0, K->pointsH.p, hl, K->table_ch, s))) return rc;
     }
     WS_HIP_CHECK(hipStreamSynchronize(s));
+    K->load_ms[3] = lap(t_phase);
+    K->load_ms[4] = std::chrono::duration<double, std::milli>(Clock::now() - t_begin).count();
     *out = K.release();
     return WS_OK;
 }
@@ -175,7 +239,7 @@ int pkey_load(const uint8_t* buf, size_t len, ProvingKey** out) {
                   buf + pPolsA, pPolsB - pPolsA, buf + pPolsB, pA - pPolsB,
                   buf + pA, buf + pB1, buf + pB2, buf + pC, buf + pH,
                   len - pA, len - pB1, len - pB2, len - pC, len - pH};
-    return pkey_load_sections(S, out);
+    return pkey_load_sections(S, out, KeyShard{});
 }
 
 void pkey_free(ProvingKey* K) { delete K; }
@@ -190,7 +254,16 @@ void pkey_table_info(const ProvingKey* K, uint32_t* cw, uint32_t* rw, uint32_t* 
     if (rw) *rw = msm_table_rows(K->table_cw);
     if (ch) *ch = K->table_ch;
     if (rh) *rh = msm_table_rows(K->table_ch);
-    if (bytes) *bytes = (uint64_t)K->n_vars * 320 * msm_table_rows(K->table_cw) + (uint64_t)K->domain * 64 * msm_table_rows(K->table_ch);
+    if (bytes) *bytes = (uint64_t)K->n_local * 320 * msm_table_rows(K->table_cw) + (uint64_t)K->h_local * 64 * msm_table_rows(K->table_ch);
+}
+void pkey_load_stats(const ProvingKey* K, double* out5) { memcpy(out5, K->load_ms, sizeof K->load_ms); }
+void pkey_shard_info(const ProvingKey* K, uint32_t* rank, uint32_t* world, uint64_t* lo, uint64_t* n_local, uint64_t* h_local, uint32_t* h_log_m) {
+    if (rank) *rank = K->shard_rank;
+    if (world) *world = K->shard_world;
+    if (lo) *lo = K->lo;
+    if (n_local) *n_local = K->n_local;
+    if (h_local) *h_local = K->h_local;
+    if (h_log_m) *h_log_m = K->h_log_m;
 }
 
 // serial EC sum of Jacobian-Montgomery partials: the main-thread gather loop of the reference
@@ -256,7 +329,13 @@ struct MsmSums {
 static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard sh, MsmSums* out, hipStream_t s,
                       const std::function<void(const MsmSums&)>& after_ab1 = nullptr, bool skip_h = false) {
     Trace tr;
-    const uint32_t nv = K->n_vars, dom = K->domain;
+    // a points-sharded key sums its own pairs: the witness slice [lo, lo + n_local) against the resident slice of every
+    // section (all windows), h[hlo ..] against its hExps slice
+    const uint32_t nv = K->n_local, dom = K->domain;
+    const Fe* d_witness_all = d_witness;
+    d_witness += K->lo;
+    if (K->shard_world > 1 && (sh.off != 0 || sh.stride != 1)) { set_last_error("prove: a points-sharded key cannot be window-sharded as well"); return WS_ERR_ARG; }
+    if (K->h_log_m && !skip_h) { set_last_error("prove: this handle holds an interleaved hExps slice (distributed CALC_H only)"); return WS_ERR_ARG; }
     int rc;
     // WSNARK_PROVE_OVERLAP: 0 = one queue; 1 = the second queue (CALC_H, H) is released when the first batched tail starts;
     // 2 (default) = released at once.  Round-2 sweep on the dense 2^20 key, after the finish-order fix below:
@@ -339,10 +418,10 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
     if (s2 != s) WS_HIP_CHECK(hipStreamWaitEvent(s2, overlap == 2 ? L.ev_start : L.ev_tail, 0));
     WS_HIP_CHECK(L.h.reserve((size_t)dom * 32));
     Fe* d_h = L.h.as<Fe>();
-    if ((rc = calc_h_dev(L, d_witness, nv, K->polsA, K->polsB, dom, d_h, s2))) return rc;
+    if ((rc = calc_h_dev(L, d_witness_all, K->n_vars, K->polsA, K->polsB, dom, d_h, s2))) return rc;
     tr.mark("calc_h enqueued");
     msm_select_plan(L, s2 != s ? 1 : 0);
-    rc = msm_plan_dev(L, d_h, dom, sh, s2, K->table_ch);
+    rc = msm_plan_dev(L, d_h + K->hlo, K->h_local, sh, s2, K->table_ch);
     if (!rc) rc = msm_g1_launch(L, K->pointsH.as<Affine<Fq>>(), true, &hH, s2);                           // :614
     msm_select_plan(L, 0);
     if (rc) return rc;
@@ -490,6 +569,15 @@ static int upload_witness(ProvingKey* K, Lane& L, const uint8_t* witness) {
 // ---- multi-GPU proving: per-rank partial sums, then one 576-byte record per rank to combine ----
 // record = A | B1 | C | H (4 x 96 B G1) | B2 (192 B G2), Jacobian-Montgomery, affine-normalised
 static int prove_partial_on(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard sh, uint8_t* out576, hipStream_t s, bool skip_h) {
+    if (K->shard_world > 1) {
+        // the handle IS the shard (its slice of the points, every window): the per-call rank / world must name the same one
+        if (sh.off != K->shard_rank || sh.stride != K->shard_world) {
+            set_last_error("prove_partial: the handle holds points shard " + std::to_string(K->shard_rank) + " of " + std::to_string(K->shard_world) +
+                           ", the call names " + std::to_string(sh.off) + " of " + std::to_string(sh.stride));
+            return WS_ERR_ARG;
+        }
+        sh = WindowShard{};
+    }
     MsmSums M;
     int rc = prove_msms(K, L, d_witness, sh, &M, s ? s : L.stream, nullptr, skip_h);
     if (rc) return rc;
@@ -550,11 +638,38 @@ int groth16_prove_finish(ProvingKey* K, const uint8_t* partials, uint64_t n_rank
     return WS_OK;
 }
 
+static int whole_key_only(ProvingKey* K) {
+    if (K->shard_world > 1) { set_last_error("this handle holds a points shard of the key: use prove_partial + prove_finish"); return WS_ERR_ARG; }
+    return WS_OK;
+}
+
+// The H sum of a points-sharded key on its own (distributed CALC_H: the rank's slice of h in the layout the handle's hExps
+// slice was loaded in).  out96: Jacobian-Montgomery, affine-normalised.
+int pkey_h_msm_dev(ProvingKey* K, const Fe* d_h_local, uint64_t n, uint8_t* out96, hipStream_t s) {
+    Context* C = ctx();
+    if (!C) return WS_ERR_NOINIT;
+    if (n != K->h_local) { set_last_error("pkey_h_msm: the handle holds " + std::to_string(K->h_local) + " hExps points"); return WS_ERR_SIZE; }
+    LaneLock L = acquire_lane(C);
+    if (!s) s = L->stream;
+    msm_select_plan(*L, 0);
+    int rc = msm_plan_dev(*L, d_h_local, n, WindowShard{}, s, K->table_ch);
+    if (rc) return rc;
+    int slot = -1;
+    if ((rc = msm_g1_launch(*L, K->pointsH.as<Affine<Fq>>(), true, &slot, s))) return rc;
+    XYZZ<Fq> r;
+    if ((rc = msm_g1_finish(*L, slot, &r))) return rc;
+    const Jac<Fq> j = G1::to_affine_jac(r);
+    memcpy(out96, &j, 96);
+    return WS_OK;
+}
+
 int groth16_prove_host_witness(ProvingKey* K, const uint8_t* witness, size_t witness_len, const uint8_t* r32,
                                const uint8_t* s32, uint8_t* out384) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
-    int rc = check_witness_len(K, witness_len);
+    int rc = whole_key_only(K);
+    if (rc) return rc;
+    rc = check_witness_len(K, witness_len);
     if (rc) return rc;
     LaneLock L = acquire_lane(C);
     if ((rc = upload_witness(K, *L, witness))) return rc;
@@ -565,7 +680,9 @@ int groth16_prove_dev_witness(ProvingKey* K, const Fe* d_witness, size_t witness
                               const uint8_t* s32, uint8_t* out384, hipStream_t s) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
-    int rc = check_witness_len(K, witness_len);
+    int rc = whole_key_only(K);
+    if (rc) return rc;
+    rc = check_witness_len(K, witness_len);
     if (rc) return rc;
     LaneLock L = acquire_lane(C);
     return groth16_prove(K, *L, d_witness, r32, s32, out384, s);

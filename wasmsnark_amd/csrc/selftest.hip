@@ -300,4 +300,116 @@ int selftest_curve(int g, int impl, int op, const uint8_t* p, const uint8_t* q, 
     return WS_ERR_ARG;
 }
 
+// ---- peak probes (bench.py: the integer roofline's peak, re-measured on the box the run is on) ----
+// probe 0: every lane runs one dependent chain of the PRODUCT'S OWN radix-2^29 Montgomery product (Fq29::mul, the
+//          function the accumulation kernels call): what a kernel made of nothing but products reaches = the "multiplier
+//          peak" in Gmodmul/s.  probe 1: the same with the inlined body (Fq29I).  probe 2: eight independent chains of
+//          v_mad_u64_u32 per lane: the raw multiply-add issue rate in Gmad/s.
+template <class F>
+__global__ __launch_bounds__(256) void probe_modmul_kernel(const Fe* __restrict__ in, Fe* __restrict__ out, int iters) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    typename F::El x = F::to_internal(in[t]);
+    const typename F::El y = x;
+    for (int i = 0; i < iters; i++) x = F::mul(x, y);
+    out[t] = F::from_internal(x);
+}
+__global__ __launch_bounds__(256) void probe_mad_kernel(uint64_t* __restrict__ out, uint32_t a, uint32_t b, int iters) {
+    uint64_t c0 = threadIdx.x, c1 = c0 + 1, c2 = c0 + 2, c3 = c0 + 3, c4 = c0 + 4, c5 = c0 + 5, c6 = c0 + 6, c7 = c0 + 7;
+    uint32_t x = a + threadIdx.x, y = b;
+    for (int i = 0; i < iters; i++) {
+        c0 = (uint64_t)x * y + c0; c1 = (uint64_t)x * y + c1; c2 = (uint64_t)x * y + c2; c3 = (uint64_t)x * y + c3;
+        c4 = (uint64_t)x * y + c4; c5 = (uint64_t)x * y + c5; c6 = (uint64_t)x * y + c6; c7 = (uint64_t)x * y + c7;
+        x = (uint32_t)c0; y = (uint32_t)(c7 >> 32) | 1;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5 ^ c6 ^ c7;
+}
+// probes 3 / 4: traffic calibration for the FETCH_SIZE counter (the guide: "calibrate on a known byte count in your own
+// access pattern").  3 = the accumulation kernel's pattern: every lane gathers 64-byte points (one AffP load, as
+// msm_accumulate does) at pseudo-random indices of a 1 GiB table -- far beyond the 256 MiB Infinity Cache -- 2^25 gathers
+// = 2 GiB of known algorithmic bytes (sector granularity 64 B: nothing to over-fetch).  4 = a streaming read of the same
+// table, 16 B per lane and load: the pattern the guide's x2 correction was measured on.  Result: GB/s of known bytes.
+__global__ __launch_bounds__(256) void probe_gather64_kernel(const Affine<Fq>* __restrict__ table, uint32_t mask, uint32_t per_lane,
+                                                              uint64_t* __restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t idx = t * 2654435761u;
+    uint64_t acc = 0;
+    for (uint32_t k = 0; k < per_lane; k++) {
+        idx = idx * 1664525u + 1013904223u;
+        const Affine<Fq> p = table[idx & mask];
+        acc += p.x.l[0] ^ p.x.l[3] ^ p.y.l[1] ^ p.y.l[2];
+    }
+    out[t] = acc;
+}
+__global__ __launch_bounds__(256) void probe_stream16_kernel(const uint4* __restrict__ src, uint64_t n16, uint64_t* __restrict__ out) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t acc = 0;
+    for (uint64_t i = t; i < n16; i += stride) { const uint4 v = src[i]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+    out[t] = acc;
+}
+static int traffic_probe(Context* C, int probe, double* gbs) {
+    hipStream_t s = C->stream;
+    const size_t table_bytes = (size_t)1 << 30;
+    const uint32_t n_pts = (uint32_t)(table_bytes / 64);
+    DevBuf table, out;
+    WS_HIP_CHECK(table.alloc(table_bytes));
+    WS_HIP_CHECK(hipMemsetAsync(table.p, 0x5a, table_bytes, s));
+    const uint32_t lanes = 1u << 20, per_lane = 32;
+    WS_HIP_CHECK(out.alloc((size_t)lanes * 8));
+    hipEvent_t a = nullptr, b = nullptr;
+    WS_HIP_CHECK(hipEventCreate(&a));
+    WS_HIP_CHECK(hipEventCreate(&b));
+    double best = 0;
+    for (int rep = 0; rep < 3; rep++) {
+        (void)hipEventRecord(a, s);
+        if (probe == 3) hipLaunchKernelGGL(probe_gather64_kernel, dim3(lanes / 256), dim3(256), 0, s, table.as<Affine<Fq>>(), n_pts - 1, per_lane, out.as<uint64_t>());
+        else hipLaunchKernelGGL(probe_stream16_kernel, dim3(lanes / 256), dim3(256), 0, s, table.as<uint4>(), (uint64_t)(table_bytes / 16), out.as<uint64_t>());
+        (void)hipEventRecord(b, s);
+        if (hipEventSynchronize(b) != hipSuccess) break;
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, a, b);
+        const double bytes = probe == 3 ? (double)lanes * per_lane * 64 : (double)table_bytes;
+        if (ms > 0 && bytes / ms / 1e6 > best) best = bytes / ms / 1e6;
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    WS_HIP_CHECK(hipGetLastError());
+    *gbs = best;
+    return WS_OK;
+}
+
+int peak_probe(int probe, double* gops) {
+    Context* C = ctx();
+    if (!C) return WS_ERR_NOINIT;
+    if (!gops || probe < 0 || probe > 4) return WS_ERR_ARG;
+    if (probe >= 3) return traffic_probe(C, probe, gops);
+    hipStream_t s = C->stream;
+    const uint32_t blocks = (uint32_t)C->num_cu * 8, threads = 256, total = blocks * threads;
+    DevBuf in, out;
+    WS_HIP_CHECK(in.alloc((size_t)total * 32));
+    WS_HIP_CHECK(out.alloc((size_t)total * 32));
+    WS_HIP_CHECK(hipMemsetAsync(in.p, 0x11, (size_t)total * 32, s));
+    hipEvent_t a = nullptr, b = nullptr;
+    WS_HIP_CHECK(hipEventCreate(&a));
+    WS_HIP_CHECK(hipEventCreate(&b));
+    const int iters = probe == 2 ? 20000 : 2000;
+    double best = 0;
+    for (int rep = 0; rep < 4; rep++) {          // the first repetition warms the clocks; the best of the rest counts
+        (void)hipEventRecord(a, s);
+        if (probe == 0) hipLaunchKernelGGL(probe_modmul_kernel<Fq29>, dim3(blocks), dim3(threads), 0, s, in.as<Fe>(), out.as<Fe>(), iters);
+        else if (probe == 1) hipLaunchKernelGGL(probe_modmul_kernel<Fq29I>, dim3(blocks), dim3(threads), 0, s, in.as<Fe>(), out.as<Fe>(), iters);
+        else hipLaunchKernelGGL(probe_mad_kernel, dim3(blocks), dim3(threads), 0, s, out.as<uint64_t>(), 12345u, 777u, iters);
+        (void)hipEventRecord(b, s);
+        if (hipEventSynchronize(b) != hipSuccess) break;
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, a, b);
+        const double ops = (probe == 2 ? 8.0 : 1.0) * iters * (double)total;
+        if (rep && ms > 0 && ops / ms / 1e6 > best) best = ops / ms / 1e6;
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    WS_HIP_CHECK(hipGetLastError());
+    *gops = best;
+    return WS_OK;
+}
+
 }  // namespace wsnark

@@ -16,7 +16,13 @@
 //   * ONE final exponentiation of the product of the four Miller values by plain square-and-multiply with the
 //     2790-bit exponent (p^12 - 1)/r: no Frobenius constants anywhere.
 // Host arithmetic (field.h / fp2.h, the same headers the proof assembly uses); ~30 ms per verification on one core.
-// Like the reference, no subgroup / on-curve checks are made on the proof points.
+// "Same verdict under any pairing" holds for points of G1 x G2 only: for a B on the twist but outside the order-r
+// subgroup, or for off-curve coordinates, neither this map nor the reference's is bilinear and the two could disagree
+// (ADVICE r2).  The reference makes no such checks (its verdict on malformed points is an accident of its Miller loop);
+// here every proof and key point must satisfy its curve equation and every G2 point must be killed by r, otherwise the
+// proof is INVALID (*valid = 0) before any pairing is evaluated.  Like the reference (setG1Affine / setG2Affine force
+// z = 1, src/bn128.js:741-760) the z coordinates of the proof are ignored: (x, y) is the point, so the (0, 1, 0) a
+// prover prints for infinity is the off-curve point (0, 1) and makes the proof invalid.
 #include <string.h>
 
 #include "../../include/wsnark.h"
@@ -149,19 +155,35 @@ bool load_fq(const uint8_t* p, Fe* out) {
     *out = Fq::to_mont(v);
     return true;
 }
-// (x, y, z) plain triple as wsnark_groth16_prove writes it: z == 0 -> infinity, else affine (z == 1)
+// (x, y[, z]) plain coordinates; the z of a proof element must be a reduced field element but is otherwise ignored
+// (the reference forces z = 1).  Key points (no z): (0, 0) stands for infinity, as in proving keys.
 bool load_g1(const uint8_t* p, bool has_z, G1A* out) {
     Fe z = Fq::one();
     if (!load_fq(p, &out->x) || !load_fq(p + 32, &out->y) || (has_z && !load_fq(p + 64, &z))) return false;
-    out->inf = Fq::is_zero(z) || (!has_z && Fq::is_zero(out->x) && Fq::is_zero(out->y));
+    out->inf = !has_z && Fq::is_zero(out->x) && Fq::is_zero(out->y);
     return true;
 }
 bool load_g2(const uint8_t* p, bool has_z, G2A* out) {
     F2 z = Fq2::one();
     if (!load_fq(p, &out->x.c0) || !load_fq(p + 32, &out->x.c1) || !load_fq(p + 64, &out->y.c0) || !load_fq(p + 96, &out->y.c1)) return false;
     if (has_z && (!load_fq(p + 128, &z.c0) || !load_fq(p + 160, &z.c1))) return false;
-    out->inf = Fq2::is_zero(z) || (!has_z && Fq2::is_zero(out->x) && Fq2::is_zero(out->y));
+    out->inf = !has_z && Fq2::is_zero(out->x) && Fq2::is_zero(out->y);
     return true;
+}
+// y^2 == x^3 + 3 (G1 has cofactor 1: on the curve is in the group)
+bool g1_ok(const G1A& P) {
+    if (P.inf) return true;
+    const Fe three = Fq::to_mont(Fe{{3, 0, 0, 0}});
+    return Fq::eq(Fq::sqr(P.y), Fq::add(Fq::mul(Fq::sqr(P.x), P.x), three));
+}
+// on the twist y^2 == x^3 + 3/(9 + u) (src/bn128/build_bn128.js:79-90) AND in the order-r subgroup: [r] Q == O
+bool g2_ok(const G2A& Q) {
+    if (Q.inf) return true;
+    static const F2 b2 = Fq2::mul(F2{Fq::to_mont(Fe{{3, 0, 0, 0}}), Fq::zero()}, Fq2::inv(F2{Fq::to_mont(Fe{{9, 0, 0, 0}}), Fq::one()}));
+    if (!Fq2::eq(Fq2::sqr(Q.y), Fq2::add(Fq2::mul(Fq2::sqr(Q.x), Q.x), b2))) return false;
+    const Fe r = Fr::modulus();
+    const G2::Pt rq = G2::mul_bytes(G2::Pt{Q.x, Q.y, Fq2::one(), Fq2::one()}, reinterpret_cast<const uint8_t*>(&r), 32);
+    return G2::is_inf(rq);
 }
 
 }  // namespace
@@ -169,7 +191,8 @@ bool load_g2(const uint8_t* p, bool has_z, G2A* out) {
 // vk: alfa1 (64 B) | beta2 (128 B) | gamma2 (128 B) | delta2 (128 B) | IC[0 .. n_inputs] (64 B each); all affine, PLAIN LE.
 int groth16_verify(const uint8_t* vk, size_t vk_len, const uint8_t* inputs, uint64_t n_inputs, const uint8_t* proof384, int* valid) {
     *valid = 0;
-    if (vk_len < 448 + (n_inputs + 1) * 64) { set_last_error("verification key has fewer IC points than inputs + 1"); return WS_ERR_SIZE; }
+    // (compared without the multiplication: (n_inputs + 1) * 64 wraps for n_inputs near 2^58)
+    if (vk_len < 512 || n_inputs > (vk_len - 448) / 64 - 1) { set_last_error("verification key has fewer IC points than inputs + 1"); return WS_ERR_SIZE; }
     G1A alfa1, A, C;
     G2A beta2, gamma2, delta2, B;
     if (!load_g1(vk, false, &alfa1) || !load_g2(vk + 64, false, &beta2) || !load_g2(vk + 192, false, &gamma2) ||
@@ -178,11 +201,14 @@ int groth16_verify(const uint8_t* vk, size_t vk_len, const uint8_t* inputs, uint
         set_last_error("verify: a coordinate is not a reduced field element");
         return WS_ERR_FORMAT;
     }
+    // malformed points: invalid, before anything is paired (see the header)
+    if (!g1_ok(alfa1) || !g1_ok(A) || !g1_ok(C) || !g2_ok(beta2) || !g2_ok(gamma2) || !g2_ok(delta2) || !g2_ok(B)) return WS_OK;
     // IC(inputs) = IC[0] + sum input_i * IC[i+1]   (src/bn128.js:765-777; an input >= r makes the proof invalid, :772)
     G1::Pt acc = G1::infinity();
     for (uint64_t i = 0; i <= n_inputs; i++) {
         G1A ic;
         if (!load_g1(vk + 448 + i * 64, false, &ic)) { set_last_error("verify: IC coordinate not reduced"); return WS_ERR_FORMAT; }
+        if (!g1_ok(ic)) return WS_OK;
         G1::Pt pt = ic.inf ? G1::infinity() : G1::Pt{ic.x, ic.y, Fq::one(), Fq::one()};
         if (i > 0) {
             Fe s;

@@ -209,6 +209,20 @@ def pkey_bin_to_json(b: bytes) -> dict:
     }
 
 
+def pkey_bin_to_sections(b: bytes) -> dict:
+    """proving_key.bin -> the separate sections wsnark_pkey_load_sections / wsnark_pkey_load_shard take (true section
+    bounds from the header, tools/buildpkey.js:124-186; the reference itself slices over-long, src/bn128.js:592-593)."""
+    if len(b) < 488:
+        raise FormatError("proving key shorter than its fixed header")
+    nv, npub, dom, pPA, pPB, pA, pB1, pB2, pC, pH = struct.unpack_from("<10I", b, 0)
+    if npub + 1 > nv or not (488 <= pPA <= pPB <= pA) or pH + dom * 64 > len(b) or pB2 + nv * 128 > len(b):
+        raise FormatError("proving key: section offsets out of range")
+    return {"n_vars": nv, "n_public": npub, "domain": dom, "alfa1": b[40:104], "beta1": b[104:168], "delta1": b[168:232],
+            "beta2": b[232:360], "delta2": b[360:488], "polsA": b[pPA:pPB], "polsB": b[pPB:pA],
+            "pointsA": b[pA:pA + nv * 64], "pointsB1": b[pB1:pB1 + nv * 64], "pointsB2": b[pB2:pB2 + nv * 128],
+            "pointsC": b[pC:pC + (nv - npub - 1) * 64], "pointsH": b[pH:pH + dom * 64]}
+
+
 def proof_from_bytes(p: bytes) -> dict:
     """The 384-byte proof record of wsnark_groth16_prove (12 plain LE 256-bit integers) -> the reference's
     proof object of decimal strings (src/bn128.js:714-718)."""

@@ -24,16 +24,12 @@ function proofFromBytes(ab) {       // bin2g1 / bin2g2, src/bn128.js:329-351, 71
     return { pi_a: [v[0], v[1], v[2]], pi_b: [[v[3], v[4]], [v[5], v[6]], [v[7], v[8]]], pi_c: [v[9], v[10], v[11]] };
 }
 
-/* cheap fingerprint of a key buffer: its length, its fixed header (10 x u32 + alfa1 .. delta2) and 64 words spread over
- * the rest -- enough to notice that a cached handle no longer describes the bytes the caller is holding */
-function fingerprint(u8) {
-    let h = 0x811c9dc5 ^ u8.length;
-    const mix = (b) => { h = Math.imul(h ^ b, 0x01000193) >>> 0; };
-    const head = Math.min(u8.length, 488);
-    for (let i = 0; i < head; i++) mix(u8[i]);
-    const step = Math.max(1, Math.floor((u8.length - head) / 64));
-    for (let o = head; o + 4 <= u8.length; o += step) { mix(u8[o]); mix(u8[o + 1]); mix(u8[o + 2]); mix(u8[o + 3]); }
-    return h;
+/* digest of a key buffer -- ALL of its bytes (addon.hashBytes, off the event loop; < 0.1 s for a 0.6 GB key): enough to
+ * notice that a cached handle no longer describes the bytes the caller is holding, wherever they were rewritten.  The
+ * reference re-parses pkey inside every call (src/bn128.js:581-604); a caller that wants no per-call pass over the key at
+ * all holds the handle of loadKey() and passes that instead of the bytes. */
+async function digest(u8) {
+    return Buffer.from(await addon.hashBytes(u8)).toString("hex");
 }
 function asBytes(x) {
     if (x instanceof ArrayBuffer) return new Uint8Array(x);
@@ -46,11 +42,13 @@ class Bn128 {
         this.deviceInfo = deviceInfo;
         // proving-key OBJECT (the exact ArrayBuffer / view the caller passed) -> {handle, byteOffset, byteLength, fp}.
         // Two views of one ArrayBuffer (sub-arrays of a bundle, Node's pooled small Buffers) are different keys here,
-        // and a cached handle is only reused while offset, length and fingerprint still match; the reference re-reads
-        // pkey on every call (src/bn128.js:581-604) -- callers that want no check at all hold the handle of loadKey().
+        // and a cached handle is only reused while offset, length and the digest of the WHOLE buffer still match; the
+        // reference re-reads pkey on every call (src/bn128.js:581-604) -- callers that want no check at all hold the
+        // handle of loadKey().
         this._keys = new WeakMap();
         this._pr = null;     // blinding values of the last proof, "for tests" like the reference (src/bn128.js:662-664)
         this._ps = null;
+        this._live = true;
     }
     g1_multiexp(scalars, points) { return addon.g1Multiexp(scalars, points); }
     g2_multiexp(scalars, points) { return addon.g2Multiexp(scalars, points); }
@@ -61,7 +59,7 @@ class Bn128 {
     async loadKey(pkey) {
         if (pkey !== null && typeof pkey === "object" && !(pkey instanceof ArrayBuffer) && !ArrayBuffer.isView(pkey)) return pkey;   // already a handle
         const u8 = asBytes(pkey);
-        const fp = fingerprint(u8);
+        const fp = await digest(u8);
         const hit = this._keys.get(pkey);
         if (hit && hit.byteOffset === u8.byteOffset && hit.byteLength === u8.byteLength && hit.fp === fp) return hit.handle;
         const handle = await addon.loadKey(pkey);
@@ -92,8 +90,15 @@ class Bn128 {
         const pf = le32cat([].concat(proof.pi_a, proof.pi_b[0], proof.pi_b[1], proof.pi_b[2], proof.pi_c));
         return addon.verify(vk, le32cat(vals), pf);
     }
-    terminate() { addon.shutdown(); }
+    /* src/bn128.js:562-566.  The GPU context is process-wide (one per addon): it is shut down when the LAST live Bn128
+     * object terminates, so one object's terminate() does not pull the device out from under another's proofs. */
+    terminate() {
+        if (!this._live) return;
+        this._live = false;
+        if (--liveInstances === 0) addon.shutdown();
+    }
 }
+let liveInstances = 0;
 function le32cat(list) {            // decimal strings / BigInts -> concatenated 32-byte little-endian integers
     const out = new Uint8Array(32 * list.length);
     list.forEach((x, k) => { let v = BigInt(x); for (let i = 0; i < 32; i++) { out[32 * k + i] = Number(v & 0xffn); v >>= 8n; } });
@@ -105,6 +110,7 @@ let singleton = null;
  * thread-emulator build; nothing else should: there is no CPU path in the product. */
 async function buildBn128(device, opts) {
     const info = addon.init(device === undefined || device === null ? -1 : device, opts && opts.lib ? String(opts.lib) : undefined);
+    liveInstances++;
     return new Bn128(info);
 }
 function groth16GenProof(witness, provingKey, cb) {   // main_bn128.js:26-39
