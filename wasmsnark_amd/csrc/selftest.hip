@@ -340,10 +340,11 @@ __global__ __launch_bounds__(256) void probe_gather64_kernel(const Affine<Fq>* _
     }
     out[t] = acc;
 }
-__global__ __launch_bounds__(256) void probe_stream16_kernel(const uint4* __restrict__ src, uint64_t n16, uint64_t* __restrict__ out) {
+struct alignas(16) Word16 { uint32_t x, y, z, w; };
+__global__ __launch_bounds__(256) void probe_stream16_kernel(const Word16* __restrict__ src, uint64_t n16, uint64_t* __restrict__ out) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
     uint64_t acc = 0;
-    for (uint64_t i = t; i < n16; i += stride) { const uint4 v = src[i]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+    for (uint64_t i = t; i < n16; i += stride) { const Word16 v = src[i]; acc += v.x ^ v.y ^ v.z ^ v.w; }
     out[t] = acc;
 }
 static int traffic_probe(Context* C, int probe, double* gbs) {
@@ -362,7 +363,7 @@ static int traffic_probe(Context* C, int probe, double* gbs) {
     for (int rep = 0; rep < 3; rep++) {
         (void)hipEventRecord(a, s);
         if (probe == 3) hipLaunchKernelGGL(probe_gather64_kernel, dim3(lanes / 256), dim3(256), 0, s, table.as<Affine<Fq>>(), n_pts - 1, per_lane, out.as<uint64_t>());
-        else hipLaunchKernelGGL(probe_stream16_kernel, dim3(lanes / 256), dim3(256), 0, s, table.as<uint4>(), (uint64_t)(table_bytes / 16), out.as<uint64_t>());
+        else hipLaunchKernelGGL(probe_stream16_kernel, dim3(lanes / 256), dim3(256), 0, s, table.as<Word16>(), (uint64_t)(table_bytes / 16), out.as<uint64_t>());
         (void)hipEventRecord(b, s);
         if (hipEventSynchronize(b) != hipSuccess) break;
         float ms = 0;
