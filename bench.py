@@ -165,14 +165,15 @@ def pmc_traffic(kernel, pairs_per_launch, windows):
     """HBM-side bytes per launch of `kernel`, measured out of band by tools/gpu_session.sh (rocprofv3 cannot wrap
     itself): two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) over this same command, summary committed."""
     # (two committed summaries: proofs on the table key -- 13 passes per launch at 2^20 -- and the plain 16-window launches)
-    for name in ("r02_pmc_traffic_table.json", "r02_pmc_traffic.json"):
+    for name in ("r03_s1_pmc_traffic_table.json", "r02_pmc_traffic_table.json", "r02_pmc_traffic.json"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
             k = pm["kernels"][kernel]
             shape = pm.get("msm_accumulate_shape") or {"pairs_per_launch": 1 << 20, "windows_per_launch": 16}
             if abs(pairs_per_launch - shape["pairs_per_launch"]) > 16 or windows != shape["windows_per_launch"]:
                 continue        # the committed summary was taken on another launch shape: not quoted
-            return k["fetch_bytes"] + k["write_bytes"], "profiles/%s: %s" % (name, pm.get("how", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bytes per launch"))
+            return k["fetch_bytes"] + k["write_bytes"], ("profiles/%s: %s; FETCH_SIZE calibrated on this access pattern (64-B point gathers out of a 1 GiB table: counter / known bytes = 1.00, "
+                                                         "profiles/r03_s1_pmc_calibration.json)" % (name, pm.get("how", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bytes per launch")))
         except Exception:  # noqa: BLE001
             continue
     return None, None
@@ -551,7 +552,10 @@ def cpu_baseline_prove(ctx, logd, circ, wit, sec):
         from wasmsnark_amd import synth
         if logd > 21:
             return {"skipped": "the oracle takes proving_key.bin (u32 offsets); the CPU leg is timed on the 2^20 workload only"}
-        cores = os.cpu_count() or 1
+        host_threads = os.cpu_count() or 1
+        # one worker per PHYSICAL core: the sums are integer-multiply bound, SMT siblings only add contention (measured on the
+        # 2 x 64-core box: 256 threads 39.2 s, 64 threads 24.0 s)
+        cores = max(1, host_threads // 2) if host_threads >= 16 else host_threads
         pkey = bytearray(synth.sections_to_pkey(sec))
         nv, dom = circ.n_vars, circ.domain
         r32, s32 = bytes(range(32)), bytes(range(32, 64))
@@ -574,7 +578,7 @@ def cpu_baseline_prove(ctx, logd, circ, wit, sec):
         t0 = time.perf_counter()
         orc.multiexp(2, "multiexp", wit[:n2 * 32], bytes(sec["pointsB2"][:n2 * 128]), n2)
         t_g2 = time.perf_counter() - t0
-        return {"value": round(t_all * 1e3, 1), "unit": "ms", "cores": cores, "host_cores": cores, "kind": "port",
+        return {"value": round(t_all * 1e3, 1), "unit": "ms", "cores": cores, "host_cores": host_threads, "kind": "port",
                 "sample": "one whole proof of the benchmark's own 2^%d circuit and witness (n_vars %d, nnz %d) by the oracle's groth16GenProof "
                           "restatement: every sum split over %d threads, CALC_H on one thread like the reference's worker; %.2f s"
                           % (logd, nv, circ.nnz, cores, t_all),

@@ -234,6 +234,32 @@ int wsnark_groth16_prove_partial_dev(wsnark_pkey_t* handle, const void* d_witnes
 int wsnark_groth16_prove_finish(wsnark_pkey_t* handle, const void* partials, uint64_t n_ranks, const void* r32,
                                 const void* s32, void* out384);
 
+/* ONE CALL per proof and rank for the whole multi-GPU prover (csrc/dist.hip): the rank's partial sums over its points shard,
+ * CALC_H on the distributed four-step transform (three all-to-alls per proof), the H sum over the rank's hExps share, one
+ * all-gather of the 576-byte records and the host-side assembly -- no host language between the kernels.  The library links
+ * no collectives library: the host passes its transport as two callbacks (torch.distributed on RCCL in
+ * wasmsnark_amd/dist.py; MPI, a thread pool, ... elsewhere):
+ *   d_send / d_recv  two device buffers of buf_bytes >= 3 * 32 * domain / world each, owned by the host side
+ *   all_to_all(user, bytes_per_rank, stream)   block q (bytes_per_rank bytes) of d_send goes to rank q, block q of d_recv comes
+ *                    from rank q; must be ORDERED ON `stream` (the library's kernels that fill d_send were enqueued on it and
+ *                    the ones that read d_recv follow on it) -- enqueue it there, or synchronise it; return 0 on success
+ *   all_gather(user, send, recv, bytes)        host memory: recv = the `bytes`-byte records of all ranks in rank order
+ * handle: the rank's points shard with h_interleave_log = floor(log2(domain) / 2) (wsnark_pkey_load_shard); world must be a
+ * power of two <= 2^floor(log2(domain) / 2).  world == 1: callbacks may be NULL (the exchange is the identity).  r32 / s32
+ * NULL: rank 0 draws the blinding values and they ride in its all-gather slot -- every rank returns the same proof.
+ * stream: the queue d_witness is ready on (NULL: the library's own). */
+typedef struct {
+    uint32_t rank, world;
+    void* d_send;
+    void* d_recv;
+    uint64_t buf_bytes;
+    int (*all_to_all)(void* user, uint64_t bytes_per_rank, void* stream);
+    int (*all_gather)(void* user, const void* send, void* recv, uint64_t bytes);
+    void* user;
+} wsnark_comm_t;
+int wsnark_groth16_prove_dist(wsnark_pkey_t* handle, const void* d_witness, size_t witness_len, const wsnark_comm_t* comm,
+                              const void* r32, const void* s32, void* out384_host, void* stream);
+
 /* ---- synthetic-input helpers: NO reference counterpart ----
  * out[i] = scalars[i] * base (affine Montgomery in and out; infinity written as all-zero bytes).
  * The reference ships no proving key (its test/data/proving_key.bin is absent), so benches and

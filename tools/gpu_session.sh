@@ -45,7 +45,7 @@ if ! skip sq; then
     echo "pmc sq$I rc=$?" >> "$O/env.log"
   done
   python tools/pmc_counters.py "$O/sq" > "$O/pmc_sq_counters.json" 2>> "$O/env.log"
-  find "$O/sq" -name "*.csv" -size +2M -delete 2>/dev/null
+  find "$O/sq" -name "*kernel_trace.csv" -size +2M -delete 2>/dev/null
 fi
 # FETCH_SIZE / WRITE_SIZE calibration on known byte counts (64-B gathers out of a 1 GiB table; a 16-B-per-lane stream)
 if ! skip calib; then

@@ -22,7 +22,7 @@ SYMBOLS = [
     "wsnark_pkey_eval_ab_dev", "wsnark_fr_mul_dev", "wsnark_fr_dist_combine_dev", "wsnark_fr_to_montgomery", "wsnark_fr_from_montgomery",
     "wsnark_calc_h", "wsnark_pkey_load", "wsnark_pkey_free", "wsnark_pkey_info", "wsnark_pkey_table_info",
     "wsnark_groth16_prove", "wsnark_groth16_prove_dev", "wsnark_pkey_load_sections", "wsnark_pkey_load_shard", "wsnark_pkey_shard_info", "wsnark_pkey_load_stats", "wsnark_pkey_h_msm_dev", "wsnark_last_blinding", "wsnark_groth16_verify",
-    "wsnark_groth16_prove_partial", "wsnark_groth16_prove_partial_dev", "wsnark_groth16_prove_finish",
+    "wsnark_groth16_prove_partial", "wsnark_groth16_prove_partial_dev", "wsnark_groth16_prove_finish", "wsnark_groth16_prove_dist",
     "wsnark_g1_mul_base_batch", "wsnark_g2_mul_base_batch",
     "wsnark_synth_new", "wsnark_synth_free", "wsnark_synth_info", "wsnark_synth_witness", "wsnark_synth_pols",
     "wsnark_synth_key_scalars", "wsnark_synth_expected",
@@ -96,6 +96,7 @@ class Lib:
         c.wsnark_pkey_h_msm_dev.argtypes = [vp, vp, u64, vp, vp]
         c.wsnark_groth16_prove_partial.argtypes = [vp, vp, sz, u32, u32, u32, vp]
         c.wsnark_groth16_prove_partial_dev.argtypes = [vp, vp, sz, u32, u32, u32, vp, vp]
+        c.wsnark_groth16_prove_dist.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp]
         c.wsnark_pkey_eval_ab_dev.argtypes = [vp, vp, sz, vp, vp, vp]
         c.wsnark_fr_mul_dev.argtypes = [vp, vp, vp, u64, vp]
         c.wsnark_fr_dist_combine_dev.argtypes = [vp, vp, vp, u64, u64, u64, u32, u32, vp]

@@ -28,6 +28,8 @@ struct KeyShard { uint32_t rank = 0, world = 1, h_log_m = 0; };
 int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard);
 void pkey_shard_info(const ProvingKey* K, uint32_t* rank, uint32_t* world, uint64_t* lo, uint64_t* n_local, uint64_t* h_local, uint32_t* h_log_m);
 void pkey_load_stats(const ProvingKey* K, double* out5);
+int groth16_prove_dist(ProvingKey* K, const Fe* d_witness, size_t witness_len, const DistComm& cm, const uint8_t* r32, const uint8_t* s32,
+                       uint8_t* out384, hipStream_t s);
 int pkey_h_msm_dev(ProvingKey* K, const Fe* d_h_local, uint64_t n, uint8_t* out96, hipStream_t s);
 int groth16_prove_partial(ProvingKey* K, const uint8_t* witness, size_t witness_len, WindowShard sh, uint8_t* out576, bool skip_h);
 int groth16_prove_partial_dev(ProvingKey* K, const Fe* d_witness, size_t witness_len, WindowShard sh, uint8_t* out576, hipStream_t s, bool skip_h);
@@ -301,6 +303,17 @@ int wsnark_groth16_prove_partial_dev(wsnark_pkey_t* h, const void* d_witness, si
     if (!h || !d_witness || !out576_host || !shard_ok(rank, world) || (flags & ~(uint32_t)WSNARK_PARTIAL_SKIP_H)) return WSNARK_ERR_ARG;
     return groth16_prove_partial_dev(reinterpret_cast<ProvingKey*>(h), (const Fe*)d_witness, witness_len, WindowShard{rank, world},
                                      (uint8_t*)out576_host, (hipStream_t)stream, (flags & WSNARK_PARTIAL_SKIP_H) != 0);
+}
+int wsnark_groth16_prove_dist(wsnark_pkey_t* h, const void* d_witness, size_t witness_len, const wsnark_comm_t* comm, const void* r32,
+                              const void* s32, void* out384_host, void* stream) {
+    REQUIRE_CTX();
+    if (!h || !d_witness || !comm || !out384_host) return WSNARK_ERR_ARG;
+    DistComm cm;
+    cm.rank = comm->rank; cm.world = comm->world;
+    cm.d_send = (Fe*)comm->d_send; cm.d_recv = (Fe*)comm->d_recv; cm.buf_bytes = comm->buf_bytes;
+    cm.all_to_all = comm->all_to_all; cm.all_gather = comm->all_gather; cm.user = comm->user;
+    return groth16_prove_dist(reinterpret_cast<ProvingKey*>(h), (const Fe*)d_witness, witness_len, cm, (const uint8_t*)r32, (const uint8_t*)s32,
+                              (uint8_t*)out384_host, (hipStream_t)stream);
 }
 int wsnark_pkey_eval_ab_dev(wsnark_pkey_t* h, const void* d_witness, size_t witness_len, void* d_a_out, void* d_b_out, void* stream) {
     REQUIRE_CTX();

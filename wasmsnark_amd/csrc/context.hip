@@ -85,6 +85,7 @@ void context_shutdown() {
             if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
         L.ntt_scratch.release();
         for (auto& b : L.calch_buf) b.release();
+        for (auto& b : L.dist_buf) b.release();
         L.host_in[0].release(); L.host_in[1].release();
         L.witness.release(); L.h.release();
         (void)hipStreamDestroy(L.stream);

@@ -1,0 +1,143 @@
+// dist.hip -- one proof over the ranks of one node, orchestrated behind the C ABI (wsnark_groth16_prove_dist).
+//
+// Reference shape: the reference's only parallel strategy is the worker split + gather of Bn128.g1_multiexp /
+// g2_multiexp (/root/reference src/bn128.js:353-415) driven from groth16GenProof (:607-622), with CALC_H on ONE worker
+// (:126-166).  Here the workers are GPUs, every rank holds a POINTS shard of the key (wsnark_pkey_load_shard: the
+// reference's own contiguous split), and CALC_H -- which the reference never parallelises -- runs as a distributed
+// four-step transform so that nothing but the two sparse-matrix structures is replicated:
+//
+//   queue 1   plan(witness slice) -> B2, A, B1, C partial sums over the rank's pairs           (prove.hip: prove_msms)
+//   queue 2   a, b = rows of A w, B w that this rank's slice needs (row-sharded sparse products, written directly in the
+//             layout the transform reads) -> E = a.b -> [iNTT of a, b, E: ONE exchange] -> [coset NTT of a, b: ONE
+//             exchange] -> O = a.b -> [iNTT of O: ONE exchange] -> h slice -> H partial sum over the rank's hExps slice
+//   host      ONE all-gather of the 576-byte records (+ rank 0's blinding bytes) -> prove_finish on every rank
+//
+// Four-step transform, n = n1 n2 (wasmsnark_amd/dist.py documents the layouts; this file is the same algorithm without
+// Python between the kernels):  X[k2 + n2 k1] = sum_i1 w_n1^(i1 k1) [ w_n^(i1 k2) sum_i2 x[i1 + n1 i2] w_n2^(i2 k2) ].
+// A rank holds r1 = n1 / P complete sub-sequences (rows i1, all i2): column step and twiddle are local; the pack kernel
+// applies the twiddle while it writes the send buffer in exactly the block order the exchange needs; after the exchange
+// the unpack kernel writes the (n2 / P) x n1 blocks the row step reads.  No permute().contiguous() round trips.
+//
+// Transport: the library does not link a collectives library.  The host passes two callbacks (all-to-all on device
+// buffers it owns, ordered on the stream the library names; all-gather of small host records) -- torch.distributed on
+// RCCL in wasmsnark_amd/dist.py, anything else a host has.
+#include <string.h>
+
+#include "../../include/wsnark.h"
+#include "internal.h"
+
+namespace wsnark {
+
+// res[(r, j)] = sum_k coef[k] * sig[col[k]] over row t = (row0 + r) + (j << log_n1) of the CSR matrix: pol_constructLC
+// (src/build_pol.js:62-144) for the rows of one rank's slice only, stored in the slice's own (rows x cols) layout
+__global__ __launch_bounds__(256) void lc_spmv_rows_kernel(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+                                                             const Fe* __restrict__ coef, const Fe* __restrict__ sig,
+                                                             uint64_t rows, uint64_t cols, uint64_t row0, uint32_t log_n1, Fe* __restrict__ res) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const uint64_t r = idx / cols, j = idx - r * cols;
+    const uint64_t t = (row0 + r) + (j << log_n1);
+    Fe acc = Fr::zero();
+    const uint32_t e = row_ptr[t + 1];
+    for (uint32_t k = row_ptr[t]; k < e; k++) acc = Fr::add(acc, Fr::mul(coef[k], sig[col[k]]));
+    res[idx] = acc;
+}
+
+// send[q][v][r][c2] = x[v][r][q r2 + c2] * w_n^(+-(row0 + r)(q r2 + c2)): twiddle + block order of the exchange in one pass
+__global__ __launch_bounds__(256) void dist_pack_kernel(const Fe* __restrict__ x, Fe* __restrict__ send, uint64_t k, uint64_t r1, uint64_t r2,
+                                                          uint64_t world, uint64_t row0, const Fe* __restrict__ lo, const Fe* __restrict__ hi, uint32_t h) {
+    const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= world * k * r1 * r2) return;
+    const uint64_t c2 = o % r2, t1 = o / r2, r = t1 % r1, t2 = t1 / r1, v = t2 % k, q = t2 / k;
+    const uint64_t c = q * r2 + c2, n2 = world * r2;
+    const uint64_t e = (row0 + r) * c;
+    const Fe f = Fr::mul(hi[e >> h], lo[e & (((uint64_t)1 << h) - 1)]);
+    send[o] = Fr::mul(x[(v * r1 + r) * n2 + c], f);
+}
+// y[v][c2][q r1 + r] = recv[q][v][r][c2]: the (n2 / P) x n1 blocks of the row step
+__global__ __launch_bounds__(256) void dist_unpack_kernel(const Fe* __restrict__ recv, Fe* __restrict__ y, uint64_t k, uint64_t r1, uint64_t r2, uint64_t world) {
+    const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t n1 = world * r1;
+    if (o >= k * r2 * n1) return;
+    const uint64_t i1 = o % n1, t1 = o / n1, c2 = t1 % r2, v = t1 / r2;
+    const uint64_t q = i1 / r1, r = i1 - q * r1;
+    y[o] = recv[((q * k + v) * r1 + r) * r2 + c2];
+}
+
+// fft_fft / fft_ifft (src/build_fft.js:159-221) of `k` stacked vectors spread over the ranks: x = the rank's k blocks of
+// r1 x n2 (n1-interleaved layout), overwritten; the result -- k blocks of r2 x n1, n2-interleaved -- is written to y.
+static int dist_ntt_native(Lane& L, const DistComm& cm, Fe* x, Fe* y, uint32_t log_n, uint32_t log_n1, int odd, int inverse, uint64_t k, hipStream_t s) {
+    const uint32_t log_n2 = log_n - log_n1;
+    const uint64_t n1 = (uint64_t)1 << log_n1, n2 = (uint64_t)1 << log_n2, P = cm.world;
+    const uint64_t r1 = n1 / P, r2 = n2 / P, row0 = (uint64_t)cm.rank * r1;
+    const uint64_t total = k * r1 * n2;
+    if (total * sizeof(Fe) > cm.buf_bytes) { set_last_error("prove_dist: exchange buffers too small"); return WS_ERR_SIZE; }
+    int rc;
+    if (odd && (rc = dist_scale_dev(x, k, r1, n2, row0, log_n1, log_n, 1, 0, s))) return rc;          // x[t] *= w_2n^t
+    if (log_n2 >= 1 && (rc = ntt_dev(L, x, n2, 0, inverse, s, k * r1))) return rc;                    // column step
+    const Fe *lo, *hi;
+    int h;
+    if ((rc = ntt_twiddle_tables((int)log_n, inverse, &lo, &hi, &h, s))) return rc;
+    Context* C = ctx();
+    C->timer.begin("dist_pack", s);
+    hipLaunchKernelGGL(dist_pack_kernel, dim3(ceil_div_u64(total, 256)), dim3(256), 0, s, x, cm.d_send, k, r1, r2, P, row0, lo, hi, (uint32_t)h);
+    C->timer.end(s);
+    WS_HIP_CHECK(hipGetLastError());
+    const Fe* recv = cm.d_send;                                                                        // a world of one: the exchange is the identity
+    if (P > 1) {
+        if (!cm.all_to_all || cm.all_to_all(cm.user, k * r1 * r2 * sizeof(Fe), (void*)s) != 0) { set_last_error("prove_dist: the all-to-all callback failed"); return WS_ERR_ARG; }
+        recv = cm.d_recv;
+    }
+    C->timer.begin("dist_unpack", s);
+    hipLaunchKernelGGL(dist_unpack_kernel, dim3(ceil_div_u64(total, 256)), dim3(256), 0, s, recv, y, k, r1, r2, P);
+    C->timer.end(s);
+    WS_HIP_CHECK(hipGetLastError());
+    if (log_n1 >= 1 && (rc = ntt_dev(L, y, n1, 0, inverse, s, k * r2))) return rc;                    // row step
+    return WS_OK;
+}
+
+// CALC_H (src/bn128.js:139-164) for the rank's slice: h[(r, j)] = h[(rank rows + r) + 2^l2 j] in plain form
+int calc_h_dist(Lane& L, const DistComm& cm, const Fe* d_signals_plain, uint32_t n_signals, const CsrMatrix& A, const CsrMatrix& B,
+                uint32_t domain, uint32_t l2_expected, Fe* d_h_local, hipStream_t s) {
+    Context* C = ctx();
+    if (!C) return WS_ERR_NOINIT;
+    if (domain < 2 || (domain & (domain - 1)) || domain > (1u << 27)) return WS_ERR_SIZE;
+    if (A.n_rows != domain || B.n_rows != domain || A.n_cols != n_signals || B.n_cols != n_signals) return WS_ERR_ARG;
+    uint32_t log_n = 0;
+    while ((1u << log_n) < domain) log_n++;
+    const uint32_t l1 = (log_n + 1) / 2, l2 = log_n - l1, P = cm.world;
+    if ((P & (P - 1)) || ((uint64_t)1 << l2) < P) { set_last_error("prove_dist: needs a power-of-two world size <= 2^floor(log2(domain)/2)"); return WS_ERR_SIZE; }
+    if (l2 != l2_expected) { set_last_error("prove_dist: the handle's hExps interleave does not match this domain (load the shard with h_interleave_log = floor(log2(domain) / 2))"); return WS_ERR_ARG; }
+    const uint64_t n_loc = domain / P;
+    ScratchGuard scratch_turn(L.calch_chain, s);
+    WS_HIP_CHECK(L.calch_buf[0].reserve((size_t)n_signals * sizeof(Fe)));
+    WS_HIP_CHECK(L.dist_buf[0].reserve((size_t)3 * n_loc * sizeof(Fe)));
+    WS_HIP_CHECK(L.dist_buf[1].reserve((size_t)3 * n_loc * sizeof(Fe)));
+    Fe* sigM = L.calch_buf[0].as<Fe>();
+    Fe* X = L.dist_buf[0].as<Fe>();
+    Fe* T = L.dist_buf[1].as<Fe>();
+    KernelTimer& Tm = C->timer;
+    int rc;
+    Tm.begin("fr_to_montgomery", s);
+    rc = fr_map_dev(d_signals_plain, sigM, n_signals, 1, s);                                          // bn128.js:139
+    Tm.end(s);
+    if (rc) return rc;
+    // a, b: only the rows of this rank's slice, in the l1-interleaved layout (rows i1 in the rank's range, all i2)
+    const uint64_t r1 = ((uint64_t)1 << l1) / P, c1 = (uint64_t)1 << (log_n - l1);
+    Tm.begin("lc_spmv", s);
+    hipLaunchKernelGGL(lc_spmv_rows_kernel, dim3(ceil_div_u64(n_loc, 256)), dim3(256), 0, s, A.row_ptr.as<uint32_t>(), A.col.as<uint32_t>(),
+                       A.coef.as<Fe>(), sigM, r1, c1, (uint64_t)cm.rank * r1, l1, X);
+    hipLaunchKernelGGL(lc_spmv_rows_kernel, dim3(ceil_div_u64(n_loc, 256)), dim3(256), 0, s, B.row_ptr.as<uint32_t>(), B.col.as<uint32_t>(),
+                       B.coef.as<Fe>(), sigM, r1, c1, (uint64_t)cm.rank * r1, l1, X + n_loc);
+    Tm.end(s);
+    WS_HIP_CHECK(hipGetLastError());
+    if ((rc = fr_mul_dev(X, X + n_loc, X + 2 * n_loc, n_loc, s))) return rc;                           // E = A.B on the domain
+    if ((rc = dist_ntt_native(L, cm, X, T, log_n, l1, 0, 1, 3, s))) return rc;                         // coefficients of a, b; e   (l2-interleaved)
+    if ((rc = dist_ntt_native(L, cm, T, X, log_n, l2, 1, 0, 2, s))) return rc;                         // odd-coset evaluations     (l1-interleaved)
+    if ((rc = fr_mul_dev(X, X + n_loc, X, n_loc, s))) return rc;                                       // O = A.B on the coset
+    if ((rc = dist_ntt_native(L, cm, X, T, log_n, l1, 0, 1, 1, s))) return rc;                         // o                          (l2-interleaved, like e)
+    const uint64_t rows = ((uint64_t)1 << l2) / P;
+    return dist_combine_dev(T + 2 * n_loc, T, d_h_local, rows, (uint64_t)1 << (log_n - l2), (uint64_t)cm.rank * rows, l2, log_n, s);
+}
+
+}  // namespace wsnark

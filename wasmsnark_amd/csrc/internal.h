@@ -73,6 +73,7 @@ struct Lane {
     DevBuf host_in[2];                          // host-pointer boundary: grow-only device copies of the caller's buffers
     DevBuf ntt_scratch;                         // ping-pong buffer of the multi-pass transforms
     DevBuf calch_buf[4];                        // sigM, A, B, E
+    DevBuf dist_buf[2];                         // distributed CALC_H: the rank's slices of (a, b, E), ping-pong (dist.hip)
     ScratchChain ntt_chain, calch_chain;        // who may touch ntt_scratch / calch_buf next (calls return before the GPU is done)
     DevBuf witness, h;                          // per-proof device buffers (grow-only)
     hipEvent_t ev_start = nullptr, ev_tail = nullptr, ev_h = nullptr;   // cross-queue ordering of one proof
@@ -199,5 +200,21 @@ int fr_mul_dev(const Fe* d_a, const Fe* d_b, Fe* d_out, uint64_t n, hipStream_t 
 int eval_ab_dev(Lane& L, const Fe* d_signals_plain, uint32_t n_signals, const CsrMatrix& A, const CsrMatrix& B, uint32_t domain,
                 Fe* d_a, Fe* d_b, hipStream_t s);
 int dist_combine_dev(const Fe* d_e, const Fe* d_o, Fe* d_h, uint64_t rows, uint64_t cols, uint64_t row0, uint32_t log_n1, uint32_t log_n, hipStream_t s);
+int dist_scale_dev(Fe* d_data, uint64_t stack, uint64_t rows, uint64_t cols, uint64_t row0, uint32_t log_n1, uint32_t log_n, int mode, int inverse, hipStream_t s);
+
+// ---- one proof over the ranks of a node (dist.hip) ----
+// The host's transport (include/wsnark.h: wsnark_comm_t): exchange buffers it owns and two callbacks.
+struct DistComm {
+    uint32_t rank = 0, world = 1;
+    Fe* d_send = nullptr;
+    Fe* d_recv = nullptr;
+    uint64_t buf_bytes = 0;
+    int (*all_to_all)(void* user, uint64_t bytes_per_rank, void* stream) = nullptr;
+    int (*all_gather)(void* user, const void* send, void* recv, uint64_t bytes) = nullptr;
+    void* user = nullptr;
+};
+// the rank's slice of h (plain form, 2^l2-interleaved rows of the rank), three exchanges
+int calc_h_dist(Lane& L, const DistComm& cm, const Fe* d_signals_plain, uint32_t n_signals, const CsrMatrix& A, const CsrMatrix& B,
+                uint32_t domain, uint32_t l2_expected, Fe* d_h_local, hipStream_t s);
 
 }  // namespace wsnark

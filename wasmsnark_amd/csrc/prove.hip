@@ -83,7 +83,7 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
         K->n_local = shard.rank == shard.world - 1 ? nv - K->lo : per;
         K->hlo = shard.rank * hper;
         K->h_local = shard.rank == shard.world - 1 ? dom - K->hlo : hper;
-        if (shard.world > 1 && shard.h_log_m) {
+        if (shard.h_log_m) {
             const uint64_t m = (uint64_t)1 << shard.h_log_m;
             if (shard.h_log_m > 27 || m > dom || (shard.world & (shard.world - 1)) || m % shard.world) {
                 set_last_error("proving key shard: the interleave 2^h_log_m must divide the domain and be a multiple of the (power-of-two) world size");
@@ -326,8 +326,11 @@ struct MsmSums {
 // with a full-width kernel runs 2-3x slower (the kernel timeline of one proof: profiles/r02_session25_prove_timeline.txt).
 // The host finishes each sum while the GPU works on the next ones; `after_ab1` (optional) runs on the host as soon
 // as A and B1 are known.
+// calc_h (optional): enqueues the computation of the h this handle's hExps share is summed against on the given queue
+// (the distributed CALC_H of dist.hip) instead of the whole CALC_H.
+typedef std::function<int(hipStream_t, Fe*)> CalcHFn;
 static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard sh, MsmSums* out, hipStream_t s,
-                      const std::function<void(const MsmSums&)>& after_ab1 = nullptr, bool skip_h = false) {
+                      const std::function<void(const MsmSums&)>& after_ab1 = nullptr, bool skip_h = false, const CalcHFn& calc_h = nullptr) {
     Trace tr;
     // a points-sharded key sums its own pairs: the witness slice [lo, lo + n_local) against the resident slice of every
     // section (all windows), h[hlo ..] against its hExps slice
@@ -335,7 +338,7 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
     const Fe* d_witness_all = d_witness;
     d_witness += K->lo;
     if (K->shard_world > 1 && (sh.off != 0 || sh.stride != 1)) { set_last_error("prove: a points-sharded key cannot be window-sharded as well"); return WS_ERR_ARG; }
-    if (K->h_log_m && !skip_h) { set_last_error("prove: this handle holds an interleaved hExps slice (distributed CALC_H only)"); return WS_ERR_ARG; }
+    if (K->h_log_m && !skip_h && !calc_h) { set_last_error("prove: this handle holds an interleaved hExps slice (distributed CALC_H only)"); return WS_ERR_ARG; }
     int rc;
     // WSNARK_PROVE_OVERLAP: 0 = one queue; 1 = the second queue (CALC_H, H) is released when the first batched tail starts;
     // 2 (default) = released at once.  Round-2 sweep on the dense 2^20 key, after the finish-order fix below:
@@ -418,7 +421,9 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
     if (s2 != s) WS_HIP_CHECK(hipStreamWaitEvent(s2, overlap == 2 ? L.ev_start : L.ev_tail, 0));
     WS_HIP_CHECK(L.h.reserve((size_t)dom * 32));
     Fe* d_h = L.h.as<Fe>();
-    if ((rc = calc_h_dev(L, d_witness_all, K->n_vars, K->polsA, K->polsB, dom, d_h, s2))) return rc;
+    if (calc_h) rc = calc_h(s2, d_h);
+    else rc = calc_h_dev(L, d_witness_all, K->n_vars, K->polsA, K->polsB, dom, d_h, s2);
+    if (rc) return rc;
     tr.mark("calc_h enqueued");
     msm_select_plan(L, s2 != s ? 1 : 0);
     rc = msm_plan_dev(L, d_h + K->hlo, K->h_local, sh, s2, K->table_ch);
@@ -638,6 +643,8 @@ int groth16_prove_finish(ProvingKey* K, const uint8_t* partials, uint64_t n_rank
     return WS_OK;
 }
 
+int groth16_prove_finish(ProvingKey* K, const uint8_t* partials, uint64_t n_ranks, const uint8_t* r32,
+                         const uint8_t* s32, uint8_t* out384);
 static int whole_key_only(ProvingKey* K) {
     if (K->shard_world > 1) { set_last_error("this handle holds a points shard of the key: use prove_partial + prove_finish"); return WS_ERR_ARG; }
     return WS_OK;
@@ -661,6 +668,49 @@ int pkey_h_msm_dev(ProvingKey* K, const Fe* d_h_local, uint64_t n, uint8_t* out9
     const Jac<Fq> j = G1::to_affine_jac(r);
     memcpy(out96, &j, 96);
     return WS_OK;
+}
+
+// One proof over the ranks of a node: this rank's partial sums (points shard), CALC_H on the distributed transform, one
+// all-gather of the records, the same host-side assembly on every rank.  r32 / s32 NULL: rank 0 draws the blinding values
+// and they travel in its slot of the all-gather, so that every rank returns the same proof.
+int groth16_prove_dist(ProvingKey* K, const Fe* d_witness, size_t witness_len, const DistComm& cm, const uint8_t* r32, const uint8_t* s32,
+                       uint8_t* out384, hipStream_t s) {
+    Context* C = ctx();
+    if (!C) return WS_ERR_NOINIT;
+    int rc = check_witness_len(K, witness_len);
+    if (rc) return rc;
+    if (cm.world == 0 || cm.rank >= cm.world || K->shard_world != cm.world || K->shard_rank != cm.rank) {
+        set_last_error("prove_dist: the handle must hold this communicator's points shard (wsnark_pkey_load_shard(rank, world, floor(log2(domain) / 2)))");
+        return WS_ERR_ARG;
+    }
+    if (!cm.d_send || (cm.world > 1 && (!cm.d_recv || !cm.all_to_all || !cm.all_gather))) return WS_ERR_ARG;
+    uint8_t rec[640];
+    memset(rec, 0, sizeof rec);
+    {
+        LaneLock L = acquire_lane(C);
+        MsmSums M;
+        const CalcHFn calc_h = [&](hipStream_t s2, Fe* d_h) {
+            return calc_h_dist(*L, cm, d_witness, K->n_vars, K->polsA, K->polsB, K->domain, K->h_log_m, d_h, s2);
+        };
+        if ((rc = prove_msms(K, *L, d_witness, WindowShard{}, &M, s ? s : L->stream, nullptr, false, calc_h))) return rc;
+        Jac<Fq> j;
+        j = G1::to_affine_jac(M.A); memcpy(rec, &j, 96);
+        j = G1::to_affine_jac(M.B1); memcpy(rec + 96, &j, 96);
+        j = G1::to_affine_jac(M.C); memcpy(rec + 192, &j, 96);
+        j = G1::to_affine_jac(M.H); memcpy(rec + 288, &j, 96);
+        const Jac<Fq2> j2 = G2::to_affine_jac(M.B2); memcpy(rec + 384, &j2, 192);
+    }
+    const bool draw = !r32 || !s32;
+    if (draw && cm.rank == 0 && os_random(rec + 576, 64)) { set_last_error("cannot read /dev/urandom"); return WS_ERR_ARG; }
+    std::vector<uint8_t> all((size_t)cm.world * 640);
+    if (cm.world > 1) {
+        if (cm.all_gather(cm.user, rec, all.data(), 640) != 0) { set_last_error("prove_dist: the all-gather callback failed"); return WS_ERR_ARG; }
+    } else {
+        memcpy(all.data(), rec, 640);
+    }
+    std::vector<uint8_t> parts((size_t)cm.world * 576);
+    for (uint32_t i = 0; i < cm.world; i++) memcpy(&parts[(size_t)i * 576], &all[(size_t)i * 640], 576);
+    return groth16_prove_finish(K, parts.data(), cm.world, r32 ? r32 : &all[576], s32 ? s32 : &all[608], out384);
 }
 
 int groth16_prove_host_witness(ProvingKey* K, const uint8_t* witness, size_t witness_len, const uint8_t* r32,
