@@ -43,7 +43,7 @@ def kernel_ms(report, per=1):
     return {k: round(v[0] / max(per, 1), 4) for k, v in sorted(report.items())}
 
 
-def build_prover(bn, logd, style, seed=1, keep_h=False, container="auto"):
+def build_prover(bn, logd, style, seed=1, keep_h=False, container="auto", load=True):
     """Synthetic circuit + key (device-resident) + witness bytes.  Keys past the 4 GiB of proving_key.bin's u32 offsets
     (2^23 constraints and up) go through the sections loader.  The circuit comes from the library's host-side generator
     (csrc/synth.hip; same family as wasmsnark_amd/synth.py's Python generator, seconds instead of minutes)."""
@@ -53,6 +53,13 @@ def build_prover(bn, logd, style, seed=1, keep_h=False, container="auto"):
     sec, _ = circ.build_sections()
     use_sections = container == "sections" or (container == "auto" and logd >= 23)
     t1 = time.perf_counter()
+    if not load:      # N > 1: every rank loads only ITS shard of these sections (NativeDistProver); nothing whole is resident
+        wit = circ.witness_bin()
+        info = {"log_domain": logd, "n_vars": circ.n_vars, "n_public": circ.n_public, "nnz_A_plus_B": int(circ.nnz), "style": style,
+                "vars_absent_from_A_B": [int(x) for x in circ.absent],
+                "key_bytes": sum(len(v) for v in sec.values() if isinstance(v, (bytes, bytearray))), "key_container": "sections, points-sharded per rank",
+                "generator": "csrc/synth.hip (wsnark_synth_*)", "setup_s": round(time.perf_counter() - t0, 1), "_cold": {}, "_sections": sec}
+        return circ, None, wit, info
     if use_sections:
         key = bn.load_key(sections=sec)
         key_bytes = sum(len(v) for v in sec.values() if isinstance(v, (bytes, bytearray)))
@@ -95,9 +102,11 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="N>1 transport: nccl (= RCCL over xGMI; one GPU per rank) or gloo with host staging -- the latter lets "
                          "several ranks SHARE one GPU (functional check of the N>1 path on a one-GPU box; not a scaling measurement)")
-    ap.add_argument("--calc-h", choices=["replicated", "dist"], default="dist",
-                    help="N>1: 'dist' = CALC_H on the distributed four-step transform + points-sharded H sum (DistProver); "
-                         "'replicated' = every rank repeats the whole CALC_H (round 1)")
+    ap.add_argument("--calc-h", choices=["replicated", "dist", "native"], default="native",
+                    help="N>1: 'native' = wsnark_groth16_prove_dist: points-sharded key (1/N resident per rank), distributed CALC_H, one C call "
+                         "per proof with the transport as callbacks; 'dist' = the same algorithm orchestrated from Python on window shards of "
+                         "the whole key (DistProver); 'replicated' = every rank repeats the whole CALC_H (round 1).  A mode that fails or "
+                         "disagrees with the closed form on any rank falls through to the next one and the line says so")
     args = ap.parse_args()
 
     import torch
@@ -226,8 +235,8 @@ def bench_prove(ctx):
     args, bn, rank, world, dev, torch = ctx["args"], ctx["bn"], ctx["rank"], ctx["world"], ctx["dev"], ctx["torch"]
     from wasmsnark_amd import dist as wdist, synth
     logd = args.prove_log_domain
-    circ, key, wit, info = build_prover(bn, logd, args.circuit, keep_h=(world > 1 and args.calc_h == "dist"), container=args.key_container)
-    pkey_h_points = info.pop("h_points", None)
+    circ, key, wit, info = build_prover(bn, logd, args.circuit, container=args.key_container, load=(world == 1))
+    info.pop("h_points", None)
     cold = info.pop("_cold")
     sec = info.pop("_sections", None)
     r32, s32 = bytes(range(32)), bytes(range(32, 64))
@@ -244,35 +253,52 @@ def bench_prove(ctx):
     d_w = torch.frombuffer(bytearray(wit), dtype=torch.uint8).to(dev)
     torch.cuda.synchronize()
 
-    dprover = None
-    if world > 1 and args.calc_h == "dist":
-        import struct as _st
-        ph = pkey_h_points if pkey_h_points is not None else None
-        dprover = wdist.DistProver(bn, key, ph, device=dev)
+    # N > 1: a ladder of orchestrations, each checked against the closed form on EVERY rank before it is timed.  None of them
+    # had run on RCCL when this was written (the build's boxes have one GPU; they are tested on gloo, with ranks sharing a
+    # GPU, and with a world of one): a mode that fails or disagrees anywhere falls through to the next and the line says so.
+    holder = {"key": key, "npv": None, "dp": None}
 
-    def step():
-        if dprover is not None:
-            return dprover.prove(d_w.data_ptr(), len(wit), r=r32, s=s32)
-        if world > 1:
-            return wdist.sharded_prove(bn, key, None, r=r32, s=s32, device=dev, d_witness=(d_w.data_ptr(), len(wit)))
-        return bn.groth16GenProof_dev(d_w.data_ptr(), len(wit), key, r=r32, s=s32)
+    def whole_key():
+        if holder["key"] is None:
+            holder["key"] = bn.load_key(sections=sec)
+        return holder["key"]
 
-    calc_h_mode = (args.calc_h if world > 1 else "single GPU")
-    if dprover is not None:
-        # the distributed CALC_H has only ever run on gloo + the CPU emulator and with a world of one (no multi-GPU node was
-        # available to the build): if it fails or disagrees with the closed form HERE, every rank falls back to the
-        # replicated CALC_H (round 1's path) and the line says so
-        ok_here, why = 1, ""
-        try:
-            ok_here = int(dprover.prove(d_w.data_ptr(), len(wit), r=r32, s=s32) == want)
-            why = "" if ok_here else "proof != closed form"
-        except Exception as ex:  # noqa: BLE001
-            ok_here, why = 0, repr(ex)
-        flag = torch.tensor([ok_here], dtype=torch.int32, device=(dev if ctx["dist"].get_backend() == "nccl" else "cpu"))
-        ctx["dist"].all_reduce(flag, op=ctx["dist"].ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            dprover = None
-            calc_h_mode = "replicated (distributed CALC_H disabled: %s)" % (why or "another rank failed")
+    def mode_native():
+        holder["npv"] = wdist.NativeDistProver(bn, sec, device=dev)
+        return lambda: holder["npv"].prove(d_w.data_ptr(), len(wit), r=r32, s=s32)
+
+    def mode_dist():
+        holder["dp"] = wdist.DistProver(bn, whole_key(), bytes(sec["pointsH"]), device=dev)
+        return lambda: holder["dp"].prove(d_w.data_ptr(), len(wit), r=r32, s=s32)
+
+    def mode_replicated():
+        k = whole_key()
+        return lambda: wdist.sharded_prove(bn, k, None, r=r32, s=s32, device=dev, d_witness=(d_w.data_ptr(), len(wit)))
+
+    calc_h_mode, fell = "single GPU", []
+    if world == 1:
+        step = lambda: bn.groth16GenProof_dev(d_w.data_ptr(), len(wit), key, r=r32, s=s32)
+    else:
+        ladder = [("native", mode_native), ("dist", mode_dist), ("replicated", mode_replicated)]
+        ladder = ladder[[m for m, _ in ladder].index(args.calc_h):]
+        step = None
+        for name, make in ladder:
+            ok_here, why = 1, ""
+            try:
+                cand = make()
+                ok_here = int(cand() == want)
+                why = "" if ok_here else "proof != closed form"
+            except Exception as ex:  # noqa: BLE001
+                ok_here, why = 0, repr(ex)[:300]
+            flag = torch.tensor([ok_here], dtype=torch.int32, device=(dev if ctx["dist"].get_backend() == "nccl" else "cpu"))
+            ctx["dist"].all_reduce(flag, op=ctx["dist"].ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                step, calc_h_mode = cand, name
+                break
+            fell.append("%s: %s" % (name, why or "another rank failed"))
+        if step is None:
+            raise RuntimeError("no N > 1 orchestration produced the closed-form proof on every rank: %s" % "; ".join(fell))
+    key = holder["key"]
     first = step()
     dt, kt, last = timed(ctx, step, args.steps, args.warmup)
     ok = bool(first == want and last == want)
@@ -302,13 +328,22 @@ def bench_prove(ctx):
     nv, dom = circ.n_vars, circ.domain
     peak = measure_peaks(bn) if world == 1 else None
     # passes over the points per sum: the rows of the key's fixed-base tables (13 at 2^20), or the windows of the plain method
-    if key.table["rows_w"] > 1:
-        W_all = key.table["rows_w"]
+    if calc_h_mode == "native":
+        # points shards: every rank sums its own n / N pairs over ALL rows of its shard's tables
+        sk = holder["npv"].key
+        W_own = sk.table["rows_w"] if sk.table["rows_w"] > 1 else (255 + 15) // 16
+        pairs = (3 * sk.shard["n_signals"] + sk.shard["n_hexps"]) / 4.0
+        shard_info = {"resident_table_bytes_this_rank": int(sk.table["bytes"]), "pairs_this_rank": int(sk.shard["n_signals"]),
+                      "hexps_this_rank": int(sk.shard["n_hexps"]), "table_rows": [sk.table["rows_w"], sk.table["rows_h"]]}
     else:
-        c_win = 16 if logd >= 20 else max(4, logd - 4)
-        W_all = (255 + c_win - 1) // c_win
-    W_own = len(range(rank, W_all, world))
-    pairs = (3 * nv + dom) / 4.0                       # msm_accumulate_g1 launches per proof: A, B1, C (nVars pairs) and H (domain pairs)
+        if key.table["rows_w"] > 1:
+            W_all = key.table["rows_w"]
+        else:
+            c_win = 16 if logd >= 20 else max(4, logd - 4)
+            W_all = (255 + c_win - 1) // c_win
+        W_own = len(range(rank, W_all, world))
+        pairs = (3 * nv + dom) / 4.0                   # msm_accumulate_g1 launches per proof: A, B1, C (nVars pairs) and H (domain pairs)
+        shard_info = None
     hbm, alu = rooflines(kt, "msm_accumulate_g1", pairs, W_own, 96, 10, peak)
     g2 = kt.get("msm_accumulate_g2")
     # algorithmic bytes of one proof
@@ -320,10 +355,12 @@ def bench_prove(ctx):
                                   "every variable present), key and witness resident in HBM, r and s injected" % logd
                                   if args.circuit == "columns" else
                                   "BN128 full Groth16 prove, synthetic 2^%d-constraint R1CS, round-1 sparse generator (1-2 terms per row)" % logd,
-                      "circuit": info, "parallelism": (("MSM windows sharded w %% %d == rank, " % world)
-                                                       + ("CALC_H on the distributed four-step NTT (3 all-to-alls per proof: 3 + 2 + 1 vectors of %d B per rank each), H sum points-sharded, "
-                                                          % ((world - 1) * (circ.domain // world // world) * 32) if calc_h_mode == "dist" else "CALC_H %s, " % calc_h_mode)
-                                                       + "1 all_gather of 576 B records per proof")
+                      "circuit": info, "parallelism": ((("key POINTS-sharded: 1/%d of every section resident per rank (wsnark_pkey_load_shard), one C call per proof "
+                                                         "(wsnark_groth16_prove_dist), " % world) if calc_h_mode == "native" else ("MSM windows sharded w %% %d == rank, " % world))
+                                                       + ("CALC_H on the distributed four-step NTT (3 all-to-alls per proof: 3 + 2 + 1 vectors of %d B per rank and peer), H sum points-sharded, "
+                                                          % ((circ.domain // world // world) * 32) if calc_h_mode in ("dist", "native") else "CALC_H %s, " % calc_h_mode)
+                                                       + "1 all_gather of 576 B records per proof"
+                                                       + ("; fell through: " + "; ".join(fell) if fell else ""))
                       + ("" if args.backend == "nccl" else " [transport gloo with host staging: ranks may share a GPU -- functional check, not a scaling figure]")
                       if world > 1 else "1 GPU, no collective", "lanes": int(os.environ.get("WSNARK_LANES", "2")), "device": bn.device_info},
            "proofs_match_toxic_waste_closed_form": ok,
@@ -334,6 +371,7 @@ def bench_prove(ctx):
                "ms": round(host_ms, 3), "proofs_per_s": round(1e3 / host_ms, 2), "steps": args.steps, "same_proof": host_ok,
                "over_resident_witness_ms": round(host_ms - ms, 3)},
            "cold": cold if world == 1 else None,
+           "shard": shard_info,
            "int_alu_peaks_this_run": peak,
            "prove_algorithmic_bytes": int(alg_bytes), "prove_algorithmic_GBps": round(alg_bytes / (ms / 1e3) / 1e9, 1),
            "prove_hbm_frac": round(alg_bytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5),

@@ -51,3 +51,6 @@ def test_bench_two_ranks_line():
     d = _line(out)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["proofs_match_toxic_waste_closed_form"] is True
     assert "distributed four-step NTT" in d["config"]["parallelism"] and "extras" not in d
+    # the default N > 1 orchestration is the native one (points-sharded key, one C call per proof) and it did not fall through
+    assert "wsnark_groth16_prove_dist" in d["config"]["parallelism"] and "fell through" not in d["config"]["parallelism"]
+    assert d["shard"]["pairs_this_rank"] > 0 and d["shard"]["resident_table_bytes_this_rank"] > 0

@@ -75,6 +75,27 @@ for name in ("t3", "t6"):
     got = dp.prove(w.data_ptr(), len(wit))                     # rank 0 draws r, s
     r_used, s_used = bn.last_blinding()
     assert got == bn.groth16GenProof(wit, key, r=r_used, s=s_used), ("DistProver default blinding", name, rank)
+# the same proofs from the NATIVE orchestration (wsnark_groth16_prove_dist, csrc/dist.hip): points shards of the key (1 / world
+# resident per rank), row-sharded sparse products, pack / unpack kernels instead of permute().contiguous(), the transport as
+# callbacks -- nothing in Python between the kernels.  Must equal the reference's proofs and DistProver's.
+from wasmsnark_amd import formats
+for name in ("t3", "t6"):
+    pkey = open(os.path.join(gold, "keys", name + ".pkey.bin"), "rb").read()
+    wit = open(os.path.join(gold, "keys", name + ".witness.bin"), "rb").read()
+    sec = formats.pkey_bin_to_sections(pkey)
+    if (1 << ((sec["domain"].bit_length() - 1) // 2)) < world:
+        continue                                               # (t3: domain 8 only splits over two ranks)
+    npv = wd.NativeDistProver(bn, sec)
+    assert npv.key.shard["world"] == world and npv.key.shard["n_signals"] <= sec["n_vars"] // world + world
+    w = torch.frombuffer(bytearray(wit), dtype=torch.uint8)
+    for c in json.load(open(os.path.join(gold, "proofs.json")))[name]:
+        got = npv.prove(w.data_ptr(), len(wit), r=bytes.fromhex(c["r"]), s=bytes.fromhex(c["s"]))
+        assert got == c["proof"], ("NativeDistProver", name, rank)
+    got = npv.prove(w.data_ptr(), len(wit))                    # rank 0 draws r, s: every rank must assemble the same proof
+    mine = torch.frombuffer(bytearray(json.dumps(got, sort_keys=True).encode().ljust(4096)), dtype=torch.uint8)
+    both = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    assert all(torch.equal(both[0], b) for b in both), "ranks disagree on the native proof"
 dist.barrier()
 open(os.path.join(os.environ["WS_OUT"], "rank%d.ok" % rank), "w").write("ok")
 '''
@@ -91,6 +112,48 @@ def test_dist_ntt_world2(tmp_path):
                          env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
+
+
+WORKER4 = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["WS_ROOT"]); sys.path.insert(0, os.path.join(os.environ["WS_ROOT"], "tests"))
+import torch, torch.distributed as dist
+from emul_util import emul_bn128
+from wasmsnark_amd import dist as wd, formats
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+bn = emul_bn128()
+gold = os.path.join(os.environ["WS_ROOT"], "tests", "golden")
+pkey = open(os.path.join(gold, "keys", "t6.pkey.bin"), "rb").read()
+wit = open(os.path.join(gold, "keys", "t6.witness.bin"), "rb").read()
+sec = formats.pkey_bin_to_sections(pkey)
+npv = wd.NativeDistProver(bn, sec)
+sh = npv.key.shard
+assert (sh["rank"], sh["world"], sh["h_interleave_log"], sh["n_hexps"]) == (rank, world, 3, sec["domain"] // world)
+w = torch.frombuffer(bytearray(wit), dtype=torch.uint8)
+for c in json.load(open(os.path.join(gold, "proofs.json")))["t6"]:
+    assert npv.prove(w.data_ptr(), len(wit), r=bytes.fromhex(c["r"]), s=bytes.fromhex(c["s"])) == c["proof"], ("native", rank)
+dist.barrier()
+open(os.path.join(os.environ["WS_OUT"], "rank%d.ok" % rank), "w").write("ok")
+'''
+
+
+def test_native_dist_prover_world4_and_world8(tmp_path):
+    """wsnark_groth16_prove_dist over 4 and 8 ranks (gloo, emulator): points shards of 1/4 and 1/8 of the t6 key, the three
+    exchanges of the distributed CALC_H among that many ranks, against the reference's own proofs."""
+    from emul_util import emul_bn128
+    emul_bn128()
+    script = tmp_path / "worker4.py"
+    script.write_text(WORKER4)
+    for world, port in ((4, "29643"), (8, "29644")):
+        out_dir = tmp_path / ("w%d" % world)
+        out_dir.mkdir()
+        env = dict(os.environ, WS_ROOT=ROOT, WS_OUT=str(out_dir), MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                              "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
+                             env=env, capture_output=True, text=True, timeout=1200)
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+        assert all((out_dir / ("rank%d.ok" % r)).exists() for r in range(world))
 
 
 def test_layout_helpers_roundtrip():

@@ -80,6 +80,23 @@ r14, s14 = bytes(range(32)), bytes(range(64, 96))
 want14 = synth.expected_proof(circ, S, r14, s14, bn.mul_base)
 assert dp.prove(d_w14.data_ptr(), len(w14), r=r14, s=s14) == want14, ("DistProver", rank)
 assert wd.sharded_prove(bn, key14, w14, r=r14, s=s14, device=dev) == want14, ("sharded_prove 2^14", rank)
+# the native orchestration (wsnark_groth16_prove_dist): every rank holds a POINTS shard of the key, the transport is called
+# back on the library's own queue; 2^14 and 2^18 against the closed form, injected and rank-0-drawn blinding
+from wasmsnark_amd import formats
+npv = wd.NativeDistProver(bn, formats.pkey_bin_to_sections(pk14), device=dev)
+assert npv.key.shard["world"] == world and npv.key.table["bytes"] < key14.table["bytes"]
+assert npv.prove(d_w14.data_ptr(), len(w14), r=r14, s=s14) == want14, ("NativeDistProver", rank)
+got_n = npv.prove(d_w14.data_ptr(), len(w14))
+r_n, s_n = bn.last_blinding()
+assert got_n == synth.expected_proof(circ, S, r_n, s_n, bn.mul_base), ("NativeDistProver, drawn blinding", rank)
+c18 = synth.NativeCircuit(bn.lib, 18, n_public=5, seed=18)
+sec18, _ = c18.build_sections()
+w18 = c18.witness_bin()
+d_w18 = torch.frombuffer(bytearray(w18), dtype=torch.uint8).to(dev)
+torch.cuda.synchronize()
+np18 = wd.NativeDistProver(bn, sec18, device=dev)
+for _ in range(3):
+    assert np18.prove(d_w18.data_ptr(), len(w18), r=r14, s=s14) == c18.expected_proof(r14, s14), ("NativeDistProver 2^18", rank)
 got = wd.sharded_prove(bn, key, wit, device=dev)                  # rank 0 draws r, s: all ranks, one proof
 r_used, s_used = bn.last_blinding()
 assert got == bn.groth16GenProof(wit, key, r=r_used, s=s_used)

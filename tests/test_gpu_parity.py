@@ -494,6 +494,29 @@ def test_c1_example_witness_vs_reference_proof(bn, orc):
     assert orc.groth16_prove(wit, pkey, r, s, workers=32) == g["proof"]  # and the oracle agrees at this size too
 
 
+@pytest.mark.parametrize("logd", [13, 16, 20])
+def test_native_dist_prover_world_of_one_on_gpu(bn, logd):
+    """wsnark_groth16_prove_dist with a world of one: the same kernels, queues and exchange-buffer layouts as N ranks (the
+    exchange itself is the identity), odd and even log2(domain), against the closed form and the one-call prover."""
+    import torch
+    from wasmsnark_amd import dist as wd, synth
+    circ = synth.NativeCircuit(bn.lib, logd, n_public=5, seed=40 + logd)
+    sec, _ = circ.build_sections()
+    wit = circ.witness_bin()
+    dev = torch.device("cuda", 0)
+    d_w = torch.frombuffer(bytearray(wit), dtype=torch.uint8).to(dev)
+    torch.cuda.synchronize()
+    npv = wd.NativeDistProver(bn, sec, device=dev)
+    assert npv.key.shard["h_interleave_log"] == logd // 2 and npv.key.table["rows_w"] > 1
+    whole = bn.load_key(sections=sec)
+    for _ in range(2):
+        r, s = os.urandom(32), os.urandom(32)
+        got = npv.prove(d_w.data_ptr(), len(wit), r=r, s=s)
+        assert got == circ.expected_proof(r, s) == bn.groth16GenProof(wit, whole, r=r, s=s)
+    whole.free()
+    npv.key.free()
+
+
 def test_window_shards_sum_to_full_msm_on_gpu(bn, orc):
     # wsnark_g1_msm_windows: the partial sums over the window shards of any world size add up
     rnd = random.Random(321)

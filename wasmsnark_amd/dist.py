@@ -337,3 +337,86 @@ class DistProver:
             r, s = (r if r is not None else r0), (s if s is not None else s0)
             allp = b"".join(allp[i * rec:i * rec + 576] for i in range(world))
         return bn.groth16_prove_finish(self.key, allp, r=r, s=s)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The same prover with NOTHING in Python between the kernels: wsnark_groth16_prove_dist (csrc/dist.hip) runs the whole
+# proof of a rank behind the C ABI -- partial sums over the rank's POINTS shard of the key (wsnark_pkey_load_shard: 1 / world
+# of the key resident, the reference's own worker split src/bn128.js:353-361), row-sharded sparse products written directly
+# in the transform's layout, three exchanges, the H sum over the rank's hExps share, one all-gather -- and calls back into
+# the host only for the transport.  DistProver above stays as the reference orchestration the tests compare it with.
+# ---------------------------------------------------------------------------------------------------------------
+import ctypes as _C
+
+
+class _Comm(_C.Structure):     # wsnark_comm_t
+    _fields_ = [("rank", _C.c_uint32), ("world", _C.c_uint32), ("d_send", _C.c_void_p), ("d_recv", _C.c_void_p),
+                ("buf_bytes", _C.c_uint64), ("all_to_all", _C.c_void_p), ("all_gather", _C.c_void_p), ("user", _C.c_void_p)]
+
+
+_A2A = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_uint64, _C.c_void_p)
+_AG = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_uint64)
+
+
+class NativeDistProver:
+    """One rank of the multi-GPU prover over wsnark_groth16_prove_dist.  `sections`: the key's sections (every rank passes
+    the whole key and keeps its share).  The transport callbacks run torch.distributed collectives: "nccl" (= RCCL over
+    xGMI) enqueued on the library's own queue (torch.cuda.ExternalStream), so no host synchronisation separates kernels and
+    exchanges; "gloo" (CPU tests, ranks sharing a GPU) staged through the host."""
+
+    def __init__(self, bn, sections, device=None, group=None):
+        self.bn, self.group, self.device = bn, group, device
+        if dist.is_available() and dist.is_initialized():
+            self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        else:
+            self.world, self.rank = 1, 0
+        dom = sections["domain"]
+        self.log_n = dom.bit_length() - 1
+        self.l2 = self.log_n // 2
+        if self.world & (self.world - 1) or (1 << self.l2) < self.world:
+            raise ValueError("the distributed prover needs a power-of-two world size <= 2^%d" % self.l2)
+        self.key = bn.load_key(sections=sections, shard=(self.rank, self.world), h_interleave_log=self.l2)
+        nbytes = 3 * (dom // self.world) * 32
+        self.send = torch.empty(nbytes, dtype=torch.uint8, device=device if device is not None else "cpu")
+        self.recv = torch.empty(nbytes, dtype=torch.uint8, device=self.send.device)
+        self.errors = []
+        self._a2a = _A2A(self._all_to_all_cb)
+        self._ag = _AG(self._all_gather_cb)
+        self.comm = _Comm(self.rank, self.world, self.send.data_ptr(), self.recv.data_ptr(), nbytes,
+                          _C.cast(self._a2a, _C.c_void_p), _C.cast(self._ag, _C.c_void_p), None)
+
+    def _all_to_all_cb(self, user, bytes_per_rank, stream):
+        try:
+            n = int(bytes_per_rank) * self.world
+            send, recv = self.send[:n], self.recv[:n]
+            if send.is_cuda:
+                ext = torch.cuda.ExternalStream(int(stream), device=send.device) if stream else torch.cuda.current_stream(send.device)
+                with torch.cuda.stream(ext):      # the collective is ordered on the queue the library's kernels run on
+                    _all_to_all(recv, send, self.group)
+            else:
+                _all_to_all(recv, send, self.group)
+            return 0
+        except Exception as ex:  # noqa: BLE001 - must not unwind through the C frame
+            self.errors.append(ex)
+            return 1
+
+    def _all_gather_cb(self, user, send, recv, nbytes):
+        try:
+            allp = allgather_partials(_C.string_at(send, int(nbytes)), self.device)
+            _C.memmove(recv, allp, len(allp))
+            return 0
+        except Exception as ex:  # noqa: BLE001
+            self.errors.append(ex)
+            return 1
+
+    def prove(self, d_witness, witness_len, r=None, s=None, stream=None):
+        """d_witness: device pointer of the plain witness on this rank's GPU (all nVars signals).  r, s = None: rank 0 draws
+        the blinding values; every rank returns the same proof."""
+        from .bn128 import proof_from_bytes
+        out = (_C.c_uint8 * 384)()
+        del self.errors[:]
+        rc = self.bn.lib.c.wsnark_groth16_prove_dist(self.key._h, d_witness, witness_len, _C.byref(self.comm), r, s, out, stream)
+        if rc and self.errors:
+            raise self.errors[0]
+        self.bn.lib.check(rc)
+        return proof_from_bytes(bytes(out))
