@@ -8,7 +8,7 @@ B="$ROOT/tools/alt/build_$NAME"
 mkdir -p "$B"
 cd "$ROOT/wasmsnark_amd/csrc"
 OBJS=""
-for f in context ntt msm calch prove fixedbase selftest verify cabi; do
+for f in context ntt msm calch dist prove fixedbase synth selftest verify cabi; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $FLAGS -c $f.hip -o "$B/$f.o" &
   OBJS="$OBJS $B/$f.o"
 done

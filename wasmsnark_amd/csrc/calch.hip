@@ -16,6 +16,9 @@
 //    so h[t] = c[n + t] = (e[t] - w_2n^-t o[t]) / 2: two size-n transforms, no 2n buffer.
 #include <string.h>
 
+#include <atomic>
+#include <thread>
+
 #include "internal.h"
 
 namespace wsnark {
@@ -174,40 +177,71 @@ int fr_map_dev(const Fe* d_in, Fe* d_out, uint64_t n, int to_mont, hipStream_t s
     return WS_OK;
 }
 
+// Host-side transposition of the record stream.  The records are variable-length, so a first sequential walk over the
+// per-signal headers finds where every signal starts (and validates the lengths); counting and filling then run over
+// signal ranges on several threads (atomic per-row counters / cursors: the order of the terms inside a row is free, the
+// modular sum is exact).  Cold key load of a 2^20 key: 123 ms single-threaded -> the header walk plus two parallel passes.
+template <class Fn>
+static void host_parallel_for(uint64_t n, Fn fn) {
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (nt < 2 || n < (1u << 15)) { fn((uint64_t)0, n); return; }
+    std::vector<std::thread> th;
+    const uint64_t per = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; t++) {
+        const uint64_t lo = t * per, hi = lo + per < n ? lo + per : n;
+        if (lo >= hi) break;
+        th.emplace_back([=] { fn(lo, hi); });
+    }
+    for (auto& t : th) t.join();
+}
+
 int pols_to_csr(const uint8_t* pols, size_t len, uint32_t n_signals, uint32_t domain, CsrMatrix* out,
                 size_t* consumed, hipStream_t s) {
-    // pass 1: validate + count per row
-    std::vector<uint32_t> row_ptr((size_t)domain + 1, 0);
+    // pass 0 (sequential): where every signal's records start; lengths validated
+    std::vector<size_t> start((size_t)n_signals + 1);
     size_t pp = 0;
     uint64_t nnz = 0;
     for (uint32_t i = 0; i < n_signals; i++) {
+        start[i] = pp;
         if (pp + 4 > len) { set_last_error("pols: truncated record header"); return WS_ERR_FORMAT; }
         uint32_t nc; memcpy(&nc, pols + pp, 4); pp += 4;
         if ((uint64_t)nc * 36 > len - pp) { set_last_error("pols: truncated coefficient records"); return WS_ERR_FORMAT; }
-        for (uint32_t j = 0; j < nc; j++) {
-            uint32_t idx; memcpy(&idx, pols + pp, 4);
-            if (idx >= domain) { set_last_error("pols: coefficient index >= domainSize"); return WS_ERR_FORMAT; }
-            row_ptr[(size_t)idx + 1]++;
-            pp += 36;
-        }
+        pp += (size_t)nc * 36;
         nnz += nc;
     }
+    start[n_signals] = pp;
     if (nnz >= ((uint64_t)1 << 32)) return WS_ERR_SIZE;
-    for (uint32_t r = 0; r < domain; r++) row_ptr[(size_t)r + 1] += row_ptr[r];
+    // pass 1 (parallel): validate the indices, count per row
+    std::unique_ptr<std::atomic<uint32_t>[]> cnt(new std::atomic<uint32_t>[(size_t)domain + 1]);
+    for (size_t r = 0; r <= domain; r++) cnt[r].store(0, std::memory_order_relaxed);
+    std::atomic<int> bad(0);
+    host_parallel_for(n_signals, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; i++) {
+            for (size_t q = start[i] + 4; q < start[i + 1]; q += 36) {
+                uint32_t idx; memcpy(&idx, pols + q, 4);
+                if (idx >= domain) { bad.store(1, std::memory_order_relaxed); return; }
+                cnt[(size_t)idx + 1].fetch_add(1, std::memory_order_relaxed);
+            }
+        }
+    });
+    if (bad.load()) { set_last_error("pols: coefficient index >= domainSize"); return WS_ERR_FORMAT; }
+    std::vector<uint32_t> row_ptr((size_t)domain + 1, 0);
+    for (uint32_t r = 0; r < domain; r++) row_ptr[(size_t)r + 1] = row_ptr[r] + cnt[(size_t)r + 1].load(std::memory_order_relaxed);
     std::vector<uint32_t> col((size_t)nnz ? (size_t)nnz : 1);
     std::vector<Fe> coef((size_t)nnz ? (size_t)nnz : 1);
-    std::vector<uint32_t> fill(row_ptr.begin(), row_ptr.end() - 1);
-    pp = 0;
-    for (uint32_t i = 0; i < n_signals; i++) {
-        uint32_t nc; memcpy(&nc, pols + pp, 4); pp += 4;
-        for (uint32_t j = 0; j < nc; j++) {
-            uint32_t idx; memcpy(&idx, pols + pp, 4);
-            const uint32_t k = fill[idx]++;
-            col[k] = i;
-            memcpy(&coef[k], pols + pp + 4, 32);
-            pp += 36;
+    // pass 2 (parallel): fill; cnt[] becomes the per-row cursor
+    for (uint32_t r = 0; r < domain; r++) cnt[r].store(row_ptr[r], std::memory_order_relaxed);
+    host_parallel_for(n_signals, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; i++) {
+            for (size_t q = start[i] + 4; q < start[i + 1]; q += 36) {
+                uint32_t idx; memcpy(&idx, pols + q, 4);
+                const uint32_t k = cnt[idx].fetch_add(1, std::memory_order_relaxed);
+                col[k] = (uint32_t)i;
+                memcpy(&coef[k], pols + q + 4, 32);
+            }
         }
-    }
+    });
     if (consumed) *consumed = pp;
     out->n_rows = domain; out->n_cols = n_signals; out->nnz = nnz;
     WS_HIP_CHECK(out->row_ptr.alloc(row_ptr.size() * 4));

@@ -93,7 +93,7 @@ struct Context {
     KernelTimer timer;
     // host-pointer boundary: pinned staging ring for uploads
     void* pin_ring = nullptr;
-    hipEvent_t pin_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t pin_ev[16] = {};
 };
 
 // RAII: a free lane; with every lane busy the caller waits until ANY of them is released (not for one picked in advance:
@@ -149,7 +149,9 @@ int msm_g2_host(Lane& L, const void* h_scalars, const void* h_points, uint64_t n
 // two-phase form: one digit/sort/task plan per scalar vector, then any number of point sets of the
 // same length against it (the prover's A, B1, B2 and C sums all use the witness as scalars).
 // table_c != 0: plan for fixed-base window tables of that window width (msm_build_table; the launches then take the table)
-int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipStream_t s, uint32_t table_c = 0);
+// allow_split: the plan may order its tasks in two segments (high windows first) so that msm_g{1,2}_launch can run the
+// reduction tail of the high windows on the lane's second queue beside the accumulation of the low ones (one stand-alone MSM)
+int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipStream_t s, uint32_t table_c = 0, bool allow_split = false);
 uint32_t msm_table_rows(uint32_t table_c);
 uint32_t msm_table_window(uint64_t n);
 int msm_build_table(int which, void* d_table, uint64_t n, uint32_t table_c, hipStream_t s);   // rows 1.. from row 0 (device domain: after msm_prepare_points)

@@ -46,6 +46,9 @@ namespace wsnark {
 #ifndef WS_G2_PREFETCH
 #define WS_G2_PREFETCH 0
 #endif
+#ifndef WS_G1_PREFETCH
+#define WS_G1_PREFETCH 1   // G1 accumulation: next point's gather in flight during the current addition (0: gather just before use, 16 VGPRs fewer)
+#endif
 #ifndef WS_MADD_WIDE
 #define WS_MADD_WIDE 1     // accumulation loop keeps X wide between additions (curve.h: madd_wide); 0 = strict madd, for A/B builds
 #endif
@@ -101,6 +104,10 @@ __global__ __launch_bounds__(256) void msm_digits(const Fe* __restrict__ scalars
 // (vs 160 MB digits + ~830 MB three-pass radix sort + 64 MB bounds).
 // ---------------------------------------------------------------------------
 static const uint32_t PRESORT_MAX_BINS = 4096; // W * HB, 16 KiB of LDS counters
+// layout of a plan's counter block (u32 words): [0] partial slots, [1] multi-task buckets, [3] total tasks, [4] hot buckets,
+// [5] hot slices, [6] tasks of segment 0; task-length histograms of the two task segments at CNT_HIST (2 x 256), their
+// rank cursors at CNT_CURSOR (2 x 256), the coarse-bin counts / starts / cursors of the grouping pass from CNT_BINS on
+static const uint32_t CNT_HIST = 16, CNT_CURSOR = 16 + 512, CNT_BINS = 2048;
 
 // calls f(k, d, neg) for every owned window k (local index) with a non-zero signed digit d in [1, NB]
 template <class Fn>
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(1024) void presort_bins(const E* __restrict__ entri
                                                        uint32_t lo_bits, uint32_t idx_bits, uint32_t* __restrict__ vals_out,
                                                        uint32_t* __restrict__ bstart, uint32_t* __restrict__ bend,
                                                        uint32_t lmax, uint32_t* __restrict__ hist,
-                                                       const uint8_t* __restrict__ mask, uint32_t mask_mod) {
+                                                       const uint8_t* __restrict__ mask, uint32_t mask_mod, uint32_t split_bin) {
     __shared__ uint32_t sub[1u << PRESORT_MAX_LO];
     __shared__ uint32_t off[1u << PRESORT_MAX_LO];
     __shared__ uint32_t part[1024];
@@ -324,8 +331,10 @@ __global__ __launch_bounds__(1024) void presort_bins(const E* __restrict__ entri
         }
     }
     __syncthreads();
+    // (split plans: the bins of the high windows form task segment 0, the low windows segment 1 -- see msm_plan_emit)
+    uint32_t* __restrict__ hseg = hist + (bin >= split_bin ? 0u : 256u);
     for (uint32_t t = threadIdx.x; t < 256; t += blockDim.x)
-        if (lhist[t]) atomicAdd(&hist[t], lhist[t]);
+        if (lhist[t]) atomicAdd(&hseg[t], lhist[t]);
     for (uint32_t it = 0; it < iters; it++) {
         const uint32_t i = s + threadIdx.x + it * stride;
         E v[4];
@@ -369,7 +378,7 @@ __device__ __forceinline__ typename C::Pt accumulate_range(const typename C::Aff
                                                            const uint32_t* __restrict__ vals, uint32_t s, uint32_t len) {
     typename C::Pt acc = C::infinity();
     if (len == 0) return acc;
-    if (sizeof(typename C::AffP) > 64 && !WS_G2_PREFETCH) {
+    if (sizeof(typename C::AffP) > 64 ? !WS_G2_PREFETCH : !WS_G1_PREFETCH) {
         // G2: the accumulator alone is 72 VGPRs; holding a prefetched 128-byte point as well costs a
         // wavefront of occupancy, so the gather is issued just before use (touching only the next point's cache line one
         // addition ahead was measured too: +4 %, profiles/r02_ab_g2_variants.txt -- the kernel is issue-bound, not latency-bound)
@@ -447,29 +456,46 @@ __global__ __launch_bounds__(256) void msm_plan_hist(const uint32_t* __restrict_
 // Tasks are laid out longest-first: the slots of key k start after all tasks with a longer key.  Every workgroup
 // derives those starts from the (complete) histogram itself -- 256 entries -- instead of a separate one-thread
 // kernel; `cursor` (zeroed) only hands out ranks within a key.  counters[3] = total tasks.
+// Split plans (split_bucket != 0, a multiple of the workgroup's 256 buckets): the buckets >= split_bucket -- the HIGH
+// windows -- form task segment 0, laid out first, the others segment 1 behind it (each segment longest-first on its own
+// histogram); counters[6] = tasks of segment 0.  The accumulation then runs as two launches, and the reduction tail of
+// the high windows runs on the lane's second queue beside the accumulation of the low ones (msm_launch_split).
 __global__ __launch_bounds__(256) void msm_plan_emit(const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bend,
-                                                       uint32_t nbuckets, uint32_t lmax, const uint32_t* __restrict__ hist,
-                                                       uint32_t* __restrict__ cursor,
+                                                       uint32_t nbuckets, uint32_t lmax, const uint32_t* __restrict__ hist2,
+                                                       uint32_t* __restrict__ cursor2,
                                                        Task* __restrict__ tasks, uint32_t* __restrict__ counters,
                                                        MultiBucket* __restrict__ multi, HotBucket* __restrict__ hot,
-                                                       uint32_t hot_min) {
+                                                       uint32_t hot_min, uint32_t split_bucket) {
     __shared__ uint32_t lcnt[256];
     __shared__ uint32_t lbase[256];
     __shared__ uint32_t first[256];          // start of key k's slots = number of tasks with a longer key
+    __shared__ uint32_t red[256];
+    const uint32_t seg = (blockIdx.x * blockDim.x >= split_bucket) ? 0u : 1u;      // uniform per workgroup
+    const uint32_t* __restrict__ hist = hist2 + seg * 256;
+    uint32_t* __restrict__ cursor = cursor2 + seg * 256;
     lcnt[threadIdx.x] = 0;
     first[threadIdx.x] = hist[threadIdx.x];
+    red[threadIdx.x] = hist2[threadIdx.x];   // segment 0's histogram: its total is where segment 1 starts
     __syncthreads();
     // inclusive suffix sum over the 256 keys (Hillis-Steele), then shift to exclusive
     for (uint32_t d = 1; d < 256; d <<= 1) {
         const uint32_t v = threadIdx.x + d < 256 ? first[threadIdx.x + d] : 0;
+        const uint32_t w = threadIdx.x + d < 256 ? red[threadIdx.x + d] : 0;
         __syncthreads();
         first[threadIdx.x] += v;
+        red[threadIdx.x] += w;
         __syncthreads();
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) counters[3] = first[0];
+    const uint32_t total0 = red[0], seg_base = seg ? total0 : 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        counters[6] = total0;
+        counters[3] = seg ? total0 + first[0] : total0;
+    }
+    // (a split plan's workgroup 0 always belongs to segment 1 -- bucket 0 is a low window -- so counters[3] is complete;
+    //  without a split every workgroup is segment 0 and total0 is the whole count)
     const uint32_t excl = threadIdx.x + 1 < 256 ? first[threadIdx.x + 1] : 0;
     __syncthreads();
-    first[threadIdx.x] = excl;
+    first[threadIdx.x] = seg_base + excl;
     __syncthreads();
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t cnt = 0, s = 0, nt = 0, rem = 0, krem = 0, r255 = 0, rrem = 0;
@@ -524,14 +550,78 @@ __global__ __launch_bounds__(256, (sizeof(typename C::PtP) > 128 ? WS_ACC_WAVES_
                                                         const Task* __restrict__ tasks,
                                                         const uint32_t* __restrict__ counters,
                                                         typename C::PtP* __restrict__ buckets,
-                                                        typename C::PtP* __restrict__ partials) {
+                                                        typename C::PtP* __restrict__ partials, uint32_t seg) {
     // the grid is sized for the worst case; the real task count stays on the device (no host round trip)
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= counters[3]) return;
+    // seg: 0 / 1 = that task segment of a split plan, 2 = all tasks
+    const uint32_t t0 = seg == 1 ? counters[6] : 0u, t1 = seg == 0 ? counters[6] : counters[3];
+    const uint32_t t = t0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= t1) return;
     const Task k = tasks[t];
     const typename C::PtP acc = C::pack_pt(accumulate_range<C>(points, vals, k.start, k.len));
     if (k.dst & PARTIAL_FLAG) partials[k.dst & ~PARTIAL_FLAG] = acc;
     else buckets[k.dst] = acc;
+}
+
+// 4'. A/B ONLY (WSNARK_ACC_SHAPE=segscan): the accumulation shape BASELINE.json's north star words --
+// "one scalar/point pair per lane ... LDS-staged bucket accumulation with wavefront segmented reduction" -- over the same
+// bucket-sorted stream.  A wavefront takes 64 CONSECUTIVE entries of the sorted stream (coalesced index reads), every lane
+// gathers its one point, and a segmented inclusive scan keyed by the bucket (six Hillis-Steele steps, operands staged through
+// LDS, full XYZZ additions) leaves every bucket run's sum in its last lane.  Runs that lie inside the wavefront are stored as
+// buckets; a run that crosses a wavefront boundary leaves a partial (slot 2 w + [the run does not start at lane 0]) and
+// msm_segscan_merge adds the partials of such buckets.  The shipped shape (msm_accumulate: one lane = one bucket run in
+// registers, no cross-lane step) does 64 mixed additions (10 products each) per wavefront step where this one spends six
+// full additions (14 products each) per 64 ENTRIES: measured in profiles/r03_ab_accumulate_shape.txt.
+template <class C>
+__global__ __launch_bounds__(256) void msm_accumulate_segscan(const typename C::AffP* __restrict__ points, const uint32_t* __restrict__ vals,
+                                                                const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bend,
+                                                                uint32_t nbuckets, const uint32_t* __restrict__ total_ptr,
+                                                                typename C::PtP* __restrict__ buckets, typename C::PtP* __restrict__ partials) {
+    __shared__ typename C::PtP sh[256];
+    __shared__ uint32_t key[256];
+    const uint32_t total = *total_ptr;
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, w0 = threadIdx.x & ~63u;
+    const bool live = e < total;                                   // (uniform trip counts: every thread reaches every barrier)
+    uint32_t b = 0xFFFFFFFFu;
+    typename C::Pt P = C::infinity();
+    if (live) {
+        uint32_t lo = 0, hi = nbuckets;                            // largest bucket with bstart <= e (bstart is monotone; empty buckets repeat a start)
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (bstart[mid] <= e) lo = mid; else hi = mid; }
+        while (bend[lo] <= e) lo++;                                // skip empty buckets that share the start
+        b = lo;
+        const uint32_t v = vals[e];
+        C::madd(P, C::unpack_aff(points[v & 0x7FFFFFFFu]), (v >> 31) != 0);
+    }
+    key[threadIdx.x] = b;
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        sh[threadIdx.x] = C::pack_pt(P);
+        __syncthreads();
+        if (live && lane >= d && key[threadIdx.x - d] == b) P = C::add(P, C::unpack_pt(sh[threadIdx.x - d]));
+        __syncthreads();
+    }
+    if (!live) return;
+    const bool tail = lane == 63 || e + 1 >= total || key[threadIdx.x + 1] != b;
+    if (!tail) return;
+    const uint32_t wave_first = blockIdx.x * blockDim.x + w0;      // first entry of this wavefront
+    const uint32_t s0 = bstart[b], s1 = bend[b];
+    if (s0 >= wave_first && s1 <= wave_first + 64) { buckets[b] = C::pack_pt(P); return; }
+    const uint32_t first_lane = s0 > wave_first ? s0 - wave_first : 0;
+    partials[2 * (wave_first >> 6) + (first_lane != 0 ? 1u : 0u)] = C::pack_pt(P);
+}
+template <class C>
+__global__ __launch_bounds__(256) void msm_segscan_merge(const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bend, uint32_t nbuckets,
+                                                           const typename C::PtP* __restrict__ partials, typename C::PtP* __restrict__ buckets) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbuckets) return;
+    const uint32_t s0 = bstart[b], s1 = bend[b];
+    if (s1 == s0) { buckets[b] = C::pack_pt(C::infinity()); return; }
+    const uint32_t wf = s0 >> 6, wl = (s1 - 1) >> 6;
+    if (wf == wl) return;                                          // the run lies inside one wavefront: already stored
+    typename C::Pt acc = C::infinity();
+    for (uint32_t w = wf; w <= wl; w++) {
+        const uint32_t first_lane = s0 > (w << 6) ? s0 - (w << 6) : 0;
+        acc = C::add(acc, C::unpack_pt(partials[2 * w + (first_lane != 0 ? 1u : 0u)]));
+    }
+    buckets[b] = C::pack_pt(acc);
 }
 
 // 5a. buckets cut into a few tasks: one lane sums the partials
@@ -542,14 +632,15 @@ __global__ __launch_bounds__(256) void msm_combine_small(const MultiBucket* __re
                                                            const typename C::PtP* __restrict__ partials,
                                                            typename C::PtP* __restrict__ buckets,
                                                            const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bend,
-                                                           uint32_t nbuckets) {
+                                                           uint32_t b_lo, uint32_t b_hi) {
+    // (b_lo, b_hi: the buckets this launch is responsible for -- all of them, or one half of a split plan)
     // empty buckets = infinity (ZZ == 0); the others are written by their task or by a combine step
-    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nbuckets; b += gridDim.x * blockDim.x)
+    for (uint32_t b = b_lo + blockIdx.x * blockDim.x + threadIdx.x; b < b_hi; b += gridDim.x * blockDim.x)
         if (bend[b] == bstart[b]) buckets[b] = C::pack_pt(C::infinity());
     const uint32_t nmb = counters[1];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nmb; i += gridDim.x * blockDim.x) {
         const MultiBucket h = mbs[i];
-        if (h.ntasks >= WAVE_COMBINE_MIN) continue;
+        if (h.ntasks >= WAVE_COMBINE_MIN || h.bucket < b_lo || h.bucket >= b_hi) continue;
         typename C::Pt acc = C::unpack_pt(partials[h.first_partial]);
         for (uint32_t k = 1; k < h.ntasks; k++) acc = C::add(acc, C::unpack_pt(partials[h.first_partial + k]));
         buckets[h.bucket] = C::pack_pt(acc);
@@ -562,13 +653,13 @@ template <class C>
 __global__ __launch_bounds__(64) void msm_combine_wave(const MultiBucket* __restrict__ mbs,
                                                          const uint32_t* __restrict__ counters,
                                                          const typename C::PtP* __restrict__ partials,
-                                                         typename C::PtP* __restrict__ buckets) {
+                                                         typename C::PtP* __restrict__ buckets, uint32_t b_lo, uint32_t b_hi) {
     __shared__ typename C::PtP sh[64];
     const uint32_t nmb = counters[1];
     const uint32_t lane = threadIdx.x;
     for (uint32_t hb = blockIdx.x; hb < nmb; hb += gridDim.x) {     // uniform per block
         const MultiBucket h = mbs[hb];
-        if (h.ntasks < WAVE_COMBINE_MIN) continue;
+        if (h.ntasks < WAVE_COMBINE_MIN || h.bucket < b_lo || h.bucket >= b_hi) continue;
         typename C::Pt acc = C::infinity();
         for (uint32_t k = lane; k < h.ntasks; k += 64) acc = C::add(acc, C::unpack_pt(partials[h.first_partial + k]));
         sh[lane] = C::pack_pt(acc);
@@ -587,11 +678,12 @@ __global__ __launch_bounds__(64) void msm_combine_wave(const MultiBucket* __rest
 template <class C>
 __global__ __launch_bounds__(64) void msm_combine_hot1(const HotBucket* __restrict__ hot, const uint32_t* __restrict__ counters,
                                                          const typename C::PtP* __restrict__ partials,
-                                                         typename C::PtP* __restrict__ slice_sums) {
+                                                         typename C::PtP* __restrict__ slice_sums, uint32_t b_lo, uint32_t b_hi) {
     __shared__ typename C::PtP sh[64];
     const uint32_t nhot = counters[4], lane = threadIdx.x;
     for (uint32_t hb = 0; hb < nhot; hb++) {                          // few entries; every workgroup walks them all
         const HotBucket h = hot[hb];
+        if (h.bucket < b_lo || h.bucket >= b_hi) continue;
         const uint32_t nsl = (h.ntasks + HOT_SLICE - 1) / HOT_SLICE;
         // slices are dealt round-robin over the workgroups by their GLOBAL number, so that many moderately hot
         // buckets spread as well as one very hot one
@@ -614,11 +706,12 @@ __global__ __launch_bounds__(64) void msm_combine_hot1(const HotBucket* __restri
 template <class C>
 __global__ __launch_bounds__(64) void msm_combine_hot2(const HotBucket* __restrict__ hot, const uint32_t* __restrict__ counters,
                                                          const typename C::PtP* __restrict__ slice_sums,
-                                                         typename C::PtP* __restrict__ buckets) {
+                                                         typename C::PtP* __restrict__ buckets, uint32_t b_lo, uint32_t b_hi) {
     __shared__ typename C::PtP sh[64];
     const uint32_t nhot = counters[4], lane = threadIdx.x;
     for (uint32_t hb = blockIdx.x; hb < nhot; hb += gridDim.x) {
         const HotBucket h = hot[hb];
+        if (h.bucket < b_lo || h.bucket >= b_hi) continue;
         const uint32_t nsl = (h.ntasks + HOT_SLICE - 1) / HOT_SLICE;
         typename C::Pt acc = C::infinity();
         for (uint32_t k = lane; k < nsl; k += 64) acc = C::add(acc, C::unpack_pt(slice_sums[h.slice_base + k]));
@@ -648,11 +741,11 @@ struct TailSets {
 };
 
 template <class C>
-__global__ __launch_bounds__(256) void msm_chunks(TailSets<C> ts, uint32_t nchunks, uint32_t m) {
+__global__ __launch_bounds__(256) void msm_chunks(TailSets<C> ts, uint32_t chunk0, uint32_t nchunks, uint32_t m) {
     const typename C::PtP* __restrict__ buckets = ts.buckets[blockIdx.y];
     typename C::PtP* __restrict__ chunkS = ts.chunkS[blockIdx.y];
     typename C::PtP* __restrict__ chunkA = ts.chunkA[blockIdx.y];
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = chunk0 + blockIdx.x * blockDim.x + threadIdx.x;      // chunks [chunk0, nchunks): all, or the windows of one half
     if (j >= nchunks) return;
     typename C::Pt run = C::infinity(), acc = C::infinity();
     const typename C::PtP* B = buckets + (uint64_t)j * m;
@@ -670,12 +763,12 @@ __global__ __launch_bounds__(256) void msm_chunks(TailSets<C> ts, uint32_t nchun
 // ---------------------------------------------------------------------------
 template <class C>
 __global__ __launch_bounds__(sizeof(typename C::PtP) > 128 ? 256 : 512) void msm_tree(TailSets<C> ts, uint32_t J,
-                                                                                           uint32_t logJ) {
+                                                                                           uint32_t logJ, uint32_t w0) {
     const typename C::PtP* __restrict__ chunkS = ts.chunkS[blockIdx.z];
     const typename C::PtP* __restrict__ chunkA = ts.chunkA[blockIdx.z];
     typename C::PtP* __restrict__ sums = ts.sums[blockIdx.z];
     WS_DYN_SMEM(typename C::PtP, sh);
-    const uint32_t q = blockIdx.x, w = blockIdx.y;
+    const uint32_t q = blockIdx.x, w = w0 + blockIdx.y;              // windows [w0, w0 + gridDim.y)
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     const typename C::PtP* src = (q == logJ ? chunkA : chunkS) + (uint64_t)w * J;
     typename C::Pt acc = C::infinity();
@@ -757,6 +850,9 @@ struct MsmPlanInfo {
     bool flat = false;
     uint32_t tW = 0, tNB = 0;
     uint32_t ntasks = 0, nmulti = 0;
+    // split plans (per-window plans of one whole MSM call): the high windows [split_k, W) are task segment 0, the low ones
+    // segment 1; 0 = one segment
+    uint32_t split_k = 0;
     bool valid = false;
 };
 // ---- asynchronous completion: the last kernel's W x nsum window sums are copied to pinned host memory
@@ -772,10 +868,15 @@ struct MsmPending {
     void* h_sums = nullptr;
     size_t h_bytes = 0;
     hipEvent_t ev = nullptr;
+    const void* d_points_used = nullptr;            // the (converted) point array the accumulation reads
+    hipEvent_t ev_hi = nullptr, ev_acc = nullptr;   // split launches: the high windows' sums have reached the host / segment 0 is accumulated
+    bool split = false;
     void release() {
         if (h_sums) (void)hipHostFree(h_sums);
         if (ev) (void)hipEventDestroy(ev);
-        h_sums = nullptr; ev = nullptr; h_bytes = 0; active = false;
+        if (ev_hi) (void)hipEventDestroy(ev_hi);
+        if (ev_acc) (void)hipEventDestroy(ev_acc);
+        h_sums = nullptr; ev = nullptr; ev_hi = nullptr; ev_acc = nullptr; h_bytes = 0; active = false;
         d_sums.release();
         S.buckets.release(); S.partials.release(); S.chunkS.release(); S.chunkA.release(); S.points_conv.release(); S.hot_sums.release();
     }
@@ -826,7 +927,10 @@ static int msm_finish_t(MsmPending& P, typename H::Pt* out_host) {
     struct Done { MsmPending& p; ~Done() { p.active = false; } } done{P};   // the slot is free again whatever happens
     static const bool trace = [] { const char* e = getenv("WSNARK_TRACE"); return e && atoi(e) == 1; }();
     const auto t_wait = std::chrono::steady_clock::now();
-    WS_HIP_CHECK(hipEventSynchronize(P.ev));
+    // split launches: the rows of the high windows arrive first (ev_hi); the Horner chain starts on them while the GPU is still
+    // reducing the low windows, and waits for the rest (ev) where it first needs one
+    bool waited_all = !(P.split && P.ev_hi);
+    WS_HIP_CHECK(hipEventSynchronize(waited_all ? P.ev : P.ev_hi));
     const auto t_tail = std::chrono::steady_clock::now();
     const HPt* sums = reinterpret_cast<const HPt*>(P.h_sums);
     if (I.flat) {
@@ -869,7 +973,9 @@ static int msm_finish_t(MsmPending& P, typename H::Pt* out_host) {
     bool started = false;                                  // leading doublings of infinity are skipped
     for (int wg = (int)I.Wall - 1; wg >= 0; wg--) {      // global window index; rows exist for the owned ones
         const bool owned = (uint32_t)wg >= I.w_off && ((uint32_t)wg - I.w_off) % I.w_stride == 0;
-        const HPt* row = owned ? &sums[(size_t)(((uint32_t)wg - I.w_off) / I.w_stride) * I.nsum] : nullptr;
+        const uint32_t krow = owned ? ((uint32_t)wg - I.w_off) / I.w_stride : 0;
+        if (owned && !waited_all && krow < I.split_k) { WS_HIP_CHECK(hipEventSynchronize(P.ev)); waited_all = true; }
+        const HPt* row = owned ? &sums[(size_t)krow * I.nsum] : nullptr;
         for (int k = (int)I.c - 1; k >= 0; k--) {
             if (started) acc = H::dbl(acc);
             if (!owned) continue;
@@ -877,6 +983,7 @@ static int msm_finish_t(MsmPending& P, typename H::Pt* out_host) {
             if (k == 0) { acc = H::add(acc, row[I.logJ]); started = true; }
         }
     }
+    if (!waited_all) WS_HIP_CHECK(hipEventSynchronize(P.ev));       // (nothing left to read, but the launch must be over before its slot is reused)
     *out_host = acc;
     if (trace)
         fprintf(stderr, "[wsnark trace]   msm finish (%s): waited %.3f ms for the GPU, host Horner %.3f ms\n", sizeof(HPt) > 128 ? "G2" : "G1",
@@ -912,7 +1019,7 @@ uint32_t msm_table_window(uint64_t n) {
     return (uint32_t)c;
 }
 
-int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipStream_t s, uint32_t table_c) {
+int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipStream_t s, uint32_t table_c, bool allow_split) {
     Context* X = ctx();
     if (!X) return WS_ERR_NOINIT;
     if (!s) s = L.stream;
@@ -974,7 +1081,7 @@ int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipSt
     WS_HIP_CHECK(S.vals_out.reserve(total * 4));
     WS_HIP_CHECK(S.bstart.reserve((size_t)nbuckets * 4));
     WS_HIP_CHECK(S.bend.reserve((size_t)nbuckets * 4));
-    WS_HIP_CHECK(S.counters.reserve(4096 + ((size_t)PRESORT_MAX_BINS + 1) * 4 * 3));
+    WS_HIP_CHECK(S.counters.reserve((size_t)CNT_BINS * 4 + ((size_t)PRESORT_MAX_BINS + 1) * 4 * 3));
     WS_HIP_CHECK(S.tasks.reserve((size_t)I.hot_cap * sizeof(Task)));
     WS_HIP_CHECK(S.multi.reserve((size_t)I.hot_cap * sizeof(MultiBucket)));
     uint32_t hot_min = HOT_MIN;      // (WSNARK_MSM_HOT_MIN: lets small tests reach the hot-bucket path)
@@ -1009,10 +1116,20 @@ int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipSt
         // ---- grouping by coarse bins + per-bin LDS counting sort (hand-written; see the kernels above) ----
         const bool e32 = !env_e64 && idx_bits + 1 + lo_bits <= 32;
         WS_HIP_CHECK(S.entries.reserve(total * (e32 ? 4 : 8)));
-        uint32_t* bin_count = d_cnt + 1024;
+        uint32_t* bin_count = d_cnt + CNT_BINS;
         uint32_t* bin_start = bin_count + (nbins + 1);
         uint32_t* bin_cursor = bin_start + (nbins + 1);
-        WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, (1024 + (size_t)nbins + 1) * 4, s));
+        WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, (CNT_BINS + (size_t)nbins + 1) * 4, s));
+        // split plans: only for a whole stand-alone MSM (allow_split), per-window buckets in workgroup-aligned sets
+        // (WSNARK_MSM_SPLIT_MIN: smallest n that splits; tests lower it to reach the path at sizes the oracle finishes)
+        // Measured on MI355X (profiles/r03_s3_msm_split.txt): 2^20 pairs 2.28 ms split against 2.07 ms in one piece -- two half-size
+        // accumulations cost 2 x 0.68 ms instead of 1.21 ms (each ends in its own partly filled last round of wavefronts, and the
+        // second shares the SIMDs with the first one's tail) and that is more than the hidden tail saves.  Kept OFF by default
+        // (WSNARK_MSM_SPLIT=1 turns it on) as the recorded A/B of VERDICT r2 item 4.
+        const bool split_env = [] { const char* e = getenv("WSNARK_MSM_SPLIT"); return e && atoi(e) == 1; }();
+        const uint64_t split_min = [] { const char* e = getenv("WSNARK_MSM_SPLIT_MIN"); return e ? (uint64_t)atoll(e) : (uint64_t)1 << 14; }();
+        if (allow_split && split_env && !I.flat && W >= 4 && I.NB >= 256 && n >= split_min) I.split_k = W / 2;
+        const uint32_t split_bin = I.split_k * HB;
         PresortArgs PA{d_scalars, (uint32_t)n, c, I.Wall, I.w_off, I.w_stride, lo_bits, HB, nbins, env_tile, idx_bits, nullptr, I.flat ? 1u : 0u};
         const dim3 grid(ceil_div_u64(n, env_tile)), blk(env_thr);
         T.begin("msm_presort_count", s);
@@ -1031,10 +1148,10 @@ int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipSt
         T.begin("msm_presort_bins", s);
         if (e32)
             hipLaunchKernelGGL(presort_bins<uint32_t>, dim3(nbins), bblk, 0, s, S.entries.as<uint32_t>(), bin_start, lo_bits,
-                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(), lmax, d_cnt + 16, nullptr, 0u);
+                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(), lmax, d_cnt + CNT_HIST, nullptr, 0u, split_bin);
         else
             hipLaunchKernelGGL(presort_bins<uint64_t>, dim3(nbins), bblk, 0, s, S.entries.as<uint64_t>(), bin_start, lo_bits,
-                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(), lmax, d_cnt + 16, nullptr, 0u);
+                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(), lmax, d_cnt + CNT_HIST, nullptr, 0u, split_bin);
         T.end(s);
         WS_HIP_CHECK(hipGetLastError());
         have_hist = true;
@@ -1042,7 +1159,7 @@ int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipSt
         I.ps_lo_bits = lo_bits; I.ps_idx_bits = idx_bits; I.ps_nbins = nbins; I.ps_bthr = bthr; I.ps_e32 = e32;
     } else {
         if (I.flat) { set_last_error("msm: table plans need the grouping pass (WSNARK_MSM_SORT=cub or too many bins)"); return WS_ERR_ARG; }
-        WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, 4096, s));
+        WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, (size_t)CNT_BINS * 4, s));
         // ---- reference pipeline: explicit digit arrays + hipCUB radix sort (WSNARK_MSM_SORT=cub) ----
         WS_HIP_CHECK(S.keys.reserve(total * 4));
         WS_HIP_CHECK(S.vals.reserve(total * 4));
@@ -1068,10 +1185,10 @@ int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipSt
     T.begin("msm_plan", s);
     if (!have_hist)
         hipLaunchKernelGGL(msm_plan_hist, dim3(ceil_div_u64(nbuckets, 256)), dim3(256), 0, s, S.bstart.as<uint32_t>(),
-                           S.bend.as<uint32_t>(), nbuckets, lmax, d_cnt + 16);
+                           S.bend.as<uint32_t>(), nbuckets, lmax, d_cnt + CNT_HIST);
     hipLaunchKernelGGL(msm_plan_emit, dim3(ceil_div_u64(nbuckets, 256)), dim3(256), 0, s, S.bstart.as<uint32_t>(),
-                       S.bend.as<uint32_t>(), nbuckets, lmax, d_cnt + 16, d_cnt + 272, S.tasks.as<Task>(), d_cnt,
-                       S.multi.as<MultiBucket>(), S.hot.as<HotBucket>(), hot_min);
+                       S.bend.as<uint32_t>(), nbuckets, lmax, d_cnt + CNT_HIST, d_cnt + CNT_CURSOR, S.tasks.as<Task>(), d_cnt,
+                       S.multi.as<MultiBucket>(), S.hot.as<HotBucket>(), hot_min, I.split_k * I.NB);
     hipLaunchKernelGGL(msm_plan_emit_hot, dim3(64), dim3(256), 0, s, S.hot.as<HotBucket>(), d_cnt, lmax, S.tasks.as<Task>());
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
@@ -1103,28 +1220,29 @@ int msm_plan_variant(Lane& L, int src_id, int dst_id, const uint8_t* d_mask, hip
     WS_HIP_CHECK(S.vals_out.reserve(total * 4));
     WS_HIP_CHECK(S.bstart.reserve((size_t)src.nbuckets * 4));
     WS_HIP_CHECK(S.bend.reserve((size_t)src.nbuckets * 4));
-    WS_HIP_CHECK(S.counters.reserve(4096 + ((size_t)PRESORT_MAX_BINS + 1) * 4 * 3));
+    WS_HIP_CHECK(S.counters.reserve((size_t)CNT_BINS * 4 + ((size_t)PRESORT_MAX_BINS + 1) * 4 * 3));
     WS_HIP_CHECK(S.tasks.reserve((size_t)src.hot_cap * sizeof(Task)));
     WS_HIP_CHECK(S.multi.reserve((size_t)src.hot_cap * sizeof(MultiBucket)));
     WS_HIP_CHECK(S.hot.reserve(((size_t)src.hot_cap / src.hot_min + 16) * sizeof(HotBucket)));
     uint32_t* d_cnt = S.counters.as<uint32_t>();
-    WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, 4096, s));
-    const uint32_t* bin_start = SS.counters.as<uint32_t>() + 1024 + (src.ps_nbins + 1);
+    WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, (size_t)CNT_BINS * 4, s));
+    I.split_k = 0;
+    const uint32_t* bin_start = SS.counters.as<uint32_t>() + CNT_BINS + (src.ps_nbins + 1);
     KernelTimer& T = X->timer;
     T.begin("msm_presort_bins", s);
     if (src.ps_e32)
         hipLaunchKernelGGL(presort_bins<uint32_t>, dim3(src.ps_nbins), dim3(src.ps_bthr), 0, s, SS.entries.as<uint32_t>(), bin_start,
                            src.ps_lo_bits, src.ps_idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(),
-                           src.lmax, d_cnt + 16, d_mask, src.flat ? (uint32_t)src.n : 0u);
+                           src.lmax, d_cnt + CNT_HIST, d_mask, src.flat ? (uint32_t)src.n : 0u, 0u);
     else
         hipLaunchKernelGGL(presort_bins<uint64_t>, dim3(src.ps_nbins), dim3(src.ps_bthr), 0, s, SS.entries.as<uint64_t>(), bin_start,
                            src.ps_lo_bits, src.ps_idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(),
-                           src.lmax, d_cnt + 16, d_mask, src.flat ? (uint32_t)src.n : 0u);
+                           src.lmax, d_cnt + CNT_HIST, d_mask, src.flat ? (uint32_t)src.n : 0u, 0u);
     T.end(s);
     T.begin("msm_plan", s);
     hipLaunchKernelGGL(msm_plan_emit, dim3(ceil_div_u64(src.nbuckets, 256)), dim3(256), 0, s, S.bstart.as<uint32_t>(),
-                       S.bend.as<uint32_t>(), src.nbuckets, src.lmax, d_cnt + 16, d_cnt + 272, S.tasks.as<Task>(), d_cnt,
-                       S.multi.as<MultiBucket>(), S.hot.as<HotBucket>(), src.hot_min);
+                       S.bend.as<uint32_t>(), src.nbuckets, src.lmax, d_cnt + CNT_HIST, d_cnt + CNT_CURSOR, S.tasks.as<Task>(), d_cnt,
+                       S.multi.as<MultiBucket>(), S.hot.as<HotBucket>(), src.hot_min, 0u);
     hipLaunchKernelGGL(msm_plan_emit_hot, dim3(64), dim3(256), 0, s, S.hot.as<HotBucket>(), d_cnt, src.lmax, S.tasks.as<Task>());
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
@@ -1135,8 +1253,61 @@ int msm_plan_variant(Lane& L, int src_id, int dst_id, const uint8_t* d_mask, hip
 // ---- phase 2: bucket accumulation and reduction for one point set, against the current plan ----
 // C = device curve (arithmetic of the kernels), H = host curve (reference-format results, host tail).
 // `prepared`: d_points are already in C's internal domain (msm_prepare_points).
+// accumulation + combine of one task segment of a launch (seg 2 = everything) against the launch's plan
+template <class C>
+static int msm_acc_segment(Lane& L, MsmPending& P, int which, uint32_t seg, hipStream_t s) {
+    typedef typename C::PtP Pt;
+    Context* X = ctx();
+    MsmWorkspace& M = ws(L);
+    const MsmPlanInfo& I = P.info;
+    MsmScratch& PS = M.plan[P.plan_id].S;
+    MsmScratch& S = P.S;
+    KernelTimer& T = X->timer;
+    // bucket range of the segment: segment 0 = the high windows [split_k, W), segment 1 = the low ones
+    const uint32_t b_split = I.split_k * I.NB;
+    const uint32_t b_lo = seg == 0 ? b_split : 0u, b_hi = seg == 1 ? b_split : I.nbuckets;
+    // A/B only: the wavefront-segmented-scan shape over the same sorted stream (see msm_accumulate_segscan)
+    const bool segscan = [] { const char* e = getenv("WSNARK_ACC_SHAPE"); return e && !strcmp(e, "segscan"); }();
+    if (segscan && seg == 2 && I.ps_valid) {
+        const uint64_t total_max = (uint64_t)I.n * I.W;            // worst case: no zero digit
+        WS_HIP_CHECK(S.partials.reserve((size_t)(2 * (total_max / 64 + 2)) * sizeof(Pt)));
+        const uint32_t* total_ptr = PS.counters.as<uint32_t>() + CNT_BINS + (I.ps_nbins + 1) + I.ps_nbins;      // bin_start[nbins]
+        T.begin(which ? "msm_accumulate_g2" : "msm_accumulate_g1", s);
+        hipLaunchKernelGGL(msm_accumulate_segscan<C>, dim3(ceil_div_u64(total_max, 256)), dim3(256), 0, s,
+                           reinterpret_cast<const typename C::AffP*>(P.d_points_used), PS.vals_out.as<uint32_t>(), PS.bstart.as<uint32_t>(),
+                           PS.bend.as<uint32_t>(), I.nbuckets, total_ptr, S.buckets.as<Pt>(), S.partials.as<Pt>());
+        T.end(s);
+        T.begin("msm_combine", s);
+        hipLaunchKernelGGL(msm_segscan_merge<C>, dim3(ceil_div_u64(I.nbuckets, 256)), dim3(256), 0, s, PS.bstart.as<uint32_t>(), PS.bend.as<uint32_t>(),
+                           I.nbuckets, S.partials.as<Pt>(), S.buckets.as<Pt>());
+        T.end(s);
+        WS_HIP_CHECK(hipGetLastError());
+        return WS_OK;
+    }
+    T.begin(which ? "msm_accumulate_g2" : "msm_accumulate_g1", s);
+    hipLaunchKernelGGL(msm_accumulate<C>, dim3(ceil_div_u64(I.ntasks, 256)), dim3(256), 0, s,
+                       reinterpret_cast<const typename C::AffP*>(P.d_points_used),
+                       PS.vals_out.as<uint32_t>(), PS.tasks.as<Task>(), PS.counters.as<uint32_t>(), S.buckets.as<Pt>(),
+                       S.partials.as<Pt>(), seg);
+    T.end(s);
+    WS_HIP_CHECK(hipGetLastError());
+    T.begin("msm_combine", s);
+    hipLaunchKernelGGL(msm_combine_small<C>, dim3(256), dim3(256), 0, s, PS.multi.as<MultiBucket>(),
+                       PS.counters.as<uint32_t>(), S.partials.as<Pt>(), S.buckets.as<Pt>(), PS.bstart.as<uint32_t>(),
+                       PS.bend.as<uint32_t>(), b_lo, b_hi);
+    hipLaunchKernelGGL(msm_combine_wave<C>, dim3(2048), dim3(64), 0, s, PS.multi.as<MultiBucket>(),
+                       PS.counters.as<uint32_t>(), S.partials.as<Pt>(), S.buckets.as<Pt>(), b_lo, b_hi);
+    hipLaunchKernelGGL(msm_combine_hot1<C>, dim3(1024), dim3(64), 0, s, PS.hot.as<HotBucket>(), PS.counters.as<uint32_t>(),
+                       S.partials.as<Pt>(), S.hot_sums.as<Pt>(), b_lo, b_hi);
+    hipLaunchKernelGGL(msm_combine_hot2<C>, dim3(64), dim3(64), 0, s, PS.hot.as<HotBucket>(), PS.counters.as<uint32_t>(),
+                       S.hot_sums.as<Pt>(), S.buckets.as<Pt>(), b_lo, b_hi);
+    T.end(s);
+    WS_HIP_CHECK(hipGetLastError());
+    return WS_OK;
+}
+
 template <class C, class H>
-static int msm_launch_acc(Lane& L, int which, const typename H::Aff* d_points_ref, bool prepared, int* slot_out, hipStream_t s) {
+static int msm_launch_acc(Lane& L, int which, const typename H::Aff* d_points_ref, bool prepared, int* slot_out, hipStream_t s, bool split_first = false) {
     typedef typename C::PtP Pt;      // packed accumulator in global memory (same bytes as H::Pt)
     static_assert(sizeof(typename C::PtP) == sizeof(typename H::Pt) && sizeof(typename C::AffP) == sizeof(typename H::Aff), "layouts");
     Context* X = ctx();
@@ -1190,24 +1361,10 @@ static int msm_launch_acc(Lane& L, int which, const typename H::Aff* d_points_re
         T.end(s);
         d_points = S.points_conv.as<typename C::AffP>();
     }
-    T.begin(which ? "msm_accumulate_g2" : "msm_accumulate_g1", s);
-    hipLaunchKernelGGL(msm_accumulate<C>, dim3(ceil_div_u64(ntasks, 256)), dim3(256), 0, s, d_points,
-                       PS.vals_out.as<uint32_t>(), PS.tasks.as<Task>(), PS.counters.as<uint32_t>(), S.buckets.as<Pt>(),
-                       S.partials.as<Pt>());
-    T.end(s);
-    WS_HIP_CHECK(hipGetLastError());
-    T.begin("msm_combine", s);
-    hipLaunchKernelGGL(msm_combine_small<C>, dim3(256), dim3(256), 0, s, PS.multi.as<MultiBucket>(),
-                       PS.counters.as<uint32_t>(), S.partials.as<Pt>(), S.buckets.as<Pt>(), PS.bstart.as<uint32_t>(),
-                       PS.bend.as<uint32_t>(), nbuckets);
-    hipLaunchKernelGGL(msm_combine_wave<C>, dim3(2048), dim3(64), 0, s, PS.multi.as<MultiBucket>(),
-                       PS.counters.as<uint32_t>(), S.partials.as<Pt>(), S.buckets.as<Pt>());
-    hipLaunchKernelGGL(msm_combine_hot1<C>, dim3(1024), dim3(64), 0, s, PS.hot.as<HotBucket>(), PS.counters.as<uint32_t>(),
-                       S.partials.as<Pt>(), S.hot_sums.as<Pt>());
-    hipLaunchKernelGGL(msm_combine_hot2<C>, dim3(64), dim3(64), 0, s, PS.hot.as<HotBucket>(), PS.counters.as<uint32_t>(),
-                       S.hot_sums.as<Pt>(), S.buckets.as<Pt>());
-    T.end(s);
-    WS_HIP_CHECK(hipGetLastError());
+    P.d_points_used = d_points;
+    P.split = false;
+    int rc = msm_acc_segment<C>(L, P, which, split_first ? 0u : 2u, s);
+    if (rc) return rc;
     // the slot is taken only now: an error above (null points, a failed reserve) leaves it free
     P.active = true;
     *slot_out = slot;
@@ -1225,8 +1382,9 @@ template <> struct TailCurve<G1R29> { typedef G1R29I type; };
 #endif
 
 // reduction tail (chunks, tree, copy of the window sums, completion event) for up to 4 launches of one plan
+// w0, w1: the windows (tail pieces) [w0, w1) only -- one half of a split launch; its rows are copied and `done` recorded
 template <class C>
-static int msm_launch_tail(Lane& L, const int* slot_ids, int nslots, hipStream_t s) {
+static int msm_launch_tail(Lane& L, const int* slot_ids, int nslots, hipStream_t s, uint32_t w0 = 0, uint32_t w1 = 0xffffffffu, hipEvent_t done = nullptr) {
     typedef typename C::PtP Pt;
     Context* X = ctx();
     if (!s) s = L.stream;
@@ -1241,24 +1399,26 @@ static int msm_launch_tail(Lane& L, const int* slot_ids, int nslots, hipStream_t
         ts.chunkA[k] = P.S.chunkA.template as<Pt>();
         ts.sums[k] = P.d_sums.template as<Pt>();
     }
-    const uint32_t W = I.tW, J = I.J, logJ = I.logJ, nsum = I.nsum, m = I.m;
+    const uint32_t J = I.J, logJ = I.logJ, nsum = I.nsum, m = I.m;
+    if (w1 > I.tW) w1 = I.tW;
+    const uint32_t W = w1 - w0;
     KernelTimer& T = X->timer;
     T.begin("msm_chunks", s);
-    hipLaunchKernelGGL(msm_chunks<C>, dim3(ceil_div_u64((uint64_t)W * J, 256), nslots), dim3(256), 0, s, ts, W * J, m);
+    hipLaunchKernelGGL(msm_chunks<C>, dim3(ceil_div_u64((uint64_t)W * J, 256), nslots), dim3(256), 0, s, ts, w0 * J, w1 * J, m);
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
     uint32_t tthreads = 1;
     const uint32_t tmax = sizeof(Pt) > 128 ? 256 : 512;   // LDS: threads * sizeof(packed point) <= 64 KiB
     while (tthreads < J && tthreads < tmax) tthreads <<= 1;
     T.begin("msm_tree", s);
-    hipLaunchKernelGGL(msm_tree<C>, dim3(nsum, W, nslots), dim3(tthreads), (size_t)tthreads * sizeof(Pt), s, ts, J, logJ);
+    hipLaunchKernelGGL(msm_tree<C>, dim3(nsum, W, nslots), dim3(tthreads), (size_t)tthreads * sizeof(Pt), s, ts, J, logJ, w0);
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
-    const size_t sums_bytes = (size_t)W * nsum * sizeof(Pt);
+    const size_t row_bytes = (size_t)nsum * sizeof(Pt), sums_bytes = (size_t)W * row_bytes, off = (size_t)w0 * row_bytes;
     for (int k = 0; k < nslots; k++) {
         MsmPending& P = slots[slot_ids[k]];
-        WS_HIP_CHECK(hipMemcpyAsync(P.h_sums, P.d_sums.p, sums_bytes, hipMemcpyDeviceToHost, s));
-        WS_HIP_CHECK(hipEventRecord(P.ev, s));
+        WS_HIP_CHECK(hipMemcpyAsync((uint8_t*)P.h_sums + off, (const uint8_t*)P.d_sums.p + off, sums_bytes, hipMemcpyDeviceToHost, s));
+        WS_HIP_CHECK(hipEventRecord(done ? done : P.ev, s));
     }
     return WS_OK;
 }
@@ -1267,12 +1427,35 @@ template <class C, class H>
 static int msm_launch(Lane& L, int which, const typename H::Aff* d_points_ref, bool prepared, int* slot_out, hipStream_t s,
                       hipEvent_t before_tail = nullptr) {
     if (!s) s = L.stream;
-    int rc = msm_launch_acc<C, H>(L, which, d_points_ref, prepared, slot_out, s);
+    typedef typename TailCurve<C>::type TC;
+    MsmWorkspace& M = ws(L);
+    // A split plan (one whole stand-alone MSM): the accumulation of the HIGH windows, then -- on the lane's second queue -- their
+    // reduction tail beside the accumulation of the LOW windows on this one.  The tail is a latency chain on a few hundred
+    // wavefronts (0.33 ms of 2.04 at 2^20); beside a full-width kernel it is hidden instead of exposed, and the host starts its
+    // Horner chain on the high rows while the low windows are still being reduced.  Only plans built with WSNARK_MSM_SPLIT=1
+    // have two segments (msm_plan_dev: measured slower than one piece, off by default).
+    const MsmPlanInfo& I = M.plan[M.cur].info;
+    const bool split = I.valid && I.n && I.split_k && !before_tail && s != L.stream2 && L.stream2;
+    int rc = msm_launch_acc<C, H>(L, which, d_points_ref, prepared, slot_out, s, split);
     if (rc) return rc;
-    if (before_tail) WS_HIP_CHECK(hipEventRecord(before_tail, s));
-    rc = msm_launch_tail<typename TailCurve<C>::type>(L, slot_out, 1, s);
-    if (rc) msm_abort_slots(L, slot_out, 1, s, nullptr);
-    return rc;
+    MsmPending& P = M.slot[*slot_out];
+    if (!split || P.info.n == 0) {
+        if (before_tail) WS_HIP_CHECK(hipEventRecord(before_tail, s));
+        rc = msm_launch_tail<TC>(L, slot_out, 1, s);
+        if (rc) msm_abort_slots(L, slot_out, 1, s, nullptr);
+        return rc;
+    }
+    hipStream_t s2 = L.stream2;
+    auto fail = [&](int code) { msm_abort_slots(L, slot_out, 1, s, s2); return code; };
+    if (!P.ev_hi && hipEventCreate(&P.ev_hi) != hipSuccess) return fail(WS_ERR_HIP);
+    if (!P.ev_acc && hipEventCreateWithFlags(&P.ev_acc, hipEventDisableTiming) != hipSuccess) return fail(WS_ERR_HIP);
+    P.split = true;
+    if (hipEventRecord(P.ev_acc, s) != hipSuccess || hipStreamWaitEvent(s2, P.ev_acc, 0) != hipSuccess) return fail(WS_ERR_HIP);
+    if ((rc = msm_launch_tail<TC>(L, slot_out, 1, s2, P.info.split_k, P.info.tW, P.ev_hi))) return fail(rc);      // high windows: tail on queue 2
+    if ((rc = msm_acc_segment<C>(L, P, which, 1u, s))) return fail(rc);                                            // low windows: accumulate on queue 1
+    if (hipStreamWaitEvent(s, P.ev_hi, 0) != hipSuccess) return fail(WS_ERR_HIP);                                  // P.ev (recorded next) then covers both queues
+    if ((rc = msm_launch_tail<TC>(L, slot_out, 1, s, 0, P.info.split_k))) return fail(rc);
+    return WS_OK;
 }
 
 // several G1 point sets against the current plan: accumulations back to back, then ONE batched tail
@@ -1461,7 +1644,7 @@ static int msm_dev_t(Lane& L, int which, const Fe* d_scalars, const typename H::
     msm_select_plan(L, 0);
     int rc = convert_beside_plan<CD>(L, d_points, n, s, &pts, &prepared);
     if (rc) return rc;
-    if ((rc = msm_plan_dev(L, d_scalars, n, sh, s, 0))) return rc;
+    if ((rc = msm_plan_dev(L, d_scalars, n, sh, s, 0, true))) return rc;
     if (prepared) WS_HIP_CHECK(hipStreamWaitEvent(s, ws(L).conv_ev[1], 0));
     int slot = -1;
     rc = which == 0 ? msm_g1_launch(L, reinterpret_cast<const Affine<Fq>*>(pts), prepared, &slot, s)
@@ -1498,7 +1681,7 @@ static int msm_host_t(Lane& L, int which, const void* h_scalars, const void* h_p
     int rc = upload_staged(L.host_in[0].p, h_scalars, (size_t)n * 32, s);
     if (rc) return rc;
     msm_select_plan(L, 0);
-    if ((rc = msm_plan_dev(L, L.host_in[0].as<Fe>(), n, sh, s, 0))) return rc;
+    if ((rc = msm_plan_dev(L, L.host_in[0].as<Fe>(), n, sh, s, 0, true))) return rc;
     if ((rc = upload_staged(L.host_in[1].p, h_points, (size_t)n * sizeof(typename H::Aff), s2))) return rc;
     WS_HIP_CHECK(hipEventRecord(M.host_ev, s2));
     WS_HIP_CHECK(hipStreamWaitEvent(s, M.host_ev, 0));
