@@ -340,7 +340,8 @@ size_t wsnark_timing_report(char* buf, size_t cap);
  * FETCH_SIZE counter (run under rocprofv3 --pmc by tools/gpu_session.sh): 3 = 2^25 pseudo-random 64-byte point gathers out
  * of a 1 GiB table (the accumulation kernel's access pattern; 2 GiB of known bytes per launch, kernel
  * `probe_gather64_kernel`), 4 = a 16-B-per-lane streaming read of the same 1 GiB (`probe_stream16_kernel`); both return
- * GB/s of those known bytes. */
+ * GB/s of those known bytes.  5 = one field inversion per lane (the library's Fermat inversion on the radix-2^29 product,
+ * every lane busy): G inversions/s -- what a lane-parallel batch inversion costs per batch. */
 int wsnark_peak_probe(int probe, double* gops_per_s);
 
 #ifdef __cplusplus

@@ -66,3 +66,84 @@ def test_argument_errors(lib):
     # a proof at infinity is well-formed and simply does not verify
     inf = {"pi_a": ["0", "1", "0"], "pi_b": [["0", "0"], ["1", "0"], ["0", "0"]], "pi_c": ["0", "1", "0"]}
     assert groth16_verify(lib, vk, c["inputs"], inf) is False
+
+
+# ---- malformed points: off-curve coordinates and twist points outside the order-r subgroup are INVALID ----
+Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+
+
+def _f2_mul(a, b):
+    return ((a[0] * b[0] - a[1] * b[1]) % Q, (a[0] * b[1] + a[1] * b[0]) % Q)
+
+
+def _f2_inv(a):
+    n = pow((a[0] * a[0] + a[1] * a[1]) % Q, Q - 2, Q)
+    return (a[0] * n % Q, (-a[1]) * n % Q)
+
+
+def _f2_sqrt(a):
+    """sqrt in Fq[u]/(u^2 + 1), q = 3 mod 4 (complex method); None if a is not a square."""
+    if a == (0, 0):
+        return (0, 0)
+    norm = (a[0] * a[0] + a[1] * a[1]) % Q
+    s = pow(norm, (Q + 1) // 4, Q)
+    if s * s % Q != norm:
+        return None
+    half = pow(2, Q - 2, Q)
+    for sign in (1, -1):
+        t = (a[0] + sign * s) * half % Q
+        x0 = pow(t, (Q + 1) // 4, Q)
+        if x0 * x0 % Q == t and x0:
+            x1 = a[1] * pow(2 * x0 % Q, Q - 2, Q) % Q
+            if _f2_mul((x0, x1), (x0, x1)) == (a[0] % Q, a[1] % Q):
+                return (x0, x1)
+    return None
+
+
+def _twist_point_outside_g2():
+    """A point on the twist y^2 = x^3 + 3/(9 + u) (src/bn128/build_bn128.js:79-90) -- almost surely NOT in the order-r
+    subgroup (the twist's cofactor is ~2^254)."""
+    b2 = _f2_mul((3, 0), _f2_inv((9, 1)))
+    k = 1
+    while True:
+        x = (k, 7 * k + 1)
+        x3 = _f2_mul(_f2_mul(x, x), x)
+        y = _f2_sqrt(((x3[0] + b2[0]) % Q, (x3[1] + b2[1]) % Q))
+        if y is not None:
+            return x, y
+        k += 1
+
+
+def test_malformed_points_are_invalid_not_paired(lib):
+    from wasmsnark_amd.bn128 import groth16_verify
+    vk = json.load(open(os.path.join(GOLDEN, "keys", "t6.vk.json")))
+    pub = json.load(open(os.path.join(GOLDEN, "keys", "t6.public.json")))
+    good = load_golden("proofs.json")["t6"][1]["proof"]
+    assert groth16_verify(lib, vk, pub, good) is True
+    # G1 off the curve (y + 1), in pi_a, pi_c, the key's alfa1 and an IC point
+    bump = lambda p: [p[0], str((int(p[1]) + 1) % Q), p[2]]
+    assert groth16_verify(lib, vk, pub, dict(good, pi_a=bump(good["pi_a"]))) is False
+    assert groth16_verify(lib, vk, pub, dict(good, pi_c=bump(good["pi_c"]))) is False
+    assert groth16_verify(lib, dict(vk, vk_alfa_1=bump(vk["vk_alfa_1"])), pub, good) is False
+    assert groth16_verify(lib, dict(vk, IC=[bump(vk["IC"][0])] + vk["IC"][1:]), pub, good) is False
+    # G2 off the twist
+    b = good["pi_b"]
+    assert groth16_verify(lib, vk, pub, dict(good, pi_b=[b[0], [b[1][0], str((int(b[1][1]) + 1) % Q)], b[2]])) is False
+    # G2 ON the twist but outside the order-r subgroup: in pi_b and as the key's gamma2 / delta2
+    x, y = _twist_point_outside_g2()
+    rogue = [[str(x[0]), str(x[1])], [str(y[0]), str(y[1])], ["1", "0"]]
+    assert groth16_verify(lib, vk, pub, dict(good, pi_b=rogue)) is False
+    assert groth16_verify(lib, dict(vk, vk_gamma_2=rogue), pub, good) is False
+    assert groth16_verify(lib, dict(vk, vk_delta_2=rogue), pub, good) is False
+    # the z coordinates of the proof are ignored like the reference does (src/bn128.js:741-760 force z = 1)
+    assert groth16_verify(lib, vk, pub, dict(good, pi_a=[good["pi_a"][0], good["pi_a"][1], "0"], pi_c=good["pi_c"][:2] + ["5"])) is True
+
+
+def test_input_count_cannot_wrap_the_size_check(lib):
+    """(n_inputs + 1) * 64 wraps for n_inputs near 2^58: the size comparison is done without the product."""
+    import ctypes as C
+    vkb = bytes(512)
+    valid = C.c_int(7)
+    for n_inputs in (1 << 58, (1 << 58) - 1, (1 << 64) - 1, 2):
+        rc = lib.c.wsnark_groth16_verify(vkb, len(vkb), bytes(64), C.c_uint64(n_inputs), bytes(384), C.byref(valid))
+        assert rc == 1 and valid.value == 0, n_inputs      # WSNARK_ERR_SIZE, nothing read past the key

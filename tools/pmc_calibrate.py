@@ -14,8 +14,9 @@ import wasmsnark_amd  # noqa: E402
 
 bn = wasmsnark_amd.build(device=0)
 out = {"known_bytes_per_launch": {"probe_gather64_kernel": (1 << 20) * 32 * 64, "probe_stream16_kernel": 1 << 30}, "launches_each": 3}
-for name, probe in (("modmul_G_per_s", 0), ("modmul_inlined_G_per_s", 1), ("mad_u64_u32_G_per_s", 2), ("gather64_GB_per_s", 3), ("stream16_GB_per_s", 4)):
+for name, probe in (("modmul_G_per_s", 0), ("modmul_inlined_G_per_s", 1), ("mad_u64_u32_G_per_s", 2), ("gather64_GB_per_s", 3), ("stream16_GB_per_s", 4), ("inversions_G_per_s", 5)):
     v = C.c_double(0)
     bn.lib.check(bn.lib.c.wsnark_peak_probe(probe, C.byref(v)))
-    out[name] = round(v.value, 1)
+    out[name] = round(v.value, 4 if v.value < 10 else 1)
+out["products_per_inversion_equivalent"] = round(out["modmul_inlined_G_per_s"] / out["inversions_G_per_s"], 1) if out.get("inversions_G_per_s") else None
 print(json.dumps(out))

@@ -228,8 +228,10 @@ int pols_to_csr(const uint8_t* pols, size_t len, uint32_t n_signals, uint32_t do
     if (bad.load()) { set_last_error("pols: coefficient index >= domainSize"); return WS_ERR_FORMAT; }
     std::vector<uint32_t> row_ptr((size_t)domain + 1, 0);
     for (uint32_t r = 0; r < domain; r++) row_ptr[(size_t)r + 1] = row_ptr[r] + cnt[(size_t)r + 1].load(std::memory_order_relaxed);
-    std::vector<uint32_t> col((size_t)nnz ? (size_t)nnz : 1);
-    std::vector<Fe> coef((size_t)nnz ? (size_t)nnz : 1);
+    // (plain arrays, not vectors: 36 bytes per non-zero need no zero-fill before they are written)
+    const size_t nz = (size_t)nnz ? (size_t)nnz : 1;
+    std::unique_ptr<uint32_t[]> col(new uint32_t[nz]);
+    std::unique_ptr<Fe[]> coef(new Fe[nz]);
     // pass 2 (parallel): fill; cnt[] becomes the per-row cursor
     for (uint32_t r = 0; r < domain; r++) cnt[r].store(row_ptr[r], std::memory_order_relaxed);
     host_parallel_for(n_signals, [&](uint64_t lo, uint64_t hi) {
@@ -245,11 +247,12 @@ int pols_to_csr(const uint8_t* pols, size_t len, uint32_t n_signals, uint32_t do
     if (consumed) *consumed = pp;
     out->n_rows = domain; out->n_cols = n_signals; out->nnz = nnz;
     WS_HIP_CHECK(out->row_ptr.alloc(row_ptr.size() * 4));
-    WS_HIP_CHECK(out->col.alloc(col.size() * 4));
-    WS_HIP_CHECK(out->coef.alloc(coef.size() * sizeof(Fe)));
-    WS_HIP_CHECK(hipMemcpyAsync(out->row_ptr.p, row_ptr.data(), row_ptr.size() * 4, hipMemcpyHostToDevice, s));
-    WS_HIP_CHECK(hipMemcpyAsync(out->col.p, col.data(), col.size() * 4, hipMemcpyHostToDevice, s));
-    WS_HIP_CHECK(hipMemcpyAsync(out->coef.p, coef.data(), coef.size() * sizeof(Fe), hipMemcpyHostToDevice, s));
+    WS_HIP_CHECK(out->col.alloc(nz * 4));
+    WS_HIP_CHECK(out->coef.alloc(nz * sizeof(Fe)));
+    int rc;
+    if ((rc = upload_staged(out->row_ptr.p, row_ptr.data(), row_ptr.size() * 4, s))) return rc;
+    if ((rc = upload_staged(out->col.p, col.get(), nz * 4, s))) return rc;
+    if ((rc = upload_staged(out->coef.p, coef.get(), nz * sizeof(Fe), s))) return rc;
     WS_HIP_CHECK(hipStreamSynchronize(s));
     return WS_OK;
 }

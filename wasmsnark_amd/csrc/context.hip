@@ -4,6 +4,9 @@
 #include <string.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <vector>
 #include <thread>
 
 #include <chrono>
@@ -120,6 +123,49 @@ LaneLock::~LaneLock() {
 }
 
 // ---- staged uploads ----
+// n persistent worker threads; run(n, fn) executes fn(0) on the caller and fn(1..n-1) on the pool, and returns when all are done.
+// One job at a time (upload_staged holds its ring mutex around run()).  The threads live as long as the process.
+struct StagePool {
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    std::vector<std::thread> th;
+    const std::function<void(int)>* job = nullptr;
+    unsigned long generation = 0;
+    int pending = 0;
+    void loop(int w) {
+        unsigned long seen = 0;
+        for (;;) {
+            const std::function<void(int)>* f;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_go.wait(lk, [&] { return generation != seen; });
+                seen = generation;
+                f = job;
+            }
+            (*f)(w);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--pending == 0) cv_done.notify_one();
+            }
+        }
+    }
+    void run(int n, const std::function<void(int)>& fn) {
+        if ((int)th.size() < n - 1) {
+            for (int w = (int)th.size() + 1; w < n; w++) { th.emplace_back([this, w] { loop(w); }); th.back().detach(); }
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = &fn;
+            pending = n - 1;
+            generation++;
+        }
+        cv_go.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+};
+
 static const size_t PIN_CHUNK = (size_t)8 << 20;
 static const int PIN_WORKERS = 8, PIN_PER_WORKER = 2;
 int upload_staged(void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
@@ -142,9 +188,16 @@ int upload_staged(void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
         for (auto& e : C->pin_ev) WS_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     // chunk length: the ring's slots are 8 MiB, but a 32 MiB witness cut into 8 MiB pieces gives every worker ONE piece --
-    // no DMA starts before a whole 8 MiB memcpy is done and nothing overlaps (measured: 1.4 ms for 32 MiB).  Shorter pieces
-    // (a 32nd of the buffer, 512 KiB .. 8 MiB) keep four pieces per worker in flight behind each other.
-    size_t chunk = (bytes / (4 * PIN_WORKERS) + 0xFFFF) & ~(size_t)0xFFFF;
+    // no DMA starts before a whole 8 MiB memcpy is done and nothing overlaps.  Shorter pieces (a 32nd of the buffer,
+    // 512 KiB .. 8 MiB) keep four pieces per worker in flight behind each other.
+    // Swept on the MI355X box with a 32 MiB witness (profiles/r03_s8_stage_sweep.txt): the proof from a host witness costs
+    // 1.0-1.4 ms more than from a resident one whatever the split -- that is the PCIe transfer itself (32 MiB at ~35 GB/s) --
+    // best with two workers and one or two pieces each; a 0.6 GB key section wants all eight (memcpy-bound: 10 ms).
+    static const int env_workers = [] { const char* e = getenv("WSNARK_STAGE_WORKERS"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > PIN_WORKERS ? PIN_WORKERS : v); }();
+    static const int env_pieces = [] { const char* e = getenv("WSNARK_STAGE_PIECES"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+    int n_workers = env_workers;
+    if (!n_workers) { n_workers = (int)(bytes >> 24); n_workers = n_workers < 2 ? 2 : (n_workers > PIN_WORKERS ? PIN_WORKERS : n_workers); }   // one per 16 MiB, 2..8
+    size_t chunk = (bytes / ((size_t)env_pieces * n_workers) + 0xFFFF) & ~(size_t)0xFFFF;
     chunk = chunk < ((size_t)512 << 10) ? ((size_t)512 << 10) : (chunk > PIN_CHUNK ? PIN_CHUNK : chunk);
     const size_t nchunks = (bytes + chunk - 1) / chunk;
     const int device = C->device;
@@ -152,7 +205,7 @@ int upload_staged(void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
     auto worker = [&](int w) {
         if (hipSetDevice(device) != hipSuccess) { err = 1; return; }
         int use = 0;
-        for (size_t c = (size_t)w; c < nchunks; c += PIN_WORKERS, use++) {
+        for (size_t c = (size_t)w; c < nchunks; c += (size_t)n_workers, use++) {
             const int b = w * PIN_PER_WORKER + (use % PIN_PER_WORKER);
             char* pin = (char*)C->pin_ring + (size_t)b * PIN_CHUNK;
             // the buffer's previous DMA (this call or an earlier one) must have drained
@@ -163,10 +216,10 @@ int upload_staged(void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
                 hipEventRecord(C->pin_ev[b], s) != hipSuccess) { err = 1; return; }
         }
     };
-    std::thread th[PIN_WORKERS - 1];
-    for (int w = 1; w < PIN_WORKERS; w++) th[w - 1] = std::thread(worker, w);
-    worker(0);
-    for (auto& t : th) t.join();
+    // The copy workers are PERSISTENT threads (created once, parked on a condition variable): spawning seven threads per
+    // upload cost ~0.4 ms of the 0.87 ms a 32 MiB witness took to stage (measured, profiles/r03_s6_hostwitness.txt).
+    static StagePool* pool = new StagePool();       // never destroyed: its threads are parked on it until the process ends
+    pool->run(n_workers, worker);
     if (err) { set_last_error("staged upload failed"); return WS_ERR_HIP; }
     return WS_OK;
 #endif

@@ -47,6 +47,8 @@ struct ProvingKey {
     // per-proof buffers and events).
 };
 
+const std::string& get_last_error();
+
 static bool range_ok(uint64_t off, uint64_t bytes, size_t len) { return off <= len && bytes <= len - off; }
 
 struct KeySections {      // everything wsnark_pkey_load reads from proving_key.bin, as separate host buffers
@@ -130,10 +132,26 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
         return ms;
     };
     auto t_phase = t_begin;
-    int rc = pols_to_csr(S.polsA, (size_t)S.lenA, nv, dom, &K->polsA, &used, s);
-    if (rc) return rc;
-    rc = pols_to_csr(S.polsB, (size_t)S.lenB, nv, dom, &K->polsB, &used, s);
-    if (rc) return rc;
+    // the two record streams are transposed side by side (host threads; the B side on a queue of its own)
+    int rc;
+    {
+        hipStream_t sb = nullptr;
+        WS_HIP_CHECK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+        size_t used_b = 0;
+        const int device = C->device;
+        std::string err_b;                      // (the error text is per thread: carried back by hand)
+        std::future<int> fb = std::async(std::launch::async, [&, device, sb]() {
+            if (hipSetDevice(device) != hipSuccess) return (int)WS_ERR_HIP;
+            const int r = pols_to_csr(S.polsB, (size_t)S.lenB, nv, dom, &K->polsB, &used_b, sb);
+            if (r) err_b = get_last_error();
+            return r;
+        });
+        rc = pols_to_csr(S.polsA, (size_t)S.lenA, nv, dom, &K->polsA, &used, s);
+        const int rcb = fb.get();
+        (void)hipStreamDestroy(sb);
+        if (rc) return rc;
+        if (rcb) { set_last_error(err_b); return rcb; }
+    }
     K->load_ms[0] = lap(t_phase);
     // the rank's slice of every section.  C holds points for signals nPublic+1.. only (src/bn128.js:620 slices the scalars
     // instead).  Resident copy: padded in front with infinities (x == 0) for the signals 0..nPublic, so that the C sum uses
@@ -722,7 +740,9 @@ int groth16_prove_host_witness(ProvingKey* K, const uint8_t* witness, size_t wit
     rc = check_witness_len(K, witness_len);
     if (rc) return rc;
     LaneLock L = acquire_lane(C);
+    Trace tr;
     if ((rc = upload_witness(K, *L, witness))) return rc;
+    if (tr.on) { tr.mark("witness staged (host side)"); (void)hipStreamSynchronize(L->stream); tr.mark("witness resident (DMA drained)"); }
     return groth16_prove(K, *L, L->witness.as<Fe>(), r32, s32, out384, L->stream);
 }
 

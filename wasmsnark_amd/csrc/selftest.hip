@@ -378,11 +378,20 @@ static int traffic_probe(Context* C, int probe, double* gbs) {
     return WS_OK;
 }
 
+// probe 5: one field inversion per lane and iteration (Fq29::inv: Fermat, x^(q-2) by square-and-multiply on the radix-2^29 product),
+// every lane busy -- the cost a LANE-PARALLEL batch inversion adds per batch (the batch-affine analysis of DESIGN.md); G inversions/s
+__global__ __launch_bounds__(256) void probe_inverse_kernel(const Fe* __restrict__ in, Fe* __restrict__ out, int iters) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    Fq29::El x = Fq29::to_internal(in[t]);
+    for (int i = 0; i < iters; i++) x = Fq29::inv(x);
+    out[t] = Fq29::from_internal(x);
+}
+
 int peak_probe(int probe, double* gops) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
-    if (!gops || probe < 0 || probe > 4) return WS_ERR_ARG;
-    if (probe >= 3) return traffic_probe(C, probe, gops);
+    if (!gops || probe < 0 || probe > 5) return WS_ERR_ARG;
+    if (probe == 3 || probe == 4) return traffic_probe(C, probe, gops);
     hipStream_t s = C->stream;
     const uint32_t blocks = (uint32_t)C->num_cu * 8, threads = 256, total = blocks * threads;
     DevBuf in, out;
@@ -392,12 +401,13 @@ int peak_probe(int probe, double* gops) {
     hipEvent_t a = nullptr, b = nullptr;
     WS_HIP_CHECK(hipEventCreate(&a));
     WS_HIP_CHECK(hipEventCreate(&b));
-    const int iters = probe == 2 ? 20000 : 2000;
+    const int iters = probe == 2 ? 20000 : probe == 5 ? 8 : 2000;
     double best = 0;
     for (int rep = 0; rep < 4; rep++) {          // the first repetition warms the clocks; the best of the rest counts
         (void)hipEventRecord(a, s);
         if (probe == 0) hipLaunchKernelGGL(probe_modmul_kernel<Fq29>, dim3(blocks), dim3(threads), 0, s, in.as<Fe>(), out.as<Fe>(), iters);
         else if (probe == 1) hipLaunchKernelGGL(probe_modmul_kernel<Fq29I>, dim3(blocks), dim3(threads), 0, s, in.as<Fe>(), out.as<Fe>(), iters);
+        else if (probe == 5) hipLaunchKernelGGL(probe_inverse_kernel, dim3(blocks), dim3(threads), 0, s, in.as<Fe>(), out.as<Fe>(), iters);
         else hipLaunchKernelGGL(probe_mad_kernel, dim3(blocks), dim3(threads), 0, s, out.as<uint64_t>(), 12345u, 777u, iters);
         (void)hipEventRecord(b, s);
         if (hipEventSynchronize(b) != hipSuccess) break;
