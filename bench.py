@@ -37,6 +37,7 @@ MODMUL_PEAK_G = 172.0            # tools/microbench.hip on MI355X (profiles/r01_
 DTYPE = "u256 (Montgomery; 9x29-bit limbs, v_mad_u64_u32)"
 REF_WASM_PROVE_2P20_S = 132.6    # the reference (Node + WASM, 8 workers) in the survey container -- OTHER hardware
 REF_WASM_MSM_MPTS = 0.0695
+EXTRA_REPS = int(os.environ.get("WSNARK_BENCH_EXTRA_REPS", "20"))   # repetitions inside the extras (the CPU dry run of tests/ lowers it)
 
 
 def kernel_ms(report, per=1):
@@ -409,7 +410,7 @@ def extra_prove_inflight(ctx, key, d_w, wlen, r32, s32, want, ms_single):
     """Two host threads, one key handle: each proof holds a lane; one proof's reduction tails leave SIMDs idle that the
     other's full-width kernels take."""
     bn, torch = ctx["bn"], ctx["torch"]
-    reps, bad = 10, []
+    reps, bad = min(10, EXTRA_REPS), []
 
     def worker():
         for _ in range(reps):
@@ -456,11 +457,11 @@ def extra_msm(ctx, cold):
     bn, torch, args = ctx["bn"], ctx["torch"], ctx["args"]
     n, rng, sc, pts, d_s, d_p = msm_inputs(ctx, args.log_n, 1234)
     call = lambda: bn.g1_multiexp_dev(d_s.data_ptr(), d_p.data_ptr(), n)
-    for _ in range(10):
+    for _ in range(min(10, EXTRA_REPS)):
         ref = call()
     bn.lib.c.wsnark_timing_reset(); bn.lib.c.wsnark_timing_enable(2)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    reps = 20
+    reps = EXTRA_REPS
     for _ in range(reps):
         call()
     torch.cuda.synchronize()

@@ -24,7 +24,7 @@ def test_bench_single_gpu_line():
     emul_bn128()
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_dryrun.py"), "--prove-log-domain", "6", "--log-n", "8",
                           "--steps", "2", "--warmup", "1", "--extras", "msm,inflight"],
-                         capture_output=True, text=True, timeout=900)
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, WSNARK_BENCH_EXTRA_REPS="2"))
     d = _line(out)
     assert all(k in d for k in FIELDS) and d["n_gpus"] == 1 and d["higher_is_better"] is False and d["unit"] == "ms"
     assert d["proofs_match_toxic_waste_closed_form"] is True

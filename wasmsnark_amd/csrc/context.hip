@@ -61,6 +61,7 @@ int context_init(int device) {
         WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
         if (prio && hipStreamCreateWithPriority(&L.stream2, hipStreamNonBlocking, hi) != hipSuccess) L.stream2 = nullptr;
         if (!L.stream2) WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream2, hipStreamNonBlocking));   // (no priorities here)
+        WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream3, hipStreamNonBlocking));
     }
     g_ctx = C;
     return WS_OK;
@@ -74,6 +75,7 @@ void context_shutdown() {
     for (int i = 0; i < g_ctx->n_lanes; i++) {
         (void)hipStreamSynchronize(g_ctx->lanes[i].stream);
         (void)hipStreamSynchronize(g_ctx->lanes[i].stream2);
+        (void)hipStreamSynchronize(g_ctx->lanes[i].stream3);
     }
     g_ctx->timer.reset();
     for (hipEvent_t e : g_ctx->timer.pool) (void)hipEventDestroy(e);
@@ -84,7 +86,7 @@ void context_shutdown() {
     for (int i = 0; i < g_ctx->n_lanes; i++) {
         Lane& L = g_ctx->lanes[i];
         msm_workspace_free(L);
-        for (hipEvent_t* e : {&L.ntt_chain.done, &L.calch_chain.done, &L.ev_start, &L.ev_tail, &L.ev_h})
+        for (hipEvent_t* e : {&L.ntt_chain.done, &L.calch_chain.done, &L.ev_start, &L.ev_tail, &L.ev_h, &L.ev_plan, &L.ev_g2})
             if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
         L.ntt_scratch.release();
         for (auto& b : L.calch_buf) b.release();
@@ -93,6 +95,7 @@ void context_shutdown() {
         L.witness.release(); L.h.release();
         (void)hipStreamDestroy(L.stream);
         (void)hipStreamDestroy(L.stream2);
+        (void)hipStreamDestroy(L.stream3);
     }
     (void)hipStreamDestroy(g_ctx->stream);
     delete g_ctx;
@@ -131,7 +134,7 @@ struct StagePool {
     std::vector<std::thread> th;
     const std::function<void(int)>* job = nullptr;
     unsigned long generation = 0;
-    int pending = 0;
+    int pending = 0, active = 0;                  // workers 1 .. active-1 take part in the current job; the others stay parked
     void loop(int w) {
         unsigned long seen = 0;
         for (;;) {
@@ -140,6 +143,7 @@ struct StagePool {
                 std::unique_lock<std::mutex> lk(mu);
                 cv_go.wait(lk, [&] { return generation != seen; });
                 seen = generation;
+                if (w >= active) continue;          // a job with fewer workers than the pool has threads: not this one's
                 f = job;
             }
             (*f)(w);
@@ -156,6 +160,7 @@ struct StagePool {
         {
             std::lock_guard<std::mutex> lk(mu);
             job = &fn;
+            active = n;
             pending = n - 1;
             generation++;
         }

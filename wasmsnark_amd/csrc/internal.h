@@ -69,6 +69,7 @@ struct Lane {
     std::mutex mu;
     hipStream_t stream = nullptr;               // first in-order queue (or the caller's stream for _dev entry points)
     hipStream_t stream2 = nullptr;              // second queue (prover: CALC_H and the H sum beside the tails)
+    hipStream_t stream3 = nullptr;              // third queue (small proofs / points shards: the G2 sum beside the G1 sums)
     MsmWorkspace* msm = nullptr;                // plans, launch slots (owned; msm_workspace_free)
     DevBuf host_in[2];                          // host-pointer boundary: grow-only device copies of the caller's buffers
     DevBuf ntt_scratch;                         // ping-pong buffer of the multi-pass transforms
@@ -77,6 +78,7 @@ struct Lane {
     ScratchChain ntt_chain, calch_chain;        // who may touch ntt_scratch / calch_buf next (calls return before the GPU is done)
     DevBuf witness, h;                          // per-proof device buffers (grow-only)
     hipEvent_t ev_start = nullptr, ev_tail = nullptr, ev_h = nullptr;   // cross-queue ordering of one proof
+    hipEvent_t ev_plan = nullptr, ev_g2 = nullptr;                      // ... witness plan ready / G2 sum enqueued (third queue)
 };
 static const int kMaxLanes = 4;
 

@@ -368,7 +368,7 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
     int &hA = slots[0], &hB1 = slots[1], &hC = slots[2], &hB2 = slots[3], &hH = slots[4];
     struct Abort {
         Lane& L; int* slots; hipStream_t a, b; bool armed;
-        ~Abort() { if (armed) { msm_select_plan(L, 0); msm_abort_slots(L, slots, 5, a, b); } }
+        ~Abort() { if (armed) { msm_select_plan(L, 0); if (L.stream3) (void)hipStreamSynchronize(L.stream3); msm_abort_slots(L, slots, 5, a, b); } }
     } guard{L, slots, s, s2, true};
     for (hipEvent_t* e : {&L.ev_start, &L.ev_tail, &L.ev_h})
         if (!*e) WS_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -387,7 +387,16 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
     // beside CALC_H's full-width kernels instead of at the end of the proof, where nothing is left to fill the SIMDs
     // (WSNARK_PROVE_ORDER=0: the round-1 order A, B1, C, B2).  A and B1 reach the host before C's accumulation ends,
     // so the host's share of pi_c (after_ab1) still overlaps GPU work.
-    static const int order = [] { const char* e = getenv("WSNARK_PROVE_ORDER"); return e ? atoi(e) : 1; }();
+    static const int order_env = [] { const char* e = getenv("WSNARK_PROVE_ORDER"); return e ? atoi(e) : -1; }();
+    // Order 3 (round 3; small sums: a rank's share of a points-sharded key, small circuits): every sum of such a proof is a
+    // latency chain -- grouping, a sub-millisecond accumulation on a fraction of the SIMDs, a reduction tail of ~33 dependent
+    // additions -- so the chains run BESIDE each other instead of behind each other: B2 with its tail on a third queue, A, B1
+    // and C under ONE batched tail on the first, CALC_H and H on the second.  At full size the accumulations fill the chip and
+    // the same arrangement loses (round 1 / 2 sweeps: kernels that share the SIMDs starve each other), hence the size switch:
+    // fewer than 2^23 (row, pair) entries per G1 sum.  Measured on the 8 shards of a 2^20 key, one GPU, rank after rank
+    // (tools/shard_probe.py): 3.7 -> see profiles/r03_s11_shard_probe_2p20.json.
+    const bool small = (uint64_t)nv * msm_table_rows(K->table_cw ? K->table_cw : 16) < ((uint64_t)1 << 23);
+    const int order = order_env >= 0 ? order_env : (small && L.stream3 && s != L.stream3 ? 3 : 1);
     const bool g2_first = order != 0;
     auto launch_b2 = [&]() -> int {
         msm_select_plan(L, planB);
@@ -395,7 +404,26 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
         msm_select_plan(L, 0);
         return r;
     };
-    if (g2_first) {
+    if (order == 3) {
+        hipStream_t s3 = L.stream3;
+        for (hipEvent_t* e : {&L.ev_plan, &L.ev_g2})
+            if (!*e) WS_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        WS_HIP_CHECK(hipEventRecord(L.ev_plan, s));                  // the plan (and its variants) are complete on s
+        WS_HIP_CHECK(hipStreamWaitEvent(s3, L.ev_plan, 0));
+        msm_select_plan(L, planB);
+        rc = msm_g2_launch(L, K->pointsB2.as<Affine<Fq2>>(), true, &hB2, s3);                              // :619, on its own queue
+        msm_select_plan(L, 0);
+        if (rc) return rc;
+        WS_HIP_CHECK(hipEventRecord(L.ev_g2, s3));
+        const Affine<Fq>* g1sets[3] = {K->pointsA.as<Affine<Fq>>(), K->pointsB1.as<Affine<Fq>>(), K->pointsC.as<Affine<Fq>>()};
+        const int plans[3] = {planA, planB, 0};
+        int g1slots[3] = {-1, -1, -1};
+        rc = msm_g1_launch_batch(L, g1sets, 3, true, g1slots, s, L.ev_tail, plans);                        // :617, :618, :620: one tail
+        hA = g1slots[0]; hB1 = g1slots[1]; hC = g1slots[2];
+        if (rc) return rc;
+        WS_HIP_CHECK(hipStreamWaitEvent(s, L.ev_g2, 0));              // s stays the caller's ordering point
+        tr.mark("plan(w) + B2 on queue 3 + A, B1, C batched");
+    } else if (g2_first) {
         if ((rc = launch_b2())) return rc;
         tr.mark("plan(w) [+ variants] + launch B2");
         const Affine<Fq>* g1sets[3] = {K->pointsA.as<Affine<Fq>>(), K->pointsB1.as<Affine<Fq>>(), K->pointsC.as<Affine<Fq>>()};
@@ -450,18 +478,19 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
     if (rc) return rc;
     if (s2 != s) { WS_HIP_CHECK(hipEventRecord(L.ev_h, s2)); WS_HIP_CHECK(hipStreamWaitEvent(s, L.ev_h, 0)); }   // s stays the caller's ordering point
     tr.mark("plan(h) + launch H");
-    if (g2_first && (rc = msm_g2_finish(L, hB2, &out->B2))) return rc;
+    const bool g2_fin = g2_first && order != 3;      // (order 3: B2 ends on its own queue, A / B1 / C come first)
+    if (g2_fin && (rc = msm_g2_finish(L, hB2, &out->B2))) return rc;
     if ((rc = msm_g1_finish(L, hA, &out->A))) return rc;
     if ((rc = msm_g1_finish(L, hB1, &out->B1))) return rc;
-    tr.mark(g2_first ? "finish B2, A, B1" : "finish A, B1");
+    tr.mark(g2_fin ? "finish B2, A, B1" : "finish A, B1");
     if (after_ab1) after_ab1(*out);
-    if (!g2_first && (rc = msm_g1_finish(L, hC, &out->C))) return rc;
-    tr.mark(g2_first ? "host work on A, B1" : "host work on A, B1; finish C");
+    if (!g2_fin && (rc = msm_g1_finish(L, hC, &out->C))) return rc;
+    tr.mark(g2_fin ? "host work on A, B1" : "host work on A, B1; finish C");
     // the two queues end independently: finish whichever sum reaches the host first (its serial host tail then runs while
     // the GPU still works on the other one), so poll both instead of blocking on one
     {
-        const int hX = g2_first ? hC : hB2;                 // the first queue's last sum
-        auto finish_x = [&]() -> int { return g2_first ? msm_g1_finish(L, hC, &out->C) : msm_g2_finish(L, hB2, &out->B2); };
+        const int hX = g2_fin ? hC : hB2;                 // the first queue's last sum
+        auto finish_x = [&]() -> int { return g2_fin ? msm_g1_finish(L, hC, &out->C) : msm_g2_finish(L, hB2, &out->B2); };
         bool doneX = false, doneH = false;
         for (unsigned spins = 0; !(doneX && doneH); spins++) {
             if (!doneX && (doneH || msm_ready(L, hX))) { if ((rc = finish_x())) return rc; doneX = true; continue; }
@@ -473,7 +502,7 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
             }
         }
     }
-    tr.mark(g2_first ? "finish H, C" : "finish H, B2");
+    tr.mark(g2_first && order != 3 ? "finish H, C" : "finish H, B2");
     guard.armed = false;
     return WS_OK;
 }

@@ -393,7 +393,11 @@ int peak_probe(int probe, double* gops) {
     if (!gops || probe < 0 || probe > 5) return WS_ERR_ARG;
     if (probe == 3 || probe == 4) return traffic_probe(C, probe, gops);
     hipStream_t s = C->stream;
+#ifdef WSNARK_EMUL
+    const uint32_t blocks = 2, threads = 256, total = blocks * threads;      // (CPU thread emulator: the control flow only, no rate)
+#else
     const uint32_t blocks = (uint32_t)C->num_cu * 8, threads = 256, total = blocks * threads;
+#endif
     DevBuf in, out;
     WS_HIP_CHECK(in.alloc((size_t)total * 32));
     WS_HIP_CHECK(out.alloc((size_t)total * 32));
@@ -401,7 +405,11 @@ int peak_probe(int probe, double* gops) {
     hipEvent_t a = nullptr, b = nullptr;
     WS_HIP_CHECK(hipEventCreate(&a));
     WS_HIP_CHECK(hipEventCreate(&b));
+#ifdef WSNARK_EMUL
+    const int iters = 2;
+#else
     const int iters = probe == 2 ? 20000 : probe == 5 ? 8 : 2000;
+#endif
     double best = 0;
     for (int rep = 0; rep < 4; rep++) {          // the first repetition warms the clocks; the best of the rest counts
         (void)hipEventRecord(a, s);
