@@ -543,14 +543,33 @@ __global__ __launch_bounds__(256) void msm_plan_emit_hot(const HotBucket* __rest
     }
 }
 
+// Up to 4 point sets per launch (blockIdx.y selects one): the sets of a proof that share a plan -- or run on variants of it --
+// are accumulated and combined by ONE launch each, so that small sums, which fill a fraction of the chip each, run beside
+// each other instead of behind each other (a rank's share of a points-sharded key; circuits up to 2^19).
+template <class C>
+struct AccSets {
+    const typename C::AffP* points[4];
+    const uint32_t* vals[4];
+    const Task* tasks[4];
+    const uint32_t* counters[4];
+    const MultiBucket* multi[4];
+    const HotBucket* hot[4];
+    const uint32_t* bstart[4];
+    const uint32_t* bend[4];
+    typename C::PtP* buckets[4];
+    typename C::PtP* partials[4];
+    typename C::PtP* hot_sums[4];
+};
+
 // 4. one lane per task: mixed additions of the task's points
 template <class C>
-__global__ __launch_bounds__(256, (sizeof(typename C::PtP) > 128 ? WS_ACC_WAVES_G2 : WS_ACC_WAVES)) void msm_accumulate(const typename C::AffP* __restrict__ points,
-                                                        const uint32_t* __restrict__ vals,
-                                                        const Task* __restrict__ tasks,
-                                                        const uint32_t* __restrict__ counters,
-                                                        typename C::PtP* __restrict__ buckets,
-                                                        typename C::PtP* __restrict__ partials, uint32_t seg) {
+__global__ __launch_bounds__(256, (sizeof(typename C::PtP) > 128 ? WS_ACC_WAVES_G2 : WS_ACC_WAVES)) void msm_accumulate(AccSets<C> as, uint32_t seg) {
+    const typename C::AffP* __restrict__ points = as.points[blockIdx.y];
+    const uint32_t* __restrict__ vals = as.vals[blockIdx.y];
+    const Task* __restrict__ tasks = as.tasks[blockIdx.y];
+    const uint32_t* __restrict__ counters = as.counters[blockIdx.y];
+    typename C::PtP* __restrict__ buckets = as.buckets[blockIdx.y];
+    typename C::PtP* __restrict__ partials = as.partials[blockIdx.y];
     // the grid is sized for the worst case; the real task count stays on the device (no host round trip)
     // seg: 0 / 1 = that task segment of a split plan, 2 = all tasks
     const uint32_t t0 = seg == 1 ? counters[6] : 0u, t1 = seg == 0 ? counters[6] : counters[3];
@@ -627,12 +646,13 @@ __global__ __launch_bounds__(256) void msm_segscan_merge(const uint32_t* __restr
 // 5a. buckets cut into a few tasks: one lane sums the partials
 static const uint32_t WAVE_COMBINE_MIN = 17;
 template <class C>
-__global__ __launch_bounds__(256) void msm_combine_small(const MultiBucket* __restrict__ mbs,
-                                                           const uint32_t* __restrict__ counters,
-                                                           const typename C::PtP* __restrict__ partials,
-                                                           typename C::PtP* __restrict__ buckets,
-                                                           const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bend,
-                                                           uint32_t b_lo, uint32_t b_hi) {
+__global__ __launch_bounds__(256) void msm_combine_small(AccSets<C> as, uint32_t b_lo, uint32_t b_hi) {
+    const MultiBucket* __restrict__ mbs = as.multi[blockIdx.y];
+    const uint32_t* __restrict__ counters = as.counters[blockIdx.y];
+    const typename C::PtP* __restrict__ partials = as.partials[blockIdx.y];
+    typename C::PtP* __restrict__ buckets = as.buckets[blockIdx.y];
+    const uint32_t* __restrict__ bstart = as.bstart[blockIdx.y];
+    const uint32_t* __restrict__ bend = as.bend[blockIdx.y];
     // (b_lo, b_hi: the buckets this launch is responsible for -- all of them, or one half of a split plan)
     // empty buckets = infinity (ZZ == 0); the others are written by their task or by a combine step
     for (uint32_t b = b_lo + blockIdx.x * blockDim.x + threadIdx.x; b < b_hi; b += gridDim.x * blockDim.x)
@@ -650,10 +670,11 @@ __global__ __launch_bounds__(256) void msm_combine_small(const MultiBucket* __re
 // 5b. hot buckets (many tasks): one wavefront per bucket, lanes stride over the partial sums,
 // then an LDS tree folds the 64 lane sums (wavefront segmented reduction)
 template <class C>
-__global__ __launch_bounds__(64) void msm_combine_wave(const MultiBucket* __restrict__ mbs,
-                                                         const uint32_t* __restrict__ counters,
-                                                         const typename C::PtP* __restrict__ partials,
-                                                         typename C::PtP* __restrict__ buckets, uint32_t b_lo, uint32_t b_hi) {
+__global__ __launch_bounds__(64) void msm_combine_wave(AccSets<C> as, uint32_t b_lo, uint32_t b_hi) {
+    const MultiBucket* __restrict__ mbs = as.multi[blockIdx.y];
+    const uint32_t* __restrict__ counters = as.counters[blockIdx.y];
+    const typename C::PtP* __restrict__ partials = as.partials[blockIdx.y];
+    typename C::PtP* __restrict__ buckets = as.buckets[blockIdx.y];
     __shared__ typename C::PtP sh[64];
     const uint32_t nmb = counters[1];
     const uint32_t lane = threadIdx.x;
@@ -676,9 +697,11 @@ __global__ __launch_bounds__(64) void msm_combine_wave(const MultiBucket* __rest
 // 5c. very hot buckets: stage 1 = one wavefront per HOT_SLICE partial sums (lanes stride, LDS tree), stage 2 = one
 // wavefront per bucket over the slice sums
 template <class C>
-__global__ __launch_bounds__(64) void msm_combine_hot1(const HotBucket* __restrict__ hot, const uint32_t* __restrict__ counters,
-                                                         const typename C::PtP* __restrict__ partials,
-                                                         typename C::PtP* __restrict__ slice_sums, uint32_t b_lo, uint32_t b_hi) {
+__global__ __launch_bounds__(64) void msm_combine_hot1(AccSets<C> as, uint32_t b_lo, uint32_t b_hi) {
+    const HotBucket* __restrict__ hot = as.hot[blockIdx.y];
+    const uint32_t* __restrict__ counters = as.counters[blockIdx.y];
+    const typename C::PtP* __restrict__ partials = as.partials[blockIdx.y];
+    typename C::PtP* __restrict__ slice_sums = as.hot_sums[blockIdx.y];
     __shared__ typename C::PtP sh[64];
     const uint32_t nhot = counters[4], lane = threadIdx.x;
     for (uint32_t hb = 0; hb < nhot; hb++) {                          // few entries; every workgroup walks them all
@@ -704,9 +727,11 @@ __global__ __launch_bounds__(64) void msm_combine_hot1(const HotBucket* __restri
     }
 }
 template <class C>
-__global__ __launch_bounds__(64) void msm_combine_hot2(const HotBucket* __restrict__ hot, const uint32_t* __restrict__ counters,
-                                                         const typename C::PtP* __restrict__ slice_sums,
-                                                         typename C::PtP* __restrict__ buckets, uint32_t b_lo, uint32_t b_hi) {
+__global__ __launch_bounds__(64) void msm_combine_hot2(AccSets<C> as, uint32_t b_lo, uint32_t b_hi) {
+    const HotBucket* __restrict__ hot = as.hot[blockIdx.y];
+    const uint32_t* __restrict__ counters = as.counters[blockIdx.y];
+    const typename C::PtP* __restrict__ slice_sums = as.hot_sums[blockIdx.y];
+    typename C::PtP* __restrict__ buckets = as.buckets[blockIdx.y];
     __shared__ typename C::PtP sh[64];
     const uint32_t nhot = counters[4], lane = threadIdx.x;
     for (uint32_t hb = blockIdx.x; hb < nhot; hb += gridDim.x) {
@@ -1070,8 +1095,23 @@ int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipSt
         const uint32_t by_tasks = (uint32_t)((total + (1u << 19) - 1) >> 19);
         if (I.lmax > by_tasks) I.lmax = by_tasks;
     }
-    if (const char* e = getenv("WSNARK_MSM_LMAX")) { int v = atoi(e); if (v >= 4 && v <= 65536) I.lmax = (uint32_t)v; }
-    if (I.lmax < 32) I.lmax = 32;
+    // Very small sums (round 3): fewer bucket runs than the chip has SIMDs x 64 lanes (2^16).  One lane per run then leaves SIMDs
+    // without any wavefront, so the runs are cut until about 2^17 tasks exist and the partial sums are folded by
+    // msm_combine_small.  2^16-constraint proofs: 2.43 -> 1.95 ms together with the batched accumulation of msm_g1_launch_batch.
+    // With 2^16 runs or more every SIMD has work, and sums that run beside each other already fill the issue slots -- cutting
+    // further only adds combine work (measured on a rank's share of a 2^20 key over 8 ranks: 2.07 vs 2.12 ms,
+    // profiles/r03_s14_small_sums.txt).  WSNARK_MSM_SMALL_TASKS=0 switches the rule off (A/B).
+    uint32_t lmin = 32;
+    {
+        static const bool small_tasks = [] { const char* e = getenv("WSNARK_MSM_SMALL_TASKS"); return !(e && atoi(e) == 0); }();
+        if (small_tasks && I.nbuckets < (1u << 16) && total >= ((uint64_t)1 << 16)) {
+            const uint32_t by_tasks = (uint32_t)((total + (1u << 17) - 1) >> 17);
+            if (by_tasks < I.lmax) I.lmax = by_tasks;
+            lmin = 8;
+        }
+    }
+    if (const char* e = getenv("WSNARK_MSM_LMAX")) { int v = atoi(e); if (v >= 4 && v <= 65536) { I.lmax = (uint32_t)v; lmin = 4; } }
+    if (I.lmax < lmin) I.lmax = lmin;
     I.hot_cap = (uint32_t)(total / I.lmax) + I.nbuckets + 16;
     const uint32_t c = I.c, W = I.W, nbuckets = I.nbuckets, lmax = I.lmax;
 
@@ -1251,15 +1291,14 @@ int msm_plan_variant(Lane& L, int src_id, int dst_id, const uint8_t* d_mask, hip
 }
 
 // ---- phase 2: bucket accumulation and reduction for one point set, against the current plan ----
-// C = device curve (arithmetic of the kernels), H = host curve (reference-format results, host tail).
-// `prepared`: d_points are already in C's internal domain (msm_prepare_points).
 // accumulation + combine of one task segment of a launch (seg 2 = everything) against the launch's plan
 template <class C>
-static int msm_acc_segment(Lane& L, MsmPending& P, int which, uint32_t seg, hipStream_t s) {
+static int msm_acc_sets(Lane& L, MsmPending* const* Ps, int nsets, int which, uint32_t seg, hipStream_t s) {
     typedef typename C::PtP Pt;
     Context* X = ctx();
     MsmWorkspace& M = ws(L);
-    const MsmPlanInfo& I = P.info;
+    MsmPending& P = *Ps[0];
+    const MsmPlanInfo& I = P.info;             // (the sets share the plan's geometry: one plan or its variants)
     MsmScratch& PS = M.plan[P.plan_id].S;
     MsmScratch& S = P.S;
     KernelTimer& T = X->timer;
@@ -1268,7 +1307,7 @@ static int msm_acc_segment(Lane& L, MsmPending& P, int which, uint32_t seg, hipS
     const uint32_t b_lo = seg == 0 ? b_split : 0u, b_hi = seg == 1 ? b_split : I.nbuckets;
     // A/B only: the wavefront-segmented-scan shape over the same sorted stream (see msm_accumulate_segscan)
     const bool segscan = [] { const char* e = getenv("WSNARK_ACC_SHAPE"); return e && !strcmp(e, "segscan"); }();
-    if (segscan && seg == 2 && I.ps_valid) {
+    if (segscan && seg == 2 && I.ps_valid && nsets == 1) {
         const uint64_t total_max = (uint64_t)I.n * I.W;            // worst case: no zero digit
         WS_HIP_CHECK(S.partials.reserve((size_t)(2 * (total_max / 64 + 2)) * sizeof(Pt)));
         const uint32_t* total_ptr = PS.counters.as<uint32_t>() + CNT_BINS + (I.ps_nbins + 1) + I.ps_nbins;      // bin_start[nbins]
@@ -1284,30 +1323,49 @@ static int msm_acc_segment(Lane& L, MsmPending& P, int which, uint32_t seg, hipS
         WS_HIP_CHECK(hipGetLastError());
         return WS_OK;
     }
+    AccSets<C> as;
+    uint32_t ntasks = 0;
+    for (int k = 0; k < 4; k++) {
+        MsmPending& Q = *Ps[k < nsets ? k : 0];
+        MsmScratch& QS = M.plan[Q.plan_id].S;
+        as.points[k] = reinterpret_cast<const typename C::AffP*>(Q.d_points_used);
+        as.vals[k] = QS.vals_out.as<uint32_t>();
+        as.tasks[k] = QS.tasks.as<Task>();
+        as.counters[k] = QS.counters.as<uint32_t>();
+        as.multi[k] = QS.multi.as<MultiBucket>();
+        as.hot[k] = QS.hot.as<HotBucket>();
+        as.bstart[k] = QS.bstart.as<uint32_t>();
+        as.bend[k] = QS.bend.as<uint32_t>();
+        as.buckets[k] = Q.S.buckets.template as<Pt>();
+        as.partials[k] = Q.S.partials.template as<Pt>();
+        as.hot_sums[k] = Q.S.hot_sums.template as<Pt>();
+        if (k < nsets && Q.info.ntasks > ntasks) ntasks = Q.info.ntasks;
+    }
+    const uint32_t ny = (uint32_t)nsets;
     T.begin(which ? "msm_accumulate_g2" : "msm_accumulate_g1", s);
-    hipLaunchKernelGGL(msm_accumulate<C>, dim3(ceil_div_u64(I.ntasks, 256)), dim3(256), 0, s,
-                       reinterpret_cast<const typename C::AffP*>(P.d_points_used),
-                       PS.vals_out.as<uint32_t>(), PS.tasks.as<Task>(), PS.counters.as<uint32_t>(), S.buckets.as<Pt>(),
-                       S.partials.as<Pt>(), seg);
+    hipLaunchKernelGGL(msm_accumulate<C>, dim3(ceil_div_u64(ntasks, 256), ny), dim3(256), 0, s, as, seg);
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
     T.begin("msm_combine", s);
-    hipLaunchKernelGGL(msm_combine_small<C>, dim3(256), dim3(256), 0, s, PS.multi.as<MultiBucket>(),
-                       PS.counters.as<uint32_t>(), S.partials.as<Pt>(), S.buckets.as<Pt>(), PS.bstart.as<uint32_t>(),
-                       PS.bend.as<uint32_t>(), b_lo, b_hi);
-    hipLaunchKernelGGL(msm_combine_wave<C>, dim3(2048), dim3(64), 0, s, PS.multi.as<MultiBucket>(),
-                       PS.counters.as<uint32_t>(), S.partials.as<Pt>(), S.buckets.as<Pt>(), b_lo, b_hi);
-    hipLaunchKernelGGL(msm_combine_hot1<C>, dim3(1024), dim3(64), 0, s, PS.hot.as<HotBucket>(), PS.counters.as<uint32_t>(),
-                       S.partials.as<Pt>(), S.hot_sums.as<Pt>(), b_lo, b_hi);
-    hipLaunchKernelGGL(msm_combine_hot2<C>, dim3(64), dim3(64), 0, s, PS.hot.as<HotBucket>(), PS.counters.as<uint32_t>(),
-                       S.hot_sums.as<Pt>(), S.buckets.as<Pt>(), b_lo, b_hi);
+    hipLaunchKernelGGL(msm_combine_small<C>, dim3(256, ny), dim3(256), 0, s, as, b_lo, b_hi);
+    hipLaunchKernelGGL(msm_combine_wave<C>, dim3(2048, ny), dim3(64), 0, s, as, b_lo, b_hi);
+    hipLaunchKernelGGL(msm_combine_hot1<C>, dim3(1024, ny), dim3(64), 0, s, as, b_lo, b_hi);
+    hipLaunchKernelGGL(msm_combine_hot2<C>, dim3(64, ny), dim3(64), 0, s, as, b_lo, b_hi);
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
     return WS_OK;
 }
+template <class C>
+static int msm_acc_segment(Lane& L, MsmPending& P, int which, uint32_t seg, hipStream_t s) {
+    MsmPending* one[1] = {&P};
+    return msm_acc_sets<C>(L, one, 1, which, seg, s);
+}
 
+// C = device curve (arithmetic of the kernels), H = host curve (reference-format results, host tail).
+// `prepared`: d_points are already in C's internal domain (msm_prepare_points).
 template <class C, class H>
-static int msm_launch_acc(Lane& L, int which, const typename H::Aff* d_points_ref, bool prepared, int* slot_out, hipStream_t s, bool split_first = false) {
+static int msm_launch_acc(Lane& L, int which, const typename H::Aff* d_points_ref, bool prepared, int* slot_out, hipStream_t s, bool split_first = false,
+                          bool defer_kernels = false) {
     typedef typename C::PtP Pt;      // packed accumulator in global memory (same bytes as H::Pt)
     static_assert(sizeof(typename C::PtP) == sizeof(typename H::Pt) && sizeof(typename C::AffP) == sizeof(typename H::Aff), "layouts");
     Context* X = ctx();
@@ -1328,10 +1386,8 @@ static int msm_launch_acc(Lane& L, int which, const typename H::Aff* d_points_re
     const typename C::AffP* d_points = reinterpret_cast<const typename C::AffP*>(d_points_ref);
     const uint64_t n = I.n;
     const uint32_t W = I.tW, nbuckets = I.nbuckets, J = I.J, nsum = I.nsum;
-    const uint32_t ntasks = I.ntasks;
 
-    MsmScratch& PS = M.plan[M.cur].S;           // plan buffers (read-only here)
-    MsmScratch& S = P.S;                        // this launch's accumulation buffers
+    MsmScratch& S = P.S;                        // this launch's accumulation buffers (the plan's own are read by msm_acc_segment)
     // Everything runs in order on the caller's stream.  Tried and measured slower on MI355X (round 1, sessions
     // 7, 8, 11): accumulations on concurrent streams (cache thrash), and the reduction tail on a second,
     // high-priority stream (the kernels starve each other: prove 2^20 16.4-16.7 ms vs 14.6 ms in order).
@@ -1363,8 +1419,10 @@ static int msm_launch_acc(Lane& L, int which, const typename H::Aff* d_points_re
     }
     P.d_points_used = d_points;
     P.split = false;
-    int rc = msm_acc_segment<C>(L, P, which, split_first ? 0u : 2u, s);
-    if (rc) return rc;
+    if (!defer_kernels) {      // (deferred: the caller accumulates several prepared launches in ONE batched launch, msm_acc_sets)
+        int rc = msm_acc_segment<C>(L, P, which, split_first ? 0u : 2u, s);
+        if (rc) return rc;
+    }
     // the slot is taken only now: an error above (null points, a failed reserve) leaves it free
     P.active = true;
     *slot_out = slot;
@@ -1468,11 +1526,24 @@ int msm_g1_launch_batch(Lane& L, const Affine<Fq>* const* d_points, int nsets, b
     const int keep = M.cur;
     for (int k = 0; k < nsets; k++) slots[k] = -1;
     int rc = WS_OK;
+    // Very small sums (fewer bucket runs than the chip has lanes in one wavefront per SIMD, see msm_plan_dev): the sets are
+    // accumulated by ONE launch (blockIdx.y = set) and run beside each other; from 2^16 runs on one launch per set, back to
+    // back, measures better (same box, profiles/r03_s14_small_sums.txt: a rank's share of a 2^20 key over 8 ranks 2.08 vs 2.33 ms,
+    // 2^18 proofs 4.15 vs 4.45 ms, 2^19 6.2 vs 6.43 ms; 2^14 / 2^16 proofs the other way: 1.55 vs 2.1 ms, 1.93 vs 2.4 ms with the
+    // shorter tasks).  WSNARK_MSM_BATCH_ACC: 0 never, 1 always, unset = by size.
+    const MsmPlanInfo& I0 = M.plan[plan_ids ? plan_ids[0] : M.cur].info;
+    static const int batch_env = [] { const char* e = getenv("WSNARK_MSM_BATCH_ACC"); return e ? atoi(e) : -1; }();
+    const bool batched = nsets > 1 && I0.valid && I0.n && (batch_env >= 0 ? batch_env != 0 : I0.nbuckets < (1u << 16));
     for (int k = 0; k < nsets && !rc; k++) {
         if (plan_ids) msm_select_plan(L, plan_ids[k]);
-        rc = msm_uses_field29() ? msm_launch_acc<G1R29, G1>(L, 0, d_points[k], prepared, &slots[k], s)
-                                : msm_launch_acc<G1, G1>(L, 0, d_points[k], prepared, &slots[k], s);
+        rc = msm_uses_field29() ? msm_launch_acc<G1R29, G1>(L, 0, d_points[k], prepared, &slots[k], s, false, batched)
+                                : msm_launch_acc<G1, G1>(L, 0, d_points[k], prepared, &slots[k], s, false, batched);
         if (plan_ids) msm_select_plan(L, keep);
+    }
+    if (!rc && batched) {
+        MsmPending* Ps[4];
+        for (int k = 0; k < nsets; k++) Ps[k] = &M.slot[slots[k]];
+        rc = msm_uses_field29() ? msm_acc_sets<G1R29>(L, Ps, nsets, 0, 2u, s) : msm_acc_sets<G1>(L, Ps, nsets, 0, 2u, s);
     }
     if (!rc && before_tail && hipEventRecord(before_tail, s) != hipSuccess) rc = WS_ERR_HIP;
     if (!rc) rc = msm_uses_field29() ? msm_launch_tail<TailCurve<G1R29>::type>(L, slots, nsets, s) : msm_launch_tail<G1>(L, slots, nsets, s);
