@@ -175,7 +175,7 @@ def pmc_traffic(kernel, pairs_per_launch, windows):
     """HBM-side bytes per launch of `kernel`, measured out of band by tools/gpu_session.sh (rocprofv3 cannot wrap
     itself): two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) over this same command, summary committed."""
     # (two committed summaries: proofs on the table key -- 13 passes per launch at 2^20 -- and the plain 16-window launches)
-    for name in ("r03_s1_pmc_traffic_table.json", "r02_pmc_traffic_table.json", "r02_pmc_traffic.json"):
+    for name in ("r03_final_pmc_traffic_table.json", "r03_s1_pmc_traffic_table.json", "r02_pmc_traffic_table.json", "r02_pmc_traffic.json"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
             k = pm["kernels"][kernel]
