@@ -145,10 +145,13 @@ def test_msm_all_same_point(bn, orc):
 
 @pytest.mark.parametrize("env", [{"WSNARK_MSM_ENTRY64": "1"}, {"WSNARK_MSM_LO_BITS": "5"}, {"WSNARK_MSM_LO_BITS": "10"},
                                  {"WSNARK_MSM_TILE": "256", "WSNARK_MSM_TILE_THREADS": "256"}, {"WSNARK_MSM_HOT_MIN": "2"},
-                                 {"WSNARK_MSM_SORT": "cub"}])
+                                 {"WSNARK_MSM_SORT": "cub"}, {"WSNARK_MSM_SPLIT": "1"}, {"WSNARK_ACC_SHAPE": "segscan"},
+                                 {"WSNARK_MSM_SMALL_TASKS": "0"}, {"WSNARK_MSM_LMAX": "6"}])
 def test_msm_grouping_variants_agree(bn, monkeypatch, env):
     """Entry width, bin geometry, tile shape, hot-bucket threshold and the hipCUB pipeline only change how the
-    pairs are grouped: the sum must not move by a bit (G1 and G2, 60 000 pairs with 30 % ones)."""
+    pairs are grouped: the sum must not move by a bit (G1 and G2, 60 000 pairs with 30 % ones).  Round 3's recorded A/B
+    shapes are in the list too: the split plan (two task segments, the high windows' tail on the second queue), the
+    wavefront-segmented-scan accumulation, and the task-cutting rule for very small sums."""
     import numpy as np
     n = 60000
     rng = np.random.default_rng(42)
@@ -330,7 +333,11 @@ def test_msm_full_size_adversarial_closed_forms(bn, orc, g):
 @pytest.mark.parametrize("logd,style", [(10, "columns"), (16, "columns"), (16, "rows"), (20, "columns")])
 def test_prove_vs_toxic_waste_closed_form(bn, logd, style):
     """(20, columns) is BASELINE config 4 at full size: the circuit SURVEY.md section 8d C4 specifies (1-3 non-zeros per
-    column, every variable present).  'rows' leaves ~40 % of the A / B key points at infinity: the plan-variant path."""
+    column, every variable present).  'rows' leaves ~40 % of the A / B key points at infinity: the plan-variant path.
+    The expectation is the toxic-waste closed form a*G1, b*G2, c*G1; those three group elements come from the product's own
+    fixed-base helper (`mul_base_kernel`: one lane per scalar, double-and-add on the saturated 4x64 field -- not the prover's
+    code path), which is itself pinned by the C1 key hash (test_c1_example_witness_vs_reference_proof) and by smoke()'s
+    comparison with the oracle; the scalars a, b, c are plain Python integers (wasmsnark_amd/synth.py)."""
     from wasmsnark_amd import synth
     circ = synth.make_circuit(logd, n_public=5, seed=logd, style=style)
     S = synth.setup(circ, seed=3)
