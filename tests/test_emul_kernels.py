@@ -133,8 +133,7 @@ def test_msm_hot_bucket_path(bn, orc, monkeypatch, g, n):
     assert out == orc.g_affine(g, orc.multiexp(g, "multiexp2" if g == 1 else "multiexp", sc, pts, n))
 
 
-@pytest.mark.parametrize("g,n,c", [(1, 3000, 9), (1, 1500, 10), (2, 700, 9)])
-@pytest.mark.parametrize("hot", [False, True])
+@pytest.mark.parametrize("g,n,c,hot", [(1, 2000, 9, False), (1, 1500, 10, True), (2, 700, 9, False), (2, 500, 9, True)])
 def test_msm_split_plan(bn, orc, monkeypatch, g, n, c, hot):
     """A whole stand-alone MSM runs on a SPLIT plan: the tasks of the high windows form a first segment, the low windows a
     second one; the reduction tail of the first runs on the lane's second queue beside the accumulation of the second, and the

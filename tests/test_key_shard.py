@@ -17,8 +17,8 @@ def _t(name):
     return rd(".pkey.bin"), rd(".witness.bin")
 
 
-@pytest.mark.parametrize("name,world", [("t6", 2), ("t6", 3), ("t6", 8), ("t6", 70), ("t3", 4)])
-@pytest.mark.parametrize("table", ["table", "plain"])
+@pytest.mark.parametrize("name,world,table", [("t6", 2, "table"), ("t6", 8, "table"), ("t6", 70, "table"), ("t3", 4, "table"),
+                                              ("t6", 3, "plain"), ("t6", 8, "plain")])
 def test_point_shards_combine_to_the_reference_proof(monkeypatch, name, world, table):
     if table == "plain":
         monkeypatch.setenv("WSNARK_KEY_TABLE", "0")
