@@ -25,6 +25,7 @@
 
 #include "../../include/wsnark.h"
 #include "internal.h"
+#include "field29.h"
 
 namespace wsnark {
 
@@ -43,25 +44,32 @@ __global__ __launch_bounds__(256) void lc_spmv_rows_kernel(const uint32_t* __res
     res[idx] = acc;
 }
 
-// send[q][v][r][c2] = x[v][r][q r2 + c2] * w_n^(+-(row0 + r)(q r2 + c2)): twiddle + block order of the exchange in one pass
-__global__ __launch_bounds__(256) void dist_pack_kernel(const Fe* __restrict__ x, Fe* __restrict__ send, uint64_t k, uint64_t r1, uint64_t r2,
-                                                          uint64_t world, uint64_t row0, const Fe* __restrict__ lo, const Fe* __restrict__ hi, uint32_t h) {
-    const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= world * k * r1 * r2) return;
-    const uint64_t c2 = o % r2, t1 = o / r2, r = t1 % r1, t2 = t1 / r1, v = t2 % k, q = t2 / k;
-    const uint64_t c = q * r2 + c2, n2 = world * r2;
+// send[q][v][r][c2] = x[v][r][q r2 + c2] * w_n^(+-(row0 + r)(q r2 + c2)): twiddle + block order of the exchange in one pass.
+// r1, r2 and the world size are powers of two (lr1, lr2, lw): the index arithmetic is shifts and masks, blockIdx.y = the
+// vector v of the stack (64-bit divisions by run-time values cost more than the two field products here).
+// The twiddle is formed and applied on the radix-2^29 field: lo29 / hi29 are the two-level tables in its internal form
+// (entry x 2^5), product of the two = the factor in internal form, times the unpacked element = the result in the reference
+// Montgomery form (R = 2^256) after one canonicalisation -- 2 x 217 instructions instead of 2 x 584 on the saturated field.
+__global__ __launch_bounds__(256) void dist_pack_kernel(const Fe* __restrict__ x, Fe* __restrict__ send, uint32_t k, uint32_t lr1, uint32_t lr2,
+                                                          uint32_t lw, uint64_t row0, const Fe* __restrict__ lo29, const Fe* __restrict__ hi29, uint32_t h) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >> (lr1 + lr2 + lw)) return;
+    const uint32_t v = blockIdx.y;
+    const uint64_t c2 = t & (((uint64_t)1 << lr2) - 1), r = (t >> lr2) & (((uint64_t)1 << lr1) - 1), q = t >> (lr1 + lr2);
+    const uint64_t c = (q << lr2) + c2;
     const uint64_t e = (row0 + r) * c;
-    const Fe f = Fr::mul(hi[e >> h], lo[e & (((uint64_t)1 << h) - 1)]);
-    send[o] = Fr::mul(x[(v * r1 + r) * n2 + c], f);
+    const F29 f = Fr29::mul(Fr29::unpack(hi29[e >> h]), Fr29::unpack(lo29[e & (((uint64_t)1 << h) - 1)]));
+    const F29 y = Fr29::mul(Fr29::unpack(x[((((uint64_t)v << lr1) + r) << (lr2 + lw)) + c]), f);
+    send[((((q * k + v) << lr1) + r) << lr2) + c2] = Fr29::pack(Fr29::canonical(y));
 }
 // y[v][c2][q r1 + r] = recv[q][v][r][c2]: the (n2 / P) x n1 blocks of the row step
-__global__ __launch_bounds__(256) void dist_unpack_kernel(const Fe* __restrict__ recv, Fe* __restrict__ y, uint64_t k, uint64_t r1, uint64_t r2, uint64_t world) {
-    const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t n1 = world * r1;
-    if (o >= k * r2 * n1) return;
-    const uint64_t i1 = o % n1, t1 = o / n1, c2 = t1 % r2, v = t1 / r2;
-    const uint64_t q = i1 / r1, r = i1 - q * r1;
-    y[o] = recv[((q * k + v) * r1 + r) * r2 + c2];
+__global__ __launch_bounds__(256) void dist_unpack_kernel(const Fe* __restrict__ recv, Fe* __restrict__ y, uint32_t k, uint32_t lr1, uint32_t lr2, uint32_t lw) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // index inside y[v]: c2 x n1
+    if (t >> (lr1 + lr2 + lw)) return;
+    const uint32_t v = blockIdx.y;
+    const uint64_t i1 = t & (((uint64_t)1 << (lr1 + lw)) - 1), c2 = t >> (lr1 + lw);
+    const uint64_t q = i1 >> lr1, r = i1 & (((uint64_t)1 << lr1) - 1);
+    y[((uint64_t)v << (lr1 + lr2 + lw)) + t] = recv[((((q * k + v) << lr1) + r) << lr2) + c2];
 }
 
 // fft_fft / fft_ifft (src/build_fft.js:159-221) of `k` stacked vectors spread over the ranks: x = the rank's k blocks of
@@ -77,10 +85,14 @@ static int dist_ntt_native(Lane& L, const DistComm& cm, Fe* x, Fe* y, uint32_t l
     if (log_n2 >= 1 && (rc = ntt_dev(L, x, n2, 0, inverse, s, k * r1))) return rc;                    // column step
     const Fe *lo, *hi;
     int h;
-    if ((rc = ntt_twiddle_tables((int)log_n, inverse, &lo, &hi, &h, s))) return rc;
+    if ((rc = ntt_twiddle_tables((int)log_n, inverse, &lo, &hi, &h, s, /* internal form of the radix-2^29 field */ true))) return rc;
     Context* C = ctx();
+    uint32_t lw = 0;
+    while (((uint64_t)1 << lw) < P) lw++;
+    const uint32_t lr1 = log_n1 - lw, lr2 = log_n2 - lw;
+    const uint64_t per_vec = r1 * n2;
     C->timer.begin("dist_pack", s);
-    hipLaunchKernelGGL(dist_pack_kernel, dim3(ceil_div_u64(total, 256)), dim3(256), 0, s, x, cm.d_send, k, r1, r2, P, row0, lo, hi, (uint32_t)h);
+    hipLaunchKernelGGL(dist_pack_kernel, dim3(ceil_div_u64(per_vec, 256), (uint32_t)k), dim3(256), 0, s, x, cm.d_send, (uint32_t)k, lr1, lr2, lw, row0, lo, hi, (uint32_t)h);
     C->timer.end(s);
     WS_HIP_CHECK(hipGetLastError());
     const Fe* recv = cm.d_send;                                                                        // a world of one: the exchange is the identity
@@ -89,7 +101,7 @@ static int dist_ntt_native(Lane& L, const DistComm& cm, Fe* x, Fe* y, uint32_t l
         recv = cm.d_recv;
     }
     C->timer.begin("dist_unpack", s);
-    hipLaunchKernelGGL(dist_unpack_kernel, dim3(ceil_div_u64(total, 256)), dim3(256), 0, s, recv, y, k, r1, r2, P);
+    hipLaunchKernelGGL(dist_unpack_kernel, dim3(ceil_div_u64(per_vec, 256), (uint32_t)k), dim3(256), 0, s, recv, y, (uint32_t)k, lr1, lr2, lw);
     C->timer.end(s);
     WS_HIP_CHECK(hipGetLastError());
     if (log_n1 >= 1 && (rc = ntt_dev(L, y, n1, 0, inverse, s, k * r2))) return rc;                    // row step

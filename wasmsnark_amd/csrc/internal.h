@@ -134,7 +134,8 @@ int ntt_dev(Lane& L, Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s
 // pass stores CALC_H's h[t] = fromMontgomery((e[t] - w_2n^-t v[t]) / 2) instead of the transform v (calch.hip)
 int ntt_run(Lane& L, const Fe* d_src, const Fe* d_in2, Fe* d_dst, const Fe* combine_e, uint64_t n, int odd, int inverse,
             hipStream_t s, uint64_t count = 1);
-int ntt_twiddle_tables(int bits, int inverse, const Fe** lo, const Fe** hi, int* h, hipStream_t s);
+// internal = true: the same tables in the internal form of the radix-2^29 field (entries x 2^5), as the transform kernels read them
+int ntt_twiddle_tables(int bits, int inverse, const Fe** lo, const Fe** hi, int* h, hipStream_t s, bool internal = false);
 
 int ntt_coset_tables(int bits, const Fe** lo, const Fe** hi, int* hc, Fe* n_inv, hipStream_t s);
 

@@ -436,13 +436,18 @@ int ntt_coset_tables(int bits, const Fe** lo, const Fe** hi, int* hc, Fe* n_inv,
 }
 
 // w_n^(+-e), e < n = 2^bits, two-level in the reference Montgomery form: value = hi[e >> h] * lo[e & mask]
-int ntt_twiddle_tables(int bits, int inverse, const Fe** lo, const Fe** hi, int* h, hipStream_t s) {
+int ntt_twiddle_tables(int bits, int inverse, const Fe** lo, const Fe** hi, int* h, hipStream_t s, bool internal) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
     if (bits < 1 || bits > 28) return WS_ERR_SIZE;
     std::shared_ptr<NttPlan> P;
     int rc = get_plan(C, bits, P, s);
     if (rc) return rc;
+    if (internal) {
+        if (!P->field29) { set_last_error("ntt: the internal twiddle tables exist on the radix-2^29 field only"); return WS_ERR_ARG; }
+        *lo = P->tw_lo[inverse ? 1 : 0].as<Fe>(); *hi = P->tw_hi[inverse ? 1 : 0].as<Fe>(); *h = P->h;
+        return WS_OK;
+    }
     *lo = P->tw_lo_ref[inverse ? 1 : 0].as<Fe>(); *hi = P->tw_hi_ref[inverse ? 1 : 0].as<Fe>(); *h = P->h;
     return WS_OK;
 }
