@@ -666,11 +666,9 @@ int pkey_eval_ab_dev(ProvingKey* K, const Fe* d_witness, size_t witness_len, Fe*
     LaneLock L = acquire_lane(C);
     return eval_ab_dev(*L, d_witness, K->n_vars, K->polsA, K->polsB, K->domain, d_a, d_b, s);
 }
-int groth16_prove_finish(ProvingKey* K, const uint8_t* partials, uint64_t n_ranks, const uint8_t* r32,
-                         const uint8_t* s32, uint8_t* out384) {
-    Blinding B;
-    int rc = start_blinding(K, r32, s32, &B);
-    if (rc) return rc;
+// the gather loop over the ranks' records + the proof assembly, with a blinding whose key-only scalar multiplications may
+// already be under way
+static void finish_records(ProvingKey* K, const uint8_t* partials, uint64_t n_ranks, Blinding& B, uint8_t* out384) {
     MsmSums M;
     M.A = M.B1 = M.C = M.H = G1::infinity();
     M.B2 = G2::infinity();
@@ -687,11 +685,16 @@ int groth16_prove_finish(ProvingKey* K, const uint8_t* partials, uint64_t n_rank
     Blinding::Pre pp;
     EarlyParts E;
     prove_assemble(K, M, B, pp, E, out384);
+}
+int groth16_prove_finish(ProvingKey* K, const uint8_t* partials, uint64_t n_ranks, const uint8_t* r32,
+                         const uint8_t* s32, uint8_t* out384) {
+    Blinding B;
+    int rc = start_blinding(K, r32, s32, &B);
+    if (rc) return rc;
+    finish_records(K, partials, n_ranks, B, out384);
     return WS_OK;
 }
 
-int groth16_prove_finish(ProvingKey* K, const uint8_t* partials, uint64_t n_ranks, const uint8_t* r32,
-                         const uint8_t* s32, uint8_t* out384);
 static int whole_key_only(ProvingKey* K) {
     if (K->shard_world > 1) { set_last_error("this handle holds a points shard of the key: use prove_partial + prove_finish"); return WS_ERR_ARG; }
     return WS_OK;
@@ -731,8 +734,29 @@ int groth16_prove_dist(ProvingKey* K, const Fe* d_witness, size_t witness_len, c
         return WS_ERR_ARG;
     }
     if (!cm.d_send || (cm.world > 1 && (!cm.d_recv || !cm.all_to_all || !cm.all_gather))) return WS_ERR_ARG;
-    uint8_t rec[640];
-    memset(rec, 0, sizeof rec);
+    // The blinding values first: the scalar multiplications that involve key points only (r delta1, s delta1, rs delta1, s delta2:
+    // ~0.5 ms on a host thread) then run under the GPU work, as in the one-call prover, instead of after the gather.  Injected
+    // values are known at once; drawn ones come from rank 0 through one more (64-byte) all-gather before the sums are enqueued.
+    uint8_t rs[64];
+    if (r32 && s32) {
+        memcpy(rs, r32, 32); memcpy(rs + 32, s32, 32);
+    } else {
+        uint8_t mine[64];
+        memset(mine, 0, sizeof mine);
+        if (cm.rank == 0 && os_random(mine, 64)) { set_last_error("cannot read /dev/urandom"); return WS_ERR_ARG; }
+        if (cm.world > 1) {
+            std::vector<uint8_t> all_rs((size_t)cm.world * 64);
+            if (cm.all_gather(cm.user, mine, all_rs.data(), 64) != 0) { set_last_error("prove_dist: the all-gather callback failed"); return WS_ERR_ARG; }
+            memcpy(rs, all_rs.data(), 64);                           // rank 0's draw
+        } else {
+            memcpy(rs, mine, 64);
+        }
+        if (r32) memcpy(rs, r32, 32);
+        if (s32) memcpy(rs + 32, s32, 32);
+    }
+    Blinding B;
+    if ((rc = start_blinding(K, rs, rs + 32, &B))) return rc;
+    uint8_t rec[576];
     {
         LaneLock L = acquire_lane(C);
         MsmSums M;
@@ -747,17 +771,14 @@ int groth16_prove_dist(ProvingKey* K, const Fe* d_witness, size_t witness_len, c
         j = G1::to_affine_jac(M.H); memcpy(rec + 288, &j, 96);
         const Jac<Fq2> j2 = G2::to_affine_jac(M.B2); memcpy(rec + 384, &j2, 192);
     }
-    const bool draw = !r32 || !s32;
-    if (draw && cm.rank == 0 && os_random(rec + 576, 64)) { set_last_error("cannot read /dev/urandom"); return WS_ERR_ARG; }
-    std::vector<uint8_t> all((size_t)cm.world * 640);
-    if (cm.world > 1) {
-        if (cm.all_gather(cm.user, rec, all.data(), 640) != 0) { set_last_error("prove_dist: the all-gather callback failed"); return WS_ERR_ARG; }
-    } else {
-        memcpy(all.data(), rec, 640);
-    }
     std::vector<uint8_t> parts((size_t)cm.world * 576);
-    for (uint32_t i = 0; i < cm.world; i++) memcpy(&parts[(size_t)i * 576], &all[(size_t)i * 640], 576);
-    return groth16_prove_finish(K, parts.data(), cm.world, r32 ? r32 : &all[576], s32 ? s32 : &all[608], out384);
+    if (cm.world > 1) {
+        if (cm.all_gather(cm.user, rec, parts.data(), 576) != 0) { set_last_error("prove_dist: the all-gather callback failed"); return WS_ERR_ARG; }
+    } else {
+        memcpy(parts.data(), rec, 576);
+    }
+    finish_records(K, parts.data(), cm.world, B, out384);
+    return WS_OK;
 }
 
 int groth16_prove_host_witness(ProvingKey* K, const uint8_t* witness, size_t witness_len, const uint8_t* r32,
