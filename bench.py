@@ -265,10 +265,14 @@ def bench_prove(ctx):
         return holder["key"]
 
     def mode_native():
+        if "native" in os.environ.get("WSNARK_BENCH_FAIL", "").split(","):       # (tests: exercise the fall-through)
+            raise RuntimeError("forced by WSNARK_BENCH_FAIL")
         holder["npv"] = wdist.NativeDistProver(bn, sec, device=dev)
         return lambda: holder["npv"].prove(d_w.data_ptr(), len(wit), r=r32, s=s32)
 
     def mode_dist():
+        if "dist" in os.environ.get("WSNARK_BENCH_FAIL", "").split(","):
+            raise RuntimeError("forced by WSNARK_BENCH_FAIL")
         holder["dp"] = wdist.DistProver(bn, whole_key(), bytes(sec["pointsH"]), device=dev)
         return lambda: holder["dp"].prove(d_w.data_ptr(), len(wit), r=r32, s=s32)
 

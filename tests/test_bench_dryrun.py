@@ -54,3 +54,20 @@ def test_bench_two_ranks_line():
     # the default N > 1 orchestration is the native one (points-sharded key, one C call per proof) and it did not fall through
     assert "wsnark_groth16_prove_dist" in d["config"]["parallelism"] and "fell through" not in d["config"]["parallelism"]
     assert d["shard"]["pairs_this_rank"] > 0 and d["shard"]["resident_table_bytes_this_rank"] > 0
+
+
+def test_bench_two_ranks_falls_through_when_an_orchestration_fails():
+    """None of the N > 1 orchestrations has run on RCCL in the build container: bench.py checks each one against the closed form on
+    every rank and falls through native -> Python (DistProver) -> replicated CALC_H.  Forced here: the native mode fails on every
+    rank, then the Python one too; the line must say which ran and why the others did not."""
+    from emul_util import emul_bn128
+    emul_bn128()
+    for fail, ran in (("native", "CALC_H on the distributed four-step NTT"), ("native,dist", "CALC_H replicated")):
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                              "--master-port", "29659", os.path.join(ROOT, "tools", "bench_dryrun.py"), "--gpus", "2", "--prove-log-domain", "6",
+                              "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                             capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1", WSNARK_BENCH_FAIL=fail))
+        d = _line(out)
+        par = d["config"]["parallelism"]
+        assert d["proofs_match_toxic_waste_closed_form"] is True and "fell through: native: RuntimeError" in par and ran in par, par
+        assert "wsnark_groth16_prove_dist" not in par and d["shard"] is None
