@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "wasmsnark_amd", "csrc")
-SRCS = ["ntt.hip", "msm.hip", "calch.hip", "fixedbase.hip", "selftest.hip"]
+SRCS = ["ntt.hip", "msm.hip", "calch.hip", "dist.hip", "fixedbase.hip", "selftest.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage"]
 KEYS = ["VGPRs", "AGPRs", "TotalSGPRs", "ScratchSize [bytes/lane]", "VGPRs Spill", "SGPRs Spill", "LDS Size [bytes/block]", "Occupancy [waves/SIMD]"]
 
