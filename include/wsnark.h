@@ -246,7 +246,8 @@ int wsnark_groth16_prove_finish(wsnark_pkey_t* handle, const void* partials, uin
  *   all_gather(user, send, recv, bytes)        host memory: recv = the `bytes`-byte records of all ranks in rank order
  * handle: the rank's points shard with h_interleave_log = floor(log2(domain) / 2) (wsnark_pkey_load_shard); world must be a
  * power of two <= 2^floor(log2(domain) / 2).  world == 1: callbacks may be NULL (the exchange is the identity).  r32 / s32
- * NULL: rank 0 draws the blinding values and they ride in its all-gather slot -- every rank returns the same proof.
+ * NULL: rank 0 draws the blinding values and one more all_gather (64-byte records, before the GPU work, so that the host's
+ * key-only scalar multiplications run under it) hands them to every rank -- every rank returns the same proof.
  * stream: the queue d_witness is ready on (NULL: the library's own). */
 typedef struct {
     uint32_t rank, world;
