@@ -192,12 +192,59 @@ int upload_staged(void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
         WS_HIP_CHECK(hipHostMalloc(&C->pin_ring, PIN_CHUNK * PIN_WORKERS * PIN_PER_WORKER, 0));
         for (auto& e : C->pin_ev) WS_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    // chunk length: the ring's slots are 8 MiB, but a 32 MiB witness cut into 8 MiB pieces gives every worker ONE piece --
+    const int device = C->device;
+    std::atomic<int> err(0);
+    static StagePool* pool = new StagePool();       // never destroyed: its threads are parked on it until the process ends
+    // Mode 1 (default; WSNARK_STAGE_MODE=0 = the per-piece scheme below, for A/B): MANY threads copy, FEW DMAs are issued.
+    // Every hipMemcpyAsync costs tens of microseconds of runtime time on the stream's lock, so one DMA per copied piece made
+    // the staging API-bound (32 MiB: 0.87 ms on the host whatever the worker count, profiles/r03_s8_stage_sweep.txt).  Here the
+    // ring is two halves of 64 MiB; an upload goes through them in super-chunks, each cut into a few GROUPS: all workers copy
+    // their slices of group g, the last one to arrive issues ONE DMA for the whole group and everybody moves on to group g + 1
+    // while it runs.
+    static const int stage_mode = [] { const char* e = getenv("WSNARK_STAGE_MODE"); return e ? atoi(e) : 1; }();
+    if (stage_mode == 1) {
+        const size_t HALF = PIN_CHUNK * PIN_WORKERS * PIN_PER_WORKER / 2;
+        static const int env_groups = [] { const char* e = getenv("WSNARK_STAGE_GROUPS"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 8 ? 8 : v); }();
+        static const int env_w = [] { const char* e = getenv("WSNARK_STAGE_WORKERS"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > PIN_WORKERS ? PIN_WORKERS : v); }();
+        int half = 0;
+        for (size_t done = 0; done < bytes; half ^= 1) {
+            const size_t sz = bytes - done < HALF ? bytes - done : HALF;
+            const int G = env_groups ? env_groups : (sz >= ((size_t)48 << 20) ? 4 : sz >= ((size_t)12 << 20) ? 2 : 1);
+            const int n_workers = env_w ? env_w : (sz >= ((size_t)8 << 20) ? PIN_WORKERS : 2);
+            const size_t gs = ((sz + G - 1) / G + 0xFFFF) & ~(size_t)0xFFFF;          // group size, 64 KiB granules
+            char* pin = (char*)C->pin_ring + (size_t)half * HALF;
+            const char* src = (const char*)h_src + done;
+            char* dst = (char*)d_dst + done;
+            WS_HIP_CHECK(hipEventSynchronize(C->pin_ev[half]));                       // the half's previous DMAs have drained
+            std::atomic<int> arrived[8];
+            for (auto& a : arrived) a.store(0);
+            auto worker = [&](int w) {
+                if (hipSetDevice(device) != hipSuccess) { err = 1; return; }
+                for (int g = 0; g < G; g++) {
+                    const size_t g_lo = (size_t)g * gs, g_hi = g_lo + gs < sz ? g_lo + gs : sz;
+                    if (g_lo < g_hi) {
+                        const size_t per = (((g_hi - g_lo) + n_workers - 1) / n_workers + 4095) & ~(size_t)4095;
+                        const size_t lo = g_lo + (size_t)w * per, hi = lo + per < g_hi ? lo + per : g_hi;
+                        if (lo < hi) memcpy(pin + lo, src + lo, hi - lo);
+                    }
+                    if (arrived[g].fetch_add(1) == n_workers - 1 && g_lo < g_hi) {     // last one in: the group is staged
+                        if (hipMemcpyAsync(dst + g_lo, pin + g_lo, g_hi - g_lo, hipMemcpyHostToDevice, s) != hipSuccess) err = 1;
+                    }
+                }
+            };
+            pool->run(n_workers, worker);
+            if (err) { set_last_error("staged upload failed"); return WS_ERR_HIP; }
+            WS_HIP_CHECK(hipEventRecord(C->pin_ev[half], s));
+            done += sz;
+        }
+        return WS_OK;
+    }
+    // Mode 0: one DMA per copied piece.  The ring's slots are 8 MiB, but a 32 MiB witness cut into 8 MiB pieces gives every worker ONE piece --
     // no DMA starts before a whole 8 MiB memcpy is done and nothing overlaps.  Shorter pieces (a 32nd of the buffer,
     // 512 KiB .. 8 MiB) keep four pieces per worker in flight behind each other.
     // Swept on the MI355X box with a 32 MiB witness (profiles/r03_s8_stage_sweep.txt): the proof from a host witness costs
-    // 1.0-1.4 ms more than from a resident one whatever the split -- that is the PCIe transfer itself (32 MiB at ~35 GB/s) --
-    // best with two workers and one or two pieces each; a 0.6 GB key section wants all eight (memcpy-bound: 10 ms).
+    // 1.0-1.4 ms more than from a resident one whatever the split -- best with two workers and one or two pieces each; a 0.6 GB
+    // key section wants all eight (memcpy-bound: 10 ms).
     static const int env_workers = [] { const char* e = getenv("WSNARK_STAGE_WORKERS"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > PIN_WORKERS ? PIN_WORKERS : v); }();
     static const int env_pieces = [] { const char* e = getenv("WSNARK_STAGE_PIECES"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
     int n_workers = env_workers;
@@ -205,8 +252,7 @@ int upload_staged(void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
     size_t chunk = (bytes / ((size_t)env_pieces * n_workers) + 0xFFFF) & ~(size_t)0xFFFF;
     chunk = chunk < ((size_t)512 << 10) ? ((size_t)512 << 10) : (chunk > PIN_CHUNK ? PIN_CHUNK : chunk);
     const size_t nchunks = (bytes + chunk - 1) / chunk;
-    const int device = C->device;
-    std::atomic<int> err(0);
+    for (int b = 0; b < 2; b++) WS_HIP_CHECK(hipEventSynchronize(C->pin_ev[b]));     // (mode 1's half events share slots 0, 1)
     auto worker = [&](int w) {
         if (hipSetDevice(device) != hipSuccess) { err = 1; return; }
         int use = 0;
@@ -221,9 +267,7 @@ int upload_staged(void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
                 hipEventRecord(C->pin_ev[b], s) != hipSuccess) { err = 1; return; }
         }
     };
-    // The copy workers are PERSISTENT threads (created once, parked on a condition variable): spawning seven threads per
-    // upload cost ~0.4 ms of the 0.87 ms a 32 MiB witness took to stage (measured, profiles/r03_s6_hostwitness.txt).
-    static StagePool* pool = new StagePool();       // never destroyed: its threads are parked on it until the process ends
+    // (the copy workers are PERSISTENT threads, created once and parked on a condition variable)
     pool->run(n_workers, worker);
     if (err) { set_last_error("staged upload failed"); return WS_ERR_HIP; }
     return WS_OK;
