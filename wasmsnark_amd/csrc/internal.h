@@ -163,12 +163,13 @@ int msm_points_mask(const Affine<Fq>* d_g1, const Affine<Fq2>* d_g2, uint64_t n,
 // asynchronous form: launch enqueues the kernels and the copy of the window sums, finish waits
 // for that copy and runs the serial host tail.  `prepared` = the point array was converted in place by
 // msm_prepare_points (resident keys).
-int msm_g1_launch(Lane& L, const Affine<Fq>* d_points, bool prepared, int* slot, hipStream_t s);
-int msm_g2_launch(Lane& L, const Affine<Fq2>* d_points, bool prepared, int* slot, hipStream_t s, hipEvent_t before_tail = nullptr);
+// tail_stream (optional, all three launchers): the reduction tail is enqueued on that queue of the lane instead of on s
+int msm_g1_launch(Lane& L, const Affine<Fq>* d_points, bool prepared, int* slot, hipStream_t s, hipStream_t tail_stream = nullptr);
+int msm_g2_launch(Lane& L, const Affine<Fq2>* d_points, bool prepared, int* slot, hipStream_t s, hipEvent_t before_tail = nullptr, hipStream_t tail_stream = nullptr);
 // `before_tail` (optional) is recorded on s after the accumulations, before the batched reduction tail
 // plan_ids (optional): the plan each set is accumulated against (variants of one plan: same geometry)
 int msm_g1_launch_batch(Lane& L, const Affine<Fq>* const* d_points, int nsets, bool prepared, int* slots, hipStream_t s,
-                        hipEvent_t before_tail = nullptr, const int* plan_ids = nullptr);
+                        hipEvent_t before_tail = nullptr, const int* plan_ids = nullptr, hipStream_t tail_stream = nullptr);
 // several independent plans (digit/sort/task buffers) can be alive at once; plan and launches use the selected one
 void msm_select_plan(Lane& L, int id);      // id in [0, 4)
 // A second plan over the SAME scalars that leaves out the pairs with mask[i] == 0, derived from plan `src_id`

@@ -1481,9 +1481,22 @@ static int msm_launch_tail(Lane& L, const int* slot_ids, int nslots, hipStream_t
     return WS_OK;
 }
 
+// The reduction tail of launches accumulated on `s`, enqueued on `ts` (another queue of the lane) behind an event: the next
+// full-width kernel on `s` then starts at once instead of behind a chain of ~33 dependent additions on a few hundred wavefronts.
+template <class TC>
+static int msm_tail_on(Lane& L, const int* slot_ids, int nslots, hipStream_t s, hipStream_t ts) {
+    if (!ts || ts == s) return msm_launch_tail<TC>(L, slot_ids, nslots, s);
+    MsmPending& P0 = ws(L).slot[slot_ids[0]];
+    if (P0.info.n == 0) return WS_OK;
+    if (!P0.ev_acc) WS_HIP_CHECK(hipEventCreateWithFlags(&P0.ev_acc, hipEventDisableTiming));
+    WS_HIP_CHECK(hipEventRecord(P0.ev_acc, s));
+    WS_HIP_CHECK(hipStreamWaitEvent(ts, P0.ev_acc, 0));
+    return msm_launch_tail<TC>(L, slot_ids, nslots, ts);
+}
+
 template <class C, class H>
 static int msm_launch(Lane& L, int which, const typename H::Aff* d_points_ref, bool prepared, int* slot_out, hipStream_t s,
-                      hipEvent_t before_tail = nullptr) {
+                      hipEvent_t before_tail = nullptr, hipStream_t tail_stream = nullptr) {
     if (!s) s = L.stream;
     typedef typename TailCurve<C>::type TC;
     MsmWorkspace& M = ws(L);
@@ -1499,8 +1512,8 @@ static int msm_launch(Lane& L, int which, const typename H::Aff* d_points_ref, b
     MsmPending& P = M.slot[*slot_out];
     if (!split || P.info.n == 0) {
         if (before_tail) WS_HIP_CHECK(hipEventRecord(before_tail, s));
-        rc = msm_launch_tail<TC>(L, slot_out, 1, s);
-        if (rc) msm_abort_slots(L, slot_out, 1, s, nullptr);
+        rc = msm_tail_on<TC>(L, slot_out, 1, s, tail_stream);
+        if (rc) msm_abort_slots(L, slot_out, 1, s, tail_stream);
         return rc;
     }
     hipStream_t s2 = L.stream2;
@@ -1518,7 +1531,7 @@ static int msm_launch(Lane& L, int which, const typename H::Aff* d_points_ref, b
 
 // several G1 point sets against the current plan: accumulations back to back, then ONE batched tail
 int msm_g1_launch_batch(Lane& L, const Affine<Fq>* const* d_points, int nsets, bool prepared, int* slots, hipStream_t s,
-                        hipEvent_t before_tail, const int* plan_ids) {
+                        hipEvent_t before_tail, const int* plan_ids, hipStream_t tail_stream) {
     if (!ctx()) return WS_ERR_NOINIT;
     if (nsets < 1 || nsets > 4) return WS_ERR_ARG;
     if (!s) s = L.stream;
@@ -1546,20 +1559,20 @@ int msm_g1_launch_batch(Lane& L, const Affine<Fq>* const* d_points, int nsets, b
         rc = msm_uses_field29() ? msm_acc_sets<G1R29>(L, Ps, nsets, 0, 2u, s) : msm_acc_sets<G1>(L, Ps, nsets, 0, 2u, s);
     }
     if (!rc && before_tail && hipEventRecord(before_tail, s) != hipSuccess) rc = WS_ERR_HIP;
-    if (!rc) rc = msm_uses_field29() ? msm_launch_tail<TailCurve<G1R29>::type>(L, slots, nsets, s) : msm_launch_tail<G1>(L, slots, nsets, s);
-    if (rc) msm_abort_slots(L, slots, nsets, s, nullptr);
+    if (!rc) rc = msm_uses_field29() ? msm_tail_on<TailCurve<G1R29>::type>(L, slots, nsets, s, tail_stream) : msm_tail_on<G1>(L, slots, nsets, s, tail_stream);
+    if (rc) msm_abort_slots(L, slots, nsets, s, tail_stream);
     return rc;
 }
 
-int msm_g1_launch(Lane& L, const Affine<Fq>* d_points, bool prepared, int* slot, hipStream_t s) {
+int msm_g1_launch(Lane& L, const Affine<Fq>* d_points, bool prepared, int* slot, hipStream_t s, hipStream_t tail_stream) {
     if (!ctx()) return WS_ERR_NOINIT;
-    if (msm_uses_field29()) return msm_launch<G1R29, G1>(L, 0, d_points, prepared, slot, s);
-    return msm_launch<G1, G1>(L, 0, d_points, prepared, slot, s);
+    if (msm_uses_field29()) return msm_launch<G1R29, G1>(L, 0, d_points, prepared, slot, s, nullptr, tail_stream);
+    return msm_launch<G1, G1>(L, 0, d_points, prepared, slot, s, nullptr, tail_stream);
 }
-int msm_g2_launch(Lane& L, const Affine<Fq2>* d_points, bool prepared, int* slot, hipStream_t s, hipEvent_t before_tail) {
+int msm_g2_launch(Lane& L, const Affine<Fq2>* d_points, bool prepared, int* slot, hipStream_t s, hipEvent_t before_tail, hipStream_t tail_stream) {
     if (!ctx()) return WS_ERR_NOINIT;
-    if (msm_uses_field29()) return msm_launch<G2R29, G2>(L, 1, d_points, prepared, slot, s, before_tail);
-    return msm_launch<G2, G2>(L, 1, d_points, prepared, slot, s, before_tail);
+    if (msm_uses_field29()) return msm_launch<G2R29, G2>(L, 1, d_points, prepared, slot, s, before_tail, tail_stream);
+    return msm_launch<G2, G2>(L, 1, d_points, prepared, slot, s, before_tail, tail_stream);
 }
 static MsmPending* live_slot(Lane& L, int slot, int which) {
     if (!L.msm || slot < 0 || slot >= kPendingSlots) return nullptr;

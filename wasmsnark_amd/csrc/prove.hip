@@ -398,9 +398,13 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
     const bool small = (uint64_t)nv * msm_table_rows(K->table_cw ? K->table_cw : 16) < ((uint64_t)1 << 23);
     const int order = order_env >= 0 ? order_env : (small && L.stream3 && s != L.stream3 ? 3 : 1);
     const bool g2_first = order != 0;
+    // Order 4 (round 3, full-size sums): order 1 with the reduction tails of B2 and of A + B1 on the THIRD queue, so that the
+    // next accumulation on the first queue starts at once instead of behind the tail (kernel timeline of a 2^20 proof: the
+    // batched A + B1 tail held queue 1 for 1.6 ms while only the H plan ran beside it).
+    hipStream_t tail_q = (order == 4 && L.stream3 && s != L.stream3) ? L.stream3 : nullptr;
     auto launch_b2 = [&]() -> int {
         msm_select_plan(L, planB);
-        int r = msm_g2_launch(L, K->pointsB2.as<Affine<Fq2>>(), true, &hB2, s);                           // :619
+        int r = msm_g2_launch(L, K->pointsB2.as<Affine<Fq2>>(), true, &hB2, s, nullptr, tail_q);           // :619
         msm_select_plan(L, 0);
         return r;
     };
@@ -434,11 +438,17 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
             hA = g1slots[0]; hB1 = g1slots[1]; hC = g1slots[2];
             if (rc) return rc;
         } else {
-            rc = msm_g1_launch_batch(L, g1sets, 2, true, g1slots, s, L.ev_tail, plans);                   // :617, :618
+            rc = msm_g1_launch_batch(L, g1sets, 2, true, g1slots, s, L.ev_tail, plans, tail_q);           // :617, :618
             hA = g1slots[0]; hB1 = g1slots[1];
             if (rc) return rc;
             msm_select_plan(L, 0);
             if ((rc = msm_g1_launch(L, K->pointsC.as<Affine<Fq>>(), true, &hC, s))) return rc;            // :620 (padded)
+            if (tail_q) {                                                                                  // s stays the caller's ordering point
+                for (hipEvent_t* e : {&L.ev_g2})
+                    if (!*e) WS_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+                WS_HIP_CHECK(hipEventRecord(L.ev_g2, tail_q));
+                WS_HIP_CHECK(hipStreamWaitEvent(s, L.ev_g2, 0));
+            }
         }
         tr.mark("launch A, B1, C");
     } else {
