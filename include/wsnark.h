@@ -327,6 +327,11 @@ int wsnark_selftest_field(int which, int impl, int op, const void* a, const void
 int wsnark_selftest_curve(int g, int impl, int op, const void* p, const void* q, void* out, uint64_t n);
 
 /* ---- measurement hooks (bench.py) ---- */
+/* A/B switches of the library (queue arrangement of a proof, reduction-tail geometry, ...; the names are the WSNARK_<name>
+ * environment variables DESIGN.md lists, without the prefix): an override set here wins over the environment and is read by
+ * every later call, so that one process can time several settings on one resident key.  value == INT64_MIN forgets the
+ * override.  Results never depend on these switches -- only the schedule does. */
+int wsnark_tuning_set(const char* name, int64_t value);
 /* per-kernel HIP-event timing on the stream the kernels are launched on: 0 = off, 1 = every kernel,
  * 2 = only the dominant kernel (msm_accumulate_*), for timed regions where the brackets themselves must
  * stay out of the way */

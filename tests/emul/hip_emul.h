@@ -86,7 +86,7 @@ template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; ret
 
 // ---- host runtime ----
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600 };
 typedef struct emul_stream* hipStream_t;
 typedef struct emul_event* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };

@@ -96,6 +96,22 @@ for name in ("t3", "t6"):
     both = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(both, mine)
     assert all(torch.equal(both[0], b) for b in both), "ranks disagree on the native proof"
+    # Error agreement (the collectives pair up by call order): whatever goes wrong on ONE rank, EVERY rank returns an error and
+    # nobody is left waiting in a collective.  (a) rank 0 injects r, s and rank 1 lets them be drawn; (b) the ranks inject different
+    # values; (c) rank 1 is handed a witness that is too short; then a good proof again on the same prover.
+    from wasmsnark_amd._lib import WsnarkError
+    c0 = json.load(open(os.path.join(gold, "proofs.json")))[name][0]
+    r_ok, s_ok = bytes.fromhex(c0["r"]), bytes.fromhex(c0["s"])
+    for kw in (dict(r=r_ok if rank == 0 else None, s=s_ok if rank == 0 else None),
+               dict(r=r_ok, s=s_ok if rank == 0 else bytes(x ^ 0x5A for x in s_ok)),
+               dict(r=r_ok, s=s_ok, short=(rank == 1))):
+        short = kw.pop("short", False)
+        try:
+            npv.prove(w.data_ptr(), len(wit) - (32 if short else 0), **kw)
+            raise AssertionError("rank %d: a proof came out of a call the ranks disagreed on" % rank)
+        except WsnarkError as ex:
+            assert ex.code in (1, 4), ex
+    assert npv.prove(w.data_ptr(), len(wit), r=r_ok, s=s_ok) == c0["proof"], ("NativeDistProver after errors", name, rank)
 dist.barrier()
 open(os.path.join(os.environ["WS_OUT"], "rank%d.ok" % rank), "w").write("ok")
 '''

@@ -27,7 +27,7 @@ SYMBOLS = [
     "wsnark_synth_new", "wsnark_synth_free", "wsnark_synth_info", "wsnark_synth_witness", "wsnark_synth_pols",
     "wsnark_synth_key_scalars", "wsnark_synth_expected",
     "wsnark_selftest_field", "wsnark_selftest_curve",
-    "wsnark_timing_enable", "wsnark_timing_reset", "wsnark_timing_report", "wsnark_peak_probe",
+    "wsnark_timing_enable", "wsnark_timing_reset", "wsnark_timing_report", "wsnark_peak_probe", "wsnark_tuning_set",
 ]
 
 
@@ -92,6 +92,7 @@ class Lib:
         c.wsnark_pkey_load_shard.argtypes = [vp, u32, u32, u32, C.POINTER(vp)]
         c.wsnark_pkey_shard_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
         c.wsnark_peak_probe.argtypes = [C.c_int, C.POINTER(C.c_double)]
+        c.wsnark_tuning_set.argtypes = [C.c_char_p, C.c_int64]
         c.wsnark_pkey_load_stats.argtypes = [vp, C.POINTER(C.c_double)]
         c.wsnark_pkey_h_msm_dev.argtypes = [vp, vp, u64, vp, vp]
         c.wsnark_groth16_prove_partial.argtypes = [vp, vp, sz, u32, u32, u32, vp]
@@ -129,6 +130,11 @@ class Lib:
     def shutdown(self):
         self.c.wsnark_shutdown()
         self.initialised = False
+
+    def tune(self, name, value=None):
+        """A/B switch `name` (the WSNARK_<name> environment variable without its prefix): override it for every later call;
+        None forgets the override."""
+        self.check(self.c.wsnark_tuning_set(name.encode(), -(1 << 63) if value is None else int(value)))
 
     def timing_report(self):
         n = self.c.wsnark_timing_report(None, 0)

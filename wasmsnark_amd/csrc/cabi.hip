@@ -1,4 +1,5 @@
 // cabi.hip -- the extern "C" surface declared in include/wsnark.h.
+#include <limits.h>
 #include <string.h>
 
 #include "../../include/wsnark.h"
@@ -172,8 +173,8 @@ static int fr_map_host(const void* in, void* out, uint64_t n, int to_mont) {
     if (!in || !out) return WSNARK_ERR_ARG;
     DevBuf d;
     WS_HIP_CHECK(d.alloc(n * 32));
-    WS_HIP_CHECK(hipMemcpyAsync(d.p, in, n * 32, hipMemcpyHostToDevice, C->stream));
-    int rc = fr_map_dev(d.as<Fe>(), d.as<Fe>(), n, to_mont, C->stream);
+    int rc = upload_staged(d.p, in, n * 32, C->stream);
+    if (!rc) rc = fr_map_dev(d.as<Fe>(), d.as<Fe>(), n, to_mont, C->stream);
     if (rc) return rc;
     WS_HIP_CHECK(hipMemcpyAsync(out, d.p, n * 32, hipMemcpyDeviceToHost, C->stream));
     WS_HIP_CHECK(hipStreamSynchronize(C->stream));
@@ -368,6 +369,13 @@ int wsnark_selftest_curve(int g, int impl, int op, const void* p, const void* q,
 int wsnark_peak_probe(int probe, double* gops_per_s) {
     REQUIRE_CTX();
     return peak_probe(probe, gops_per_s);
+}
+
+// ---- measurement switches ----
+int wsnark_tuning_set(const char* name, int64_t value) {
+    if (!name || !*name) return WSNARK_ERR_ARG;
+    tuning_set(name, value == INT64_MIN ? LONG_MIN : (long)value);
+    return WSNARK_OK;
 }
 
 // ---- timing ----

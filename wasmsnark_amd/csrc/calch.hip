@@ -155,14 +155,11 @@ int eval_ab_dev(Lane& L, const Fe* d_signals_plain, uint32_t n_signals, const Cs
     if (!C) return WS_ERR_NOINIT;
     if (!s) s = L.stream;
     if (A.n_rows != domain || B.n_rows != domain || A.n_cols != n_signals || B.n_cols != n_signals || !d_a || !d_b) return WS_ERR_ARG;
-    ScratchGuard scratch_turn(L.calch_chain, s);
-    WS_HIP_CHECK(L.calch_buf[0].reserve((size_t)n_signals * sizeof(Fe)));
-    Fe* sigM = L.calch_buf[0].as<Fe>();
-    int rc = fr_map_dev(d_signals_plain, sigM, n_signals, 1, s);
-    if (rc) return rc;
+    (void)L;
     const dim3 blk(256), grd(ceil_div_u64(domain, 256));
-    hipLaunchKernelGGL(lc_spmv_kernel, grd, blk, 0, s, A.row_ptr.as<uint32_t>(), A.col.as<uint32_t>(), A.coef.as<Fe>(), sigM, domain, d_a);
-    hipLaunchKernelGGL(lc_spmv_kernel, grd, blk, 0, s, B.row_ptr.as<uint32_t>(), B.col.as<uint32_t>(), B.coef.as<Fe>(), sigM, domain, d_b);
+    // (the resident coefficients are pre-scaled by R: plain signals in, Montgomery sums out -- see pols_to_csr)
+    hipLaunchKernelGGL(lc_spmv_kernel, grd, blk, 0, s, A.row_ptr.as<uint32_t>(), A.col.as<uint32_t>(), A.coef.as<Fe>(), d_signals_plain, domain, d_a);
+    hipLaunchKernelGGL(lc_spmv_kernel, grd, blk, 0, s, B.row_ptr.as<uint32_t>(), B.col.as<uint32_t>(), B.coef.as<Fe>(), d_signals_plain, domain, d_b);
     WS_HIP_CHECK(hipGetLastError());
     return WS_OK;
 }
@@ -253,6 +250,13 @@ int pols_to_csr(const uint8_t* pols, size_t len, uint32_t n_signals, uint32_t do
     if ((rc = upload_staged(out->row_ptr.p, row_ptr.data(), row_ptr.size() * 4, s))) return rc;
     if ((rc = upload_staged(out->col.p, col.get(), nz * 4, s))) return rc;
     if ((rc = upload_staged(out->coef.p, coef.get(), nz * sizeof(Fe), s))) return rc;
+    // The resident coefficients carry one more factor R (c R^2 instead of the file's Montgomery form c R): the product with a
+    // PLAIN signal s then is c R^2 s / R = (c s) R, the Montgomery form of the term.  The reference converts the nSignals
+    // signals of every proof instead (fft_toMontgomeryN, src/bn128.js:139); scaling the key's coefficients once at load time
+    // removes that pass -- and its buffer -- from every proof, and the sparse product reads the caller's witness as it is
+    // (raw 256-bit values: the product of a reduced operand and any value below 2^256 reduces correctly).
+    if (nnz) hipLaunchKernelGGL(fr_map_kernel, dim3(ceil_div_u64(nnz, 256)), dim3(256), 0, s, out->coef.as<Fe>(), out->coef.as<Fe>(), (uint64_t)nnz, 1);
+    WS_HIP_CHECK(hipGetLastError());
     WS_HIP_CHECK(hipStreamSynchronize(s));
     return WS_OK;
 }
@@ -270,9 +274,7 @@ int calc_h_dev(Lane& L, const Fe* d_signals_plain, uint32_t n_signals, const Csr
     while ((1u << bits) < domain) bits++;
     const size_t nb = (size_t)domain * sizeof(Fe);
     ScratchGuard scratch_turn(L.calch_chain, s);   // the work arrays below are shared by every CALC_H on this lane
-    WS_HIP_CHECK(L.calch_buf[0].reserve((size_t)n_signals * sizeof(Fe)));
     for (int i = 1; i < 4; i++) WS_HIP_CHECK(L.calch_buf[i].reserve(nb));
-    Fe* sigM = L.calch_buf[0].as<Fe>();
     Fe* a = L.calch_buf[1].as<Fe>();
     Fe* b = L.calch_buf[2].as<Fe>();
     Fe* e = L.calch_buf[3].as<Fe>();
@@ -280,13 +282,11 @@ int calc_h_dev(Lane& L, const Fe* d_signals_plain, uint32_t n_signals, const Csr
     const dim3 blk(256), grd(ceil_div_u64(domain, 256));
     int rc;
 
-    T.begin("fr_to_montgomery", s);                                  // bn128.js:139
-    rc = fr_map_dev(d_signals_plain, sigM, n_signals, 1, s);
-    T.end(s);
-    if (rc) return rc;
+    // bn128.js:139 (fft_toMontgomeryN of the signals) has no counterpart per proof: the key's coefficients were scaled once
+    // at load time (pols_to_csr), so the sparse products read the plain witness and still leave Montgomery sums
     T.begin("lc_spmv", s);                                           // bn128.js:141-145
-    hipLaunchKernelGGL(lc_spmv_kernel, grd, blk, 0, s, A.row_ptr.as<uint32_t>(), A.col.as<uint32_t>(), A.coef.as<Fe>(), sigM, domain, a);
-    hipLaunchKernelGGL(lc_spmv_kernel, grd, blk, 0, s, B.row_ptr.as<uint32_t>(), B.col.as<uint32_t>(), B.coef.as<Fe>(), sigM, domain, b);
+    hipLaunchKernelGGL(lc_spmv_kernel, grd, blk, 0, s, A.row_ptr.as<uint32_t>(), A.col.as<uint32_t>(), A.coef.as<Fe>(), d_signals_plain, domain, a);
+    hipLaunchKernelGGL(lc_spmv_kernel, grd, blk, 0, s, B.row_ptr.as<uint32_t>(), B.col.as<uint32_t>(), B.coef.as<Fe>(), d_signals_plain, domain, b);
     T.end(s);
     // The pointwise products and the final combination are fused into the transforms next to them (WSNARK_CALCH_FUSE=0:
     // separate kernels, for A/B runs): E = A.B is formed by the FIRST pass of its inverse transform while it loads,

@@ -1,4 +1,5 @@
 // context.hip -- library context, error string, per-kernel HIP-event timing.
+#include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -8,6 +9,8 @@
 #include <functional>
 #include <vector>
 #include <thread>
+#include <memory>
+#include <unistd.h>
 
 #include <chrono>
 
@@ -24,6 +27,24 @@ static std::mutex g_ctx_mu;
 static std::string g_devinfo;
 
 Context* ctx() { return g_ctx; }
+
+static std::mutex g_tune_mu;
+static std::map<std::string, long> g_tune;
+long tuning_get(const char* name, long dflt) {
+    {
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        auto it = g_tune.find(name);
+        if (it != g_tune.end()) return it->second;
+    }
+    const std::string env = std::string("WSNARK_") + name;
+    const char* e = getenv(env.c_str());
+    return e ? atol(e) : dflt;
+}
+void tuning_set(const char* name, long value) {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    if (value == LONG_MIN) g_tune.erase(name);
+    else g_tune[name] = value;
+}
 
 int context_init(int device) {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
@@ -62,6 +83,7 @@ int context_init(int device) {
         if (prio && hipStreamCreateWithPriority(&L.stream2, hipStreamNonBlocking, hi) != hipSuccess) L.stream2 = nullptr;
         if (!L.stream2) WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream2, hipStreamNonBlocking));   // (no priorities here)
         WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream3, hipStreamNonBlocking));
+        WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream_copy, hipStreamNonBlocking));
     }
     g_ctx = C;
     return WS_OK;
@@ -76,6 +98,7 @@ void context_shutdown() {
         (void)hipStreamSynchronize(g_ctx->lanes[i].stream);
         (void)hipStreamSynchronize(g_ctx->lanes[i].stream2);
         (void)hipStreamSynchronize(g_ctx->lanes[i].stream3);
+        (void)hipStreamSynchronize(g_ctx->lanes[i].stream_copy);
     }
     g_ctx->timer.reset();
     for (hipEvent_t e : g_ctx->timer.pool) (void)hipEventDestroy(e);
@@ -86,7 +109,7 @@ void context_shutdown() {
     for (int i = 0; i < g_ctx->n_lanes; i++) {
         Lane& L = g_ctx->lanes[i];
         msm_workspace_free(L);
-        for (hipEvent_t* e : {&L.ntt_chain.done, &L.calch_chain.done, &L.ev_start, &L.ev_tail, &L.ev_h, &L.ev_plan, &L.ev_g2})
+        for (hipEvent_t* e : {&L.ntt_chain.done, &L.calch_chain.done, &L.ev_start, &L.ev_tail, &L.ev_h, &L.ev_plan, &L.ev_g2, &L.ev_chunk[0], &L.ev_chunk[1]})
             if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
         L.ntt_scratch.release();
         for (auto& b : L.calch_buf) b.release();
@@ -96,6 +119,7 @@ void context_shutdown() {
         (void)hipStreamDestroy(L.stream);
         (void)hipStreamDestroy(L.stream2);
         (void)hipStreamDestroy(L.stream3);
+        (void)hipStreamDestroy(L.stream_copy);
     }
     (void)hipStreamDestroy(g_ctx->stream);
     delete g_ctx;
@@ -126,15 +150,24 @@ LaneLock::~LaneLock() {
 }
 
 // ---- staged uploads ----
-// n persistent worker threads; run(n, fn) executes fn(0) on the caller and fn(1..n-1) on the pool, and returns when all are done.
-// One job at a time (upload_staged holds its ring mutex around run()).  The threads live as long as the process.
+// Host -> device copies of caller memory that may be pageable and never touched by the runtime before (the witness and key
+// bytes of the reference's callers, src/bn128.js:580).  The runtime's own pageable path pins fresh pages at ~10 GB/s; here
+// worker threads memcpy CHUNKS into a pinned ring and the calling thread -- the orchestrator -- issues one DMA per chunk as soon
+// as the chunk is staged, so that copying chunk g + 1 overlaps the DMA of chunk g.  Round 4: (a) the orchestrator no longer
+// copies (a 32 MiB witness used to be staged in 0.87 ms before its last DMA could start: 38 GB/s of memcpy against ~50 GB/s
+// of PCIe -- the staging, not the link, set the pace), (b) chunks are 4 MiB instead of 16, (c) every chunk is announced to the
+// caller (`on_chunk`, on the orchestrator thread, after its DMA has been queued on `s`), which lets the prover start the first
+// pass over the witness -- the digit histogram of the grouping pass -- while the rest is still on its way, and (d) a source that
+// is ALREADY pinned (hipHostMalloc / hipHostRegister: the N-API addon's external ArrayBuffers) is DMA'd in place.
+// The pool threads never call into the HIP runtime.
 struct StagePool {
     std::mutex mu;
     std::condition_variable cv_go, cv_done;
     std::vector<std::thread> th;
     const std::function<void(int)>* job = nullptr;
     unsigned long generation = 0;
-    int pending = 0, active = 0;                  // workers 1 .. active-1 take part in the current job; the others stay parked
+    int pending = 0, active = 0;                  // workers 0 .. active-1 take part in the current job; the others stay parked
+    pid_t owner = 0;                              // the process the threads live in: a fork()ed child has the vector but not the threads
     void loop(int w) {
         unsigned long seen = 0;
         for (;;) {
@@ -153,125 +186,153 @@ struct StagePool {
             }
         }
     }
-    void run(int n, const std::function<void(int)>& fn) {
-        if ((int)th.size() < n - 1) {
-            for (int w = (int)th.size() + 1; w < n; w++) { th.emplace_back([this, w] { loop(w); }); th.back().detach(); }
-        }
+    // starts fn(0 .. n-1) on the pool and returns at once; wait() returns when all are done
+    void start(int n, const std::function<void(int)>& fn) {
+        for (int w = (int)th.size(); w < n; w++) { th.emplace_back([this, w] { loop(w); }); th.back().detach(); }
         {
             std::lock_guard<std::mutex> lk(mu);
             job = &fn;
             active = n;
-            pending = n - 1;
+            pending = n;
             generation++;
         }
         cv_go.notify_all();
-        fn(0);
+    }
+    void wait() {
         std::unique_lock<std::mutex> lk(mu);
         cv_done.wait(lk, [&] { return pending == 0; });
     }
 };
+// One pool per process: after fork() (Python multiprocessing with the "fork" start method, Node child workers) the child
+// inherits the object -- thread handles, possibly a locked mutex -- but none of the threads, so it gets a pool of its own.
+// Never destroyed: the threads are parked on it until the process ends (the library must not be dlclose'd).
+static StagePool* stage_pool() {
+    static std::mutex mu;
+    static StagePool* pool = nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!pool || pool->owner != getpid()) { pool = new StagePool(); pool->owner = getpid(); }
+    return pool;
+}
 
-static const size_t PIN_CHUNK = (size_t)8 << 20;
-static const int PIN_WORKERS = 8, PIN_PER_WORKER = 2;
-int upload_staged(void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
+static const int PIN_MAX_WORKERS = 24, PIN_MAX_SLOTS = 128;
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+}
+
+int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s, const ChunkFn& on_chunk) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
     if (!s) s = C->stream;
     if (bytes == 0) return WS_OK;
+    // chunk size: WSNARK_STAGE_CHUNK_KB (default 4 MiB; 64 KiB granules, 64 KiB .. 16 MiB)
+    size_t chunk = ((size_t)tuning_get("STAGE_CHUNK_KB", 4096) << 10) & ~(size_t)0xFFFF;
+    chunk = chunk < ((size_t)64 << 10) ? ((size_t)64 << 10) : chunk > ((size_t)16 << 20) ? ((size_t)16 << 20) : chunk;
+    int rc = WS_OK;
+    // small copies, and sources that are ALREADY pinned (hipHostMalloc / hipHostRegister), need no staging
+    bool direct = bytes < ((size_t)1 << 20);
 #ifdef WSNARK_EMUL
-    WS_HIP_CHECK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, s));
-    return WS_OK;
+    direct = !tuning_get("STAGE_FORCE_RING", 0);    // (the emulator's "device" memory is host memory; tests force the ring to run its bookkeeping)
 #else
-    if (bytes < PIN_CHUNK / 2) {
-        WS_HIP_CHECK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, s));
+    if (!direct && tuning_get("STAGE_DIRECT_PINNED", 1)) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, h_src) == hipSuccess) direct = at.type == hipMemoryTypeHost;
+        else (void)hipGetLastError();               // pageable memory is "invalid value" to the runtime: not an error here
+    }
+#endif
+    if (direct) {
+        const size_t G = (bytes + chunk - 1) / chunk;
+        for (size_t g = 0; g < G; g++) {
+            const size_t lo = g * chunk, hi = lo + chunk < bytes ? lo + chunk : bytes;
+            WS_HIP_CHECK(hipMemcpyAsync((char*)d_dst + lo, (const char*)h_src + lo, hi - lo, hipMemcpyHostToDevice, s));
+            if (on_chunk && (rc = on_chunk(lo, hi))) return rc;
+        }
         return WS_OK;
     }
     static std::mutex ring_mu;                      // one upload at a time uses the ring
     std::lock_guard<std::mutex> lk(ring_mu);
     if (!C->pin_ring) {
-        WS_HIP_CHECK(hipHostMalloc(&C->pin_ring, PIN_CHUNK * PIN_WORKERS * PIN_PER_WORKER, 0));
+        size_t ring = (size_t)tuning_get("STAGE_RING_KB", 128 << 10) << 10;        // (read once, when the ring is created)
+        ring = ring < ((size_t)1 << 20) ? ((size_t)1 << 20) : ring > ((size_t)1 << 30) ? ((size_t)1 << 30) : ring;
+        WS_HIP_CHECK(hipHostMalloc(&C->pin_ring, ring, 0));
+        C->pin_ring_bytes = ring;
         for (auto& e : C->pin_ev) WS_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    const int device = C->device;
-    std::atomic<int> err(0);
-    static StagePool* pool = new StagePool();       // never destroyed: its threads are parked on it until the process ends
-    // Mode 1 (default; WSNARK_STAGE_MODE=0 = the per-piece scheme below, for A/B): MANY threads copy, FEW DMAs are issued.
-    // Every hipMemcpyAsync costs tens of microseconds of runtime time on the stream's lock, so one DMA per copied piece made
-    // the staging API-bound (32 MiB: 0.87 ms on the host whatever the worker count, profiles/r03_s8_stage_sweep.txt).  Here the
-    // ring is two halves of 64 MiB; an upload goes through them in super-chunks, each cut into a few GROUPS: all workers copy
-    // their slices of group g, the last one to arrive issues ONE DMA for the whole group and everybody moves on to group g + 1
-    // while it runs.
-    static const int stage_mode = [] { const char* e = getenv("WSNARK_STAGE_MODE"); return e ? atoi(e) : 1; }();
-    if (stage_mode == 1) {
-        const size_t HALF = PIN_CHUNK * PIN_WORKERS * PIN_PER_WORKER / 2;
-        static const int env_groups = [] { const char* e = getenv("WSNARK_STAGE_GROUPS"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 8 ? 8 : v); }();
-        static const int env_w = [] { const char* e = getenv("WSNARK_STAGE_WORKERS"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > PIN_WORKERS ? PIN_WORKERS : v); }();
-        int half = 0;
-        for (size_t done = 0; done < bytes; half ^= 1) {
-            const size_t sz = bytes - done < HALF ? bytes - done : HALF;
-            const int G = env_groups ? env_groups : (sz >= ((size_t)48 << 20) ? 4 : sz >= ((size_t)12 << 20) ? 2 : 1);
-            const int n_workers = env_w ? env_w : (sz >= ((size_t)8 << 20) ? PIN_WORKERS : 2);
-            const size_t gs = ((sz + G - 1) / G + 0xFFFF) & ~(size_t)0xFFFF;          // group size, 64 KiB granules
-            char* pin = (char*)C->pin_ring + (size_t)half * HALF;
-            const char* src = (const char*)h_src + done;
-            char* dst = (char*)d_dst + done;
-            WS_HIP_CHECK(hipEventSynchronize(C->pin_ev[half]));                       // the half's previous DMAs have drained
-            std::atomic<int> arrived[8];
-            for (auto& a : arrived) a.store(0);
-            auto worker = [&](int w) {
-                if (hipSetDevice(device) != hipSuccess) { err = 1; return; }
-                for (int g = 0; g < G; g++) {
-                    const size_t g_lo = (size_t)g * gs, g_hi = g_lo + gs < sz ? g_lo + gs : sz;
-                    if (g_lo < g_hi) {
-                        const size_t per = (((g_hi - g_lo) + n_workers - 1) / n_workers + 4095) & ~(size_t)4095;
-                        const size_t lo = g_lo + (size_t)w * per, hi = lo + per < g_hi ? lo + per : g_hi;
-                        if (lo < hi) memcpy(pin + lo, src + lo, hi - lo);
-                    }
-                    if (arrived[g].fetch_add(1) == n_workers - 1 && g_lo < g_hi) {     // last one in: the group is staged
-                        if (hipMemcpyAsync(dst + g_lo, pin + g_lo, g_hi - g_lo, hipMemcpyHostToDevice, s) != hipSuccess) err = 1;
-                    }
-                }
-            };
-            pool->run(n_workers, worker);
-            if (err) { set_last_error("staged upload failed"); return WS_ERR_HIP; }
-            WS_HIP_CHECK(hipEventRecord(C->pin_ev[half], s));
-            done += sz;
-        }
-        return WS_OK;
-    }
-    // Mode 0: one DMA per copied piece.  The ring's slots are 8 MiB, but a 32 MiB witness cut into 8 MiB pieces gives every worker ONE piece --
-    // no DMA starts before a whole 8 MiB memcpy is done and nothing overlaps.  Shorter pieces (a 32nd of the buffer,
-    // 512 KiB .. 8 MiB) keep four pieces per worker in flight behind each other.
-    // Swept on the MI355X box with a 32 MiB witness (profiles/r03_s8_stage_sweep.txt): the proof from a host witness costs
-    // 1.0-1.4 ms more than from a resident one whatever the split -- best with two workers and one or two pieces each; a 0.6 GB
-    // key section wants all eight (memcpy-bound: 10 ms).
-    static const int env_workers = [] { const char* e = getenv("WSNARK_STAGE_WORKERS"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > PIN_WORKERS ? PIN_WORKERS : v); }();
-    static const int env_pieces = [] { const char* e = getenv("WSNARK_STAGE_PIECES"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
-    int n_workers = env_workers;
-    if (!n_workers) { n_workers = (int)(bytes >> 24); n_workers = n_workers < 2 ? 2 : (n_workers > PIN_WORKERS ? PIN_WORKERS : n_workers); }   // one per 16 MiB, 2..8
-    size_t chunk = (bytes / ((size_t)env_pieces * n_workers) + 0xFFFF) & ~(size_t)0xFFFF;
-    chunk = chunk < ((size_t)512 << 10) ? ((size_t)512 << 10) : (chunk > PIN_CHUNK ? PIN_CHUNK : chunk);
-    const size_t nchunks = (bytes + chunk - 1) / chunk;
-    for (int b = 0; b < 2; b++) WS_HIP_CHECK(hipEventSynchronize(C->pin_ev[b]));     // (mode 1's half events share slots 0, 1)
-    auto worker = [&](int w) {
-        if (hipSetDevice(device) != hipSuccess) { err = 1; return; }
-        int use = 0;
-        for (size_t c = (size_t)w; c < nchunks; c += (size_t)n_workers, use++) {
-            const int b = w * PIN_PER_WORKER + (use % PIN_PER_WORKER);
-            char* pin = (char*)C->pin_ring + (size_t)b * PIN_CHUNK;
-            // the buffer's previous DMA (this call or an earlier one) must have drained
-            if (hipEventSynchronize(C->pin_ev[b]) != hipSuccess) { err = 1; return; }
-            const size_t off = c * chunk, len = off + chunk <= bytes ? chunk : bytes - off;
-            memcpy(pin, (const char*)h_src + off, len);
-            if (hipMemcpyAsync((char*)d_dst + off, pin, len, hipMemcpyHostToDevice, s) != hipSuccess ||
-                hipEventRecord(C->pin_ev[b], s) != hipSuccess) { err = 1; return; }
+    if (chunk > C->pin_ring_bytes / 2) chunk = (C->pin_ring_bytes / 2) & ~(size_t)0xFFFF;
+    size_t nslots = C->pin_ring_bytes / chunk;
+    if (nslots > (size_t)PIN_MAX_SLOTS) nslots = PIN_MAX_SLOTS;
+    const size_t G = (bytes + chunk - 1) / chunk;
+    // workers: WSNARK_STAGE_WORKERS, default one per 2 MiB of the upload, 2 .. 12
+    const long env_w = tuning_get("STAGE_WORKERS", 0);
+    int W = env_w > 0 ? (int)env_w : (int)(bytes >> 21);
+    W = W < 2 ? 2 : W > PIN_MAX_WORKERS ? PIN_MAX_WORKERS : W;
+    if (env_w <= 0 && W > 12) W = 12;
+    const size_t per = ((chunk + W - 1) / W + 4095) & ~(size_t)4095;      // a worker's slice of a chunk, page granules
+    // Bookkeeping.  Chunk g lives in slot g % nslots.  Workers may write chunk g once released > g; the orchestrator releases
+    // chunk k only when the slot's previous occupant -- chunk k - nslots of THIS upload (whose DMA it has queued itself, so the
+    // slot's event is the fresh one), or an earlier upload's -- has drained.
+    std::atomic<size_t> released(0);
+    std::unique_ptr<std::atomic<int>[]> arrived(new std::atomic<int>[G]);
+    for (size_t g = 0; g < G; g++) arrived[g].store(0, std::memory_order_relaxed);
+    std::atomic<int> stop(0);
+    char* ring = (char*)C->pin_ring;
+    const std::function<void(int)> worker = [&](int w) {
+        for (size_t g = 0; g < G; g++) {
+            unsigned spins = 0;
+            while (released.load(std::memory_order_acquire) <= g) {
+                if (stop.load(std::memory_order_relaxed)) return;
+                if (++spins > 2000) std::this_thread::yield(); else cpu_relax();
+            }
+            if (stop.load(std::memory_order_relaxed)) return;
+            const size_t c_lo = g * chunk, c_hi = c_lo + chunk < bytes ? c_lo + chunk : bytes;
+            const size_t lo = c_lo + (size_t)w * per, hi = lo + per < c_hi ? lo + per : c_hi;
+            if (lo < hi) memcpy(ring + (g % nslots) * chunk + (lo - c_lo), (const char*)h_src + lo, hi - lo);
+            arrived[g].fetch_add(1, std::memory_order_release);
         }
     };
-    // (the copy workers are PERSISTENT threads, created once and parked on a condition variable)
-    pool->run(n_workers, worker);
-    if (err) { set_last_error("staged upload failed"); return WS_ERR_HIP; }
-    return WS_OK;
-#endif
+    StagePool* pool = stage_pool();
+    pool->start(W, worker);
+    size_t next = 0;                                // next chunk to release
+    // release chunks below `limit`; block = wait for the first one's slot instead of giving up when it is still draining
+    auto release_upto = [&](size_t limit, bool block) -> int {
+        while (next < limit) {
+            hipEvent_t ev = C->pin_ev[next % nslots];
+            if (block) {
+                if (hipEventSynchronize(ev) != hipSuccess) { set_last_error("staged upload: a ring slot's DMA failed"); return WS_ERR_HIP; }
+            } else {
+                const hipError_t q = hipEventQuery(ev);
+                if (q == hipErrorNotReady) { (void)hipGetLastError(); return WS_OK; }
+                if (q != hipSuccess) { set_last_error(std::string("staged upload: ") + hipGetErrorString(q)); return WS_ERR_HIP; }
+            }
+            released.store(++next, std::memory_order_release);
+            block = false;
+        }
+        return WS_OK;
+    };
+    for (size_t g = 0; g < G && !rc; g++) {
+        // chunks < g have their DMA queued, so slots of chunks < g + nslots carry fresh events (or none from this upload)
+        const size_t limit = g + nslots < G ? g + nslots : G;
+        unsigned spins = 0;
+        while (!rc && arrived[g].load(std::memory_order_acquire) < W) {
+            if (next <= g) rc = release_upto(limit, true);               // the workers have nothing they may write: wait for the slot
+            else if (next < limit && (spins & 31) == 0) rc = release_upto(limit, false);
+            if (++spins > 4000) std::this_thread::yield(); else cpu_relax();
+        }
+        if (rc) break;
+        const size_t lo = g * chunk, hi = lo + chunk < bytes ? lo + chunk : bytes;
+        const size_t slot = g % nslots;
+        if (hipMemcpyAsync((char*)d_dst + lo, ring + slot * chunk, hi - lo, hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipEventRecord(C->pin_ev[slot], s) != hipSuccess) { set_last_error("staged upload: DMA failed"); rc = WS_ERR_HIP; break; }
+        if (on_chunk) rc = on_chunk(lo, hi);
+    }
+    if (rc) stop.store(1);                          // the workers leave at their next chunk boundary
+    pool->wait();
+    return rc;
+}
+
+int upload_staged(void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
+    return upload_pipelined(d_dst, h_src, bytes, s, nullptr);
 }
 
 // ---- KernelTimer ----

@@ -77,7 +77,10 @@ __global__ __launch_bounds__(256) void dist_unpack_kernel(const Fe* __restrict__
 
 // fft_fft / fft_ifft (src/build_fft.js:159-221) of `k` stacked vectors spread over the ranks: x = the rank's k blocks of
 // r1 x n2 (n1-interleaved layout), overwritten; the result -- k blocks of r2 x n1, n2-interleaved -- is written to y.
-static int dist_ntt_native(Lane& L, const DistComm& cm, Fe* x, Fe* y, uint32_t log_n, uint32_t log_n1, int odd, int inverse, uint64_t k, hipStream_t s) {
+// *exchanges (optional) counts the all-to-all callbacks this rank has posted: a caller that gives up half-way still owes its
+// peers the remaining ones (prove.hip: groth16_prove_dist).
+static int dist_ntt_native(Lane& L, const DistComm& cm, Fe* x, Fe* y, uint32_t log_n, uint32_t log_n1, int odd, int inverse, uint64_t k, hipStream_t s,
+                           int* exchanges) {
     const uint32_t log_n2 = log_n - log_n1;
     const uint64_t n1 = (uint64_t)1 << log_n1, n2 = (uint64_t)1 << log_n2, P = cm.world;
     const uint64_t r1 = n1 / P, r2 = n2 / P, row0 = (uint64_t)cm.rank * r1;
@@ -100,7 +103,10 @@ static int dist_ntt_native(Lane& L, const DistComm& cm, Fe* x, Fe* y, uint32_t l
     WS_HIP_CHECK(hipGetLastError());
     const Fe* recv = cm.d_send;                                                                        // a world of one: the exchange is the identity
     if (P > 1) {
-        if (!cm.all_to_all || cm.all_to_all(cm.user, k * r1 * r2 * sizeof(Fe), (void*)s) != 0) { set_last_error("prove_dist: the all-to-all callback failed"); return WS_ERR_ARG; }
+        if (!cm.all_to_all) { set_last_error("prove_dist: no all-to-all callback"); return WS_ERR_ARG; }
+        const int xrc = cm.all_to_all(cm.user, k * r1 * r2 * sizeof(Fe), (void*)s);
+        if (exchanges) ++*exchanges;                                                                   // posted (or attempted): the peers' matching call has its partner
+        if (xrc != 0) { set_last_error("prove_dist: the all-to-all callback failed"); return WS_ERR_ARG; }
         recv = cm.d_recv;
     }
     C->timer.begin("dist_unpack", s);
@@ -111,32 +117,41 @@ static int dist_ntt_native(Lane& L, const DistComm& cm, Fe* x, Fe* y, uint32_t l
     return WS_OK;
 }
 
-// CALC_H (src/bn128.js:139-164) for the rank's slice: h[(r, j)] = h[(rank rows + r) + 2^l2 j] in plain form
-int calc_h_dist(Lane& L, const DistComm& cm, const Fe* d_signals_plain, uint32_t n_signals, const CsrMatrix& A, const CsrMatrix& B,
-                uint32_t domain, uint32_t l2_expected, Fe* d_h_local, hipStream_t s) {
-    Context* C = ctx();
-    if (!C) return WS_ERR_NOINIT;
+// Everything of calc_h_dist that can fail on ONE rank without a collective being involved: the geometry checks and the
+// grow-only reserves of the lane's buffers.  groth16_prove_dist calls it before its first collective and ships the result.
+int calc_h_dist_reserve(Lane& L, const DistComm& cm, uint32_t n_signals, uint32_t domain, uint32_t l2_expected) {
     if (domain < 2 || (domain & (domain - 1)) || domain > (1u << 27)) return WS_ERR_SIZE;
-    if (A.n_rows != domain || B.n_rows != domain || A.n_cols != n_signals || B.n_cols != n_signals) return WS_ERR_ARG;
     uint32_t log_n = 0;
     while ((1u << log_n) < domain) log_n++;
     const uint32_t l1 = (log_n + 1) / 2, l2 = log_n - l1, P = cm.world;
     if ((P & (P - 1)) || ((uint64_t)1 << l2) < P) { set_last_error("prove_dist: needs a power-of-two world size <= 2^floor(log2(domain)/2)"); return WS_ERR_SIZE; }
     if (l2 != l2_expected) { set_last_error("prove_dist: the handle's hExps interleave does not match this domain (load the shard with h_interleave_log = floor(log2(domain) / 2))"); return WS_ERR_ARG; }
     const uint64_t n_loc = domain / P;
-    ScratchGuard scratch_turn(L.calch_chain, s);
-    WS_HIP_CHECK(L.calch_buf[0].reserve((size_t)n_signals * sizeof(Fe)));
+    if ((uint64_t)3 * n_loc * sizeof(Fe) > cm.buf_bytes) { set_last_error("prove_dist: exchange buffers too small (3 * 32 * domain / world bytes each)"); return WS_ERR_SIZE; }
+    (void)n_signals;
     WS_HIP_CHECK(L.dist_buf[0].reserve((size_t)3 * n_loc * sizeof(Fe)));
     WS_HIP_CHECK(L.dist_buf[1].reserve((size_t)3 * n_loc * sizeof(Fe)));
-    Fe* sigM = L.calch_buf[0].as<Fe>();
+    return WS_OK;
+}
+
+// CALC_H (src/bn128.js:139-164) for the rank's slice: h[(r, j)] = h[(rank rows + r) + 2^l2 j] in plain form
+int calc_h_dist(Lane& L, const DistComm& cm, const Fe* d_signals_plain, uint32_t n_signals, const CsrMatrix& A, const CsrMatrix& B,
+                uint32_t domain, uint32_t l2_expected, Fe* d_h_local, hipStream_t s, int* exchanges) {
+    Context* C = ctx();
+    if (!C) return WS_ERR_NOINIT;
+    if (A.n_rows != domain || B.n_rows != domain || A.n_cols != n_signals || B.n_cols != n_signals) return WS_ERR_ARG;
+    int rc0 = calc_h_dist_reserve(L, cm, n_signals, domain, l2_expected);      // (no-ops after the caller's preflight)
+    if (rc0) return rc0;
+    uint32_t log_n = 0;
+    while ((1u << log_n) < domain) log_n++;
+    const uint32_t l1 = (log_n + 1) / 2, l2 = log_n - l1, P = cm.world;
+    const uint64_t n_loc = domain / P;
+    ScratchGuard scratch_turn(L.calch_chain, s);
     Fe* X = L.dist_buf[0].as<Fe>();
     Fe* T = L.dist_buf[1].as<Fe>();
     KernelTimer& Tm = C->timer;
     int rc;
-    Tm.begin("fr_to_montgomery", s);
-    rc = fr_map_dev(d_signals_plain, sigM, n_signals, 1, s);                                          // bn128.js:139
-    Tm.end(s);
-    if (rc) return rc;
+    const Fe* sigM = d_signals_plain;          // (plain signals against pre-scaled coefficients: calch.hip, pols_to_csr)
     // a, b: only the rows of this rank's slice, in the l1-interleaved layout (rows i1 in the rank's range, all i2)
     const uint64_t r1 = ((uint64_t)1 << l1) / P, c1 = (uint64_t)1 << (log_n - l1);
     uint32_t log_r1 = 0;
@@ -149,10 +164,10 @@ int calc_h_dist(Lane& L, const DistComm& cm, const Fe* d_signals_plain, uint32_t
     Tm.end(s);
     WS_HIP_CHECK(hipGetLastError());
     if ((rc = fr_mul_dev(X, X + n_loc, X + 2 * n_loc, n_loc, s))) return rc;                           // E = A.B on the domain
-    if ((rc = dist_ntt_native(L, cm, X, T, log_n, l1, 0, 1, 3, s))) return rc;                         // coefficients of a, b; e   (l2-interleaved)
-    if ((rc = dist_ntt_native(L, cm, T, X, log_n, l2, 1, 0, 2, s))) return rc;                         // odd-coset evaluations     (l1-interleaved)
+    if ((rc = dist_ntt_native(L, cm, X, T, log_n, l1, 0, 1, 3, s, exchanges))) return rc;                         // coefficients of a, b; e   (l2-interleaved)
+    if ((rc = dist_ntt_native(L, cm, T, X, log_n, l2, 1, 0, 2, s, exchanges))) return rc;                         // odd-coset evaluations     (l1-interleaved)
     if ((rc = fr_mul_dev(X, X + n_loc, X, n_loc, s))) return rc;                                       // O = A.B on the coset
-    if ((rc = dist_ntt_native(L, cm, X, T, log_n, l1, 0, 1, 1, s))) return rc;                         // o                          (l2-interleaved, like e)
+    if ((rc = dist_ntt_native(L, cm, X, T, log_n, l1, 0, 1, 1, s, exchanges))) return rc;                         // o                          (l2-interleaved, like e)
     const uint64_t rows = ((uint64_t)1 << l2) / P;
     return dist_combine_dev(T + 2 * n_loc, T, d_h_local, rows, (uint64_t)1 << (log_n - l2), (uint64_t)cm.rank * rows, l2, log_n, s);
 }

@@ -1,6 +1,7 @@
 // internal.h -- C++ interfaces between the translation units of libwsnark.
 #pragma once
 #include <condition_variable>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -70,6 +71,8 @@ struct Lane {
     hipStream_t stream = nullptr;               // first in-order queue (or the caller's stream for _dev entry points)
     hipStream_t stream2 = nullptr;              // second queue (prover: CALC_H and the H sum beside the tails)
     hipStream_t stream3 = nullptr;              // third queue (small proofs / points shards: the G2 sum beside the G1 sums)
+    hipStream_t stream_copy = nullptr;          // host -> device copies of a call's inputs (the witness, chunk by chunk, beside the first kernels)
+    hipEvent_t ev_chunk[2] = {nullptr, nullptr};   // ... a chunk has landed
     MsmWorkspace* msm = nullptr;                // plans, launch slots (owned; msm_workspace_free)
     DevBuf host_in[2];                          // host-pointer boundary: grow-only device copies of the caller's buffers
     DevBuf ntt_scratch;                         // ping-pong buffer of the multi-pass transforms
@@ -95,7 +98,8 @@ struct Context {
     KernelTimer timer;
     // host-pointer boundary: pinned staging ring for uploads
     void* pin_ring = nullptr;
-    hipEvent_t pin_ev[16] = {};
+    size_t pin_ring_bytes = 0;
+    hipEvent_t pin_ev[128] = {};                // one per ring slot: the slot's last DMA
 };
 
 // RAII: a free lane; with every lane busy the caller waits until ANY of them is released (not for one picked in advance:
@@ -119,8 +123,19 @@ LaneLock acquire_lane(Context* C);
 // path pins fresh pages at ~10 GB/s; this runs at memcpy speed, ~40 GB/s).  Returns once the source has been
 // read completely; the DMAs may still be in flight on `s`.
 int upload_staged(void* d_dst, const void* h_src, size_t bytes, hipStream_t s);
+// The same, announcing every chunk: on_chunk(lo, hi) runs on the calling thread right after the DMA of bytes [lo, hi) has
+// been queued on `s` (chunks arrive in order; a non-zero return aborts the upload and is returned).  Typical use: record an
+// event on `s` and make another queue start its first pass over that part while the rest is still being staged.
+typedef std::function<int(size_t, size_t)> ChunkFn;
+int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s, const ChunkFn& on_chunk);
 
 Context* ctx();   // nullptr before wsnark_init
+
+// Measurement switches (A/B runs): the value set through wsnark_tuning_set for `name`, else the environment variable
+// WSNARK_<name>, else dflt.  Read per call, so that ONE process can time several settings on the same resident key
+// (a gpurun box is charged by the minute; a fresh process per setting pays the key setup every time).
+long tuning_get(const char* name, long dflt);
+void tuning_set(const char* name, long value);     // value == LONG_MIN: forget the override
 
 // ---- NTT (ntt.hip) ----
 // In-place transform of n Montgomery Fr elements resident on the device.
@@ -155,6 +170,11 @@ int msm_g2_host(Lane& L, const void* h_scalars, const void* h_points, uint64_t n
 // allow_split: the plan may order its tasks in two segments (high windows first) so that msm_g{1,2}_launch can run the
 // reduction tail of the high windows on the lane's second queue beside the accumulation of the low ones (one stand-alone MSM)
 int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipStream_t s, uint32_t table_c = 0, bool allow_split = false);
+// the same plan in three steps: the digit histogram -- the first pass over the scalars -- may be taken over parts [i0, i1) of
+// the vector as they become available (a witness uploaded chunk by chunk), on `s` or on queues ordered before the finish
+int msm_plan_begin(Lane& L, uint64_t n, WindowShard sh, hipStream_t s, uint32_t table_c = 0, bool allow_split = false);
+int msm_plan_count(Lane& L, const Fe* d_scalars, uint64_t i0, uint64_t i1, hipStream_t s);
+int msm_plan_finish(Lane& L, const Fe* d_scalars, hipStream_t s);
 uint32_t msm_table_rows(uint32_t table_c);
 uint32_t msm_table_window(uint64_t n);
 int msm_build_table(int which, void* d_table, uint64_t n, uint32_t table_c, hipStream_t s);   // rows 1.. from row 0 (device domain: after msm_prepare_points)
@@ -220,7 +240,10 @@ struct DistComm {
     void* user = nullptr;
 };
 // the rank's slice of h (plain form, 2^l2-interleaved rows of the rank), three exchanges
+// *exchanges (optional): how many of the three all-to-alls this rank has posted when the call returns
 int calc_h_dist(Lane& L, const DistComm& cm, const Fe* d_signals_plain, uint32_t n_signals, const CsrMatrix& A, const CsrMatrix& B,
-                uint32_t domain, uint32_t l2_expected, Fe* d_h_local, hipStream_t s);
+                uint32_t domain, uint32_t l2_expected, Fe* d_h_local, hipStream_t s, int* exchanges = nullptr);
+// its checks and buffer reserves alone (what can fail on one rank before any collective)
+int calc_h_dist_reserve(Lane& L, const DistComm& cm, uint32_t n_signals, uint32_t domain, uint32_t l2_expected);
 
 }  // namespace wsnark

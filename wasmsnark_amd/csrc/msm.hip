@@ -133,6 +133,7 @@ __device__ __forceinline__ void for_each_digit(const Fe& raw, uint32_t c, uint32
 struct PresortArgs {
     const Fe* scalars;
     uint32_t n, c, Wall, w_off, w_stride;
+    uint32_t i0, i_end;                // the scalars [i0, i_end) this launch covers (the digit histogram may be taken chunk by chunk)
     uint32_t lo_bits, HB, nbins;       // bin = k*HB + ((d-1) >> lo_bits)
     uint32_t tile;                     // scalars per workgroup
     uint32_t idx_bits;                 // packed 4-byte entries: idx | neg << idx_bits | lo << (idx_bits+1)
@@ -166,8 +167,8 @@ __global__ __launch_bounds__(1024) void presort_count(PresortArgs A, uint32_t* _
     __shared__ uint32_t cnt[PRESORT_MAX_BINS];
     for (uint32_t b = threadIdx.x; b < A.nbins; b += blockDim.x) cnt[b] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * A.tile;
-    for (uint32_t i = base + threadIdx.x; i < base + A.tile && i < A.n; i += blockDim.x) {
+    const uint32_t base = A.i0 + blockIdx.x * A.tile;
+    for (uint32_t i = base + threadIdx.x; i < base + A.tile && i < A.i_end; i += blockDim.x) {
         if (A.mask && !A.mask[i]) continue;
         for_each_digit(A.scalars[i], A.c, A.Wall, A.w_off, A.w_stride, [&](uint32_t k, uint32_t d, uint32_t) {
             atomicAdd(&cnt[presort_bin(A, k, d)], 1u);
@@ -207,8 +208,8 @@ __global__ __launch_bounds__(1024) void presort_scatter(PresortArgs A, uint32_t*
     __shared__ uint32_t gbase[PRESORT_MAX_BINS];
     for (uint32_t b = threadIdx.x; b < A.nbins; b += blockDim.x) cnt[b] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * A.tile;
-    for (uint32_t i = base + threadIdx.x; i < base + A.tile && i < A.n; i += blockDim.x) {
+    const uint32_t base = A.i0 + blockIdx.x * A.tile;
+    for (uint32_t i = base + threadIdx.x; i < base + A.tile && i < A.i_end; i += blockDim.x) {
         if (A.mask && !A.mask[i]) continue;
         for_each_digit(A.scalars[i], A.c, A.Wall, A.w_off, A.w_stride, [&](uint32_t k, uint32_t d, uint32_t) {
             atomicAdd(&cnt[presort_bin(A, k, d)], 1u);
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(1024) void presort_scatter(PresortArgs A, uint32_t*
     }
     __syncthreads();
     const uint32_t lo_mask = (1u << A.lo_bits) - 1;
-    for (uint32_t i = base + threadIdx.x; i < base + A.tile && i < A.n; i += blockDim.x) {
+    for (uint32_t i = base + threadIdx.x; i < base + A.tile && i < A.i_end; i += blockDim.x) {
         if (A.mask && !A.mask[i]) continue;
         for_each_digit(A.scalars[i], A.c, A.Wall, A.w_off, A.w_stride, [&](uint32_t k, uint32_t d, uint32_t neg) {
             const uint32_t b = presort_bin(A, k, d);
@@ -867,7 +868,9 @@ struct MsmPlanInfo {
     uint32_t c = 0, W = 0, NB = 0, nbuckets = 0, m = 0, J = 0, logJ = 0, nsum = 0, lmax = 0, hot_cap = 0;
     uint32_t hot_min = 1024;
     uint32_t ps_lo_bits = 0, ps_idx_bits = 0, ps_nbins = 0, ps_bthr = 0;   // grouping pass geometry (presort plans)
+    uint32_t ps_HB = 0, ps_tile = 0, ps_thr = 0;
     bool ps_valid = false, ps_e32 = false;
+    bool building = false;        // between msm_plan_begin and msm_plan_finish: the digit histogram is being taken
     uint32_t Wall = 0, w_off = 0, w_stride = 1;   // W = owned windows; Wall = windows of the whole scalar
     // fixed-base table plans (flat): the points array holds Wall rows of n points, row w = 2^(c w) * row 0, so every window's
     // digits go into ONE set of NB buckets and no doubling is left for the tail.  For the reduction tail the bucket set is
@@ -1044,7 +1047,14 @@ uint32_t msm_table_window(uint64_t n) {
     return (uint32_t)c;
 }
 
-int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipStream_t s, uint32_t table_c, bool allow_split) {
+// The plan in three steps, so that the FIRST pass over the scalars -- the digit histogram -- can run on parts of the vector
+// while the rest is still on its way to the device (prove.hip: a witness uploaded chunk by chunk):
+//   msm_plan_begin   geometry, buffers, cleared counters
+//   msm_plan_count   histogram of the scalars [i0, i1) (any number of calls that together cover [0, n), on queues ordered
+//                    before the one msm_plan_finish runs on)
+//   msm_plan_finish  scan, scatter, per-bin sort, task list
+// msm_plan_dev is the three in a row.
+int msm_plan_begin(Lane& L, uint64_t n, WindowShard sh, hipStream_t s, uint32_t table_c, bool allow_split) {
     Context* X = ctx();
     if (!X) return WS_ERR_NOINIT;
     if (!s) s = L.stream;
@@ -1052,7 +1062,6 @@ int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipSt
     MsmPlanInfo& I = M.plan[M.cur].info;
     I = MsmPlanInfo();
     if (n == 0) { I.valid = true; return WS_OK; }
-    if (!d_scalars) return WS_ERR_ARG;
     if (n > ((uint64_t)1 << 28)) return WS_ERR_SIZE;
     if (sh.stride == 0) return WS_ERR_ARG;
     I.n = n;
@@ -1070,10 +1079,10 @@ int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipSt
     const uint64_t total = n * I.W;
     if (total >= ((uint64_t)1 << 32)) return WS_ERR_SIZE;
     uint32_t chunk = CHUNK;
-    if (const char* e = getenv("WSNARK_MSM_CHUNK")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32) chunk = (uint32_t)v; }
+    { const long v = tuning_get("MSM_CHUNK", 0); if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32) chunk = (uint32_t)v; }
     if (I.flat) {
         uint32_t tbits = 15;       // buckets per tail piece (WSNARK_TAIL_BITS): shorter pieces = shallower trees, more rows for the host
-        if (const char* e = getenv("WSNARK_TAIL_BITS")) { int v = atoi(e); if (v >= 6 && v <= 20) tbits = (uint32_t)v; }
+        { const long v = tuning_get("TAIL_BITS", 0); if (v >= 6 && v <= 20) tbits = (uint32_t)v; }
         I.tNB = I.NB < (1u << tbits) ? I.NB : (1u << tbits);
         I.tW = I.NB / I.tNB;
     } else {
@@ -1129,12 +1138,10 @@ int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipSt
     I.hot_min = hot_min;
     WS_HIP_CHECK(S.hot.reserve(((size_t)I.hot_cap / hot_min + 16) * sizeof(HotBucket)));
 
-    KernelTimer& T = X->timer;
     // counters: [0] partial slots, [1] multi-task buckets, [3] total tasks; [16..271] length histogram,
     // [272..527] cursors
     // (the coarse-bin counts of the grouping pass follow at [1024 ..]: one memset clears both)
     uint32_t* d_cnt = S.counters.as<uint32_t>();
-    bool have_hist = false;
     const bool use_cub = [] { const char* e = getenv("WSNARK_MSM_SORT"); return e && !strcmp(e, "cub"); }();
     const uint32_t env_lo = [] { const char* e = getenv("WSNARK_MSM_LO_BITS"); return e ? (uint32_t)atoi(e) : 8u; }();
     const uint32_t env_tile = [] { const char* e = getenv("WSNARK_MSM_TILE"); return e ? (uint32_t)atoi(e) : 1024u; }();
@@ -1156,10 +1163,10 @@ int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipSt
         // ---- grouping by coarse bins + per-bin LDS counting sort (hand-written; see the kernels above) ----
         const bool e32 = !env_e64 && idx_bits + 1 + lo_bits <= 32;
         WS_HIP_CHECK(S.entries.reserve(total * (e32 ? 4 : 8)));
-        uint32_t* bin_count = d_cnt + CNT_BINS;
-        uint32_t* bin_start = bin_count + (nbins + 1);
-        uint32_t* bin_cursor = bin_start + (nbins + 1);
         WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, (CNT_BINS + (size_t)nbins + 1) * 4, s));
+        I.ps_valid = true;
+        I.ps_lo_bits = lo_bits; I.ps_idx_bits = idx_bits; I.ps_nbins = nbins; I.ps_e32 = e32;
+        I.ps_HB = HB; I.ps_tile = env_tile; I.ps_thr = env_thr;
         // split plans: only for a whole stand-alone MSM (allow_split), per-window buckets in workgroup-aligned sets
         // (WSNARK_MSM_SPLIT_MIN: smallest n that splits; tests lower it to reach the path at sizes the oracle finishes)
         // Measured on MI355X (profiles/r03_s3_msm_split.txt): 2^20 pairs 2.28 ms split against 2.07 ms in one piece -- two half-size
@@ -1169,11 +1176,70 @@ int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipSt
         const bool split_env = [] { const char* e = getenv("WSNARK_MSM_SPLIT"); return e && atoi(e) == 1; }();
         const uint64_t split_min = [] { const char* e = getenv("WSNARK_MSM_SPLIT_MIN"); return e ? (uint64_t)atoll(e) : (uint64_t)1 << 14; }();
         if (allow_split && split_env && !I.flat && W >= 4 && I.NB >= 256 && n >= split_min) I.split_k = W / 2;
-        const uint32_t split_bin = I.split_k * HB;
-        PresortArgs PA{d_scalars, (uint32_t)n, c, I.Wall, I.w_off, I.w_stride, lo_bits, HB, nbins, env_tile, idx_bits, nullptr, I.flat ? 1u : 0u};
-        const dim3 grid(ceil_div_u64(n, env_tile)), blk(env_thr);
-        T.begin("msm_presort_count", s);
-        hipLaunchKernelGGL(presort_count, grid, blk, 0, s, PA, bin_count);
+    } else {
+        if (I.flat) { set_last_error("msm: table plans need the grouping pass (WSNARK_MSM_SORT=cub or too many bins)"); return WS_ERR_ARG; }
+        WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, (size_t)CNT_BINS * 4, s));
+        WS_HIP_CHECK(S.keys.reserve(total * 4));
+        WS_HIP_CHECK(S.vals.reserve(total * 4));
+        WS_HIP_CHECK(S.keys_out.reserve(total * 4));
+    }
+    (void)d_cnt; (void)hot_min; (void)lmax; (void)nbuckets;
+    I.building = true;
+    return WS_OK;
+}
+
+static PresortArgs plan_presort_args(const MsmPlanInfo& I, const Fe* d_scalars, uint32_t i0, uint32_t i_end) {
+    return PresortArgs{d_scalars, (uint32_t)I.n, I.c, I.Wall, I.w_off, I.w_stride, i0, i_end, I.ps_lo_bits, I.ps_HB, I.ps_nbins, I.ps_tile,
+                       I.ps_idx_bits, nullptr, I.flat ? 1u : 0u};
+}
+
+int msm_plan_count(Lane& L, const Fe* d_scalars, uint64_t i0, uint64_t i1, hipStream_t s) {
+    Context* X = ctx();
+    if (!X) return WS_ERR_NOINIT;
+    if (!s) s = L.stream;
+    MsmWorkspace& M = ws(L);
+    MsmPlanInfo& I = M.plan[M.cur].info;
+    if (I.n == 0 && I.valid) return WS_OK;                 // (nothing to group: n == 0, or a rank that owns no window)
+    if (!I.building) { set_last_error("msm_plan_count: no plan is being built"); return WS_ERR_ARG; }
+    if (!d_scalars || i0 > i1 || i1 > I.n) return WS_ERR_ARG;
+    if (!I.ps_valid || i0 == i1) return WS_OK;             // (the hipCUB pipeline has no histogram pass)
+    MsmScratch& S = M.plan[M.cur].S;
+    uint32_t* bin_count = S.counters.as<uint32_t>() + CNT_BINS;
+    const PresortArgs PA = plan_presort_args(I, d_scalars, (uint32_t)i0, (uint32_t)i1);
+    X->timer.begin("msm_presort_count", s);
+    hipLaunchKernelGGL(presort_count, dim3(ceil_div_u64(i1 - i0, I.ps_tile)), dim3(I.ps_thr), 0, s, PA, bin_count);
+    X->timer.end(s);
+    WS_HIP_CHECK(hipGetLastError());
+    return WS_OK;
+}
+
+int msm_plan_finish(Lane& L, const Fe* d_scalars, hipStream_t s) {
+    Context* X = ctx();
+    if (!X) return WS_ERR_NOINIT;
+    if (!s) s = L.stream;
+    MsmWorkspace& M = ws(L);
+    MsmPlanInfo& I = M.plan[M.cur].info;
+    if (I.n == 0 && I.valid) return WS_OK;
+    if (!I.building) { set_last_error("msm_plan_finish: no plan is being built"); return WS_ERR_ARG; }
+    if (!d_scalars) return WS_ERR_ARG;
+    I.building = false;
+    MsmScratch& S = M.plan[M.cur].S;
+    KernelTimer& T = X->timer;
+    const uint64_t n = I.n, total = n * I.W;
+    const uint32_t c = I.c, nbuckets = I.nbuckets, lmax = I.lmax, hot_min = I.hot_min;
+    uint32_t* d_cnt = S.counters.as<uint32_t>();
+    bool have_hist = false;
+    int rc;
+    if (I.ps_valid) {
+        const uint32_t nbins = I.ps_nbins, lo_bits = I.ps_lo_bits, idx_bits = I.ps_idx_bits;
+        const bool e32 = I.ps_e32;
+        uint32_t* bin_count = d_cnt + CNT_BINS;
+        uint32_t* bin_start = bin_count + (nbins + 1);
+        uint32_t* bin_cursor = bin_start + (nbins + 1);
+        const uint32_t split_bin = I.split_k * I.ps_HB;
+        const PresortArgs PA = plan_presort_args(I, d_scalars, 0u, (uint32_t)n);
+        const dim3 grid(ceil_div_u64(n, I.ps_tile)), blk(I.ps_thr);
+        T.begin("msm_presort_scan", s);
         hipLaunchKernelGGL(presort_scan, dim3(1), dim3(256), 0, s, bin_count, nbins, bin_start, bin_cursor);
         T.end(s);
         T.begin("msm_presort_scatter", s);
@@ -1195,15 +1261,9 @@ int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipSt
         T.end(s);
         WS_HIP_CHECK(hipGetLastError());
         have_hist = true;
-        I.ps_valid = true;
-        I.ps_lo_bits = lo_bits; I.ps_idx_bits = idx_bits; I.ps_nbins = nbins; I.ps_bthr = bthr; I.ps_e32 = e32;
+        I.ps_bthr = bthr;
     } else {
-        if (I.flat) { set_last_error("msm: table plans need the grouping pass (WSNARK_MSM_SORT=cub or too many bins)"); return WS_ERR_ARG; }
-        WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, (size_t)CNT_BINS * 4, s));
         // ---- reference pipeline: explicit digit arrays + hipCUB radix sort (WSNARK_MSM_SORT=cub) ----
-        WS_HIP_CHECK(S.keys.reserve(total * 4));
-        WS_HIP_CHECK(S.vals.reserve(total * 4));
-        WS_HIP_CHECK(S.keys_out.reserve(total * 4));
         T.begin("msm_digits", s);
         hipLaunchKernelGGL(msm_digits, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s, d_scalars, (uint32_t)n, c, I.Wall,
                            I.w_off, I.w_stride, nbuckets, S.keys.as<uint32_t>(), S.vals.as<uint32_t>());
@@ -1238,6 +1298,15 @@ int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipSt
     I.nmulti = 0;
     I.valid = true;
     return WS_OK;
+}
+
+
+int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipStream_t s, uint32_t table_c, bool allow_split) {
+    if (n && !d_scalars) return WS_ERR_ARG;
+    int rc = msm_plan_begin(L, n, sh, s, table_c, allow_split);
+    if (!rc) rc = msm_plan_count(L, d_scalars, 0, n, s);
+    if (!rc) rc = msm_plan_finish(L, d_scalars, s);
+    return rc;
 }
 
 int msm_plan_variant(Lane& L, int src_id, int dst_id, const uint8_t* d_mask, hipStream_t s) {

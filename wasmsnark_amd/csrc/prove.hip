@@ -86,8 +86,8 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
         K->hlo = shard.rank * hper;
         K->h_local = shard.rank == shard.world - 1 ? dom - K->hlo : hper;
         if (shard.h_log_m) {
-            const uint64_t m = (uint64_t)1 << shard.h_log_m;
-            if (shard.h_log_m > 27 || m > dom || (shard.world & (shard.world - 1)) || m % shard.world) {
+            const uint64_t m = shard.h_log_m <= 27 ? (uint64_t)1 << shard.h_log_m : 0;      // (range first: the value comes straight from the C ABI)
+            if (m == 0 || m > dom || (shard.world & (shard.world - 1)) || m % shard.world) {
                 set_last_error("proving key shard: the interleave 2^h_log_m must divide the domain and be a multiple of the (power-of-two) world size");
                 return WS_ERR_ARG;
             }
@@ -347,8 +347,13 @@ struct MsmSums {
 // calc_h (optional): enqueues the computation of the h this handle's hExps share is summed against on the given queue
 // (the distributed CALC_H of dist.hip) instead of the whole CALC_H.
 typedef std::function<int(hipStream_t, Fe*)> CalcHFn;
+// h_witness (optional): the witness is still in HOST memory.  It is uploaded into d_witness (which must then be the lane's
+// own witness buffer) chunk by chunk on the lane's copy queue, and the first pass over it -- the digit histogram of the
+// grouping pass -- runs on every chunk as it lands, instead of behind the whole transfer (src/bn128.js:580: the reference's
+// callers hand over host memory; the 32 B x nVars of H2D are inside every drop-in call).
 static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard sh, MsmSums* out, hipStream_t s,
-                      const std::function<void(const MsmSums&)>& after_ab1 = nullptr, bool skip_h = false, const CalcHFn& calc_h = nullptr) {
+                      const std::function<void(const MsmSums&)>& after_ab1 = nullptr, bool skip_h = false, const CalcHFn& calc_h = nullptr,
+                      const uint8_t* h_witness = nullptr) {
     Trace tr;
     // a points-sharded key sums its own pairs: the witness slice [lo, lo + n_local) against the resident slice of every
     // section (all windows), h[hlo ..] against its hExps slice
@@ -361,7 +366,7 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
     // WSNARK_PROVE_OVERLAP: 0 = one queue; 1 = the second queue (CALC_H, H) is released when the first batched tail starts;
     // 2 (default) = released at once.  Round-2 sweep on the dense 2^20 key, after the finish-order fix below:
     // 2: 11.26 ms, 1: 11.34 ms (plain queues); with a high-priority second queue 2: 11.6 ms, 1: 11.3 ms.
-    static const int overlap = [] { const char* e = getenv("WSNARK_PROVE_OVERLAP"); return e ? atoi(e) : 2; }();
+    const int overlap = (int)tuning_get("PROVE_OVERLAP", 2);
     hipStream_t s2 = overlap ? L.stream2 : s;
     // launch slots: A, B1, C, B2, H.  On an error path the launches of THIS proof are forgotten (other lanes' are not touched)
     int slots[5] = {-1, -1, -1, -1, -1};
@@ -372,10 +377,36 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
     } guard{L, slots, s, s2, true};
     for (hipEvent_t* e : {&L.ev_start, &L.ev_tail, &L.ev_h})
         if (!*e) WS_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-    WS_HIP_CHECK(hipEventRecord(L.ev_start, s));          // the witness is ready on s
     // the four sums whose scalars are the witness (:617-620)
     msm_select_plan(L, 0);
-    if ((rc = msm_plan_dev(L, d_witness, nv, sh, s, K->table_cw))) return rc;
+    if (h_witness && tuning_get("PROVE_CHUNKED_UPLOAD", 1)) {
+        hipStream_t sc = L.stream_copy;
+        for (hipEvent_t* e : {&L.ev_chunk[0], &L.ev_chunk[1]})
+            if (!*e) WS_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        // the copy queue starts behind whatever the caller's queue still holds for this lane's witness buffer
+        WS_HIP_CHECK(hipEventRecord(L.ev_start, s));
+        WS_HIP_CHECK(hipStreamWaitEvent(sc, L.ev_start, 0));
+        if ((rc = msm_plan_begin(L, nv, sh, s, K->table_cw))) return rc;
+        unsigned k = 0;
+        const uint64_t lo_sig = K->lo, hi_sig = (uint64_t)K->lo + nv;
+        rc = upload_pipelined(const_cast<Fe*>(d_witness_all), h_witness, (size_t)K->n_vars * 32, sc, [&](size_t blo, size_t bhi) -> int {
+            hipEvent_t ev = L.ev_chunk[k++ & 1];             // (a wait captures the record that precedes it: two events suffice)
+            WS_HIP_CHECK(hipEventRecord(ev, sc));
+            WS_HIP_CHECK(hipStreamWaitEvent(s, ev, 0));
+            uint64_t e0 = blo / 32, e1 = bhi / 32;            // signals of this chunk; the part of them this handle sums
+            if (e0 < lo_sig) e0 = lo_sig;
+            if (e1 > hi_sig) e1 = hi_sig;
+            return e0 < e1 ? msm_plan_count(L, d_witness, e0 - lo_sig, e1 - lo_sig, s) : (int)WS_OK;
+        });
+        if (rc) return rc;
+        tr.mark("witness staged, histogram enqueued per chunk");
+        WS_HIP_CHECK(hipEventRecord(L.ev_start, s));      // the whole witness is resident (s has waited for every chunk)
+        if ((rc = msm_plan_finish(L, d_witness, s))) return rc;
+    } else {
+        if (h_witness && (rc = upload_staged(const_cast<Fe*>(d_witness_all), h_witness, (size_t)K->n_vars * 32, s))) return rc;
+        WS_HIP_CHECK(hipEventRecord(L.ev_start, s));      // the witness is ready on s
+        if ((rc = msm_plan_dev(L, d_witness, nv, sh, s, K->table_cw))) return rc;
+    }
     // one grouping pass for all four; A and B1/B2 may run on variants of the plan that leave out the variables
     // absent from their matrix (plan 0 = full, 2 = without B's absentees, 3 = without A's).  A, B1 and C: three
     // accumulations back to back, then ONE batched reduction tail
@@ -387,7 +418,7 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
     // beside CALC_H's full-width kernels instead of at the end of the proof, where nothing is left to fill the SIMDs
     // (WSNARK_PROVE_ORDER=0: the round-1 order A, B1, C, B2).  A and B1 reach the host before C's accumulation ends,
     // so the host's share of pi_c (after_ab1) still overlaps GPU work.
-    static const int order_env = [] { const char* e = getenv("WSNARK_PROVE_ORDER"); return e ? atoi(e) : -1; }();
+    const int order_env = (int)tuning_get("PROVE_ORDER", -1);
     // Order 3 (round 3; small sums: a rank's share of a points-sharded key, small circuits): every sum of such a proof is a
     // latency chain -- grouping, a sub-millisecond accumulation on a fraction of the SIMDs, a reduction tail of ~33 dependent
     // additions -- so the chains run BESIDE each other instead of behind each other: B2 with its tail on a third queue, A, B1
@@ -604,7 +635,7 @@ static void prove_assemble(ProvingKey* K, const MsmSums& M, Blinding& B, Blindin
 
 // witness on the device, lane L held by the caller
 static int groth16_prove(ProvingKey* K, Lane& L, const Fe* d_witness, const uint8_t* r32, const uint8_t* s32, uint8_t* out384,
-                         hipStream_t s) {
+                         hipStream_t s, const uint8_t* h_witness = nullptr) {
     if (!s) s = L.stream;
     Blinding B;
     int rc = start_blinding(K, r32, s32, &B);
@@ -612,7 +643,8 @@ static int groth16_prove(ProvingKey* K, Lane& L, const Fe* d_witness, const uint
     MsmSums M;
     Blinding::Pre pp;
     EarlyParts E;
-    if ((rc = prove_msms(K, L, d_witness, WindowShard{}, &M, s, [&](const MsmSums& m) { prove_assemble_early(K, m, B, pp, &E); }))) return rc;
+    if ((rc = prove_msms(K, L, d_witness, WindowShard{}, &M, s, [&](const MsmSums& m) { prove_assemble_early(K, m, B, pp, &E); }, false, nullptr, h_witness)))
+        return rc;
     Trace tr;
     prove_assemble(K, M, B, pp, E, out384);
     tr.mark("assemble (host)");
@@ -623,14 +655,11 @@ static int check_witness_len(ProvingKey* K, size_t witness_len) {
     if ((uint64_t)witness_len < (uint64_t)K->n_vars * 32) { set_last_error("witness shorter than nVars*32 bytes"); return WS_ERR_SIZE; }
     return WS_OK;
 }
-static int upload_witness(ProvingKey* K, Lane& L, const uint8_t* witness) {
-    WS_HIP_CHECK(L.witness.reserve((size_t)K->n_vars * 32));
-    return upload_staged(L.witness.p, witness, (size_t)K->n_vars * 32, L.stream);
-}
 
 // ---- multi-GPU proving: per-rank partial sums, then one 576-byte record per rank to combine ----
 // record = A | B1 | C | H (4 x 96 B G1) | B2 (192 B G2), Jacobian-Montgomery, affine-normalised
-static int prove_partial_on(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard sh, uint8_t* out576, hipStream_t s, bool skip_h) {
+static int prove_partial_on(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard sh, uint8_t* out576, hipStream_t s, bool skip_h,
+                            const uint8_t* h_witness = nullptr) {
     if (K->shard_world > 1) {
         // the handle IS the shard (its slice of the points, every window): the per-call rank / world must name the same one
         if (sh.off != K->shard_rank || sh.stride != K->shard_world) {
@@ -641,7 +670,7 @@ static int prove_partial_on(ProvingKey* K, Lane& L, const Fe* d_witness, WindowS
         sh = WindowShard{};
     }
     MsmSums M;
-    int rc = prove_msms(K, L, d_witness, sh, &M, s ? s : L.stream, nullptr, skip_h);
+    int rc = prove_msms(K, L, d_witness, sh, &M, s ? s : L.stream, nullptr, skip_h, nullptr, h_witness);
     if (rc) return rc;
     Jac<Fq> j;
     j = G1::to_affine_jac(M.A); memcpy(out576, &j, 96);
@@ -657,8 +686,8 @@ int groth16_prove_partial(ProvingKey* K, const uint8_t* witness, size_t witness_
     int rc = check_witness_len(K, witness_len);
     if (rc) return rc;
     LaneLock L = acquire_lane(C);
-    if ((rc = upload_witness(K, *L, witness))) return rc;
-    return prove_partial_on(K, *L, L->witness.as<Fe>(), sh, out576, L->stream, skip_h);
+    WS_HIP_CHECK(L->witness.reserve((size_t)K->n_vars * 32));
+    return prove_partial_on(K, *L, L->witness.as<Fe>(), sh, out576, L->stream, skip_h, witness);
 }
 int groth16_prove_partial_dev(ProvingKey* K, const Fe* d_witness, size_t witness_len, WindowShard sh, uint8_t* out576, hipStream_t s, bool skip_h) {
     Context* C = ctx();
@@ -732,62 +761,124 @@ int pkey_h_msm_dev(ProvingKey* K, const Fe* d_h_local, uint64_t n, uint8_t* out9
 
 // One proof over the ranks of a node: this rank's partial sums (points shard), CALC_H on the distributed transform, one
 // all-gather of the records, the same host-side assembly on every rank.  r32 / s32 NULL: rank 0 draws the blinding values
-// and they travel in its slot of the all-gather, so that every rank returns the same proof.
+// and they travel in its slot of the first all-gather, so that every rank returns the same proof.
+//
+// Error agreement (the collectives pair up by call order, so a rank must never skip one its peers will post):
+//   * everything that can fail locally without a collective -- argument checks, the grow-only buffer reserves of the
+//     distributed CALC_H -- happens BEFORE the first collective, and its outcome travels in that collective;
+//   * the first all-gather is ALWAYS posted (80-byte records: status | which of r, s were injected | the 64 blinding bytes),
+//     whether the caller injected r, s or not: ranks that disagree about the injection, or about the injected values, all
+//     return WSNARK_ERR_ARG instead of pairing a 64-byte gather with a 576-byte one;
+//   * a rank that fails after that keeps posting the exchanges its peers are waiting in (`drain` below: the data no longer
+//     matters) and reports its status in the trailer of the record all-gather; every rank then returns an error.
+// What is left to the transport: a callback that fails or hangs on one rank (a dead peer, a broken link) -- the host's
+// collectives library has to time out there, nothing in this file can.
+static const size_t kDistHello = 80, kDistRecord = 576 + 16;
 int groth16_prove_dist(ProvingKey* K, const Fe* d_witness, size_t witness_len, const DistComm& cm, const uint8_t* r32, const uint8_t* s32,
                        uint8_t* out384, hipStream_t s) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
-    int rc = check_witness_len(K, witness_len);
-    if (rc) return rc;
+    // (argument errors every rank sees alike -- a communicator that does not match the handle -- return before any collective)
     if (cm.world == 0 || cm.rank >= cm.world || K->shard_world != cm.world || K->shard_rank != cm.rank) {
         set_last_error("prove_dist: the handle must hold this communicator's points shard (wsnark_pkey_load_shard(rank, world, floor(log2(domain) / 2)))");
         return WS_ERR_ARG;
     }
     if (!cm.d_send || (cm.world > 1 && (!cm.d_recv || !cm.all_to_all || !cm.all_gather))) return WS_ERR_ARG;
-    // The blinding values first: the scalar multiplications that involve key points only (r delta1, s delta1, rs delta1, s delta2:
-    // ~0.5 ms on a host thread) then run under the GPU work, as in the one-call prover, instead of after the gather.  Injected
-    // values are known at once; drawn ones come from rank 0 through one more (64-byte) all-gather before the sums are enqueued.
+    const uint32_t P = cm.world;
+    LaneLock L = acquire_lane(C);
+    // ---- local preflight: may fail on this rank only, so its result goes into the first collective ----
+    int st = check_witness_len(K, witness_len);
+    std::string st_msg = st ? get_last_error() : std::string();
+    if (!st && (st = calc_h_dist_reserve(*L, cm, K->n_vars, K->domain, K->h_log_m))) st_msg = get_last_error();
+    if (!st && L->h.reserve((size_t)K->domain * 32) != hipSuccess) { st = WS_ERR_HIP; st_msg = "prove_dist: device allocation of h failed"; }
+    uint8_t hello[kDistHello];
+    memset(hello, 0, sizeof hello);
+    const uint32_t inj = (r32 ? 1u : 0u) | (s32 ? 2u : 0u);
+    if (!st && inj != 3u && cm.rank == 0 && os_random(hello + 16, 64)) { st = WS_ERR_ARG; st_msg = "cannot read /dev/urandom"; }
+    if (r32) memcpy(hello + 16, r32, 32);
+    if (s32) memcpy(hello + 48, s32, 32);
+    const uint32_t st_u = (uint32_t)st;
+    memcpy(hello, &st_u, 4);
+    memcpy(hello + 4, &inj, 4);
     uint8_t rs[64];
-    if (r32 && s32) {
-        memcpy(rs, r32, 32); memcpy(rs + 32, s32, 32);
-    } else {
-        uint8_t mine[64];
-        memset(mine, 0, sizeof mine);
-        if (cm.rank == 0 && os_random(mine, 64)) { set_last_error("cannot read /dev/urandom"); return WS_ERR_ARG; }
-        if (cm.world > 1) {
-            std::vector<uint8_t> all_rs((size_t)cm.world * 64);
-            if (cm.all_gather(cm.user, mine, all_rs.data(), 64) != 0) { set_last_error("prove_dist: the all-gather callback failed"); return WS_ERR_ARG; }
-            memcpy(rs, all_rs.data(), 64);                           // rank 0's draw
-        } else {
-            memcpy(rs, mine, 64);
+    if (P > 1) {
+        std::vector<uint8_t> all((size_t)P * kDistHello);
+        if (cm.all_gather(cm.user, hello, all.data(), kDistHello) != 0) { set_last_error("prove_dist: the all-gather callback failed"); return WS_ERR_ARG; }
+        for (uint32_t q = 0; q < P; q++) {
+            uint32_t qs, qi;
+            memcpy(&qs, &all[q * kDistHello], 4);
+            memcpy(&qi, &all[q * kDistHello + 4], 4);
+            if (qs) {
+                set_last_error(q == cm.rank ? st_msg : "prove_dist: rank " + std::to_string(q) + " failed before the proof started (status " + std::to_string(qs) + ")");
+                return (int)qs;
+            }
+            if (qi != inj) { set_last_error("prove_dist: the ranks disagree about which of r, s are injected (every rank must pass the same r32 / s32, or all NULL)"); return WS_ERR_ARG; }
         }
-        if (r32) memcpy(rs, r32, 32);
-        if (s32) memcpy(rs + 32, s32, 32);
+        memcpy(rs, &all[16], 64);                                        // rank 0's slot: its draw, overlaid with what it injected
+        for (uint32_t q = 1; q < P; q++) {
+            const uint8_t* o = &all[q * kDistHello + 16];
+            if ((r32 && memcmp(o, rs, 32)) || (s32 && memcmp(o + 32, rs + 32, 32))) {
+                set_last_error("prove_dist: the ranks injected different r / s");
+                return WS_ERR_ARG;
+            }
+        }
+    } else {
+        if (st) { set_last_error(st_msg); return st; }
+        memcpy(rs, hello + 16, 64);
     }
+    // the blinding values are known: the scalar multiplications that involve key points only (r delta1, s delta1, rs delta1,
+    // s delta2: ~0.5 ms on a host thread) run under the GPU work, as in the one-call prover
     Blinding B;
-    if ((rc = start_blinding(K, rs, rs + 32, &B))) return rc;
-    uint8_t rec[576];
-    {
-        LaneLock L = acquire_lane(C);
+    int rc = start_blinding(K, rs, rs + 32, &B);
+    uint8_t rec[kDistRecord];
+    memset(rec, 0, sizeof rec);
+    int exchanges = 0;
+    uint32_t log_n = 0;
+    while ((1u << log_n) < K->domain) log_n++;
+    if (!rc) {
         MsmSums M;
         const CalcHFn calc_h = [&](hipStream_t s2, Fe* d_h) {
-            return calc_h_dist(*L, cm, d_witness, K->n_vars, K->polsA, K->polsB, K->domain, K->h_log_m, d_h, s2);
+            return calc_h_dist(*L, cm, d_witness, K->n_vars, K->polsA, K->polsB, K->domain, K->h_log_m, d_h, s2, &exchanges);
         };
-        if ((rc = prove_msms(K, *L, d_witness, WindowShard{}, &M, s ? s : L->stream, nullptr, false, calc_h))) return rc;
-        Jac<Fq> j;
-        j = G1::to_affine_jac(M.A); memcpy(rec, &j, 96);
-        j = G1::to_affine_jac(M.B1); memcpy(rec + 96, &j, 96);
-        j = G1::to_affine_jac(M.C); memcpy(rec + 192, &j, 96);
-        j = G1::to_affine_jac(M.H); memcpy(rec + 288, &j, 96);
-        const Jac<Fq2> j2 = G2::to_affine_jac(M.B2); memcpy(rec + 384, &j2, 192);
+        rc = prove_msms(K, *L, d_witness, WindowShard{}, &M, s ? s : L->stream, nullptr, false, calc_h);
+        if (!rc) {
+            Jac<Fq> j;
+            j = G1::to_affine_jac(M.A); memcpy(rec, &j, 96);
+            j = G1::to_affine_jac(M.B1); memcpy(rec + 96, &j, 96);
+            j = G1::to_affine_jac(M.C); memcpy(rec + 192, &j, 96);
+            j = G1::to_affine_jac(M.H); memcpy(rec + 288, &j, 96);
+            const Jac<Fq2> j2 = G2::to_affine_jac(M.B2); memcpy(rec + 384, &j2, 192);
+        }
     }
-    std::vector<uint8_t> parts((size_t)cm.world * 576);
-    if (cm.world > 1) {
-        if (cm.all_gather(cm.user, rec, parts.data(), 576) != 0) { set_last_error("prove_dist: the all-gather callback failed"); return WS_ERR_ARG; }
+    const std::string rc_msg = rc ? get_last_error() : std::string();
+    if (rc && P > 1) {
+        // drain: the peers are (or will be) waiting in the exchanges this rank has not posted yet: 3, 2, 1 vectors of n / P^2
+        // elements per peer.  The send buffer's contents no longer matter -- every rank is about to learn of the failure.
+        static const uint64_t vecs[3] = {3, 2, 1};
+        const uint64_t per = ((uint64_t)K->domain / P / P) * sizeof(Fe);
+        for (int e = exchanges; e < 3; e++) (void)cm.all_to_all(cm.user, vecs[e] * per, (void*)L->stream2);
+        (void)hipStreamSynchronize(L->stream2);
+    }
+    const uint32_t rc_u = (uint32_t)rc;
+    memcpy(rec + 576, &rc_u, 4);
+    std::vector<uint8_t> parts((size_t)P * 576);
+    if (P > 1) {
+        std::vector<uint8_t> all((size_t)P * kDistRecord);
+        if (cm.all_gather(cm.user, rec, all.data(), kDistRecord) != 0) { set_last_error("prove_dist: the all-gather callback failed"); return WS_ERR_ARG; }
+        for (uint32_t q = 0; q < P; q++) {
+            uint32_t qs;
+            memcpy(&qs, &all[q * kDistRecord + 576], 4);
+            if (qs) {
+                set_last_error(q == cm.rank ? rc_msg : "prove_dist: rank " + std::to_string(q) + " failed (status " + std::to_string(qs) + ")");
+                return (int)qs;
+            }
+            memcpy(&parts[(size_t)q * 576], &all[q * kDistRecord], 576);
+        }
     } else {
+        if (rc) { set_last_error(rc_msg); return rc; }
         memcpy(parts.data(), rec, 576);
     }
-    finish_records(K, parts.data(), cm.world, B, out384);
+    finish_records(K, parts.data(), P, B, out384);
     return WS_OK;
 }
 
@@ -800,10 +891,8 @@ int groth16_prove_host_witness(ProvingKey* K, const uint8_t* witness, size_t wit
     rc = check_witness_len(K, witness_len);
     if (rc) return rc;
     LaneLock L = acquire_lane(C);
-    Trace tr;
-    if ((rc = upload_witness(K, *L, witness))) return rc;
-    if (tr.on) { tr.mark("witness staged (host side)"); (void)hipStreamSynchronize(L->stream); tr.mark("witness resident (DMA drained)"); }
-    return groth16_prove(K, *L, L->witness.as<Fe>(), r32, s32, out384, L->stream);
+    WS_HIP_CHECK(L->witness.reserve((size_t)K->n_vars * 32));
+    return groth16_prove(K, *L, L->witness.as<Fe>(), r32, s32, out384, L->stream, witness);
 }
 
 int groth16_prove_dev_witness(ProvingKey* K, const Fe* d_witness, size_t witness_len, const uint8_t* r32,
