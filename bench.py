@@ -189,6 +189,71 @@ def pmc_traffic(kernel, pairs_per_launch, windows):
     return None, None
 
 
+def _latest_profile(pattern):
+    """Newest committed profiles/rNN_<pattern> (by round tag, then name)."""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + pattern)))
+    return c[-1] if c else None
+
+
+def rocprof_kernel_mean(csv_path, must_contain, must_not_contain=()):
+    """Mean duration (ms), calls, min, max of one kernel in a committed `rocprofv3 --kernel-trace --stats` summary."""
+    import csv
+    try:
+        with open(csv_path, newline="") as fh:
+            for row in csv.DictReader(fh):
+                name = row.get("Name", "")
+                if all(x in name for x in must_contain) and not any(x in name for x in must_not_contain):
+                    return {"mean_ms": round(float(row["AverageNs"]) / 1e6, 4), "calls": int(row["Calls"]),
+                            "min_ms": round(float(row["MinNs"]) / 1e6, 4), "max_ms": round(float(row["MaxNs"]) / 1e6, 4),
+                            "file": "profiles/" + os.path.basename(csv_path)}
+    except Exception:  # noqa: BLE001
+        pass
+    return None
+
+
+def rocprof_citation(alg_bytes):
+    """What the committed rocprofv3 summaries of THIS command say about the dominant kernel: (a) proofs only, the shipped two-queue
+    schedule -- the profiler's per-dispatch instrumentation stretches a proof by ~0.5 ms and changes which kernels share the SIMDs,
+    so launches that run beside the other queue's full-width kernels are longer than in the unprofiled run; (b) proofs only with
+    WSNARK_PROVE_OVERLAP=0 -- one queue, every kernel alone: there the profiler and HIP events must agree."""
+    g1 = (["msm_accumulate", "Field29"], ["Fp2T"])
+    out = {}
+    for key, pat in (("in_situ_two_queues", "*kernel_stats_proofs_only.csv"), ("serialised_one_queue", "*kernel_stats_proofs_only_serialised.csv")):
+        f = _latest_profile(pat)
+        m = rocprof_kernel_mean(f, *g1) if f else None
+        if m:
+            m["GBps"] = round(alg_bytes / (m["mean_ms"] / 1e3) / 1e9, 2)
+            m["hbm_frac"] = round(m["GBps"] / HBM_PEAK_GBS, 5)
+            out[key] = m
+    return out or None
+
+
+def proof_issue_roofline(ms_per_proof, clock_hz, n_simd=1024):
+    """Whole-proof VALU-issue roofline: the wave-instructions one proof executes (rocprofv3 --pmc SQ_INSTS_VALU over exactly P
+    proofs, committed summary) x 4 cycles each / 1024 SIMD16s = the cycles a chip that did nothing but issue them would need,
+    over the cycles one measured proof takes.  The instruction count is a property of the workload and the build (same circuit,
+    same kernels), the time is this run's."""
+    f = _latest_profile("*proof_issue_budget.json")
+    if not f:
+        return None
+    try:
+        b = json.load(open(f))
+        insts = float(b["valu_insts_per_proof"])
+    except Exception:  # noqa: BLE001
+        return None
+    cycles = ms_per_proof / 1e3 * clock_hz
+    floor_ms = 4.0 * insts / n_simd / clock_hz * 1e3
+    top = sorted(((k, v["valu_insts_per_proof"]) for k, v in b.get("kernels", {}).items()), key=lambda kv: -kv[1])[:6]
+    return {"bound": "valu-issue", "achieved": round(4.0 * insts / n_simd / 1e6, 3), "peak": round(cycles / 1e6, 3), "unit": "Mcycles per proof",
+            "frac": round(4.0 * insts / n_simd / cycles, 4), "valu_wave_insts_per_proof": int(insts), "issue_floor_ms": round(floor_ms, 3),
+            "ms_per_proof": round(ms_per_proof, 3), "clock_GHz": round(clock_hz / 1e9, 3), "n_simd": n_simd,
+            "share_of_issue_by_kernel": {k: round(v / insts, 4) for k, v in top},
+            "source": "profiles/%s (%s)" % (os.path.basename(f), b.get("how", "")),
+            "note": "achieved = 4 x SQ_INSTS_VALU / 1024 SIMDs (the issue cycles of one proof's instruction stream); peak = cycles of one "
+                    "measured proof at the device's shader clock; frac = the share of the chip's VALU issue slots a whole proof uses"}
+
+
 def measure_peaks(bn):
     """The integer roofline's peak from THIS box and THIS run (wsnark_peak_probe, ~10 ms each): a dependent chain of the
     library's own radix-2^29 Montgomery product on every lane, and the raw v_mad_u64_u32 rate."""
@@ -205,7 +270,7 @@ def measure_peaks(bn):
     return out
 
 
-def rooflines(kt, kernel, pairs_per_launch, windows_owned, bytes_per_pair, modmul_per_add, peak=None):
+def rooflines(kt, kernel, pairs_per_launch, windows_owned, bytes_per_pair, modmul_per_add, peak=None, alone_ms=None, cite_rocprof=False):
     ms, cnt = kt.get(kernel, (0.0, 0))
     if not cnt or ms <= 0:
         return None, None
@@ -219,8 +284,15 @@ def rooflines(kt, kernel, pairs_per_launch, windows_owned, bytes_per_pair, modmu
     hbm = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": src,
            "avg_launch_ms": round(ms / cnt, 4), "launches_timed": cnt, "algorithmic_bytes_per_launch": int(alg),
+           "avg_launch_ms_is": "HIP events on the launching queue over the timed region: the launch IN SITU (two-queue schedule, no profiler)",
            "note": "reported because the contract asks for it; the kernel is integer-ALU bound (see roofline_int_alu): "
                    "~%d modmul per %d bytes" % (modmul_per_add * windows_owned, bytes_per_pair)}
+    if alone_ms:
+        hbm["avg_launch_ms_alone"] = round(alone_ms, 4)
+        hbm["frac_alone"] = round(alg / (alone_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5)
+        hbm["avg_launch_ms_alone_is"] = "HIP events, same run, proofs with WSNARK_PROVE_OVERLAP=0 (one queue: nothing shares the SIMDs)"
+    if cite_rocprof:
+        hbm["rocprofv3"] = rocprof_citation(alg)
     live = max([v for k, v in (peak or {}).items() if k.startswith("modmul") and v] or [0])
     pk = live or MODMUL_PEAK_G
     alu = {"bound": "int-alu", "kernel": kernel, "achieved": round(g, 1), "peak": pk, "unit": "Gmodmul/s",
@@ -315,6 +387,27 @@ def bench_prove(ctx):
     torch.cuda.synchronize()
     bn.lib.c.wsnark_timing_enable(0)
     kt_all = bn.lib.timing_report()
+    # the dominant kernel ALONE, and a proof with nothing overlapped: a few more proofs on ONE queue (WSNARK_PROVE_OVERLAP=0 through the
+    # library's A/B switch), HIP events around the accumulations only.  (single GPU: the N > 1 modes bring their own schedule)
+    alone_ms = serial_ms = None
+    if world == 1:
+        bn.lib.tune("PROVE_OVERLAP", 0)
+        try:
+            for _ in range(2):
+                step()
+            bn.lib.c.wsnark_timing_reset()
+            bn.lib.c.wsnark_timing_enable(2)
+            n_alone = max(4, args.steps // 2)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(n_alone):
+                step()
+            torch.cuda.synchronize()
+            serial_ms = (time.perf_counter() - t0) / n_alone * 1e3
+            bn.lib.c.wsnark_timing_enable(0)
+            ka = bn.lib.timing_report().get("msm_accumulate_g1")
+            alone_ms = ka[0] / ka[1] if ka and ka[1] else None
+        finally:
+            bn.lib.tune("PROVE_OVERLAP", None)
     # the drop-in call itself: genZKSnarkProof(witness, provingKey) hands over a HOST witness (32 B x nVars of H2D inside
     # every proof).  Timed like the headline, same steps; reported beside `value` (the contract keeps PCIe out of `value`)
     host_ms = host_ok = None
@@ -331,7 +424,7 @@ def bench_prove(ctx):
         return None
     ms = dt / args.steps * 1e3
     nv, dom = circ.n_vars, circ.domain
-    peak = measure_peaks(bn) if world == 1 else None
+    peak = measure_peaks(bn)                  # (rank 0, any world size: ~30 ms after the timed region)
     # passes over the points per sum: the rows of the key's fixed-base tables (13 at 2^20), or the windows of the plain method
     if calc_h_mode == "native":
         # points shards: every rank sums its own n / N pairs over ALL rows of its shard's tables
@@ -349,7 +442,11 @@ def bench_prove(ctx):
         W_own = len(range(rank, W_all, world))
         pairs = (3 * nv + dom) / 4.0                   # msm_accumulate_g1 launches per proof: A, B1, C (nVars pairs) and H (domain pairs)
         shard_info = None
-    hbm, alu = rooflines(kt, "msm_accumulate_g1", pairs, W_own, 96, 10, peak)
+    hbm, alu = rooflines(kt, "msm_accumulate_g1", pairs, W_own, 96, 10, peak, alone_ms=alone_ms, cite_rocprof=(world == 1 and logd == 20))
+    try:
+        clock_hz = float(torch.cuda.get_device_properties(dev).clock_rate) * 1e3
+    except Exception:  # noqa: BLE001
+        clock_hz = 2.4e9
     g2 = kt.get("msm_accumulate_g2")
     # algorithmic bytes of one proof
     alg_bytes = 32 * nv + 8 * nv + 36 * info["nnz_A_plus_B"] + 64 * nv * 2 + 128 * nv + 64 * (nv - circ.n_public - 1) + 64 * dom + 64 * 6 * dom
@@ -381,6 +478,8 @@ def bench_prove(ctx):
            "prove_algorithmic_bytes": int(alg_bytes), "prove_algorithmic_GBps": round(alg_bytes / (ms / 1e3) / 1e9, 1),
            "prove_hbm_frac": round(alg_bytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
            "roofline": hbm, "roofline_int_alu": alu,
+           "roofline_proof": proof_issue_roofline(ms, clock_hz) if (world == 1 and logd == 20 and args.circuit == "columns") else None,
+           "serialised_one_queue_ms_per_proof": round(serial_ms, 3) if serial_ms else None,
            "msm_accumulate_g2_avg_launch_ms": round(g2[0] / g2[1], 4) if g2 and g2[1] else None,
            "kernel_ms_per_proof": kernel_ms(kt_all, 2),
            "reference_wasm_8_workers_prove_2p20_s": {"value": REF_WASM_PROVE_2P20_S, "where": "BASELINE.md: survey container (8 vCPU), NOT this box: the reference may not travel"}}
@@ -398,9 +497,36 @@ def bench_prove(ctx):
         run_extra(extras, "prove_sparse_rows_circuit", lambda: extra_prove_sparse(ctx, logd))
     if extras:
         out["extras"] = extras
+    # cpu_baseline: timed on rank 0 at N = 1 only (the contract); an N > 1 line carries the last N = 1 measurement of this
+    # checkout on this box if there is one (.bench_cache/, written below), else the committed one, and says which
+    cache = os.path.join(ROOT, ".bench_cache", "cpu_baseline_2p%d.json" % logd)
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline_prove(ctx, logd, circ, wit, sec)
+        try:
+            if "value" in out["cpu_baseline"]:
+                os.makedirs(os.path.dirname(cache), exist_ok=True)
+                json.dump(dict(out["cpu_baseline"], measured_by="bench.py --gpus 1 on this box", device=bn.device_info), open(cache, "w"))
+        except Exception:  # noqa: BLE001
+            pass
+    elif world > 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cached_cpu_baseline(cache, logd)
     return out
+
+
+def cached_cpu_baseline(cache, logd):
+    try:
+        cb = json.load(open(cache))
+        cb["from"] = "the N = 1 run of this checkout on this box (.bench_cache/): the CPU leg is timed at N = 1 only"
+        return cb
+    except Exception:  # noqa: BLE001
+        pass
+    f = _latest_profile("*bench.json") if logd == 20 else None
+    try:
+        cb = json.load(open(f))["cpu_baseline"]
+        cb["from"] = "profiles/%s: ANOTHER box (no N = 1 run of this checkout was found here); the CPU leg is timed at N = 1 only" % os.path.basename(f)
+        return cb
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def run_extra(extras, name, fn):

@@ -188,7 +188,9 @@ int wsnark_pkey_shard_info(const wsnark_pkey_t* handle, uint32_t* rank, uint32_t
 int wsnark_pkey_h_msm_dev(wsnark_pkey_t* handle, const void* d_h_slice, uint64_t n, void* out96_host, void* stream);
 
 /* Bn128.groth16GenProof (src/bn128.js:580-720).  witness: nVars x 32 B plain
- * (tools/buildwitness.js:36-41).  r32 / s32: the two 32-byte blinding values the reference
+ * (tools/buildwitness.js:36-41); witness_len < nVars * 32 is WSNARK_ERR_SIZE, a LONGER buffer is accepted and only its first
+ * nVars signals are read -- exactly what the reference does with an over-long signals buffer (it walks nSignals records,
+ * src/bn128.js:607-620).  r32 / s32: the two 32-byte blinding values the reference
  * draws from crypto.randomBytes (src/bn128.js:642-661); NULL => drawn from the OS CSPRNG.
  * out384 = pi_a (x, y, z) 96 B | pi_b (x.c0, x.c1, y.c0, y.c1, z.c0, z.c1) 192 B |
  * pi_c 96 B: affine, PLAIN (non-Montgomery) little-endian, i.e. exactly the integers
@@ -199,12 +201,23 @@ int wsnark_groth16_prove(wsnark_pkey_t* handle, const void* witness, size_t witn
 int wsnark_groth16_prove_dev(wsnark_pkey_t* handle, const void* d_witness, size_t witness_len, const void* r32,
                              const void* s32, void* out384_host, void* stream);
 
+/* Host buffers the GPU can read in place (no counterpart in the reference, whose inputs live in the WASM heap).  A witness --
+ * or the scalars / points of an MSM -- that is WRITTEN into such a buffer is DMA'd straight from it, chunk by chunk; any other
+ * host pointer is first copied into the library's pinned staging ring by worker threads (about as fast as the link, but it
+ * costs host cores and a second pass over the bytes).  The Node addon hands these out as external ArrayBuffers
+ * (Bn128.allocInput).  Needs wsnark_init; free with wsnark_host_free (NULL is ignored). */
+int wsnark_host_alloc(size_t bytes, void** out);
+void wsnark_host_free(void* p);
+
 /* Bn128.groth16Verify (src/bn128.js:722-791; pairing bn128_pairingEq4, src/bn128/build_bn128.js:265-1374): native host
  * arithmetic, no GPU and no wsnark_init needed.  Checks e(A,B) e(-IC(inputs),gamma2) e(-C,delta2) e(-alfa1,beta2) == 1.
  *   vk     : alfa1 (64 B) | beta2 (128 B) | gamma2 (128 B) | delta2 (128 B) | IC[0 .. n_inputs] (64 B each) -- the points
  *            of verification_key.json as affine PLAIN (non-Montgomery) little-endian integers, G2 as (x.c0, x.c1, y.c0, y.c1)
  *   inputs : n_inputs x 32 B plain little-endian public signals; one >= r gives *valid = 0 like the reference (:772)
- *   proof384: what wsnark_groth16_prove writes (pi_a | pi_b | pi_c with their z coordinates; z == 0 = infinity)
+ *   proof384: what wsnark_groth16_prove writes (pi_a | pi_b | pi_c with their z coordinates).  The z coordinates are IGNORED,
+ *            as the reference's setG1Affine / setG2Affine do (src/bn128.js:741-760): (x, y) is the point.  Consequence: a proof
+ *            with a component at infinity -- printed (0, 1, 0); reachable only with r = s = 0 on degenerate witnesses -- is read
+ *            as the point (0, 1), which is not on the curve, and is therefore always INVALID here
  * Returns WSNARK_OK with *valid = 1 / 0; WSNARK_ERR_FORMAT if a coordinate is not a reduced field element,
  * WSNARK_ERR_SIZE if vk holds fewer than n_inputs + 1 IC points.  Unlike the reference, which makes no such test (its
  * verdict on malformed points is an accident of its Miller loop), a point that is not on its curve, or a G2 point outside
@@ -245,9 +258,14 @@ int wsnark_groth16_prove_finish(wsnark_pkey_t* handle, const void* partials, uin
  *                    the ones that read d_recv follow on it) -- enqueue it there, or synchronise it; return 0 on success
  *   all_gather(user, send, recv, bytes)        host memory: recv = the `bytes`-byte records of all ranks in rank order
  * handle: the rank's points shard with h_interleave_log = floor(log2(domain) / 2) (wsnark_pkey_load_shard); world must be a
- * power of two <= 2^floor(log2(domain) / 2).  world == 1: callbacks may be NULL (the exchange is the identity).  r32 / s32
- * NULL: rank 0 draws the blinding values and one more all_gather (64-byte records, before the GPU work, so that the host's
- * key-only scalar multiplications run under it) hands them to every rank -- every rank returns the same proof.
+ * power of two <= 2^floor(log2(domain) / 2).  world == 1: callbacks may be NULL (the exchange is the identity).
+ * Collectives per proof, posted by EVERY rank in the same order whatever happens on it: all_gather (80-byte records: the
+ * rank's preflight status, which of r / s it was given, the blinding bytes -- rank 0's draw when r32 / s32 are NULL -- before
+ * the GPU work, so that the host's key-only scalar multiplications run under it), three all_to_all, all_gather (592-byte
+ * records: the 576 bytes of partial sums + the rank's status).  EVERY RANK MUST PASS THE SAME r32 / s32 (all NULL, or the
+ * same bytes): ranks that disagree all return WSNARK_ERR_ARG.  A rank that fails locally still posts the exchanges its peers
+ * are waiting in and reports through the last gather: every rank then returns an error, nobody is left in a collective
+ * (what remains the transport's job: a callback that itself fails or hangs on one rank).
  * stream: the queue d_witness is ready on (NULL: the library's own). */
 typedef struct {
     uint32_t rank, world;

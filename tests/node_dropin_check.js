@@ -70,16 +70,31 @@ const toAB = (b) => b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength);
         const a3 = reuse.subarray(0, k3.length);
         await bn.groth16GenProof(wit, a3, { r: Buffer.from(c3.r, "hex"), s: Buffer.from(c3.s, "hex") });
         const hk = await bn.loadKey(a3);
+        const digestsBefore = bn.fullDigests;
         if ((await bn.loadKey(a3)) !== hk) throw new Error("unchanged key was reloaded");
-        a3[100] ^= 0xff;
+        if (bn.fullDigests !== digestsBefore) throw new Error("a cache hit took a whole-buffer digest (round 4: the sampled fingerprint only)");
+        if ((await bn.loadKey(a3, { trustCache: false })) !== hk || bn.fullDigests !== digestsBefore + 1) throw new Error("trustCache: false must digest the whole buffer and still hit");
+        // two concurrent first calls with one key object share ONE load (ADVICE r3: no second resident copy of the tables)
+        {
+            const fresh = new Uint8Array(k3);
+            const [h1, h2] = await Promise.all([bn.loadKey(fresh), bn.loadKey(fresh)]);
+            if (h1 !== h2) throw new Error("concurrent callers loaded the same key twice");
+        }
+        a3[100] ^= 0xff;                                   // (inside the header: the sampled fingerprint covers it)
         if ((await bn.loadKey(a3)) === hk) throw new Error("stale key handle returned for changed bytes");
+        // invalidateKey: the next call loads afresh even though nothing the fingerprint samples has changed
+        {
+            const before = await bn.loadKey(a3);
+            if (!bn.invalidateKey(a3) || (await bn.loadKey(a3)) === before) throw new Error("invalidateKey did not drop the cached handle");
+        }
         // ... wherever the byte is: the digest covers the whole buffer, not samples of it (VERDICT r2 item 8) -- every
         // offset of a stretch well past the header, one flip at a time, each must give a fresh handle
+        // (round 4: the whole-buffer digest is what a caller who rewrites bytes in place ASKS for -- {trustCache: false})
         let prev = await bn.loadKey(a3);
         for (const off of [489, 500, 510, 777, 1001, k3.length - 33, k3.length - 2, k3.length - 1]) {
             a3[off] ^= 0x01;
             let h2 = null;
-            try { h2 = await bn.loadKey(a3); } catch (e) { h2 = null; }        // (a flip inside a record count makes the key malformed: a fresh parse that fails has noticed, too)
+            try { h2 = await bn.loadKey(a3, { trustCache: false }); } catch (e) { h2 = null; }        // (a flip inside a record count makes the key malformed: a fresh parse that fails has noticed, too)
             if (h2 !== null && h2 === prev) throw new Error("stale key handle after a flip at offset " + off);
             if (h2 === null) a3[off] ^= 0x01; else prev = h2;
         }
@@ -109,6 +124,17 @@ const toAB = (b) => b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength);
             if ((await bn.groth16Verify(ref.verification_key, c.inputs, c.proof)) !== c.reference_verdict) throw new Error("verdict differs from the reference: " + c.label);
             checked++;
         }
+    }
+    // a witness written into a pinned input buffer (Bn128.allocInput) gives the same proof as the same bytes in a Buffer
+    {
+        const w6 = fs.readFileSync(path.join(gold, "keys", "t6.witness.bin")), k6 = fs.readFileSync(path.join(gold, "keys", "t6.pkey.bin"));
+        const c6 = proofs.t6[1];
+        const pinned = new Uint8Array(bn.allocInput(w6.length));
+        pinned.set(w6);
+        const timing = {};
+        const q = await bn.groth16GenProof(pinned, k6, { r: Buffer.from(c6.r, "hex"), s: Buffer.from(c6.s, "hex"), timing });
+        if (JSON.stringify(q) !== JSON.stringify(c6.proof)) throw new Error("proof from a pinned input buffer");
+        if (!(timing.prove_ms > 0) || !(timing.loadKey_ms >= 0) || !(timing.format_ms >= 0)) throw new Error("opts.timing was not filled");
     }
     // error path: rejected Promise, not a hang (the reference hangs: SURVEY section 5)
     let rejected = false;

@@ -39,6 +39,8 @@ def test_bench_single_gpu_line():
     assert cold["first_proof_matches_closed_form"] is True and cold["table_bytes"] > 0
     assert set(cold["key_load_ms"]) == {"pols_to_csr", "points_h2d", "masks_convert", "table_build", "total"}
     assert set(d["int_alu_peaks_this_run"]) >= {"modmul_G_per_s", "modmul_inlined_G_per_s", "mad_u64_u32_G_per_s"}   # (values need a GPU clock)
+    # round 4: the one-queue pass (the dominant kernel alone) ran, and the whole-proof issue roofline has its slot in the line
+    assert d["serialised_one_queue_ms_per_proof"] > 0 and "roofline_proof" in d
 
 
 def test_bench_two_ranks_line():
@@ -54,6 +56,7 @@ def test_bench_two_ranks_line():
     # the default N > 1 orchestration is the native one (points-sharded key, one C call per proof) and it did not fall through
     assert "wsnark_groth16_prove_dist" in d["config"]["parallelism"] and "fell through" not in d["config"]["parallelism"]
     assert d["shard"]["pairs_this_rank"] > 0 and d["shard"]["resident_table_bytes_this_rank"] > 0
+    assert "modmul_G_per_s" in d["int_alu_peaks_this_run"]          # the N > 1 line keeps the integer peak of its own run
 
 
 def test_bench_two_ranks_falls_through_when_an_orchestration_fails():

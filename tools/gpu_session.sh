@@ -19,13 +19,29 @@ if ! skip bench; then
   timeout 1500 python bench.py $BENCH_ARGS > "$O/bench.json" 2> "$O/bench.err"
   echo "bench rc=$?" >> "$O/env.log"
 fi
-# (proofs only: every msm_accumulate launch then has the shape bench.py's roofline is quoted on)
+# rocprofv3 --kernel-trace --stats of the bench command, PROOFS ONLY (no extras: every msm_accumulate launch then has the shape
+# bench.py's roofline is quoted on), twice: the shipped two-queue schedule (in situ), and WSNARK_PROVE_OVERLAP=0 (one queue: every
+# kernel alone -- where the profiler and the bench's HIP events must agree).  The bench line of each profiled run is kept beside
+# its summary (the events of THAT run are the ones to compare with its csv).
 PROF_CMD="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras"
 if ! skip prof; then
   ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$O/prof" -o prof -- $PROF_CMD ) > "$O/prof.log" 2>&1
   echo "rocprof rc=$?" >> "$O/env.log"
-  find "$O/prof" -name "*kernel_stats.csv" -exec cp {} "$O/kernel_stats.csv" \; 2>/dev/null
+  find "$O/prof" -name "*kernel_stats.csv" -exec cp {} "$O/kernel_stats_proofs_only.csv" \; 2>/dev/null
+  grep '^{"metric"' "$O/prof.log" > "$O/bench_under_rocprof.json"
   find "$O/prof" -name "*kernel_trace.csv" -size +8M -delete 2>/dev/null
+  ( cd /tmp && export TMPDIR=/tmp WSNARK_PROVE_OVERLAP=0 && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$O/prof_serial" -o prof -- $PROF_CMD ) > "$O/prof_serial.log" 2>&1
+  echo "rocprof serialised rc=$?" >> "$O/env.log"
+  find "$O/prof_serial" -name "*kernel_stats.csv" -exec cp {} "$O/kernel_stats_proofs_only_serialised.csv" \; 2>/dev/null
+  grep '^{"metric"' "$O/prof_serial.log" > "$O/bench_under_rocprof_serialised.json"
+  find "$O/prof_serial" -name "*kernel_trace.csv" -size +8M -delete 2>/dev/null
+fi
+# whole-proof instruction budget: SQ_INSTS_VALU over exactly P proofs between two marker launches (tools/proof_counters.py)
+if ! skip issue; then
+  ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/$O/issue/pmc_issue" -o pmc -- python "$GRAFT_REPO_ROOT/tools/proof_counters.py" 20 4 ) > "$O/issue.log" 2>&1
+  echo "pmc issue rc=$?" >> "$O/env.log"
+  python tools/pmc_proof_budget.py "$O/issue" 4 > "$O/proof_issue_budget.json" 2>> "$O/env.log"
+  find "$O/issue" -name "*.csv" -size +2M -delete 2>/dev/null
 fi
 # HBM traffic counters: separate --pmc passes, kernel-trace only (never combined with sys/hip/hsa traces)
 if ! skip pmc; then

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Proof from a HOST witness against the resident-witness call, one process, the staging settings swept through the library's
+A/B switches (wsnark_tuning_set): workers x chunk size, chunked histogram on / off, and a PINNED source (torch pinned tensor:
+DMA in place, no staging).  Prints one JSON line per setting.   python tools/upload_sweep.py [log_domain] [reps]"""
+import json
+import os
+import sys
+import time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import wasmsnark_amd
+from wasmsnark_amd import synth
+logd = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+bn = wasmsnark_amd.build(device=0)
+circ = synth.NativeCircuit(bn.lib, logd, n_public=5, seed=1)
+sec, _ = circ.build_sections()
+key = bn.load_key(sections=sec)
+wit = circ.witness_bin()
+r, s = bytes(range(32)), bytes(range(32, 64))
+want = circ.expected_proof(r, s)
+d_w = torch.frombuffer(bytearray(wit), dtype=torch.uint8).cuda()
+pinned = torch.frombuffer(bytearray(wit), dtype=torch.uint8).pin_memory()
+torch.cuda.synchronize()
+
+
+def t(f, n=reps):
+    for _ in range(3):
+        out = f()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n):
+        out = f()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3, out
+
+
+dev = lambda: bn.groth16GenProof_dev(d_w.data_ptr(), len(wit), key, r=r, s=s)
+host = lambda: bn.groth16GenProof(wit, key, r=r, s=s)
+pin = lambda: bn.groth16GenProof_hostptr(pinned.data_ptr(), len(wit), key, r=r, s=s)
+base, p = t(dev)
+print(json.dumps({"setting": "resident witness", "ms": round(base, 3), "ok": p == want}), flush=True)
+for chunked in (1, 0):
+    for workers in (0, 4, 8, 12, 16, 24):
+        for chunk_kb in (4096, 2048, 8192):
+            if workers == 0 and chunk_kb != 4096:
+                continue
+            bn.lib.tune("PROVE_CHUNKED_UPLOAD", chunked); bn.lib.tune("STAGE_WORKERS", workers); bn.lib.tune("STAGE_CHUNK_KB", chunk_kb)
+            ms, p = t(host)
+            print(json.dumps({"setting": {"chunked_histogram": chunked, "workers": workers or "default", "chunk_kb": chunk_kb}, "host_witness_ms": round(ms, 3),
+                              "over_resident_ms": round(ms - base, 3), "ok": p == want}), flush=True)
+for name in ("PROVE_CHUNKED_UPLOAD", "STAGE_WORKERS", "STAGE_CHUNK_KB"):
+    bn.lib.tune(name, None)
+ms, p = t(pin)
+print(json.dumps({"setting": "pinned source (torch pin_memory), DMA in place", "host_witness_ms": round(ms, 3), "over_resident_ms": round(ms - base, 3), "ok": p == want}), flush=True)
+base2, _ = t(dev)
+print(json.dumps({"setting": "resident witness (again)", "ms": round(base2, 3)}), flush=True)

@@ -27,7 +27,7 @@ SYMBOLS = [
     "wsnark_synth_new", "wsnark_synth_free", "wsnark_synth_info", "wsnark_synth_witness", "wsnark_synth_pols",
     "wsnark_synth_key_scalars", "wsnark_synth_expected",
     "wsnark_selftest_field", "wsnark_selftest_curve",
-    "wsnark_timing_enable", "wsnark_timing_reset", "wsnark_timing_report", "wsnark_peak_probe", "wsnark_tuning_set",
+    "wsnark_timing_enable", "wsnark_timing_reset", "wsnark_timing_report", "wsnark_peak_probe", "wsnark_tuning_set", "wsnark_host_alloc", "wsnark_host_free",
 ]
 
 
@@ -93,6 +93,9 @@ class Lib:
         c.wsnark_pkey_shard_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
         c.wsnark_peak_probe.argtypes = [C.c_int, C.POINTER(C.c_double)]
         c.wsnark_tuning_set.argtypes = [C.c_char_p, C.c_int64]
+        c.wsnark_host_alloc.argtypes = [sz, C.POINTER(vp)]
+        c.wsnark_host_free.argtypes = [vp]
+        c.wsnark_host_free.restype = None
         c.wsnark_pkey_load_stats.argtypes = [vp, C.POINTER(C.c_double)]
         c.wsnark_pkey_h_msm_dev.argtypes = [vp, vp, u64, vp, vp]
         c.wsnark_groth16_prove_partial.argtypes = [vp, vp, sz, u32, u32, u32, vp]

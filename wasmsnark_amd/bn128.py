@@ -275,6 +275,15 @@ class Bn128:
             key.free()
         return proof_from_bytes(bytes(out))
 
+    def groth16GenProof_hostptr(self, h_witness, witness_len, key, r=None, s=None):
+        """The same call with the witness given as a raw HOST address (e.g. a pinned torch tensor's data_ptr(): a source the
+        runtime already knows as pinned is DMA'd in place, chunk by chunk, without the staging copy)."""
+        out = (C.c_uint8 * 384)()
+        rb = _ro(r)[0] if r is not None else None
+        sb = _ro(s)[0] if s is not None else None
+        self.lib.check(self.lib.c.wsnark_groth16_prove(key._h, C.c_void_p(h_witness), witness_len, rb, sb, out))
+        return proof_from_bytes(bytes(out))
+
     # --- src/bn128.js:722-791 ---
     def groth16Verify(self, verificationKey, input, proof):
         """verificationKey: the snarkjs "groth" verification_key.json object (vk_alfa_1, vk_beta_2, vk_gamma_2, vk_delta_2,

@@ -371,6 +371,20 @@ int wsnark_peak_probe(int probe, double* gops_per_s) {
     return peak_probe(probe, gops_per_s);
 }
 
+// ---- pinned host buffers ----
+int wsnark_host_alloc(size_t bytes, void** out) {
+    REQUIRE_CTX();
+    if (!out) return WSNARK_ERR_ARG;
+    *out = nullptr;
+    WS_HIP_CHECK(hipHostMalloc(out, bytes ? bytes : 16, 0));
+    return WSNARK_OK;
+}
+void wsnark_host_free(void* p) {
+    if (!p) return;
+    if (Context* C = ctx()) (void)hipSetDevice(C->device);
+    (void)hipHostFree(p);
+}
+
 // ---- measurement switches ----
 int wsnark_tuning_set(const char* name, int64_t value) {
     if (!name || !*name) return WSNARK_ERR_ARG;

@@ -31,7 +31,10 @@
 #include <chrono>
 
 #include "internal.h"
-#ifndef WSNARK_EMUL
+// The first version of the grouping pass (explicit digit arrays + hipCUB radix sort) is an A/B path only: builds with
+// -DWSNARK_WITH_CUB (make HIPFLAGS+=-DWSNARK_WITH_CUB) carry it, selected by WSNARK_MSM_SORT=cub; the default build does not
+// link the 20-odd rocPRIM kernels it brings into the code object.
+#if defined(WSNARK_WITH_CUB) && !defined(WSNARK_EMUL)
 #include <hipcub/hipcub.hpp>
 #endif
 
@@ -832,6 +835,10 @@ static int sort_pairs(MsmScratch& S, uint64_t total, int end_bit, hipStream_t s)
     uint32_t* ko = S.keys_out.as<uint32_t>(); uint32_t* vo = S.vals_out.as<uint32_t>();
     for (uint64_t i = 0; i < total; i++) { ko[i] = kv[i].first; vo[i] = kv[i].second; }
     return WS_OK;
+#elif !defined(WSNARK_WITH_CUB)
+    (void)S; (void)total; (void)end_bit; (void)s;
+    set_last_error("WSNARK_MSM_SORT=cub: this library was built without hipCUB (rebuild with -DWSNARK_WITH_CUB for the A/B path)");
+    return WS_ERR_ARG;
 #else
     size_t tmp_bytes = 0;
     WS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, S.keys.as<uint32_t>(), S.keys_out.as<uint32_t>(),
@@ -1143,6 +1150,9 @@ int msm_plan_begin(Lane& L, uint64_t n, WindowShard sh, hipStream_t s, uint32_t 
     // (the coarse-bin counts of the grouping pass follow at [1024 ..]: one memset clears both)
     uint32_t* d_cnt = S.counters.as<uint32_t>();
     const bool use_cub = [] { const char* e = getenv("WSNARK_MSM_SORT"); return e && !strcmp(e, "cub"); }();
+#if !defined(WSNARK_WITH_CUB) && !defined(WSNARK_EMUL)
+    if (use_cub) { set_last_error("WSNARK_MSM_SORT=cub: this library was built without hipCUB (rebuild with -DWSNARK_WITH_CUB for the A/B path)"); return WS_ERR_ARG; }
+#endif
     const uint32_t env_lo = [] { const char* e = getenv("WSNARK_MSM_LO_BITS"); return e ? (uint32_t)atoi(e) : 8u; }();
     const uint32_t env_tile = [] { const char* e = getenv("WSNARK_MSM_TILE"); return e ? (uint32_t)atoi(e) : 1024u; }();
     const uint32_t env_thr = [] { const char* e = getenv("WSNARK_MSM_TILE_THREADS"); return e ? (uint32_t)atoi(e) : 1024u; }();

@@ -24,12 +24,31 @@ function proofFromBytes(ab) {       // bin2g1 / bin2g2, src/bn128.js:329-351, 71
     return { pi_a: [v[0], v[1], v[2]], pi_b: [[v[3], v[4]], [v[5], v[6]], [v[7], v[8]]], pi_c: [v[9], v[10], v[11]] };
 }
 
-/* digest of a key buffer -- ALL of its bytes (addon.hashBytes, off the event loop; < 0.1 s for a 0.6 GB key): enough to
- * notice that a cached handle no longer describes the bytes the caller is holding, wherever they were rewritten.  The
- * reference re-parses pkey inside every call (src/bn128.js:581-604); a caller that wants no per-call pass over the key at
- * all holds the handle of loadKey() and passes that instead of the bytes. */
+/* Two checks that a cached key handle still describes the bytes the caller is holding.
+ *   fingerprint(u8): synchronous, a few KiB -- the 488-byte header + fixed points, 64 samples of 32 bytes spread over the buffer and
+ *                    its tail.  Run on EVERY cache hit: it catches a buffer that was refilled with another key.
+ *   digest(u8):      ALL of the bytes (addon.hashBytes, off the event loop; tens of ms for a 0.6 GB key -- several proofs' worth).
+ *                    Run when the key is first seen (beside the load) and, after that, only when the caller asks:
+ *                    {trustCache: false}, or invalidateKey(pkey) after rewriting bytes in place.
+ * The reference re-parses pkey inside every call (src/bn128.js:581-604), so for IT a caller may patch a few bytes of a key between
+ * two proofs and be served; here such a caller has to say so.  A caller that wants no check at all holds the handle of loadKey(). */
 async function digest(u8) {
     return Buffer.from(await addon.hashBytes(u8)).toString("hex");
+}
+function fingerprint(u8) {
+    const n = u8.byteLength, parts = [];
+    const take = (off, len) => { if (off < n) parts.push(Buffer.from(u8.buffer, u8.byteOffset + off, Math.min(len, n - off))); };
+    take(0, 488);
+    const step = Math.max(32, Math.floor(n / 64 / 32) * 32);
+    for (let k = 1; k <= 64; k++) take(k * step - 32, 32);
+    take(Math.max(0, n - 64), 64);
+    let h = 0xcbf29ce484222325n;                    // FNV-1a over the sampled bytes, 8 at a time
+    for (const b of parts) {
+        let i = 0;
+        for (; i + 8 <= b.length; i += 8) h = ((h ^ b.readBigUInt64LE(i)) * 0x100000001b3n) & 0xffffffffffffffffn;
+        for (; i < b.length; i++) h = ((h ^ BigInt(b[i])) * 0x100000001b3n) & 0xffffffffffffffffn;
+    }
+    return h.toString(16) + ":" + n;
 }
 function asBytes(x) {
     if (x instanceof ArrayBuffer) return new Uint8Array(x);
@@ -40,12 +59,13 @@ function asBytes(x) {
 class Bn128 {
     constructor(deviceInfo) {
         this.deviceInfo = deviceInfo;
-        // proving-key OBJECT (the exact ArrayBuffer / view the caller passed) -> {handle, byteOffset, byteLength, fp}.
-        // Two views of one ArrayBuffer (sub-arrays of a bundle, Node's pooled small Buffers) are different keys here,
-        // and a cached handle is only reused while offset, length and the digest of the WHOLE buffer still match; the
-        // reference re-reads pkey on every call (src/bn128.js:581-604) -- callers that want no check at all hold the
-        // handle of loadKey().
+        // proving-key OBJECT (the exact ArrayBuffer / view the caller passed) -> {handle (a Promise), byteOffset, byteLength,
+        // fp (sampled fingerprint), digest (Promise of the whole-buffer digest taken at load time)}.
+        // Two views of one ArrayBuffer (sub-arrays of a bundle, Node's pooled small Buffers) are different keys here.
+        // A cached handle is reused while offset, length and the sampled fingerprint still match -- and, for callers that
+        // ask ({trustCache: false}), the digest of the WHOLE buffer; see fingerprint() / digest() above.
         this._keys = new WeakMap();
+        this.fullDigests = 0;   // how many whole-buffer digests this object has computed (tests, tools/node_bench.js)
         this._pr = null;     // blinding values of the last proof, "for tests" like the reference (src/bn128.js:662-664)
         this._ps = null;
         this._live = true;
@@ -55,25 +75,51 @@ class Bn128 {
     calcH(signals, polsA, polsB, nSignals, domainSize) { return addon.calcH(signals, polsA, polsB, nSignals, domainSize); }
     fft(buf, odd) { return addon.fft(buf, odd | 0, false); }
     ifft(buf, odd) { return addon.fft(buf, odd | 0, true); }
-    /* pkey bytes -> device-resident key handle (stays in HBM across proofs; freed by the GC) */
-    async loadKey(pkey) {
+    /* pkey bytes -> device-resident key handle (stays in HBM across proofs; freed by the GC).
+     * opts.trustCache === false: compare the digest of ALL bytes with the one taken when the key was loaded (default: the sampled
+     * fingerprint only).  Concurrent callers with the same key object share ONE load: the entry is in the map before it is awaited. */
+    async loadKey(pkey, opts) {
         if (pkey !== null && typeof pkey === "object" && !(pkey instanceof ArrayBuffer) && !ArrayBuffer.isView(pkey)) return pkey;   // already a handle
         const u8 = asBytes(pkey);
-        const fp = await digest(u8);
         const hit = this._keys.get(pkey);
-        if (hit && hit.byteOffset === u8.byteOffset && hit.byteLength === u8.byteLength && hit.fp === fp) return hit.handle;
-        const handle = await addon.loadKey(pkey);
-        this._keys.set(pkey, { handle, byteOffset: u8.byteOffset, byteLength: u8.byteLength, fp });
-        return handle;
+        if (hit && hit.byteOffset === u8.byteOffset && hit.byteLength === u8.byteLength && hit.fp === fingerprint(u8)) {
+            if (!(opts && opts.trustCache === false)) return hit.handle;                 // (a Promise: resolved, or the load in flight)
+            this.fullDigests++;
+            if ((await hit.digest) === (await digest(u8))) return hit.handle;
+        }
+        const entry = { byteOffset: u8.byteOffset, byteLength: u8.byteLength, fp: fingerprint(u8), handle: addon.loadKey(pkey), digest: digest(u8) };
+        this.fullDigests++;
+        this._keys.set(pkey, entry);
+        entry.digest.catch(() => {});
+        try {
+            return await entry.handle;
+        } catch (e) {
+            if (this._keys.get(pkey) === entry) this._keys.delete(pkey);                // a key that failed to parse is not cached
+            throw e;
+        }
     }
+    /* forget the cached handle of a key object (its bytes were rewritten in place, or its HBM should go back) */
+    invalidateKey(pkey) { return this._keys.delete(pkey); }
+    /* an ArrayBuffer of `bytes` bytes in PINNED host memory: a witness written into it is DMA'd to the GPU in place, chunk by
+     * chunk, instead of being copied through the library's staging ring first (no counterpart in the reference) */
+    allocInput(bytes) { return addon.allocPinned(bytes); }
     /* pkey: proving_key.bin bytes, or a handle from loadKey().
-     * opts.r / opts.s: optional 32-byte blinding values (the reference draws them from crypto.randomBytes) */
+     * opts.r / opts.s: optional 32-byte blinding values (the reference draws them from crypto.randomBytes)
+     * opts.trustCache: see loadKey.  opts.timing: an object that receives {loadKey_ms, prove_ms, format_ms} of this call */
     async groth16GenProof(signals, pkey, opts) {
-        const h = await this.loadKey(pkey);
+        const t0 = process.hrtime.bigint();
+        const h = await this.loadKey(pkey, opts);
+        const t1 = process.hrtime.bigint();
         const out = await addon.prove(h, signals, opts && opts.r ? opts.r : null, opts && opts.s ? opts.s : null);
+        const t2 = process.hrtime.bigint();
         this._pr = new Uint8Array(out.slice(384, 416));
         this._ps = new Uint8Array(out.slice(416, 448));
-        return proofFromBytes(out.slice(0, 384));
+        const proof = proofFromBytes(out.slice(0, 384));
+        if (opts && opts.timing) {
+            const ms = (a, b) => Number(b - a) / 1e6;
+            Object.assign(opts.timing, { loadKey_ms: ms(t0, t1), prove_ms: ms(t1, t2), format_ms: ms(t2, process.hrtime.bigint()) });
+        }
+        return proof;
     }
     /* src/bn128.js:722-791: verificationKey = snarkjs "groth" verification_key.json object, input = public signals
      * (one value is wrapped like the reference does), proof = {pi_a, pi_b, pi_c}.  Native host arithmetic, no GPU. */
@@ -113,6 +159,12 @@ async function buildBn128(device, opts) {
     liveInstances++;
     return new Bn128(info);
 }
+/* The module-level calls share one Bn128 object that is never terminated on its own, exactly like the reference's
+ * (main_bn128.js:26-39 builds its singleton and leaves the workers running; src/bn128.js:562-566 needs an explicit call): a
+ * process that only uses these forms ends with terminate() below (the reference has no such export), or process.exit(). */
+function terminate() {
+    if (singleton) { singleton.terminate(); singleton = null; }
+}
 function groth16GenProof(witness, provingKey, cb) {   // main_bn128.js:26-39
     const p = (async () => {
         if (!singleton) singleton = await buildBn128();
@@ -132,5 +184,5 @@ function groth16Verify(verificationKey, input, proof, cb) {   // main_bn128.js:4
 }
 
 const formats = require("./formats.js");     // snarkjs JSON -> proving_key.bin / witness.bin (reference tools/build*.js)
-module.exports = { buildBn128, groth16GenProof, genZKSnarkProof: groth16GenProof, groth16Verify, Bn128, proofFromBytes,
+module.exports = { buildBn128, groth16GenProof, genZKSnarkProof: groth16GenProof, groth16Verify, terminate, Bn128, proofFromBytes,
     pkeyJsonToBin: formats.pkeyJsonToBin, witnessJsonToBin: formats.witnessJsonToBin };

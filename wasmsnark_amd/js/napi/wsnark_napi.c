@@ -36,6 +36,8 @@ static struct {
     int (*prove)(wsnark_pkey_t*, const void*, size_t, const void*, const void*, void*);
     int (*last_blinding)(void*, void*);
     int (*verify)(const void*, size_t, const void*, uint64_t, const void*, int*);
+    int (*host_alloc)(size_t, void**);
+    void (*host_free)(void*);
     char dir[4096];
 } L;
 
@@ -62,6 +64,7 @@ static int load_lib(const char* explicit_path, char* err, size_t errlen) {
     SYM(fr_ntt, "wsnark_fr_ntt") SYM(calc_h, "wsnark_calc_h") SYM(pkey_load, "wsnark_pkey_load")
     SYM(pkey_free, "wsnark_pkey_free") SYM(pkey_info, "wsnark_pkey_info") SYM(prove, "wsnark_groth16_prove")
     SYM(last_blinding, "wsnark_last_blinding") SYM(verify, "wsnark_groth16_verify")
+    SYM(host_alloc, "wsnark_host_alloc") SYM(host_free, "wsnark_host_free")
 #undef SYM
     return 0;
 }
@@ -294,6 +297,34 @@ static napi_value js_verify(napi_env env, napi_callback_info info) {
     return start_job(env, j, "wsnark_groth16_verify");
 }
 
+/* allocPinned(bytes) -> ArrayBuffer over pinned host memory (wsnark_host_alloc): a witness written into it is DMA'd in place,
+ * without the staging copy.  Freed by the GC finalizer. */
+static void pinned_finalize(napi_env env, void* data, void* hint) {
+    (void)env; (void)hint;
+    if (data && L.host_free) L.host_free(data);
+}
+static napi_value js_alloc_pinned(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1], ab;
+    double nbytes = 0;
+    void* p = NULL;
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (!L.h) { napi_throw_error(env, NULL, "wsnark_napi: init() has not been called (use buildBn128())"); return NULL; }
+    if (argc < 1 || napi_get_value_double(env, argv[0], &nbytes) != napi_ok || nbytes < 0 || nbytes > 1e12) { napi_throw_type_error(env, NULL, "expected a byte count"); return NULL; }
+    int rc = L.host_alloc((size_t)nbytes, &p);
+    if (rc || !p) {
+        char msg[600];
+        snprintf(msg, sizeof msg, "wsnark_host_alloc failed (%d): %s", rc, L.last_error());
+        napi_throw_error(env, NULL, msg);
+        return NULL;
+    }
+    if (napi_create_external_arraybuffer(env, p, (size_t)nbytes, pinned_finalize, NULL, &ab) != napi_ok) {
+        L.host_free(p);
+        napi_throw_error(env, NULL, "wsnark_napi: cannot wrap the pinned buffer");
+        return NULL;
+    }
+    return ab;
+}
+
 static napi_value js_keyinfo(napi_env env, napi_callback_info info) {
     size_t argc = 1; napi_value argv[1], o, v;
     wsnark_pkey_t* k = NULL;
@@ -352,6 +383,7 @@ static napi_value module_init(napi_env env, napi_value exports) {
         {"loadKey", NULL, js_loadkey, NULL, NULL, NULL, napi_default, NULL},
         {"hashBytes", NULL, js_hash, NULL, NULL, NULL, napi_default, NULL},
         {"keyInfo", NULL, js_keyinfo, NULL, NULL, NULL, napi_default, NULL},
+        {"allocPinned", NULL, js_alloc_pinned, NULL, NULL, NULL, napi_default, NULL},
         {"prove", NULL, js_prove, NULL, NULL, NULL, napi_default, NULL},
         {"verify", NULL, js_verify, NULL, NULL, NULL, napi_default, NULL},
     };
