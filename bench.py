@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--extras", default="msm,ntt,cold,inflight,sparse", help="comma list (N=1 only): msm, ntt, cold, inflight, sparse")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alone-pass", action="store_true",
+                    help="skip the one-queue proofs that time the dominant kernel alone (the in-situ rocprofv3 pass of tools/gpu_session.sh: "
+                         "its kernel summary must hold two-queue launches only)")
     ap.add_argument("--shard", choices=["points", "windows"], default="points", help="--workload msm, N>1")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="N>1 transport: nccl (= RCCL over xGMI; one GPU per rank) or gloo with host staging -- the latter lets "
@@ -390,7 +393,7 @@ def bench_prove(ctx):
     # the dominant kernel ALONE, and a proof with nothing overlapped: a few more proofs on ONE queue (WSNARK_PROVE_OVERLAP=0 through the
     # library's A/B switch), HIP events around the accumulations only.  (single GPU: the N > 1 modes bring their own schedule)
     alone_ms = serial_ms = None
-    if world == 1:
+    if world == 1 and not args.no_alone_pass:
         bn.lib.tune("PROVE_OVERLAP", 0)
         try:
             for _ in range(2):

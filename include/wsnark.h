@@ -335,7 +335,8 @@ enum {
 };
 int wsnark_selftest_field(int which, int impl, int op, const void* a, const void* b, void* out, uint64_t n);
 /*   g: 1 or 2; impl: 0 = radix-2^29 curve of the accumulation kernels, 1 = saturated-field curve on the device,
- *   2 = host curve, 3 = (G1 only) the radix-2^29 variant of the reduction-tail kernels (inlined products).
+ *   2 = host curve, 3 = (G1 only) the radix-2^29 variant of the reduction-tail kernels (inlined products), 4 = (G2 only) the
+ *   reduction-tail variant with the quadratic extension's two components on two adjacent lanes (two lanes per vector).
  *   p, q: n Jacobian-Montgomery points (96 / 192 B, any z; z == 0 = infinity); out: n affine-normalised
  *   Jacobian-Montgomery points ((x, y, 1) or (0, 1, 0)) like every group element this ABI returns.
  *   op: 0 = p + q (full addition), 1 = 2p, 2 = -p, 3 = p (normalisation only), 4 = p + q as a MIXED addition

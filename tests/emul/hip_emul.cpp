@@ -22,6 +22,8 @@ struct Thr {
     bool at_shfl = false;
     uint32_t shfl_val = 0;
     int shfl_src = 0;
+    bool at_pair = false;      // waiting in pair_exchange for lane ^ 1
+    uint32_t pair_val = 0;
 };
 
 thread_local std::vector<Thr>* g_thr = nullptr;
@@ -60,6 +62,16 @@ uint32_t shfl_exchange(uint32_t v, int src_lane, int /*width*/) {
     return me.shfl_val;
 }
 
+// exchange with lane ^ 1 only (a DPP quad_perm swap on the device): unlike the wave shuffles above it may be called from code
+// that only SOME lane pairs of the wave execute -- both lanes of a pair always take the same branch
+uint32_t pair_exchange(uint32_t v) {
+    Thr& me = (*g_thr)[g_cur];
+    me.pair_val = v;
+    me.at_pair = true;
+    swapcontext(&me.uc, &g_sched);   // the scheduler resumes us once the partner has posted
+    return me.pair_val;
+}
+
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
     // __shared__ arrays are process-wide statics here: kernels of different host threads (two lanes) take turns
     static std::mutex one_kernel_at_a_time;
@@ -78,7 +90,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
         t_blockIdx.x = bx; t_blockIdx.y = by; t_blockIdx.z = bz;
         for (int t = 0; t < nthr; t++) {
             Thr& T = thr[(size_t)t];
-            T.done = false; T.at_barrier = false; T.at_shfl = false;
+            T.done = false; T.at_barrier = false; T.at_shfl = false; T.at_pair = false;
             getcontext(&T.uc);
             T.stack = g_stack_pool[(size_t)t];
             T.uc.uc_stack.ss_sp = T.stack;
@@ -91,20 +103,30 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
             // run every runnable thread until it finishes or blocks
             for (int t = 0; t < nthr; t++) {
                 Thr& T = thr[(size_t)t];
-                if (T.done || T.at_barrier || T.at_shfl) continue;
+                if (T.done || T.at_barrier || T.at_shfl || T.at_pair) continue;
                 g_cur = t;
                 set_ids(t, block);
                 swapcontext(&g_sched, &T.uc);
                 if (T.done) live--;
             }
-            // resolve wave shuffles: a wave proceeds when all its live lanes posted
             bool progressed = false;
+            // resolve pair exchanges: lanes 2k and 2k + 1 swap once both have posted
+            for (int t = 0; t + 1 < nthr; t += 2) {
+                Thr &A = thr[(size_t)t], &B = thr[(size_t)t + 1];
+                if (A.at_pair && B.at_pair) {
+                    const uint32_t x = A.pair_val;
+                    A.pair_val = B.pair_val; B.pair_val = x;
+                    A.at_pair = B.at_pair = false;
+                    progressed = true;
+                }
+            }
+            // resolve wave shuffles: a wave proceeds when all its live lanes posted
             for (int w0 = 0; w0 < nthr; w0 += 64) {
                 int w1 = w0 + 64 < nthr ? w0 + 64 : nthr;
                 bool any = false, all = true;
                 for (int t = w0; t < w1; t++) {
                     if (thr[(size_t)t].done) continue;
-                    if (thr[(size_t)t].at_shfl) any = true; else all = false;
+                    if (thr[(size_t)t].at_shfl) any = true; else all = false;      // (a lane waiting for its pair partner has not posted either)
                 }
                 if (any && all) {
                     uint32_t vals[64];
@@ -126,7 +148,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
             if (all_bar) for (int t = 0; t < nthr; t++) thr[(size_t)t].at_barrier = false;
             else if (live > 0) {
                 bool runnable = false;
-                for (int t = 0; t < nthr; t++) if (!thr[(size_t)t].done && !thr[(size_t)t].at_barrier && !thr[(size_t)t].at_shfl) runnable = true;
+                for (int t = 0; t < nthr; t++) if (!thr[(size_t)t].done && !thr[(size_t)t].at_barrier && !thr[(size_t)t].at_shfl && !thr[(size_t)t].at_pair) runnable = true;
                 if (!runnable) abort();   // deadlock: divergent barrier / partial-wave shuffle
             }
         }

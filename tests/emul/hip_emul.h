@@ -35,6 +35,7 @@ extern thread_local dim3 t_blockDim, t_gridDim;
 void* dyn_smem();
 void sync_threads();
 uint32_t shfl_exchange(uint32_t v, int src_lane, int width);
+uint32_t pair_exchange(uint32_t v);
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
 }  // namespace hip_emul
 

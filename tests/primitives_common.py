@@ -13,7 +13,7 @@ H = bytes.fromhex
 
 MUL, SQR, ADD, SUB, NEG, TOMONT, FROMMONT, SUB_WEAK, ADD_LAZY_MUL, NEG_WEAK_MUL, MUL2ADD, MULSUB2, EQ, EQ_WEAK, INVERSE, SQR_WEAK, MUL_WEAK_A, MULSUB2_WEAK_B = range(18)
 FIELD_IMPLS = {0: "radix-2^29 device field", 1: "saturated device field", 2: "host field"}
-CURVE_IMPLS = {1: (0, 1, 2, 3), 2: (0, 1, 2)}
+CURVE_IMPLS = {1: (0, 1, 2, 3), 2: (0, 1, 2, 4)}    # 3: G1 tail variant (inlined products); 4: G2 on lane pairs (reduction-tail kernels)
 
 
 def st_field(bn, which, impl, op, a_list, b_list):

@@ -293,3 +293,41 @@ def test_staging_ring_and_chunked_witness_upload(orc):
     finally:
         for name in ("STAGE_FORCE_RING", "STAGE_RING_KB", "STAGE_CHUNK_KB", "STAGE_WORKERS", "PROVE_CHUNKED_UPLOAD"):
             tune(name, None)
+
+
+def test_reduction_tail_geometries_and_paired_g2(orc):
+    """Round 4: the reduction tail's geometry is chosen by size (chunks of 4 / 8 buckets, pieces of 2^11 / 2^15 buckets whose rows
+    are folded on the GPU by msm_rows) and the G2 tail runs with the extension's components on lane pairs.  None of it may move a
+    bit: stand-alone sums (per-window plans, windows cut into pieces) against the oracle, whole proofs (table plans: ONE bucket set
+    cut into pieces) against the closed form, every combination of chunk size, piece size, host- / GPU-folded rows, paired / plain G2."""
+    import itertools
+    import random
+    bn = emul_bn128()
+    tune = bn.lib.tune
+    names = ("MSM_CHUNK", "TAIL_BITS", "TAIL_BITS_W", "TAIL_REDUCE", "G2_TAIL_PAIR")
+    try:
+        rnd = random.Random(5)
+        for g, n in ((1, 1500), (2, 400)):
+            ks = b"".join(rnd.randrange(1, orc.R).to_bytes(32, "little") for _ in range(n))
+            pts = bn.mul_base(g, ks)
+            sc = b"".join((rnd.randrange(orc.R) if i % 7 else i % 3).to_bytes(32, "little") for i in range(n))
+            want = orc.g_affine(g, orc.multiexp(g, "multiexp2" if g == 1 else "multiexp", sc, pts, n))
+            msm = bn.g1_multiexp if g == 1 else bn.g2_multiexp
+            for chunk, bits_w, pair in itertools.product((2, 4, 8), (None, 3, 4), (1, 0)):
+                tune("MSM_CHUNK", chunk); tune("TAIL_BITS_W", bits_w); tune("G2_TAIL_PAIR", pair)
+                assert msm(sc, pts) == want, (g, chunk, bits_w, pair)
+        for name in names:
+            tune(name, None)
+        circ = synth.NativeCircuit(bn.lib, 10, n_public=3, seed=8, style="columns")
+        sec, _ = circ.build_sections()
+        wit = circ.witness_bin()
+        r, s = bytes(range(9, 41)), bytes(range(60, 92))
+        want = circ.expected_proof(r, s)
+        key = bn.load_key(sections=sec)
+        assert key.table["rows_w"] > 1                      # table plans: one bucket set of 2^(c-1) buckets per sum
+        for chunk, bits, red, pair in itertools.product((2, 4, 8), (None, 4, 6), (1, 0), (1, 0)):
+            tune("MSM_CHUNK", chunk); tune("TAIL_BITS", bits); tune("TAIL_REDUCE", red); tune("G2_TAIL_PAIR", pair)
+            assert bn.groth16GenProof(wit, key, r=r, s=s) == want, (chunk, bits, red, pair)
+    finally:
+        for name in names:
+            tune(name, None)

@@ -25,7 +25,7 @@ fi
 # its summary (the events of THAT run are the ones to compare with its csv).
 PROF_CMD="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras"
 if ! skip prof; then
-  ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$O/prof" -o prof -- $PROF_CMD ) > "$O/prof.log" 2>&1
+  ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$O/prof" -o prof -- $PROF_CMD --no-alone-pass ) > "$O/prof.log" 2>&1
   echo "rocprof rc=$?" >> "$O/env.log"
   find "$O/prof" -name "*kernel_stats.csv" -exec cp {} "$O/kernel_stats_proofs_only.csv" \; 2>/dev/null
   grep '^{"metric"' "$O/prof.log" > "$O/bench_under_rocprof.json"

@@ -44,7 +44,7 @@ def main():
         name = dm.get(r["name"], r["name"])
         name = re.sub(r"\(.*$", "", name).replace("wsnark::", "").replace("void ", "")
         name = name.replace("Curve<Fp2T<Field29<Fq29Params> > >", "G2R29").replace("Curve<Field29I<Fq29Params> >", "G1R29I").replace("Curve<Field29<Fq29Params> >", "G1R29")
-        name = name.replace("Curve<Fp2T<Field<FqParams> > >", "G2").replace("Curve<Field<FqParams> >", "G1").replace("Field29<Fr29Params>", "Fr29").replace("Field<FrParams>", "Fr")
+        name = name.replace("Curve<Fp2PairT<Field29<Fq29Params> > >", "G2P29").replace("Curve<Fp2T<Field<FqParams> > >", "G2").replace("Curve<Field<FqParams> >", "G1").replace("Field29<Fr29Params>", "Fr29").replace("Field<FrParams>", "Fr")
         print("| %s | `%s` | " % (r["src"], name) + " | ".join(r.get(k, "?") for k in KEYS) + " |")
 
 

@@ -39,18 +39,46 @@ host = lambda: bn.groth16GenProof(wit, key, r=r, s=s)
 pin = lambda: bn.groth16GenProof_hostptr(pinned.data_ptr(), len(wit), key, r=r, s=s)
 base, p = t(dev)
 print(json.dumps({"setting": "resident witness", "ms": round(base, 3), "ok": p == want}), flush=True)
-for chunked in (1, 0):
-    for workers in (0, 4, 8, 12, 16, 24):
-        for chunk_kb in (4096, 2048, 8192):
-            if workers == 0 and chunk_kb != 4096:
-                continue
-            bn.lib.tune("PROVE_CHUNKED_UPLOAD", chunked); bn.lib.tune("STAGE_WORKERS", workers); bn.lib.tune("STAGE_CHUNK_KB", chunk_kb)
-            ms, p = t(host)
-            print(json.dumps({"setting": {"chunked_histogram": chunked, "workers": workers or "default", "chunk_kb": chunk_kb}, "host_witness_ms": round(ms, 3),
-                              "over_resident_ms": round(ms - base, 3), "ok": p == want}), flush=True)
+# the transfer itself: 32 MiB from pinned memory with nothing else on the GPU -- one copy on one queue, and halves on two queues
+s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+dst = torch.empty_like(d_w)
+half = pinned.numel() // 2
+
+
+def copy_one():
+    with torch.cuda.stream(s1):
+        dst.copy_(pinned, non_blocking=True)
+    s1.synchronize()
+
+
+def copy_two():
+    with torch.cuda.stream(s1):
+        dst[:half].copy_(pinned[:half], non_blocking=True)
+    with torch.cuda.stream(s2):
+        dst[half:].copy_(pinned[half:], non_blocking=True)
+    s1.synchronize(); s2.synchronize()
+
+
+for name, f in (("one DMA, one queue", copy_one), ("two halves on two queues", copy_two)):
+    ms, _ = t(f)
+    print(json.dumps({"setting": "raw H2D of the %d-byte witness from pinned memory, %s" % (len(wit), name), "ms": round(ms, 3), "GBps": round(len(wit) / ms / 1e6, 1)}), flush=True)
+for dual in (1, 0):
+    for chunked in (1, 0):
+        for workers in (0, 2, 4, 8):
+            for chunk_kb in (0, 4096, 16384):
+                if (workers == 0) != (chunk_kb == 0):
+                    continue
+                bn.lib.tune("STAGE_DUAL", dual); bn.lib.tune("PROVE_CHUNKED_UPLOAD", chunked)
+                bn.lib.tune("STAGE_WORKERS", workers or None); bn.lib.tune("STAGE_CHUNK_KB", chunk_kb or None)
+                ms, p = t(host)
+                print(json.dumps({"setting": {"two_copy_queues": dual, "chunked_histogram": chunked, "workers": workers or "default (4)", "chunk_kb": chunk_kb or "default (8192)"},
+                                  "host_witness_ms": round(ms, 3), "over_resident_ms": round(ms - base, 3), "ok": p == want}), flush=True)
 for name in ("PROVE_CHUNKED_UPLOAD", "STAGE_WORKERS", "STAGE_CHUNK_KB"):
     bn.lib.tune(name, None)
-ms, p = t(pin)
-print(json.dumps({"setting": "pinned source (torch pin_memory), DMA in place", "host_witness_ms": round(ms, 3), "over_resident_ms": round(ms - base, 3), "ok": p == want}), flush=True)
+for dual in (1, 0):
+    bn.lib.tune("STAGE_DUAL", dual)
+    ms, p = t(pin)
+    print(json.dumps({"setting": "pinned source (torch pin_memory), DMA in place, two copy queues = %d" % dual, "host_witness_ms": round(ms, 3), "over_resident_ms": round(ms - base, 3), "ok": p == want}), flush=True)
+bn.lib.tune("STAGE_DUAL", None)
 base2, _ = t(dev)
 print(json.dumps({"setting": "resident witness (again)", "ms": round(base2, 3)}), flush=True)

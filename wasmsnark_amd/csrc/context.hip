@@ -84,6 +84,7 @@ int context_init(int device) {
         if (!L.stream2) WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream2, hipStreamNonBlocking));   // (no priorities here)
         WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream3, hipStreamNonBlocking));
         WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream_copy, hipStreamNonBlocking));
+        WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream_copy2, hipStreamNonBlocking));
     }
     g_ctx = C;
     return WS_OK;
@@ -99,6 +100,7 @@ void context_shutdown() {
         (void)hipStreamSynchronize(g_ctx->lanes[i].stream2);
         (void)hipStreamSynchronize(g_ctx->lanes[i].stream3);
         (void)hipStreamSynchronize(g_ctx->lanes[i].stream_copy);
+        (void)hipStreamSynchronize(g_ctx->lanes[i].stream_copy2);
     }
     g_ctx->timer.reset();
     for (hipEvent_t e : g_ctx->timer.pool) (void)hipEventDestroy(e);
@@ -120,6 +122,7 @@ void context_shutdown() {
         (void)hipStreamDestroy(L.stream2);
         (void)hipStreamDestroy(L.stream3);
         (void)hipStreamDestroy(L.stream_copy);
+        (void)hipStreamDestroy(L.stream_copy2);
     }
     (void)hipStreamDestroy(g_ctx->stream);
     delete g_ctx;
@@ -221,13 +224,20 @@ static inline void cpu_relax() {
 #endif
 }
 
-int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s, const ChunkFn& on_chunk) {
+int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s, const ChunkFn& on_chunk, hipStream_t s_alt) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
     if (!s) s = C->stream;
     if (bytes == 0) return WS_OK;
-    // chunk size: WSNARK_STAGE_CHUNK_KB (default 4 MiB; 64 KiB granules, 64 KiB .. 16 MiB)
-    size_t chunk = ((size_t)tuning_get("STAGE_CHUNK_KB", 4096) << 10) & ~(size_t)0xFFFF;
+    // s_alt (optional): a second copy queue; the chunks then alternate between the two, so that two DMAs are in flight at once
+    // (one queue feeds one SDMA engine: 32 MiB in ~0.95 ms = ~35 GB/s on the MI355X box, below what the link carries).
+    // WSNARK_STAGE_DUAL=0 keeps everything on `s`.
+    if (s_alt == s || !tuning_get("STAGE_DUAL", 1)) s_alt = nullptr;
+    auto q = [&](size_t g) { return (s_alt && (g & 1)) ? s_alt : s; };
+    // chunk size: WSNARK_STAGE_CHUNK_KB (default 8 MiB from 16 MiB on, 4 MiB below; 64 KiB granules, 64 KiB .. 16 MiB).  Measured on
+    // the MI355X box with a 32 MiB witness (profiles/r04_s1_upload_sweep.txt): 8 MiB chunks and 4 copy threads cost the proof
+    // +1.12 ms over a resident witness, 4 MiB / 12 threads +1.6 ms, a pinned source DMA'd in place +0.99 ms -- the transfer itself.
+    size_t chunk = ((size_t)tuning_get("STAGE_CHUNK_KB", bytes >= ((size_t)16 << 20) ? 8192 : 4096) << 10) & ~(size_t)0xFFFF;
     chunk = chunk < ((size_t)64 << 10) ? ((size_t)64 << 10) : chunk > ((size_t)16 << 20) ? ((size_t)16 << 20) : chunk;
     int rc = WS_OK;
     // small copies, and sources that are ALREADY pinned (hipHostMalloc / hipHostRegister), need no staging
@@ -245,8 +255,8 @@ int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s
         const size_t G = (bytes + chunk - 1) / chunk;
         for (size_t g = 0; g < G; g++) {
             const size_t lo = g * chunk, hi = lo + chunk < bytes ? lo + chunk : bytes;
-            WS_HIP_CHECK(hipMemcpyAsync((char*)d_dst + lo, (const char*)h_src + lo, hi - lo, hipMemcpyHostToDevice, s));
-            if (on_chunk && (rc = on_chunk(lo, hi))) return rc;
+            WS_HIP_CHECK(hipMemcpyAsync((char*)d_dst + lo, (const char*)h_src + lo, hi - lo, hipMemcpyHostToDevice, q(g)));
+            if (on_chunk && (rc = on_chunk(lo, hi, q(g)))) return rc;
         }
         return WS_OK;
     }
@@ -263,11 +273,10 @@ int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s
     size_t nslots = C->pin_ring_bytes / chunk;
     if (nslots > (size_t)PIN_MAX_SLOTS) nslots = PIN_MAX_SLOTS;
     const size_t G = (bytes + chunk - 1) / chunk;
-    // workers: WSNARK_STAGE_WORKERS, default one per 2 MiB of the upload, 2 .. 12
+    // workers: WSNARK_STAGE_WORKERS, default 4 (more only get in each other's way: the sweep above), 2 below 8 MiB
     const long env_w = tuning_get("STAGE_WORKERS", 0);
-    int W = env_w > 0 ? (int)env_w : (int)(bytes >> 21);
-    W = W < 2 ? 2 : W > PIN_MAX_WORKERS ? PIN_MAX_WORKERS : W;
-    if (env_w <= 0 && W > 12) W = 12;
+    int W = env_w > 0 ? (int)env_w : (bytes < ((size_t)8 << 20) ? 2 : 4);
+    W = W < 1 ? 1 : W > PIN_MAX_WORKERS ? PIN_MAX_WORKERS : W;
     const size_t per = ((chunk + W - 1) / W + 4095) & ~(size_t)4095;      // a worker's slice of a chunk, page granules
     // Bookkeeping.  Chunk g lives in slot g % nslots.  Workers may write chunk g once released > g; the orchestrator releases
     // chunk k only when the slot's previous occupant -- chunk k - nslots of THIS upload (whose DMA it has queued itself, so the
@@ -322,9 +331,9 @@ int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s
         if (rc) break;
         const size_t lo = g * chunk, hi = lo + chunk < bytes ? lo + chunk : bytes;
         const size_t slot = g % nslots;
-        if (hipMemcpyAsync((char*)d_dst + lo, ring + slot * chunk, hi - lo, hipMemcpyHostToDevice, s) != hipSuccess ||
-            hipEventRecord(C->pin_ev[slot], s) != hipSuccess) { set_last_error("staged upload: DMA failed"); rc = WS_ERR_HIP; break; }
-        if (on_chunk) rc = on_chunk(lo, hi);
+        if (hipMemcpyAsync((char*)d_dst + lo, ring + slot * chunk, hi - lo, hipMemcpyHostToDevice, q(g)) != hipSuccess ||
+            hipEventRecord(C->pin_ev[slot], q(g)) != hipSuccess) { set_last_error("staged upload: DMA failed"); rc = WS_ERR_HIP; break; }
+        if (on_chunk) rc = on_chunk(lo, hi, q(g));
     }
     if (rc) stop.store(1);                          // the workers leave at their next chunk boundary
     pool->wait();
@@ -332,7 +341,7 @@ int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s
 }
 
 int upload_staged(void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
-    return upload_pipelined(d_dst, h_src, bytes, s, nullptr);
+    return upload_pipelined(d_dst, h_src, bytes, s, nullptr, nullptr);
 }
 
 // ---- KernelTimer ----

@@ -235,5 +235,36 @@ typedef Curve<Fq29> G1R29;
 #endif
 typedef Curve<Fq29I> G1R29I;   // inlined products: reduction-tail kernels
 typedef Curve<Fp2T<Fq29>> G2R29;
+typedef Curve<Fp2PairT<Fq29>> G2P29;   // G2 with the extension's components on two adjacent lanes: reduction-tail kernels (fp2.h)
+
+// How the lanes of a kernel map to STORED points: one lane per point, or -- the paired extension field -- two lanes per point,
+// lane p of the pair owning component p of every coordinate (bytes [32 p, 32 p + 32) of each 64-byte Fp2 element).
+template <class C>
+struct PointIO {
+    static constexpr uint32_t LPP = 1;                 // lanes per point
+    typedef typename C::PtP Stored;
+    WS_HD static typename C::Pt load(const Stored* a, uint64_t i) { return C::unpack_pt(a[i]); }
+    WS_HD static void store(Stored* a, uint64_t i, const typename C::Pt& p) { a[i] = C::pack_pt(p); }
+    WS_HD static void store_ref(Stored* a, uint64_t i, const typename C::Pt& p) { a[i] = C::pt_from_internal(p); }   // reference format
+};
+template <class B>
+struct PointIO<Curve<Fp2PairT<B>>> {
+    typedef Curve<Fp2PairT<B>> C;
+    typedef Fp2PairT<B> F;
+    static constexpr uint32_t LPP = 2;
+    typedef XYZZP<Fp2T<B>> Stored;                     // the full 256-byte point, as the one-lane kernels store it
+    WS_HD static typename C::Pt load(const Stored* a, uint64_t i) {
+        const typename B::Packed* f = reinterpret_cast<const typename B::Packed*>(a + i) + (F::hi() ? 1 : 0);
+        return typename C::Pt{F::unpack(f[0]), F::unpack(f[2]), F::unpack(f[4]), F::unpack(f[6])};
+    }
+    WS_HD static void store(Stored* a, uint64_t i, const typename C::Pt& p) {
+        typename B::Packed* f = reinterpret_cast<typename B::Packed*>(a + i) + (F::hi() ? 1 : 0);
+        f[0] = F::pack(p.x); f[2] = F::pack(p.y); f[4] = F::pack(p.zz); f[6] = F::pack(p.zzz);
+    }
+    WS_HD static void store_ref(Stored* a, uint64_t i, const typename C::Pt& p) {
+        typename B::Packed* f = reinterpret_cast<typename B::Packed*>(a + i) + (F::hi() ? 1 : 0);
+        f[0] = F::from_internal(p.x); f[2] = F::from_internal(p.y); f[4] = F::from_internal(p.zz); f[6] = F::from_internal(p.zzz);
+    }
+};
 
 }  // namespace wsnark

@@ -8,6 +8,7 @@
 #include <type_traits>
 
 #include "field.h"
+#include "rt.h"     // threadIdx / the emulator's pair exchange, for the lane-paired variant below
 
 #ifndef WS_FP2_INLINE
 #define WS_FP2_INLINE 1   // products of the quadratic extension as inlined bodies (G2 accumulate 4.15 -> 3.93 ms)
@@ -119,5 +120,96 @@ struct Fp2T {
 };
 
 typedef Fp2T<Fq> Fq2;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same extension with its two components on TWO ADJACENT LANES (2k holds c0, 2k + 1 holds c1): El is ONE base-field
+// element per lane, so a G2 point is 36 VGPRs per lane instead of 72.  For the LATENCY-bound kernels of an MSM's reduction
+// tail (msm.hip: chains of ~20-30 dependent additions on a few hundred wavefronts, where a G2 addition on a lone wavefront
+// took 23 us at 256 VGPRs + ~100 AGPRs of spill): every extension product is still two fused base products, but each lane
+// computes ONE of them -- half the dependent instruction chain per addition -- after fetching the partner's operands with a DPP
+// quad_perm swap (9 v_mov_dpp per operand against 243 multiply-adds per fused product).  Not for throughput kernels: the
+// instruction count per addition is the same plus the swaps.
+//   * Both lanes of a pair must execute the same control flow: every predicate (is_zero, is_zero_weak, eq) is the AND over the
+//     pair, so the curve formulas' branches are pair-uniform by construction.
+//   * Packed = the base field's 32 bytes: in a stored Fp2 element (c0 | c1) lane p owns bytes [32 p, 32 p + 32).
+//   * Same operand bounds as Fp2T above (first operand of mul / operand of sqr / first two of mulsub2 may be uncorrected
+//     differences), same results bit for bit (tests: selftest impl 4).
+// ---------------------------------------------------------------------------------------------------------------------
+#if defined(WSNARK_EMUL)
+#define WS_PAIR_SWAP_U32(v) (::hip_emul::pair_exchange(v))
+#define WS_PAIR_HI() ((threadIdx.x & 1u) != 0)
+#elif defined(__HIP_DEVICE_COMPILE__)
+#define WS_PAIR_SWAP_U32(v) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true))
+#define WS_PAIR_HI() ((threadIdx.x & 1u) != 0)
+#else
+#define WS_PAIR_SWAP_U32(v) (v)        // (host pass of hipcc: these functions are device-only)
+#define WS_PAIR_HI() (false)
+#endif
+
+template <class B>
+struct Fp2PairT {
+    typedef typename B::El El;
+    typedef typename B::Packed Packed;
+    static constexpr bool kInternalDomain = B::kInternalDomain;
+    static constexpr bool kPaired = true;
+    WS_HD static bool hi() { return WS_PAIR_HI(); }
+    WS_HD static El swap(const El& a) {                 // the partner lane's component
+        El r;
+#pragma unroll
+        for (int i = 0; i < 9; i++) r.v[i] = WS_PAIR_SWAP_U32(a.v[i]);
+        return r;
+    }
+    WS_HD static El sel(bool c, const El& x, const El& y) {
+        El r;
+#pragma unroll
+        for (int i = 0; i < 9; i++) r.v[i] = c ? x.v[i] : y.v[i];
+        return r;
+    }
+    WS_HD static bool both(bool mine) {                 // (the exchange is unconditional: both lanes of the pair must execute it)
+        const uint32_t other = WS_PAIR_SWAP_U32(mine ? 1u : 0u);
+        return mine && other != 0;
+    }
+
+    WS_HD static El unpack(const Packed& x) { return B::unpack(x); }
+    WS_HD static Packed pack(const El& x) { return B::pack(x); }
+    WS_HD static El to_internal(const Packed& x) { return B::to_internal(x); }
+    WS_HD static Packed from_internal(const El& x) { return B::from_internal(x); }
+    WS_HD static El zero() { return B::zero(); }
+    WS_HD static El one() { return hi() ? B::zero() : B::one(); }
+    WS_HD static bool is_zero(const El& a) { return both(B::is_zero(a)); }
+    WS_HD static bool is_zero_weak(const El& a) { return both(B::is_zero_weak(a)); }
+    WS_HD static bool is_zero_wide(const El& a) { return is_zero_weak(a); }
+    WS_HD static bool eq(const El& a, const El& b) { return is_zero(B::sub(a, b)); }
+    WS_HD static El add(const El& a, const El& b) { return B::add(a, b); }
+    WS_HD static El dbl(const El& a) { return B::dbl(a); }
+    WS_HD static El sub(const El& a, const El& b) { return B::sub(a, b); }
+    WS_HD static El sub_weak(const El& a, const El& b) { return B::sub_weak(a, b); }
+    WS_HD static El sub_wide(const El& a, const El& b) { return B::sub_weak(a, b); }
+    WS_HD static El narrow(const El& a) { return a; }
+    WS_HD static El x3_wide(const El& rr, const El& ppp, const El& q) { return B::narrow(B::x3_wide(rr, ppp, q)); }
+    WS_HD static El neg(const El& a) { return B::neg(a); }
+    WS_HD static El cneg(const El& a, bool s) { return s ? B::neg(a) : a; }
+    // (a0 + a1 u)(b0 + b1 u): lane 0 forms a0 b0 + a1 (2p - b1), lane 1 forms a0 b1 + a1 b0 -- one fused double product each
+    WS_HD static El mul(const El& a, const El& b) {
+        const bool h = hi();
+        const El oa = swap(a), ob = swap(b);
+        return B::mul2add_inl(sel(h, oa, a), b, sel(h, a, oa), sel(h, ob, B::neg_weak(ob)));
+    }
+    // complex squaring: lane 0 forms (a0 + a1)(a0 - a1 + 4p), lane 1 forms 2 (a0 a1)
+    WS_HD static El sqr(const El& a) {
+        const bool h = hi();
+        const El oa = swap(a);
+        const El t = B::mul_inl(sel(h, oa, B::add_lazy(a, oa)), sel(h, a, B::sub_weak4(a, oa)));
+        return h ? B::dbl(t) : t;
+    }
+    // a b - c d: one fused four-product reduction per lane (operands as in Fp2T::mulsub2)
+    WS_HD static El mulsub2(const El& a, const El& b, const El& c, const El& d) {
+        const bool h = hi();
+        const El oa = swap(a), ob = swap(b), oc = swap(c), od = swap(d);
+        return B::mul4add(sel(h, oa, a), b, sel(h, a, oa), sel(h, ob, B::neg_weak4(ob)), B::neg_weak(sel(h, oc, c)), d,
+                          sel(h, B::neg_weak(c), oc), od);
+    }
+};
+
 
 }  // namespace wsnark

@@ -72,6 +72,7 @@ struct Lane {
     hipStream_t stream2 = nullptr;              // second queue (prover: CALC_H and the H sum beside the tails)
     hipStream_t stream3 = nullptr;              // third queue (small proofs / points shards: the G2 sum beside the G1 sums)
     hipStream_t stream_copy = nullptr;          // host -> device copies of a call's inputs (the witness, chunk by chunk, beside the first kernels)
+    hipStream_t stream_copy2 = nullptr;         // ... a second copy queue: the chunks alternate between the two (two DMAs in flight)
     hipEvent_t ev_chunk[2] = {nullptr, nullptr};   // ... a chunk has landed
     MsmWorkspace* msm = nullptr;                // plans, launch slots (owned; msm_workspace_free)
     DevBuf host_in[2];                          // host-pointer boundary: grow-only device copies of the caller's buffers
@@ -126,8 +127,9 @@ int upload_staged(void* d_dst, const void* h_src, size_t bytes, hipStream_t s);
 // The same, announcing every chunk: on_chunk(lo, hi) runs on the calling thread right after the DMA of bytes [lo, hi) has
 // been queued on `s` (chunks arrive in order; a non-zero return aborts the upload and is returned).  Typical use: record an
 // event on `s` and make another queue start its first pass over that part while the rest is still being staged.
-typedef std::function<int(size_t, size_t)> ChunkFn;
-int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s, const ChunkFn& on_chunk);
+// (the third argument of on_chunk is the queue that chunk's DMA went to: `s`, or s_alt when a second copy queue is given)
+typedef std::function<int(size_t, size_t, hipStream_t)> ChunkFn;
+int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s, const ChunkFn& on_chunk, hipStream_t s_alt = nullptr);
 
 Context* ctx();   // nullptr before wsnark_init
 

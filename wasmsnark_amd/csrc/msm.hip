@@ -759,66 +759,110 @@ __global__ __launch_bounds__(64) void msm_combine_hot2(AccSets<C> as, uint32_t b
 // 6. chunk sums: for CHUNK consecutive buckets of one window
 //    S = sum B_i,  A = sum (i - i0 + 1) B_i   (descending running sum)
 // ---------------------------------------------------------------------------
-// the reduction tail is latency-bound (a dependent chain of ~33 full additions), so up to 4 point sets that
-// share a plan (the prover's A, B1, C) go through it in ONE launch: blockIdx.y / .z selects the set
+// the reduction tail is latency-bound (a dependent chain of ~20-30 full additions), so up to 4 point sets that
+// share a plan (the prover's A, B1, C) go through it in ONE launch: blockIdx.y / .z selects the set.
+// The tail kernels are written over PointIO<C> (curve.h): one lane per point, or -- the lane-paired G2 curve -- two.
 template <class C>
 struct TailSets {
-    const typename C::PtP* buckets[4];
-    typename C::PtP* chunkS[4];
-    typename C::PtP* chunkA[4];
-    typename C::PtP* sums[4];
+    typedef typename PointIO<C>::Stored St;
+    const St* buckets[4];
+    St* chunkS[4];
+    St* chunkA[4];
+    St* rows[4];         // per piece: U_0 .. U_{logJ-1}, A [, T]; in the internal domain when a piece-reduction pass follows
+    St* sums[4];         // what leaves for the host (reference format)
 };
 
 template <class C>
 __global__ __launch_bounds__(256) void msm_chunks(TailSets<C> ts, uint32_t chunk0, uint32_t nchunks, uint32_t m) {
-    const typename C::PtP* __restrict__ buckets = ts.buckets[blockIdx.y];
-    typename C::PtP* __restrict__ chunkS = ts.chunkS[blockIdx.y];
-    typename C::PtP* __restrict__ chunkA = ts.chunkA[blockIdx.y];
-    const uint32_t j = chunk0 + blockIdx.x * blockDim.x + threadIdx.x;      // chunks [chunk0, nchunks): all, or the windows of one half
+    typedef PointIO<C> IO;
+    const typename IO::Stored* __restrict__ buckets = ts.buckets[blockIdx.y];
+    typename IO::Stored* __restrict__ chunkS = ts.chunkS[blockIdx.y];
+    typename IO::Stored* __restrict__ chunkA = ts.chunkA[blockIdx.y];
+    const uint32_t j = chunk0 + (blockIdx.x * blockDim.x + threadIdx.x) / IO::LPP;      // chunks [chunk0, nchunks): all, or the windows of one half
     if (j >= nchunks) return;
     typename C::Pt run = C::infinity(), acc = C::infinity();
-    const typename C::PtP* B = buckets + (uint64_t)j * m;
+    const typename IO::Stored* B = buckets + (uint64_t)j * m;
     for (int i = (int)m - 1; i >= 0; i--) {
-        run = C::add(run, C::unpack_pt(B[i]));
+        run = C::add(run, IO::load(B, (uint64_t)i));
         acc = C::add(acc, run);
     }
-    chunkS[j] = C::pack_pt(run);
-    chunkA[j] = C::pack_pt(acc);
+    IO::store(chunkS, j, run);
+    IO::store(chunkA, j, acc);
 }
 
 // ---------------------------------------------------------------------------
-// 7. masked tree sums per window: blockIdx.y = window, blockIdx.x = q
-//    q < logJ : U_q = sum_{j : bit q of j set} S_j ;  q == logJ : sum_j A_j ;  q == logJ + 1 (table plans) : sum_j S_j
+// 7. masked tree sums per piece: blockIdx.y = piece ("window"), blockIdx.x = q
+//    q < logJ : U_q = sum_{j : bit q of j set} S_j ;  q == logJ : sum_j A_j ;  q == logJ + 1 (pieces of one bucket set) : sum_j S_j
+//    to_ref: the rows leave in the reference format (they go straight to the host); otherwise they stay in the internal
+//    domain for msm_rows
 // ---------------------------------------------------------------------------
+// (one lane per 256-byte G2 point: 256 threads at most, so that a wavefront may use the whole register file)
+template <class C> struct TreeBound { static constexpr int value = (PointIO<C>::LPP == 1 && sizeof(typename PointIO<C>::Stored) > 128) ? 256 : 512; };
 template <class C>
-__global__ __launch_bounds__(sizeof(typename C::PtP) > 128 ? 256 : 512) void msm_tree(TailSets<C> ts, uint32_t J,
-                                                                                           uint32_t logJ, uint32_t w0) {
-    const typename C::PtP* __restrict__ chunkS = ts.chunkS[blockIdx.z];
-    const typename C::PtP* __restrict__ chunkA = ts.chunkA[blockIdx.z];
-    typename C::PtP* __restrict__ sums = ts.sums[blockIdx.z];
-    WS_DYN_SMEM(typename C::PtP, sh);
-    const uint32_t q = blockIdx.x, w = w0 + blockIdx.y;              // windows [w0, w0 + gridDim.y)
-    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
-    const typename C::PtP* src = (q == logJ ? chunkA : chunkS) + (uint64_t)w * J;
+__global__ __launch_bounds__(TreeBound<C>::value) void msm_tree(TailSets<C> ts, uint32_t J, uint32_t logJ, uint32_t w0, uint32_t to_ref) {
+    typedef PointIO<C> IO;
+    typedef typename IO::Stored St;
+    const St* __restrict__ chunkS = ts.chunkS[blockIdx.z];
+    const St* __restrict__ chunkA = ts.chunkA[blockIdx.z];
+    St* __restrict__ rows = to_ref ? ts.sums[blockIdx.z] : ts.rows[blockIdx.z];
+    WS_DYN_SMEM(St, sh);
+    const uint32_t q = blockIdx.x, w = w0 + blockIdx.y;              // pieces [w0, w0 + gridDim.y)
+    const uint32_t slot = threadIdx.x / IO::LPP, nslots = blockDim.x / IO::LPP;
+    const St* src = (q == logJ ? chunkA : chunkS) + (uint64_t)w * J;
     typename C::Pt acc = C::infinity();
     if (q >= logJ) {
-        for (uint32_t j = tid; j < J; j += nthr) acc = C::add(acc, C::unpack_pt(src[j]));
+        for (uint32_t j = slot; j < J; j += nslots) acc = C::add(acc, IO::load(src, j));
     } else {
         // enumerate only the J/2 indices whose bit q is set (insert a 1 at bit q): every lane stays busy
         const uint32_t low = (1u << q) - 1;
-        for (uint32_t i = tid; i < (J >> 1); i += nthr) {
+        for (uint32_t i = slot; i < (J >> 1); i += nslots) {
             const uint32_t j = ((i & ~low) << 1) | (1u << q) | (i & low);
-            acc = C::add(acc, C::unpack_pt(src[j]));
+            acc = C::add(acc, IO::load(src, j));
         }
     }
-    sh[tid] = C::pack_pt(acc);
+    IO::store(sh, slot, acc);
     __syncthreads();
-    for (uint32_t step = nthr >> 1; step >= 1; step >>= 1) {
-        if (tid < step) sh[tid] = C::pack_pt(C::add(C::unpack_pt(sh[tid]), C::unpack_pt(sh[tid + step])));
+    for (uint32_t step = nslots >> 1; step >= 1; step >>= 1) {
+        if (slot < step) IO::store(sh, slot, C::add(IO::load(sh, slot), IO::load(sh, slot + step)));
         __syncthreads();
     }
-    // results leave the device in the reference format (canonical, Montgomery R = 2^256)
-    if (tid == 0) sums[(uint64_t)w * gridDim.x + q] = C::pt_from_internal(C::unpack_pt(sh[0]));
+    if (slot == 0) {
+        const typename C::Pt r = IO::load(sh, 0);
+        if (to_ref) IO::store_ref(rows, (uint64_t)w * gridDim.x + q, r);
+        else IO::store(rows, (uint64_t)w * gridDim.x + q, r);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 7'. piece reduction (round 4): a bucket set of NB buckets is cut into P pieces of tNB buckets (short trees above), and the
+//     rows of the pieces are folded HERE instead of on the host:  sum_b (b + 1) B_b,  b = v tNB + u,
+//        = sum_v [ A_v + m sum_q 2^q U_{v,q} ] + tNB sum_v v T_v
+//        = R_A + m sum_q 2^q R_q + tNB sum_p 2^p V_p,   R_q = sum_v U_{v,q},  R_A = sum_v A_v,  V_p = sum_{v : bit p of v} T_v.
+//     blockIdx.x = output row r (r < logJ: R_r; r == logJ: R_A; r > logJ: V_{r - logJ - 1}), blockIdx.y = group (the whole bucket
+//     set of a table plan; one window of a per-window plan), blockIdx.z = point set.  One slot per piece, LDS tree, the result
+//     leaves in the reference format: logJ + 1 + log2 P rows per group for the host instead of P (logJ + 2).
+// ---------------------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(TreeBound<C>::value) void msm_rows(TailSets<C> ts, uint32_t P, uint32_t logJ, uint32_t nsum_in, uint32_t nrows_out) {
+    typedef PointIO<C> IO;
+    typedef typename IO::Stored St;
+    const St* __restrict__ rows = ts.rows[blockIdx.z];
+    St* __restrict__ out = ts.sums[blockIdx.z];
+    WS_DYN_SMEM(St, sh);
+    const uint32_t r = blockIdx.x, g = blockIdx.y;
+    const uint32_t slot = threadIdx.x / IO::LPP, nslots = blockDim.x / IO::LPP;
+    const uint32_t in_row = r <= logJ ? r : logJ + 1;
+    const uint32_t bit = r > logJ ? r - logJ - 1 : 0xFFFFFFFFu;
+    typename C::Pt acc = C::infinity();
+    for (uint32_t v = slot; v < P; v += nslots)
+        if (bit == 0xFFFFFFFFu || ((v >> bit) & 1u)) acc = C::add(acc, IO::load(rows, ((uint64_t)g * P + v) * nsum_in + in_row));
+    IO::store(sh, slot, acc);
+    __syncthreads();
+    for (uint32_t step = nslots >> 1; step >= 1; step >>= 1) {
+        if (slot < step) IO::store(sh, slot, C::add(IO::load(sh, slot), IO::load(sh, slot + step)));
+        __syncthreads();
+    }
+    if (slot == 0) IO::store_ref(out, (uint64_t)g * nrows_out + r, IO::load(sh, 0));
 }
 
 
@@ -884,6 +928,11 @@ struct MsmPlanInfo {
     // cut into tW pieces of tNB buckets ("windows" of the chunk/tree kernels; classic plans: tW = W, tNB = NB).
     bool flat = false;
     uint32_t tW = 0, tNB = 0;
+    // round 4: a group (the one bucket set of a table plan; a window of a per-window plan) is cut into tP pieces of tNB buckets;
+    // with `reduce` the pieces' rows are folded on the GPU (msm_rows) and nrows = logJ + 1 + log2(tP) rows per GROUP reach the
+    // host, otherwise nsum rows per PIECE do (the round-2 / 3 arrangement, TAIL_REDUCE=0)
+    uint32_t tP = 1, groups = 1, nrows = 0;
+    bool reduce = false;
     uint32_t ntasks = 0, nmulti = 0;
     // split plans (per-window plans of one whole MSM call): the high windows [split_k, W) are task segment 0, the low ones
     // segment 1; 0 = one segment
@@ -898,7 +947,7 @@ struct MsmPending {
     int which = 0;
     int plan_id = 0;
     MsmPlanInfo info;
-    DevBuf d_sums;
+    DevBuf d_sums, d_rows;        // what goes to the host; the pieces' rows before msm_rows folds them
     MsmScratch S;                 // this launch's accumulation buffers (buckets, partials, chunk sums)
     void* h_sums = nullptr;
     size_t h_bytes = 0;
@@ -912,7 +961,7 @@ struct MsmPending {
         if (ev_hi) (void)hipEventDestroy(ev_hi);
         if (ev_acc) (void)hipEventDestroy(ev_acc);
         h_sums = nullptr; ev = nullptr; ev_hi = nullptr; ev_acc = nullptr; h_bytes = 0; active = false;
-        d_sums.release();
+        d_sums.release(); d_rows.release();
         S.buckets.release(); S.partials.release(); S.chunkS.release(); S.chunkA.release(); S.points_conv.release(); S.hot_sums.release();
     }
 };
@@ -968,6 +1017,27 @@ static int msm_finish_t(MsmPending& P, typename H::Pt* out_host) {
     WS_HIP_CHECK(hipEventSynchronize(waited_all ? P.ev : P.ev_hi));
     const auto t_tail = std::chrono::steady_clock::now();
     const HPt* sums = reinterpret_cast<const HPt*>(P.h_sums);
+    if (I.flat && I.reduce) {
+        // table plans with the pieces folded on the GPU (msm_rows): R_A + m sum_q 2^q R_q + tNB sum_p 2^p V_p -- two short Horner
+        // chains over logJ + 1 + log2(tP) rows, c - 1 doublings in all
+        uint32_t logm = 0, logt = 0, logP = 0;
+        while ((1u << logm) < I.m) logm++;
+        while ((1u << logt) < I.tNB) logt++;
+        while ((1u << logP) < I.tP) logP++;
+        HPt acc = H::infinity();
+        for (int q = (int)I.logJ - 1; q >= 0; q--) acc = H::add(H::dbl(acc), sums[q]);
+        for (uint32_t k = 0; k < logm; k++) acc = H::dbl(acc);
+        acc = H::add(acc, sums[I.logJ]);
+        HPt tot = H::infinity();
+        for (int pb = (int)logP - 1; pb >= 0; pb--) tot = H::add(H::dbl(tot), sums[I.logJ + 1 + (uint32_t)pb]);
+        for (uint32_t k = 0; k < logt; k++) tot = H::dbl(tot);
+        *out_host = H::add(acc, tot);
+        if (trace)
+            fprintf(stderr, "[wsnark trace]   msm finish (%s, table, rows folded on the GPU): waited %.3f ms for the GPU, host tail %.3f ms\n", sizeof(HPt) > 128 ? "G2" : "G1",
+                    std::chrono::duration<double, std::milli>(t_tail - t_wait).count(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_tail).count());
+        return WS_OK;
+    }
     if (I.flat) {
         // table plans: sum_b (b+1) B_b over ONE bucket set, b = v*tNB + u:  sum_v [ A_v + m sum_q 2^q U_{v,q} ] + tNB sum_v v T_v
         // (rows per piece v: U_{v,0..logJ-1}, A_v, T_v = sum of the piece's buckets).  The pieces are summed row-wise first,
@@ -1002,18 +1072,23 @@ static int msm_finish_t(MsmPending& P, typename H::Pt* out_host) {
     // positions of the whole scalar (MSB first): U_{w,q} sits at bit c*w + log2(m) + q, A_w at bit c*w, and
     // log2(m) + logJ = c - 1, so every window's terms fall inside its own c positions: c*Wall doublings and
     // (logJ + 1) additions per owned window -- no per-window inner chain.
-    uint32_t logm = 0;
+    uint32_t logm = 0, logt = 0, logP = 0;
     while ((1u << logm) < I.m) logm++;
+    while ((1u << logt) < I.tNB) logt++;
+    while ((1u << logP) < I.tP) logP++;
+    // (windows cut into pieces, rows folded by msm_rows: V_{w,p} = sum_{v: bit p} T_{w,v} sits at bit c*w + log2(tNB) + p)
+    const uint32_t rows_per_window = I.reduce ? I.nrows : I.nsum;
     HPt acc = H::infinity();
     bool started = false;                                  // leading doublings of infinity are skipped
     for (int wg = (int)I.Wall - 1; wg >= 0; wg--) {      // global window index; rows exist for the owned ones
         const bool owned = (uint32_t)wg >= I.w_off && ((uint32_t)wg - I.w_off) % I.w_stride == 0;
         const uint32_t krow = owned ? ((uint32_t)wg - I.w_off) / I.w_stride : 0;
         if (owned && !waited_all && krow < I.split_k) { WS_HIP_CHECK(hipEventSynchronize(P.ev)); waited_all = true; }
-        const HPt* row = owned ? &sums[(size_t)krow * I.nsum] : nullptr;
+        const HPt* row = owned ? &sums[(size_t)krow * rows_per_window] : nullptr;
         for (int k = (int)I.c - 1; k >= 0; k--) {
             if (started) acc = H::dbl(acc);
             if (!owned) continue;
+            if (I.reduce && (uint32_t)k >= logt && (uint32_t)k - logt < logP) { acc = H::add(acc, row[I.logJ + 1 + (uint32_t)k - logt]); started = true; }
             if ((uint32_t)k >= logm && (uint32_t)k - logm < I.logJ) { acc = H::add(acc, row[(uint32_t)k - logm]); started = true; }
             if (k == 0) { acc = H::add(acc, row[I.logJ]); started = true; }
         }
@@ -1085,21 +1160,34 @@ int msm_plan_begin(Lane& L, uint64_t n, WindowShard sh, hipStream_t s, uint32_t 
     I.nbuckets = I.flat ? I.NB : I.W * I.NB;
     const uint64_t total = n * I.W;
     if (total >= ((uint64_t)1 << 32)) return WS_ERR_SIZE;
-    uint32_t chunk = CHUNK;
+    // Reduction-tail geometry.  The tail is a chain of dependent additions -- 2 m in a chunk lane, then log2 of what is left in
+    // trees -- on few wavefronts; its WORK only matters at full size, its DEPTH matters whenever nothing else fills the chip
+    // (small sums, a rank's share of a sharded key, a stand-alone MSM).  So: chunks of 8 buckets and 2^15-bucket pieces for
+    // large bucket sets (the round-2 / 3 shape), chunks of 4 and 2^11-bucket pieces below 2^18 buckets, and the pieces' rows are
+    // folded on the GPU (msm_rows) so that short pieces do not turn into host work.  WSNARK_MSM_CHUNK / WSNARK_TAIL_BITS /
+    // WSNARK_TAIL_REDUCE override (A/B: profiles/r04_*).
+    const bool big_set = I.NB >= (1u << 18);
+    uint32_t chunk = (I.flat && !big_set) ? 4u : CHUNK;
     { const long v = tuning_get("MSM_CHUNK", 0); if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32) chunk = (uint32_t)v; }
-    if (I.flat) {
-        uint32_t tbits = 15;       // buckets per tail piece (WSNARK_TAIL_BITS): shorter pieces = shallower trees, more rows for the host
-        { const long v = tuning_get("TAIL_BITS", 0); if (v >= 6 && v <= 20) tbits = (uint32_t)v; }
-        I.tNB = I.NB < (1u << tbits) ? I.NB : (1u << tbits);
-        I.tW = I.NB / I.tNB;
-    } else {
-        I.tNB = I.NB;
-        I.tW = I.W;
+    {
+        uint32_t tbits = I.flat ? (big_set ? 15u : 11u) : 31u;      // buckets per tail piece; per-window plans: the whole window
+        { const long v = tuning_get(I.flat ? "TAIL_BITS" : "TAIL_BITS_W", 0); if (v >= 3 && v <= 20) tbits = (uint32_t)v; }
+        I.tNB = (tbits >= 31 || I.NB < (1u << tbits)) ? I.NB : (1u << tbits);
+        I.tP = I.NB / I.tNB;
+        if (I.tP > 256) { I.tP = 256; I.tNB = I.NB / 256; }        // (msm_rows folds a group's pieces in one workgroup)
+        I.groups = I.flat ? 1 : I.W;
+        I.tW = I.groups * I.tP;
     }
     I.m = I.tNB < chunk ? I.tNB : chunk;
     I.J = I.tNB / I.m;
     while ((1u << I.logJ) < I.J) I.logJ++;
-    I.nsum = I.logJ + 1 + (I.flat ? 1 : 0);
+    I.nsum = I.logJ + 1 + ((I.flat || I.tP > 1) ? 1 : 0);
+    I.reduce = I.tP > 1 && (!I.flat || tuning_get("TAIL_REDUCE", 1) != 0);
+    {
+        uint32_t logP = 0;
+        while ((1u << logP) < I.tP) logP++;
+        I.nrows = I.reduce ? I.logJ + 1 + logP : I.nsum;
+    }
     // task length cap: a multiple of the mean bucket load (default 2x); WSNARK_MSM_LMAX_X4 = multiplier * 4 for tuning
     uint32_t mult4 = 8;
     if (const char* e = getenv("WSNARK_MSM_LMAX_X4")) { int v = atoi(e); if (v >= 1 && v <= 64) mult4 = (uint32_t)v; }
@@ -1185,7 +1273,7 @@ int msm_plan_begin(Lane& L, uint64_t n, WindowShard sh, hipStream_t s, uint32_t 
         // (WSNARK_MSM_SPLIT=1 turns it on) as the recorded A/B of VERDICT r2 item 4.
         const bool split_env = [] { const char* e = getenv("WSNARK_MSM_SPLIT"); return e && atoi(e) == 1; }();
         const uint64_t split_min = [] { const char* e = getenv("WSNARK_MSM_SPLIT_MIN"); return e ? (uint64_t)atoll(e) : (uint64_t)1 << 14; }();
-        if (allow_split && split_env && !I.flat && W >= 4 && I.NB >= 256 && n >= split_min) I.split_k = W / 2;
+        if (allow_split && split_env && !I.flat && I.tP == 1 && W >= 4 && I.NB >= 256 && n >= split_min) I.split_k = W / 2;
     } else {
         if (I.flat) { set_last_error("msm: table plans need the grouping pass (WSNARK_MSM_SORT=cub or too many bins)"); return WS_ERR_ARG; }
         WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, (size_t)CNT_BINS * 4, s));
@@ -1474,8 +1562,11 @@ static int msm_launch_acc(Lane& L, int which, const typename H::Aff* d_points_re
     WS_HIP_CHECK(S.partials.reserve((size_t)I.hot_cap * sizeof(Pt)));
     WS_HIP_CHECK(S.chunkS.reserve((size_t)W * J * sizeof(Pt)));
     WS_HIP_CHECK(S.chunkA.reserve((size_t)W * J * sizeof(Pt)));
-    const size_t sums_bytes = (size_t)W * nsum * sizeof(Pt);
+    // rows that reach the host: nrows per group when the pieces are folded on the GPU (their nsum rows per piece then stay in
+    // d_rows), nsum per piece otherwise
+    const size_t sums_bytes = (I.reduce ? (size_t)I.groups * I.nrows : (size_t)W * nsum) * sizeof(Pt);
     WS_HIP_CHECK(P.d_sums.reserve(sums_bytes));
+    if (I.reduce) WS_HIP_CHECK(P.d_rows.reserve((size_t)W * nsum * sizeof(Pt)));
     if (P.h_bytes < sums_bytes) {
         if (P.h_sums) (void)hipHostFree(P.h_sums);
         P.h_sums = nullptr; P.h_bytes = 0;
@@ -1518,11 +1609,13 @@ template <class C> struct TailCurve { typedef C type; };
 template <> struct TailCurve<G1R29> { typedef G1R29I type; };
 #endif
 
-// reduction tail (chunks, tree, copy of the window sums, completion event) for up to 4 launches of one plan
-// w0, w1: the windows (tail pieces) [w0, w1) only -- one half of a split launch; its rows are copied and `done` recorded
+// reduction tail (chunks, trees, [piece reduction,] copy of the rows, completion event) for up to 4 launches of one plan
+// w0, w1: the windows [w0, w1) only -- one half of a split launch (split plans keep whole windows as pieces); its rows are
+// copied and `done` recorded
 template <class C>
 static int msm_launch_tail(Lane& L, const int* slot_ids, int nslots, hipStream_t s, uint32_t w0 = 0, uint32_t w1 = 0xffffffffu, hipEvent_t done = nullptr) {
-    typedef typename C::PtP Pt;
+    typedef PointIO<C> IO;
+    typedef typename IO::Stored St;
     Context* X = ctx();
     if (!s) s = L.stream;
     MsmPending* slots = ws(L).slot;
@@ -1531,27 +1624,43 @@ static int msm_launch_tail(Lane& L, const int* slot_ids, int nslots, hipStream_t
     TailSets<C> ts;
     for (int k = 0; k < 4; k++) {
         MsmPending& P = slots[slot_ids[k < nslots ? k : 0]];
-        ts.buckets[k] = P.S.buckets.template as<Pt>();
-        ts.chunkS[k] = P.S.chunkS.template as<Pt>();
-        ts.chunkA[k] = P.S.chunkA.template as<Pt>();
-        ts.sums[k] = P.d_sums.template as<Pt>();
+        ts.buckets[k] = P.S.buckets.template as<St>();
+        ts.chunkS[k] = P.S.chunkS.template as<St>();
+        ts.chunkA[k] = P.S.chunkA.template as<St>();
+        ts.rows[k] = P.d_rows.template as<St>();
+        ts.sums[k] = P.d_sums.template as<St>();
     }
-    const uint32_t J = I.J, logJ = I.logJ, nsum = I.nsum, m = I.m;
+    const uint32_t J = I.J, logJ = I.logJ, nsum = I.nsum, m = I.m, LPP = IO::LPP;
     if (w1 > I.tW) w1 = I.tW;
     const uint32_t W = w1 - w0;
     KernelTimer& T = X->timer;
     T.begin("msm_chunks", s);
-    hipLaunchKernelGGL(msm_chunks<C>, dim3(ceil_div_u64((uint64_t)W * J, 256), nslots), dim3(256), 0, s, ts, w0 * J, w1 * J, m);
+    hipLaunchKernelGGL(msm_chunks<C>, dim3(ceil_div_u64((uint64_t)W * J * LPP, 256), nslots), dim3(256), 0, s, ts, w0 * J, w1 * J, m);
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
-    uint32_t tthreads = 1;
-    const uint32_t tmax = sizeof(Pt) > 128 ? 256 : 512;   // LDS: threads * sizeof(packed point) <= 64 KiB
-    while (tthreads < J && tthreads < tmax) tthreads <<= 1;
+    // one slot per element of the longest strided sum (J/2 for the masked rows), at most 64 KiB of LDS and 512 threads
+    uint32_t tslots = 1;
+    const uint32_t smax = sizeof(St) > 128 ? 256 : 512;
+    while (tslots < (J > 1 ? J / 2 : 1) && tslots < smax && tslots * LPP < (uint32_t)TreeBound<C>::value) tslots <<= 1;
     T.begin("msm_tree", s);
-    hipLaunchKernelGGL(msm_tree<C>, dim3(nsum, W, nslots), dim3(tthreads), (size_t)tthreads * sizeof(Pt), s, ts, J, logJ, w0);
+    hipLaunchKernelGGL(msm_tree<C>, dim3(nsum, W, nslots), dim3(tslots * LPP), (size_t)tslots * sizeof(St), s, ts, J, logJ, w0, I.reduce ? 0u : 1u);
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
-    const size_t row_bytes = (size_t)nsum * sizeof(Pt), sums_bytes = (size_t)W * row_bytes, off = (size_t)w0 * row_bytes;
+    size_t sums_bytes, off;
+    if (I.reduce) {
+        uint32_t rslots = 1;
+        while (rslots < I.tP && rslots < smax && rslots * LPP < (uint32_t)TreeBound<C>::value) rslots <<= 1;
+        T.begin("msm_rows", s);
+        hipLaunchKernelGGL(msm_rows<C>, dim3(I.nrows, I.groups, nslots), dim3(rslots * LPP), (size_t)rslots * sizeof(St), s, ts, I.tP, logJ, nsum, I.nrows);
+        T.end(s);
+        WS_HIP_CHECK(hipGetLastError());
+        sums_bytes = (size_t)I.groups * I.nrows * sizeof(St);
+        off = 0;
+    } else {
+        const size_t row_bytes = (size_t)nsum * sizeof(St);
+        sums_bytes = (size_t)W * row_bytes;
+        off = (size_t)w0 * row_bytes;
+    }
     for (int k = 0; k < nslots; k++) {
         MsmPending& P = slots[slot_ids[k]];
         WS_HIP_CHECK(hipMemcpyAsync((uint8_t*)P.h_sums + off, (const uint8_t*)P.d_sums.p + off, sums_bytes, hipMemcpyDeviceToHost, s));
@@ -1562,15 +1671,24 @@ static int msm_launch_tail(Lane& L, const int* slot_ids, int nslots, hipStream_t
 
 // The reduction tail of launches accumulated on `s`, enqueued on `ts` (another queue of the lane) behind an event: the next
 // full-width kernel on `s` then starts at once instead of behind a chain of ~33 dependent additions on a few hundred wavefronts.
+// (G2: the tail kernels run on the lane-paired curve unless WSNARK_G2_TAIL_PAIR=0 -- same buffers, same results)
+template <class TC> struct PairedTail { typedef TC type; static constexpr bool has = false; };
+template <> struct PairedTail<G2R29> { typedef G2P29 type; static constexpr bool has = true; };
+template <class TC>
+static int msm_launch_tail_sel(Lane& L, const int* slot_ids, int nslots, hipStream_t s, uint32_t w0 = 0, uint32_t w1 = 0xffffffffu, hipEvent_t done = nullptr) {
+    if (PairedTail<TC>::has && tuning_get("G2_TAIL_PAIR", 1) != 0)
+        return msm_launch_tail<typename PairedTail<TC>::type>(L, slot_ids, nslots, s, w0, w1, done);
+    return msm_launch_tail<TC>(L, slot_ids, nslots, s, w0, w1, done);
+}
 template <class TC>
 static int msm_tail_on(Lane& L, const int* slot_ids, int nslots, hipStream_t s, hipStream_t ts) {
-    if (!ts || ts == s) return msm_launch_tail<TC>(L, slot_ids, nslots, s);
+    if (!ts || ts == s) return msm_launch_tail_sel<TC>(L, slot_ids, nslots, s);
     MsmPending& P0 = ws(L).slot[slot_ids[0]];
     if (P0.info.n == 0) return WS_OK;
     if (!P0.ev_acc) WS_HIP_CHECK(hipEventCreateWithFlags(&P0.ev_acc, hipEventDisableTiming));
     WS_HIP_CHECK(hipEventRecord(P0.ev_acc, s));
     WS_HIP_CHECK(hipStreamWaitEvent(ts, P0.ev_acc, 0));
-    return msm_launch_tail<TC>(L, slot_ids, nslots, ts);
+    return msm_launch_tail_sel<TC>(L, slot_ids, nslots, ts);
 }
 
 template <class C, class H>
@@ -1601,10 +1719,10 @@ static int msm_launch(Lane& L, int which, const typename H::Aff* d_points_ref, b
     if (!P.ev_acc && hipEventCreateWithFlags(&P.ev_acc, hipEventDisableTiming) != hipSuccess) return fail(WS_ERR_HIP);
     P.split = true;
     if (hipEventRecord(P.ev_acc, s) != hipSuccess || hipStreamWaitEvent(s2, P.ev_acc, 0) != hipSuccess) return fail(WS_ERR_HIP);
-    if ((rc = msm_launch_tail<TC>(L, slot_out, 1, s2, P.info.split_k, P.info.tW, P.ev_hi))) return fail(rc);      // high windows: tail on queue 2
+    if ((rc = msm_launch_tail_sel<TC>(L, slot_out, 1, s2, P.info.split_k, P.info.tW, P.ev_hi))) return fail(rc);      // high windows: tail on queue 2
     if ((rc = msm_acc_segment<C>(L, P, which, 1u, s))) return fail(rc);                                            // low windows: accumulate on queue 1
     if (hipStreamWaitEvent(s, P.ev_hi, 0) != hipSuccess) return fail(WS_ERR_HIP);                                  // P.ev (recorded next) then covers both queues
-    if ((rc = msm_launch_tail<TC>(L, slot_out, 1, s, 0, P.info.split_k))) return fail(rc);
+    if ((rc = msm_launch_tail_sel<TC>(L, slot_out, 1, s, 0, P.info.split_k))) return fail(rc);
     return WS_OK;
 }
 

@@ -386,18 +386,19 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
         // the copy queue starts behind whatever the caller's queue still holds for this lane's witness buffer
         WS_HIP_CHECK(hipEventRecord(L.ev_start, s));
         WS_HIP_CHECK(hipStreamWaitEvent(sc, L.ev_start, 0));
+        WS_HIP_CHECK(hipStreamWaitEvent(L.stream_copy2, L.ev_start, 0));
         if ((rc = msm_plan_begin(L, nv, sh, s, K->table_cw))) return rc;
         unsigned k = 0;
         const uint64_t lo_sig = K->lo, hi_sig = (uint64_t)K->lo + nv;
-        rc = upload_pipelined(const_cast<Fe*>(d_witness_all), h_witness, (size_t)K->n_vars * 32, sc, [&](size_t blo, size_t bhi) -> int {
+        rc = upload_pipelined(const_cast<Fe*>(d_witness_all), h_witness, (size_t)K->n_vars * 32, sc, [&](size_t blo, size_t bhi, hipStream_t cq) -> int {
             hipEvent_t ev = L.ev_chunk[k++ & 1];             // (a wait captures the record that precedes it: two events suffice)
-            WS_HIP_CHECK(hipEventRecord(ev, sc));
+            WS_HIP_CHECK(hipEventRecord(ev, cq));
             WS_HIP_CHECK(hipStreamWaitEvent(s, ev, 0));
             uint64_t e0 = blo / 32, e1 = bhi / 32;            // signals of this chunk; the part of them this handle sums
             if (e0 < lo_sig) e0 = lo_sig;
             if (e1 > hi_sig) e1 = hi_sig;
             return e0 < e1 ? msm_plan_count(L, d_witness, e0 - lo_sig, e1 - lo_sig, s) : (int)WS_OK;
-        });
+        }, L.stream_copy2);
         if (rc) return rc;
         tr.mark("witness staged, histogram enqueued per chunk");
         WS_HIP_CHECK(hipEventRecord(L.ev_start, s));      // the whole witness is resident (s has waited for every chunk)

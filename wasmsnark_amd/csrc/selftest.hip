@@ -246,6 +246,34 @@ __global__ __launch_bounds__(64) void st_curve_kernel(int op, const typename C::
     if (!ok) *bad = 1;
 }
 
+// the paired G2 curve (fp2.h: Fp2PairT): two lanes per vector, lane p of a pair reads / writes component p of every coordinate
+__global__ __launch_bounds__(64) void st_curve_pair_kernel(int op, const Fe* __restrict__ p, const Fe* __restrict__ q, Fe* __restrict__ out,
+                                                             uint64_t n, int* __restrict__ bad) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = t >> 1;
+    const uint32_t h = (uint32_t)(t & 1);
+    if (i >= n) return;
+    const Fe pj[3] = {p[6 * i + h], p[6 * i + 2 + h], p[6 * i + 4 + h]};
+    const Fe qj[3] = {q[6 * i + h], q[6 * i + 2 + h], q[6 * i + 4 + h]};
+    bool ok;
+    const G2P29::PtP r = st_curve_op<G2P29>(op, pj, qj, &ok);
+    out[8 * i + h] = r.x; out[8 * i + 2 + h] = r.y; out[8 * i + 4 + h] = r.zz; out[8 * i + 6 + h] = r.zzz;
+    if (!ok) *bad = 1;
+}
+static int st_curve_pair_dev(int op, const uint8_t* p, const uint8_t* q, uint8_t* out, uint64_t n, hipStream_t s) {
+    StBufs B;
+    int rc = B.up(p, q, n * 192, n * 256, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(st_curve_pair_kernel, dim3(ceil_div_u64(2 * n, 64)), dim3(64), 0, s, op, B.a.as<Fe>(), B.b.as<Fe>(), B.out.as<Fe>(), n, B.bad.as<int>());
+    std::vector<G2::Pt> host(n);
+    if ((rc = B.down(reinterpret_cast<uint8_t*>(host.data()), n * sizeof(G2::Pt), s))) return rc;
+    for (uint64_t i = 0; i < n; i++) {
+        auto j = G2::to_affine_jac(host[i]);
+        memcpy(out + i * sizeof j, &j, sizeof j);
+    }
+    return WS_OK;
+}
+
 template <class C, class H>
 static int st_curve_dev(int op, const uint8_t* p, const uint8_t* q, uint8_t* out, uint64_t n, hipStream_t s) {
     typedef typename C::Field::Packed Pk;
@@ -296,6 +324,7 @@ int selftest_curve(int g, int impl, int op, const uint8_t* p, const uint8_t* q, 
         if (impl == 0) return st_curve_dev<G2R29, G2>(op, p, q, out, n, s);
         if (impl == 1) return st_curve_dev<G2, G2>(op, p, q, out, n, s);
         if (impl == 2) return st_curve_host<G2>(op, p, q, out, n);
+        if (impl == 4) return st_curve_pair_dev(op, p, q, out, n, s);
     }
     return WS_ERR_ARG;
 }
