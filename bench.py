@@ -7,19 +7,27 @@
 A "step" is one whole proof (CALC_H + 5 MSMs + assembly) of the SURVEY.md section 8d C4 circuit -- synthetic R1CS, domain
 2^20, 1-3 non-zeros per COLUMN of A and B (every variable present), valid witness, key from known toxic waste -- with
 the key and the witness already resident in HBM.  Every timed proof is checked (first and last) against the toxic-waste
-closed form.  For N > 1 the driver launches one rank per GPU (torch.distributed.run, backend nccl = RCCL): same key and
-witness on every rank, the Pippenger windows of all five sums sharded w % N == rank (strong scaling), ONE all_gather of
-the 576-byte records of partial sums per proof, host-side EC sum + assembly on every rank (RCCL has no elliptic-curve
-reduction).  N = 1 is the same code with a world of one and no collective.
+closed form.  For N > 1 the driver launches one rank per GPU (torch.distributed.run, backend nccl = RCCL): the same proof
+strong-scaled -- every rank holds a POINTS shard of the key (1/N of every section, wsnark_pkey_load_shard), CALC_H runs on the
+distributed four-step transform (three all-to-alls), ONE all_gather of the 592-byte records of partial sums per proof, host-side
+EC sum + assembly on every rank (RCCL has no elliptic-curve reduction); a mode that fails or disagrees with the closed form on
+any rank falls through to the next (native -> Python orchestration -> replicated CALC_H) and the line says so.  N = 1 is the
+one-call prover, no collective.
 
-Rank 0 prints ONE JSON line.  `value` = ms per proof (max over ranks).  Objects beside the contract's fields:
-  roofline          dominant kernel msm_accumulate_g1: algorithmic bytes (96 B/pair) per launch / mean launch duration from
-                    HIP events on the launching stream, inside the timed region; the HBM bound says little here --
-  roofline_int_alu  -- the governing bound: 256-bit modmul/s against the multiplier's measured peak
+Rank 0 prints ONE JSON line.  `value` = ms per proof (max over ranks), witness resident in HBM (the contract keeps PCIe out of
+`value`; the drop-in call from a HOST witness sits beside it).  Objects beside the contract's fields:
+  roofline          dominant kernel msm_accumulate_g1: algorithmic bytes (96 B/pair) per launch / mean launch duration from HIP events
+                    on the launching queue over the timed region (IN SITU: two-queue schedule), plus the same kernel ALONE (a few
+                    more proofs on one queue, same run) and what the committed rocprofv3 summaries of this command say (in situ under
+                    the profiler, and serialised -- where profiler and events agree); the HBM bound says little here --
+  roofline_int_alu  -- the governing bound: 256-bit modmul/s against the multiplier's peak measured in this run
+  roofline_proof    the whole proof: issue cycles of its VALU instruction stream (committed rocprofv3 --pmc SQ_INSTS_VALU over exactly
+                    P proofs) over the cycles one measured proof takes
   cpu_baseline      the oracle (C port of the reference's groth16GenProof: w=7 subset-table multiexp over worker threads,
-                    single-thread CALC_H) on a bounded sample, timed on this box's host cores, rank 0 at N=1
+                    single-thread CALC_H) on the benchmark's own circuit, timed on this box's host cores, rank 0 at N=1 (an N > 1
+                    line carries the last N = 1 measurement and says so)
   extras            G1 MSM 2^20 (one at a time / two in flight / host pointers), NTT 2^22 (odd 0, odd 1, inverse),
-                    proofs from a host witness, two proofs in flight, the sparse (round-1) circuit
+                    two proofs in flight, the sparse (round-1) circuit
 --workload msm keeps round 1's line (one G1 MSM of 2^20 pairs per step, weak scaling over ranks).
 """
 import argparse

@@ -229,15 +229,16 @@ int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s
     if (!C) return WS_ERR_NOINIT;
     if (!s) s = C->stream;
     if (bytes == 0) return WS_OK;
-    // s_alt (optional): a second copy queue; the chunks then alternate between the two, so that two DMAs are in flight at once
-    // (one queue feeds one SDMA engine: 32 MiB in ~0.95 ms = ~35 GB/s on the MI355X box, below what the link carries).
-    // WSNARK_STAGE_DUAL=0 keeps everything on `s`.
-    if (s_alt == s || !tuning_get("STAGE_DUAL", 1)) s_alt = nullptr;
+    // s_alt (optional): a second copy queue; with WSNARK_STAGE_DUAL=1 the chunks alternate between the two, so that two DMAs are
+    // in flight at once.  OFF by default: measured on the MI355X box (profiles/r04_s3_upload_sweep.txt) one queue already moves a
+    // pinned 32 MiB witness at 53.5 GB/s (0.63 ms) -- the link, not the engine, is the limit (two queues: 53.0 GB/s).
+    if (s_alt == s || !tuning_get("STAGE_DUAL", 0)) s_alt = nullptr;
     auto q = [&](size_t g) { return (s_alt && (g & 1)) ? s_alt : s; };
-    // chunk size: WSNARK_STAGE_CHUNK_KB (default 8 MiB from 16 MiB on, 4 MiB below; 64 KiB granules, 64 KiB .. 16 MiB).  Measured on
-    // the MI355X box with a 32 MiB witness (profiles/r04_s1_upload_sweep.txt): 8 MiB chunks and 4 copy threads cost the proof
-    // +1.12 ms over a resident witness, 4 MiB / 12 threads +1.6 ms, a pinned source DMA'd in place +0.99 ms -- the transfer itself.
-    size_t chunk = ((size_t)tuning_get("STAGE_CHUNK_KB", bytes >= ((size_t)16 << 20) ? 8192 : 4096) << 10) & ~(size_t)0xFFFF;
+    // chunk size: WSNARK_STAGE_CHUNK_KB (default 4 MiB; 64 KiB granules, 64 KiB .. 16 MiB).  Measured on the MI355X box with a
+    // 32 MiB witness (profiles/r04_s3_upload_sweep.txt): 4 MiB chunks and 4 copy threads cost the proof +0.95 ms over a resident
+    // witness, 16 MiB chunks +1.17, 8 threads +1.06, a pinned source DMA'd in place +0.97 -- of which 0.63 ms is the transfer
+    // itself at the link's 53.5 GB/s; 12 threads (round 4's first default) +1.6 ms.
+    size_t chunk = ((size_t)tuning_get("STAGE_CHUNK_KB", 4096) << 10) & ~(size_t)0xFFFF;
     chunk = chunk < ((size_t)64 << 10) ? ((size_t)64 << 10) : chunk > ((size_t)16 << 20) ? ((size_t)16 << 20) : chunk;
     int rc = WS_OK;
     // small copies, and sources that are ALREADY pinned (hipHostMalloc / hipHostRegister), need no staging
@@ -272,6 +273,16 @@ int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s
     if (chunk > C->pin_ring_bytes / 2) chunk = (C->pin_ring_bytes / 2) & ~(size_t)0xFFFF;
     size_t nslots = C->pin_ring_bytes / chunk;
     if (nslots > (size_t)PIN_MAX_SLOTS) nslots = PIN_MAX_SLOTS;
+    // A slot's event guards the bytes [slot * chunk, (slot + 1) * chunk) of the ring ONLY under the chunk size it was recorded
+    // with: an upload with another chunk size lays its slots over different bytes (two 4 MiB slots of the previous upload under one
+    // 8 MiB slot of this one), so it first waits for everything the previous geometry still has in flight.  (Found the hard way:
+    // a points shard's 8 MiB sections went up in 4 MiB chunks, the 16 MiB one behind them in 8 MiB chunks -- and overwrote the second
+    // half of its predecessor before that had left the ring.)
+    if (C->pin_chunk_last != chunk) {
+        for (auto& e : C->pin_ev)
+            if (hipEventSynchronize(e) != hipSuccess) { set_last_error("staged upload: a ring slot's DMA failed"); return WS_ERR_HIP; }
+        C->pin_chunk_last = chunk;
+    }
     const size_t G = (bytes + chunk - 1) / chunk;
     // workers: WSNARK_STAGE_WORKERS, default 4 (more only get in each other's way: the sweep above), 2 below 8 MiB
     const long env_w = tuning_get("STAGE_WORKERS", 0);
@@ -368,6 +379,13 @@ void KernelTimer::begin(const char* name, hipStream_t s) {
     t_gen = generation;
 }
 void KernelTimer::end(hipStream_t s) {
+    // WSNARK_SYNC_DEBUG=1 (with timing enabled): wait for every bracket and name it on stderr -- a faulting kernel is then the
+    // last name printed
+    static const bool sync_debug = [] { const char* e = getenv("WSNARK_SYNC_DEBUG"); return e && atoi(e) == 1; }();
+    if (sync_debug && enabled && t_rec >= 0) {
+        const hipError_t e = hipStreamSynchronize(s);
+        fprintf(stderr, "[wsnark sync] %s -> %s\n", recs[(size_t)t_rec].name, hipGetErrorString(e));
+    }
     if (!enabled || t_rec < 0) return;
     std::lock_guard<std::mutex> lk(mu);
     if (t_gen == generation && (size_t)t_rec < recs.size()) (void)hipEventRecord(recs[(size_t)t_rec].b, s);

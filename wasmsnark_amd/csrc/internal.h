@@ -100,6 +100,7 @@ struct Context {
     // host-pointer boundary: pinned staging ring for uploads
     void* pin_ring = nullptr;
     size_t pin_ring_bytes = 0;
+    size_t pin_chunk_last = 0;                  // chunk size of the last upload through the ring (slot geometry of the events)
     hipEvent_t pin_ev[128] = {};                // one per ring slot: the slot's last DMA
 };
 

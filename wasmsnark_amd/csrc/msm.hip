@@ -1207,14 +1207,20 @@ int msm_plan_begin(Lane& L, uint64_t n, WindowShard sh, hipStream_t s, uint32_t 
     // profiles/r03_s14_small_sums.txt).  WSNARK_MSM_SMALL_TASKS=0 switches the rule off (A/B).
     uint32_t lmin = 32;
     {
-        static const bool small_tasks = [] { const char* e = getenv("WSNARK_MSM_SMALL_TASKS"); return !(e && atoi(e) == 0); }();
+        const bool small_tasks = tuning_get("MSM_SMALL_TASKS", 1) != 0;
         if (small_tasks && I.nbuckets < (1u << 16) && total >= ((uint64_t)1 << 16)) {
             const uint32_t by_tasks = (uint32_t)((total + (1u << 17) - 1) >> 17);
             if (by_tasks < I.lmax) I.lmax = by_tasks;
             lmin = 8;
+        } else if (small_tasks && I.flat && I.nbuckets == (1u << 16) && I.lmax > 16) {
+            // Round 4, exactly 2^16 bucket runs (a rank's share of a 2^20 key over 8 ranks, 2^17 proofs): with the shorter reduction
+            // tails the accumulations are what is left of such a sum, and a lane's chain of ~30 additions (G2: 0.7 ms whatever the
+            // parallelism) is their floor -- runs cut at 16 entries + the G1 sets in one launch (msm_g1_launch_batch): the rank's four
+            // witness sums 1.80 -> 1.66 ms (profiles/r04_s4_shard_sweep.txt; round 3 had measured the opposite with its longer tails).
+            I.lmax = 16;
         }
     }
-    if (const char* e = getenv("WSNARK_MSM_LMAX")) { int v = atoi(e); if (v >= 4 && v <= 65536) { I.lmax = (uint32_t)v; lmin = 4; } }
+    { const long v = tuning_get("MSM_LMAX", 0); if (v >= 4 && v <= 65536) { I.lmax = (uint32_t)v; lmin = 4; } }
     if (I.lmax < lmin) I.lmax = lmin;
     I.hot_cap = (uint32_t)(total / I.lmax) + I.nbuckets + 16;
     const uint32_t c = I.c, W = I.W, nbuckets = I.nbuckets, lmax = I.lmax;
@@ -1742,8 +1748,8 @@ int msm_g1_launch_batch(Lane& L, const Affine<Fq>* const* d_points, int nsets, b
     // 2^18 proofs 4.15 vs 4.45 ms, 2^19 6.2 vs 6.43 ms; 2^14 / 2^16 proofs the other way: 1.55 vs 2.1 ms, 1.93 vs 2.4 ms with the
     // shorter tasks).  WSNARK_MSM_BATCH_ACC: 0 never, 1 always, unset = by size.
     const MsmPlanInfo& I0 = M.plan[plan_ids ? plan_ids[0] : M.cur].info;
-    static const int batch_env = [] { const char* e = getenv("WSNARK_MSM_BATCH_ACC"); return e ? atoi(e) : -1; }();
-    const bool batched = nsets > 1 && I0.valid && I0.n && (batch_env >= 0 ? batch_env != 0 : I0.nbuckets < (1u << 16));
+    const int batch_env = (int)tuning_get("MSM_BATCH_ACC", -1);
+    const bool batched = nsets > 1 && I0.valid && I0.n && (batch_env >= 0 ? batch_env != 0 : I0.nbuckets <= (1u << 16));
     for (int k = 0; k < nsets && !rc; k++) {
         if (plan_ids) msm_select_plan(L, plan_ids[k]);
         rc = msm_uses_field29() ? msm_launch_acc<G1R29, G1>(L, 0, d_points[k], prepared, &slots[k], s, false, batched)
@@ -1841,7 +1847,13 @@ int msm_prepare_points(int which, void* d_points, uint64_t n, hipStream_t s) {
 // One lane per point walks the rows with c doublings each (XYZZ, never normalised in between) and normalises
 // TABLE_GROUP rows with one shared inversion (Montgomery's trick on the ZZZ coordinates; 1/ZZ = ZZ^2 / ZZZ^2).
 // Key-load time only.
-static const uint32_t TABLE_GROUP = 8;
+// Rows normalised per shared inversion.  12 = all the rows of a 13-row table (c = 20) behind ONE Fermat inversion per point instead
+// of two (8 + 4): the inversion is ~380 products against 12 x 20 doublings x 9 = 2 160, so about -12 % of the build (the round-3
+// review's item 7; the group lives in scratch memory either way -- this kernel runs at key-load time only).
+#ifndef WS_TABLE_GROUP
+#define WS_TABLE_GROUP 12
+#endif
+static const uint32_t TABLE_GROUP = WS_TABLE_GROUP;
 template <class C>
 __global__ __launch_bounds__(256) void msm_table_kernel(typename C::AffP* __restrict__ table, uint64_t n, uint32_t c, uint32_t rows) {
     typedef typename C::Field F;
