@@ -186,7 +186,10 @@ def pmc_traffic(kernel, pairs_per_launch, windows):
     """HBM-side bytes per launch of `kernel`, measured out of band by tools/gpu_session.sh (rocprofv3 cannot wrap
     itself): two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) over this same command, summary committed."""
     # (two committed summaries: proofs on the table key -- 13 passes per launch at 2^20 -- and the plain 16-window launches)
-    for name in ("r03_final_pmc_traffic_table.json", "r03_s1_pmc_traffic_table.json", "r02_pmc_traffic_table.json", "r02_pmc_traffic.json"):
+    latest = _latest_profile("*pmc_traffic_table.json")
+    calib = _latest_profile("*pmc_calibration.json")
+    names = ([os.path.basename(latest)] if latest else []) + ["r03_final_pmc_traffic_table.json", "r02_pmc_traffic_table.json", "r02_pmc_traffic.json"]
+    for name in names:
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
             k = pm["kernels"][kernel]
@@ -194,7 +197,8 @@ def pmc_traffic(kernel, pairs_per_launch, windows):
             if abs(pairs_per_launch - shape["pairs_per_launch"]) > 16 or windows != shape["windows_per_launch"]:
                 continue        # the committed summary was taken on another launch shape: not quoted
             return k["fetch_bytes"] + k["write_bytes"], ("profiles/%s: %s; FETCH_SIZE calibrated on this access pattern (64-B point gathers out of a 1 GiB table: counter / known bytes = 1.00, "
-                                                         "profiles/r03_s1_pmc_calibration.json)" % (name, pm.get("how", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bytes per launch")))
+                                                         "profiles/%s)" % (name, pm.get("how", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bytes per launch"),
+                                                                         os.path.basename(calib) if calib else "r03_s1_pmc_calibration.json"))
         except Exception:  # noqa: BLE001
             continue
     return None, None
@@ -237,6 +241,11 @@ def rocprof_citation(alg_bytes):
             m["GBps"] = round(alg_bytes / (m["mean_ms"] / 1e3) / 1e9, 2)
             m["hbm_frac"] = round(m["GBps"] / HBM_PEAK_GBS, 5)
             out[key] = m
+    if out:
+        out["how_to_read"] = ("serialised_one_queue is the same command with WSNARK_PROVE_OVERLAP=0: every kernel alone -- compare with "
+                              "roofline.avg_launch_ms (basis alone); in_situ_two_queues is the shipped schedule UNDER the profiler, whose per-dispatch "
+                              "instrumentation stretches a proof by ~0.2-0.5 ms and changes the overlap -- compare with the events of THAT run "
+                              "(profiles/*bench_under_rocprof.json), not with roofline.in_situ of an unprofiled run")
     return out or None
 
 
@@ -282,32 +291,42 @@ def measure_peaks(bn):
 
 
 def rooflines(kt, kernel, pairs_per_launch, windows_owned, bytes_per_pair, modmul_per_add, peak=None, alone_ms=None, cite_rocprof=False):
+    """Both rooflines of the dominant kernel.  Basis of `achieved` / `frac`: the launch ALONE when this run measured it (HIP events
+    around the kernel in proofs that run on one queue, right after the timed region) -- a kernel's roofline is the kernel's, and it
+    is the figure a profiler reproduces (rocprofv3 instruments every dispatch and thereby changes which kernels of a two-queue
+    proof share the SIMDs; with one queue it agrees with the events: profiles/*kernel_stats_proofs_only_serialised.csv) -- with the
+    launch IN SITU (events over the timed region, two-queue schedule, no profiler) beside it in `in_situ`.  Without an alone
+    pass (N > 1, --no-alone-pass, stand-alone MSM) the in-situ figure is the basis and `basis` says so."""
     ms, cnt = kt.get(kernel, (0.0, 0))
     if not cnt or ms <= 0:
         return None, None
-    avg_s = ms / cnt / 1e3
+    situ_ms = ms / cnt
     alg = bytes_per_pair * pairs_per_launch
-    achieved = alg / avg_s / 1e9
+    modmul = modmul_per_add * windows_owned * pairs_per_launch
+    base_ms = alone_ms if alone_ms else situ_ms
+    basis = ("alone: HIP events around the kernel, same run, proofs on ONE queue (WSNARK_PROVE_OVERLAP=0 through wsnark_tuning_set) "
+             "right after the timed region" if alone_ms else
+             "in situ: HIP events on the launching queue over the timed region (whatever the lane's other queue runs beside the kernel is inside)")
+    achieved = alg / (base_ms / 1e3) / 1e9
     # the committed PMC summary names the launch shape it was taken on: only quoted for that shape
     traffic, src = pmc_traffic(kernel, pairs_per_launch, windows_owned)
-    modmul = modmul_per_add * windows_owned * pairs_per_launch
-    g = modmul / avg_s / 1e9
     hbm = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": src,
-           "avg_launch_ms": round(ms / cnt, 4), "launches_timed": cnt, "algorithmic_bytes_per_launch": int(alg),
-           "avg_launch_ms_is": "HIP events on the launching queue over the timed region: the launch IN SITU (two-queue schedule, no profiler)",
+           "avg_launch_ms": round(base_ms, 4), "basis": basis, "launches_timed": cnt, "algorithmic_bytes_per_launch": int(alg),
+           "in_situ": {"avg_launch_ms": round(situ_ms, 4), "GBps": round(alg / (situ_ms / 1e3) / 1e9, 2),
+                       "frac": round(alg / (situ_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5), "launches_timed": cnt,
+                       "what": "HIP events on the launching queue over the timed region: the two-queue schedule, no profiler"},
            "note": "reported because the contract asks for it; the kernel is integer-ALU bound (see roofline_int_alu): "
                    "~%d modmul per %d bytes" % (modmul_per_add * windows_owned, bytes_per_pair)}
-    if alone_ms:
-        hbm["avg_launch_ms_alone"] = round(alone_ms, 4)
-        hbm["frac_alone"] = round(alg / (alone_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5)
-        hbm["avg_launch_ms_alone_is"] = "HIP events, same run, proofs with WSNARK_PROVE_OVERLAP=0 (one queue: nothing shares the SIMDs)"
     if cite_rocprof:
         hbm["rocprofv3"] = rocprof_citation(alg)
     live = max([v for k, v in (peak or {}).items() if k.startswith("modmul") and v] or [0])
     pk = live or MODMUL_PEAK_G
+    g = modmul / (base_ms / 1e3) / 1e9
     alu = {"bound": "int-alu", "kernel": kernel, "achieved": round(g, 1), "peak": pk, "unit": "Gmodmul/s",
-           "frac": round(g / pk, 4), "modmul_per_launch": int(modmul), "windows_per_launch": windows_owned,
+           "frac": round(g / pk, 4), "basis": "alone" if alone_ms else "in situ",
+           "in_situ": {"achieved": round(modmul / (situ_ms / 1e3) / 1e9, 1), "frac": round(modmul / (situ_ms / 1e3) / 1e9 / pk, 4)},
+           "modmul_per_launch": int(modmul), "windows_per_launch": windows_owned,
            "peak_source": ("wsnark_peak_probe in this run on this box: dependent chain of the library's radix-2^29 Montgomery product "
                            "(162 v_mad_u64_u32 each) on 8 x 256 lanes per CU; best of 3 after a warm-up launch" if live else
                            "tools/microbench.hip on MI355X, round 1 (profiles/r01_session17_microbench.jsonl): not re-measured in this run"),

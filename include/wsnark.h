@@ -141,9 +141,11 @@ int wsnark_pkey_info(const wsnark_pkey_t* handle, uint32_t* n_vars, uint32_t* n_
 int wsnark_pkey_table_info(const wsnark_pkey_t* handle, uint32_t* c_w, uint32_t* rows_w, uint32_t* c_h, uint32_t* rows_h,
                            uint64_t* bytes);
 
-/* Wall-clock of the handle's load, in ms: [0] pols -> CSR, [1] point sections host -> device, [2] infinity masks +
- * conversion to the device field's domain, [3] fixed-base table build, [4] the whole call -- what a cold caller pays
- * before its first proof (the reference re-parses the key inside every groth16GenProof call, src/bn128.js:581-604). */
+/* Wall-clock of the handle's load, in ms: [1] point sections host -> device, [2] infinity masks + conversion to the device
+ * field's domain, [3] fixed-base table build, [4] the whole call ([1] + [2] + [3]) -- what a cold caller pays before its first
+ * proof (the reference re-parses the key inside every groth16GenProof call, src/bn128.js:581-604); [0] = the transposition of
+ * polsA / polsB into CSR, which runs UNDER [3] (header walk on the host, upload and kernels on queues of their own while the
+ * table kernels run): its own wall-clock, not an addend of the total. */
 int wsnark_pkey_load_stats(const wsnark_pkey_t* handle, double* ms5);
 
 /* The same key given as separate host buffers with 64-bit lengths: proving_key.bin addresses its

@@ -30,7 +30,7 @@ for f in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"),
             name = row.get("Kernel_Name") or row.get("Kernel Name") or ""
             m = re.search(r"wsnark::([A-Za-z0-9_]+)", name)
             short = m.group(1) if m else name.split("(")[0].replace("void ", "").strip()[:60]
-            if m and ("Fp2T" in name or "Fe2T" in name):
+            if m and ("Fp2" in name or "Fe2T" in name):
                 short += "_g2"
             try:
                 acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))

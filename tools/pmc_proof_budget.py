@@ -43,7 +43,7 @@ lo, hi = marks[gap - 1], marks[gap]
 def short(name):
     m = re.search(r"wsnark::([A-Za-z0-9_]+)", name)
     s = m.group(1) if m else name.split("(")[0].replace("void ", "").strip()[:60]
-    if m and ("Fp2T" in name or "Fe2T" in name):
+    if m and ("Fp2" in name or "Fe2T" in name):
         s += "_g2"
     return s
 

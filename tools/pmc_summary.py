@@ -28,7 +28,7 @@ for ctr, key in (("FETCH_SIZE", "fetch_bytes"), ("WRITE_SIZE", "write_bytes")):
                 m = re.search(r"wsnark::([A-Za-z0-9_]+)", name)
                 short = m.group(1) if m else name.split("(")[0].replace("void ", "").strip()[:60]
                 # distinguish the G1 / G2 instantiations of the templated MSM kernels
-                if m and ("Fp2T" in name or "Fe2T" in name):
+                if m and ("Fp2" in name or "Fe2T" in name):
                     short += "_g2"
                 try:
                     acc[short].append(float(row["Counter_Value"]) * 1024.0)

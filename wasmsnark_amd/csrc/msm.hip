@@ -1218,6 +1218,7 @@ int msm_plan_begin(Lane& L, uint64_t n, WindowShard sh, hipStream_t s, uint32_t 
             // parallelism) is their floor -- runs cut at 16 entries + the G1 sets in one launch (msm_g1_launch_batch): the rank's four
             // witness sums 1.80 -> 1.66 ms (profiles/r04_s4_shard_sweep.txt; round 3 had measured the opposite with its longer tails).
             I.lmax = 16;
+            lmin = 16;
         }
     }
     { const long v = tuning_get("MSM_LMAX", 0); if (v >= 4 && v <= 65536) { I.lmax = (uint32_t)v; lmin = 4; } }

@@ -132,27 +132,7 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
         return ms;
     };
     auto t_phase = t_begin;
-    // the two record streams are transposed side by side (host threads; the B side on a queue of its own)
     int rc;
-    {
-        hipStream_t sb = nullptr;
-        WS_HIP_CHECK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
-        size_t used_b = 0;
-        const int device = C->device;
-        std::string err_b;                      // (the error text is per thread: carried back by hand)
-        std::future<int> fb = std::async(std::launch::async, [&, device, sb]() {
-            if (hipSetDevice(device) != hipSuccess) return (int)WS_ERR_HIP;
-            const int r = pols_to_csr(S.polsB, (size_t)S.lenB, nv, dom, &K->polsB, &used_b, sb);
-            if (r) err_b = get_last_error();
-            return r;
-        });
-        rc = pols_to_csr(S.polsA, (size_t)S.lenA, nv, dom, &K->polsA, &used, s);
-        const int rcb = fb.get();
-        (void)hipStreamDestroy(sb);
-        if (rc) return rc;
-        if (rcb) { set_last_error(err_b); return rcb; }
-    }
-    K->load_ms[0] = lap(t_phase);
     // the rank's slice of every section.  C holds points for signals nPublic+1.. only (src/bn128.js:620 slices the scalars
     // instead).  Resident copy: padded in front with infinities (x == 0) for the signals 0..nPublic, so that the C sum uses
     // the SAME scalar vector -- and the same digit/sort plan -- as A, B1 and B2: local index i = signal lo + i everywhere.
@@ -228,8 +208,32 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
         if ((rc = msm_build_table(0, K->pointsC.p, nl, K->table_cw, s))) return rc;
         if ((rc = msm_build_table(0, K->pointsH.p, hl, K->table_ch, s))) return rc;
     }
+    // The two record streams are transposed (calch.hip: pols_to_csr -- a header walk on the host, upload, three kernels each)
+    // on queues of their own WHILE the table kernels above run: the walk and the 0.18 GB of PCIe traffic cost the load nothing
+    // (round 3 did this first, on its own: 56-65 ms of a 2^20 key's 214).
+    {
+        hipStream_t sa = nullptr, sb = nullptr;
+        WS_HIP_CHECK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
+        WS_HIP_CHECK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+        size_t used_b = 0;
+        const int device = C->device;
+        std::string err_b;                      // (the error text is per thread: carried back by hand)
+        std::future<int> fb = std::async(std::launch::async, [&, device, sb]() {
+            if (hipSetDevice(device) != hipSuccess) return (int)WS_ERR_HIP;
+            const int r = pols_to_csr(S.polsB, (size_t)S.lenB, nv, dom, &K->polsB, &used_b, sb);
+            if (r) err_b = get_last_error();
+            return r;
+        });
+        rc = pols_to_csr(S.polsA, (size_t)S.lenA, nv, dom, &K->polsA, &used, sa);
+        const int rcb = fb.get();
+        (void)hipStreamDestroy(sa);
+        (void)hipStreamDestroy(sb);
+        if (rc) { (void)hipStreamSynchronize(s); return rc; }
+        if (rcb) { (void)hipStreamSynchronize(s); set_last_error(err_b); return rcb; }
+    }
+    K->load_ms[0] = std::chrono::duration<double, std::milli>(Clock::now() - t_phase).count();      // host-side wall of the transposition (the table build runs under it)
     WS_HIP_CHECK(hipStreamSynchronize(s));
-    K->load_ms[3] = lap(t_phase);
+    K->load_ms[3] = lap(t_phase);               // the table build, the transposition of the matrices under it
     K->load_ms[4] = std::chrono::duration<double, std::milli>(Clock::now() - t_begin).count();
     *out = K.release();
     return WS_OK;
