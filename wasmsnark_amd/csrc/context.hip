@@ -253,6 +253,17 @@ int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s
     }
 #endif
     if (direct) {
+        // A pinned source goes up in ONE DMA (WSNARK_STAGE_DIRECT_CHUNK_KB cuts it): measured on the MI355X box with the 32 MiB witness
+        // (profiles/r04_s6_pinned_sweep.txt), proof from the pinned buffer minus proof from a resident witness: one DMA +0.73-0.87 ms,
+        // 4 MiB pieces with the histogram per piece +0.95-0.97 -- every copy command has its own start-up, and the 0.06 ms of histogram
+        // it would hide is less than that.  (A plain copy + synchronise + resident proof costs +0.92: the link's 0.63 ms plus ~0.3 ms
+        // that a proof loses by starting on a GPU whose shader clocks have idled during the transfer.)
+        chunk = bytes;
+        { const long v = tuning_get("STAGE_DIRECT_CHUNK_KB", 0); if (v >= 64) chunk = ((size_t)v << 10) & ~(size_t)0xFFFF; }
+#ifdef WSNARK_EMUL
+        chunk = ((size_t)tuning_get("STAGE_CHUNK_KB", 4096) << 10) & ~(size_t)0xFFFF;       // (tests: the chunked bookkeeping on small inputs)
+        if (chunk < ((size_t)64 << 10)) chunk = (size_t)64 << 10;
+#endif
         const size_t G = (bytes + chunk - 1) / chunk;
         for (size_t g = 0; g < G; g++) {
             const size_t lo = g * chunk, hi = lo + chunk < bytes ? lo + chunk : bytes;

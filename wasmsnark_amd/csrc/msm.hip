@@ -1647,7 +1647,11 @@ static int msm_launch_tail(Lane& L, const int* slot_ids, int nslots, hipStream_t
     WS_HIP_CHECK(hipGetLastError());
     // one slot per element of the longest strided sum (J/2 for the masked rows), at most 64 KiB of LDS and 512 threads
     uint32_t tslots = 1;
-    const uint32_t smax = sizeof(St) > 128 ? 256 : 512;
+    // (256 slots per workgroup for G1 as well: at 152 VGPRs a 512-thread workgroup is one per CU and a full-size tree launch takes
+    //  three rounds of them; 256 threads fit three per CU -- prove 2^20 9.53 -> 9.51 ms, 2^16 1.55 -> 1.51-1.54, profiles/r04_s6_*)
+    uint32_t smax = 256;
+    { const long v = tuning_get("TREE_SLOTS", 0); if (v >= 32 && v <= 512) smax = (uint32_t)v; }
+    if (sizeof(St) > 128 && smax > 256) smax = 256;
     while (tslots < (J > 1 ? J / 2 : 1) && tslots < smax && tslots * LPP < (uint32_t)TreeBound<C>::value) tslots <<= 1;
     T.begin("msm_tree", s);
     hipLaunchKernelGGL(msm_tree<C>, dim3(nsum, W, nslots), dim3(tslots * LPP), (size_t)tslots * sizeof(St), s, ts, J, logJ, w0, I.reduce ? 0u : 1u);
