@@ -362,6 +362,48 @@ def test_prove_vs_toxic_waste_closed_form(bn, logd, style):
     key.free()
 
 
+def test_host_witness_paths_and_runtime_switches(bn):
+    """Round 4: a witness in HOST memory reaches the GPU by three routes -- pageable memory through the pinned ring (chunk by chunk,
+    the grouping histogram taken per arriving chunk; ring slots reused: 64 KiB chunks through a ring the first upload sized), the same
+    with the whole witness uploaded before the first kernel, and a PINNED buffer (wsnark_host_alloc) DMA'd in place -- and the
+    reduction tail has its round-3 and round-4 geometries behind run-time switches (wsnark_tuning_set).  Every combination must give
+    the closed-form proof at 2^18 (129 chunks of the witness at the smallest chunk size: one more than the ring has slots), on the whole key and on a points shard."""
+    import ctypes as C
+    from wasmsnark_amd import synth
+    circ = synth.NativeCircuit(bn.lib, 18, n_public=5, seed=44)
+    sec, _ = circ.build_sections()
+    wit = circ.witness_bin()
+    r, s = os.urandom(32), os.urandom(32)
+    want = circ.expected_proof(r, s)
+    key = bn.load_key(sections=sec)
+    pinned = C.c_void_p()
+    bn.lib.check(bn.lib.c.wsnark_host_alloc(len(wit), C.byref(pinned)))
+    names = ("STAGE_CHUNK_KB", "STAGE_WORKERS", "PROVE_CHUNKED_UPLOAD", "STAGE_DUAL", "STAGE_DIRECT_CHUNK_KB", "MSM_CHUNK", "TAIL_BITS", "TAIL_REDUCE", "G2_TAIL_PAIR")
+    try:
+        C.memmove(pinned, wit, len(wit))
+        for cfg in ({}, {"STAGE_CHUNK_KB": 64, "STAGE_WORKERS": 3}, {"STAGE_CHUNK_KB": 1024, "STAGE_DUAL": 1}, {"PROVE_CHUNKED_UPLOAD": 0},
+                    {"STAGE_DIRECT_CHUNK_KB": 1024}, {"MSM_CHUNK": 8, "TAIL_BITS": 15, "TAIL_REDUCE": 0, "G2_TAIL_PAIR": 0}, {"MSM_CHUNK": 2, "TAIL_BITS": 10}):
+            for n in names:
+                bn.lib.tune(n, cfg.get(n))
+            assert bn.groth16GenProof(wit, key, r=r, s=s) == want, cfg
+            assert bn.groth16GenProof_hostptr(pinned.value, len(wit), key, r=r, s=s) == want, cfg
+        for n in names:
+            bn.lib.tune(n, None)
+        key.free()
+        recs = b""
+        for rank in range(2):
+            k = bn.load_key(sections=sec, shard=(rank, 2))
+            recs += bn.groth16_prove_partial(wit, k, shard=(rank, 2))
+            if rank == 0:
+                k.free()
+        assert bn.groth16_prove_finish(k, recs, r=r, s=s) == want
+        k.free()
+    finally:
+        for n in names:
+            bn.lib.tune(n, None)
+        bn.lib.c.wsnark_host_free(pinned)
+
+
 def test_sections_loader_2p18_equals_file_loader(bn):
     """wsnark_pkey_load_sections (the container for keys beyond proving_key.bin's 4 GiB of u32 offsets: BASELINE
     config 5) against wsnark_pkey_load on the same 2^18 key: same proofs, equal to the closed form; short
