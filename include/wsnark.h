@@ -141,11 +141,19 @@ int wsnark_pkey_info(const wsnark_pkey_t* handle, uint32_t* n_vars, uint32_t* n_
 int wsnark_pkey_table_info(const wsnark_pkey_t* handle, uint32_t* c_w, uint32_t* rows_w, uint32_t* c_h, uint32_t* rows_h,
                            uint64_t* bytes);
 
+/* The table rows beyond the plain sections are built in the BACKGROUND: wsnark_pkey_load* return as soon as the sections are
+ * resident (about 40 ms for a 0.59 GB key instead of 160), proofs that start before the build is over (~130 ms at 2^20) run on the
+ * plain sections -- same results, ~15 % slower -- and later ones on the tables.  This call blocks until the handle's tables are
+ * built (benchmarks; callers that want the steady state before their first proof).  WSNARK_TABLE_ASYNC=0 makes the load itself wait,
+ * as in round 3.  Calls that shard the WINDOWS of a whole key over ranks (wsnark_groth16_prove_partial with world > 1 on a whole
+ * key) wait by themselves: their partial sums must mean the same on every rank. */
+int wsnark_pkey_wait_tables(wsnark_pkey_t* handle);
+
 /* Wall-clock of the handle's load, in ms: [1] point sections host -> device, [2] infinity masks + conversion to the device
- * field's domain, [3] fixed-base table build, [4] the whole call ([1] + [2] + [3]) -- what a cold caller pays before its first
- * proof (the reference re-parses the key inside every groth16GenProof call, src/bn128.js:581-604); [0] = the transposition of
- * polsA / polsB into CSR, which runs UNDER [3] (header walk on the host, upload and kernels on queues of their own while the
- * table kernels run): its own wall-clock, not an addend of the total. */
+ * field's domain, [0] polsA / polsB -> CSR (header walk on the host, upload, transposition on the GPU), [3] fixed-base table
+ * build, [4] the whole call -- what a cold caller waits before its first proof (the reference re-parses the key inside every
+ * groth16GenProof call, src/bn128.js:581-604).  With the background build (the default) [4] = [1] + [2] + [0] and [3] is the
+ * build's own duration on the GPU (0 until it is over); with WSNARK_TABLE_ASYNC=0 the call waits for it and [4] includes it. */
 int wsnark_pkey_load_stats(const wsnark_pkey_t* handle, double* ms5);
 
 /* The same key given as separate host buffers with 64-bit lengths: proving_key.bin addresses its

@@ -47,6 +47,8 @@ res["ctypes_proofs_match_closed_form"] = bool(p == want and p2 == want)
 key.free()
 bn.lib.shutdown()          # the Node process gets the GPU to itself
 out = subprocess.run(["node", os.path.join(ROOT, "tools", "node_bench.js"), kp, wp, str(reps)], capture_output=True, text=True, timeout=900)
+if os.environ.get("NODE_BENCH_STDERR"):
+    sys.stderr.write(out.stderr[:6000])
 line = [l for l in out.stdout.splitlines() if l.startswith("NODE_BENCH ")]
 if not line:
     res["node_error"] = (out.stdout + out.stderr)[-1500:]

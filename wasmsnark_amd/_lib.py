@@ -21,7 +21,7 @@ SYMBOLS = [
     "wsnark_fr_ntt", "wsnark_fr_ntt_dev", "wsnark_fr_ntt_batch_dev", "wsnark_fr_dist_scale_dev",
     "wsnark_pkey_eval_ab_dev", "wsnark_fr_mul_dev", "wsnark_fr_dist_combine_dev", "wsnark_fr_to_montgomery", "wsnark_fr_from_montgomery",
     "wsnark_calc_h", "wsnark_pkey_load", "wsnark_pkey_free", "wsnark_pkey_info", "wsnark_pkey_table_info",
-    "wsnark_groth16_prove", "wsnark_groth16_prove_dev", "wsnark_pkey_load_sections", "wsnark_pkey_load_shard", "wsnark_pkey_shard_info", "wsnark_pkey_load_stats", "wsnark_pkey_h_msm_dev", "wsnark_last_blinding", "wsnark_groth16_verify",
+    "wsnark_groth16_prove", "wsnark_groth16_prove_dev", "wsnark_pkey_load_sections", "wsnark_pkey_load_shard", "wsnark_pkey_shard_info", "wsnark_pkey_load_stats", "wsnark_pkey_wait_tables", "wsnark_pkey_h_msm_dev", "wsnark_last_blinding", "wsnark_groth16_verify",
     "wsnark_groth16_prove_partial", "wsnark_groth16_prove_partial_dev", "wsnark_groth16_prove_finish", "wsnark_groth16_prove_dist",
     "wsnark_g1_mul_base_batch", "wsnark_g2_mul_base_batch",
     "wsnark_synth_new", "wsnark_synth_free", "wsnark_synth_info", "wsnark_synth_witness", "wsnark_synth_pols",
@@ -97,6 +97,7 @@ class Lib:
         c.wsnark_host_free.argtypes = [vp]
         c.wsnark_host_free.restype = None
         c.wsnark_pkey_load_stats.argtypes = [vp, C.POINTER(C.c_double)]
+        c.wsnark_pkey_wait_tables.argtypes = [vp]
         c.wsnark_pkey_h_msm_dev.argtypes = [vp, vp, u64, vp, vp]
         c.wsnark_groth16_prove_partial.argtypes = [vp, vp, sz, u32, u32, u32, vp]
         c.wsnark_groth16_prove_partial_dev.argtypes = [vp, vp, sz, u32, u32, u32, vp, vp]

@@ -60,9 +60,13 @@ class _KeySections(C.Structure):   # wsnark_key_sections_t
 class ProvingKey:
     """Device-resident proving key (wsnark_pkey_load, or wsnark_pkey_load_sections for `sections`)."""
 
-    def __init__(self, lib, data=None, sections=None, shard=None, h_interleave_log=0):
+    def __init__(self, lib, data=None, sections=None, shard=None, h_interleave_log=0, wait_tables=True):
         """shard=(rank, world) with `sections`: only that rank's share of the points becomes resident
-        (wsnark_pkey_load_shard; h_interleave_log: the layout of its hExps share, see include/wsnark.h)."""
+        (wsnark_pkey_load_shard; h_interleave_log: the layout of its hExps share, see include/wsnark.h).
+        wait_tables: the library builds the fixed-base table rows in the background and serves proofs from the plain sections
+        until they are there; this mirror waits for them by default (tests and timing tools want the steady state from the first
+        call); wait_tables=False returns as the C call does -- `load_ms` then holds what the caller waited for, and
+        `wait_tables()` / `refresh_load_stats()` complete the picture later."""
         self._lib = lib
         self._h = C.c_void_p()
         if shard is not None and sections is None:
@@ -93,15 +97,26 @@ class ProvingKey:
         lib.check(lib.c.wsnark_pkey_table_info(self._h, C.byref(cw), C.byref(rw), C.byref(ch), C.byref(rh), C.byref(nb)))
         # how the point sections are resident: fixed-base window tables (rows > 1) or the plain sections
         self.table = {"c_w": cw.value, "rows_w": rw.value, "c_h": ch.value, "rows_h": rh.value, "bytes": nb.value}
-        ms = (C.c_double * 5)()
-        lib.check(lib.c.wsnark_pkey_load_stats(self._h, ms))
-        self.load_ms = {"pols_to_csr": ms[0], "points_h2d": ms[1], "masks_convert": ms[2], "table_build": ms[3], "total": ms[4]}
+        if wait_tables:
+            lib.check(lib.c.wsnark_pkey_wait_tables(self._h))
+        self.refresh_load_stats()
         rk, wd, hl = C.c_uint32(), C.c_uint32(), C.c_uint32()
         lo, nl, nh = C.c_uint64(), C.c_uint64(), C.c_uint64()
         lib.check(lib.c.wsnark_pkey_shard_info(self._h, C.byref(rk), C.byref(wd), C.byref(lo), C.byref(nl), C.byref(nh), C.byref(hl)))
         # which share of the points this handle holds (a whole key: rank 0 of 1, all nVars signals, all hExps)
         self.shard = {"rank": rk.value, "world": wd.value, "first_signal": lo.value, "n_signals": nl.value, "n_hexps": nh.value,
                       "h_interleave_log": hl.value}
+
+    def wait_tables(self):
+        """Block until the background build of the table rows is over (wsnark_pkey_wait_tables)."""
+        self._lib.check(self._lib.c.wsnark_pkey_wait_tables(self._h))
+        self.refresh_load_stats()
+
+    def refresh_load_stats(self):
+        ms = (C.c_double * 5)()
+        self._lib.check(self._lib.c.wsnark_pkey_load_stats(self._h, ms))
+        # total = what the load call took; table_build = the background build's own duration (0 while it is still running)
+        self.load_ms = {"pols_to_csr": ms[0], "points_h2d": ms[1], "masks_convert": ms[2], "table_build": ms[3], "total": ms[4]}
 
     def free(self):
         if self._h:
@@ -220,8 +235,8 @@ class Bn128:
         self.lib.check(fn(b, s, n, out))
         return bytes(out)[: n * sz]
 
-    def load_key(self, pkey=None, sections=None, shard=None, h_interleave_log=0):
-        return ProvingKey(self.lib, pkey, sections, shard, h_interleave_log)
+    def load_key(self, pkey=None, sections=None, shard=None, h_interleave_log=0, wait_tables=True):
+        return ProvingKey(self.lib, pkey, sections, shard, h_interleave_log, wait_tables)
 
     def h_multiexp_dev(self, key, d_h_slice, n, stream=None):
         """The H sum of one rank against the key handle's resident hExps share (wsnark_pkey_h_msm_dev)."""

@@ -29,6 +29,7 @@ struct KeyShard { uint32_t rank = 0, world = 1, h_log_m = 0; };
 int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard);
 void pkey_shard_info(const ProvingKey* K, uint32_t* rank, uint32_t* world, uint64_t* lo, uint64_t* n_local, uint64_t* h_local, uint32_t* h_log_m);
 void pkey_load_stats(const ProvingKey* K, double* out5);
+int pkey_wait_tables(ProvingKey* K);
 int groth16_prove_dist(ProvingKey* K, const Fe* d_witness, size_t witness_len, const DistComm& cm, const uint8_t* r32, const uint8_t* s32,
                        uint8_t* out384, hipStream_t s);
 int pkey_h_msm_dev(ProvingKey* K, const Fe* d_h_local, uint64_t n, uint8_t* out96, hipStream_t s);
@@ -285,6 +286,11 @@ int wsnark_pkey_load_stats(const wsnark_pkey_t* h, double* ms5) {
     if (!h || !ms5) return WSNARK_ERR_ARG;
     pkey_load_stats(reinterpret_cast<const ProvingKey*>(h), ms5);
     return WSNARK_OK;
+}
+int wsnark_pkey_wait_tables(wsnark_pkey_t* h) {
+    REQUIRE_CTX();
+    if (!h) return WSNARK_ERR_ARG;
+    return pkey_wait_tables(reinterpret_cast<ProvingKey*>(h));
 }
 int wsnark_pkey_h_msm_dev(wsnark_pkey_t* h, const void* d_h_slice, uint64_t n, void* out96_host, void* stream) {
     REQUIRE_CTX();

@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
 #include <future>
 
@@ -43,9 +44,39 @@ struct ProvingKey {
     // wall-clock of the load, by phase (ms): pols -> CSR, point sections host -> device, masks + conversion to the device
     // field's domain, fixed-base table build, whole call (what a cold caller pays before its first proof)
     double load_ms[5] = {0, 0, 0, 0, 0};
-    // Read-only after load: any number of proofs may use one handle at once (each on its own lane, which holds the
+    // Round 4: the table rows 1.. are built IN THE BACKGROUND (queue `build_q`): the load returns once the sections are resident
+    // and converted (row 0 of every table = the plain section), proofs that arrive before `ev_tables` has fired run on the
+    // plain sections (per-window plans: the round-1 / 2 path, ~15 % slower), later ones on the tables.  `tables_ready` only ever
+    // goes 0 -> 1.  WSNARK_TABLE_ASYNC=0: the load waits for the build as in round 3.
+    hipStream_t build_q = nullptr;
+    hipEvent_t ev_build0 = nullptr, ev_tables = nullptr;      // (timing events: their distance is the build's duration)
+    std::atomic<int> tables_ready{1};
+    // Otherwise read-only after load: any number of proofs may use one handle at once (each on its own lane, which holds the
     // per-proof buffers and events).
+    ~ProvingKey() {
+        if (build_q) { (void)hipStreamSynchronize(build_q); (void)hipStreamDestroy(build_q); }
+        if (ev_build0) (void)hipEventDestroy(ev_build0);
+        if (ev_tables) (void)hipEventDestroy(ev_tables);
+    }
 };
+
+// which window width a call that starts NOW may plan with: the tables' once they are built (wait = block until they are: calls
+// whose partial results must mean the same on every rank), 0 = the plain sections
+static void pkey_table_state(ProvingKey* K, bool wait, uint32_t* cw, uint32_t* ch) {
+    *cw = K->table_cw; *ch = K->table_ch;
+    if (!K->table_cw || K->tables_ready.load(std::memory_order_acquire)) return;
+    if (wait ? hipEventSynchronize(K->ev_tables) == hipSuccess : hipEventQuery(K->ev_tables) == hipSuccess) {
+        K->tables_ready.store(1, std::memory_order_release);
+        return;
+    }
+    (void)hipGetLastError();      // (hipErrorNotReady is not an error here)
+    *cw = *ch = 0;
+}
+int pkey_wait_tables(ProvingKey* K) {
+    uint32_t cw, ch;
+    pkey_table_state(K, true, &cw, &ch);
+    return (K->table_cw && !cw) ? (int)WS_ERR_HIP : (int)WS_OK;
+}
 
 const std::string& get_last_error();
 
@@ -201,16 +232,10 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
     if ((rc = msm_prepare_points(0, K->pointsC.p, nl, s))) return rc;
     if ((rc = msm_prepare_points(0, K->pointsH.p, hl, s))) return rc;
     K->load_ms[2] = lap(t_phase);
-    if (K->table_cw) {      // rows 1.. of the tables, from row 0, in that domain
-        if ((rc = msm_build_table(0, K->pointsA.p, nl, K->table_cw, s))) return rc;
-        if ((rc = msm_build_table(0, K->pointsB1.p, nl, K->table_cw, s))) return rc;
-        if ((rc = msm_build_table(1, K->pointsB2.p, nl, K->table_cw, s))) return rc;
-        if ((rc = msm_build_table(0, K->pointsC.p, nl, K->table_cw, s))) return rc;
-        if ((rc = msm_build_table(0, K->pointsH.p, hl, K->table_ch, s))) return rc;
-    }
-    // The two record streams are transposed (calch.hip: pols_to_csr -- a header walk on the host, upload, three kernels each)
-    // on queues of their own WHILE the table kernels above run: the walk and the 0.18 GB of PCIe traffic cost the load nothing
-    // (round 3 did this first, on its own: 56-65 ms of a 2^20 key's 214).
+    // The two record streams are transposed side by side (calch.hip: pols_to_csr -- a header walk on the host, upload, three kernels
+    // each, on queues of their own; round 3 did the two passes over the records on host threads: 56-65 ms of a 2^20 key's 214).
+    // BEFORE the table build is launched: under it the transposition's small kernels wait for issue slots behind kernels that
+    // use 0.95 of them (measured: 133 ms instead of 20), and the load must not return before the matrices are in.
     {
         hipStream_t sa = nullptr, sb = nullptr;
         WS_HIP_CHECK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
@@ -228,12 +253,41 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
         const int rcb = fb.get();
         (void)hipStreamDestroy(sa);
         (void)hipStreamDestroy(sb);
-        if (rc) { (void)hipStreamSynchronize(s); return rc; }
-        if (rcb) { (void)hipStreamSynchronize(s); set_last_error(err_b); return rcb; }
+        if (rc) return rc;                      // (~ProvingKey waits for the build queue)
+        if (rcb) { set_last_error(err_b); return rcb; }
     }
-    K->load_ms[0] = std::chrono::duration<double, std::milli>(Clock::now() - t_phase).count();      // host-side wall of the transposition (the table build runs under it)
-    WS_HIP_CHECK(hipStreamSynchronize(s));
-    K->load_ms[3] = lap(t_phase);               // the table build, the transposition of the matrices under it
+    K->load_ms[0] = lap(t_phase);               // (also drains `s`: sections resident and converted -- proofs may start)
+    if (K->table_cw) {      // rows 1.. of the tables, from row 0, in that domain: on the key's own queue, behind everything `s` holds so far
+        // (the LOWEST stream priority: the runtime multiplexes a process's streams onto a few hardware queues per priority class,
+        //  and a proof whose queue shared one with a normal-priority build would sit behind 130 ms of table kernels -- seen through the
+        //  Node addon: first proof 133 ms instead of 13; at the lowest priority the build has queues of its own and yields to proofs)
+        {
+            int lo = 0, hi = 0;
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&K->build_q, hipStreamNonBlocking, lo) != hipSuccess) {
+                (void)hipGetLastError();
+                K->build_q = nullptr;
+                WS_HIP_CHECK(hipStreamCreateWithFlags(&K->build_q, hipStreamNonBlocking));
+            }
+        }
+        WS_HIP_CHECK(hipEventCreate(&K->ev_build0));
+        WS_HIP_CHECK(hipEventCreate(&K->ev_tables));
+        K->tables_ready.store(0);
+        hipStream_t b = K->build_q;
+        WS_HIP_CHECK(hipEventRecord(K->ev_build0, s));
+        WS_HIP_CHECK(hipStreamWaitEvent(b, K->ev_build0, 0));
+        WS_HIP_CHECK(hipEventRecord(K->ev_build0, b));
+        if ((rc = msm_build_table(0, K->pointsA.p, nl, K->table_cw, b))) return rc;
+        if ((rc = msm_build_table(0, K->pointsB1.p, nl, K->table_cw, b))) return rc;
+        if ((rc = msm_build_table(1, K->pointsB2.p, nl, K->table_cw, b))) return rc;
+        if ((rc = msm_build_table(0, K->pointsC.p, nl, K->table_cw, b))) return rc;
+        if ((rc = msm_build_table(0, K->pointsH.p, hl, K->table_ch, b))) return rc;
+        WS_HIP_CHECK(hipEventRecord(K->ev_tables, b));
+    }
+    if (K->table_cw && tuning_get("TABLE_ASYNC", 1) == 0) {
+        WS_HIP_CHECK(hipEventSynchronize(K->ev_tables));
+        K->tables_ready.store(1);
+        K->load_ms[3] = lap(t_phase);           // the table build, waited for
+    }
     K->load_ms[4] = std::chrono::duration<double, std::milli>(Clock::now() - t_begin).count();
     *out = K.release();
     return WS_OK;
@@ -278,7 +332,16 @@ void pkey_table_info(const ProvingKey* K, uint32_t* cw, uint32_t* rw, uint32_t* 
     if (rh) *rh = msm_table_rows(K->table_ch);
     if (bytes) *bytes = (uint64_t)K->n_local * 320 * msm_table_rows(K->table_cw) + (uint64_t)K->h_local * 64 * msm_table_rows(K->table_ch);
 }
-void pkey_load_stats(const ProvingKey* K, double* out5) { memcpy(out5, K->load_ms, sizeof K->load_ms); }
+void pkey_load_stats(const ProvingKey* K, double* out5) {
+    memcpy(out5, K->load_ms, sizeof K->load_ms);
+    // a background build reports its duration once it is over (0 until then)
+    if (K->table_cw && out5[3] == 0 && K->ev_tables && hipEventQuery(K->ev_tables) == hipSuccess) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, K->ev_build0, K->ev_tables) == hipSuccess) out5[3] = ms;
+    } else {
+        (void)hipGetLastError();
+    }
+}
 void pkey_shard_info(const ProvingKey* K, uint32_t* rank, uint32_t* world, uint64_t* lo, uint64_t* n_local, uint64_t* h_local, uint32_t* h_log_m) {
     if (rank) *rank = K->shard_rank;
     if (world) *world = K->shard_world;
@@ -362,6 +425,10 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
     // a points-sharded key sums its own pairs: the witness slice [lo, lo + n_local) against the resident slice of every
     // section (all windows), h[hlo ..] against its hExps slice
     const uint32_t nv = K->n_local, dom = K->domain;
+    // tables or plain sections: decided once per proof (a window-sharded call waits for the tables: its partial sums must mean
+    // the same on every rank)
+    uint32_t table_cw, table_ch;
+    pkey_table_state(K, sh.off != 0 || sh.stride != 1, &table_cw, &table_ch);
     const Fe* d_witness_all = d_witness;
     d_witness += K->lo;
     if (K->shard_world > 1 && (sh.off != 0 || sh.stride != 1)) { set_last_error("prove: a points-sharded key cannot be window-sharded as well"); return WS_ERR_ARG; }
@@ -391,7 +458,7 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
         WS_HIP_CHECK(hipEventRecord(L.ev_start, s));
         WS_HIP_CHECK(hipStreamWaitEvent(sc, L.ev_start, 0));
         WS_HIP_CHECK(hipStreamWaitEvent(L.stream_copy2, L.ev_start, 0));
-        if ((rc = msm_plan_begin(L, nv, sh, s, K->table_cw))) return rc;
+        if ((rc = msm_plan_begin(L, nv, sh, s, table_cw))) return rc;
         unsigned k = 0;
         const uint64_t lo_sig = K->lo, hi_sig = (uint64_t)K->lo + nv;
         rc = upload_pipelined(const_cast<Fe*>(d_witness_all), h_witness, (size_t)K->n_vars * 32, sc, [&](size_t blo, size_t bhi, hipStream_t cq) -> int {
@@ -410,7 +477,7 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
     } else {
         if (h_witness && (rc = upload_staged(const_cast<Fe*>(d_witness_all), h_witness, (size_t)K->n_vars * 32, s))) return rc;
         WS_HIP_CHECK(hipEventRecord(L.ev_start, s));      // the witness is ready on s
-        if ((rc = msm_plan_dev(L, d_witness, nv, sh, s, K->table_cw))) return rc;
+        if ((rc = msm_plan_dev(L, d_witness, nv, sh, s, table_cw))) return rc;
     }
     // one grouping pass for all four; A and B1/B2 may run on variants of the plan that leave out the variables
     // absent from their matrix (plan 0 = full, 2 = without B's absentees, 3 = without A's).  A, B1 and C: three
@@ -431,7 +498,7 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
     // the same arrangement loses (round 1 / 2 sweeps: kernels that share the SIMDs starve each other), hence the size switch:
     // fewer than 2^23 (row, pair) entries per G1 sum.  Measured on the 8 shards of a 2^20 key, one GPU, rank after rank
     // (tools/shard_probe.py): 3.7 -> see profiles/r03_s11_shard_probe_2p20.json.
-    const bool small = (uint64_t)nv * msm_table_rows(K->table_cw ? K->table_cw : 16) < ((uint64_t)1 << 23);
+    const bool small = (uint64_t)nv * msm_table_rows(table_cw ? table_cw : 16) < ((uint64_t)1 << 23);
     const int order = order_env >= 0 ? order_env : (small && L.stream3 && s != L.stream3 ? 3 : 1);
     const bool g2_first = order != 0;
     // Order 4 (round 3, full-size sums): order 1 with the reduction tails of B2 and of A + B1 on the THIRD queue, so that the
@@ -518,7 +585,7 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
     if (rc) return rc;
     tr.mark("calc_h enqueued");
     msm_select_plan(L, s2 != s ? 1 : 0);
-    rc = msm_plan_dev(L, d_h + K->hlo, K->h_local, sh, s2, K->table_ch);
+    rc = msm_plan_dev(L, d_h + K->hlo, K->h_local, sh, s2, table_ch);
     if (!rc) rc = msm_g1_launch(L, K->pointsH.as<Affine<Fq>>(), true, &hH, s2);                           // :614
     msm_select_plan(L, 0);
     if (rc) return rc;
@@ -753,7 +820,9 @@ int pkey_h_msm_dev(ProvingKey* K, const Fe* d_h_local, uint64_t n, uint8_t* out9
     LaneLock L = acquire_lane(C);
     if (!s) s = L->stream;
     msm_select_plan(*L, 0);
-    int rc = msm_plan_dev(*L, d_h_local, n, WindowShard{}, s, K->table_ch);
+    uint32_t table_cw, table_ch;
+    pkey_table_state(K, false, &table_cw, &table_ch);
+    int rc = msm_plan_dev(*L, d_h_local, n, WindowShard{}, s, table_ch);
     if (rc) return rc;
     int slot = -1;
     if ((rc = msm_g1_launch(*L, K->pointsH.as<Affine<Fq>>(), true, &slot, s))) return rc;
