@@ -71,6 +71,7 @@ def build_prover(bn, logd, style, seed=1, keep_h=False, container="auto", load=T
         return circ, None, wit, info
     # (wait_tables=False: the load returns as the C call does, with the table rows still being built in the background; bench_prove
     #  times the first proof right behind it and then waits for the build before anything steady-state is timed)
+    wit = circ.witness_bin()            # (before the load: nothing may stand between the load's return and the first proof)
     if use_sections:
         key = bn.load_key(sections=sec, wait_tables=not cold_probe)
         key_bytes = sum(len(v) for v in sec.values() if isinstance(v, (bytes, bytearray)))
@@ -81,7 +82,20 @@ def build_prover(bn, logd, style, seed=1, keep_h=False, container="auto", load=T
         key_bytes = len(pkey)
     t_load = time.perf_counter() - t1
     t_loaded = time.perf_counter()
-    wit = circ.witness_bin()
+    cold_runs = None
+    if cold_probe:
+        # cold: the very first proofs of this process on the freshly loaded key, from a host witness, right behind the load's return
+        # (transform plans and their twiddle tables, lane buffers are created inside the first one; the table rows are still being
+        # built under all of them) -- the reference's timing hook wraps the whole call, key parsing included
+        # (example/bn128/index.html:39-49, src/bn128.js:581-604)
+        r32, s32 = bytes(range(32)), bytes(range(32, 64))
+        cold_runs = {"ms": [], "proofs": []}
+        for _ in range(4):
+            tq = time.perf_counter()
+            cold_runs["proofs"].append(bn.groth16GenProof(wit, key, r=r32, s=s32))
+            cold_runs["ms"].append(round((time.perf_counter() - tq) * 1e3, 2))
+        key.wait_tables()                                   # everything after this is steady state: tables resident
+        cold_runs["tables_ready_ms"] = round((time.perf_counter() - t_loaded) * 1e3, 2)
     info = {"log_domain": logd, "n_vars": circ.n_vars, "n_public": circ.n_public, "nnz_A_plus_B": int(circ.nnz), "style": style,
             "vars_absent_from_A_B": [int(x) for x in circ.absent], "key_bytes": key_bytes,
             "key_container": "sections" if use_sections else "proving_key.bin", "generator": "csrc/synth.hip (wsnark_synth_*)",
@@ -91,7 +105,7 @@ def build_prover(bn, logd, style, seed=1, keep_h=False, container="auto", load=T
             "table_window_bits": [key.table["c_w"], key.table["c_h"]]}
     if keep_h:
         info["h_points"] = bytes(sec["pointsH"])
-    cold["_t_loaded"] = t_loaded
+    cold["_runs"] = cold_runs
     info["_cold"] = cold
     info["_sections"] = sec
     return circ, key, wit, info
@@ -348,24 +362,17 @@ def bench_prove(ctx):
     sec = info.pop("_sections", None)
     r32, s32 = bytes(range(32)), bytes(range(32, 64))
     want = circ.expected_proof(r32, s32)
-    # cold: the very first proof of this process on the freshly loaded key, from a host witness (transform plans and their
-    # twiddle tables, lane buffers, pinned staging ring are all created inside it) -- the reference's timing hook wraps the
-    # whole call, key parsing included (example/bn128/index.html:39-49, src/bn128.js:581-604)
-    if world == 1:
-        t_loaded = cold.pop("_t_loaded")
-        t0 = time.perf_counter()
-        first_cold = bn.groth16GenProof(wit, key, r=r32, s=s32)
-        cold["first_proof_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
-        cold["first_proof_matches_closed_form"] = bool(first_cold == want)
+    runs = cold.pop("_runs", None)
+    if world == 1 and runs:
+        cold["first_proof_ms"] = runs["ms"][0]
+        cold["next_proofs_ms"] = runs["ms"][1:]
+        cold["tables_ready_ms_after_the_load_returned"] = runs["tables_ready_ms"]
+        cold["first_proof_matches_closed_form"] = bool(all(p == want for p in runs["proofs"]))
         cold["first_proof_ran_on"] = "the plain sections, beside the background build of the table rows (wsnark_pkey_wait_tables not called yet)"
         cold["key_load_plus_first_proof_ms"] = round(cold["key_load_ms"]["total"] + cold["first_proof_ms"], 2)
-        key.wait_tables()                                   # everything below is steady state: tables resident
-        cold["tables_ready_ms_after_the_load_returned"] = round((time.perf_counter() - t_loaded) * 1e3, 2)
         cold["key_load_ms"] = {k: round(v, 2) for k, v in key.load_ms.items()}
         cold["key_load_ms_note"] = ("total = what the load call took (points_h2d + masks_convert + pols_to_csr); table_build = the background build's own "
-                                    "duration on the GPU, with the first proof running beside it")
-    else:
-        cold.pop("_t_loaded", None)
+                                    "duration on the GPU, with the first four proofs running beside it")
     d_w = torch.frombuffer(bytearray(wit), dtype=torch.uint8).to(dev)
     torch.cuda.synchronize()
 

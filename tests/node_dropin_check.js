@@ -136,6 +136,13 @@ const toAB = (b) => b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength);
         if (JSON.stringify(q) !== JSON.stringify(c6.proof)) throw new Error("proof from a pinned input buffer");
         if (!(timing.prove_ms > 0) || !(timing.loadKey_ms >= 0) || !(timing.format_ms >= 0)) throw new Error("opts.timing was not filled");
     }
+    // keyInfo / waitTables on key bytes
+    {
+        const k6 = fs.readFileSync(path.join(gold, "keys", "t6.pkey.bin"));
+        const ki = await bn.keyInfo(k6);
+        if (!(ki.nVars > 0 && ki.domainSize > 0 && ki.loadMs && ki.loadMs.total > 0)) throw new Error("keyInfo: " + JSON.stringify(ki));
+        if ((await bn.waitTables(k6)) !== true) throw new Error("waitTables");
+    }
     // error path: rejected Promise, not a hang (the reference hangs: SURVEY section 5)
     let rejected = false;
     try { await bn.fft(new Uint8Array(96), 0); } catch (e) { rejected = true; }

@@ -76,12 +76,14 @@ def test_emulated_prove_sparse_b_plan(monkeypatch, name):
 
 
 @pytest.mark.parametrize("name", NAMES)
-@pytest.mark.parametrize("mode", ["plain", "pieces", "pieces-sparse", "wide", "round1-order", "entry64"])
+@pytest.mark.parametrize("mode", ["plain", "pieces", "pieces-sparse", "wide", "round1-order", "entry64", "one-kernel-build", "slabs"])
 def test_emulated_prove_key_table_modes(monkeypatch, name, mode):
     """Resident keys are fixed-base window tables by default (row w = 2^(c w) * section; one bucket set per sum).
     `plain` switches them off (the per-window path the MSM entry points use); `pieces` forces a table whose bucket set
     is cut into several tail pieces (the sum_v v T_v term of the host tail), also together with the masked plan
-    variants; `wide` a window wider than the pair count suggests.  Same proofs, bit for bit."""
+    variants; `wide` a window wider than the pair count suggests; `one-kernel-build` the table rows from the one long kernel
+    per section instead of the short launches through the scratch slab, `slabs` those launches with a slab smaller than the
+    sections (and three groups of rows behind an inversion each).  Same proofs, bit for bit."""
     if mode == "plain":
         monkeypatch.setenv("WSNARK_KEY_TABLE", "0")
     elif mode.startswith("pieces"):
@@ -91,6 +93,11 @@ def test_emulated_prove_key_table_modes(monkeypatch, name, mode):
             monkeypatch.setenv("WSNARK_PROVE_SPARSE", "2")
     elif mode == "wide":
         monkeypatch.setenv("WSNARK_TABLE_C", "13")
+    elif mode == "one-kernel-build":
+        monkeypatch.setenv("WSNARK_TABLE_STEPPED", "0")
+    elif mode == "slabs":
+        monkeypatch.setenv("WSNARK_TABLE_C", "9")
+        monkeypatch.setenv("WSNARK_TABLE_SLAB_LANES", "64")
     elif mode == "entry64":
         monkeypatch.setenv("WSNARK_MSM_ENTRY64", "1")     # 8-byte grouping entries: what a 2^24 table key needs (28 index bits)
         monkeypatch.setenv("WSNARK_PROVE_SPARSE", "2")
@@ -101,13 +108,13 @@ def test_emulated_prove_key_table_modes(monkeypatch, name, mode):
     key = bn.load_key(pkey)
     # wsnark_pkey_table_info: plain sections report one row; tables ceil(255 / c) rows of the window the mode asks for
     t = key.table
-    assert (t["rows_w"], t["c_w"]) == ((1, 0) if mode == "plain" else (-(-255 // t["c_w"]), {"pieces": 9, "pieces-sparse": 9, "wide": 13}.get(mode, t["c_w"])))
+    assert (t["rows_w"], t["c_w"]) == ((1, 0) if mode == "plain" else (-(-255 // t["c_w"]), {"pieces": 9, "pieces-sparse": 9, "wide": 13, "slabs": 9}.get(mode, t["c_w"])))
     assert t["bytes"] == key.n_vars * 320 * t["rows_w"] + key.domain * 64 * t["rows_h"]
     for c in load_golden("proofs.json")[name]:
         assert bn.groth16GenProof(wit, key, r=bytes.fromhex(c["r"]), s=bytes.fromhex(c["s"])) == c["proof"]
 
 
-@pytest.mark.parametrize("mode", ["table", "plain"])
+@pytest.mark.parametrize("mode", ["table", "table-one-kernel-build", "plain"])
 def test_degenerate_key_points_against_the_oracle_prover(orc, monkeypatch, mode):
     """The prover is a pure function of (witness, key, r, s) -- the key's points need not come from a setup.  Here the
     point sections of the t6 key are made degenerate: runs of EQUAL points (the accumulation's doubling case: equal
@@ -117,10 +124,14 @@ def test_degenerate_key_points_against_the_oracle_prover(orc, monkeypatch, mode)
     from primitives_common import degenerate_key_and_witness
     if mode == "plain":
         monkeypatch.setenv("WSNARK_KEY_TABLE", "0")
+    elif mode == "table-one-kernel-build":
+        monkeypatch.setenv("WSNARK_TABLE_STEPPED", "0")
+    else:
+        monkeypatch.setenv("WSNARK_TABLE_SLAB_LANES", "64")
     key, w = degenerate_key_and_witness(orc, *_key("t6")[:2])
     bn = emul_bn128()
     k = bn.load_key(key)
-    assert (k.table["rows_w"] > 1) == (mode == "table")
+    assert (k.table["rows_w"] > 1) == (mode != "plain")
     for r, s in ((bytes(32), bytes(32)), (bytes(range(1, 33)), bytes(range(101, 133)))):
         assert bn.groth16GenProof(w, k, r=r, s=s) == orc.groth16_prove(w, key, r, s, workers=8)
 

@@ -1,0 +1,12 @@
+timeout 300 python tools/node_bench.py 20 5 > gpurun_out/nb3.json 2>gpurun_out/nb3.err
+python -c "
+import json
+d=json.load(open('gpurun_out/nb3.json')); n=d.get('node', {}); print({k:n.get(k) for k in ('first_call_ms','first_call_phases_ms','next_calls_ms','key_bytes_call_ms')}); print(d.get('fresh_python_process')); print(d.get('fresh_python_process_hash_beside_load')); print(d.get('node_error','')[:300])"
+timeout 200 python bench.py --no-extras --no-cpu-baseline --steps 10 > gpurun_out/b3.json 2>gpurun_out/b3.err
+python -c "
+import json
+d=json.load(open('gpurun_out/b3.json')); print(d['value'], d['proofs_match_toxic_waste_closed_form'], json.dumps(d['cold']))"
+WSNARK_TABLE_STEPPED=0 timeout 200 python bench.py --no-extras --no-cpu-baseline --steps 10 > gpurun_out/b3o.json 2>gpurun_out/b3o.err
+python -c "
+import json
+d=json.load(open('gpurun_out/b3o.json')); print('one-kernel', d['value'], json.dumps(d['cold']))"

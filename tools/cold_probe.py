@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""A fresh process's first calls on a key read from a file, one by one (what tools/node_bench.js sees, without Node): load the
+key without waiting for the table rows, then six proofs from a host witness, each timed; optionally with a thread hashing the
+key bytes beside the load (the JS edge takes a whole-buffer digest off the event loop at load time).
+    python tools/cold_probe.py <proving_key.bin> <witness.bin> [--hash] [--wait]    -> one JSON line"""
+import hashlib
+import json
+import os
+import sys
+import threading
+import time
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+t_start = time.perf_counter()
+import wasmsnark_amd
+pkey = open(sys.argv[1], "rb").read()
+wit = open(sys.argv[2], "rb").read()
+r, s = bytes(range(32)), bytes(range(32, 64))
+ms = lambda t0: round((time.perf_counter() - t0) * 1e3, 2)
+t0 = time.perf_counter()
+bn = wasmsnark_amd.build(device=0)
+out = {"hash_beside_load": "--hash" in sys.argv, "wait_tables": "--wait" in sys.argv, "init_ms": ms(t0)}
+th = None
+if "--hash" in sys.argv:
+    th = threading.Thread(target=lambda: out.__setitem__("hash_ms", (lambda t: (hashlib.blake2b(pkey).digest(), ms(t))[1])(time.perf_counter())))
+    th.start()
+t0 = time.perf_counter()
+key = bn.load_key(pkey, wait_tables=("--wait" in sys.argv))
+out["load_ms"] = ms(t0)
+calls = []
+proofs = []
+for i in range(6):
+    t0 = time.perf_counter()
+    proofs.append(bn.groth16GenProof(wit, key, r=r, s=s))
+    calls.append(ms(t0))
+out["calls_ms"] = calls
+out["all_equal"] = all(p == proofs[0] for p in proofs)
+if th:
+    th.join()
+key.wait_tables()
+t0 = time.perf_counter()
+for i in range(10):
+    bn.groth16GenProof(wit, key, r=r, s=s)
+out["steady_ms"] = round(ms(t0) / 10, 3)
+out["pi_a0"] = proofs[0]["pi_a"][0]
+print("COLD_PROBE " + json.dumps(out))

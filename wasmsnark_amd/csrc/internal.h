@@ -180,7 +180,8 @@ int msm_plan_count(Lane& L, const Fe* d_scalars, uint64_t i0, uint64_t i1, hipSt
 int msm_plan_finish(Lane& L, const Fe* d_scalars, hipStream_t s);
 uint32_t msm_table_rows(uint32_t table_c);
 uint32_t msm_table_window(uint64_t n);
-int msm_build_table(int which, void* d_table, uint64_t n, uint32_t table_c, hipStream_t s);   // rows 1.. from row 0 (device domain: after msm_prepare_points)
+int msm_build_table(int which, void* d_table, uint64_t n, uint32_t table_c, hipStream_t s, void* d_tmp = nullptr, size_t tmp_bytes = 0);
+size_t msm_table_scratch_bytes(uint64_t lanes);      // scratch of the build in short launches, for `lanes` points at a time   // rows 1.. from row 0 (device domain: after msm_prepare_points)
 // mask[i] = 0 where the point is infinity (x == 0, reference format) in every given set; *skipped_host = how many
 int msm_points_mask(const Affine<Fq>* d_g1, const Affine<Fq2>* d_g2, uint64_t n, uint8_t* d_mask, uint32_t* skipped_host, hipStream_t s);
 // asynchronous form: launch enqueues the kernels and the copy of the window sums, finish waits

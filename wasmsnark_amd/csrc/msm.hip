@@ -1892,15 +1892,83 @@ __global__ __launch_bounds__(256) void msm_table_kernel(typename C::AffP* __rest
         }
     }
 }
-// d_table: rows x n points, row 0 already in the device domain (msm_prepare_points)
-int msm_build_table(int which, void* d_table, uint64_t n, uint32_t tc, hipStream_t s) {
+// The same build cut into short launches (round 4, for the background build: a workgroup of the kernel above lives for ~2 ms --
+// 240 doublings and an inversion per lane -- and a proof kernel that arrives meanwhile waits for such workgroups to retire before
+// its own fit; below a workgroup lives for one row, 20 doublings).  Step k takes the running XYZZ point of every lane from slot
+// `src` of the scratch slab (row 0 of the table when src < 0), doubles it c times and leaves it in slot `dst`; the closing launch
+// normalises the g slots behind one inversion per lane, exactly as the one-kernel build does (same products in the same order:
+// the tables come out bit-identical).  Scratch: TABLE_GROUP slots x S lanes of XYZZ points.
+template <class C>
+__global__ __launch_bounds__(256) void msm_table_step_kernel(const typename C::AffP* __restrict__ row0, typename C::Pt* __restrict__ tmp, uint64_t cnt,
+                                                             uint64_t S, uint32_t c, int src, uint32_t dst) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    const typename C::Aff p0 = C::unpack_aff(row0[i]);
+    if (C::aff_is_inf(p0)) return;
+    typename C::Pt P = src < 0 ? C::from_affine(p0) : tmp[(uint64_t)src * S + i];
+    for (uint32_t d = 0; d < c; d++) P = C::dbl(P);
+    tmp[(uint64_t)dst * S + i] = P;
+}
+template <class C>
+__global__ __launch_bounds__(256) void msm_table_norm_kernel(typename C::AffP* __restrict__ table, uint64_t n, uint64_t base, uint64_t cnt,
+                                                             const typename C::Pt* __restrict__ tmp, uint64_t S, uint32_t w0, uint32_t g) {
+    typedef typename C::Field F;
+    typedef typename F::El El;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    const typename C::AffP p0p = table[base + i];
+    if (C::aff_is_inf(C::unpack_aff(p0p))) {
+        for (uint32_t k = 0; k < g; k++) table[(uint64_t)(w0 + k) * n + base + i] = p0p;
+        return;
+    }
+    El pre[TABLE_GROUP];
+    El run = F::one();
+    for (uint32_t k = 0; k < g; k++) {
+        pre[k] = run;
+        run = F::mul(run, tmp[(uint64_t)k * S + i].zzz);
+    }
+    El inv = F::inv(run);
+    for (int k = (int)g - 1; k >= 0; k--) {
+        const typename C::Pt q = tmp[(uint64_t)k * S + i];
+        const El izzz = F::mul(inv, pre[k]);
+        inv = F::mul(inv, q.zzz);
+        const El izz = F::mul(F::sqr(izzz), F::sqr(q.zz));
+        table[(uint64_t)(w0 + k) * n + base + i] = C::pack_aff(typename C::Aff{F::mul(q.x, izz), F::mul(q.y, izzz)});
+    }
+}
+size_t msm_table_scratch_bytes(uint64_t lanes) { return (size_t)TABLE_GROUP * lanes * sizeof(G2R29::Pt); }
+template <class C>
+static void table_stepped(typename C::AffP* table, uint64_t n, uint32_t tc, uint32_t rows, hipStream_t s, void* d_tmp, size_t tmp_bytes) {
+    typename C::Pt* tmp = (typename C::Pt*)d_tmp;
+    uint64_t S = tmp_bytes / ((size_t)TABLE_GROUP * sizeof(typename C::Pt));
+    S &= ~(uint64_t)63;
+    for (uint64_t base = 0; base < n; base += S) {
+        const uint64_t cnt = n - base < S ? n - base : S;
+        const dim3 grid(ceil_div_u64(cnt, 256));
+        int src = -1;
+        for (uint32_t w0 = 1; w0 < rows; w0 += TABLE_GROUP) {
+            const uint32_t g = rows - w0 < TABLE_GROUP ? rows - w0 : TABLE_GROUP;
+            for (uint32_t k = 0; k < g; k++) {
+                hipLaunchKernelGGL(msm_table_step_kernel<C>, grid, dim3(256), 0, s, table + base, tmp, cnt, S, tc, src, k);
+                src = (int)k;
+            }
+            hipLaunchKernelGGL(msm_table_norm_kernel<C>, grid, dim3(256), 0, s, table, n, base, cnt, tmp, S, w0, g);
+        }
+    }
+}
+// d_table: rows x n points, row 0 already in the device domain (msm_prepare_points).  d_tmp (msm_table_scratch_bytes of at least
+// 64 lanes; may be NULL): build in short launches through that scratch instead of one long kernel
+int msm_build_table(int which, void* d_table, uint64_t n, uint32_t tc, hipStream_t s, void* d_tmp, size_t tmp_bytes) {
     Context* X = ctx();
     if (!X) return WS_ERR_NOINIT;
     if (!s) s = X->stream;
     const uint32_t rows = msm_table_rows(tc);
     if (n == 0 || rows < 2) return WS_OK;
     if (!msm_uses_field29()) { set_last_error("msm: fixed-base tables are built on the radix-2^29 field"); return WS_ERR_ARG; }
-    if (which == 0)
+    if (d_tmp && tmp_bytes >= msm_table_scratch_bytes(64)) {
+        if (which == 0) table_stepped<G1R29>((G1R29::AffP*)d_table, n, tc, rows, s, d_tmp, tmp_bytes);
+        else table_stepped<G2R29>((G2R29::AffP*)d_table, n, tc, rows, s, d_tmp, tmp_bytes);
+    } else if (which == 0)
         hipLaunchKernelGGL(msm_table_kernel<G1R29>, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s, (G1R29::AffP*)d_table, n, tc, rows);
     else
         hipLaunchKernelGGL(msm_table_kernel<G2R29>, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s, (G2R29::AffP*)d_table, n, tc, rows);

@@ -276,11 +276,22 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
         WS_HIP_CHECK(hipEventRecord(K->ev_build0, s));
         WS_HIP_CHECK(hipStreamWaitEvent(b, K->ev_build0, 0));
         WS_HIP_CHECK(hipEventRecord(K->ev_build0, b));
-        if ((rc = msm_build_table(0, K->pointsA.p, nl, K->table_cw, b))) return rc;
-        if ((rc = msm_build_table(0, K->pointsB1.p, nl, K->table_cw, b))) return rc;
-        if ((rc = msm_build_table(1, K->pointsB2.p, nl, K->table_cw, b))) return rc;
-        if ((rc = msm_build_table(0, K->pointsC.p, nl, K->table_cw, b))) return rc;
-        if ((rc = msm_build_table(0, K->pointsH.p, hl, K->table_ch, b))) return rc;
+        // in short launches (a row per launch) through a scratch slab that lives on the build queue only -- allocated and freed in
+        // queue order, no host-side wait; TABLE_STEPPED=0 (or no stream-ordered allocator): the one long kernel per section
+        void* tmp = nullptr;
+        size_t tmp_bytes = 0;
+        if (tuning_get("TABLE_STEPPED", 1)) {
+            const uint64_t most = nl > hl ? nl : hl, cap = (uint64_t)tuning_get("TABLE_SLAB_LANES", 1 << 18);
+            tmp_bytes = msm_table_scratch_bytes(((most < cap ? most : cap) + 63) & ~(uint64_t)63);
+            if (hipMallocAsync(&tmp, tmp_bytes, b) != hipSuccess) { (void)hipGetLastError(); tmp = nullptr; tmp_bytes = 0; }
+        }
+        rc = msm_build_table(0, K->pointsA.p, nl, K->table_cw, b, tmp, tmp_bytes);
+        if (!rc) rc = msm_build_table(0, K->pointsB1.p, nl, K->table_cw, b, tmp, tmp_bytes);
+        if (!rc) rc = msm_build_table(1, K->pointsB2.p, nl, K->table_cw, b, tmp, tmp_bytes);
+        if (!rc) rc = msm_build_table(0, K->pointsC.p, nl, K->table_cw, b, tmp, tmp_bytes);
+        if (!rc) rc = msm_build_table(0, K->pointsH.p, hl, K->table_ch, b, tmp, tmp_bytes);
+        if (tmp) (void)hipFreeAsync(tmp, b);
+        if (rc) return rc;
         WS_HIP_CHECK(hipEventRecord(K->ev_tables, b));
     }
     if (K->table_cw && tuning_get("TABLE_ASYNC", 1) == 0) {

@@ -27,7 +27,7 @@ function proofFromBytes(ab) {       // bin2g1 / bin2g2, src/bn128.js:329-351, 71
 /* Two checks that a cached key handle still describes the bytes the caller is holding.
  *   fingerprint(u8): synchronous, a few KiB -- the 488-byte header + fixed points, 64 samples of 32 bytes spread over the buffer and
  *                    its tail.  Run on EVERY cache hit: it catches a buffer that was refilled with another key.
- *   digest(u8):      ALL of the bytes (addon.hashBytes, off the event loop; tens of ms for a 0.6 GB key -- several proofs' worth).
+ *   digest(u8):      ALL of the bytes (addon.hashBytes, off the event loop, several threads; ~10 ms for a 0.6 GB key -- a proof's worth).
  *                    Run when the key is first seen (beside the load) and, after that, only when the caller asks:
  *                    {trustCache: false}, or invalidateKey(pkey) after rewriting bytes in place.
  * The reference re-parses pkey inside every call (src/bn128.js:581-604), so for IT a caller may patch a few bytes of a key between
@@ -92,12 +92,18 @@ class Bn128 {
             this.fullDigests++;
             if ((await hit.digest) === (await digest(u8))) return hit.handle;
         }
+        // The digest is taken beside the load (addon.hashBytes deals the buffer's blocks to several threads: ~10 ms for a 0.6 GB
+        // key, a quarter of the load) and loadKey() resolves only when BOTH are done: a caller who rewrites bytes in place as
+        // soon as the first call returns must find them compared against the bytes that were loaded, not against a digest that
+        // was still being taken while they changed.
         const entry = { byteOffset: u8.byteOffset, byteLength: u8.byteLength, fp: fingerprint(u8), handle: addon.loadKey(pkey), digest: digest(u8) };
         this.fullDigests++;
         this._keys.set(pkey, entry);
         entry.digest.catch(() => {});
         try {
-            return await entry.handle;
+            const h = await entry.handle;
+            await entry.digest;
+            return h;
         } catch (e) {
             if (this._keys.get(pkey) === entry) this._keys.delete(pkey);                // a key that failed to parse is not cached
             throw e;
@@ -105,6 +111,12 @@ class Bn128 {
     }
     /* forget the cached handle of a key object (its bytes were rewritten in place, or its HBM should go back) */
     invalidateKey(pkey) { return this._keys.delete(pkey); }
+    /* {nVars, nPublic, domainSize, loadMs: {polsToCsr, pointsH2d, masksConvert, tableBuild, total}} of a key (bytes or handle) */
+    async keyInfo(pkey) { return addon.keyInfo(await this.loadKey(pkey)); }
+    /* loadKey() returns once the key's sections are resident: proofs may start at once and run on the plain sections while the rows
+     * of the fixed-base tables are built behind them (about 0.2 s for a 2^20 key).  A caller that wants its first timed proof at the
+     * steady-state rate awaits this first. */
+    async waitTables(pkey) { return addon.waitTables(await this.loadKey(pkey)).then(() => true); }
     /* an ArrayBuffer of `bytes` bytes in PINNED host memory: a witness written into it is DMA'd to the GPU in place, chunk by
      * chunk, instead of being copied through the library's staging ring first (no counterpart in the reference) */
     allocInput(bytes) { return addon.allocPinned(bytes); }

@@ -14,6 +14,7 @@
 #define _GNU_SOURCE
 #include <dlfcn.h>
 #include <node_api.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -38,6 +39,8 @@ static struct {
     int (*verify)(const void*, size_t, const void*, uint64_t, const void*, int*);
     int (*host_alloc)(size_t, void**);
     void (*host_free)(void*);
+    int (*pkey_load_stats)(const wsnark_pkey_t*, double*);
+    int (*pkey_wait_tables)(wsnark_pkey_t*);
     char dir[4096];
 } L;
 
@@ -65,6 +68,7 @@ static int load_lib(const char* explicit_path, char* err, size_t errlen) {
     SYM(pkey_free, "wsnark_pkey_free") SYM(pkey_info, "wsnark_pkey_info") SYM(prove, "wsnark_groth16_prove")
     SYM(last_blinding, "wsnark_last_blinding") SYM(verify, "wsnark_groth16_verify")
     SYM(host_alloc, "wsnark_host_alloc") SYM(host_free, "wsnark_host_free")
+    SYM(pkey_load_stats, "wsnark_pkey_load_stats") SYM(pkey_wait_tables, "wsnark_pkey_wait_tables")
 #undef SYM
     return 0;
 }
@@ -90,7 +94,7 @@ static int get_bytes(napi_env env, napi_value v, uint8_t** p, size_t* n) {
     return 0;
 }
 
-enum { OP_G1, OP_G2, OP_NTT, OP_CALCH, OP_PROVE, OP_LOADKEY, OP_VERIFY, OP_HASH };
+enum { OP_G1, OP_G2, OP_NTT, OP_CALCH, OP_PROVE, OP_LOADKEY, OP_VERIFY, OP_HASH, OP_WAIT_TABLES };
 typedef struct {
     int op, rc;
     napi_async_work work;
@@ -107,10 +111,9 @@ typedef struct {
     char err[512];
 } job_t;
 
-/* 128-bit digest of a whole buffer: four independent multiply-rotate lanes over 8-byte words (memory-bound on one
- * core: a 0.6 GB key in well under 0.1 s), folded with the length.  Not cryptographic: it only has to notice that
- * the bytes behind a cached key handle are no longer the bytes that were loaded. */
-static void hash_bytes(const uint8_t* p, size_t n, uint8_t out[16]) {
+/* 128-bit digest of a run of bytes: four independent multiply-rotate lanes over 8-byte words, folded with the length.
+ * Not cryptographic: it only has to notice that the bytes behind a cached key handle are no longer the bytes that were loaded. */
+static void hash_run(const uint8_t* p, size_t n, uint8_t out[16]) {
     uint64_t h[4] = {0x9e3779b97f4a7c15ull, 0xc2b2ae3d27d4eb4full, 0x165667b19e3779f9ull, 0x27d4eb2f165667c5ull};
     size_t i = 0;
     for (; i + 32 <= n; i += 32) {
@@ -129,6 +132,46 @@ static void hash_bytes(const uint8_t* p, size_t n, uint8_t out[16]) {
     a ^= b >> 31; b ^= a >> 27;
     memcpy(out, &a, 8); memcpy(out + 8, &b, 8);
 }
+/* ... of a whole buffer: the digests of its 4 MiB blocks, digested.  One core streams about 12 GB/s through hash_run -- 50 ms
+ * for a 0.6 GB key, longer than the key's load takes -- so the blocks are dealt to up to HASH_THREADS threads (the result does
+ * not depend on how many there were). */
+#define HASH_BLOCK ((size_t)4 << 20)
+#define HASH_THREADS 8
+typedef struct { const uint8_t* p; size_t n, nblocks; uint8_t* digests; unsigned first, step; } hash_part_t;
+static void* hash_part(void* arg) {
+    hash_part_t* h = (hash_part_t*)arg;
+    for (size_t b = h->first; b < h->nblocks; b += h->step) {
+        const size_t lo = b * HASH_BLOCK, len = h->n - lo < HASH_BLOCK ? h->n - lo : HASH_BLOCK;
+        hash_run(h->p + lo, len, h->digests + 16 * b);
+    }
+    return NULL;
+}
+static int hash_bytes(const uint8_t* p, size_t n, uint8_t out[16]) {
+    const size_t nblocks = n ? (n + HASH_BLOCK - 1) / HASH_BLOCK : 1;
+    uint8_t* digests = (uint8_t*)calloc(nblocks, 16);
+    if (!digests) return -1;
+    unsigned want = nblocks < HASH_THREADS ? (unsigned)nblocks : HASH_THREADS;
+    hash_part_t parts[HASH_THREADS];
+    pthread_t tid[HASH_THREADS];
+    unsigned started = 0;
+    for (unsigned t = 0; t < want; t++) parts[t] = (hash_part_t){p, n, nblocks, digests, t, want};
+    for (unsigned t = 1; t < want; t++) {
+        if (pthread_create(&tid[t], NULL, hash_part, &parts[t]) != 0) break;
+        started = t;
+    }
+    /* (threads that could not be started: their blocks are done here, after this thread's own) */
+    hash_part(&parts[0]);
+    for (unsigned t = started + 1; t < want; t++) hash_part(&parts[t]);
+    for (unsigned t = 1; t <= started; t++) pthread_join(tid[t], NULL);
+    uint8_t top[16];
+    hash_run(digests, nblocks * 16, top);
+    uint64_t a, b;
+    memcpy(&a, top, 8); memcpy(&b, top + 8, 8);
+    a ^= (uint64_t)n * 0x9e3779b97f4a7c15ull;
+    memcpy(out, &a, 8); memcpy(out + 8, &b, 8);
+    free(digests);
+    return 0;
+}
 
 static void job_execute(napi_env env, void* data) {
     (void)env;
@@ -144,7 +187,10 @@ static void job_execute(napi_env env, void* data) {
         break;
     case OP_LOADKEY: j->rc = L.pkey_load(j->a, j->na, &j->key); break;
     case OP_VERIFY: j->rc = L.verify(j->a, j->na, j->b, j->nb / 32, j->c, &j->i0); break;
-    case OP_HASH: hash_bytes(j->a, j->na, j->out); j->rc = 0; break;
+    case OP_WAIT_TABLES: j->rc = L.pkey_wait_tables(j->key); break;
+    case OP_HASH:
+        if (hash_bytes(j->a, j->na, j->out)) { j->rc = -1; snprintf(j->err, sizeof j->err, "hashBytes: out of memory"); return; }
+        break;
     }
     if (j->rc) snprintf(j->err, sizeof j->err, "wsnark error %d: %s", j->rc, L.last_error());
 }
@@ -261,6 +307,18 @@ static napi_value js_hash(napi_env env, napi_callback_info info) {
     return start_job(env, j, "wsnark_hash_bytes");
 }
 
+/* waitTables(keyHandle) -> Promise: resolves once the key's fixed-base table rows are built (wsnark_pkey_wait_tables; proofs before
+ * that run on the plain sections) */
+static napi_value js_wait_tables(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1];
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    job_t* j = (job_t*)calloc(1, sizeof *j);
+    j->op = OP_WAIT_TABLES; j->nout = 1; j->out = (uint8_t*)calloc(1, 1);
+    if (argc < 1 || napi_get_value_external(env, argv[0], (void**)&j->key) != napi_ok || !j->key) FAIL(env, j, "expected a key handle");
+    keep(env, j, argv[0]);
+    return start_job(env, j, "wsnark_pkey_wait_tables");
+}
+
 /* prove(keyHandle, witness, r32|null, s32|null) -> Promise<ArrayBuffer 448>: proof (384 B) | r | s used */
 static napi_value js_prove(napi_env env, napi_callback_info info) {
     size_t argc = 4; napi_value argv[4];
@@ -336,6 +394,15 @@ static napi_value js_keyinfo(napi_env env, napi_callback_info info) {
     napi_create_uint32(env, nv, &v); napi_set_named_property(env, o, "nVars", v);
     napi_create_uint32(env, np, &v); napi_set_named_property(env, o, "nPublic", v);
     napi_create_uint32(env, dom, &v); napi_set_named_property(env, o, "domainSize", v);
+    /* what the load took, phase by phase (wsnark_pkey_load_stats; tableBuild stays 0 until the background build has finished) */
+    double ms[5] = {0, 0, 0, 0, 0};
+    if (L.pkey_load_stats(k, ms) == 0) {
+        static const char* names[5] = {"polsToCsr", "pointsH2d", "masksConvert", "tableBuild", "total"};
+        napi_value lo;
+        napi_create_object(env, &lo);
+        for (int i = 0; i < 5; i++) { napi_create_double(env, ms[i], &v); napi_set_named_property(env, lo, names[i], v); }
+        napi_set_named_property(env, o, "loadMs", lo);
+    }
     return o;
 }
 
@@ -385,6 +452,7 @@ static napi_value module_init(napi_env env, napi_value exports) {
         {"keyInfo", NULL, js_keyinfo, NULL, NULL, NULL, napi_default, NULL},
         {"allocPinned", NULL, js_alloc_pinned, NULL, NULL, NULL, napi_default, NULL},
         {"prove", NULL, js_prove, NULL, NULL, NULL, napi_default, NULL},
+        {"waitTables", NULL, js_wait_tables, NULL, NULL, NULL, napi_default, NULL},
         {"verify", NULL, js_verify, NULL, NULL, NULL, napi_default, NULL},
     };
     CHECK(env, napi_define_properties(env, exports, sizeof props / sizeof props[0], props));
