@@ -10,7 +10,8 @@ const path = require("path");
 const ws = require(path.join(__dirname, "..", "wasmsnark_amd", "js", "index.js"));
 const ms = (t0) => Number(process.hrtime.bigint() - t0) / 1e6;
 (async () => {
-    const keyBytes = fs.readFileSync(process.argv[2]);
+    let keyBytes = fs.readFileSync(process.argv[2]);
+    if (process.env.NODE_BENCH_COPYKEY) { const c = Buffer.alloc(keyBytes.length); keyBytes.copy(c); keyBytes = c; }      // (probe: another allocation path for the same bytes)
     const witness = fs.readFileSync(process.argv[3]);
     const reps = parseInt(process.argv[4] || "20", 10);
     const r = Buffer.alloc(32), s = Buffer.alloc(32);

@@ -60,6 +60,8 @@ else:
 # the same first calls from a fresh PYTHON process (no Node, no digest; then with a thread hashing the key beside the load)
 for label, extra in (("fresh_python_process", []), ("fresh_python_process_hash_beside_load", ["--hash"])):
     cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cold_probe.py"), kp, wp] + extra, capture_output=True, text=True, timeout=600)
+    if os.environ.get("NODE_BENCH_STDERR"):
+        sys.stderr.write("---- " + label + "\n" + cp.stderr[:6000])
     ln = [l for l in cp.stdout.splitlines() if l.startswith("COLD_PROBE ")]
     res[label] = json.loads(ln[0][len("COLD_PROBE "):]) if ln else {"error": (cp.stdout + cp.stderr)[-800:]}
 for f in (kp, wp):

@@ -46,6 +46,7 @@ void tuning_set(const char* name, long value) {
     else g_tune[name] = value;
 }
 
+int context_warm_staging();
 int context_init(int device) {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     if (g_ctx) return WS_OK;
@@ -87,6 +88,10 @@ int context_init(int device) {
         WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream_copy2, hipStreamNonBlocking));
     }
     g_ctx = C;
+#ifndef WSNARK_EMUL
+    // the pinned staging ring now, not inside the first key load (WSNARK_STAGE_EAGER=0: on first use, as before)
+    if (tuning_get("STAGE_EAGER", 1) && context_warm_staging() != WS_OK) (void)hipGetLastError();      // (not fatal: the first upload will say)
+#endif
     return WS_OK;
 }
 
@@ -224,6 +229,30 @@ static inline void cpu_relax() {
 #endif
 }
 
+static std::mutex g_ring_mu;
+// The pinned staging ring (and its slot events): created by wsnark_init on a device build -- pinning 128 MiB takes 8-26 ms, which
+// used to sit inside the first key load of a process -- and on first use otherwise (the emulator's tests size it per test).
+// Caller holds g_ring_mu.
+static int ensure_ring(Context* C) {
+    if (C->pin_ring) return WS_OK;
+    size_t ring = (size_t)tuning_get("STAGE_RING_KB", 128 << 10) << 10;        // (read once, when the ring is created)
+    ring = ring < ((size_t)1 << 20) ? ((size_t)1 << 20) : ring > ((size_t)1 << 30) ? ((size_t)1 << 30) : ring;
+    const auto t_ring = std::chrono::steady_clock::now();
+    WS_HIP_CHECK(hipHostMalloc(&C->pin_ring, ring, 0));
+    if (getenv("WSNARK_TRACE") && atoi(getenv("WSNARK_TRACE")) == 1)
+        fprintf(stderr, "[wsnark trace] staging ring: %zu MiB of pinned host memory in %.2f ms\n", ring >> 20,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ring).count());
+    C->pin_ring_bytes = ring;
+    for (auto& e : C->pin_ev) WS_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return WS_OK;
+}
+int context_warm_staging() {
+    Context* C = ctx();
+    if (!C) return WS_ERR_NOINIT;
+    std::lock_guard<std::mutex> lk(g_ring_mu);
+    return ensure_ring(C);
+}
+
 int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s, const ChunkFn& on_chunk, hipStream_t s_alt) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
@@ -272,15 +301,8 @@ int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s
         }
         return WS_OK;
     }
-    static std::mutex ring_mu;                      // one upload at a time uses the ring
-    std::lock_guard<std::mutex> lk(ring_mu);
-    if (!C->pin_ring) {
-        size_t ring = (size_t)tuning_get("STAGE_RING_KB", 128 << 10) << 10;        // (read once, when the ring is created)
-        ring = ring < ((size_t)1 << 20) ? ((size_t)1 << 20) : ring > ((size_t)1 << 30) ? ((size_t)1 << 30) : ring;
-        WS_HIP_CHECK(hipHostMalloc(&C->pin_ring, ring, 0));
-        C->pin_ring_bytes = ring;
-        for (auto& e : C->pin_ev) WS_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
+    std::lock_guard<std::mutex> lk(g_ring_mu);      // one upload at a time uses the ring
+    if ((rc = ensure_ring(C))) return rc;
     if (chunk > C->pin_ring_bytes / 2) chunk = (C->pin_ring_bytes / 2) & ~(size_t)0xFFFF;
     size_t nslots = C->pin_ring_bytes / chunk;
     if (nslots > (size_t)PIN_MAX_SLOTS) nslots = PIN_MAX_SLOTS;

@@ -87,8 +87,18 @@ static int dist_ntt_native(Lane& L, const DistComm& cm, Fe* x, Fe* y, uint32_t l
     const uint64_t total = k * r1 * n2;
     if (total * sizeof(Fe) > cm.buf_bytes) { set_last_error("prove_dist: exchange buffers too small"); return WS_ERR_SIZE; }
     int rc;
-    if (odd && (rc = dist_scale_dev(x, k, r1, n2, row0, log_n1, log_n, 1, 0, s))) return rc;          // x[t] *= w_2n^t
-    if (log_n2 >= 1 && (rc = ntt_dev(L, x, n2, 0, inverse, s, k * r1))) return rc;                    // column step
+    // x[t] *= w_2n^t (odd), then the column step.  Round 4: the factors are applied by the column step's own first load (row b of
+    // the batch knows its t: NttRowCoset) -- the separate pass over the stack (saturated field, 64-bit divisions: 0.33 ms for two
+    // 2^20 vectors in rocprofv3, more than the pack and unpack passes together) is kept for blocks the batch cannot describe
+    if (odd && log_n2 >= 1 && (r1 & (r1 - 1)) == 0 && tuning_get("DIST_FUSED_COSET", 1)) {
+        NttRowCoset pre;
+        if ((rc = ntt_coset_tables_kernel_format((int)log_n, &pre.lo, &pre.hi, &pre.hc, s))) return rc;
+        pre.shift = log_n1; pre.row0 = (uint32_t)row0; pre.row_mask = (uint32_t)(r1 - 1);
+        if ((rc = ntt_run(L, x, nullptr, x, nullptr, n2, 0, inverse, s, k * r1, &pre))) return rc;
+    } else {
+        if (odd && (rc = dist_scale_dev(x, k, r1, n2, row0, log_n1, log_n, 1, 0, s))) return rc;
+        if (log_n2 >= 1 && (rc = ntt_dev(L, x, n2, 0, inverse, s, k * r1))) return rc;                // column step
+    }
     const Fe *lo, *hi;
     int h;
     if ((rc = ntt_twiddle_tables((int)log_n, inverse, &lo, &hi, &h, s, /* internal form of the radix-2^29 field */ true))) return rc;

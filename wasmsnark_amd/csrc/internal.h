@@ -150,8 +150,13 @@ void tuning_set(const char* name, long value);     // value == LONG_MIN: forget 
 int ntt_dev(Lane& L, Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s, uint64_t count = 1);
 // the general form: reads d_src (times d_in2 element-wise, if given), writes d_dst; combine_e (inverse only): the last
 // pass stores CALC_H's h[t] = fromMontgomery((e[t] - w_2n^-t v[t]) / 2) instead of the transform v (calch.hip)
+// rc_pre (batched column step of the distributed transform, dist.hip): transform b of the batch is row (b & row_mask) of a rank's
+// block of a longer vector; its element g is multiplied on load by that vector's coset factor w_2N^(row0 + row + (g << shift))
+// (tables of the LONGER length, ntt_coset_tables_kernel_format) -- the coset pre-scale without a pass of its own
+struct NttRowCoset { const Fe* lo; const Fe* hi; uint32_t hc, shift, row0, row_mask; };
 int ntt_run(Lane& L, const Fe* d_src, const Fe* d_in2, Fe* d_dst, const Fe* combine_e, uint64_t n, int odd, int inverse,
-            hipStream_t s, uint64_t count = 1);
+            hipStream_t s, uint64_t count = 1, const NttRowCoset* rc_pre = nullptr);
+int ntt_coset_tables_kernel_format(int bits, const Fe** lo, const Fe** hi, uint32_t* hc, hipStream_t s);
 // internal = true: the same tables in the internal form of the radix-2^29 field (entries x 2^5), as the transform kernels read them
 int ntt_twiddle_tables(int bits, int inverse, const Fe** lo, const Fe** hi, int* h, hipStream_t s, bool internal = false);
 

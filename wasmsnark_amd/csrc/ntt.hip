@@ -40,6 +40,9 @@ struct PassArgs {
     const Fe* tw_lo; const Fe* tw_hi; uint32_t h;   // two-level w_N^e = tw_hi[e>>h] * tw_lo[e & mask]
     uint32_t apply_twiddle;
     const Fe* cs_lo; const Fe* cs_hi; uint32_t hc; uint32_t prescale;   // coset factors w_2N^i
+    // prescale == 2 (distributed column step, dist.hip): transform b of the batch is row (b & pre_row_mask) of a rank's block of a
+    // LONGER vector, its element g sits at position pre_row0 + row + (g << pre_shift) of that vector, and cs_* are THAT length's tables
+    uint32_t pre_shift, pre_row0, pre_row_mask;
     uint32_t scale, first;
     Fe out_scale;   // reference-format Montgomery form of 1/n (inverse) or 1
     // radix-2^29 path, >= 2 passes: one full inter-digit twiddle table per pass (index kk*S + i_rest) that also
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
             v = F::mul(v, F::unpack(A.in2[g]));
             if (F::kInternalDomain && A.fold_in != 2) v = F::mul(v, F::unpack(A.k271));
         } else if (A.prescale) {   // only ever set for pass 0, where storage index == input index
-            const uint32_t e = (uint32_t)g;
+            const uint32_t e = A.prescale == 2 ? ((uint32_t)g << A.pre_shift) + A.pre_row0 + (blockIdx.y & A.pre_row_mask) : (uint32_t)g;
             El f = F::mul(F::unpack(A.cs_hi[e >> A.hc]), F::unpack(A.cs_lo[e & ((1u << A.hc) - 1)]));
             v = F::mul(v, f);          // (radix-2^29: cs_lo carries the extra 2^5 => also converts the domain)
         } else if (F::kInternalDomain && A.first && !A.fold_in) {
@@ -435,6 +438,18 @@ int ntt_coset_tables(int bits, const Fe** lo, const Fe** hi, int* hc, Fe* n_inv,
     return WS_OK;
 }
 
+// the coset factors w_2n^i of a length-n transform in the format ntt_pass_kernel's pre-scale reads (NttRowCoset: lo, hi, hc)
+int ntt_coset_tables_kernel_format(int bits, const Fe** lo, const Fe** hi, uint32_t* hc, hipStream_t s) {
+    Context* C = ctx();
+    if (!C) return WS_ERR_NOINIT;
+    if (bits < 1 || bits >= 28) return WS_ERR_SIZE;
+    std::shared_ptr<NttPlan> P;
+    int rc = get_plan(C, bits, P, s);
+    if (rc) return rc;
+    *lo = P->cs_lo.as<Fe>(); *hi = P->cs_hi.as<Fe>(); *hc = (uint32_t)P->hc;
+    return WS_OK;
+}
+
 // w_n^(+-e), e < n = 2^bits, two-level in the reference Montgomery form: value = hi[e >> h] * lo[e & mask]
 int ntt_twiddle_tables(int bits, int inverse, const Fe** lo, const Fe** hi, int* h, hipStream_t s, bool internal) {
     Context* C = ctx();
@@ -458,11 +473,11 @@ int ntt_dev(Lane& L, Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s
 
 // src (x in2) -> dst; combine_e != nullptr: the last pass stores CALC_H's h instead of the transform (inverse only)
 int ntt_run(Lane& L, const Fe* d_src, const Fe* d_in2, Fe* d_data, const Fe* combine_e, uint64_t n, int odd, int inverse,
-            hipStream_t s, uint64_t count) {
+            hipStream_t s, uint64_t count, const NttRowCoset* rc_pre) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
     if (!d_data || !d_src) return WS_ERR_ARG;
-    if ((d_in2 && odd) || (combine_e && (!inverse || count != 1))) return WS_ERR_ARG;
+    if ((d_in2 && odd) || (combine_e && (!inverse || count != 1)) || (rc_pre && (odd || d_in2))) return WS_ERR_ARG;
     if (!s) s = L.stream;
     // src/build_fft.js:92-157: n must be a power of two <= 2^28 (the reference traps otherwise)
     if (n == 0 || (n & (n - 1)) || n > ((uint64_t)1 << 28)) return WS_ERR_SIZE;
@@ -515,12 +530,17 @@ int ntt_run(Lane& L, const Fe* d_src, const Fe* d_in2, Fe* d_data, const Fe* com
         A.apply_twiddle = last ? 0 : 1;
         A.cs_lo = P->cs_lo.as<Fe>(); A.cs_hi = P->cs_hi.as<Fe>(); A.hc = P->hc;
         A.prescale = (odd && p == 0) ? 1 : 0;
+        A.pre_shift = A.pre_row0 = A.pre_row_mask = 0;
+        if (rc_pre && p == 0) {
+            A.cs_lo = rc_pre->lo; A.cs_hi = rc_pre->hi; A.hc = rc_pre->hc;
+            A.prescale = 2; A.pre_shift = rc_pre->shift; A.pre_row0 = rc_pre->row0; A.pre_row_mask = rc_pre->row_mask;
+        }
         A.scale = (inverse && last) ? 1 : 0;
         A.first = (p == 0) ? 1 : 0;
         A.out_scale = A.scale ? P->n_inv : Fr::one();
         A.tw_full = nullptr; A.fold_in = 0; A.out_plain = 0;
         if (P->field29 && P->np >= 2) {
-            const int fold_in = (p == 0 && !odd) ? (d_in2 ? 2 : 1) : 0;   // odd: the coset product already converts; 2: product on load
+            const int fold_in = (p == 0 && !odd && !rc_pre) ? (d_in2 ? 2 : 1) : 0;   // odd: the coset product already converts; 2: product on load
             const bool fold_out = (p == P->np - 2);
             A.fold_in = (uint32_t)fold_in;
             A.out_plain = last ? 1 : 0;

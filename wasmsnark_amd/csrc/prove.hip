@@ -190,6 +190,9 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
         for (auto& sc : secs) sc.d->release();
         K->table_cw = K->table_ch = 0;
     }
+    const bool trace_load = getenv("WSNARK_TRACE") && atoi(getenv("WSNARK_TRACE")) == 1;
+    auto since = [&](Clock::time_point from) { return std::chrono::duration<double, std::milli>(Clock::now() - from).count(); };
+    if (trace_load) fprintf(stderr, "[wsnark trace] key load: device buffers allocated at %.2f ms\n", since(t_begin));
     std::vector<uint8_t> h_gather;
     if (K->h_log_m) {
         // the rank's rows of the m-interleaved layout, row-major (m / world) x (domain / m): local (r, j) = hExps[(rank m/world + r) + m j]
@@ -207,8 +210,10 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
             WS_HIP_CHECK(hipMemsetAsync(sc.d->p, 0, front, s));
         }
         if (sc.bytes && (rc = upload_staged((uint8_t*)sc.d->p + front, sc.src, (size_t)sc.bytes, s))) return rc;
+        if (trace_load) fprintf(stderr, "[wsnark trace] key load: section of %llu bytes handed to the copy queue at %.2f ms\n", (unsigned long long)sc.bytes, since(t_begin));
     }
     K->load_ms[1] = lap(t_phase);
+    if (trace_load) fprintf(stderr, "[wsnark trace] key load: sections resident at %.2f ms\n", since(t_begin));
     // Variables that do not occur in matrix A (resp. B) have A (resp. B1 = B2) = infinity -- common: real circuits put
     // far fewer terms on the B side.  Their pairs cost a lane slot each in those sums, so when there are enough of
     // them the sums run on a plan VARIANT that leaves them out (msm_plan_variant: the per-bin sort and the task list
