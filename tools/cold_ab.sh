@@ -1,3 +1,5 @@
+# Cold path A/B on the GPU box: the Node and fresh-Python first calls (tools/node_bench.py), then the bench line's `cold` object with the
+# table rows built in short launches (default) and by the one long kernel per section (WSNARK_TABLE_STEPPED=0).
 timeout 300 python tools/node_bench.py 20 5 > gpurun_out/nb3.json 2>gpurun_out/nb3.err
 python -c "
 import json
