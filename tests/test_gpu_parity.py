@@ -404,6 +404,43 @@ def test_host_witness_paths_and_runtime_switches(bn):
         bn.lib.c.wsnark_host_free(pinned)
 
 
+def test_proofs_beside_the_background_table_build(bn):
+    """Round 4: wsnark_pkey_load returns when the sections are resident; the rows of the fixed-base tables are built behind it on a
+    queue of their own, and proofs that arrive meanwhile run on the plain sections.  At 2^18: proofs right behind the load (two of
+    them from the two lanes at once), across the moment the tables become ready, and after wsnark_pkey_wait_tables -- all equal to
+    the closed form; the same with the one-kernel build (WSNARK_TABLE_STEPPED=0) and with a scratch slab smaller than the sections; a
+    key freed while its build is still running; load stats report the build only once it is over."""
+    import threading
+    from wasmsnark_amd import synth
+    circ = synth.NativeCircuit(bn.lib, 18, n_public=5, seed=45)
+    sec, _ = circ.build_sections()
+    wit = circ.witness_bin()
+    r, s = os.urandom(32), os.urandom(32)
+    want = circ.expected_proof(r, s)
+    try:
+        for cfg in ({}, {"TABLE_STEPPED": 0}, {"TABLE_SLAB_LANES": 4096}):
+            for n in ("TABLE_STEPPED", "TABLE_SLAB_LANES"):
+                bn.lib.tune(n, cfg.get(n))
+            key = bn.load_key(sections=sec, wait_tables=False)
+            assert key.table["rows_w"] > 1
+            got = [None, None]
+            th = [threading.Thread(target=lambda i=i: got.__setitem__(i, bn.groth16GenProof(wit, key, r=r, s=s))) for i in range(2)]
+            for t in th: t.start()
+            for t in th: t.join()
+            assert got[0] == want and got[1] == want, cfg
+            for _ in range(12):                                   # (a 2^18 build takes tens of ms: some of these straddle its end)
+                assert bn.groth16GenProof(wit, key, r=r, s=s) == want, cfg
+            key.wait_tables()
+            assert key.load_ms["table_build"] > 0
+            assert bn.groth16GenProof(wit, key, r=r, s=s) == want, cfg
+            key.free()
+            doomed = bn.load_key(sections=sec, wait_tables=False)
+            doomed.free()                                         # the destructor waits for the build queue
+    finally:
+        for n in ("TABLE_STEPPED", "TABLE_SLAB_LANES"):
+            bn.lib.tune(n, None)
+
+
 def test_sections_loader_2p18_equals_file_loader(bn):
     """wsnark_pkey_load_sections (the container for keys beyond proving_key.bin's 4 GiB of u32 offsets: BASELINE
     config 5) against wsnark_pkey_load on the same 2^18 key: same proofs, equal to the closed form; short
