@@ -2,7 +2,7 @@
 """A fresh process's first calls on a key read from a file, one by one (what tools/node_bench.js sees, without Node): load the
 key without waiting for the table rows, then six proofs from a host witness, each timed; optionally with a thread hashing the
 key bytes beside the load (the JS edge takes a whole-buffer digest off the event loop at load time).
-    python tools/cold_probe.py <proving_key.bin> <witness.bin> [--hash] [--wait]    -> one JSON line"""
+    python tools/cold_probe.py <proving_key.bin> <witness.bin> [--hash] [--wait] [--no-torch]    -> one JSON line"""
 import hashlib
 import json
 import os
@@ -12,14 +12,19 @@ import time
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 t_start = time.perf_counter()
+if "--no-torch" in sys.argv:
+    # the library then resolves libamdhip64 to /opt/rocm's (what the Node addon gets) instead of the one PyTorch bundles and
+    # loads first (wasmsnark_amd/_lib.py): the two hosts otherwise run DIFFERENT HIP runtimes
+    sys.modules["torch"] = None
 import wasmsnark_amd
-pkey = open(sys.argv[1], "rb").read()
-wit = open(sys.argv[2], "rb").read()
 r, s = bytes(range(32)), bytes(range(32, 64))
 ms = lambda t0: round((time.perf_counter() - t0) * 1e3, 2)
 t0 = time.perf_counter()
-bn = wasmsnark_amd.build(device=0)
-out = {"hash_beside_load": "--hash" in sys.argv, "wait_tables": "--wait" in sys.argv, "init_ms": ms(t0)}
+bn = wasmsnark_amd.build(device=0)        # (first the library, then the inputs: wsnark_init's helper threads work while the files are read)
+t_init = ms(t0)
+pkey = open(sys.argv[1], "rb").read()
+wit = open(sys.argv[2], "rb").read()
+out = {"hip_runtime": "/opt/rocm (no PyTorch in the process)" if "--no-torch" in sys.argv else "PyTorch's bundled libamdhip64", "hash_beside_load": "--hash" in sys.argv, "wait_tables": "--wait" in sys.argv, "init_ms": t_init}
 th = None
 if "--hash" in sys.argv:
     th = threading.Thread(target=lambda: out.__setitem__("hash_ms", (lambda t: (hashlib.blake2b(pkey).digest(), ms(t))[1])(time.perf_counter())))
@@ -38,6 +43,7 @@ out["all_equal"] = all(p == proofs[0] for p in proofs)
 if th:
     th.join()
 key.wait_tables()
+out["load_ms_by_phase"] = {k: round(v, 2) for k, v in key.load_ms.items()}
 t0 = time.perf_counter()
 for i in range(10):
     bn.groth16GenProof(wit, key, r=r, s=s)

@@ -58,7 +58,7 @@ else:
     res["node_proof_matches_closed_form"] = js.get("proof_pi_a0") == want["pi_a"][0]
     res["js_key_bytes_call_over_ctypes_host_witness_ms"] = round(js["key_bytes_call_ms"] - res["ctypes_host_witness_ms"], 3)
 # the same first calls from a fresh PYTHON process (no Node, no digest; then with a thread hashing the key beside the load)
-for label, extra in (("fresh_python_process", []), ("fresh_python_process_hash_beside_load", ["--hash"])):
+for label, extra in (("fresh_python_process", []), ("fresh_python_process_rocm_hip_runtime_like_node", ["--no-torch"])):
     cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cold_probe.py"), kp, wp] + extra, capture_output=True, text=True, timeout=600)
     if os.environ.get("NODE_BENCH_STDERR"):
         sys.stderr.write("---- " + label + "\n" + cp.stderr[:6000])

@@ -257,8 +257,19 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const uint8_t* __restrict
     coef[k] = Fr::to_mont(c);
 }
 
+struct SlabPiece {      // a part of one device allocation, with DevBuf's accessor
+    void* p = nullptr;
+    template <class T> T* as() const { return (T*)p; }
+};
+
 int pols_to_csr(const uint8_t* pols, size_t len, uint32_t n_signals, uint32_t domain, CsrMatrix* out,
                 size_t* consumed, hipStream_t s) {
+    const bool trace = getenv("WSNARK_TRACE") && atoi(getenv("WSNARK_TRACE")) == 1;
+    const auto t_in = std::chrono::steady_clock::now();
+    auto at = [&](const char* what) {
+        if (trace) fprintf(stderr, "[wsnark trace] pols_to_csr (%u signals): %s at %.2f ms\n", n_signals, what,
+                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count());
+    };
     // pass 0 (host, sequential): where every signal's records start and how many records precede it; lengths validated
     std::vector<uint64_t> start((size_t)n_signals + 1);
     std::vector<uint32_t> rec_base((size_t)n_signals + 1);
@@ -283,16 +294,29 @@ int pols_to_csr(const uint8_t* pols, size_t len, uint32_t n_signals, uint32_t do
     WS_HIP_CHECK(out->col.alloc(nz * 4));
     WS_HIP_CHECK(out->coef.alloc(nz * sizeof(Fe)));
     const uint32_t ntiles = ceil_div_u64((uint64_t)domain + 1, 1024);
-    DevBuf d_blob, d_start, d_base, d_sig, d_row, d_cnt, d_cursor, d_tiles, d_bad;
-    WS_HIP_CHECK(d_blob.alloc(pp + 64));
-    WS_HIP_CHECK(d_start.alloc(start.size() * 8));
-    WS_HIP_CHECK(d_base.alloc(rec_base.size() * 4));
-    WS_HIP_CHECK(d_sig.alloc(nz * 4));
-    WS_HIP_CHECK(d_row.alloc(nz * 4));
-    WS_HIP_CHECK(d_cnt.alloc(((size_t)domain + 1) * 4));
-    WS_HIP_CHECK(d_cursor.alloc(((size_t)domain + 1) * 4));
-    WS_HIP_CHECK(d_tiles.alloc((size_t)ntiles * 4));
-    WS_HIP_CHECK(d_bad.alloc(4));
+    // the nine temporaries in ONE allocation (every hipMalloc / hipFree is a call into the driver -- and a free waits for the device:
+    // with the ROCm 7.2 runtime the 2 x 12 allocations and 2 x 9 frees of the two matrices were half of this function's 30 ms)
+    SlabPiece d_blob, d_start, d_base, d_sig, d_row, d_cnt, d_cursor, d_tiles, d_bad;
+    struct StreamSlab {       // allocated and freed in queue order where the runtime has a stream-ordered allocator (a plain hipFree waits for the whole device)
+        void* p = nullptr; hipStream_t q = nullptr; bool ordered = false;
+        hipError_t alloc(size_t bytes, hipStream_t s) {
+            q = s;
+            if (hipMallocAsync(&p, bytes, s) == hipSuccess) { ordered = true; return hipSuccess; }
+            (void)hipGetLastError();
+            return hipMalloc(&p, bytes);
+        }
+        ~StreamSlab() { if (p) { if (ordered) (void)hipFreeAsync(p, q); else (void)hipFree(p); } }
+    } d_tmp;
+    {
+        const size_t sizes[9] = {pp + 64, start.size() * 8, rec_base.size() * 4, nz * 4, nz * 4, ((size_t)domain + 1) * 4, ((size_t)domain + 1) * 4, (size_t)ntiles * 4, 4};
+        SlabPiece* const pieces[9] = {&d_blob, &d_start, &d_base, &d_sig, &d_row, &d_cnt, &d_cursor, &d_tiles, &d_bad};
+        size_t total = 0;
+        for (size_t b : sizes) total += (b + 255) & ~(size_t)255;
+        WS_HIP_CHECK(d_tmp.alloc(total, s));
+        size_t off = 0;
+        for (int i = 0; i < 9; i++) { pieces[i]->p = (uint8_t*)d_tmp.p + off; off += (sizes[i] + 255) & ~(size_t)255; }
+    }
+    at("header walk + allocations done");
     int rc;
     if ((rc = upload_staged(d_blob.p, pols, pp, s))) return rc;
     if ((rc = upload_staged(d_start.p, start.data(), start.size() * 8, s))) return rc;
@@ -310,12 +334,14 @@ int pols_to_csr(const uint8_t* pols, size_t len, uint32_t n_signals, uint32_t do
     uint32_t bad = 0;
     WS_HIP_CHECK(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, s));
     WS_HIP_CHECK(hipStreamSynchronize(s));
+    at("records uploaded, counted, scanned");
     if (bad) { set_last_error("pols: coefficient index >= domainSize"); return WS_ERR_FORMAT; }
     if (nnz)
         hipLaunchKernelGGL(csr_fill_kernel, dim3(ceil_div_u64(nnz, 256)), dim3(256), 0, s, d_blob.as<uint8_t>(), d_start.as<uint64_t>(), d_base.as<uint32_t>(),
                            (uint32_t)nnz, d_sig.as<uint32_t>(), d_row.as<uint32_t>(), d_cursor.as<uint32_t>(), out->col.as<uint32_t>(), out->coef.as<Fe>());
     WS_HIP_CHECK(hipGetLastError());
     WS_HIP_CHECK(hipStreamSynchronize(s));
+    at("filled");
     return WS_OK;
 }
 
@@ -383,5 +409,7 @@ int calc_h_dev(Lane& L, const Fe* d_signals_plain, uint32_t n_signals, const Csr
     WS_HIP_CHECK(hipGetLastError());
     return WS_OK;
 }
+
+WS_DEFINE_WARM(calch)
 
 }  // namespace wsnark

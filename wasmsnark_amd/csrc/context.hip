@@ -87,19 +87,46 @@ int context_init(int device) {
         WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream_copy, hipStreamNonBlocking));
         WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream_copy2, hipStreamNonBlocking));
     }
+    for (auto& q : C->load_q) WS_HIP_CHECK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
     g_ctx = C;
 #ifndef WSNARK_EMUL
-    // the pinned staging ring now, not inside the first key load (WSNARK_STAGE_EAGER=0: on first use, as before)
-    if (tuning_get("STAGE_EAGER", 1) && context_warm_staging() != WS_OK) (void)hipGetLastError();      // (not fatal: the first upload will say)
+    // Two helper threads do what the first key load and proof of a process would otherwise wait for: one pins the staging ring
+    // (8-26 ms), the other launches one no-op kernel per translation unit, which makes the runtime load that unit's code object
+    // (7-12 ms for msm.hip alone under ROCm 7.2).  wsnark_init returns at once; whoever needs the ring or a kernel first finds the
+    // work done or in progress (the ring is created under its mutex, module loads are serialised by the runtime) -- a key load that
+    // follows immediately waits for the ring, and the code objects load while its sections go up.  WSNARK_INIT_WARM=0: on first use.
+    if (tuning_get("INIT_WARM", 1)) {
+        const int device = C->device;
+        if (tuning_get("STAGE_EAGER", 1))
+            C->warm_ring = std::thread([device]() {
+                if (hipSetDevice(device) != hipSuccess) return;
+                if (context_warm_staging() != WS_OK) (void)hipGetLastError();      // (not fatal: the first upload will say)
+            });
+        C->warm = std::thread([device]() {
+            if (hipSetDevice(device) != hipSuccess) return;
+            hipStream_t q = nullptr;
+            if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return; }
+            warm_msm(q); warm_calch(q); warm_ntt(q); warm_fixedbase(q); warm_dist(q);
+            (void)hipStreamSynchronize(q);
+            (void)hipStreamDestroy(q);
+        });
+    }
 #endif
     return WS_OK;
+}
+void context_join_warm(Context* C) {
+    std::lock_guard<std::mutex> lk(C->warm_mu);
+    if (C->warm.joinable()) C->warm.join();
+    if (C->warm_ring.joinable()) C->warm_ring.join();
 }
 
 void context_shutdown() {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     if (!g_ctx) return;
+    context_join_warm(g_ctx);
     (void)hipSetDevice(g_ctx->device);
     (void)hipStreamSynchronize(g_ctx->stream);
+    for (auto& q : g_ctx->load_q) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); q = nullptr; }
     for (int i = 0; i < g_ctx->n_lanes; i++) {
         (void)hipStreamSynchronize(g_ctx->lanes[i].stream);
         (void)hipStreamSynchronize(g_ctx->lanes[i].stream2);

@@ -182,4 +182,6 @@ int calc_h_dist(Lane& L, const DistComm& cm, const Fe* d_signals_plain, uint32_t
     return dist_combine_dev(T + 2 * n_loc, T, d_h_local, rows, (uint64_t)1 << (log_n - l2), (uint64_t)cm.rank * rows, l2, log_n, s);
 }
 
+WS_DEFINE_WARM(dist)
+
 }  // namespace wsnark

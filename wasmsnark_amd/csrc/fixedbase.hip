@@ -56,4 +56,6 @@ static int mul_base_host(const void* base, const void* scalars, uint64_t n, void
 int g1_mul_base_batch(const void* base, const void* scalars, uint64_t n, void* out) { return mul_base_host<G1>(base, scalars, n, out); }
 int g2_mul_base_batch(const void* base, const void* scalars, uint64_t n, void* out) { return mul_base_host<G2>(base, scalars, n, out); }
 
+WS_DEFINE_WARM(fixedbase)
+
 }  // namespace wsnark

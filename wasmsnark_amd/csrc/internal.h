@@ -5,6 +5,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "curve.h"
@@ -102,7 +103,21 @@ struct Context {
     size_t pin_ring_bytes = 0;
     size_t pin_chunk_last = 0;                  // chunk size of the last upload through the ring (slot geometry of the events)
     hipEvent_t pin_ev[128] = {};                // one per ring slot: the slot's last DMA
+    hipStream_t load_q[2] = {nullptr, nullptr}; // key loads: the two matrices are transposed side by side on these
+    std::thread warm, warm_ring;                // wsnark_init's helpers: code objects; staging ring (joined by shutdown)
+    std::mutex warm_mu;
 };
+// One no-op kernel per translation unit: the runtime loads a TU's code object when the first of its kernels is launched (7-12 ms for
+// msm.hip under ROCm 7.2) -- wsnark_init's helper thread launches these so that the first key load and proof do not pay for it
+void warm_msm(hipStream_t s);
+void warm_ntt(hipStream_t s);
+void warm_calch(hipStream_t s);
+void warm_dist(hipStream_t s);
+void warm_fixedbase(hipStream_t s);
+void context_join_warm(Context* C);
+#define WS_DEFINE_WARM(tu) \
+    __global__ void warm_kernel_##tu(int) {} \
+    void warm_##tu(hipStream_t s) { hipLaunchKernelGGL(warm_kernel_##tu, dim3(1), dim3(64), 0, s, 0); (void)hipGetLastError(); }
 
 // RAII: a free lane; with every lane busy the caller waits until ANY of them is released (not for one picked in advance:
 // a caller must not queue behind a long proof while another lane has already come free)

@@ -2067,4 +2067,6 @@ int msm_g2_host(Lane& L, const void* h_scalars, const void* h_points, uint64_t n
     return msm_host_t<G2, Jac<Fq2>>(L, 1, h_scalars, h_points, n, sh, out_host);
 }
 
+WS_DEFINE_WARM(msm)
+
 }  // namespace wsnark

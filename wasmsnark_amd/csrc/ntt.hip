@@ -603,4 +603,6 @@ int ntt_run(Lane& L, const Fe* d_src, const Fe* d_in2, Fe* d_data, const Fe* com
     return WS_OK;
 }
 
+WS_DEFINE_WARM(ntt)
+
 }  // namespace wsnark

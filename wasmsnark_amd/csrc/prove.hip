@@ -221,6 +221,7 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
     // WSNARK_PROVE_SPARSE: 0 never, 2 always.
     WS_HIP_CHECK(K->maskA.alloc((size_t)std::max<uint32_t>(nl, 1)));
     WS_HIP_CHECK(K->maskB.alloc((size_t)std::max<uint32_t>(nl, 1)));
+    if (trace_load) fprintf(stderr, "[wsnark trace] key load: mask buffers allocated at %.2f ms\n", since(t_begin));
     if ((rc = msm_points_mask(K->pointsA.as<Affine<Fq>>(), nullptr, nl, K->maskA.as<uint8_t>(), &K->infA, s))) return rc;
     if ((rc = msm_points_mask(K->pointsB1.as<Affine<Fq>>(), K->pointsB2.as<Affine<Fq2>>(), nl, K->maskB.as<uint8_t>(), &K->infB, s))) return rc;
     {
@@ -230,6 +231,7 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
         K->sparseA = mode == 2 || (mode == 1 && big && (uint64_t)K->infA * 100 >= (uint64_t)nl * 15);   // saves a share of one G1 sum
         K->sparseB = mode == 2 || (mode == 1 && big && (uint64_t)K->infB * 100 >= (uint64_t)nl * 5);    // ... of a G1 and a G2 sum
     }
+    if (trace_load) fprintf(stderr, "[wsnark trace] key load: infinity masks taken at %.2f ms\n", since(t_begin));
     // resident keys are kept in the device field's internal domain: no per-proof conversion pass
     if ((rc = msm_prepare_points(0, K->pointsA.p, nl, s))) return rc;
     if ((rc = msm_prepare_points(0, K->pointsB1.p, nl, s))) return rc;
@@ -237,14 +239,13 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
     if ((rc = msm_prepare_points(0, K->pointsC.p, nl, s))) return rc;
     if ((rc = msm_prepare_points(0, K->pointsH.p, hl, s))) return rc;
     K->load_ms[2] = lap(t_phase);
+    if (trace_load) fprintf(stderr, "[wsnark trace] key load: sections converted at %.2f ms\n", since(t_begin));
     // The two record streams are transposed side by side (calch.hip: pols_to_csr -- a header walk on the host, upload, three kernels
     // each, on queues of their own; round 3 did the two passes over the records on host threads: 56-65 ms of a 2^20 key's 214).
     // BEFORE the table build is launched: under it the transposition's small kernels wait for issue slots behind kernels that
     // use 0.95 of them (measured: 133 ms instead of 20), and the load must not return before the matrices are in.
     {
-        hipStream_t sa = nullptr, sb = nullptr;
-        WS_HIP_CHECK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
-        WS_HIP_CHECK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+        hipStream_t sa = C->load_q[0], sb = C->load_q[1];       // (the context's: creating and destroying two queues per load cost milliseconds under ROCm 7.2)
         size_t used_b = 0;
         const int device = C->device;
         std::string err_b;                      // (the error text is per thread: carried back by hand)
@@ -256,12 +257,11 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
         });
         rc = pols_to_csr(S.polsA, (size_t)S.lenA, nv, dom, &K->polsA, &used, sa);
         const int rcb = fb.get();
-        (void)hipStreamDestroy(sa);
-        (void)hipStreamDestroy(sb);
         if (rc) return rc;                      // (~ProvingKey waits for the build queue)
         if (rcb) { set_last_error(err_b); return rcb; }
     }
     K->load_ms[0] = lap(t_phase);               // (also drains `s`: sections resident and converted -- proofs may start)
+    if (trace_load) fprintf(stderr, "[wsnark trace] key load: matrices transposed at %.2f ms\n", since(t_begin));
     if (K->table_cw) {      // rows 1.. of the tables, from row 0, in that domain: on the key's own queue, behind everything `s` holds so far
         // (the LOWEST stream priority: the runtime multiplexes a process's streams onto a few hardware queues per priority class,
         //  and a proof whose queue shared one with a normal-priority build would sit behind 130 ms of table kernels -- seen through the
