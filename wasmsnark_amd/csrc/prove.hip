@@ -50,10 +50,19 @@ struct ProvingKey {
     // goes 0 -> 1.  WSNARK_TABLE_ASYNC=0: the load waits for the build as in round 3.
     hipStream_t build_q = nullptr;
     hipEvent_t ev_build0 = nullptr, ev_tables = nullptr;      // (timing events: their distance is the build's duration)
+    // 1 = rows built (or no tables at all), 0 = build queued, `ev_tables` recorded behind it, 2 = the launcher thread is still
+    // queueing it (the event is NOT recorded yet: querying it would say "done"), -1 = the build could not be queued (plain sections for good)
     std::atomic<int> tables_ready{1};
+    std::thread build_launcher;                               // queues the ~170 launches of the build (~9 ms of host time) behind the load's return
+    std::mutex launcher_mu;
+    void join_launcher() {
+        std::lock_guard<std::mutex> lk(launcher_mu);
+        if (build_launcher.joinable()) build_launcher.join();
+    }
     // Otherwise read-only after load: any number of proofs may use one handle at once (each on its own lane, which holds the
     // per-proof buffers and events).
     ~ProvingKey() {
+        join_launcher();
         if (build_q) { (void)hipStreamSynchronize(build_q); (void)hipStreamDestroy(build_q); }
         if (ev_build0) (void)hipEventDestroy(ev_build0);
         if (ev_tables) (void)hipEventDestroy(ev_tables);
@@ -64,18 +73,24 @@ struct ProvingKey {
 // whose partial results must mean the same on every rank), 0 = the plain sections
 static void pkey_table_state(ProvingKey* K, bool wait, uint32_t* cw, uint32_t* ch) {
     *cw = K->table_cw; *ch = K->table_ch;
-    if (!K->table_cw || K->tables_ready.load(std::memory_order_acquire)) return;
-    if (wait ? hipEventSynchronize(K->ev_tables) == hipSuccess : hipEventQuery(K->ev_tables) == hipSuccess) {
-        K->tables_ready.store(1, std::memory_order_release);
-        return;
+    if (!K->table_cw) return;
+    int st = K->tables_ready.load(std::memory_order_acquire);
+    if (st == 1) return;
+    if (st == 2 && wait) { K->join_launcher(); st = K->tables_ready.load(std::memory_order_acquire); }
+    if (st == 0) {
+        if (wait ? hipEventSynchronize(K->ev_tables) == hipSuccess : hipEventQuery(K->ev_tables) == hipSuccess) {
+            K->tables_ready.store(1, std::memory_order_release);
+            return;
+        }
+        (void)hipGetLastError();      // (hipErrorNotReady is not an error here)
     }
-    (void)hipGetLastError();      // (hipErrorNotReady is not an error here)
     *cw = *ch = 0;
 }
 int pkey_wait_tables(ProvingKey* K) {
     uint32_t cw, ch;
     pkey_table_state(K, true, &cw, &ch);
-    return (K->table_cw && !cw) ? (int)WS_ERR_HIP : (int)WS_OK;
+    if (K->table_cw && !cw) { set_last_error("proving key: the fixed-base table rows could not be built (the key serves proofs from its plain sections)"); return WS_ERR_HIP; }
+    return WS_OK;
 }
 
 const std::string& get_last_error();
@@ -262,46 +277,59 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
     }
     K->load_ms[0] = lap(t_phase);               // (also drains `s`: sections resident and converted -- proofs may start)
     if (trace_load) fprintf(stderr, "[wsnark trace] key load: matrices transposed at %.2f ms\n", since(t_begin));
-    if (K->table_cw) {      // rows 1.. of the tables, from row 0, in that domain: on the key's own queue, behind everything `s` holds so far
-        // (the LOWEST stream priority: the runtime multiplexes a process's streams onto a few hardware queues per priority class,
-        //  and a proof whose queue shared one with a normal-priority build would sit behind 130 ms of table kernels -- seen through the
-        //  Node addon: first proof 133 ms instead of 13; at the lowest priority the build has queues of its own and yields to proofs)
-        {
-            int lo = 0, hi = 0;
-            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&K->build_q, hipStreamNonBlocking, lo) != hipSuccess) {
-                (void)hipGetLastError();
-                K->build_q = nullptr;
-                WS_HIP_CHECK(hipStreamCreateWithFlags(&K->build_q, hipStreamNonBlocking));
-            }
-        }
+    if (K->table_cw) {      // rows 1.. of the tables, from row 0, in that domain: on the key's own queue (`s` is drained: the lap above)
         WS_HIP_CHECK(hipEventCreate(&K->ev_build0));
         WS_HIP_CHECK(hipEventCreate(&K->ev_tables));
-        K->tables_ready.store(0);
-        hipStream_t b = K->build_q;
-        WS_HIP_CHECK(hipEventRecord(K->ev_build0, s));
-        WS_HIP_CHECK(hipStreamWaitEvent(b, K->ev_build0, 0));
-        WS_HIP_CHECK(hipEventRecord(K->ev_build0, b));
-        // in short launches (a row per launch) through a scratch slab that lives on the build queue only -- allocated and freed in
-        // queue order, no host-side wait; TABLE_STEPPED=0 (or no stream-ordered allocator): the one long kernel per section
-        void* tmp = nullptr;
-        size_t tmp_bytes = 0;
-        if (tuning_get("TABLE_STEPPED", 1)) {
-            const uint64_t most = nl > hl ? nl : hl, cap = (uint64_t)tuning_get("TABLE_SLAB_LANES", 1 << 18);
-            tmp_bytes = msm_table_scratch_bytes(((most < cap ? most : cap) + 63) & ~(uint64_t)63);
-            if (hipMallocAsync(&tmp, tmp_bytes, b) != hipSuccess) { (void)hipGetLastError(); tmp = nullptr; tmp_bytes = 0; }
-        }
-        rc = msm_build_table(0, K->pointsA.p, nl, K->table_cw, b, tmp, tmp_bytes);
-        if (!rc) rc = msm_build_table(0, K->pointsB1.p, nl, K->table_cw, b, tmp, tmp_bytes);
-        if (!rc) rc = msm_build_table(1, K->pointsB2.p, nl, K->table_cw, b, tmp, tmp_bytes);
-        if (!rc) rc = msm_build_table(0, K->pointsC.p, nl, K->table_cw, b, tmp, tmp_bytes);
-        if (!rc) rc = msm_build_table(0, K->pointsH.p, hl, K->table_ch, b, tmp, tmp_bytes);
-        if (tmp) (void)hipFreeAsync(tmp, b);
-        if (rc) return rc;
-        WS_HIP_CHECK(hipEventRecord(K->ev_tables, b));
+        K->tables_ready.store(2);
+        ProvingKey* const Kp = K.get();
+        const int device = C->device;
+        auto queue_build = [Kp, device, nl, hl]() {
+            auto fail = [Kp]() { (void)hipGetLastError(); Kp->tables_ready.store(-1, std::memory_order_release); };
+            if (hipSetDevice(device) != hipSuccess) return fail();
+            // (the LOWEST stream priority: the runtime multiplexes a process's streams onto a few hardware queues per priority class,
+            //  and a proof whose queue shared one with a normal-priority build would sit behind 130 ms of table kernels -- seen through the
+            //  Node addon: first proof 133 ms instead of 13; at the lowest priority the build has queues of its own and yields to proofs)
+            int lo = 0, hi = 0;
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&Kp->build_q, hipStreamNonBlocking, lo) != hipSuccess) {
+                (void)hipGetLastError();
+                Kp->build_q = nullptr;
+                if (hipStreamCreateWithFlags(&Kp->build_q, hipStreamNonBlocking) != hipSuccess) return fail();
+            }
+            hipStream_t b = Kp->build_q;
+            if (hipEventRecord(Kp->ev_build0, b) != hipSuccess) return fail();
+            // in short launches (a row per launch) through a scratch slab that lives on the build queue only -- allocated and freed in
+            // queue order, no host-side wait; TABLE_STEPPED=0 (or no stream-ordered allocator): the one long kernel per section
+            void* tmp = nullptr;
+            size_t tmp_bytes = 0;
+            if (tuning_get("TABLE_STEPPED", 1)) {
+                const uint64_t most = nl > hl ? nl : hl, cap = (uint64_t)tuning_get("TABLE_SLAB_LANES", 1 << 18);
+                tmp_bytes = msm_table_scratch_bytes(((most < cap ? most : cap) + 63) & ~(uint64_t)63);
+                if (hipMallocAsync(&tmp, tmp_bytes, b) != hipSuccess) { (void)hipGetLastError(); tmp = nullptr; tmp_bytes = 0; }
+            }
+            int rb = msm_build_table(0, Kp->pointsA.p, nl, Kp->table_cw, b, tmp, tmp_bytes);
+            if (!rb) rb = msm_build_table(0, Kp->pointsB1.p, nl, Kp->table_cw, b, tmp, tmp_bytes);
+            if (!rb) rb = msm_build_table(1, Kp->pointsB2.p, nl, Kp->table_cw, b, tmp, tmp_bytes);
+            if (!rb) rb = msm_build_table(0, Kp->pointsC.p, nl, Kp->table_cw, b, tmp, tmp_bytes);
+            if (!rb) rb = msm_build_table(0, Kp->pointsH.p, hl, Kp->table_ch, b, tmp, tmp_bytes);
+            if (tmp) (void)hipFreeAsync(tmp, b);
+            if (rb || hipEventRecord(Kp->ev_tables, b) != hipSuccess) return fail();
+            Kp->tables_ready.store(0, std::memory_order_release);
+        };
+        // Queueing the build (a stream, the slab, ~170 launches) is ~9 ms of host time: a thread of the key's does it, the load
+        // returns.  TABLE_ASYNC=0, and the emulator (whose "launch" runs the whole kernel), do it here.
+#ifdef WSNARK_EMUL
+        const bool inline_launch = true;
+#else
+        const bool inline_launch = tuning_get("TABLE_ASYNC", 1) == 0 || tuning_get("TABLE_LAUNCH_THREAD", 1) == 0;
+#endif
+        if (inline_launch) queue_build();
+        else K->build_launcher = std::thread(queue_build);
     }
     if (K->table_cw && tuning_get("TABLE_ASYNC", 1) == 0) {
-        WS_HIP_CHECK(hipEventSynchronize(K->ev_tables));
-        K->tables_ready.store(1);
+        if (K->tables_ready.load() == 0) {
+            WS_HIP_CHECK(hipEventSynchronize(K->ev_tables));
+            K->tables_ready.store(1);
+        }
         K->load_ms[3] = lap(t_phase);           // the table build, waited for
     }
     K->load_ms[4] = std::chrono::duration<double, std::milli>(Clock::now() - t_begin).count();
@@ -351,7 +379,8 @@ void pkey_table_info(const ProvingKey* K, uint32_t* cw, uint32_t* rw, uint32_t* 
 void pkey_load_stats(const ProvingKey* K, double* out5) {
     memcpy(out5, K->load_ms, sizeof K->load_ms);
     // a background build reports its duration once it is over (0 until then)
-    if (K->table_cw && out5[3] == 0 && K->ev_tables && hipEventQuery(K->ev_tables) == hipSuccess) {
+    const int st = K->tables_ready.load(std::memory_order_acquire);      // (2: the event is not recorded yet; -1: never will be)
+    if (K->table_cw && out5[3] == 0 && K->ev_tables && (st == 0 || st == 1) && hipEventQuery(K->ev_tables) == hipSuccess) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, K->ev_build0, K->ev_tables) == hipSuccess) out5[3] = ms;
     } else {
