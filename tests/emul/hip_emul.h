@@ -108,9 +108,6 @@ static inline hipError_t hipMalloc(void** p, size_t n) {
     return *p ? hipSuccess : hipErrorOutOfMemory;
 }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
-// stream-ordered allocation: kernels run to completion inside their launch call here, so "in queue order" is "now"
-static inline hipError_t hipMallocAsync(void** p, size_t n, hipStream_t) { return hipMalloc(p, n); }
-static inline hipError_t hipFreeAsync(void* p, hipStream_t) { free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = aligned_alloc(64, (n + 63) & ~(size_t)63); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }

@@ -50,5 +50,8 @@ def test_node_dropin_on_gpu():
     import __graft_entry__
     __graft_entry__.ensure_built()
     _build_addon()
-    out = _run()
-    assert out.returncode == 0 and "NODE_DROPIN_OK" in out.stdout, out.stdout + out.stderr
+    # several times: the suite loads many small keys back to back and proves while their table rows are still being built -- a
+    # version of round 4 whose build scratch came from the stream-ordered allocator passed this once and failed 3 times in 60
+    for attempt in range(6):
+        out = _run()
+        assert out.returncode == 0 and "NODE_DROPIN_OK" in out.stdout, "attempt %d: " % attempt + out.stdout + out.stderr

@@ -295,24 +295,16 @@ int pols_to_csr(const uint8_t* pols, size_t len, uint32_t n_signals, uint32_t do
     WS_HIP_CHECK(out->coef.alloc(nz * sizeof(Fe)));
     const uint32_t ntiles = ceil_div_u64((uint64_t)domain + 1, 1024);
     // the nine temporaries in ONE allocation (every hipMalloc / hipFree is a call into the driver -- and a free waits for the device:
-    // with the ROCm 7.2 runtime the 2 x 12 allocations and 2 x 9 frees of the two matrices were half of this function's 30 ms)
+    // with the ROCm 7.2 runtime the 2 x 12 allocations and 2 x 9 frees of the two matrices were half of this function's 30 ms).
+    // Plain hipMalloc / hipFree on purpose: see prove.hip on the stream-ordered allocator
     SlabPiece d_blob, d_start, d_base, d_sig, d_row, d_cnt, d_cursor, d_tiles, d_bad;
-    struct StreamSlab {       // allocated and freed in queue order where the runtime has a stream-ordered allocator (a plain hipFree waits for the whole device)
-        void* p = nullptr; hipStream_t q = nullptr; bool ordered = false;
-        hipError_t alloc(size_t bytes, hipStream_t s) {
-            q = s;
-            if (hipMallocAsync(&p, bytes, s) == hipSuccess) { ordered = true; return hipSuccess; }
-            (void)hipGetLastError();
-            return hipMalloc(&p, bytes);
-        }
-        ~StreamSlab() { if (p) { if (ordered) (void)hipFreeAsync(p, q); else (void)hipFree(p); } }
-    } d_tmp;
+    DevBuf d_tmp;
     {
         const size_t sizes[9] = {pp + 64, start.size() * 8, rec_base.size() * 4, nz * 4, nz * 4, ((size_t)domain + 1) * 4, ((size_t)domain + 1) * 4, (size_t)ntiles * 4, 4};
         SlabPiece* const pieces[9] = {&d_blob, &d_start, &d_base, &d_sig, &d_row, &d_cnt, &d_cursor, &d_tiles, &d_bad};
         size_t total = 0;
         for (size_t b : sizes) total += (b + 255) & ~(size_t)255;
-        WS_HIP_CHECK(d_tmp.alloc(total, s));
+        WS_HIP_CHECK(d_tmp.alloc(total));
         size_t off = 0;
         for (int i = 0; i < 9; i++) { pieces[i]->p = (uint8_t*)d_tmp.p + off; off += (sizes[i] + 255) & ~(size_t)255; }
     }

@@ -88,6 +88,15 @@ int context_init(int device) {
         WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream_copy2, hipStreamNonBlocking));
     }
     for (auto& q : C->load_q) WS_HIP_CHECK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+    // (the LOWEST stream priority: the runtime multiplexes a process's streams onto a few hardware queues per priority class, and a
+    //  proof whose queue shared one with a normal-priority build would sit behind 130 ms of table kernels -- seen through the Node
+    //  addon: first proof 133 ms instead of 13; at the lowest priority the builds have a queue of their own and yield to proofs.
+    //  Created HERE, once: no queue is ever created while proofs may be in flight on other threads)
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&C->build_q, hipStreamNonBlocking, lo) != hipSuccess) {
+        (void)hipGetLastError();
+        C->build_q = nullptr;
+        WS_HIP_CHECK(hipStreamCreateWithFlags(&C->build_q, hipStreamNonBlocking));
+    }
     g_ctx = C;
 #ifndef WSNARK_EMUL
     // Two helper threads do what the first key load and proof of a process would otherwise wait for: one pins the staging ring
@@ -127,6 +136,8 @@ void context_shutdown() {
     (void)hipSetDevice(g_ctx->device);
     (void)hipStreamSynchronize(g_ctx->stream);
     for (auto& q : g_ctx->load_q) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); q = nullptr; }
+    if (g_ctx->build_q) { (void)hipStreamSynchronize(g_ctx->build_q); (void)hipStreamDestroy(g_ctx->build_q); g_ctx->build_q = nullptr; }
+    g_ctx->build_tmp.release();
     for (int i = 0; i < g_ctx->n_lanes; i++) {
         (void)hipStreamSynchronize(g_ctx->lanes[i].stream);
         (void)hipStreamSynchronize(g_ctx->lanes[i].stream2);

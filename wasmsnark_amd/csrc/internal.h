@@ -104,6 +104,9 @@ struct Context {
     size_t pin_chunk_last = 0;                  // chunk size of the last upload through the ring (slot geometry of the events)
     hipEvent_t pin_ev[128] = {};                // one per ring slot: the slot's last DMA
     hipStream_t load_q[2] = {nullptr, nullptr}; // key loads: the two matrices are transposed side by side on these
+    hipStream_t build_q = nullptr;              // the keys' background table builds, one after the other: the LOWEST stream priority (prove.hip)
+    DevBuf build_tmp;                           // ... and their scratch slab (the builds are serial on build_q: one slab serves them all); grow-only
+    std::mutex build_mu;                        // queueing a build (and growing the slab) is one key at a time
     std::thread warm, warm_ring;                // wsnark_init's helpers: code objects; staging ring (joined by shutdown)
     std::mutex warm_mu;
 };

@@ -44,26 +44,19 @@ struct ProvingKey {
     // wall-clock of the load, by phase (ms): pols -> CSR, point sections host -> device, masks + conversion to the device
     // field's domain, fixed-base table build, whole call (what a cold caller pays before its first proof)
     double load_ms[5] = {0, 0, 0, 0, 0};
-    // Round 4: the table rows 1.. are built IN THE BACKGROUND (queue `build_q`): the load returns once the sections are resident
+    // Round 4: the table rows 1.. are built IN THE BACKGROUND (the context's queue `build_q`): the load returns once the sections are resident
     // and converted (row 0 of every table = the plain section), proofs that arrive before `ev_tables` has fired run on the
     // plain sections (per-window plans: the round-1 / 2 path, ~15 % slower), later ones on the tables.  `tables_ready` only ever
     // goes 0 -> 1.  WSNARK_TABLE_ASYNC=0: the load waits for the build as in round 3.
-    hipStream_t build_q = nullptr;
     hipEvent_t ev_build0 = nullptr, ev_tables = nullptr;      // (timing events: their distance is the build's duration)
-    // 1 = rows built (or no tables at all), 0 = build queued, `ev_tables` recorded behind it, 2 = the launcher thread is still
-    // queueing it (the event is NOT recorded yet: querying it would say "done"), -1 = the build could not be queued (plain sections for good)
+    // 1 = rows built (or no tables at all), 0 = build queued, `ev_tables` recorded behind it, -1 = the build could not be queued
+    // (plain sections for good)
     std::atomic<int> tables_ready{1};
-    std::thread build_launcher;                               // queues the ~170 launches of the build (~9 ms of host time) behind the load's return
-    std::mutex launcher_mu;
-    void join_launcher() {
-        std::lock_guard<std::mutex> lk(launcher_mu);
-        if (build_launcher.joinable()) build_launcher.join();
-    }
     // Otherwise read-only after load: any number of proofs may use one handle at once (each on its own lane, which holds the
     // per-proof buffers and events).
     ~ProvingKey() {
-        join_launcher();
-        if (build_q) { (void)hipStreamSynchronize(build_q); (void)hipStreamDestroy(build_q); }
+        // the build writes this key's buffers: it must be over before they go (the queue is the context's; the event is this key's build)
+        if (ev_tables && tables_ready.load() == 0 && hipEventSynchronize(ev_tables) != hipSuccess) (void)hipGetLastError();
         if (ev_build0) (void)hipEventDestroy(ev_build0);
         if (ev_tables) (void)hipEventDestroy(ev_tables);
     }
@@ -76,7 +69,6 @@ static void pkey_table_state(ProvingKey* K, bool wait, uint32_t* cw, uint32_t* c
     if (!K->table_cw) return;
     int st = K->tables_ready.load(std::memory_order_acquire);
     if (st == 1) return;
-    if (st == 2 && wait) { K->join_launcher(); st = K->tables_ready.load(std::memory_order_acquire); }
     if (st == 0) {
         if (wait ? hipEventSynchronize(K->ev_tables) == hipSuccess : hipEventQuery(K->ev_tables) == hipSuccess) {
             K->tables_ready.store(1, std::memory_order_release);
@@ -277,53 +269,43 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
     }
     K->load_ms[0] = lap(t_phase);               // (also drains `s`: sections resident and converted -- proofs may start)
     if (trace_load) fprintf(stderr, "[wsnark trace] key load: matrices transposed at %.2f ms\n", since(t_begin));
-    if (K->table_cw) {      // rows 1.. of the tables, from row 0, in that domain: on the key's own queue (`s` is drained: the lap above)
+    if (K->table_cw) {
+        // Rows 1.. of the tables, from row 0, in that domain: queued on the CONTEXT's build queue (lowest stream priority; `s` is
+        // drained by the lap above), one key's build after the other, in short launches (a row per launch) through the context's
+        // scratch slab.  TABLE_STEPPED=0: the one long kernel per section.  No stream-ordered allocation anywhere near this: an earlier
+        // version of this round took the slab from hipMallocAsync / hipFreeAsync (and the matrices' temporaries likewise), and the Node
+        // suite -- many small keys loaded back to back, their builds still running under later proofs -- then produced a WRONG proof in
+        // 3 to 36 of 60 runs, depending on how long the builds overlapped later loads and proofs; with plain allocations 0 of 120.
         WS_HIP_CHECK(hipEventCreate(&K->ev_build0));
         WS_HIP_CHECK(hipEventCreate(&K->ev_tables));
-        K->tables_ready.store(2);
-        ProvingKey* const Kp = K.get();
-        const int device = C->device;
-        auto queue_build = [Kp, device, nl, hl]() {
-            auto fail = [Kp]() { (void)hipGetLastError(); Kp->tables_ready.store(-1, std::memory_order_release); };
-            if (hipSetDevice(device) != hipSuccess) return fail();
-            // (the LOWEST stream priority: the runtime multiplexes a process's streams onto a few hardware queues per priority class,
-            //  and a proof whose queue shared one with a normal-priority build would sit behind 130 ms of table kernels -- seen through the
-            //  Node addon: first proof 133 ms instead of 13; at the lowest priority the build has queues of its own and yields to proofs)
-            int lo = 0, hi = 0;
-            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&Kp->build_q, hipStreamNonBlocking, lo) != hipSuccess) {
-                (void)hipGetLastError();
-                Kp->build_q = nullptr;
-                if (hipStreamCreateWithFlags(&Kp->build_q, hipStreamNonBlocking) != hipSuccess) return fail();
+        std::lock_guard<std::mutex> build_lk(C->build_mu);
+        hipStream_t b = C->build_q;
+        void* tmp = nullptr;
+        size_t tmp_bytes = 0;
+        if (tuning_get("TABLE_STEPPED", 1)) {
+            const uint64_t most = nl > hl ? nl : hl, cap = (uint64_t)tuning_get("TABLE_SLAB_LANES", 1 << 18);
+            tmp_bytes = msm_table_scratch_bytes(((most < cap ? most : cap) + 63) & ~(uint64_t)63);
+            if (C->build_tmp.bytes < tmp_bytes) {
+                // growing frees the old slab: no build may still be using it (rare: a larger key than any before, while builds run)
+                WS_HIP_CHECK(hipStreamSynchronize(b));
+                if (C->build_tmp.reserve(tmp_bytes) != hipSuccess) { (void)hipGetLastError(); tmp_bytes = 0; }
             }
-            hipStream_t b = Kp->build_q;
-            if (hipEventRecord(Kp->ev_build0, b) != hipSuccess) return fail();
-            // in short launches (a row per launch) through a scratch slab that lives on the build queue only -- allocated and freed in
-            // queue order, no host-side wait; TABLE_STEPPED=0 (or no stream-ordered allocator): the one long kernel per section
-            void* tmp = nullptr;
-            size_t tmp_bytes = 0;
-            if (tuning_get("TABLE_STEPPED", 1)) {
-                const uint64_t most = nl > hl ? nl : hl, cap = (uint64_t)tuning_get("TABLE_SLAB_LANES", 1 << 18);
-                tmp_bytes = msm_table_scratch_bytes(((most < cap ? most : cap) + 63) & ~(uint64_t)63);
-                if (hipMallocAsync(&tmp, tmp_bytes, b) != hipSuccess) { (void)hipGetLastError(); tmp = nullptr; tmp_bytes = 0; }
-            }
-            int rb = msm_build_table(0, Kp->pointsA.p, nl, Kp->table_cw, b, tmp, tmp_bytes);
-            if (!rb) rb = msm_build_table(0, Kp->pointsB1.p, nl, Kp->table_cw, b, tmp, tmp_bytes);
-            if (!rb) rb = msm_build_table(1, Kp->pointsB2.p, nl, Kp->table_cw, b, tmp, tmp_bytes);
-            if (!rb) rb = msm_build_table(0, Kp->pointsC.p, nl, Kp->table_cw, b, tmp, tmp_bytes);
-            if (!rb) rb = msm_build_table(0, Kp->pointsH.p, hl, Kp->table_ch, b, tmp, tmp_bytes);
-            if (tmp) (void)hipFreeAsync(tmp, b);
-            if (rb || hipEventRecord(Kp->ev_tables, b) != hipSuccess) return fail();
-            Kp->tables_ready.store(0, std::memory_order_release);
-        };
-        // Queueing the build (a stream, the slab, ~170 launches) is ~9 ms of host time: a thread of the key's does it, the load
-        // returns.  TABLE_ASYNC=0, and the emulator (whose "launch" runs the whole kernel), do it here.
-#ifdef WSNARK_EMUL
-        const bool inline_launch = true;
-#else
-        const bool inline_launch = tuning_get("TABLE_ASYNC", 1) == 0 || tuning_get("TABLE_LAUNCH_THREAD", 1) == 0;
-#endif
-        if (inline_launch) queue_build();
-        else K->build_launcher = std::thread(queue_build);
+            tmp = tmp_bytes ? C->build_tmp.p : nullptr;
+        }
+        K->tables_ready.store(0);
+        WS_HIP_CHECK(hipEventRecord(K->ev_build0, b));
+        rc = msm_build_table(0, K->pointsA.p, nl, K->table_cw, b, tmp, tmp_bytes);
+        if (!rc) rc = msm_build_table(0, K->pointsB1.p, nl, K->table_cw, b, tmp, tmp_bytes);
+        if (!rc) rc = msm_build_table(1, K->pointsB2.p, nl, K->table_cw, b, tmp, tmp_bytes);
+        if (!rc) rc = msm_build_table(0, K->pointsC.p, nl, K->table_cw, b, tmp, tmp_bytes);
+        if (!rc) rc = msm_build_table(0, K->pointsH.p, hl, K->table_ch, b, tmp, tmp_bytes);
+        if (rc || hipEventRecord(K->ev_tables, b) != hipSuccess) {
+            // whatever was queued still writes this key's buffers: wait for it before the handle (and its buffers) go away
+            (void)hipStreamSynchronize(b);
+            (void)hipGetLastError();
+            K->tables_ready.store(-1);
+            return rc ? rc : (int)WS_ERR_HIP;
+        }
     }
     if (K->table_cw && tuning_get("TABLE_ASYNC", 1) == 0) {
         if (K->tables_ready.load() == 0) {
