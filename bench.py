@@ -570,7 +570,11 @@ def cached_cpu_baseline(cache, logd):
         return cb
     except Exception:  # noqa: BLE001
         pass
-    f = _latest_profile("*bench.json") if logd == 20 else None
+    import glob
+    import re
+    c = sorted(x for x in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*bench.json"))
+               if re.fullmatch(r"r\d\d_s\d+_bench\.json", os.path.basename(x)))          # (rNN_sM_bench.json: not ..._node_bench.json)
+    f = c[-1] if (c and logd == 20) else None
     try:
         cb = json.load(open(f))["cpu_baseline"]
         cb["from"] = "profiles/%s: ANOTHER box (no N = 1 run of this checkout was found here); the CPU leg is timed at N = 1 only" % os.path.basename(f)

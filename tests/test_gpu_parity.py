@@ -441,6 +441,62 @@ def test_proofs_beside_the_background_table_build(bn):
             bn.lib.tune(n, None)
 
 
+def test_loads_frees_and_proofs_overlap(bn):
+    """What the Node suite does, from Python threads (round 4: the background table builds of keys loaded back to back are still
+    queued while later keys load and proofs run; an intermediate version whose build scratch came from the stream-ordered
+    allocator returned wrong proofs in this pattern while every test that does one thing at a time passed).  One thread keeps
+    loading and freeing small reference keys (builds pile up on the context's build queue), two others prove -- on keys whose
+    tables are long ready, on keys loaded a moment ago, on a 2^12 circuit -- and every proof must be the golden / closed-form one."""
+    import threading
+    from wasmsnark_amd import synth
+    gold = load_golden("proofs.json")
+    names = [n for n in gold if os.path.exists(os.path.join(GOLDEN, "keys", n + ".pkey.bin"))]
+    files = {n: (open(os.path.join(GOLDEN, "keys", n + ".pkey.bin"), "rb").read(), open(os.path.join(GOLDEN, "keys", n + ".witness.bin"), "rb").read()) for n in names}
+    circ = synth.NativeCircuit(bn.lib, 12, n_public=5, seed=46)
+    sec, _ = circ.build_sections()
+    cwit = circ.witness_bin()
+    r, s = os.urandom(32), os.urandom(32)
+    cwant = circ.expected_proof(r, s)
+    old = {n: bn.load_key(files[n][0]) for n in names}                  # tables ready
+    stop = threading.Event()
+    errors = []
+
+    def loader():
+        try:
+            i = 0
+            while not stop.is_set():
+                n = names[i % len(names)]
+                k = bn.load_key(files[n][0], wait_tables=False)
+                if i % 3 == 0:
+                    k2 = bn.load_key(sections=sec, wait_tables=False)
+                    if bn.groth16GenProof(cwit, k2, r=r, s=s) != cwant: errors.append("fresh 2^12 key")
+                    k2.free()
+                c = gold[n][i % len(gold[n])]
+                if bn.groth16GenProof(files[n][1], k, r=H(c["r"]), s=H(c["s"])) != c["proof"]: errors.append("fresh key " + n)
+                k.free()
+                i += 1
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def prover(seed):
+        try:
+            rnd = random.Random(seed)
+            for _ in range(600):
+                n = rnd.choice(names)
+                c = rnd.choice(gold[n])
+                if bn.groth16GenProof(files[n][1], old[n], r=H(c["r"]), s=H(c["s"])) != c["proof"]: errors.append("resident key " + n)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=loader)] + [threading.Thread(target=prover, args=(i,)) for i in range(2)]
+    for t in th: t.start()
+    for t in th[1:]: t.join()
+    stop.set()
+    th[0].join()
+    for k in old.values(): k.free()
+    assert not errors, errors[:5]
+
+
 def test_sections_loader_2p18_equals_file_loader(bn):
     """wsnark_pkey_load_sections (the container for keys beyond proving_key.bin's 4 GiB of u32 offsets: BASELINE
     config 5) against wsnark_pkey_load on the same 2^18 key: same proofs, equal to the closed form; short
