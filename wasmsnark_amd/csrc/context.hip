@@ -111,13 +111,10 @@ int context_init(int device) {
                 if (hipSetDevice(device) != hipSuccess) return;
                 if (context_warm_staging() != WS_OK) (void)hipGetLastError();      // (not fatal: the first upload will say)
             });
-        C->warm = std::thread([device]() {
+        hipStream_t q = C->stream;      // (the utility queue: the launch itself is what loads the code object -- nothing to wait for)
+        C->warm = std::thread([device, q]() {
             if (hipSetDevice(device) != hipSuccess) return;
-            hipStream_t q = nullptr;
-            if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return; }
             warm_msm(q); warm_calch(q); warm_ntt(q); warm_fixedbase(q); warm_dist(q);
-            (void)hipStreamSynchronize(q);
-            (void)hipStreamDestroy(q);
         });
     }
 #endif
