@@ -6,9 +6,11 @@ import sys; sys.path.insert(0,'tests')
 import test_node_dropin as t
 t._build_addon()
 " 2>&1 | tail -1
-for cfg in "" "WSNARK_TABLE_STEPPED=0"; do
+# CONFIGS: space-separated VAR=value settings, one run series each ("default" = none);  RUNS: runs per series
+for cfg in ${CONFIGS:-default WSNARK_TABLE_STEPPED=0}; do
+  [ "$cfg" = default ] && cfg=WSNARK_NOOP=1
   ok=0; bad=0
-  for i in $(seq 1 60); do
+  for i in $(seq 1 ${RUNS:-60}); do
     env $cfg timeout 120 node tests/node_dropin_check.js > /tmp/nd.out 2>&1; rc=$?
     if [ $rc -eq 0 ]; then ok=$((ok+1)); else bad=$((bad+1)); echo "[$cfg] run $i rc=$rc $(grep -o 'NODE_DROPIN_FAIL.*' /tmp/nd.out | head -1 | cut -c1-160)"; fi
   done
