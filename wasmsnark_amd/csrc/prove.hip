@@ -275,7 +275,8 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
         // scratch slab.  TABLE_STEPPED=0: the one long kernel per section.  No stream-ordered allocation anywhere near this: an earlier
         // version of this round took the slab from hipMallocAsync / hipFreeAsync (and the matrices' temporaries likewise), and the Node
         // suite -- many small keys loaded back to back, their builds still running under later proofs -- then produced a WRONG proof in
-        // 3 to 36 of 60 runs, depending on how long the builds overlapped later loads and proofs; with plain allocations 0 of 120.
+        // 3 to 36 of 60 runs, depending on how long the builds overlapped later loads and proofs; with plain allocations 0 of 120
+        // (tools/async_alloc_repro.hip shows the same corruption without any of this library's code, on ROCm 7.2.0).
         WS_HIP_CHECK(hipEventCreate(&K->ev_build0));
         WS_HIP_CHECK(hipEventCreate(&K->ev_tables));
         std::lock_guard<std::mutex> build_lk(C->build_mu);
