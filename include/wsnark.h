@@ -144,7 +144,7 @@ int wsnark_pkey_table_info(const wsnark_pkey_t* handle, uint32_t* c_w, uint32_t*
 /* The table rows beyond the plain sections are built in the BACKGROUND (the context's build queue, lowest stream priority, one key
  * after the other): wsnark_pkey_load* return as soon as the sections are resident (about 30 ms for a 0.59 GB key instead of 214),
  * proofs that start before the build is over (~0.17 s at 2^20) run on the plain sections -- same results, about twice the
- * steady-state time -- and later ones on the tables.  This call blocks until the handle's tables are
+ * steady-state time while the build shares the GPU with them (10 % over it on an idle GPU) -- and later ones on the tables.  This call blocks until the handle's tables are
  * built (benchmarks; callers that want the steady state before their first proof).  WSNARK_TABLE_ASYNC=0 makes the load itself wait,
  * as in round 3.  Calls that shard the WINDOWS of a whole key over ranks (wsnark_groth16_prove_partial with world > 1 on a whole
  * key) wait by themselves: their partial sums must mean the same on every rank. */

@@ -46,7 +46,7 @@ struct ProvingKey {
     double load_ms[5] = {0, 0, 0, 0, 0};
     // Round 4: the table rows 1.. are built IN THE BACKGROUND (the context's queue `build_q`): the load returns once the sections are resident
     // and converted (row 0 of every table = the plain section), proofs that arrive before `ev_tables` has fired run on the
-    // plain sections (per-window plans: the round-1 / 2 path, about twice the time), later ones on the tables.  `tables_ready` only ever
+    // plain sections (per-window plans: the round-1 / 2 path; 10 % slower by itself, about twice the time beside the build), later ones on the tables.  `tables_ready` only ever
     // goes 0 -> 1.  WSNARK_TABLE_ASYNC=0: the load waits for the build as in round 3.
     hipEvent_t ev_build0 = nullptr, ev_tables = nullptr;      // (timing events: their distance is the build's duration)
     // 1 = rows built (or no tables at all), 0 = build queued, `ev_tables` recorded behind it, -1 = the build could not be queued
