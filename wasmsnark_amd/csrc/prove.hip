@@ -284,7 +284,13 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
         void* tmp = nullptr;
         size_t tmp_bytes = 0;
         if (tuning_get("TABLE_STEPPED", 1)) {
-            const uint64_t most = nl > hl ? nl : hl, cap = (uint64_t)tuning_get("TABLE_SLAB_LANES", 1 << 18);
+            // lanes per slab = how much of the chip the build holds at a time.  Measured at 2^20 (tools/build_slab_ab.sh): 2^18 lanes
+            // (1024-2048 workgroups in flight) -- proofs beside the build 19-23 ms, build 166 ms; 2^16 -- 16-17 ms, 189 ms; 2^15 --
+            // 14-15 ms, 264 ms (and 8x the launches).  Default 2^16, growing with the key so that the build stays ~2 700 launches
+            // (2^24: 2^18 lanes): they all have to fit the queue before the load can return.
+            const uint64_t most = nl > hl ? nl : hl;
+            uint64_t cap = (uint64_t)tuning_get("TABLE_SLAB_LANES", 0);
+            if (!cap) { cap = most >> 6; cap = cap < (1u << 16) ? (1u << 16) : cap > (1u << 18) ? (1u << 18) : cap; }
             tmp_bytes = msm_table_scratch_bytes(((most < cap ? most : cap) + 63) & ~(uint64_t)63);
             if (C->build_tmp.bytes < tmp_bytes) {
                 // growing frees the old slab: no build may still be using it (rare: a larger key than any before, while builds run)
