@@ -136,6 +136,33 @@ def test_degenerate_key_points_against_the_oracle_prover(orc, monkeypatch, mode)
         assert bn.groth16GenProof(w, k, r=r, s=s) == orc.groth16_prove(w, key, r, s, workers=8)
 
 
+def test_proofs_before_the_table_rows_are_ready():
+    """Round 4: a key load returns with the table rows still being built; proofs that arrive meanwhile plan on the plain sections
+    (row 0 of every table-layout buffer), window-sharded partial calls wait for the rows (their sums must mean the same on every
+    rank), and proofs after the build use the tables.  The emulator has no background: WSNARK_EMUL_TABLES_PENDING holds a key in the
+    not-yet-ready state.  Same proofs in every state, bit for bit."""
+    bn = emul_bn128()
+    tune = bn.lib.tune
+    try:
+        for name in NAMES:
+            pkey, wit, _ = _key(name)
+            key = bn.load_key(pkey, wait_tables=False)
+            assert key.table["rows_w"] > 1
+            cases = load_golden("proofs.json")[name]
+            tune("EMUL_TABLES_PENDING", 1)
+            for c in cases:
+                r, s = bytes.fromhex(c["r"]), bytes.fromhex(c["s"])
+                assert bn.groth16GenProof(wit, key, r=r, s=s) == c["proof"]                      # plain sections
+                recs = b"".join(bn.groth16_prove_partial(wit, key, shard=(g, 2)) for g in range(2))  # window shards: wait, tables
+                assert bn.groth16_prove_finish(key, recs, r=r, s=s) == c["proof"]
+            tune("EMUL_TABLES_PENDING", None)
+            key.wait_tables()
+            for c in cases:
+                assert bn.groth16GenProof(wit, key, r=bytes.fromhex(c["r"]), s=bytes.fromhex(c["s"])) == c["proof"]   # tables
+    finally:
+        tune("EMUL_TABLES_PENDING", None)
+
+
 def test_key_falls_back_to_plain_sections_when_a_table_does_not_fit(monkeypatch):
     """A table allocation the device refuses (emulator: WSNARK_EMUL_MAX_ALLOC) must not fail the load: the key keeps
     its plain sections (one row) and proves the same."""
