@@ -76,7 +76,7 @@ def test_emulated_prove_sparse_b_plan(monkeypatch, name):
 
 
 @pytest.mark.parametrize("name", NAMES)
-@pytest.mark.parametrize("mode", ["plain", "pieces", "pieces-sparse", "wide", "round1-order", "entry64", "one-kernel-build", "slabs"])
+@pytest.mark.parametrize("mode", ["plain", "pieces", "pieces-sparse", "wide", "round1-order", "entry64", "one-kernel-build", "slabs", "jacobian-build"])
 def test_emulated_prove_key_table_modes(monkeypatch, name, mode):
     """Resident keys are fixed-base window tables by default (row w = 2^(c w) * section; one bucket set per sum).
     `plain` switches them off (the per-window path the MSM entry points use); `pieces` forces a table whose bucket set
@@ -98,6 +98,9 @@ def test_emulated_prove_key_table_modes(monkeypatch, name, mode):
     elif mode == "slabs":
         monkeypatch.setenv("WSNARK_TABLE_C", "9")
         monkeypatch.setenv("WSNARK_TABLE_SLAB_LANES", "64")
+    elif mode == "jacobian-build":      # the row-per-launch build on Jacobian coordinates (curve.h: dbl_jac; default: XYZZ); same rows, bit for bit
+        monkeypatch.setenv("WSNARK_TABLE_JACOBIAN", "1")
+        monkeypatch.setenv("WSNARK_TABLE_C", "9")
     elif mode == "entry64":
         monkeypatch.setenv("WSNARK_MSM_ENTRY64", "1")     # 8-byte grouping entries: what a 2^24 table key needs (28 index bits)
         monkeypatch.setenv("WSNARK_PROVE_SPARSE", "2")
@@ -108,13 +111,13 @@ def test_emulated_prove_key_table_modes(monkeypatch, name, mode):
     key = bn.load_key(pkey)
     # wsnark_pkey_table_info: plain sections report one row; tables ceil(255 / c) rows of the window the mode asks for
     t = key.table
-    assert (t["rows_w"], t["c_w"]) == ((1, 0) if mode == "plain" else (-(-255 // t["c_w"]), {"pieces": 9, "pieces-sparse": 9, "wide": 13, "slabs": 9}.get(mode, t["c_w"])))
+    assert (t["rows_w"], t["c_w"]) == ((1, 0) if mode == "plain" else (-(-255 // t["c_w"]), {"pieces": 9, "pieces-sparse": 9, "wide": 13, "slabs": 9, "jacobian-build": 9}.get(mode, t["c_w"])))
     assert t["bytes"] == key.n_vars * 320 * t["rows_w"] + key.domain * 64 * t["rows_h"]
     for c in load_golden("proofs.json")[name]:
         assert bn.groth16GenProof(wit, key, r=bytes.fromhex(c["r"]), s=bytes.fromhex(c["s"])) == c["proof"]
 
 
-@pytest.mark.parametrize("mode", ["table", "table-one-kernel-build", "plain"])
+@pytest.mark.parametrize("mode", ["table", "table-one-kernel-build", "table-jacobian-build", "plain"])
 def test_degenerate_key_points_against_the_oracle_prover(orc, monkeypatch, mode):
     """The prover is a pure function of (witness, key, r, s) -- the key's points need not come from a setup.  Here the
     point sections of the t6 key are made degenerate: runs of EQUAL points (the accumulation's doubling case: equal
@@ -126,6 +129,8 @@ def test_degenerate_key_points_against_the_oracle_prover(orc, monkeypatch, mode)
         monkeypatch.setenv("WSNARK_KEY_TABLE", "0")
     elif mode == "table-one-kernel-build":
         monkeypatch.setenv("WSNARK_TABLE_STEPPED", "0")
+    elif mode == "table-jacobian-build":
+        monkeypatch.setenv("WSNARK_TABLE_JACOBIAN", "1")
     else:
         monkeypatch.setenv("WSNARK_TABLE_SLAB_LANES", "64")
     key, w = degenerate_key_and_witness(orc, *_key("t6")[:2])

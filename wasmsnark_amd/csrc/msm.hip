@@ -1936,10 +1936,57 @@ __global__ __launch_bounds__(256) void msm_table_norm_kernel(typename C::AffP* _
         table[(uint64_t)(w0 + k) * n + base + i] = C::pack_aff(typename C::Aff{F::mul(q.x, izz), F::mul(q.y, izzz)});
     }
 }
+// The same two launches on Jacobian coordinates (curve.h: dbl_jac -- a third fewer multiply-adds per doubling; the slab holds X, Y, Z):
+// rows are normalised through 1/Z (x = X / Z^2, y = Y / Z^3), one inversion per lane behind the product of the group's Z as before.
+// The affine rows are canonical field elements either way: bit-identical tables.
+template <class C>
+__global__ __launch_bounds__(256) void msm_table_step_jac_kernel(const typename C::AffP* __restrict__ row0, Jac<typename C::Field>* __restrict__ tmp,
+                                                                 uint64_t cnt, uint64_t S, uint32_t c, int src, uint32_t dst) {
+    typedef typename C::Field F;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    const typename C::Aff p0 = C::unpack_aff(row0[i]);
+    if (C::aff_is_inf(p0)) return;
+    Jac<F> P = src < 0 ? Jac<F>{p0.x, p0.y, F::one()} : tmp[(uint64_t)src * S + i];
+    for (uint32_t d = 0; d < c; d++) P = C::dbl_jac(P);
+    tmp[(uint64_t)dst * S + i] = P;
+}
+template <class C>
+__global__ __launch_bounds__(256) void msm_table_norm_jac_kernel(typename C::AffP* __restrict__ table, uint64_t n, uint64_t base, uint64_t cnt,
+                                                                 const Jac<typename C::Field>* __restrict__ tmp, uint64_t S, uint32_t w0, uint32_t g) {
+    typedef typename C::Field F;
+    typedef typename F::El El;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    const typename C::AffP p0p = table[base + i];
+    if (C::aff_is_inf(C::unpack_aff(p0p))) {
+        for (uint32_t k = 0; k < g; k++) table[(uint64_t)(w0 + k) * n + base + i] = p0p;
+        return;
+    }
+    El pre[TABLE_GROUP];
+    El run = F::one();
+    for (uint32_t k = 0; k < g; k++) {
+        pre[k] = run;
+        run = F::mul(run, tmp[(uint64_t)k * S + i].z);
+    }
+    El inv = F::inv(run);
+    for (int k = (int)g - 1; k >= 0; k--) {
+        const Jac<F> q = tmp[(uint64_t)k * S + i];
+        const El iz = F::mul(inv, pre[k]);
+        inv = F::mul(inv, q.z);
+        const El izz = F::sqr(iz);
+        table[(uint64_t)(w0 + k) * n + base + i] = C::pack_aff(typename C::Aff{F::mul(q.x, izz), F::mul(q.y, F::mul(izz, iz))});
+    }
+}
 size_t msm_table_scratch_bytes(uint64_t lanes) { return (size_t)TABLE_GROUP * lanes * sizeof(G2R29::Pt); }
 template <class C>
 static void table_stepped(typename C::AffP* table, uint64_t n, uint32_t tc, uint32_t rows, hipStream_t s, void* d_tmp, size_t tmp_bytes) {
     typename C::Pt* tmp = (typename C::Pt*)d_tmp;
+    Jac<typename C::Field>* tmpj = (Jac<typename C::Field>*)d_tmp;      // (three coordinates instead of four: the same slab, same S)
+    // OFF by default: the one A/B this round had GPU time for (profiles/r04_s10_build_slab_ab.txt, a noisy box, proofs running beside
+    // the build) gave 219.6 ms against the XYZZ build's 211.3 -- under 2^16-lane slabs the build runs at 1-2 wavefronts per SIMD and is
+    // latency-bound, so a third fewer instructions did not show.  Same rows, bit for bit (tests/test_prove_cpu.py); to be re-measured.
+    const bool jac = tuning_get("TABLE_JACOBIAN", 0) != 0;
     uint64_t S = tmp_bytes / ((size_t)TABLE_GROUP * sizeof(typename C::Pt));
     S &= ~(uint64_t)63;
     for (uint64_t base = 0; base < n; base += S) {
@@ -1949,10 +1996,12 @@ static void table_stepped(typename C::AffP* table, uint64_t n, uint32_t tc, uint
         for (uint32_t w0 = 1; w0 < rows; w0 += TABLE_GROUP) {
             const uint32_t g = rows - w0 < TABLE_GROUP ? rows - w0 : TABLE_GROUP;
             for (uint32_t k = 0; k < g; k++) {
-                hipLaunchKernelGGL(msm_table_step_kernel<C>, grid, dim3(256), 0, s, table + base, tmp, cnt, S, tc, src, k);
+                if (jac) hipLaunchKernelGGL(msm_table_step_jac_kernel<C>, grid, dim3(256), 0, s, table + base, tmpj, cnt, S, tc, src, k);
+                else hipLaunchKernelGGL(msm_table_step_kernel<C>, grid, dim3(256), 0, s, table + base, tmp, cnt, S, tc, src, k);
                 src = (int)k;
             }
-            hipLaunchKernelGGL(msm_table_norm_kernel<C>, grid, dim3(256), 0, s, table, n, base, cnt, tmp, S, w0, g);
+            if (jac) hipLaunchKernelGGL(msm_table_norm_jac_kernel<C>, grid, dim3(256), 0, s, table, n, base, cnt, tmpj, S, w0, g);
+            else hipLaunchKernelGGL(msm_table_norm_kernel<C>, grid, dim3(256), 0, s, table, n, base, cnt, tmp, S, w0, g);
         }
     }
 }
