@@ -84,6 +84,7 @@ static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long l
 template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
+static inline void __threadfence() {}
 
 // ---- host runtime ----
 typedef int hipError_t;

@@ -83,7 +83,11 @@ int context_init(int device) {
         WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
         if (prio && hipStreamCreateWithPriority(&L.stream2, hipStreamNonBlocking, hi) != hipSuccess) L.stream2 = nullptr;
         if (!L.stream2) WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream2, hipStreamNonBlocking));   // (no priorities here)
-        WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream3, hipStreamNonBlocking));
+        // WSNARK_S3_PRIO=1: the third queue (reduction tails of a full-size proof, prove.hip order 4 / 5) at the highest priority
+        const char* p3 = getenv("WSNARK_S3_PRIO");
+        if (p3 && atoi(p3) == 1 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo &&
+            hipStreamCreateWithPriority(&L.stream3, hipStreamNonBlocking, hi) != hipSuccess) { (void)hipGetLastError(); L.stream3 = nullptr; }
+        if (!L.stream3) WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream3, hipStreamNonBlocking));
         WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream_copy, hipStreamNonBlocking));
         WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream_copy2, hipStreamNonBlocking));
     }

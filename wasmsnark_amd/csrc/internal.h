@@ -213,6 +213,10 @@ int msm_points_mask(const Affine<Fq>* d_g1, const Affine<Fq2>* d_g2, uint64_t n,
 // tail_stream (optional, all three launchers): the reduction tail is enqueued on that queue of the lane instead of on s
 int msm_g1_launch(Lane& L, const Affine<Fq>* d_points, bool prepared, int* slot, hipStream_t s, hipStream_t tail_stream = nullptr);
 int msm_g2_launch(Lane& L, const Affine<Fq2>* d_points, bool prepared, int* slot, hipStream_t s, hipEvent_t before_tail = nullptr, hipStream_t tail_stream = nullptr);
+// msm_g1_launch in two steps: the accumulation alone, and one batched reduction tail for up to 4 launches of the same tail geometry
+int msm_g1_acc_only(Lane& L, const Affine<Fq>* d_points, bool prepared, int* slot, hipStream_t s);
+int msm_g1_tail(Lane& L, const int* slots, int nslots, hipStream_t s, hipStream_t tail_stream = nullptr);
+bool msm_same_tail_geometry(Lane& L, int slot_a, int slot_b);
 // `before_tail` (optional) is recorded on s after the accumulations, before the batched reduction tail
 // plan_ids (optional): the plan each set is accumulated against (variants of one plan: same geometry)
 int msm_g1_launch_batch(Lane& L, const Affine<Fq>* const* d_points, int nsets, bool prepared, int* slots, hipStream_t s,

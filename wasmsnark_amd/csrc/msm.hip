@@ -56,11 +56,14 @@ namespace wsnark {
 #define WS_MADD_WIDE 1     // accumulation loop keeps X wide between additions (curve.h: madd_wide); 0 = strict madd, for A/B builds
 #endif
 static const uint32_t CHUNK = 8;          // buckets per msm_chunks lane
+// default wavefront issue priorities (rt.h: wave_prio) of the latency-bound kernels; WSNARK_TAIL_PRIO / WSNARK_PLAN_PRIO override
+static const long kTailPrio = 0, kPlanPrio = 0;
 
 struct MsmScratch {
     DevBuf keys, vals, keys_out, vals_out, sort_tmp, entries, hot, hot_sums;
     DevBuf bstart, bend, buckets, counters, tasks, multi, partials;
     DevBuf chunkS, chunkA, sums, points_conv;
+    DevBuf hot_done, tail_done;      // device-scope completion counters of msm_combine_all / msm_tree (zero between launches)
 };
 
 // ---------------------------------------------------------------------------
@@ -142,6 +145,7 @@ struct PresortArgs {
     uint32_t idx_bits;                 // packed 4-byte entries: idx | neg << idx_bits | lo << (idx_bits+1)
     const uint8_t* mask;               // optional: pairs with mask[i] == 0 are left out (their point is infinity)
     uint32_t flat;                     // fixed-base table plans: ONE bucket set, bin = (d-1) >> lo_bits, entries index the table (window * n + i)
+    uint32_t prio;                     // wavefront issue priority of the grouping kernels (rt.h: wave_prio)
 };
 __device__ __forceinline__ uint32_t presort_bin(const PresortArgs& A, uint32_t k, uint32_t d) {
     return (A.flat ? 0u : k * A.HB) + ((d - 1) >> A.lo_bits);
@@ -168,6 +172,7 @@ template <> struct PresortEntry<uint32_t> {
 
 __global__ __launch_bounds__(1024) void presort_count(PresortArgs A, uint32_t* __restrict__ bin_count) {
     __shared__ uint32_t cnt[PRESORT_MAX_BINS];
+    wave_prio(A.prio);
     for (uint32_t b = threadIdx.x; b < A.nbins; b += blockDim.x) cnt[b] = 0;
     __syncthreads();
     const uint32_t base = A.i0 + blockIdx.x * A.tile;
@@ -209,6 +214,7 @@ template <class E>
 __global__ __launch_bounds__(1024) void presort_scatter(PresortArgs A, uint32_t* __restrict__ bin_cursor, E* __restrict__ entries) {
     __shared__ uint32_t cnt[PRESORT_MAX_BINS];
     __shared__ uint32_t gbase[PRESORT_MAX_BINS];
+    wave_prio(A.prio);
     for (uint32_t b = threadIdx.x; b < A.nbins; b += blockDim.x) cnt[b] = 0;
     __syncthreads();
     const uint32_t base = A.i0 + blockIdx.x * A.tile;
@@ -274,11 +280,12 @@ __global__ __launch_bounds__(1024) void presort_bins(const E* __restrict__ entri
                                                        uint32_t lo_bits, uint32_t idx_bits, uint32_t* __restrict__ vals_out,
                                                        uint32_t* __restrict__ bstart, uint32_t* __restrict__ bend,
                                                        uint32_t lmax, uint32_t* __restrict__ hist,
-                                                       const uint8_t* __restrict__ mask, uint32_t mask_mod, uint32_t split_bin) {
+                                                       const uint8_t* __restrict__ mask, uint32_t mask_mod, uint32_t split_bin, uint32_t prio) {
     __shared__ uint32_t sub[1u << PRESORT_MAX_LO];
     __shared__ uint32_t off[1u << PRESORT_MAX_LO];
     __shared__ uint32_t part[1024];
     __shared__ uint32_t lhist[256];
+    wave_prio(prio);
     const uint32_t bin = blockIdx.x, SUB = 1u << lo_bits;
     const uint32_t s = bin_start[bin], e = bin_start[bin + 1];
     for (uint32_t t = threadIdx.x; t < SUB; t += blockDim.x) sub[t] = 0;
@@ -469,9 +476,10 @@ __global__ __launch_bounds__(256) void msm_plan_emit(const uint32_t* __restrict_
                                                        uint32_t* __restrict__ cursor2,
                                                        Task* __restrict__ tasks, uint32_t* __restrict__ counters,
                                                        MultiBucket* __restrict__ multi, HotBucket* __restrict__ hot,
-                                                       uint32_t hot_min, uint32_t split_bucket) {
+                                                       uint32_t hot_min, uint32_t split_bucket, uint32_t prio) {
     __shared__ uint32_t lcnt[256];
     __shared__ uint32_t lbase[256];
+    wave_prio(prio);
     __shared__ uint32_t first[256];          // start of key k's slots = number of tasks with a longer key
     __shared__ uint32_t red[256];
     const uint32_t seg = (blockIdx.x * blockDim.x >= split_bucket) ? 0u : 1u;      // uniform per workgroup
@@ -563,6 +571,8 @@ struct AccSets {
     typename C::PtP* buckets[4];
     typename C::PtP* partials[4];
     typename C::PtP* hot_sums[4];
+    uint32_t* hot_done[4];      // per hot bucket: slices folded so far (msm_combine_all; zero between launches)
+    uint32_t prio;              // wavefront issue priority of the combine kernel (rt.h: wave_prio)
 };
 
 // 4. one lane per task: mixed additions of the task's points
@@ -755,6 +765,97 @@ __global__ __launch_bounds__(64) void msm_combine_hot2(AccSets<C> as, uint32_t b
     }
 }
 
+// 5'. Round 5: the three steps above in ONE launch (four launches before, three of which find nothing to do on a uniform witness
+// and still cost a dependent launch each on the proof's critical queue).  Workgroups of one wavefront; blockIdx.x selects the role:
+//   [0, CB_SMALL)           empty buckets = infinity; buckets cut into < WAVE_COMBINE_MIN tasks: one lane sums the partials (5a)
+//   [.., + CB_WAVE)         buckets cut into more tasks: one wavefront per bucket (5b)
+//   [.., + CB_HOT)          very hot buckets: one wavefront per HOT_SLICE partial sums (5c stage 1); the wavefront that completes a
+//                           bucket's LAST slice -- a device-scope counter per hot bucket, zero between launches -- folds the slice
+//                           sums (stage 2) and clears the counter
+// (few workgroups: a launch costs ~5 us plus ~10 us per thousand workgroups it starts, whether they find work or not -- the four
+//  launches this one replaces started 3 400 workgroups per sum to find nothing on a uniform witness)
+static const uint32_t CB_SMALL = 256, CB_WAVE = 256, CB_HOT = 256;
+template <class C>
+__device__ __forceinline__ typename C::PtP wave_tree_sum(typename C::PtP* sh, uint32_t lane, const typename C::Pt& mine) {
+    sh[lane] = C::pack_pt(mine);
+    __syncthreads();
+    for (uint32_t step = 32; step >= 1; step >>= 1) {
+        if (lane < step) sh[lane] = C::pack_pt(C::add(C::unpack_pt(sh[lane]), C::unpack_pt(sh[lane + step])));
+        __syncthreads();
+    }
+    const typename C::PtP r = sh[0];
+    __syncthreads();
+    return r;
+}
+template <class C>
+__global__ __launch_bounds__(64) void msm_combine_all(AccSets<C> as, uint32_t b_lo, uint32_t b_hi) {
+    wave_prio(as.prio);
+    const uint32_t* __restrict__ counters = as.counters[blockIdx.y];
+    const typename C::PtP* __restrict__ partials = as.partials[blockIdx.y];
+    typename C::PtP* __restrict__ buckets = as.buckets[blockIdx.y];
+    __shared__ typename C::PtP sh[64];
+    const uint32_t lane = threadIdx.x;
+    if (blockIdx.x < CB_SMALL) {
+        const MultiBucket* __restrict__ mbs = as.multi[blockIdx.y];
+        const uint32_t gt = blockIdx.x * 64 + lane, gn = CB_SMALL * 64;
+        // (empty buckets are NOT cleared here any more: msm_chunks reads the plan's bounds instead -- the scan over 4 MB of bounds
+        //  was 36-70 us of the round-4 combine step on a uniform witness, a chain of memory latencies)
+        const uint32_t nmb = counters[1];
+        for (uint32_t i = gt; i < nmb; i += gn) {
+            const MultiBucket h = mbs[i];
+            if (h.ntasks >= WAVE_COMBINE_MIN || h.bucket < b_lo || h.bucket >= b_hi) continue;
+            typename C::Pt acc = C::unpack_pt(partials[h.first_partial]);
+            for (uint32_t k = 1; k < h.ntasks; k++) acc = C::add(acc, C::unpack_pt(partials[h.first_partial + k]));
+            buckets[h.bucket] = C::pack_pt(acc);
+        }
+        return;
+    }
+    if (blockIdx.x < CB_SMALL + CB_WAVE) {
+        const MultiBucket* __restrict__ mbs = as.multi[blockIdx.y];
+        const uint32_t nmb = counters[1];
+        for (uint32_t hb = blockIdx.x - CB_SMALL; hb < nmb; hb += CB_WAVE) {      // uniform per workgroup
+            const MultiBucket h = mbs[hb];
+            if (h.ntasks < WAVE_COMBINE_MIN || h.bucket < b_lo || h.bucket >= b_hi) continue;
+            typename C::Pt acc = C::infinity();
+            for (uint32_t k = lane; k < h.ntasks; k += 64) acc = C::add(acc, C::unpack_pt(partials[h.first_partial + k]));
+            const typename C::PtP r = wave_tree_sum<C>(sh, lane, acc);
+            if (lane == 0) buckets[h.bucket] = r;
+        }
+        return;
+    }
+    const uint32_t nhot = counters[4];
+    if (nhot == 0) return;
+    const HotBucket* __restrict__ hot = as.hot[blockIdx.y];
+    typename C::PtP* slice_sums = as.hot_sums[blockIdx.y];          // (written and read in this launch: no __restrict__)
+    uint32_t* done = as.hot_done[blockIdx.y];
+    const uint32_t bx = blockIdx.x - CB_SMALL - CB_WAVE;
+    for (uint32_t hb = 0; hb < nhot; hb++) {                          // few entries; every workgroup walks them all
+        const HotBucket h = hot[hb];
+        if (h.bucket < b_lo || h.bucket >= b_hi) continue;
+        const uint32_t nsl = (h.ntasks + HOT_SLICE - 1) / HOT_SLICE;
+        const uint32_t sl0 = (bx + CB_HOT - h.slice_base % CB_HOT) % CB_HOT;       // slices dealt round-robin by their GLOBAL number
+        for (uint32_t sl = sl0; sl < nsl; sl += CB_HOT) {            // uniform per workgroup
+            const uint32_t lo = sl * HOT_SLICE, hi = lo + HOT_SLICE < h.ntasks ? lo + HOT_SLICE : h.ntasks;
+            typename C::Pt acc = C::infinity();
+            for (uint32_t k = lo + lane; k < hi; k += 64) acc = C::add(acc, C::unpack_pt(partials[h.first_partial + k]));
+            const typename C::PtP r = wave_tree_sum<C>(sh, lane, acc);
+            uint32_t last = 0;
+            if (lane == 0) {
+                slice_sums[h.slice_base + sl] = r;
+                __threadfence();
+                last = atomicAdd(&done[hb], 1u) + 1 == nsl ? 1u : 0u;
+            }
+            last = __shfl(last, 0);
+            if (!last) continue;
+            __threadfence();                                          // the other wavefronts' slice sums are visible from here on
+            typename C::Pt tot = C::infinity();
+            for (uint32_t k = lane; k < nsl; k += 64) tot = C::add(tot, C::unpack_pt(slice_sums[h.slice_base + k]));
+            const typename C::PtP rr = wave_tree_sum<C>(sh, lane, tot);
+            if (lane == 0) { buckets[h.bucket] = rr; done[hb] = 0; }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // 6. chunk sums: for CHUNK consecutive buckets of one window
 //    S = sum B_i,  A = sum (i - i0 + 1) B_i   (descending running sum)
@@ -770,11 +871,16 @@ struct TailSets {
     St* chunkA[4];
     St* rows[4];         // per piece: U_0 .. U_{logJ-1}, A [, T]; in the internal domain when a piece-reduction pass follows
     St* sums[4];         // what leaves for the host (reference format)
+    const uint32_t* bstart[4];   // the plan's bucket bounds: an EMPTY bucket (no entry) is infinity whatever its slot still holds from the
+    const uint32_t* bend[4];     // launch before -- msm_chunks checks the bounds, so no pass over the buckets has to clear them
+    uint32_t* done[4];   // msm_tree with the piece reduction fused in: per (group, row) the pieces summed so far (zero between launches)
+    uint32_t prio;       // wavefront issue priority of the tail kernels (rt.h: wave_prio)
 };
 
 template <class C>
 __global__ __launch_bounds__(256) void msm_chunks(TailSets<C> ts, uint32_t chunk0, uint32_t nchunks, uint32_t m) {
     typedef PointIO<C> IO;
+    wave_prio(ts.prio);
     const typename IO::Stored* __restrict__ buckets = ts.buckets[blockIdx.y];
     typename IO::Stored* __restrict__ chunkS = ts.chunkS[blockIdx.y];
     typename IO::Stored* __restrict__ chunkA = ts.chunkA[blockIdx.y];
@@ -782,8 +888,10 @@ __global__ __launch_bounds__(256) void msm_chunks(TailSets<C> ts, uint32_t chunk
     if (j >= nchunks) return;
     typename C::Pt run = C::infinity(), acc = C::infinity();
     const typename IO::Stored* B = buckets + (uint64_t)j * m;
+    const uint32_t* __restrict__ bs = ts.bstart[blockIdx.y] + (uint64_t)j * m;
+    const uint32_t* __restrict__ be = ts.bend[blockIdx.y] + (uint64_t)j * m;
     for (int i = (int)m - 1; i >= 0; i--) {
-        run = C::add(run, IO::load(B, (uint64_t)i));
+        if (bs[i] != be[i]) run = C::add(run, IO::load(B, (uint64_t)i));      // (uniform over a lane pair: both lanes read the same bounds)
         acc = C::add(acc, run);
     }
     IO::store(chunkS, j, run);
@@ -799,12 +907,14 @@ __global__ __launch_bounds__(256) void msm_chunks(TailSets<C> ts, uint32_t chunk
 // (one lane per 256-byte G2 point: 256 threads at most, so that a wavefront may use the whole register file)
 template <class C> struct TreeBound { static constexpr int value = (PointIO<C>::LPP == 1 && sizeof(typename PointIO<C>::Stored) > 128) ? 256 : 512; };
 template <class C>
-__global__ __launch_bounds__(TreeBound<C>::value) void msm_tree(TailSets<C> ts, uint32_t J, uint32_t logJ, uint32_t w0, uint32_t to_ref) {
+__global__ __launch_bounds__(TreeBound<C>::value) void msm_tree(TailSets<C> ts, uint32_t J, uint32_t logJ, uint32_t w0, uint32_t to_ref, uint32_t fold_P,
+                                                              uint32_t nrows_out) {
     typedef PointIO<C> IO;
     typedef typename IO::Stored St;
+    wave_prio(ts.prio);
     const St* __restrict__ chunkS = ts.chunkS[blockIdx.z];
     const St* __restrict__ chunkA = ts.chunkA[blockIdx.z];
-    St* __restrict__ rows = to_ref ? ts.sums[blockIdx.z] : ts.rows[blockIdx.z];
+    St* rows = to_ref ? ts.sums[blockIdx.z] : ts.rows[blockIdx.z];      // (no __restrict__: the fused piece reduction reads other workgroups' rows)
     WS_DYN_SMEM(St, sh);
     const uint32_t q = blockIdx.x, w = w0 + blockIdx.y;              // pieces [w0, w0 + gridDim.y)
     const uint32_t slot = threadIdx.x / IO::LPP, nslots = blockDim.x / IO::LPP;
@@ -831,6 +941,64 @@ __global__ __launch_bounds__(TreeBound<C>::value) void msm_tree(TailSets<C> ts, 
         if (to_ref) IO::store_ref(rows, (uint64_t)w * gridDim.x + q, r);
         else IO::store(rows, (uint64_t)w * gridDim.x + q, r);
     }
+    if (fold_P == 0) return;
+    // ---- round 5: the piece reduction (7' below, msm_rows) fused in.  The workgroup that stores the LAST of a group's P pieces of row
+    // q -- a device-scope counter per (group, row) -- folds that row over the pieces: R_q = sum_v U_{v,q} (q < logJ), R_A (q == logJ),
+    // and for the row of the T_v (q == logJ + 1) the log2 P sums V_p = sum_{v : bit p of v} T_v, all p at once on disjoint slots.
+    __shared__ uint32_t is_last;
+    const uint32_t P = fold_P, g = w / P, nsum_in = gridDim.x;
+    uint32_t* done = ts.done[blockIdx.z] + (uint64_t)g * nsum_in + q;
+    __syncthreads();                                                  // (slot 0's store above is done: both lanes of a pair)
+    if (threadIdx.x == 0) {
+        __threadfence();
+        is_last = atomicAdd(done, 1u) + 1 == P ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();                                                  // the other workgroups' rows are visible from here on
+    const St* all = ts.rows[blockIdx.z];
+    St* __restrict__ out = ts.sums[blockIdx.z];
+    uint32_t logP = 0;
+    while ((1u << logP) < P) logP++;
+    if (q <= logJ) {
+        uint32_t fs = 1;
+        while (fs < P && fs < nslots) fs <<= 1;
+        typename C::Pt f = C::infinity();
+        if (slot < fs) for (uint32_t v = slot; v < P; v += fs) f = C::add(f, IO::load(all, ((uint64_t)g * P + v) * nsum_in + q));
+        if (slot < fs) IO::store(sh, slot, f);
+        __syncthreads();
+        for (uint32_t step = fs >> 1; step >= 1; step >>= 1) {
+            if (slot < step) IO::store(sh, slot, C::add(IO::load(sh, slot), IO::load(sh, slot + step)));
+            __syncthreads();
+        }
+        if (slot == 0) IO::store_ref(out, (uint64_t)g * nrows_out + q, IO::load(sh, 0));
+    } else if (logP * (P >> 1) <= nslots && P >= 2) {
+        // slot = p * P/2 + k: the k-th piece index with bit p set; one segmented tree of depth log2(P / 2)
+        const uint32_t half = P >> 1, p = slot / half, k = slot % half, low = (1u << p) - 1;
+        const bool act = slot < logP * half;
+        if (act) IO::store(sh, slot, IO::load(all, ((uint64_t)g * P + (((k & ~low) << 1) | (1u << p) | (k & low))) * nsum_in + q));
+        __syncthreads();
+        for (uint32_t step = half >> 1; step >= 1; step >>= 1) {
+            if (act && k < step) IO::store(sh, slot, C::add(IO::load(sh, slot), IO::load(sh, slot + step)));
+            __syncthreads();
+        }
+        if (act && k == 0) IO::store_ref(out, (uint64_t)g * nrows_out + logJ + 1 + p, IO::load(sh, slot));
+    } else {
+        for (uint32_t p = 0; p < logP; p++) {
+            typename C::Pt f = C::infinity();
+            for (uint32_t v = slot; v < P; v += nslots)
+                if ((v >> p) & 1u) f = C::add(f, IO::load(all, ((uint64_t)g * P + v) * nsum_in + q));
+            IO::store(sh, slot, f);
+            __syncthreads();
+            for (uint32_t step = nslots >> 1; step >= 1; step >>= 1) {
+                if (slot < step) IO::store(sh, slot, C::add(IO::load(sh, slot), IO::load(sh, slot + step)));
+                __syncthreads();
+            }
+            if (slot == 0) IO::store_ref(out, (uint64_t)g * nrows_out + logJ + 1 + p, IO::load(sh, 0));
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) *done = 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -846,6 +1014,7 @@ template <class C>
 __global__ __launch_bounds__(TreeBound<C>::value) void msm_rows(TailSets<C> ts, uint32_t P, uint32_t logJ, uint32_t nsum_in, uint32_t nrows_out) {
     typedef PointIO<C> IO;
     typedef typename IO::Stored St;
+    wave_prio(ts.prio);
     const St* __restrict__ rows = ts.rows[blockIdx.z];
     St* __restrict__ out = ts.sums[blockIdx.z];
     WS_DYN_SMEM(St, sh);
@@ -963,6 +1132,7 @@ struct MsmPending {
         h_sums = nullptr; ev = nullptr; ev_hi = nullptr; ev_acc = nullptr; h_bytes = 0; active = false;
         d_sums.release(); d_rows.release();
         S.buckets.release(); S.partials.release(); S.chunkS.release(); S.chunkA.release(); S.points_conv.release(); S.hot_sums.release();
+        S.hot_done.release(); S.tail_done.release();
     }
 };
 
@@ -1295,7 +1465,7 @@ int msm_plan_begin(Lane& L, uint64_t n, WindowShard sh, hipStream_t s, uint32_t 
 
 static PresortArgs plan_presort_args(const MsmPlanInfo& I, const Fe* d_scalars, uint32_t i0, uint32_t i_end) {
     return PresortArgs{d_scalars, (uint32_t)I.n, I.c, I.Wall, I.w_off, I.w_stride, i0, i_end, I.ps_lo_bits, I.ps_HB, I.ps_nbins, I.ps_tile,
-                       I.ps_idx_bits, nullptr, I.flat ? 1u : 0u};
+                       I.ps_idx_bits, nullptr, I.flat ? 1u : 0u, (uint32_t)tuning_get("PLAN_PRIO", kPlanPrio)};
 }
 
 int msm_plan_count(Lane& L, const Fe* d_scalars, uint64_t i0, uint64_t i1, hipStream_t s) {
@@ -1359,10 +1529,10 @@ int msm_plan_finish(Lane& L, const Fe* d_scalars, hipStream_t s) {
         T.begin("msm_presort_bins", s);
         if (e32)
             hipLaunchKernelGGL(presort_bins<uint32_t>, dim3(nbins), bblk, 0, s, S.entries.as<uint32_t>(), bin_start, lo_bits,
-                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(), lmax, d_cnt + CNT_HIST, nullptr, 0u, split_bin);
+                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(), lmax, d_cnt + CNT_HIST, nullptr, 0u, split_bin, PA.prio);
         else
             hipLaunchKernelGGL(presort_bins<uint64_t>, dim3(nbins), bblk, 0, s, S.entries.as<uint64_t>(), bin_start, lo_bits,
-                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(), lmax, d_cnt + CNT_HIST, nullptr, 0u, split_bin);
+                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(), lmax, d_cnt + CNT_HIST, nullptr, 0u, split_bin, PA.prio);
         T.end(s);
         WS_HIP_CHECK(hipGetLastError());
         have_hist = true;
@@ -1393,7 +1563,7 @@ int msm_plan_finish(Lane& L, const Fe* d_scalars, hipStream_t s) {
                            S.bend.as<uint32_t>(), nbuckets, lmax, d_cnt + CNT_HIST);
     hipLaunchKernelGGL(msm_plan_emit, dim3(ceil_div_u64(nbuckets, 256)), dim3(256), 0, s, S.bstart.as<uint32_t>(),
                        S.bend.as<uint32_t>(), nbuckets, lmax, d_cnt + CNT_HIST, d_cnt + CNT_CURSOR, S.tasks.as<Task>(), d_cnt,
-                       S.multi.as<MultiBucket>(), S.hot.as<HotBucket>(), hot_min, I.split_k * I.NB);
+                       S.multi.as<MultiBucket>(), S.hot.as<HotBucket>(), hot_min, I.split_k * I.NB, (uint32_t)tuning_get("PLAN_PRIO", kPlanPrio));
     hipLaunchKernelGGL(msm_plan_emit_hot, dim3(64), dim3(256), 0, s, S.hot.as<HotBucket>(), d_cnt, lmax, S.tasks.as<Task>());
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
@@ -1447,16 +1617,16 @@ int msm_plan_variant(Lane& L, int src_id, int dst_id, const uint8_t* d_mask, hip
     if (src.ps_e32)
         hipLaunchKernelGGL(presort_bins<uint32_t>, dim3(src.ps_nbins), dim3(src.ps_bthr), 0, s, SS.entries.as<uint32_t>(), bin_start,
                            src.ps_lo_bits, src.ps_idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(),
-                           src.lmax, d_cnt + CNT_HIST, d_mask, src.flat ? (uint32_t)src.n : 0u, 0u);
+                           src.lmax, d_cnt + CNT_HIST, d_mask, src.flat ? (uint32_t)src.n : 0u, 0u, (uint32_t)tuning_get("PLAN_PRIO", kPlanPrio));
     else
         hipLaunchKernelGGL(presort_bins<uint64_t>, dim3(src.ps_nbins), dim3(src.ps_bthr), 0, s, SS.entries.as<uint64_t>(), bin_start,
                            src.ps_lo_bits, src.ps_idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(),
-                           src.lmax, d_cnt + CNT_HIST, d_mask, src.flat ? (uint32_t)src.n : 0u, 0u);
+                           src.lmax, d_cnt + CNT_HIST, d_mask, src.flat ? (uint32_t)src.n : 0u, 0u, (uint32_t)tuning_get("PLAN_PRIO", kPlanPrio));
     T.end(s);
     T.begin("msm_plan", s);
     hipLaunchKernelGGL(msm_plan_emit, dim3(ceil_div_u64(src.nbuckets, 256)), dim3(256), 0, s, S.bstart.as<uint32_t>(),
                        S.bend.as<uint32_t>(), src.nbuckets, src.lmax, d_cnt + CNT_HIST, d_cnt + CNT_CURSOR, S.tasks.as<Task>(), d_cnt,
-                       S.multi.as<MultiBucket>(), S.hot.as<HotBucket>(), src.hot_min, 0u);
+                       S.multi.as<MultiBucket>(), S.hot.as<HotBucket>(), src.hot_min, 0u, (uint32_t)tuning_get("PLAN_PRIO", kPlanPrio));
     hipLaunchKernelGGL(msm_plan_emit_hot, dim3(64), dim3(256), 0, s, S.hot.as<HotBucket>(), d_cnt, src.lmax, S.tasks.as<Task>());
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
@@ -1513,18 +1683,24 @@ static int msm_acc_sets(Lane& L, MsmPending* const* Ps, int nsets, int which, ui
         as.buckets[k] = Q.S.buckets.template as<Pt>();
         as.partials[k] = Q.S.partials.template as<Pt>();
         as.hot_sums[k] = Q.S.hot_sums.template as<Pt>();
+        as.hot_done[k] = Q.S.hot_done.template as<uint32_t>();
         if (k < nsets && Q.info.ntasks > ntasks) ntasks = Q.info.ntasks;
     }
+    as.prio = (uint32_t)tuning_get("TAIL_PRIO", kTailPrio);
     const uint32_t ny = (uint32_t)nsets;
     T.begin(which ? "msm_accumulate_g2" : "msm_accumulate_g1", s);
     hipLaunchKernelGGL(msm_accumulate<C>, dim3(ceil_div_u64(ntasks, 256), ny), dim3(256), 0, s, as, seg);
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
     T.begin("msm_combine", s);
-    hipLaunchKernelGGL(msm_combine_small<C>, dim3(256, ny), dim3(256), 0, s, as, b_lo, b_hi);
-    hipLaunchKernelGGL(msm_combine_wave<C>, dim3(2048, ny), dim3(64), 0, s, as, b_lo, b_hi);
-    hipLaunchKernelGGL(msm_combine_hot1<C>, dim3(1024, ny), dim3(64), 0, s, as, b_lo, b_hi);
-    hipLaunchKernelGGL(msm_combine_hot2<C>, dim3(64, ny), dim3(64), 0, s, as, b_lo, b_hi);
+    if (tuning_get("COMBINE_FUSED", 1)) {
+        hipLaunchKernelGGL(msm_combine_all<C>, dim3(CB_SMALL + CB_WAVE + CB_HOT, ny), dim3(64), 0, s, as, b_lo, b_hi);
+    } else {
+        hipLaunchKernelGGL(msm_combine_small<C>, dim3(256, ny), dim3(256), 0, s, as, b_lo, b_hi);
+        hipLaunchKernelGGL(msm_combine_wave<C>, dim3(2048, ny), dim3(64), 0, s, as, b_lo, b_hi);
+        hipLaunchKernelGGL(msm_combine_hot1<C>, dim3(1024, ny), dim3(64), 0, s, as, b_lo, b_hi);
+        hipLaunchKernelGGL(msm_combine_hot2<C>, dim3(64, ny), dim3(64), 0, s, as, b_lo, b_hi);
+    }
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
     return WS_OK;
@@ -1583,6 +1759,12 @@ static int msm_launch_acc(Lane& L, int which, const typename H::Aff* d_points_re
     if (!P.ev) WS_HIP_CHECK(hipEventCreate(&P.ev));
     // (slots wait for hot-bucket slice sums: at most one per HOT_SLICE tasks plus one per hot bucket)
     WS_HIP_CHECK(S.hot_sums.reserve(((size_t)I.hot_cap / HOT_SLICE + (size_t)I.hot_cap / I.hot_min + 32) * sizeof(Pt)));
+    // completion counters of the fused combine / tree kernels: cleared when (re)allocated, left at zero by every launch
+    {
+        const size_t hot_bytes = ((size_t)I.hot_cap / I.hot_min + 16) * 4, tail_bytes = ((size_t)I.groups * nsum + 16) * 4;
+        if (!S.hot_done.p || S.hot_done.bytes < hot_bytes) { WS_HIP_CHECK(S.hot_done.alloc(hot_bytes)); WS_HIP_CHECK(hipMemsetAsync(S.hot_done.p, 0, hot_bytes, s)); }
+        if (!S.tail_done.p || S.tail_done.bytes < tail_bytes) { WS_HIP_CHECK(S.tail_done.alloc(tail_bytes)); WS_HIP_CHECK(hipMemsetAsync(S.tail_done.p, 0, tail_bytes, s)); }
+    }
 
     KernelTimer& T = X->timer;
     if (I.flat && !prepared) { set_last_error("msm: a table plan needs a prepared fixed-base table"); return WS_ERR_ARG; }
@@ -1636,7 +1818,11 @@ static int msm_launch_tail(Lane& L, const int* slot_ids, int nslots, hipStream_t
         ts.chunkA[k] = P.S.chunkA.template as<St>();
         ts.rows[k] = P.d_rows.template as<St>();
         ts.sums[k] = P.d_sums.template as<St>();
+        ts.done[k] = P.S.tail_done.template as<uint32_t>();
+        ts.bstart[k] = ws(L).plan[P.plan_id].S.bstart.template as<uint32_t>();
+        ts.bend[k] = ws(L).plan[P.plan_id].S.bend.template as<uint32_t>();
     }
+    ts.prio = (uint32_t)tuning_get("TAIL_PRIO", kTailPrio);
     const uint32_t J = I.J, logJ = I.logJ, nsum = I.nsum, m = I.m, LPP = IO::LPP;
     if (w1 > I.tW) w1 = I.tW;
     const uint32_t W = w1 - w0;
@@ -1654,11 +1840,18 @@ static int msm_launch_tail(Lane& L, const int* slot_ids, int nslots, hipStream_t
     if (sizeof(St) > 128 && smax > 256) smax = 256;
     while (tslots < (J > 1 ? J / 2 : 1) && tslots < smax && tslots * LPP < (uint32_t)TreeBound<C>::value) tslots <<= 1;
     T.begin("msm_tree", s);
-    hipLaunchKernelGGL(msm_tree<C>, dim3(nsum, W, nslots), dim3(tslots * LPP), (size_t)tslots * sizeof(St), s, ts, J, logJ, w0, I.reduce ? 0u : 1u);
+    // (the piece reduction fused into the tree kernel needs the whole group in ONE launch and a slot per (bit, piece) pair or a
+    //  generic loop; WSNARK_TAIL_FUSE_ROWS=0: the separate msm_rows launch of round 4)
+    const bool fuse_rows = I.reduce && w0 == 0 && W == I.tW && tuning_get("TAIL_FUSE_ROWS", 0) != 0;
+    hipLaunchKernelGGL(msm_tree<C>, dim3(nsum, W, nslots), dim3(tslots * LPP), (size_t)tslots * sizeof(St), s, ts, J, logJ, w0, I.reduce ? 0u : 1u,
+                       fuse_rows ? I.tP : 0u, I.nrows);
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
     size_t sums_bytes, off;
-    if (I.reduce) {
+    if (fuse_rows) {
+        sums_bytes = (size_t)I.groups * I.nrows * sizeof(St);
+        off = 0;
+    } else if (I.reduce) {
         uint32_t rslots = 1;
         while (rslots < I.tP && rslots < smax && rslots * LPP < (uint32_t)TreeBound<C>::value) rslots <<= 1;
         T.begin("msm_rows", s);
@@ -1772,6 +1965,28 @@ int msm_g1_launch_batch(Lane& L, const Affine<Fq>* const* d_points, int nsets, b
     return rc;
 }
 
+// the two halves of msm_g1_launch on their own (round 5, prove.hip order 6): accumulation + combine of one point set against the
+// current plan on `s`; later ONE batched reduction tail for up to 4 such launches -- of the same tail geometry, whatever their
+// plans -- on `s` (or on tail_stream behind the accumulations queued on s so far)
+int msm_g1_acc_only(Lane& L, const Affine<Fq>* d_points, bool prepared, int* slot, hipStream_t s) {
+    if (!ctx()) return WS_ERR_NOINIT;
+    if (msm_uses_field29()) return msm_launch_acc<G1R29, G1>(L, 0, d_points, prepared, slot, s);
+    return msm_launch_acc<G1, G1>(L, 0, d_points, prepared, slot, s);
+}
+bool msm_same_tail_geometry(Lane& L, int slot_a, int slot_b) {
+    if (!L.msm || slot_a < 0 || slot_b < 0 || slot_a >= kPendingSlots || slot_b >= kPendingSlots) return false;
+    const MsmPlanInfo &A = L.msm->slot[slot_a].info, &B = L.msm->slot[slot_b].info;
+    return A.n && B.n && A.flat == B.flat && A.c == B.c && A.m == B.m && A.J == B.J && A.tW == B.tW && A.tP == B.tP && A.groups == B.groups &&
+           A.nsum == B.nsum && A.nrows == B.nrows && A.reduce == B.reduce && A.nbuckets == B.nbuckets;
+}
+int msm_g1_tail(Lane& L, const int* slots, int nslots, hipStream_t s, hipStream_t tail_stream) {
+    if (!ctx()) return WS_ERR_NOINIT;
+    if (nslots < 1 || nslots > 4) return WS_ERR_ARG;
+    if (!s) s = L.stream;
+    int rc = msm_uses_field29() ? msm_tail_on<TailCurve<G1R29>::type>(L, slots, nslots, s, tail_stream) : msm_tail_on<G1>(L, slots, nslots, s, tail_stream);
+    if (rc) msm_abort_slots(L, slots, nslots, s, tail_stream);
+    return rc;
+}
 int msm_g1_launch(Lane& L, const Affine<Fq>* d_points, bool prepared, int* slot, hipStream_t s, hipStream_t tail_stream) {
     if (!ctx()) return WS_ERR_NOINIT;
     if (msm_uses_field29()) return msm_launch<G1R29, G1>(L, 0, d_points, prepared, slot, s, nullptr, tail_stream);

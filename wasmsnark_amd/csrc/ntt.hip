@@ -361,6 +361,7 @@ static int upload(DevBuf& b, const std::vector<Fe>& v, hipStream_t s) {
 static int build_plan(int bits, NttPlan& P, hipStream_t s) {
     P.bits = bits;
     P.np = bits <= LOG_LMAX ? 1 : (bits <= 16 ? 2 : (bits <= 24 ? 3 : 4));
+    { const long v = tuning_get("NTT_NP", 0); if (v >= 1 && v <= 4 && (int)v * LOG_LMAX >= bits && (int)v <= bits) P.np = (int)v; }   // (A/B: fewer, longer passes)
     int basek = bits / P.np, rem = bits % P.np;
     for (int d = 0; d < P.np; d++) P.k[d] = basek + (d < rem ? 1 : 0);
     P.h = (bits + 1) / 2;

@@ -518,6 +518,26 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
         WS_HIP_CHECK(hipEventRecord(L.ev_start, s));      // the witness is ready on s
         if ((rc = msm_plan_dev(L, d_witness, nv, sh, s, table_cw))) return rc;
     }
+    // Round 5: CALC_H goes to the second queue HERE -- right behind the witness plan's few launches, before the host enqueues the
+    // dozens of launches of the four sums.  The kernel trace of a 2^20 proof (profiles/r05_*) showed why: queued last, its first
+    // kernel reached the GPU 0.3-0.4 ms into the proof, when the G2 accumulation had just filled every SIMD with workgroups that
+    // live for ~1 ms, and did not START before 1.6 ms; the grouping pass before that (0.4 ms, LDS-atomic bound) ran alone on the
+    // chip.  Queued here the sparse products and the first transforms run beside the grouping pass.  WSNARK_PROVE_CALCH_FIRST=0: as before.
+    Fe* d_h = nullptr;
+    bool calc_h_done = false;
+    auto enqueue_calc_h = [&]() -> int {
+        if (s2 != s) WS_HIP_CHECK(hipStreamWaitEvent(s2, overlap == 2 ? L.ev_start : L.ev_tail, 0));
+        WS_HIP_CHECK(L.h.reserve((size_t)dom * 32));
+        d_h = L.h.as<Fe>();
+        int r = calc_h ? calc_h(s2, d_h) : calc_h_dev(L, d_witness_all, K->n_vars, K->polsA, K->polsB, dom, d_h, s2);
+        calc_h_done = true;
+        return r;
+    };
+    // (the distributed CALC_H keeps its place: its exchanges are host callbacks that may block this thread)
+    if (!skip_h && !calc_h && s2 != s && overlap == 2 && tuning_get("PROVE_CALCH_FIRST", 1)) {
+        if ((rc = enqueue_calc_h())) return rc;
+        tr.mark("calc_h enqueued (first)");
+    }
     // one grouping pass for all four; A and B1/B2 may run on variants of the plan that leave out the variables
     // absent from their matrix (plan 0 = full, 2 = without B's absentees, 3 = without A's).  A, B1 and C: three
     // accumulations back to back, then ONE batched reduction tail
@@ -543,14 +563,74 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
     // Order 4 (round 3, full-size sums): order 1 with the reduction tails of B2 and of A + B1 on the THIRD queue, so that the
     // next accumulation on the first queue starts at once instead of behind the tail (kernel timeline of a 2^20 proof: the
     // batched A + B1 tail held queue 1 for 1.6 ms while only the H plan ran beside it).
-    hipStream_t tail_q = (order == 4 && L.stream3 && s != L.stream3) ? L.stream3 : nullptr;
+    // Order 5 (round 5): order 4 with C's tail on the third queue as well -- queue 1 is then accumulations only.  With the tail
+    // kernels at a raised wavefront priority (rt.h: wave_prio) a chain beside a full-width accumulation keeps its own pace.
+    // Order 6 (round 5): every accumulation on queue 1, back to back -- B2, A, B1, C, H --, the tails of B2 and of A + B1 on the
+    // third queue beside the accumulations that follow them, CALC_H and the H plan on the second queue (CALC_H queued first, above),
+    // and ONE batched tail for C and H at the end: the proof ends in one exposed G1 tail instead of two in a row, and no
+    // accumulation waits behind a tail.
+    const bool order6 = order == 6 && !skip_h && !calc_h && L.stream3 && s != L.stream3 && s2 != s;
+    hipStream_t tail_q = ((order == 4 || order == 5 || order6) && L.stream3 && s != L.stream3) ? L.stream3 : nullptr;
     auto launch_b2 = [&]() -> int {
         msm_select_plan(L, planB);
         int r = msm_g2_launch(L, K->pointsB2.as<Affine<Fq2>>(), true, &hB2, s, nullptr, tail_q);           // :619
         msm_select_plan(L, 0);
         return r;
     };
-    if (order == 3) {
+    bool h_launched = false;
+    if ((order == 7 || order == 8) && !skip_h && !calc_h && L.stream3 && s != L.stream3 && s2 != s) {
+        // Order 8: the same with the G2 sum in the MIDDLE -- A, B1, then B2, then C, H.  The G1 accumulation holds 3 x 131 of a SIMD's
+        // 512 registers per lane, so CALC_H's transform passes (113) and the grouping kernels (35) fit BESIDE its wavefronts, whereas
+        // nothing fits beside the G2 accumulation's 2 x 243: the transforms run under A and B1, and B2's tail under C and H.
+        const bool b2_mid = order == 8;
+        // Order 7 (round 5): order 6 with the H plan queued BEFORE the sums and an explicit gate, because a chain of small dependent
+        // kernels (CALC_H: 20 launches; the H plan: 6) beside back-to-back accumulations is starved -- each of its launches waits for
+        // workgroup slots that free up one accumulation workgroup at a time (kernel trace of order 6: CALC_H ended 8 ms into the
+        // proof and the H accumulation ran alone behind everything else).  WSNARK_PROVE_GATE: 1 = the B2 accumulation waits for
+        // CALC_H, 2 = the A accumulation waits for the H plan, 0 = no gate.
+        hipStream_t s3 = L.stream3;
+        for (hipEvent_t* e : {&L.ev_plan, &L.ev_g2})
+            if (!*e) WS_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        const long gate = tuning_get("PROVE_GATE", 1);
+        if (!calc_h_done && (rc = enqueue_calc_h())) return rc;
+        WS_HIP_CHECK(hipEventRecord(L.ev_plan, s2));                  // CALC_H is complete on s2
+        msm_select_plan(L, 1);
+        rc = msm_plan_dev(L, d_h + K->hlo, K->h_local, sh, s2, table_ch);
+        msm_select_plan(L, 0);
+        if (rc) return rc;
+        WS_HIP_CHECK(hipEventRecord(L.ev_h, s2));                     // the H plan is complete on s2
+        if (gate == 1) WS_HIP_CHECK(hipStreamWaitEvent(s, L.ev_plan, 0));
+        auto b2 = [&]() -> int {
+            msm_select_plan(L, planB);
+            int r = msm_g2_launch(L, K->pointsB2.as<Affine<Fq2>>(), true, &hB2, s, nullptr, s3);           // :619; its tail on queue 3
+            msm_select_plan(L, 0);
+            return r;
+        };
+        if (!b2_mid && (rc = b2())) return rc;
+        if (gate == 2) WS_HIP_CHECK(hipStreamWaitEvent(s, L.ev_h, 0));
+        const Affine<Fq>* g1sets[2] = {K->pointsA.as<Affine<Fq>>(), K->pointsB1.as<Affine<Fq>>()};
+        const int plans[2] = {planA, planB};
+        int g1slots[2] = {-1, -1};
+        rc = msm_g1_launch_batch(L, g1sets, 2, true, g1slots, s, L.ev_tail, plans, s3);                    // :617, :618; one tail on queue 3
+        hA = g1slots[0]; hB1 = g1slots[1];
+        if (rc) return rc;
+        msm_select_plan(L, 0);
+        if (b2_mid && (rc = b2())) return rc;
+        if ((rc = msm_g1_acc_only(L, K->pointsC.as<Affine<Fq>>(), true, &hC, s))) return rc;              // :620
+        WS_HIP_CHECK(hipStreamWaitEvent(s, L.ev_h, 0));
+        msm_select_plan(L, 1);
+        rc = msm_g1_acc_only(L, K->pointsH.as<Affine<Fq>>(), true, &hH, s);                               // :614
+        msm_select_plan(L, 0);
+        if (rc) return rc;
+        const int both[2] = {hC, hH};
+        if (msm_same_tail_geometry(L, hC, hH)) rc = msm_g1_tail(L, both, 2, s);
+        else { rc = msm_g1_tail(L, &hC, 1, s); if (!rc) rc = msm_g1_tail(L, &hH, 1, s); }
+        if (rc) return rc;
+        WS_HIP_CHECK(hipEventRecord(L.ev_g2, s3));
+        WS_HIP_CHECK(hipStreamWaitEvent(s, L.ev_g2, 0));              // s stays the caller's ordering point
+        h_launched = true;
+        tr.mark("order 7: everything enqueued");
+    } else if (order == 3) {
         hipStream_t s3 = L.stream3;
         for (hipEvent_t* e : {&L.ev_plan, &L.ev_g2})
             if (!*e) WS_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -584,7 +664,9 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
             hA = g1slots[0]; hB1 = g1slots[1];
             if (rc) return rc;
             msm_select_plan(L, 0);
-            if ((rc = msm_g1_launch(L, K->pointsC.as<Affine<Fq>>(), true, &hC, s))) return rc;            // :620 (padded)
+            if (order6) rc = msm_g1_acc_only(L, K->pointsC.as<Affine<Fq>>(), true, &hC, s);                     // (its tail: with H's, below)
+            else rc = msm_g1_launch(L, K->pointsC.as<Affine<Fq>>(), true, &hC, s, order == 5 ? tail_q : nullptr);   // :620 (padded)
+            if (rc) return rc;
             if (tail_q) {                                                                                  // s stays the caller's ordering point
                 for (hipEvent_t* e : {&L.ev_g2})
                     if (!*e) WS_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -616,33 +698,46 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
         return WS_OK;
     }
     // CALC_H, then the H MSM over domainSize pairs (src/bn128.js:607-615)
-    if (s2 != s) WS_HIP_CHECK(hipStreamWaitEvent(s2, overlap == 2 ? L.ev_start : L.ev_tail, 0));
-    WS_HIP_CHECK(L.h.reserve((size_t)dom * 32));
-    Fe* d_h = L.h.as<Fe>();
-    if (calc_h) rc = calc_h(s2, d_h);
-    else rc = calc_h_dev(L, d_witness_all, K->n_vars, K->polsA, K->polsB, dom, d_h, s2);
-    if (rc) return rc;
-    tr.mark("calc_h enqueued");
+    if (!h_launched) {
+    if (!calc_h_done) {
+        if ((rc = enqueue_calc_h())) return rc;
+        tr.mark("calc_h enqueued");
+    }
     msm_select_plan(L, s2 != s ? 1 : 0);
     rc = msm_plan_dev(L, d_h + K->hlo, K->h_local, sh, s2, table_ch);
-    if (!rc) rc = msm_g1_launch(L, K->pointsH.as<Affine<Fq>>(), true, &hH, s2);                           // :614
+    if (!rc && order6) {
+        // the H accumulation joins queue 1 behind C's; one reduction tail for the two (or one each, should their geometries differ)
+        if (hipEventRecord(L.ev_h, s2) != hipSuccess || hipStreamWaitEvent(s, L.ev_h, 0) != hipSuccess) rc = WS_ERR_HIP;
+        if (!rc) rc = msm_g1_acc_only(L, K->pointsH.as<Affine<Fq>>(), true, &hH, s);                      // :614
+        if (!rc) {
+            const int both[2] = {hC, hH};
+            if (msm_same_tail_geometry(L, hC, hH)) rc = msm_g1_tail(L, both, 2, s);
+            else { rc = msm_g1_tail(L, &hC, 1, s); if (!rc) rc = msm_g1_tail(L, &hH, 1, s); }
+        }
+    } else if (!rc) {
+        rc = msm_g1_launch(L, K->pointsH.as<Affine<Fq>>(), true, &hH, s2);                                // :614
+    }
     msm_select_plan(L, 0);
     if (rc) return rc;
     if (s2 != s) { WS_HIP_CHECK(hipEventRecord(L.ev_h, s2)); WS_HIP_CHECK(hipStreamWaitEvent(s, L.ev_h, 0)); }   // s stays the caller's ordering point
     tr.mark("plan(h) + launch H");
-    const bool g2_fin = g2_first && order != 3;      // (order 3: B2 ends on its own queue, A / B1 / C come first)
+    }
+    const bool g2_late = order == 8 && h_launched;   // (order 8: B2's tail runs behind A + B1's, under the C and H accumulations)
+    const bool g2_fin = g2_first && order != 3 && !g2_late;      // (order 3: B2 ends on its own queue, A / B1 / C come first)
     if (g2_fin && (rc = msm_g2_finish(L, hB2, &out->B2))) return rc;
     if ((rc = msm_g1_finish(L, hA, &out->A))) return rc;
     if ((rc = msm_g1_finish(L, hB1, &out->B1))) return rc;
     tr.mark(g2_fin ? "finish B2, A, B1" : "finish A, B1");
     if (after_ab1) after_ab1(*out);
-    if (!g2_fin && (rc = msm_g1_finish(L, hC, &out->C))) return rc;
+    if (g2_late && (rc = msm_g2_finish(L, hB2, &out->B2))) return rc;
+    if (!g2_fin && !g2_late && (rc = msm_g1_finish(L, hC, &out->C))) return rc;
     tr.mark(g2_fin ? "host work on A, B1" : "host work on A, B1; finish C");
     // the two queues end independently: finish whichever sum reaches the host first (its serial host tail then runs while
     // the GPU still works on the other one), so poll both instead of blocking on one
     {
-        const int hX = g2_fin ? hC : hB2;                 // the first queue's last sum
-        auto finish_x = [&]() -> int { return g2_fin ? msm_g1_finish(L, hC, &out->C) : msm_g2_finish(L, hB2, &out->B2); };
+        const bool x_is_c = g2_fin || g2_late;
+        const int hX = x_is_c ? hC : hB2;                 // the first queue's last sum
+        auto finish_x = [&]() -> int { return x_is_c ? msm_g1_finish(L, hC, &out->C) : msm_g2_finish(L, hB2, &out->B2); };
         bool doneX = false, doneH = false;
         for (unsigned spins = 0; !(doneX && doneH); spins++) {
             if (!doneX && (doneH || msm_ready(L, hX))) { if ((rc = finish_x())) return rc; doneX = true; continue; }
