@@ -290,6 +290,39 @@ typedef struct {
 int wsnark_groth16_prove_dist(wsnark_pkey_t* handle, const void* d_witness, size_t witness_len, const wsnark_comm_t* comm,
                               const void* r32, const void* s32, void* out384_host, void* stream);
 
+/* ---- several GPUs in ONE process (csrc/group.hip; round 5) ----
+ * The reference's host is one process that starts W workers (src/bn128.js:173-265, `build()`), cuts every multi-exponentiation
+ * into W contiguous ranges of the pairs, posts one to each worker and adds the partial results (:353-415), and runs the five
+ * sums of a proof that way (:607-622).  A group is that arrangement with GPUs as the workers, for hosts that are ONE process
+ * (the Node.js drop-in): one context and one host thread per device, the transport between the devices inside the library
+ * (device-to-device copies ordered by events for the distributed CALC_H's three exchanges; the 576-byte records gathered in
+ * host memory).  Hosts that run one process per GPU keep using wsnark_groth16_prove_dist with their own transport.
+ *   wsnark_group_create      devices[n]: HIP device ordinals (the same ordinal may appear more than once: two contexts on one
+ *                            GPU -- how the path is tested on a single-GPU box).  Independent of wsnark_init.
+ *   wsnark_group_pkey_load*  one POINTS SHARD of the key per device (wsnark_pkey_load_shard: pairs [g floor(n/N), ...), all
+ *                            fixed-base table rows of that range, 1 / N of the key's memory each; the two matrices complete)
+ *   wsnark_group_prove       = wsnark_groth16_prove over the group: same inputs, same 384 bytes.  CALC_H runs on the
+ *                            distributed four-step transform when N is a power of two <= 2^floor(log2(domain) / 2)
+ *                            (wsnark_group_pkey_info reports which), otherwise complete on every device.
+ *   wsnark_group_g{1,2}_msm  = wsnark_g{1,2}_msm with the reference's split of the pairs over the devices
+ * Calls on one group are serialised (one collective at a time); different groups are independent. */
+typedef struct wsnark_group wsnark_group_t;
+typedef struct wsnark_group_pkey wsnark_group_pkey_t;
+int wsnark_group_create(const int* devices, uint32_t n, wsnark_group_t** out_group);
+void wsnark_group_free(wsnark_group_t* group);
+uint32_t wsnark_group_size(const wsnark_group_t* group);
+int wsnark_group_pkey_load(wsnark_group_t* group, const void* pkey, size_t len, wsnark_group_pkey_t** out_handle);
+int wsnark_group_pkey_load_sections(wsnark_group_t* group, const wsnark_key_sections_t* ks, wsnark_group_pkey_t** out_handle);
+void wsnark_group_pkey_free(wsnark_group_pkey_t* handle);
+int wsnark_group_pkey_info(const wsnark_group_pkey_t* handle, uint32_t* n_vars, uint32_t* n_public, uint32_t* domain, uint32_t* world,
+                           int* distributed_calc_h);
+int wsnark_group_pkey_wait_tables(wsnark_group_pkey_t* handle);
+int wsnark_group_prove(wsnark_group_pkey_t* handle, const void* witness, size_t witness_len, const void* r32, const void* s32,
+                       void* out384);
+int wsnark_group_last_blinding(wsnark_group_t* group, void* r32, void* s32);     /* = wsnark_last_blinding for the group's last proof */
+int wsnark_group_g1_msm(wsnark_group_t* group, const void* scalars, const void* points, uint64_t n, void* out96);
+int wsnark_group_g2_msm(wsnark_group_t* group, const void* scalars, const void* points, uint64_t n, void* out192);
+
 /* ---- synthetic-input helpers: NO reference counterpart ----
  * out[i] = scalars[i] * base (affine Montgomery in and out; infinity written as all-zero bytes).
  * The reference ships no proving key (its test/data/proving_key.bin is absent), so benches and

@@ -24,3 +24,18 @@ def orc():
     from oracle import pyoracle
     pyoracle.lib()
     return pyoracle
+
+
+@pytest.fixture
+def tune():
+    """tune(lib, NAME, value): a library switch for the duration of one test, through wsnark_tuning_set.  (The library reads the
+    environment ONCE per switch name and process -- on first use -- so tests never rely on changing WSNARK_* variables mid-run.)"""
+    done = []
+
+    def set_(lib, name, value):
+        lib.tune(name, value)
+        done.append((lib, name))
+
+    yield set_
+    for lib, name in done:
+        lib.tune(name, None)

@@ -30,6 +30,18 @@ const toAB = (b) => b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength);
         if (Buffer.from(r).toString("hex") !== c.multiexp_affine) throw new Error("g1 msm mismatch n=" + c.n);
         checked++;
     }
+    // G2_MULTIEXP and CALC_H through the addon as well (the reference's Bn128.g2_multiexp, calcH: src/bn128.js:385-415, 569-578)
+    for (const c of msm.g2) {
+        if (c.flavour === "accumulate_into_3G") continue;
+        const r = await bn.g2_multiexp(Buffer.from(c.scalars, "base64"), Buffer.from(c.points, "base64"));
+        if (Buffer.from(r).toString("hex") !== c.multiexp_affine) throw new Error("g2 msm mismatch n=" + c.n);
+        checked++;
+    }
+    for (const c of JSON.parse(fs.readFileSync(path.join(gold, "calch.json"), "utf8"))) {
+        const h = await bn.calcH(Buffer.from(c.signals, "base64"), Buffer.from(c.polsA, "base64"), Buffer.from(c.polsB, "base64"), c.nSignals, c.domain);
+        if (Buffer.from(h).toString("base64") !== c.h) throw new Error("calcH mismatch domain=" + c.domain);
+        checked++;
+    }
     const fft = JSON.parse(fs.readFileSync(path.join(gold, "fft.json"), "utf8"));
     for (const c of fft.cases) {
         if (c.n < 2) continue;
@@ -71,9 +83,9 @@ const toAB = (b) => b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength);
         await bn.groth16GenProof(wit, a3, { r: Buffer.from(c3.r, "hex"), s: Buffer.from(c3.s, "hex") });
         const hk = await bn.loadKey(a3);
         const digestsBefore = bn.fullDigests;
-        if ((await bn.loadKey(a3)) !== hk) throw new Error("unchanged key was reloaded");
-        if (bn.fullDigests !== digestsBefore) throw new Error("a cache hit took a whole-buffer digest (round 4: the sampled fingerprint only)");
-        if ((await bn.loadKey(a3, { trustCache: false })) !== hk || bn.fullDigests !== digestsBefore + 1) throw new Error("trustCache: false must digest the whole buffer and still hit");
+        if ((await bn.loadKey(a3, { trustCache: true })) !== hk) throw new Error("unchanged key was reloaded");
+        if (bn.fullDigests !== digestsBefore) throw new Error("trustCache: true took a whole-buffer digest (the sampled fingerprint only)");
+        if ((await bn.loadKey(a3)) !== hk || bn.fullDigests !== digestsBefore + 1) throw new Error("the default must digest the whole buffer and still hit");
         // two concurrent first calls with one key object share ONE load (ADVICE r3: no second resident copy of the tables)
         {
             const fresh = new Uint8Array(k3);
@@ -81,7 +93,7 @@ const toAB = (b) => b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength);
             if (h1 !== h2) throw new Error("concurrent callers loaded the same key twice");
         }
         a3[100] ^= 0xff;                                   // (inside the header: the sampled fingerprint covers it)
-        if ((await bn.loadKey(a3)) === hk) throw new Error("stale key handle returned for changed bytes");
+        if ((await bn.loadKey(a3, { trustCache: true })) === hk) throw new Error("stale key handle returned for changed bytes");
         // invalidateKey: the next call loads afresh even though nothing the fingerprint samples has changed
         {
             const before = await bn.loadKey(a3);
@@ -89,15 +101,40 @@ const toAB = (b) => b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength);
         }
         // ... wherever the byte is: the digest covers the whole buffer, not samples of it (VERDICT r2 item 8) -- every
         // offset of a stretch well past the header, one flip at a time, each must give a fresh handle
-        // (round 4: the whole-buffer digest is what a caller who rewrites bytes in place ASKS for -- {trustCache: false})
+        // (round 5: the whole-buffer digest is the DEFAULT for key bytes)
         let prev = await bn.loadKey(a3);
         for (const off of [489, 500, 510, 777, 1001, k3.length - 33, k3.length - 2, k3.length - 1]) {
             a3[off] ^= 0x01;
             let h2 = null;
-            try { h2 = await bn.loadKey(a3, { trustCache: false }); } catch (e) { h2 = null; }        // (a flip inside a record count makes the key malformed: a fresh parse that fails has noticed, too)
+            try { h2 = await bn.loadKey(a3); } catch (e) { h2 = null; }        // (a flip inside a record count makes the key malformed: a fresh parse that fails has noticed, too)
             if (h2 !== null && h2 === prev) throw new Error("stale key handle after a flip at offset " + off);
             if (h2 === null) a3[off] ^= 0x01; else prev = h2;
         }
+    }
+    // A key rewritten IN PLACE where no sample of the fingerprint looks (ADVICE r4): the reference re-parses pkey in every call
+    // (src/bn128.js:581-604), so the proof must be the NEW key's -- through the method and through the module-level drop-in alike.
+    {
+        const k6 = fs.readFileSync(path.join(gold, "keys", "t6.pkey.bin")), w6 = fs.readFileSync(path.join(gold, "keys", "t6.witness.bin"));
+        const c6 = proofs.t6[1], rs = { r: Buffer.from(c6.r, "hex"), s: Buffer.from(c6.s, "hex") };
+        const live = new Uint8Array(k6);
+        if (JSON.stringify(await bn.groth16GenProof(w6, live, rs)) !== JSON.stringify(c6.proof)) throw new Error("t6 proof before the in-place change");
+        // swap two A points (bytes far from the header; chosen so that no 32-byte sample of fingerprint() covers them)
+        const u32 = new Uint32Array(k6.buffer.slice(k6.byteOffset, k6.byteOffset + 40));
+        const pA = u32[5], step = Math.max(32, Math.floor(live.length / 64 / 32) * 32);
+        let off = pA + 64 * 3;
+        const sampled = (o) => { for (let k = 1; k <= 64; k++) if (o + 64 > k * step - 32 && o < k * step) return true; return o < 488 || o + 64 > live.length - 64; };
+        while (sampled(off) || sampled(off + 64)) off += 64;
+        const tmp = live.slice(off, off + 64);
+        live.copyWithin(off, off + 64, off + 128); live.set(tmp, off + 64);
+        const changed = await bn.groth16GenProof(w6, live, rs);
+        const fresh = await (await ws.buildBn128(undefined, lib ? { lib } : undefined)).groth16GenProof(w6, new Uint8Array(live), rs);
+        if (JSON.stringify(changed) === JSON.stringify(c6.proof)) throw new Error("a key patched in place was served from the stale resident copy");
+        if (JSON.stringify(changed) !== JSON.stringify(fresh)) throw new Error("proof after an in-place change differs from a fresh load of the same bytes");
+        // {trustCache: true} is the caller's promise that the bytes do not change: the stale handle is what it gets
+        live.copyWithin(off, off + 64, off + 128); live.set(tmp, off + 64);      // (swapped back: the ORIGINAL bytes again, the cached handle is the changed key's)
+        const trusted = await bn.groth16GenProof(w6, live, Object.assign({ trustCache: true }, rs));
+        if (JSON.stringify(trusted) !== JSON.stringify(changed)) throw new Error("trustCache: true must keep the cached handle");
+        checked += 2;
     }
     // terminate() of one Bn128 object must not shut the context down under another one (VERDICT r2 item 8)
     {
@@ -142,6 +179,37 @@ const toAB = (b) => b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength);
         const ki = await bn.keyInfo(k6);
         if (!(ki.nVars > 0 && ki.domainSize > 0 && ki.loadMs && ki.loadMs.total > 0)) throw new Error("keyInfo: " + JSON.stringify(ki));
         if ((await bn.waitTables(k6)) !== true) throw new Error("waitTables");
+    }
+    // SEVERAL contexts in this one process (buildBn128({devices})): the same proofs, sums and shapes over a group of two contexts
+    // on device 0 (what a single-GPU box can run; on an 8-GPU node the ordinals differ, nothing else)
+    {
+        const grp = await ws.buildBn128({ devices: [0, 0], lib: lib || undefined });
+        for (const name of Object.keys(proofs)) {
+            const pk = fs.readFileSync(path.join(gold, "keys", name + ".pkey.bin")), wt = fs.readFileSync(path.join(gold, "keys", name + ".witness.bin"));
+            for (const c of proofs[name]) {
+                const p = await grp.groth16GenProof(wt, pk, { r: Buffer.from(c.r, "hex"), s: Buffer.from(c.s, "hex") });
+                if (JSON.stringify(p) !== JSON.stringify(c.proof)) throw new Error("group proof mismatch for " + name);
+                checked++;
+            }
+            const ki = await grp.keyInfo(pk);
+            if (ki.world !== 2 || !(ki.nVars > 0)) throw new Error("group keyInfo: " + JSON.stringify(ki));
+        }
+        const pk3 = fs.readFileSync(path.join(gold, "keys", "t3.pkey.bin")), wt3 = fs.readFileSync(path.join(gold, "keys", "t3.witness.bin"));
+        const g1 = await grp.groth16GenProof(wt3, pk3);                                   // drawn blinding: kept like _pr / _ps, reproducible
+        const g2 = await grp.groth16GenProof(wt3, pk3, { r: Buffer.from(grp._pr), s: Buffer.from(grp._ps) });
+        if (JSON.stringify(g1) !== JSON.stringify(g2)) throw new Error("group proof with drawn r, s is not reproducible");
+        for (const [list, fn] of [[msm.g1, grp.g1_multiexp], [msm.g2, grp.g2_multiexp]]) {
+            for (const c of list) {
+                if (c.flavour === "accumulate_into_3G") continue;
+                const r = await fn.call(grp, Buffer.from(c.scalars, "base64"), Buffer.from(c.points, "base64"));
+                if (Buffer.from(r).toString("hex") !== c.multiexp_affine) throw new Error("group msm mismatch n=" + c.n);
+                checked++;
+            }
+        }
+        grp.terminate();
+        const c3 = proofs.t3[0];                                                          // the single-context object is untouched by it
+        const still = await bn.groth16GenProof(wit, pkey, { r: Buffer.from(c3.r, "hex"), s: Buffer.from(c3.s, "hex") });
+        if (JSON.stringify(still) !== JSON.stringify(c3.proof)) throw new Error("proof after a group's terminate()");
     }
     // error path: rejected Promise, not a hang (the reference hangs: SURVEY section 5)
     let rejected = false;

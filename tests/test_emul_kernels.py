@@ -121,10 +121,10 @@ def test_msm_vs_oracle_skewed(bn, orc, g, n):
 
 
 @pytest.mark.parametrize("g,n", [(1, 700), (2, 200)])
-def test_msm_hot_bucket_path(bn, orc, monkeypatch, g, n):
+def test_msm_hot_bucket_path(bn, orc, tune, g, n):
     """Buckets with very many tasks (one scalar value shared by most pairs: the ones of a boolean-heavy witness)
     have their task list and their partial sums handled by many workgroups; forced here with a tiny threshold."""
-    monkeypatch.setenv("WSNARK_MSM_HOT_MIN", "2")
+    tune(bn.lib, "MSM_HOT_MIN", 2)
     rnd = random.Random(300 + g)
     ks = [rnd.randrange(1, orc.R) for _ in range(n)]
     pts = _points(orc, g, ks)
@@ -134,17 +134,14 @@ def test_msm_hot_bucket_path(bn, orc, monkeypatch, g, n):
 
 
 @pytest.mark.parametrize("g,n,c,hot", [(1, 2000, 9, False), (1, 1500, 10, True), (2, 700, 9, False), (2, 500, 9, True)])
-def test_msm_split_plan(bn, orc, monkeypatch, g, n, c, hot):
-    """A whole stand-alone MSM runs on a SPLIT plan: the tasks of the high windows form a first segment, the low windows a
-    second one; the reduction tail of the first runs on the lane's second queue beside the accumulation of the second, and the
-    host starts its Horner chain on the rows that arrive first (WSNARK_MSM_SPLIT=1: measured slower on the MI355X and off by
-    default, kept as a recorded A/B).  Forced at a size the oracle finishes (the threshold is 2^14 pairs), with and without buckets that are cut into several tasks; same result as the unsplit launch."""
-    monkeypatch.setenv("WSNARK_MSM_SPLIT", "1")
-    monkeypatch.setenv("WSNARK_MSM_SPLIT_MIN", "1")
-    monkeypatch.setenv("WSNARK_MSM_C", str(c))
+def test_msm_window_widths_hot_and_multi_task_buckets_and_window_shards(bn, orc, tune, g, n, c, hot):
+    """A stand-alone MSM at forced window widths, with buckets cut into several tasks and hot buckets (the three roles of the one
+    combine launch: a lane, a wavefront, slices + the wavefront that completes a bucket's last slice), zero scalars, raw scalars
+    >= r; and the same sum as three window shards combined on the host."""
+    tune(bn.lib, "MSM_C", c)
     if hot:
-        monkeypatch.setenv("WSNARK_MSM_HOT_MIN", "2")
-        monkeypatch.setenv("WSNARK_MSM_LMAX", "4")
+        tune(bn.lib, "MSM_HOT_MIN", 2)
+        tune(bn.lib, "MSM_LMAX", 4)
     rnd = random.Random(500 + g + c)
     ks = [rnd.randrange(1, orc.R) for _ in range(n)]
     pts = _points(orc, g, ks)
@@ -152,25 +149,10 @@ def test_msm_split_plan(bn, orc, monkeypatch, g, n, c, hot):
     f = bn.g1_multiexp if g == 1 else bn.g2_multiexp
     out = f(sc, pts)
     assert out == orc.g_affine(g, orc.multiexp(g, "multiexp2" if g == 1 else "multiexp", sc, pts, n))
-    monkeypatch.setenv("WSNARK_MSM_SPLIT", "0")
-    assert f(sc, pts) == out
-    monkeypatch.setenv("WSNARK_MSM_SPLIT", "1")
-    parts = b"".join(f(sc, pts, shard=(rank, 3)) for rank in range(3))            # window shards of a split plan
+    assert f(sc, pts) == out                                                      # (the hot-bucket completion counters are left at zero)
+    parts = b"".join(f(sc, pts, shard=(rank, 3)) for rank in range(3))            # window shards
     assert (bn.g1_sum if g == 1 else bn.g2_sum)(parts) == out
 
-
-@pytest.mark.parametrize("g,n", [(1, 1000), (1, 130), (2, 300)])
-def test_msm_segscan_shape(bn, orc, monkeypatch, g, n):
-    """WSNARK_ACC_SHAPE=segscan (A/B only): the accumulation as a wavefront segmented scan over the sorted
-    stream -- one pair per lane, bucket runs folded across lanes through LDS, runs that cross a wavefront merged afterwards.
-    Same sums as the shipped one-lane-per-bucket kernel, incl. hot buckets that span many wavefronts and zero scalars."""
-    monkeypatch.setenv("WSNARK_ACC_SHAPE", "segscan")
-    rnd = random.Random(900 + g + n)
-    ks = [rnd.randrange(1, orc.R) for _ in range(n)]
-    pts = _points(orc, g, ks)
-    sc = b"".join(((5 if rnd.random() < 0.4 else rnd.randrange(1 << 256)) if i % 9 else 0).to_bytes(32, "little") for i in range(n))
-    out = bn.g1_multiexp(sc, pts) if g == 1 else bn.g2_multiexp(sc, pts)
-    assert out == orc.g_affine(g, orc.multiexp(g, "multiexp2" if g == 1 else "multiexp", sc, pts, n))
 
 
 def test_msm_same_point_many_times(bn, orc):

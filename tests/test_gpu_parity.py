@@ -144,15 +144,11 @@ def test_msm_all_same_point(bn, orc):
     assert bn.g1_multiexp(sc, pts)[:64] == want
 
 
-@pytest.mark.parametrize("env", [{"WSNARK_MSM_ENTRY64": "1"}, {"WSNARK_MSM_LO_BITS": "5"}, {"WSNARK_MSM_LO_BITS": "10"},
-                                 {"WSNARK_MSM_TILE": "256", "WSNARK_MSM_TILE_THREADS": "256"}, {"WSNARK_MSM_HOT_MIN": "2"},
-                                 {"WSNARK_MSM_SORT": "cub"}, {"WSNARK_MSM_SPLIT": "1"}, {"WSNARK_ACC_SHAPE": "segscan"},
-                                 {"WSNARK_MSM_SMALL_TASKS": "0"}, {"WSNARK_MSM_LMAX": "6"}])
-def test_msm_grouping_variants_agree(bn, monkeypatch, env):
-    """Entry width, bin geometry, tile shape, hot-bucket threshold and the hipCUB pipeline only change how the
-    pairs are grouped: the sum must not move by a bit (G1 and G2, 60 000 pairs with 30 % ones).  Round 3's recorded A/B
-    shapes are in the list too: the split plan (two task segments, the high windows' tail on the second queue), the
-    wavefront-segmented-scan accumulation, and the task-cutting rule for very small sums."""
+@pytest.mark.parametrize("cfg", [{"MSM_ENTRY64": 1}, {"MSM_HOT_MIN": 2}, {"MSM_LMAX": 6}, {"MSM_C": 12, "MSM_HOT_MIN": 2, "MSM_LMAX": 4}])
+def test_msm_grouping_variants_agree(bn, tune, cfg):
+    """Entry width, hot-bucket threshold, task cap and window width only change how the pairs are grouped and how the partial sums of
+    split buckets are folded (the three roles of the one combine launch): the sum must not move by a bit (G1 and G2, 60 000 pairs
+    with 30 % ones)."""
     import numpy as np
     n = 60000
     rng = np.random.default_rng(42)
@@ -166,25 +162,22 @@ def test_msm_grouping_variants_agree(bn, monkeypatch, env):
         pts = bn.mul_base(g, ks.tobytes())
         msm = bn.g1_multiexp if g == 1 else bn.g2_multiexp
         base = msm(sc.tobytes(), pts)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        try:
-            assert msm(sc.tobytes(), pts) == base
-        except WsnarkError as ex:
-            # the hipCUB pipeline is an A/B path of builds with -DWSNARK_WITH_CUB: the default build must refuse it loudly
-            assert env == {"WSNARK_MSM_SORT": "cub"} and "built without hipCUB" in str(ex)
-        for k in env:
-            monkeypatch.delenv(k)
+        for k, v in cfg.items():
+            tune(bn.lib, k, v)
+        assert msm(sc.tobytes(), pts) == base
+        assert msm(sc.tobytes(), pts) == base          # (twice: the hot-bucket completion counters are left at zero)
+        for k in cfg:
+            bn.lib.tune(k, None)
 
 
-def test_msm_window_override(bn, orc, monkeypatch):
+def test_msm_window_override(bn, orc, tune):
     rnd = random.Random(77)
     n = 2000
     pts = bn.mul_base(1, b"".join(rnd.randrange(1, orc.R).to_bytes(32, "little") for _ in range(n)))
     sc = _skewed_scalars(rnd, n, orc.R)
     want = orc.g_affine(1, orc.multiexp(1, "workers8", sc, pts, n))
-    for c in ("4", "9", "13", "16"):
-        monkeypatch.setenv("WSNARK_MSM_C", c)
+    for c in (4, 9, 13, 16):
+        tune(bn.lib, "MSM_C", c)
         assert bn.g1_multiexp(sc, pts) == want, c
 
 
@@ -363,10 +356,9 @@ def test_prove_vs_toxic_waste_closed_form(bn, logd, style):
 
 
 def test_host_witness_paths_and_runtime_switches(bn):
-    """Round 4: a witness in HOST memory reaches the GPU by three routes -- pageable memory through the pinned ring (chunk by chunk,
-    the grouping histogram taken per arriving chunk; ring slots reused: 64 KiB chunks through a ring the first upload sized), the same
-    with the whole witness uploaded before the first kernel, and a PINNED buffer (wsnark_host_alloc) DMA'd in place -- and the
-    reduction tail has its round-3 and round-4 geometries behind run-time switches (wsnark_tuning_set).  Every combination must give
+    """A witness in HOST memory reaches the GPU by two routes -- pageable memory through the pinned ring (chunk by chunk, the grouping
+    histogram taken per arriving chunk; ring slots reused: 64 KiB chunks through a ring the first upload sized) and a PINNED buffer
+    (wsnark_host_alloc) DMA'd in place -- and the reduction tail has its geometries behind run-time switches (wsnark_tuning_set).  Every combination must give
     the closed-form proof at 2^18 (129 chunks of the witness at the smallest chunk size: one more than the ring has slots), on the whole key and on a points shard."""
     import ctypes as C
     from wasmsnark_amd import synth
@@ -378,11 +370,10 @@ def test_host_witness_paths_and_runtime_switches(bn):
     key = bn.load_key(sections=sec)
     pinned = C.c_void_p()
     bn.lib.check(bn.lib.c.wsnark_host_alloc(len(wit), C.byref(pinned)))
-    names = ("STAGE_CHUNK_KB", "STAGE_WORKERS", "PROVE_CHUNKED_UPLOAD", "STAGE_DUAL", "STAGE_DIRECT_CHUNK_KB", "MSM_CHUNK", "TAIL_BITS", "TAIL_REDUCE", "G2_TAIL_PAIR")
+    names = ("STAGE_CHUNK_KB", "STAGE_WORKERS", "MSM_CHUNK", "TAIL_BITS")
     try:
         C.memmove(pinned, wit, len(wit))
-        for cfg in ({}, {"STAGE_CHUNK_KB": 64, "STAGE_WORKERS": 3}, {"STAGE_CHUNK_KB": 1024, "STAGE_DUAL": 1}, {"PROVE_CHUNKED_UPLOAD": 0},
-                    {"STAGE_DIRECT_CHUNK_KB": 1024}, {"MSM_CHUNK": 8, "TAIL_BITS": 15, "TAIL_REDUCE": 0, "G2_TAIL_PAIR": 0}, {"MSM_CHUNK": 2, "TAIL_BITS": 10}):
+        for cfg in ({}, {"STAGE_CHUNK_KB": 64, "STAGE_WORKERS": 3}, {"STAGE_CHUNK_KB": 1024}, {"MSM_CHUNK": 8, "TAIL_BITS": 15}, {"MSM_CHUNK": 2, "TAIL_BITS": 10}):
             for n in names:
                 bn.lib.tune(n, cfg.get(n))
             assert bn.groth16GenProof(wit, key, r=r, s=s) == want, cfg
@@ -408,7 +399,7 @@ def test_proofs_beside_the_background_table_build(bn):
     """Round 4: wsnark_pkey_load returns when the sections are resident; the rows of the fixed-base tables are built behind it on a
     queue of their own, and proofs that arrive meanwhile run on the plain sections.  At 2^18: proofs right behind the load (two of
     them from the two lanes at once), across the moment the tables become ready, and after wsnark_pkey_wait_tables -- all equal to
-    the closed form; the same with the one-kernel build (WSNARK_TABLE_STEPPED=0) and with a scratch slab smaller than the sections; a
+    the closed form; the same with a scratch slab smaller than the sections; a
     key freed while its build is still running; load stats report the build only once it is over."""
     import threading
     from wasmsnark_amd import synth
@@ -418,8 +409,8 @@ def test_proofs_beside_the_background_table_build(bn):
     r, s = os.urandom(32), os.urandom(32)
     want = circ.expected_proof(r, s)
     try:
-        for cfg in ({}, {"TABLE_STEPPED": 0}, {"TABLE_SLAB_LANES": 4096}):
-            for n in ("TABLE_STEPPED", "TABLE_SLAB_LANES"):
+        for cfg in ({}, {"TABLE_SLAB_LANES": 4096}):
+            for n in ("TABLE_SLAB_LANES",):
                 bn.lib.tune(n, cfg.get(n))
             key = bn.load_key(sections=sec, wait_tables=False)
             assert key.table["rows_w"] > 1
@@ -437,8 +428,7 @@ def test_proofs_beside_the_background_table_build(bn):
             doomed = bn.load_key(sections=sec, wait_tables=False)
             doomed.free()                                         # the destructor waits for the build queue
     finally:
-        for n in ("TABLE_STEPPED", "TABLE_SLAB_LANES"):
-            bn.lib.tune(n, None)
+        bn.lib.tune("TABLE_SLAB_LANES", None)
 
 
 def test_loads_frees_and_proofs_overlap(bn):
@@ -695,9 +685,10 @@ def test_sharded_prove_records_on_gpu(bn):
 
 
 @pytest.mark.parametrize("logd", [12, 16])
-def test_key_tables_and_plain_sections_give_the_same_proofs_on_gpu(bn, monkeypatch, logd):
+def test_key_tables_and_plain_sections_give_the_same_proofs_on_gpu(bn, tune, logd):
     """Resident keys are fixed-base window tables by default (wsnark_pkey_table_info: rows x n points per section, one
-    bucket set per sum); WSNARK_KEY_TABLE=0 keeps the plain sections and the per-window plans.  Same proofs from both,
+    bucket set per sum); KEY_TABLE=0 keeps the plain sections and the per-window plans (2 / 3: tables for the hExps / for the
+    witness sections alone).  Same proofs from all,
     equal to the closed form; also with the table's bucket set cut into several reduction pieces, with the masked plan
     variants, and through the window shards of a world of 3."""
     from wasmsnark_amd import synth
@@ -714,26 +705,25 @@ def test_key_tables_and_plain_sections_give_the_same_proofs_on_gpu(bn, monkeypat
     parts = b"".join(bn.groth16_prove_partial(wit, key, shard=(rank, 3)) for rank in range(3))
     assert bn.groth16_prove_finish(key, parts, r=r, s=s) == want
     key.free()
-    for env in ({"WSNARK_KEY_TABLE": "0"}, {"WSNARK_TABLE_C": "10", "WSNARK_TAIL_BITS": "6", "WSNARK_PROVE_SPARSE": "2"},
-                {"WSNARK_TABLE_C": "13", "WSNARK_MSM_ENTRY64": "1"}):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    for cfg in ({"KEY_TABLE": 0}, {"KEY_TABLE": 2}, {"KEY_TABLE": 3}, {"TABLE_C": 10, "TAIL_BITS": 6, "PROVE_SPARSE": 2}, {"TABLE_C": 13, "MSM_ENTRY64": 1}):
+        for k, v in cfg.items():
+            tune(bn.lib, k, v)
         key = bn.load_key(pkey)
-        assert (key.table["rows_w"] == 1) == ("WSNARK_KEY_TABLE" in env)
-        assert bn.groth16GenProof(wit, key, r=r, s=s) == want, env
+        assert (key.table["rows_w"] == 1) == (cfg.get("KEY_TABLE") in (0, 2)) and (key.table["rows_h"] == 1) == (cfg.get("KEY_TABLE") in (0, 3))
+        assert bn.groth16GenProof(wit, key, r=r, s=s) == want, cfg
         key.free()
-        for k in env:
-            monkeypatch.delenv(k)
+        for k in cfg:
+            bn.lib.tune(k, None)
 
 
 @pytest.mark.parametrize("mode", ["table", "plain"])
-def test_degenerate_key_points_against_the_oracle_prover_on_gpu(bn, orc, monkeypatch, mode):
+def test_degenerate_key_points_against_the_oracle_prover_on_gpu(bn, orc, tune, mode):
     """Equal points with equal scalars (doubling inside a bucket), P / -P neighbours, points at infinity in the A, B1, B2
     and hExps sections of the t6 key: the GPU prover against the oracle's restatement of the reference prover, on the
     fixed-base table key and on plain sections (tests/primitives_common.py: degenerate_key_and_witness)."""
     from primitives_common import degenerate_key_and_witness
     if mode == "plain":
-        monkeypatch.setenv("WSNARK_KEY_TABLE", "0")
+        tune(bn.lib, "KEY_TABLE", 0)
     rd = lambda ext: open(os.path.join(GOLDEN, "keys", "t6" + ext), "rb").read()
     key, w = degenerate_key_and_witness(orc, rd(".pkey.bin"), rd(".witness.bin"))
     k = bn.load_key(key)

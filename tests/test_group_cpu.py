@@ -1,0 +1,77 @@
+"""Several contexts in ONE process (csrc/group.hip): wsnark_group_* on the CPU thread emulator.  The emulator has one "device", so every
+context of a group sits on it -- what is under test is the orchestration: one host thread per context, points shards of one key, the
+distributed prover on every context at once with the in-library transport (device-to-device block copies between the contexts'
+exchange buffers, ordered by host barriers; the records gathered in host memory), and the fall-back with CALC_H complete on every
+device for group sizes the four-step transform cannot take.  Expected values: the REFERENCE's own proofs (tests/golden/proofs.json)."""
+import json
+import os
+
+import pytest
+
+import base64
+
+from conftest import GOLDEN, load_golden
+from emul_util import emul_bn128
+from wasmsnark_amd import bn128
+
+
+def _key(name):
+    rd = lambda ext: open(os.path.join(GOLDEN, "keys", name + ext), "rb").read()
+    return rd(".pkey.bin"), rd(".witness.bin"), json.loads(rd(".meta.json"))
+
+
+@pytest.mark.parametrize("name,world", [("t6", 1), ("t6", 2), ("t6", 4), ("t6", 3), ("t3", 2), ("t3", 4)])
+def test_group_prove_matches_reference(name, world):
+    bn = emul_bn128()
+    pkey, wit, _ = _key(name)
+    g = bn128.Group(lib=bn.lib, devices=[0] * world)
+    try:
+        key = g.load_key(pkey)
+        dom = 8 if name == "t3" else 64
+        assert (key.world, key.domain) == (world, dom)
+        # power-of-two groups of at most 2^floor(log2(domain) / 2) devices run CALC_H on the distributed transform
+        log_n = dom.bit_length() - 1
+        assert key.distributed_calc_h == (world & (world - 1) == 0 and (1 << (log_n // 2)) >= world)
+        for c in load_golden("proofs.json")[name]:
+            got = g.groth16GenProof(wit, key, r=bytes.fromhex(c["r"]), s=bytes.fromhex(c["s"]))
+            assert got == c["proof"]
+        # drawn blinding: rank 0 draws, every rank assembles the same proof; it must be a well-formed proof object
+        p = g.groth16GenProof(wit, key)
+        assert p["pi_a"][2] == "1" and p["pi_b"][2] == ["1", "0"] and p["pi_c"][2] == "1"
+        key.free()
+    finally:
+        g.terminate()
+
+
+def test_group_msm_matches_single_context():
+    """wsnark_group_g{1,2}_msm: the reference's split of the pairs over the workers (src/bn128.js:353-415), partial sums added on the host"""
+    bn = emul_bn128()
+    golden = load_golden("msm.json")
+    g = bn128.Group(lib=bn.lib, devices=[0, 0, 0])
+    try:
+        for which, name in ((0, "g1"), (1, "g2")):
+            for c in golden[name]:
+                if c["flavour"] == "accumulate_into_3G":
+                    continue
+                sc, pt = base64.b64decode(c["scalars"]), base64.b64decode(c["points"])
+                many = g.g2_multiexp(sc, pt) if which else g.g1_multiexp(sc, pt)
+                assert many == bytes.fromhex(c["multiexp_affine"]), (name, c["n"], c["flavour"])      # the reference's own result
+    finally:
+        g.terminate()
+
+
+def test_group_errors_are_agreed_and_the_group_survives():
+    bn = emul_bn128()
+    pkey, wit, _ = _key("t6")
+    g = bn128.Group(lib=bn.lib, devices=[0, 0])
+    try:
+        key = g.load_key(pkey)
+        with pytest.raises(Exception):
+            g.groth16GenProof(wit[:-32], key, r=bytes(32), s=bytes(32))       # witness too short: every rank must leave the collectives
+        c = load_golden("proofs.json")["t6"][0]
+        assert g.groth16GenProof(wit, key, r=bytes.fromhex(c["r"]), s=bytes.fromhex(c["s"])) == c["proof"]
+        with pytest.raises(Exception):
+            g.load_key(pkey[:200])
+        key.free()
+    finally:
+        g.terminate()

@@ -19,10 +19,10 @@ def _t(name):
 
 @pytest.mark.parametrize("name,world,table", [("t6", 2, "table"), ("t6", 8, "table"), ("t6", 70, "table"), ("t3", 4, "table"),
                                               ("t6", 3, "plain"), ("t6", 8, "plain")])
-def test_point_shards_combine_to_the_reference_proof(monkeypatch, name, world, table):
-    if table == "plain":
-        monkeypatch.setenv("WSNARK_KEY_TABLE", "0")
+def test_point_shards_combine_to_the_reference_proof(tune, name, world, table):
     bn = emul_bn128()
+    if table == "plain":
+        tune(bn.lib, "KEY_TABLE", 0)
     pkey, wit = _t(name)
     sec = formats.pkey_bin_to_sections(pkey)
     whole = bn.load_key(sections=sec)

@@ -64,11 +64,11 @@ def test_emulated_kernels_prove_matches_reference(name):
 
 
 @pytest.mark.parametrize("name", NAMES)
-def test_emulated_prove_sparse_b_plan(monkeypatch, name):
+def test_emulated_prove_sparse_b_plan(tune, name):
     """Variables absent from matrix B have B1 = B2 = infinity; with enough of them the two B sums get their own
     plan that leaves those pairs out (forced here).  Same proofs, bit for bit."""
-    monkeypatch.setenv("WSNARK_PROVE_SPARSE", "2")
     bn = emul_bn128()
+    tune(bn.lib, "PROVE_SPARSE", 2)
     pkey, wit, _ = _key(name)
     key = bn.load_key(pkey)
     for c in load_golden("proofs.json")[name]:
@@ -76,65 +76,61 @@ def test_emulated_prove_sparse_b_plan(monkeypatch, name):
 
 
 @pytest.mark.parametrize("name", NAMES)
-@pytest.mark.parametrize("mode", ["plain", "pieces", "pieces-sparse", "wide", "round1-order", "entry64", "one-kernel-build", "slabs", "jacobian-build"])
-def test_emulated_prove_key_table_modes(monkeypatch, name, mode):
+@pytest.mark.parametrize("mode", ["plain", "h-only", "witness-only", "pieces", "pieces-sparse", "wide", "entry64", "slabs"])
+def test_emulated_prove_key_table_modes(tune, name, mode):
     """Resident keys are fixed-base window tables by default (row w = 2^(c w) * section; one bucket set per sum).
-    `plain` switches them off (the per-window path the MSM entry points use); `pieces` forces a table whose bucket set
-    is cut into several tail pieces (the sum_v v T_v term of the host tail), also together with the masked plan
-    variants; `wide` a window wider than the pair count suggests; `one-kernel-build` the table rows from the one long kernel
-    per section instead of the short launches through the scratch slab, `slabs` those launches with a slab smaller than the
-    sections (and three groups of rows behind an inversion each).  Same proofs, bit for bit."""
-    if mode == "plain":
-        monkeypatch.setenv("WSNARK_KEY_TABLE", "0")
-    elif mode.startswith("pieces"):
-        monkeypatch.setenv("WSNARK_TABLE_C", "9")
-        monkeypatch.setenv("WSNARK_TAIL_BITS", "6")
-        if mode.endswith("sparse"):
-            monkeypatch.setenv("WSNARK_PROVE_SPARSE", "2")
-    elif mode == "wide":
-        monkeypatch.setenv("WSNARK_TABLE_C", "13")
-    elif mode == "one-kernel-build":
-        monkeypatch.setenv("WSNARK_TABLE_STEPPED", "0")
-    elif mode == "slabs":
-        monkeypatch.setenv("WSNARK_TABLE_C", "9")
-        monkeypatch.setenv("WSNARK_TABLE_SLAB_LANES", "64")
-    elif mode == "jacobian-build":      # the row-per-launch build on Jacobian coordinates (curve.h: dbl_jac; default: XYZZ); same rows, bit for bit
-        monkeypatch.setenv("WSNARK_TABLE_JACOBIAN", "1")
-        monkeypatch.setenv("WSNARK_TABLE_C", "9")
-    elif mode == "entry64":
-        monkeypatch.setenv("WSNARK_MSM_ENTRY64", "1")     # 8-byte grouping entries: what a 2^24 table key needs (28 index bits)
-        monkeypatch.setenv("WSNARK_PROVE_SPARSE", "2")
-    else:
-        monkeypatch.setenv("WSNARK_PROVE_ORDER", "0")     # A, B1, C, B2 on the first queue (default: B2, A, B1, C)
+    `plain` switches them off (the per-window path the MSM entry points use), `h-only` / `witness-only` keep tables for the hExps
+    resp. for A / B1 / B2 / C alone (WSNARK_KEY_TABLE = 2 / 3: what the resident memory buys, section by section); `pieces`
+    forces a table whose bucket set is cut into several tail pieces (the sum_v v T_v term of the host tail), also together with
+    the masked plan variants; `wide` a window wider than the pair count suggests; `slabs` the row-per-launch build with a slab
+    smaller than the sections (and three groups of rows behind an inversion each); `entry64` the 8-byte grouping entries a 2^24
+    table key needs.  Same proofs, bit for bit."""
     bn = emul_bn128()
+    lib = bn.lib
+    if mode == "plain":
+        tune(lib, "KEY_TABLE", 0)
+    elif mode == "h-only":
+        tune(lib, "KEY_TABLE", 2)
+    elif mode == "witness-only":
+        tune(lib, "KEY_TABLE", 3)
+    elif mode.startswith("pieces"):
+        tune(lib, "TABLE_C", 9)
+        tune(lib, "TAIL_BITS", 6)
+        if mode.endswith("sparse"):
+            tune(lib, "PROVE_SPARSE", 2)
+    elif mode == "wide":
+        tune(lib, "TABLE_C", 13)
+    elif mode == "slabs":
+        tune(lib, "TABLE_C", 9)
+        tune(lib, "TABLE_SLAB_LANES", 64)
+    elif mode == "entry64":
+        tune(lib, "MSM_ENTRY64", 1)
+        tune(lib, "PROVE_SPARSE", 2)
     pkey, wit, _ = _key(name)
     key = bn.load_key(pkey)
     # wsnark_pkey_table_info: plain sections report one row; tables ceil(255 / c) rows of the window the mode asks for
     t = key.table
-    assert (t["rows_w"], t["c_w"]) == ((1, 0) if mode == "plain" else (-(-255 // t["c_w"]), {"pieces": 9, "pieces-sparse": 9, "wide": 13, "slabs": 9, "jacobian-build": 9}.get(mode, t["c_w"])))
+    assert (t["rows_w"], t["c_w"]) == ((1, 0) if mode in ("plain", "h-only") else (-(-255 // t["c_w"]), {"pieces": 9, "pieces-sparse": 9, "wide": 13, "slabs": 9}.get(mode, t["c_w"])))
+    assert (t["rows_h"] == 1) == (mode in ("plain", "witness-only"))
     assert t["bytes"] == key.n_vars * 320 * t["rows_w"] + key.domain * 64 * t["rows_h"]
     for c in load_golden("proofs.json")[name]:
         assert bn.groth16GenProof(wit, key, r=bytes.fromhex(c["r"]), s=bytes.fromhex(c["s"])) == c["proof"]
 
 
-@pytest.mark.parametrize("mode", ["table", "table-one-kernel-build", "table-jacobian-build", "plain"])
-def test_degenerate_key_points_against_the_oracle_prover(orc, monkeypatch, mode):
+@pytest.mark.parametrize("mode", ["table", "plain"])
+def test_degenerate_key_points_against_the_oracle_prover(orc, tune, mode):
     """The prover is a pure function of (witness, key, r, s) -- the key's points need not come from a setup.  Here the
     point sections of the t6 key are made degenerate: runs of EQUAL points (the accumulation's doubling case: equal
     digits of equal points meet in one bucket), P / -P neighbours (the sum that passes through infinity) and points at
     infinity (x = 0), in A, B1, B2 and hExps.  The oracle's restatement of the reference prover is the judge, for the
     fixed-base table key and for the plain sections."""
     from primitives_common import degenerate_key_and_witness
-    if mode == "plain":
-        monkeypatch.setenv("WSNARK_KEY_TABLE", "0")
-    elif mode == "table-one-kernel-build":
-        monkeypatch.setenv("WSNARK_TABLE_STEPPED", "0")
-    elif mode == "table-jacobian-build":
-        monkeypatch.setenv("WSNARK_TABLE_JACOBIAN", "1")
-    else:
-        monkeypatch.setenv("WSNARK_TABLE_SLAB_LANES", "64")
-    key, w = degenerate_key_and_witness(orc, *_key("t6")[:2])
     bn = emul_bn128()
+    if mode == "plain":
+        tune(bn.lib, "KEY_TABLE", 0)
+    else:
+        tune(bn.lib, "TABLE_SLAB_LANES", 64)
+    key, w = degenerate_key_and_witness(orc, *_key("t6")[:2])
     k = bn.load_key(key)
     assert (k.table["rows_w"] > 1) == (mode != "plain")
     for r, s in ((bytes(32), bytes(32)), (bytes(range(1, 33)), bytes(range(101, 133)))):
@@ -324,9 +320,6 @@ def test_staging_ring_and_chunked_witness_upload(orc):
         want = circ.expected_proof(r, s)
         key = bn.load_key(sections=sec)
         assert bn.groth16GenProof(wit, key, r=r, s=s) == want
-        tune("PROVE_CHUNKED_UPLOAD", 0)                                               # the one-piece upload, same proof
-        assert bn.groth16GenProof(wit, key, r=r, s=s) == want
-        tune("PROVE_CHUNKED_UPLOAD", None)
         key.free()
         recs = b""
         for rank in range(2):                                                        # shards: a chunk that straddles a shard's first / last signal
@@ -336,20 +329,20 @@ def test_staging_ring_and_chunked_witness_upload(orc):
                 k.free()
         assert bn.groth16_prove_finish(k, recs, r=r, s=s) == want
     finally:
-        for name in ("STAGE_FORCE_RING", "STAGE_RING_KB", "STAGE_CHUNK_KB", "STAGE_WORKERS", "PROVE_CHUNKED_UPLOAD"):
+        for name in ("STAGE_FORCE_RING", "STAGE_RING_KB", "STAGE_CHUNK_KB", "STAGE_WORKERS"):
             tune(name, None)
 
 
-def test_reduction_tail_geometries_and_paired_g2(orc):
-    """Round 4: the reduction tail's geometry is chosen by size (chunks of 4 / 8 buckets, pieces of 2^11 / 2^15 buckets whose rows
-    are folded on the GPU by msm_rows) and the G2 tail runs with the extension's components on lane pairs.  None of it may move a
-    bit: stand-alone sums (per-window plans, windows cut into pieces) against the oracle, whole proofs (table plans: ONE bucket set
-    cut into pieces) against the closed form, every combination of chunk size, piece size, host- / GPU-folded rows, paired / plain G2."""
+def test_reduction_tail_geometries(orc):
+    """The reduction tail's geometry is chosen by size (chunks of 4 / 8 buckets, pieces of 2^11 / 2^15 buckets whose rows are folded
+    on the GPU by msm_rows; the G2 tail runs with the extension's components on lane pairs).  None of it may move a bit: stand-alone
+    sums (per-window plans, windows cut into pieces) against the oracle, whole proofs (table plans: ONE bucket set cut into pieces)
+    against the closed form, over chunk and piece sizes."""
     import itertools
     import random
     bn = emul_bn128()
     tune = bn.lib.tune
-    names = ("MSM_CHUNK", "TAIL_BITS", "TAIL_BITS_W", "TAIL_REDUCE", "G2_TAIL_PAIR")
+    names = ("MSM_CHUNK", "TAIL_BITS", "TAIL_BITS_W")
     try:
         rnd = random.Random(5)
         for g, n in ((1, 1500), (2, 400)):
@@ -358,9 +351,9 @@ def test_reduction_tail_geometries_and_paired_g2(orc):
             sc = b"".join((rnd.randrange(orc.R) if i % 7 else i % 3).to_bytes(32, "little") for i in range(n))
             want = orc.g_affine(g, orc.multiexp(g, "multiexp2" if g == 1 else "multiexp", sc, pts, n))
             msm = bn.g1_multiexp if g == 1 else bn.g2_multiexp
-            for chunk, bits_w, pair in ((2, 3, 1), (4, None, 1), (4, 4, 0), (8, 3, 1), (8, None, 0)):
-                tune("MSM_CHUNK", chunk); tune("TAIL_BITS_W", bits_w); tune("G2_TAIL_PAIR", pair)
-                assert msm(sc, pts) == want, (g, chunk, bits_w, pair)
+            for chunk, bits_w in ((2, 3), (4, None), (4, 4), (8, 3), (8, None)):
+                tune("MSM_CHUNK", chunk); tune("TAIL_BITS_W", bits_w)
+                assert msm(sc, pts) == want, (g, chunk, bits_w)
         for name in names:
             tune(name, None)
         circ = synth.NativeCircuit(bn.lib, 10, n_public=3, seed=8, style="columns")
@@ -370,9 +363,9 @@ def test_reduction_tail_geometries_and_paired_g2(orc):
         want = circ.expected_proof(r, s)
         key = bn.load_key(sections=sec)
         assert key.table["rows_w"] > 1                      # table plans: one bucket set of 2^(c-1) buckets per sum
-        for chunk, bits, red, pair in ((2, 4, 1, 1), (4, None, 1, 1), (4, 6, 0, 1), (8, 4, 1, 0), (8, 6, 0, 0), (8, None, 1, 1)):
-            tune("MSM_CHUNK", chunk); tune("TAIL_BITS", bits); tune("TAIL_REDUCE", red); tune("G2_TAIL_PAIR", pair)
-            assert bn.groth16GenProof(wit, key, r=r, s=s) == want, (chunk, bits, red, pair)
+        for chunk, bits in ((2, 4), (4, None), (4, 6), (8, 4), (8, 6), (8, None)):
+            tune("MSM_CHUNK", chunk); tune("TAIL_BITS", bits)
+            assert bn.groth16GenProof(wit, key, r=r, s=s) == want, (chunk, bits)
     finally:
         for name in names:
             tune(name, None)

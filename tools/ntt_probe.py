@@ -22,4 +22,4 @@ for bits in (22, 20):
             bn.fft_dev(dx.data_ptr(), m, odd, inverse=inv)
         bn.lib.c.wsnark_timing_enable(0)
         k = {a: round(v[0] / v[1], 4) for a, v in bn.lib.timing_report().items()}
-        print("2^%d %-5s %.4f ms/transform  kernels %s  tile_log=%s" % (bits, name, t * 1e3, k, os.environ.get("WSNARK_NTT_TILE_LOG", "10")), flush=True)
+        print("2^%d %-5s %.4f ms/transform  kernels %s" % (bits, name, t * 1e3, k), flush=True)

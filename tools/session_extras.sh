@@ -4,8 +4,5 @@ mkdir -p $O
 timeout 400 python tools/node_bench.py 20 20 > $O/node_bench.json 2> $O/node_bench.err
 timeout 400 python tools/shard_probe.py 20 8 > $O/shard_probe_2p20.json 2> $O/shard_probe.err
 timeout 300 python tools/dist_probe.py 20 > $O/dist_probe.json 2> $O/dist_probe.err
-WSNARK_TABLE_STEPPED=0 timeout 300 python bench.py --no-extras --no-cpu-baseline --steps 10 > $O/bench_one_kernel_table_build.json 2>/dev/null
-timeout 300 python tools/tail_sweep.py > $O/tail_sweep.txt 2>&1
-timeout 300 python tools/pinned_sweep.py > $O/pinned_sweep.txt 2>&1
 timeout 600 python bench.py --prove-log-domain 22 --no-extras --no-cpu-baseline --steps 10 > $O/bench_2p22.json 2> $O/bench_2p22.err
 timeout 900 python bench.py --prove-log-domain 24 --no-extras --no-cpu-baseline --steps 5 --warmup 2 > $O/bench_2p24.json 2> $O/bench_2p24.err

@@ -130,6 +130,111 @@ class ProvingKey:
             pass
 
 
+def _key_sections(sections):
+    """dict of byte strings -> (the C struct wsnark_key_sections_t, the buffers it points into)"""
+    ks = _KeySections(sections["n_vars"], sections["n_public"], sections["domain"])
+    keep = []
+    for name in ("alfa1", "beta1", "delta1", "beta2", "delta2", "polsA", "polsB", "pointsA", "pointsB1",
+                 "pointsB2", "pointsC", "pointsH"):
+        b, n = _ro(sections[name])
+        keep.append(b)
+        setattr(ks, name, C.cast(b, C.c_void_p))
+        if name.startswith(("pols", "points")):
+            setattr(ks, name + "_len", n)
+    return ks, keep
+
+
+class GroupKey:
+    """One points shard of a proving key per device of a Group (wsnark_group_pkey_load[_sections])."""
+
+    def __init__(self, group, data=None, sections=None, wait_tables=True):
+        self._group, self._lib = group, group._lib
+        lib = self._lib
+        self._h = C.c_void_p()
+        if sections is not None:
+            ks, keep = _key_sections(sections)
+            lib.check(lib.c.wsnark_group_pkey_load_sections(group._h, C.byref(ks), C.byref(self._h)))
+        else:
+            b, n = _ro(data)
+            lib.check(lib.c.wsnark_group_pkey_load(group._h, b, n, C.byref(self._h)))
+        nv, npub, dom, world, dist = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_int()
+        lib.check(lib.c.wsnark_group_pkey_info(self._h, C.byref(nv), C.byref(npub), C.byref(dom), C.byref(world), C.byref(dist)))
+        self.n_vars, self.n_public, self.domain, self.world = nv.value, npub.value, dom.value, world.value
+        self.distributed_calc_h = bool(dist.value)      # CALC_H on the four-step transform (else complete on every device)
+        if wait_tables:
+            lib.check(lib.c.wsnark_group_pkey_wait_tables(self._h))
+
+    def free(self):
+        if self._h:
+            self._lib.c.wsnark_group_pkey_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Group:
+    """Several GPUs in ONE process (wsnark_group_*, csrc/group.hip): the reference's worker pool (src/bn128.js:173-265, 353-415) with
+    GPUs as the workers and the transport inside the library.  devices: HIP ordinals (an ordinal may repeat: two contexts on one GPU)."""
+
+    def __init__(self, lib=None, devices=(0,)):
+        self._lib = lib or _lib.load()
+        self.devices = [int(d) for d in devices]
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        self._h = C.c_void_p()
+        self._lib.check(self._lib.c.wsnark_group_create(arr, len(self.devices), C.byref(self._h)))
+
+    def load_key(self, pkey=None, sections=None, wait_tables=True):
+        return GroupKey(self, data=pkey, sections=sections, wait_tables=wait_tables)
+
+    def groth16GenProof(self, signals, key, r=None, s=None):
+        """src/bn128.js:580-720 over the group: `signals` the witness bytes (host memory), `key` a GroupKey (or the key's bytes)."""
+        own = None
+        if not isinstance(key, GroupKey):
+            own = key = self.load_key(key)
+        try:
+            b, n = _ro(signals)
+            out = (C.c_uint8 * 384)()
+            rb = _ro(r)[0] if r is not None else None
+            sb = _ro(s)[0] if s is not None else None
+            self._lib.check(self._lib.c.wsnark_group_prove(key._h, b, n, rb, sb, out))
+            return proof_from_bytes(bytes(out))
+        finally:
+            if own is not None:
+                own.free()
+
+    def _multiexp(self, g, scalars, points):
+        sb, sn = _ro(scalars)
+        pb, pn = _ro(points)
+        n = sn // 32
+        if pn != n * (128 if g else 64):
+            raise ValueError("points length does not match scalars")
+        out = (C.c_uint8 * (192 if g else 96))()
+        fn = self._lib.c.wsnark_group_g2_msm if g else self._lib.c.wsnark_group_g1_msm
+        self._lib.check(fn(self._h, sb, pb, n, out))
+        return bytes(out)
+
+    def g1_multiexp(self, scalars, points):      # src/bn128.js:353-383
+        return self._multiexp(0, scalars, points)
+
+    def g2_multiexp(self, scalars, points):      # src/bn128.js:385-415
+        return self._multiexp(1, scalars, points)
+
+    def terminate(self):                         # src/bn128.js:562-566
+        if self._h:
+            self._lib.c.wsnark_group_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.terminate()
+        except Exception:
+            pass
+
+
 class Bn128:
     """`await buildBn128()` of the reference -> `build()` here (src/bn128.js:173-265)."""
 

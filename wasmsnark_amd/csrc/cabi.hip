@@ -17,19 +17,11 @@ void pkey_info(const ProvingKey* K, uint32_t* nv, uint32_t* np, uint32_t* dom);
 void pkey_table_info(const ProvingKey* K, uint32_t* cw, uint32_t* rw, uint32_t* ch, uint32_t* rh, uint64_t* bytes);
 int groth16_prove_host_witness(ProvingKey* K, const uint8_t* witness, size_t witness_len, const uint8_t* r32,
                                const uint8_t* s32, uint8_t* out384);
-struct KeySections {
-    uint32_t n_vars, n_public, domain;
-    const uint8_t *alfa1, *beta1, *delta1, *beta2, *delta2;
-    const uint8_t* polsA; uint64_t lenA;
-    const uint8_t* polsB; uint64_t lenB;
-    const uint8_t *A, *B1, *B2, *Cpts, *H;
-    uint64_t lenPA, lenPB1, lenPB2, lenPC, lenPH;
-};
-struct KeyShard { uint32_t rank = 0, world = 1, h_log_m = 0; };
 int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard);
 void pkey_shard_info(const ProvingKey* K, uint32_t* rank, uint32_t* world, uint64_t* lo, uint64_t* n_local, uint64_t* h_local, uint32_t* h_log_m);
 void pkey_load_stats(const ProvingKey* K, double* out5);
 int pkey_wait_tables(ProvingKey* K);
+Context* pkey_context(const ProvingKey* K);
 int groth16_prove_dist(ProvingKey* K, const Fe* d_witness, size_t witness_len, const DistComm& cm, const uint8_t* r32, const uint8_t* s32,
                        uint8_t* out384, hipStream_t s);
 int pkey_h_msm_dev(ProvingKey* K, const Fe* d_h_local, uint64_t n, uint8_t* out96, hipStream_t s);
@@ -65,6 +57,12 @@ static_assert(sizeof(XYZZ<Fq>) == 128 && sizeof(XYZZ<Fq2>) == 256, "xyzz layouts
     Context* C = ctx();                                                      \
     if (!C) { set_last_error("wsnark_init() has not been called"); return WSNARK_ERR_NOINIT; } \
     WS_HIP_CHECK(hipSetDevice(C->device))
+// entry points that take a key handle run on the context (device) the key is resident on, whichever thread calls
+#define REQUIRE_KEY_CTX(h)                                                   \
+    if (!(h)) return WSNARK_ERR_ARG;                                         \
+    Context* C = pkey_context(reinterpret_cast<const ProvingKey*>(h));       \
+    if (!C) { set_last_error("wsnark_init() has not been called"); return WSNARK_ERR_NOINIT; } \
+    CtxScope _key_scope(C)
 static bool shard_ok(uint32_t rank, uint32_t world) { return world != 0 && rank < world; }
 
 template <class JacT, class Fn>
@@ -221,7 +219,7 @@ int wsnark_pkey_load(const void* pkey, size_t len, wsnark_pkey_t** out_handle) {
 }
 void wsnark_pkey_free(wsnark_pkey_t* h) {
     if (!h) return;
-    if (Context* C = ctx()) (void)hipSetDevice(C->device);
+    CtxScope scope(pkey_context(reinterpret_cast<const ProvingKey*>(h)));
     pkey_free(reinterpret_cast<ProvingKey*>(h));
 }
 int wsnark_pkey_info(const wsnark_pkey_t* h, uint32_t* nv, uint32_t* np, uint32_t* dom) {
@@ -236,14 +234,14 @@ int wsnark_pkey_table_info(const wsnark_pkey_t* h, uint32_t* cw, uint32_t* rw, u
 }
 int wsnark_groth16_prove(wsnark_pkey_t* h, const void* witness, size_t witness_len, const void* r32, const void* s32,
                          void* out384) {
-    REQUIRE_CTX();
+    REQUIRE_KEY_CTX(h);
     if (!h || !witness || !out384) return WSNARK_ERR_ARG;
     return groth16_prove_host_witness(reinterpret_cast<ProvingKey*>(h), (const uint8_t*)witness, witness_len,
                                       (const uint8_t*)r32, (const uint8_t*)s32, (uint8_t*)out384);
 }
 int wsnark_groth16_prove_dev(wsnark_pkey_t* h, const void* d_witness, size_t witness_len, const void* r32,
                              const void* s32, void* out384_host, void* stream) {
-    REQUIRE_CTX();
+    REQUIRE_KEY_CTX(h);
     if (!h || !d_witness || !out384_host) return WSNARK_ERR_ARG;
     return groth16_prove_dev_witness(reinterpret_cast<ProvingKey*>(h), (const Fe*)d_witness, witness_len,
                                      (const uint8_t*)r32, (const uint8_t*)s32, (uint8_t*)out384_host, (hipStream_t)stream);
@@ -288,32 +286,32 @@ int wsnark_pkey_load_stats(const wsnark_pkey_t* h, double* ms5) {
     return WSNARK_OK;
 }
 int wsnark_pkey_wait_tables(wsnark_pkey_t* h) {
-    REQUIRE_CTX();
+    REQUIRE_KEY_CTX(h);
     if (!h) return WSNARK_ERR_ARG;
     return pkey_wait_tables(reinterpret_cast<ProvingKey*>(h));
 }
 int wsnark_pkey_h_msm_dev(wsnark_pkey_t* h, const void* d_h_slice, uint64_t n, void* out96_host, void* stream) {
-    REQUIRE_CTX();
+    REQUIRE_KEY_CTX(h);
     if (!h || !out96_host || (n && !d_h_slice)) return WSNARK_ERR_ARG;
     return pkey_h_msm_dev(reinterpret_cast<ProvingKey*>(h), (const Fe*)d_h_slice, n, (uint8_t*)out96_host, (hipStream_t)stream);
 }
 int wsnark_groth16_prove_partial(wsnark_pkey_t* h, const void* witness, size_t witness_len, uint32_t rank, uint32_t world,
                                  uint32_t flags, void* out576) {
-    REQUIRE_CTX();
+    REQUIRE_KEY_CTX(h);
     if (!h || !witness || !out576 || !shard_ok(rank, world) || (flags & ~(uint32_t)WSNARK_PARTIAL_SKIP_H)) return WSNARK_ERR_ARG;
     return groth16_prove_partial(reinterpret_cast<ProvingKey*>(h), (const uint8_t*)witness, witness_len, WindowShard{rank, world},
                                  (uint8_t*)out576, (flags & WSNARK_PARTIAL_SKIP_H) != 0);
 }
 int wsnark_groth16_prove_partial_dev(wsnark_pkey_t* h, const void* d_witness, size_t witness_len, uint32_t rank, uint32_t world,
                                      uint32_t flags, void* out576_host, void* stream) {
-    REQUIRE_CTX();
+    REQUIRE_KEY_CTX(h);
     if (!h || !d_witness || !out576_host || !shard_ok(rank, world) || (flags & ~(uint32_t)WSNARK_PARTIAL_SKIP_H)) return WSNARK_ERR_ARG;
     return groth16_prove_partial_dev(reinterpret_cast<ProvingKey*>(h), (const Fe*)d_witness, witness_len, WindowShard{rank, world},
                                      (uint8_t*)out576_host, (hipStream_t)stream, (flags & WSNARK_PARTIAL_SKIP_H) != 0);
 }
 int wsnark_groth16_prove_dist(wsnark_pkey_t* h, const void* d_witness, size_t witness_len, const wsnark_comm_t* comm, const void* r32,
                               const void* s32, void* out384_host, void* stream) {
-    REQUIRE_CTX();
+    REQUIRE_KEY_CTX(h);
     if (!h || !d_witness || !comm || !out384_host) return WSNARK_ERR_ARG;
     DistComm cm;
     cm.rank = comm->rank; cm.world = comm->world;
@@ -323,7 +321,7 @@ int wsnark_groth16_prove_dist(wsnark_pkey_t* h, const void* d_witness, size_t wi
                               (uint8_t*)out384_host, (hipStream_t)stream);
 }
 int wsnark_pkey_eval_ab_dev(wsnark_pkey_t* h, const void* d_witness, size_t witness_len, void* d_a_out, void* d_b_out, void* stream) {
-    REQUIRE_CTX();
+    REQUIRE_KEY_CTX(h);
     if (!h || !d_witness || !d_a_out || !d_b_out) return WSNARK_ERR_ARG;
     return pkey_eval_ab_dev(reinterpret_cast<ProvingKey*>(h), (const Fe*)d_witness, witness_len, (Fe*)d_a_out, (Fe*)d_b_out, (hipStream_t)stream);
 }

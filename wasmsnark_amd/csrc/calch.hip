@@ -47,23 +47,6 @@ __global__ __launch_bounds__(256) void fr_mul_kernel(const Fe* __restrict__ a, c
     out[i] = Fr::mul(a[i], b[i]);
 }
 
-// h[t] = fromMontgomery( (e[t] - w_2n^-t * o[t]) / 2 ),  w_2n^-t = -w_2n^(n-t) for t >= 1
-__global__ __launch_bounds__(256) void calch_combine_kernel(const Fe* __restrict__ e, const Fe* __restrict__ o,
-                                                              const Fe* __restrict__ cs_lo, const Fe* __restrict__ cs_hi,
-                                                              uint32_t hc, uint32_t n, Fe half, Fe* __restrict__ h) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    Fe ot = o[t], v;
-    if (t == 0) {
-        v = Fr::sub(e[0], ot);
-    } else {
-        const uint32_t x = n - t;
-        Fe f = Fr::mul(cs_hi[x >> hc], cs_lo[x & ((1u << hc) - 1)]);
-        v = Fr::add(e[t], Fr::mul(f, ot));
-    }
-    h[t] = Fr::from_mont(Fr::mul(v, half));
-}
-
 // ---- pieces of the distributed (four-step) transform: n = n1 * n2, element (r, c) of a rank's rows x cols block sits at
 // global position t = (row0 + r) + n1 * c of the length-n vector (wasmsnark_amd/dist.py: dist_ntt) ----
 //   mode 0: *= w_n^((row0 + r) * c)   the twiddle between the column step and the row step (inverse: w_n^-1)
@@ -103,7 +86,7 @@ int dist_scale_dev(Fe* d_data, uint64_t stack, uint64_t rows, uint64_t cols, uin
 }
 
 // the last step of CALC_H on a rank's block of the interleaved layout: h[t] = fromMontgomery((e[t] - w_2n^-t o[t]) / 2),
-// t = (row0 + r) + n1 * c   (same formula as calch_combine_kernel, which is the single-GPU case rows = 1... n)
+// t = (row0 + r) + n1 * c   (the formula of the single-GPU epilogue, ntt.hip: CombineEpilogue)
 __global__ __launch_bounds__(256) void dist_combine_kernel(const Fe* __restrict__ e, const Fe* __restrict__ o, Fe* __restrict__ h,
                                                              uint64_t rows, uint64_t cols, uint64_t row0, uint32_t log_n1, uint32_t log_n,
                                                              const Fe* __restrict__ cs_lo, const Fe* __restrict__ cs_hi, uint32_t hc, Fe half) {
@@ -264,7 +247,7 @@ struct SlabPiece {      // a part of one device allocation, with DevBuf's access
 
 int pols_to_csr(const uint8_t* pols, size_t len, uint32_t n_signals, uint32_t domain, CsrMatrix* out,
                 size_t* consumed, hipStream_t s) {
-    const bool trace = getenv("WSNARK_TRACE") && atoi(getenv("WSNARK_TRACE")) == 1;
+    const bool trace = tuning_get("TRACE", 0) == 1;
     const auto t_in = std::chrono::steady_clock::now();
     auto at = [&](const char* what) {
         if (trace) fprintf(stderr, "[wsnark trace] pols_to_csr (%u signals): %s at %.2f ms\n", n_signals, what,
@@ -364,15 +347,10 @@ int calc_h_dev(Lane& L, const Fe* d_signals_plain, uint32_t n_signals, const Csr
     hipLaunchKernelGGL(lc_spmv_kernel, grd, blk, 0, s, A.row_ptr.as<uint32_t>(), A.col.as<uint32_t>(), A.coef.as<Fe>(), d_signals_plain, domain, a);
     hipLaunchKernelGGL(lc_spmv_kernel, grd, blk, 0, s, B.row_ptr.as<uint32_t>(), B.col.as<uint32_t>(), B.coef.as<Fe>(), d_signals_plain, domain, b);
     T.end(s);
-    // The pointwise products and the final combination are fused into the transforms next to them (WSNARK_CALCH_FUSE=0:
-    // separate kernels, for A/B runs): E = A.B is formed by the FIRST pass of its inverse transform while it loads,
+    // The pointwise products and the final combination are fused into the transforms next to them: E = A.B is formed by the FIRST pass of its inverse transform while it loads,
     // O = A.B on the coset likewise, and the last pass of that second transform stores h directly.  Saves three
     // element-wise kernels (4 x 32 B x domain of traffic each) and their slow saturated-field products.
-    static const bool fuse = [] { const char* e = getenv("WSNARK_CALCH_FUSE"); return !(e && atoi(e) == 0); }();
-    const Fe *cs_lo, *cs_hi;
-    int hc;
-    Fe n_inv;
-    if (fuse) {
+    {
         if ((rc = ntt_run(L, a, b, e, nullptr, domain, 0, 1, s))) return rc;   // e = iNTT(A.B)            (bn128.js:148, 160)
         if ((rc = ntt_dev(L, a, domain, 0, 1, s))) return rc;                  // bn128.js:150-151  evaluations -> coefficients
         if ((rc = ntt_dev(L, b, domain, 0, 1, s))) return rc;
@@ -380,26 +358,6 @@ int calc_h_dev(Lane& L, const Fe* d_signals_plain, uint32_t n_signals, const Csr
         if ((rc = ntt_dev(L, b, domain, 1, 0, s))) return rc;
         return ntt_run(L, a, b, d_h_out, e, domain, 0, 1, s);                  // o = iNTT(A.B on the coset), h = combine(e, o)   (:158-164)
     }
-    T.begin("fr_pointwise", s);
-    hipLaunchKernelGGL(fr_mul_kernel, grd, blk, 0, s, a, b, e, (uint64_t)domain);   // E = A.B on the domain
-    T.end(s);
-    WS_HIP_CHECK(hipGetLastError());
-    if ((rc = ntt_dev(L, a, domain, 0, 1, s))) return rc;               // bn128.js:150-151  evaluations -> coefficients
-    if ((rc = ntt_dev(L, b, domain, 0, 1, s))) return rc;
-    if ((rc = ntt_dev(L, a, domain, 1, 0, s))) return rc;               // bn128.js:152-153  -> odd-coset evaluations
-    if ((rc = ntt_dev(L, b, domain, 1, 0, s))) return rc;
-    T.begin("fr_pointwise", s);
-    hipLaunchKernelGGL(fr_mul_kernel, grd, blk, 0, s, a, b, a, (uint64_t)domain);   // O = A.B on the coset (bn128.js:158)
-    T.end(s);
-    if ((rc = ntt_dev(L, e, domain, 0, 1, s))) return rc;               // bn128.js:160, split in two halves
-    if ((rc = ntt_dev(L, a, domain, 0, 1, s))) return rc;
-    if ((rc = ntt_coset_tables(bits, &cs_lo, &cs_hi, &hc, &n_inv, s))) return rc;
-    Fe half = Fr::inv(Fr::add(Fr::one(), Fr::one()));
-    T.begin("calch_combine", s);                                     // bn128.js:162-164 (+ the upper-half selection)
-    hipLaunchKernelGGL(calch_combine_kernel, grd, blk, 0, s, e, a, cs_lo, cs_hi, (uint32_t)hc, domain, half, d_h_out);
-    T.end(s);
-    WS_HIP_CHECK(hipGetLastError());
-    return WS_OK;
 }
 
 WS_DEFINE_WARM(calch)

@@ -22,23 +22,32 @@ static thread_local std::string t_last_error;
 void set_last_error(const std::string& s) { t_last_error = s; }
 const std::string& get_last_error() { return t_last_error; }
 
-static Context* g_ctx = nullptr;
+static Context* g_ctx = nullptr;                  // the default context (wsnark_init)
 static std::mutex g_ctx_mu;
 static std::string g_devinfo;
+static thread_local Context* t_ctx = nullptr;      // the calling thread's selection (CtxScope); nullptr = the default context
 
-Context* ctx() { return g_ctx; }
+Context* ctx() { return t_ctx ? t_ctx : g_ctx; }
+Context* ctx_set_current(Context* c) { Context* p = t_ctx; t_ctx = c; return p; }
 
+// Switches: an override set through wsnark_tuning_set wins; otherwise the environment variable WSNARK_<name> AS IT WAS WHEN THE
+// NAME WAS FIRST ASKED FOR (one getenv per name and process, under the mutex: prover threads never read the environment while a
+// host -- Python's os.environ[...] = ..., Node's process.env -- may be writing it, which is undefined behaviour in glibc);
+// otherwise the default.  A process that wants to change a switch after its first use calls wsnark_tuning_set.
 static std::mutex g_tune_mu;
-static std::map<std::string, long> g_tune;
+static std::map<std::string, long> g_tune;                       // overrides
+static std::map<std::string, std::pair<bool, long>> g_env;       // name -> (set in the environment, value), filled on first use
 long tuning_get(const char* name, long dflt) {
-    {
-        std::lock_guard<std::mutex> lk(g_tune_mu);
-        auto it = g_tune.find(name);
-        if (it != g_tune.end()) return it->second;
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    auto it = g_tune.find(name);
+    if (it != g_tune.end()) return it->second;
+    auto ie = g_env.find(name);
+    if (ie == g_env.end()) {
+        const std::string env = std::string("WSNARK_") + name;
+        const char* e = getenv(env.c_str());
+        ie = g_env.emplace(name, std::make_pair(e != nullptr, e ? atol(e) : 0L)).first;
     }
-    const std::string env = std::string("WSNARK_") + name;
-    const char* e = getenv(env.c_str());
-    return e ? atol(e) : dflt;
+    return ie->second.first ? ie->second.second : dflt;
 }
 void tuning_set(const char* name, long value) {
     std::lock_guard<std::mutex> lk(g_tune_mu);
@@ -46,10 +55,9 @@ void tuning_set(const char* name, long value) {
     else g_tune[name] = value;
 }
 
-int context_warm_staging();
-int context_init(int device) {
-    std::lock_guard<std::mutex> lk(g_ctx_mu);
-    if (g_ctx) return WS_OK;
+static int ensure_ring(Context* C);
+// One context on one device: its queues, lanes and helper threads.  device < 0: LOCAL_RANK, else 0.
+int context_create(int device, Context** out) {
     if (device < 0) {
         const char* lr = getenv("LOCAL_RANK");
         device = lr ? atoi(lr) : 0;
@@ -59,101 +67,96 @@ int context_init(int device) {
     if (count <= 0) { set_last_error("no HIP device visible"); return WS_ERR_HIP; }
     if (device >= count) device = device % count;
     WS_HIP_CHECK(hipSetDevice(device));
-    Context* C = new Context();
+    std::unique_ptr<Context> C(new Context());
     C->device = device;
+    C->owner_pid = (int)getpid();
     hipDeviceProp_t prop;
     WS_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     C->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     g_devinfo = std::string(prop.name) + " " + prop.gcnArchName + " CUs=" + std::to_string(C->num_cu);
     WS_HIP_CHECK(hipStreamCreateWithFlags(&C->stream, hipStreamNonBlocking));
     {
-        const char* e = getenv("WSNARK_LANES");
-        int nl = e ? atoi(e) : 2;
-        C->n_lanes = nl < 1 ? 1 : nl > kMaxLanes ? kMaxLanes : nl;
+        const long nl = tuning_get("LANES", 2);
+        C->n_lanes = nl < 1 ? 1 : nl > kMaxLanes ? kMaxLanes : (int)nl;
     }
-    // WSNARK_S2_PRIO=1 gives every lane's second queue the device's highest priority (round 1's default).  Since the prover
-    // finishes whichever sum is ready first, plain queues released at once are the best schedule on dense and sparse
-    // keys alike (profiles/r02_sweep_prove_overlap.txt: 11.26 ms against 11.30-11.68 ms for the other three combinations)
-    const char* pe = getenv("WSNARK_S2_PRIO");
-    int lo = 0, hi = 0;
-    const bool prio = (pe && atoi(pe) == 1) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo;
+    // Plain queues (one priority): high-priority second / third queues were measured in rounds 2 and 5 (profiles/r02_sweep_prove_overlap.txt,
+    // r05_schedule_experiments.txt) and change nothing -- a kernel's workgroups get SIMD slots as the other queue's workgroups retire,
+    // whatever the queue's priority.
     for (int i = 0; i < C->n_lanes; i++) {
         Lane& L = C->lanes[i];
         L.id = i;
         WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
-        if (prio && hipStreamCreateWithPriority(&L.stream2, hipStreamNonBlocking, hi) != hipSuccess) L.stream2 = nullptr;
-        if (!L.stream2) WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream2, hipStreamNonBlocking));   // (no priorities here)
-        // WSNARK_S3_PRIO=1: the third queue (reduction tails of a full-size proof, prove.hip order 4 / 5) at the highest priority
-        const char* p3 = getenv("WSNARK_S3_PRIO");
-        if (p3 && atoi(p3) == 1 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo &&
-            hipStreamCreateWithPriority(&L.stream3, hipStreamNonBlocking, hi) != hipSuccess) { (void)hipGetLastError(); L.stream3 = nullptr; }
-        if (!L.stream3) WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream3, hipStreamNonBlocking));
+        WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream2, hipStreamNonBlocking));
+        WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream3, hipStreamNonBlocking));
         WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream_copy, hipStreamNonBlocking));
-        WS_HIP_CHECK(hipStreamCreateWithFlags(&L.stream_copy2, hipStreamNonBlocking));
     }
     for (auto& q : C->load_q) WS_HIP_CHECK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
     // (the LOWEST stream priority: the runtime multiplexes a process's streams onto a few hardware queues per priority class, and a
     //  proof whose queue shared one with a normal-priority build would sit behind 130 ms of table kernels -- seen through the Node
     //  addon: first proof 133 ms instead of 13; at the lowest priority the builds have a queue of their own and yield to proofs.
     //  Created HERE, once: no queue is ever created while proofs may be in flight on other threads)
+    int lo = 0, hi = 0;
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&C->build_q, hipStreamNonBlocking, lo) != hipSuccess) {
         (void)hipGetLastError();
         C->build_q = nullptr;
         WS_HIP_CHECK(hipStreamCreateWithFlags(&C->build_q, hipStreamNonBlocking));
     }
-    g_ctx = C;
 #ifndef WSNARK_EMUL
-    // Two helper threads do what the first key load and proof of a process would otherwise wait for: one pins the staging ring
+    // Two helper threads do what the first key load and proof on this context would otherwise wait for: one pins the staging ring
     // (8-26 ms), the other launches one no-op kernel per translation unit, which makes the runtime load that unit's code object
-    // (7-12 ms for msm.hip alone under ROCm 7.2).  wsnark_init returns at once; whoever needs the ring or a kernel first finds the
-    // work done or in progress (the ring is created under its mutex, module loads are serialised by the runtime) -- a key load that
-    // follows immediately waits for the ring, and the code objects load while its sections go up.  WSNARK_INIT_WARM=0: on first use.
+    // (7-12 ms for msm.hip alone under ROCm 7.2).  The call returns at once; whoever needs the ring or a kernel first finds the
+    // work done or in progress (the ring is created under its mutex, module loads are serialised by the runtime).
+    // WSNARK_INIT_WARM=0: on first use.
     if (tuning_get("INIT_WARM", 1)) {
-        const int device = C->device;
-        if (tuning_get("STAGE_EAGER", 1))
-            C->warm_ring = std::thread([device]() {
-                if (hipSetDevice(device) != hipSuccess) return;
-                if (context_warm_staging() != WS_OK) (void)hipGetLastError();      // (not fatal: the first upload will say)
-            });
+        Context* P = C.get();
+        C->warm_ring = new std::thread([P]() {
+            if (hipSetDevice(P->device) != hipSuccess) return;
+            std::lock_guard<std::mutex> lk(P->ring_mu);
+            if (ensure_ring(P) != WS_OK) (void)hipGetLastError();      // (not fatal: the first upload will say)
+        });
         hipStream_t q = C->stream;      // (the utility queue: the launch itself is what loads the code object -- nothing to wait for)
-        C->warm = std::thread([device, q]() {
-            if (hipSetDevice(device) != hipSuccess) return;
+        const int dev = device;
+        C->warm = new std::thread([dev, q]() {
+            if (hipSetDevice(dev) != hipSuccess) return;
             warm_msm(q); warm_calch(q); warm_ntt(q); warm_fixedbase(q); warm_dist(q);
         });
     }
 #endif
+    *out = C.release();
     return WS_OK;
 }
 void context_join_warm(Context* C) {
     std::lock_guard<std::mutex> lk(C->warm_mu);
-    if (C->warm.joinable()) C->warm.join();
-    if (C->warm_ring.joinable()) C->warm_ring.join();
+    for (std::thread** t : {&C->warm, &C->warm_ring}) {
+        if (!*t) continue;
+        // (a fork()ed child inherits the objects but none of the threads: joining would never return -- they are left behind)
+        if (C->owner_pid == (int)getpid()) { if ((*t)->joinable()) (*t)->join(); delete *t; }
+        *t = nullptr;
+    }
 }
 
-void context_shutdown() {
-    std::lock_guard<std::mutex> lk(g_ctx_mu);
-    if (!g_ctx) return;
-    context_join_warm(g_ctx);
-    (void)hipSetDevice(g_ctx->device);
-    (void)hipStreamSynchronize(g_ctx->stream);
-    for (auto& q : g_ctx->load_q) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); q = nullptr; }
-    if (g_ctx->build_q) { (void)hipStreamSynchronize(g_ctx->build_q); (void)hipStreamDestroy(g_ctx->build_q); g_ctx->build_q = nullptr; }
-    g_ctx->build_tmp.release();
-    for (int i = 0; i < g_ctx->n_lanes; i++) {
-        (void)hipStreamSynchronize(g_ctx->lanes[i].stream);
-        (void)hipStreamSynchronize(g_ctx->lanes[i].stream2);
-        (void)hipStreamSynchronize(g_ctx->lanes[i].stream3);
-        (void)hipStreamSynchronize(g_ctx->lanes[i].stream_copy);
-        (void)hipStreamSynchronize(g_ctx->lanes[i].stream_copy2);
+void context_destroy(Context* C) {
+    if (!C) return;
+    context_join_warm(C);
+    (void)hipSetDevice(C->device);
+    (void)hipStreamSynchronize(C->stream);
+    for (auto& q : C->load_q) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); q = nullptr; }
+    if (C->build_q) { (void)hipStreamSynchronize(C->build_q); (void)hipStreamDestroy(C->build_q); C->build_q = nullptr; }
+    C->build_tmp.release();
+    for (int i = 0; i < C->n_lanes; i++) {
+        (void)hipStreamSynchronize(C->lanes[i].stream);
+        (void)hipStreamSynchronize(C->lanes[i].stream2);
+        (void)hipStreamSynchronize(C->lanes[i].stream3);
+        (void)hipStreamSynchronize(C->lanes[i].stream_copy);
     }
-    g_ctx->timer.reset();
-    for (hipEvent_t e : g_ctx->timer.pool) (void)hipEventDestroy(e);
-    g_ctx->timer.pool.clear();
-    g_ctx->ntt_plans.clear();
-    if (g_ctx->pin_ring) { (void)hipHostFree(g_ctx->pin_ring); g_ctx->pin_ring = nullptr; }
-    for (auto& e : g_ctx->pin_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-    for (int i = 0; i < g_ctx->n_lanes; i++) {
-        Lane& L = g_ctx->lanes[i];
+    C->timer.reset();
+    for (hipEvent_t e : C->timer.pool) (void)hipEventDestroy(e);
+    C->timer.pool.clear();
+    C->ntt_plans.clear();
+    if (C->pin_ring) { (void)hipHostFree(C->pin_ring); C->pin_ring = nullptr; }
+    for (auto& e : C->pin_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    for (int i = 0; i < C->n_lanes; i++) {
+        Lane& L = C->lanes[i];
         msm_workspace_free(L);
         for (hipEvent_t* e : {&L.ntt_chain.done, &L.calch_chain.done, &L.ev_start, &L.ev_tail, &L.ev_h, &L.ev_plan, &L.ev_g2, &L.ev_chunk[0], &L.ev_chunk[1]})
             if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
@@ -166,11 +169,26 @@ void context_shutdown() {
         (void)hipStreamDestroy(L.stream2);
         (void)hipStreamDestroy(L.stream3);
         (void)hipStreamDestroy(L.stream_copy);
-        (void)hipStreamDestroy(L.stream_copy2);
     }
-    (void)hipStreamDestroy(g_ctx->stream);
-    delete g_ctx;
+    (void)hipStreamDestroy(C->stream);
+    delete C;
+}
+
+int context_init(int device) {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    if (g_ctx) return WS_OK;
+    Context* C = nullptr;
+    int rc = context_create(device, &C);
+    if (rc) return rc;
+    g_ctx = C;
+    return WS_OK;
+}
+void context_shutdown() {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    if (!g_ctx) return;
+    Context* C = g_ctx;
     g_ctx = nullptr;
+    context_destroy(C);
 }
 
 const std::string& device_info() { return g_devinfo; }
@@ -206,7 +224,8 @@ LaneLock::~LaneLock() {
 // caller (`on_chunk`, on the orchestrator thread, after its DMA has been queued on `s`), which lets the prover start the first
 // pass over the witness -- the digit histogram of the grouping pass -- while the rest is still on its way, and (d) a source that
 // is ALREADY pinned (hipHostMalloc / hipHostRegister: the N-API addon's external ArrayBuffers) is DMA'd in place.
-// The pool threads never call into the HIP runtime.
+// The pool threads never call into the HIP runtime.  Ring, slot events and pool belong to the CONTEXT (round 5): the devices of a
+// group stage their uploads side by side.
 struct StagePool {
     std::mutex mu;
     std::condition_variable cv_go, cv_done;
@@ -250,15 +269,12 @@ struct StagePool {
         cv_done.wait(lk, [&] { return pending == 0; });
     }
 };
-// One pool per process: after fork() (Python multiprocessing with the "fork" start method, Node child workers) the child
-// inherits the object -- thread handles, possibly a locked mutex -- but none of the threads, so it gets a pool of its own.
-// Never destroyed: the threads are parked on it until the process ends (the library must not be dlclose'd).
-static StagePool* stage_pool() {
-    static std::mutex mu;
-    static StagePool* pool = nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    if (!pool || pool->owner != getpid()) { pool = new StagePool(); pool->owner = getpid(); }
-    return pool;
+// One pool per context and process: after fork() (Python multiprocessing with the "fork" start method, Node child workers) the
+// child inherits the object -- thread handles, possibly a locked mutex -- but none of the threads, so it gets a pool of its own.
+// Never destroyed: the threads are parked on it until the process ends (the library must not be dlclose'd).  Caller holds ring_mu.
+static StagePool* stage_pool(Context* C) {
+    if (!C->pool || C->pool->owner != getpid()) { C->pool = new StagePool(); C->pool->owner = getpid(); }
+    return C->pool;
 }
 
 static const int PIN_MAX_WORKERS = 24, PIN_MAX_SLOTS = 128;
@@ -268,79 +284,67 @@ static inline void cpu_relax() {
 #endif
 }
 
-static std::mutex g_ring_mu;
-// The pinned staging ring (and its slot events): created by wsnark_init on a device build -- pinning 128 MiB takes 8-26 ms, which
-// used to sit inside the first key load of a process -- and on first use otherwise (the emulator's tests size it per test).
-// Caller holds g_ring_mu.
+// The pinned staging ring (and its slot events): created by the context's helper thread on a device build -- pinning 128 MiB takes
+// 8-26 ms, which used to sit inside the first key load of a process -- and on first use otherwise (the emulator's tests size it
+// per test).  Caller holds C->ring_mu.
 static int ensure_ring(Context* C) {
     if (C->pin_ring) return WS_OK;
     size_t ring = (size_t)tuning_get("STAGE_RING_KB", 128 << 10) << 10;        // (read once, when the ring is created)
     ring = ring < ((size_t)1 << 20) ? ((size_t)1 << 20) : ring > ((size_t)1 << 30) ? ((size_t)1 << 30) : ring;
     const auto t_ring = std::chrono::steady_clock::now();
     WS_HIP_CHECK(hipHostMalloc(&C->pin_ring, ring, 0));
-    if (getenv("WSNARK_TRACE") && atoi(getenv("WSNARK_TRACE")) == 1)
+    if (tuning_get("TRACE", 0) == 1)
         fprintf(stderr, "[wsnark trace] staging ring: %zu MiB of pinned host memory in %.2f ms\n", ring >> 20,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ring).count());
     C->pin_ring_bytes = ring;
     for (auto& e : C->pin_ev) WS_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return WS_OK;
 }
-int context_warm_staging() {
-    Context* C = ctx();
-    if (!C) return WS_ERR_NOINIT;
-    std::lock_guard<std::mutex> lk(g_ring_mu);
-    return ensure_ring(C);
-}
 
-int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s, const ChunkFn& on_chunk, hipStream_t s_alt) {
+int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s, const ChunkFn& on_chunk, bool* direct_out) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
     if (!s) s = C->stream;
+    if (direct_out) *direct_out = false;
     if (bytes == 0) return WS_OK;
-    // s_alt (optional): a second copy queue; with WSNARK_STAGE_DUAL=1 the chunks alternate between the two, so that two DMAs are
-    // in flight at once.  OFF by default: measured on the MI355X box (profiles/r04_s3_upload_sweep.txt) one queue already moves a
-    // pinned 32 MiB witness at 53.5 GB/s (0.63 ms) -- the link, not the engine, is the limit (two queues: 53.0 GB/s).
-    if (s_alt == s || !tuning_get("STAGE_DUAL", 0)) s_alt = nullptr;
-    auto q = [&](size_t g) { return (s_alt && (g & 1)) ? s_alt : s; };
     // chunk size: WSNARK_STAGE_CHUNK_KB (default 4 MiB; 64 KiB granules, 64 KiB .. 16 MiB).  Measured on the MI355X box with a
     // 32 MiB witness (profiles/r04_s3_upload_sweep.txt): 4 MiB chunks and 4 copy threads cost the proof +0.95 ms over a resident
     // witness, 16 MiB chunks +1.17, 8 threads +1.06, a pinned source DMA'd in place +0.97 -- of which 0.63 ms is the transfer
-    // itself at the link's 53.5 GB/s; 12 threads (round 4's first default) +1.6 ms.
+    // itself at the link's 53.5 GB/s (one copy queue: two move no more, the link is the limit); 12 threads +1.6 ms.
     size_t chunk = ((size_t)tuning_get("STAGE_CHUNK_KB", 4096) << 10) & ~(size_t)0xFFFF;
     chunk = chunk < ((size_t)64 << 10) ? ((size_t)64 << 10) : chunk > ((size_t)16 << 20) ? ((size_t)16 << 20) : chunk;
     int rc = WS_OK;
     // small copies, and sources that are ALREADY pinned (hipHostMalloc / hipHostRegister), need no staging
-    bool direct = bytes < ((size_t)1 << 20);
+    bool direct = bytes < ((size_t)1 << 20), pinned = false;
 #ifdef WSNARK_EMUL
     direct = !tuning_get("STAGE_FORCE_RING", 0);    // (the emulator's "device" memory is host memory; tests force the ring to run its bookkeeping)
 #else
-    if (!direct && tuning_get("STAGE_DIRECT_PINNED", 1)) {
+    {
         hipPointerAttribute_t at;
-        if (hipPointerGetAttributes(&at, h_src) == hipSuccess) direct = at.type == hipMemoryTypeHost;
+        if (hipPointerGetAttributes(&at, h_src) == hipSuccess) pinned = at.type == hipMemoryTypeHost;
         else (void)hipGetLastError();               // pageable memory is "invalid value" to the runtime: not an error here
+        direct = direct || pinned;
     }
 #endif
     if (direct) {
-        // A pinned source goes up in ONE DMA (WSNARK_STAGE_DIRECT_CHUNK_KB cuts it): measured on the MI355X box with the 32 MiB witness
-        // (profiles/r04_s6_pinned_sweep.txt), proof from the pinned buffer minus proof from a resident witness: one DMA +0.73-0.87 ms,
-        // 4 MiB pieces with the histogram per piece +0.95-0.97 -- every copy command has its own start-up, and the 0.06 ms of histogram
-        // it would hide is less than that.  (A plain copy + synchronise + resident proof costs +0.92: the link's 0.63 ms plus ~0.3 ms
-        // that a proof loses by starting on a GPU whose shader clocks have idled during the transfer.)
+        // A pinned source goes up in ONE DMA: measured on the MI355X box with the 32 MiB witness (profiles/r04_s6_pinned_sweep.txt),
+        // proof from the pinned buffer minus proof from a resident witness: one DMA +0.73-0.87 ms, 4 MiB pieces with the histogram per
+        // piece +0.95-0.97 -- every copy command has its own start-up, and the 0.06 ms of histogram it would hide is less than that.
         chunk = bytes;
-        { const long v = tuning_get("STAGE_DIRECT_CHUNK_KB", 0); if (v >= 64) chunk = ((size_t)v << 10) & ~(size_t)0xFFFF; }
 #ifdef WSNARK_EMUL
         chunk = ((size_t)tuning_get("STAGE_CHUNK_KB", 4096) << 10) & ~(size_t)0xFFFF;       // (tests: the chunked bookkeeping on small inputs)
         if (chunk < ((size_t)64 << 10)) chunk = (size_t)64 << 10;
 #endif
+        if (direct_out) *direct_out = pinned;       // (a small pageable source has been staged by the runtime when hipMemcpyAsync returns)
         const size_t G = (bytes + chunk - 1) / chunk;
         for (size_t g = 0; g < G; g++) {
             const size_t lo = g * chunk, hi = lo + chunk < bytes ? lo + chunk : bytes;
-            WS_HIP_CHECK(hipMemcpyAsync((char*)d_dst + lo, (const char*)h_src + lo, hi - lo, hipMemcpyHostToDevice, q(g)));
-            if (on_chunk && (rc = on_chunk(lo, hi, q(g)))) return rc;
+            WS_HIP_CHECK(hipMemcpyAsync((char*)d_dst + lo, (const char*)h_src + lo, hi - lo, hipMemcpyHostToDevice, s));
+            if (on_chunk && (rc = on_chunk(lo, hi, s))) return rc;
         }
         return WS_OK;
     }
-    std::lock_guard<std::mutex> lk(g_ring_mu);      // one upload at a time uses the ring
+    std::lock_guard<std::mutex> lk(C->ring_mu);     // one upload at a time uses the context's ring
     if ((rc = ensure_ring(C))) return rc;
     if (chunk > C->pin_ring_bytes / 2) chunk = (C->pin_ring_bytes / 2) & ~(size_t)0xFFFF;
     size_t nslots = C->pin_ring_bytes / chunk;
@@ -383,7 +387,7 @@ int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s
             arrived[g].fetch_add(1, std::memory_order_release);
         }
     };
-    StagePool* pool = stage_pool();
+    StagePool* pool = stage_pool(C);
     pool->start(W, worker);
     size_t next = 0;                                // next chunk to release
     // release chunks below `limit`; block = wait for the first one's slot instead of giving up when it is still draining
@@ -414,9 +418,9 @@ int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s
         if (rc) break;
         const size_t lo = g * chunk, hi = lo + chunk < bytes ? lo + chunk : bytes;
         const size_t slot = g % nslots;
-        if (hipMemcpyAsync((char*)d_dst + lo, ring + slot * chunk, hi - lo, hipMemcpyHostToDevice, q(g)) != hipSuccess ||
-            hipEventRecord(C->pin_ev[slot], q(g)) != hipSuccess) { set_last_error("staged upload: DMA failed"); rc = WS_ERR_HIP; break; }
-        if (on_chunk) rc = on_chunk(lo, hi, q(g));
+        if (hipMemcpyAsync((char*)d_dst + lo, ring + slot * chunk, hi - lo, hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipEventRecord(C->pin_ev[slot], s) != hipSuccess) { set_last_error("staged upload: DMA failed"); rc = WS_ERR_HIP; break; }
+        if (on_chunk) rc = on_chunk(lo, hi, s);
     }
     if (rc) stop.store(1);                          // the workers leave at their next chunk boundary
     pool->wait();
@@ -424,7 +428,14 @@ int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s
 }
 
 int upload_staged(void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
-    return upload_pipelined(d_dst, h_src, bytes, s, nullptr, nullptr);
+    bool direct = false;
+    int rc = upload_pipelined(d_dst, h_src, bytes, s, nullptr, &direct);
+    // (a source DMA'd in place is still being read: wait, so that the caller may free or rewrite it -- as after a staged upload)
+    if (!rc && direct) {
+        Context* C = ctx();
+        WS_HIP_CHECK(hipStreamSynchronize(s ? s : C->stream));
+    }
+    return rc;
 }
 
 // ---- KernelTimer ----
@@ -453,7 +464,7 @@ void KernelTimer::begin(const char* name, hipStream_t s) {
 void KernelTimer::end(hipStream_t s) {
     // WSNARK_SYNC_DEBUG=1 (with timing enabled): wait for every bracket and name it on stderr -- a faulting kernel is then the
     // last name printed
-    static const bool sync_debug = [] { const char* e = getenv("WSNARK_SYNC_DEBUG"); return e && atoi(e) == 1; }();
+    static const bool sync_debug = tuning_get("SYNC_DEBUG", 0) == 1;
     if (sync_debug && enabled && t_rec >= 0) {
         const hipError_t e = hipStreamSynchronize(s);
         fprintf(stderr, "[wsnark sync] %s -> %s\n", recs[(size_t)t_rec].name, hipGetErrorString(e));
@@ -466,7 +477,7 @@ void KernelTimer::end(hipStream_t s) {
 void KernelTimer::collect() {
     std::lock_guard<std::mutex> lk(mu);
     // WSNARK_TIMELINE=1: start/end of every bracket relative to the first one (both queues share the device clock)
-    static const bool timeline = [] { const char* e = getenv("WSNARK_TIMELINE"); return e && atoi(e) == 1; }();
+    static const bool timeline = tuning_get("TIMELINE", 0) == 1;
     for (auto& r : recs) {
         float ms = 0.f;
         (void)hipEventSynchronize(r.b);

@@ -83,18 +83,6 @@ struct Curve {
         El Y3 = F::mulsub2(M, F::sub_weak(S, X3), W, p.y);
         return Pt{X3, Y3, F::mul(V, p.zz), F::mul(W, p.zzz)};
     }
-    // Jacobian doubling, dbl-2009-l (a = 0): 2M + 5S = 954 multiply-adds on the radix-2^29 field against the XYZZ form's 1 431 (five
-    // products, three squarings, one fused pair).  For the fixed-base table build, whose points are doubled 20 times between two
-    // normalisations and never added to anything; Z3 = 2 Y Z (a curve point of odd prime order never reaches Y = 0).
-    WS_HD static Jac<F> dbl_jac(const Jac<F>& p) {
-        const El A = F::sqr(p.x), B = F::sqr(p.y), B2 = F::sqr(B);
-        const El t = F::sqr(F::add(p.x, B));
-        const El D = F::dbl(F::sub(F::sub(t, A), B2));
-        const El E = F::add(F::dbl(A), A);
-        const El X3 = F::sub(F::sqr(E), F::dbl(D));
-        const El Y3 = F::sub(F::mul(E, F::sub(D, X3)), F::dbl(F::dbl(F::dbl(B2))));
-        return Jac<F>{X3, Y3, F::dbl(F::mul(p.y, p.z))};
-    }
     // doubling of an affine point (mdbl-2008-s-1)
     WS_HD static Pt dbl_affine(const El& x, const El& y) {
         El U = F::dbl(y);

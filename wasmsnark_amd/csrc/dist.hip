@@ -90,7 +90,7 @@ static int dist_ntt_native(Lane& L, const DistComm& cm, Fe* x, Fe* y, uint32_t l
     // x[t] *= w_2n^t (odd), then the column step.  Round 4: the factors are applied by the column step's own first load (row b of
     // the batch knows its t: NttRowCoset) -- the separate pass over the stack (saturated field, 64-bit divisions: 0.33 ms for two
     // 2^20 vectors in rocprofv3, more than the pack and unpack passes together) is kept for blocks the batch cannot describe
-    if (odd && log_n2 >= 1 && (r1 & (r1 - 1)) == 0 && tuning_get("DIST_FUSED_COSET", 1)) {
+    if (odd && log_n2 >= 1 && (r1 & (r1 - 1)) == 0) {
         NttRowCoset pre;
         if ((rc = ntt_coset_tables_kernel_format((int)log_n, &pre.lo, &pre.hi, &pre.hc, s))) return rc;
         pre.shift = log_n1; pre.row0 = (uint32_t)row0; pre.row_mask = (uint32_t)(r1 - 1);

@@ -1,5 +1,6 @@
 // internal.h -- C++ interfaces between the translation units of libwsnark.
 #pragma once
+#include <atomic>
 #include <condition_variable>
 #include <functional>
 #include <map>
@@ -73,7 +74,6 @@ struct Lane {
     hipStream_t stream2 = nullptr;              // second queue (prover: CALC_H and the H sum beside the tails)
     hipStream_t stream3 = nullptr;              // third queue (small proofs / points shards: the G2 sum beside the G1 sums)
     hipStream_t stream_copy = nullptr;          // host -> device copies of a call's inputs (the witness, chunk by chunk, beside the first kernels)
-    hipStream_t stream_copy2 = nullptr;         // ... a second copy queue: the chunks alternate between the two (two DMAs in flight)
     hipEvent_t ev_chunk[2] = {nullptr, nullptr};   // ... a chunk has landed
     MsmWorkspace* msm = nullptr;                // plans, launch slots (owned; msm_workspace_free)
     DevBuf host_in[2];                          // host-pointer boundary: grow-only device copies of the caller's buffers
@@ -87,6 +87,10 @@ struct Lane {
 };
 static const int kMaxLanes = 4;
 
+struct StagePool;     // context.hip: the copy threads of the staging ring
+// Everything that belongs to ONE device: queues, lanes, plan caches, the staging ring.  A process may hold several (round 5:
+// wsnark_group_create makes one per device of a group; wsnark_init makes the default one); a host thread works on the one it
+// has selected (CtxScope) -- HIP's own current device is per thread in the same way.
 struct Context {
     int device = 0;
     hipStream_t stream = nullptr;               // utility queue: key ingestion, table builds, small host-pointer calls
@@ -107,9 +111,25 @@ struct Context {
     hipStream_t build_q = nullptr;              // the keys' background table builds, one after the other: the LOWEST stream priority (prove.hip)
     DevBuf build_tmp;                           // ... and their scratch slab (the builds are serial on build_q: one slab serves them all); grow-only
     std::mutex build_mu;                        // queueing a build (and growing the slab) is one key at a time
-    std::thread warm, warm_ring;                // wsnark_init's helpers: code objects; staging ring (joined by shutdown)
+    std::thread *warm = nullptr, *warm_ring = nullptr;   // the context's start-up helpers: code objects; staging ring (joined by its destruction)
     std::mutex warm_mu;
+    int owner_pid = 0;                          // the process that created the helpers: a fork()ed child has the objects but not the threads
+    std::mutex ring_mu;                         // one upload at a time uses the ring
+    StagePool* pool = nullptr;                  // ... and its copy threads (never destroyed: parked until the process ends)
+    std::atomic<bool> ntt_attr_set{false};      // the transform kernel's dynamic-LDS attribute has been raised on this device
 };
+// the context the calling thread works on: the one selected by a CtxScope on this thread, else the default one (wsnark_init)
+Context* ctx();   // nullptr before wsnark_init
+Context* ctx_set_current(Context* c);          // returns the previous selection of this thread (nullptr = the default)
+struct CtxScope {
+    Context* prev;
+    explicit CtxScope(Context* c) : prev(ctx_set_current(c)) { if (c) (void)hipSetDevice(c->device); }
+    ~CtxScope() { (void)ctx_set_current(prev); }
+    CtxScope(const CtxScope&) = delete;
+    CtxScope& operator=(const CtxScope&) = delete;
+};
+int context_create(int device, Context** out);  // a context of its own on that device (wsnark_group_create)
+void context_destroy(Context* C);
 // One no-op kernel per translation unit: the runtime loads a TU's code object when the first of its kernels is launched (7-12 ms for
 // msm.hip under ROCm 7.2) -- wsnark_init's helper thread launches these so that the first key load and proof do not pay for it
 void warm_msm(hipStream_t s);
@@ -141,16 +161,17 @@ LaneLock acquire_lane(Context* C);
 // Host -> device copy of caller memory that may be pageable and never touched by the runtime before: worker
 // threads memcpy chunks into a pinned ring and queue one DMA per chunk on `s` (the runtime's own pageable
 // path pins fresh pages at ~10 GB/s; this runs at memcpy speed, ~40 GB/s).  Returns once the source has been
-// read completely; the DMAs may still be in flight on `s`.
+// read completely (the caller may free or rewrite it); the DMAs out of the ring may still be in flight on `s`.  A source that
+// is already pinned is DMA'd in place, and then the call WAITS for `s`: the contract is the same for both kinds of memory.
 int upload_staged(void* d_dst, const void* h_src, size_t bytes, hipStream_t s);
 // The same, announcing every chunk: on_chunk(lo, hi) runs on the calling thread right after the DMA of bytes [lo, hi) has
 // been queued on `s` (chunks arrive in order; a non-zero return aborts the upload and is returned).  Typical use: record an
 // event on `s` and make another queue start its first pass over that part while the rest is still being staged.
-// (the third argument of on_chunk is the queue that chunk's DMA went to: `s`, or s_alt when a second copy queue is given)
+// (the third argument of on_chunk is the queue that chunk's DMA went to: `s`)
+// A pinned source is DMA'd in place and the call returns with those DMAs in flight: the source must stay valid until `s` has
+// passed them (*direct_out, optional, says whether that path was taken).
 typedef std::function<int(size_t, size_t, hipStream_t)> ChunkFn;
-int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s, const ChunkFn& on_chunk, hipStream_t s_alt = nullptr);
-
-Context* ctx();   // nullptr before wsnark_init
+int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s, const ChunkFn& on_chunk, bool* direct_out = nullptr);
 
 // Measurement switches (A/B runs): the value set through wsnark_tuning_set for `name`, else the environment variable
 // WSNARK_<name>, else dflt.  Read per call, so that ONE process can time several settings on the same resident key
@@ -193,12 +214,10 @@ int msm_g2_host(Lane& L, const void* h_scalars, const void* h_points, uint64_t n
 // two-phase form: one digit/sort/task plan per scalar vector, then any number of point sets of the
 // same length against it (the prover's A, B1, B2 and C sums all use the witness as scalars).
 // table_c != 0: plan for fixed-base window tables of that window width (msm_build_table; the launches then take the table)
-// allow_split: the plan may order its tasks in two segments (high windows first) so that msm_g{1,2}_launch can run the
-// reduction tail of the high windows on the lane's second queue beside the accumulation of the low ones (one stand-alone MSM)
-int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipStream_t s, uint32_t table_c = 0, bool allow_split = false);
+int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipStream_t s, uint32_t table_c = 0);
 // the same plan in three steps: the digit histogram -- the first pass over the scalars -- may be taken over parts [i0, i1) of
 // the vector as they become available (a witness uploaded chunk by chunk), on `s` or on queues ordered before the finish
-int msm_plan_begin(Lane& L, uint64_t n, WindowShard sh, hipStream_t s, uint32_t table_c = 0, bool allow_split = false);
+int msm_plan_begin(Lane& L, uint64_t n, WindowShard sh, hipStream_t s, uint32_t table_c = 0);
 int msm_plan_count(Lane& L, const Fe* d_scalars, uint64_t i0, uint64_t i1, hipStream_t s);
 int msm_plan_finish(Lane& L, const Fe* d_scalars, hipStream_t s);
 uint32_t msm_table_rows(uint32_t table_c);
@@ -210,17 +229,10 @@ int msm_points_mask(const Affine<Fq>* d_g1, const Affine<Fq2>* d_g2, uint64_t n,
 // asynchronous form: launch enqueues the kernels and the copy of the window sums, finish waits
 // for that copy and runs the serial host tail.  `prepared` = the point array was converted in place by
 // msm_prepare_points (resident keys).
-// tail_stream (optional, all three launchers): the reduction tail is enqueued on that queue of the lane instead of on s
-int msm_g1_launch(Lane& L, const Affine<Fq>* d_points, bool prepared, int* slot, hipStream_t s, hipStream_t tail_stream = nullptr);
-int msm_g2_launch(Lane& L, const Affine<Fq2>* d_points, bool prepared, int* slot, hipStream_t s, hipEvent_t before_tail = nullptr, hipStream_t tail_stream = nullptr);
-// msm_g1_launch in two steps: the accumulation alone, and one batched reduction tail for up to 4 launches of the same tail geometry
-int msm_g1_acc_only(Lane& L, const Affine<Fq>* d_points, bool prepared, int* slot, hipStream_t s);
-int msm_g1_tail(Lane& L, const int* slots, int nslots, hipStream_t s, hipStream_t tail_stream = nullptr);
-bool msm_same_tail_geometry(Lane& L, int slot_a, int slot_b);
-// `before_tail` (optional) is recorded on s after the accumulations, before the batched reduction tail
+int msm_g1_launch(Lane& L, const Affine<Fq>* d_points, bool prepared, int* slot, hipStream_t s);
+int msm_g2_launch(Lane& L, const Affine<Fq2>* d_points, bool prepared, int* slot, hipStream_t s);
 // plan_ids (optional): the plan each set is accumulated against (variants of one plan: same geometry)
-int msm_g1_launch_batch(Lane& L, const Affine<Fq>* const* d_points, int nsets, bool prepared, int* slots, hipStream_t s,
-                        hipEvent_t before_tail = nullptr, const int* plan_ids = nullptr, hipStream_t tail_stream = nullptr);
+int msm_g1_launch_batch(Lane& L, const Affine<Fq>* const* d_points, int nsets, bool prepared, int* slots, hipStream_t s, const int* plan_ids = nullptr);
 // several independent plans (digit/sort/task buffers) can be alive at once; plan and launches use the selected one
 void msm_select_plan(Lane& L, int id);      // id in [0, 4)
 // A second plan over the SAME scalars that leaves out the pairs with mask[i] == 0, derived from plan `src_id`
@@ -234,7 +246,6 @@ int msm_g2_finish(Lane& L, int slot, XYZZ<Fq2>* out_host);
 void msm_abort_slots(Lane& L, const int* slots, int nslots, hipStream_t a, hipStream_t b);
 void msm_workspace_free(Lane& L);
 int msm_prepare_points(int which, void* d_points, uint64_t n, hipStream_t s);
-bool msm_uses_field29();
 
 // ---- CALC_H pieces (calch.hip) ----
 struct CsrMatrix {            // row-major transpose of the reference's column-major pols blob
@@ -258,6 +269,24 @@ int eval_ab_dev(Lane& L, const Fe* d_signals_plain, uint32_t n_signals, const Cs
                 Fe* d_a, Fe* d_b, hipStream_t s);
 int dist_combine_dev(const Fe* d_e, const Fe* d_o, Fe* d_h, uint64_t rows, uint64_t cols, uint64_t row0, uint32_t log_n1, uint32_t log_n, hipStream_t s);
 int dist_scale_dev(Fe* d_data, uint64_t stack, uint64_t rows, uint64_t cols, uint64_t row0, uint32_t log_n1, uint32_t log_n, int mode, int inverse, hipStream_t s);
+
+// ---- proving keys (prove.hip) ----
+struct ProvingKey;
+struct KeySections {      // everything wsnark_pkey_load reads from proving_key.bin, as separate host buffers
+    uint32_t n_vars, n_public, domain;
+    const uint8_t *alfa1, *beta1, *delta1, *beta2, *delta2;
+    const uint8_t* polsA; uint64_t lenA;
+    const uint8_t* polsB; uint64_t lenB;
+    const uint8_t *A, *B1, *B2, *Cpts, *H;     // nVars, nVars, nVars, nVars-nPublic-1, domain points
+    uint64_t lenPA, lenPB1, lenPB2, lenPC, lenPH;   // bytes the caller vouches for behind each of those
+};
+struct KeyShard { uint32_t rank = 0, world = 1, h_log_m = 0; };
+int pkey_parse(const uint8_t* buf, size_t len, KeySections* out);
+int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard);      // on the calling thread's context
+void pkey_free(ProvingKey* K);
+int pkey_wait_tables(ProvingKey* K);
+Context* pkey_context(const ProvingKey* K);
+void pkey_info(const ProvingKey* K, uint32_t* nv, uint32_t* np, uint32_t* dom);
 
 // ---- one proof over the ranks of a node (dist.hip) ----
 // The host's transport (include/wsnark.h: wsnark_comm_t): exchange buffers it owns and two callbacks.

@@ -16,7 +16,6 @@
 //                      task-length histogram (wavefront-aggregated counters for hot buckets)
 //         3 msm_plan_*     buckets cut into tasks of <= lmax entries, ordered longest-first (255-level
 //                      counting sort); very hot buckets get their task list from a workgroup each
-//         (WSNARK_MSM_SORT=cub: msm_digits + hipCUB radix sort + msm_bounds, the first version, for A/B runs)
 //   exec  4 msm_accumulate  one lane per task: mixed additions (XYZZ += affine, 8M+2S) of the task's points,
 //                      gathered 64/128 B per lane, next point in flight during the current addition
 //         5 msm_combine_*   partial sums of split buckets: one lane, one wavefront (LDS tree), or -- very hot
@@ -31,13 +30,6 @@
 #include <chrono>
 
 #include "internal.h"
-// The first version of the grouping pass (explicit digit arrays + hipCUB radix sort) is an A/B path only: builds with
-// -DWSNARK_WITH_CUB (make HIPFLAGS+=-DWSNARK_WITH_CUB) carry it, selected by WSNARK_MSM_SORT=cub; the default build does not
-// link the 20-odd rocPRIM kernels it brings into the code object.
-#if defined(WSNARK_WITH_CUB) && !defined(WSNARK_EMUL)
-#include <hipcub/hipcub.hpp>
-#endif
-
 namespace wsnark {
 
 #ifndef WS_ACC_WAVES
@@ -56,48 +48,13 @@ namespace wsnark {
 #define WS_MADD_WIDE 1     // accumulation loop keeps X wide between additions (curve.h: madd_wide); 0 = strict madd, for A/B builds
 #endif
 static const uint32_t CHUNK = 8;          // buckets per msm_chunks lane
-// default wavefront issue priorities (rt.h: wave_prio) of the latency-bound kernels; WSNARK_TAIL_PRIO / WSNARK_PLAN_PRIO override
-static const long kTailPrio = 0, kPlanPrio = 0;
 
 struct MsmScratch {
-    DevBuf keys, vals, keys_out, vals_out, sort_tmp, entries, hot, hot_sums;
+    DevBuf vals_out, entries, hot, hot_sums;
     DevBuf bstart, bend, buckets, counters, tasks, multi, partials;
     DevBuf chunkS, chunkA, sums, points_conv;
-    DevBuf hot_done, tail_done;      // device-scope completion counters of msm_combine_all / msm_tree (zero between launches)
+    DevBuf hot_done;                 // device-scope completion counters of msm_combine_all (zero between launches)
 };
-
-// ---------------------------------------------------------------------------
-// 1. digits
-// ---------------------------------------------------------------------------
-// (w_off, w_stride): this process owns windows w_off, w_off + w_stride, ... (multi-GPU window sharding;
-// 0, 1 = all windows).  Carries run through every window, only the owned digits are emitted.
-__global__ __launch_bounds__(256) void msm_digits(const Fe* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t W,
-                                                    uint32_t w_off, uint32_t w_stride,
-                                                    uint32_t sentinel, uint32_t* __restrict__ keys,
-                                                    uint32_t* __restrict__ vals) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    // raw 256-bit scalars (possibly >= r, src/bn128.js:642-661 and fact 3 of SURVEY.md):
-    // points have prime order r, so reduce first; then s < 2^254 and the top window cannot carry.
-    Fe s = Fr::reduce_full(scalars[i]);
-    const uint32_t NB = 1u << (c - 1);
-    uint32_t carry = 0, k = 0;
-    for (uint32_t w = 0; w < W; w++) {
-        const uint32_t bit = w * c;
-        const uint32_t limb = bit >> 6, off = bit & 63;
-        uint64_t v = limb < 4 ? (s.l[limb] >> off) : 0;
-        if (off + c > 64 && limb + 1 < 4) v |= s.l[limb + 1] << (64 - off);
-        uint32_t d = (uint32_t)(v & ((1u << c) - 1)) + carry;
-        uint32_t neg = 0;
-        if (d > NB) { d = (1u << c) - d; neg = 1; carry = 1; } else carry = 0;
-        if (w >= w_off && (w - w_off) % w_stride == 0) {
-            const uint64_t o = (uint64_t)k * n + i;
-            keys[o] = d ? (k * NB + d - 1) : sentinel;   // zero digits sort behind every bucket
-            vals[o] = i | (neg << 31);
-            k++;
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------
 // 1'/2'. bucket grouping without a general sort ("presort", the default).
@@ -145,7 +102,6 @@ struct PresortArgs {
     uint32_t idx_bits;                 // packed 4-byte entries: idx | neg << idx_bits | lo << (idx_bits+1)
     const uint8_t* mask;               // optional: pairs with mask[i] == 0 are left out (their point is infinity)
     uint32_t flat;                     // fixed-base table plans: ONE bucket set, bin = (d-1) >> lo_bits, entries index the table (window * n + i)
-    uint32_t prio;                     // wavefront issue priority of the grouping kernels (rt.h: wave_prio)
 };
 __device__ __forceinline__ uint32_t presort_bin(const PresortArgs& A, uint32_t k, uint32_t d) {
     return (A.flat ? 0u : k * A.HB) + ((d - 1) >> A.lo_bits);
@@ -172,7 +128,6 @@ template <> struct PresortEntry<uint32_t> {
 
 __global__ __launch_bounds__(1024) void presort_count(PresortArgs A, uint32_t* __restrict__ bin_count) {
     __shared__ uint32_t cnt[PRESORT_MAX_BINS];
-    wave_prio(A.prio);
     for (uint32_t b = threadIdx.x; b < A.nbins; b += blockDim.x) cnt[b] = 0;
     __syncthreads();
     const uint32_t base = A.i0 + blockIdx.x * A.tile;
@@ -214,7 +169,6 @@ template <class E>
 __global__ __launch_bounds__(1024) void presort_scatter(PresortArgs A, uint32_t* __restrict__ bin_cursor, E* __restrict__ entries) {
     __shared__ uint32_t cnt[PRESORT_MAX_BINS];
     __shared__ uint32_t gbase[PRESORT_MAX_BINS];
-    wave_prio(A.prio);
     for (uint32_t b = threadIdx.x; b < A.nbins; b += blockDim.x) cnt[b] = 0;
     __syncthreads();
     const uint32_t base = A.i0 + blockIdx.x * A.tile;
@@ -280,12 +234,11 @@ __global__ __launch_bounds__(1024) void presort_bins(const E* __restrict__ entri
                                                        uint32_t lo_bits, uint32_t idx_bits, uint32_t* __restrict__ vals_out,
                                                        uint32_t* __restrict__ bstart, uint32_t* __restrict__ bend,
                                                        uint32_t lmax, uint32_t* __restrict__ hist,
-                                                       const uint8_t* __restrict__ mask, uint32_t mask_mod, uint32_t split_bin, uint32_t prio) {
+                                                       const uint8_t* __restrict__ mask, uint32_t mask_mod) {
     __shared__ uint32_t sub[1u << PRESORT_MAX_LO];
     __shared__ uint32_t off[1u << PRESORT_MAX_LO];
     __shared__ uint32_t part[1024];
     __shared__ uint32_t lhist[256];
-    wave_prio(prio);
     const uint32_t bin = blockIdx.x, SUB = 1u << lo_bits;
     const uint32_t s = bin_start[bin], e = bin_start[bin + 1];
     for (uint32_t t = threadIdx.x; t < SUB; t += blockDim.x) sub[t] = 0;
@@ -342,10 +295,8 @@ __global__ __launch_bounds__(1024) void presort_bins(const E* __restrict__ entri
         }
     }
     __syncthreads();
-    // (split plans: the bins of the high windows form task segment 0, the low windows segment 1 -- see msm_plan_emit)
-    uint32_t* __restrict__ hseg = hist + (bin >= split_bin ? 0u : 256u);
     for (uint32_t t = threadIdx.x; t < 256; t += blockDim.x)
-        if (lhist[t]) atomicAdd(&hseg[t], lhist[t]);
+        if (lhist[t]) atomicAdd(&hist[t], lhist[t]);
     for (uint32_t it = 0; it < iters; it++) {
         const uint32_t i = s + threadIdx.x + it * stride;
         E v[4];
@@ -366,19 +317,6 @@ __global__ __launch_bounds__(1024) void presort_bins(const E* __restrict__ entri
             if (active) vals_out[off[lo] + r] = PresortEntry<E>::val(v[u], idx_bits);
         }
     }
-}
-
-// ---------------------------------------------------------------------------
-// 3. bucket boundaries in the sorted key array
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void msm_bounds(const uint32_t* __restrict__ keys, uint64_t total, uint32_t sentinel,
-                                                    uint32_t* __restrict__ bstart, uint32_t* __restrict__ bend) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const uint32_t k = keys[i];
-    if (k == sentinel) return;
-    if (i == 0 || keys[i - 1] != k) bstart[k] = (uint32_t)i;
-    if (i + 1 == total || keys[i + 1] != k) bend[k] = (uint32_t)(i + 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -446,68 +384,32 @@ static const uint32_t HOT_MIN = 1024;      // tasks
 static const uint32_t HOT_SLICE = 512;     // partial sums per first-stage wavefront
 struct HotBucket { uint32_t bucket, first_partial, ntasks, task_base, rem_index, start, rem, slice_base; };
 
-__global__ __launch_bounds__(256) void msm_plan_hist(const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bend,
-                                                       uint32_t nbuckets, uint32_t lmax, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t lcnt[256];
-    lcnt[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nbuckets) {
-        const uint32_t cnt = bend[b] - bstart[b];
-        if (cnt) {
-            const uint32_t nt = (cnt + lmax - 1) / lmax, rem = cnt - (nt - 1) * lmax;
-            if (nt > 1) atomicAdd(&lcnt[255], nt - 1);
-            atomicAdd(&lcnt[len_key(rem, lmax)], 1u);
-        }
-    }
-    __syncthreads();
-    if (lcnt[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lcnt[threadIdx.x]);
-}
-
 // Tasks are laid out longest-first: the slots of key k start after all tasks with a longer key.  Every workgroup
 // derives those starts from the (complete) histogram itself -- 256 entries -- instead of a separate one-thread
 // kernel; `cursor` (zeroed) only hands out ranks within a key.  counters[3] = total tasks.
-// Split plans (split_bucket != 0, a multiple of the workgroup's 256 buckets): the buckets >= split_bucket -- the HIGH
-// windows -- form task segment 0, laid out first, the others segment 1 behind it (each segment longest-first on its own
-// histogram); counters[6] = tasks of segment 0.  The accumulation then runs as two launches, and the reduction tail of
-// the high windows runs on the lane's second queue beside the accumulation of the low ones (msm_launch_split).
 __global__ __launch_bounds__(256) void msm_plan_emit(const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bend,
-                                                       uint32_t nbuckets, uint32_t lmax, const uint32_t* __restrict__ hist2,
-                                                       uint32_t* __restrict__ cursor2,
+                                                       uint32_t nbuckets, uint32_t lmax, const uint32_t* __restrict__ hist,
+                                                       uint32_t* __restrict__ cursor,
                                                        Task* __restrict__ tasks, uint32_t* __restrict__ counters,
                                                        MultiBucket* __restrict__ multi, HotBucket* __restrict__ hot,
-                                                       uint32_t hot_min, uint32_t split_bucket, uint32_t prio) {
+                                                       uint32_t hot_min) {
     __shared__ uint32_t lcnt[256];
     __shared__ uint32_t lbase[256];
-    wave_prio(prio);
     __shared__ uint32_t first[256];          // start of key k's slots = number of tasks with a longer key
-    __shared__ uint32_t red[256];
-    const uint32_t seg = (blockIdx.x * blockDim.x >= split_bucket) ? 0u : 1u;      // uniform per workgroup
-    const uint32_t* __restrict__ hist = hist2 + seg * 256;
-    uint32_t* __restrict__ cursor = cursor2 + seg * 256;
     lcnt[threadIdx.x] = 0;
     first[threadIdx.x] = hist[threadIdx.x];
-    red[threadIdx.x] = hist2[threadIdx.x];   // segment 0's histogram: its total is where segment 1 starts
     __syncthreads();
     // inclusive suffix sum over the 256 keys (Hillis-Steele), then shift to exclusive
     for (uint32_t d = 1; d < 256; d <<= 1) {
         const uint32_t v = threadIdx.x + d < 256 ? first[threadIdx.x + d] : 0;
-        const uint32_t w = threadIdx.x + d < 256 ? red[threadIdx.x + d] : 0;
         __syncthreads();
         first[threadIdx.x] += v;
-        red[threadIdx.x] += w;
         __syncthreads();
     }
-    const uint32_t total0 = red[0], seg_base = seg ? total0 : 0u;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        counters[6] = total0;
-        counters[3] = seg ? total0 + first[0] : total0;
-    }
-    // (a split plan's workgroup 0 always belongs to segment 1 -- bucket 0 is a low window -- so counters[3] is complete;
-    //  without a split every workgroup is segment 0 and total0 is the whole count)
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[3] = first[0];
     const uint32_t excl = threadIdx.x + 1 < 256 ? first[threadIdx.x + 1] : 0;
     __syncthreads();
-    first[threadIdx.x] = seg_base + excl;
+    first[threadIdx.x] = excl;
     __syncthreads();
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t cnt = 0, s = 0, nt = 0, rem = 0, krem = 0, r255 = 0, rrem = 0;
@@ -566,18 +468,15 @@ struct AccSets {
     const uint32_t* counters[4];
     const MultiBucket* multi[4];
     const HotBucket* hot[4];
-    const uint32_t* bstart[4];
-    const uint32_t* bend[4];
     typename C::PtP* buckets[4];
     typename C::PtP* partials[4];
     typename C::PtP* hot_sums[4];
     uint32_t* hot_done[4];      // per hot bucket: slices folded so far (msm_combine_all; zero between launches)
-    uint32_t prio;              // wavefront issue priority of the combine kernel (rt.h: wave_prio)
 };
 
 // 4. one lane per task: mixed additions of the task's points
 template <class C>
-__global__ __launch_bounds__(256, (sizeof(typename C::PtP) > 128 ? WS_ACC_WAVES_G2 : WS_ACC_WAVES)) void msm_accumulate(AccSets<C> as, uint32_t seg) {
+__global__ __launch_bounds__(256, (sizeof(typename C::PtP) > 128 ? WS_ACC_WAVES_G2 : WS_ACC_WAVES)) void msm_accumulate(AccSets<C> as) {
     const typename C::AffP* __restrict__ points = as.points[blockIdx.y];
     const uint32_t* __restrict__ vals = as.vals[blockIdx.y];
     const Task* __restrict__ tasks = as.tasks[blockIdx.y];
@@ -585,191 +484,24 @@ __global__ __launch_bounds__(256, (sizeof(typename C::PtP) > 128 ? WS_ACC_WAVES_
     typename C::PtP* __restrict__ buckets = as.buckets[blockIdx.y];
     typename C::PtP* __restrict__ partials = as.partials[blockIdx.y];
     // the grid is sized for the worst case; the real task count stays on the device (no host round trip)
-    // seg: 0 / 1 = that task segment of a split plan, 2 = all tasks
-    const uint32_t t0 = seg == 1 ? counters[6] : 0u, t1 = seg == 0 ? counters[6] : counters[3];
-    const uint32_t t = t0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= t1) return;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= counters[3]) return;
     const Task k = tasks[t];
     const typename C::PtP acc = C::pack_pt(accumulate_range<C>(points, vals, k.start, k.len));
     if (k.dst & PARTIAL_FLAG) partials[k.dst & ~PARTIAL_FLAG] = acc;
     else buckets[k.dst] = acc;
 }
 
-// 4'. A/B ONLY (WSNARK_ACC_SHAPE=segscan): the accumulation shape BASELINE.json's north star words --
-// "one scalar/point pair per lane ... LDS-staged bucket accumulation with wavefront segmented reduction" -- over the same
-// bucket-sorted stream.  A wavefront takes 64 CONSECUTIVE entries of the sorted stream (coalesced index reads), every lane
-// gathers its one point, and a segmented inclusive scan keyed by the bucket (six Hillis-Steele steps, operands staged through
-// LDS, full XYZZ additions) leaves every bucket run's sum in its last lane.  Runs that lie inside the wavefront are stored as
-// buckets; a run that crosses a wavefront boundary leaves a partial (slot 2 w + [the run does not start at lane 0]) and
-// msm_segscan_merge adds the partials of such buckets.  The shipped shape (msm_accumulate: one lane = one bucket run in
-// registers, no cross-lane step) does 64 mixed additions (10 products each) per wavefront step where this one spends six
-// full additions (14 products each) per 64 ENTRIES: measured in profiles/r03_ab_accumulate_shape.txt.
-template <class C>
-__global__ __launch_bounds__(256) void msm_accumulate_segscan(const typename C::AffP* __restrict__ points, const uint32_t* __restrict__ vals,
-                                                                const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bend,
-                                                                uint32_t nbuckets, const uint32_t* __restrict__ total_ptr,
-                                                                typename C::PtP* __restrict__ buckets, typename C::PtP* __restrict__ partials) {
-    __shared__ typename C::PtP sh[256];
-    __shared__ uint32_t key[256];
-    const uint32_t total = *total_ptr;
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, w0 = threadIdx.x & ~63u;
-    const bool live = e < total;                                   // (uniform trip counts: every thread reaches every barrier)
-    uint32_t b = 0xFFFFFFFFu;
-    typename C::Pt P = C::infinity();
-    if (live) {
-        uint32_t lo = 0, hi = nbuckets;                            // largest bucket with bstart <= e (bstart is monotone; empty buckets repeat a start)
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (bstart[mid] <= e) lo = mid; else hi = mid; }
-        while (bend[lo] <= e) lo++;                                // skip empty buckets that share the start
-        b = lo;
-        const uint32_t v = vals[e];
-        C::madd(P, C::unpack_aff(points[v & 0x7FFFFFFFu]), (v >> 31) != 0);
-    }
-    key[threadIdx.x] = b;
-    for (uint32_t d = 1; d < 64; d <<= 1) {
-        sh[threadIdx.x] = C::pack_pt(P);
-        __syncthreads();
-        if (live && lane >= d && key[threadIdx.x - d] == b) P = C::add(P, C::unpack_pt(sh[threadIdx.x - d]));
-        __syncthreads();
-    }
-    if (!live) return;
-    const bool tail = lane == 63 || e + 1 >= total || key[threadIdx.x + 1] != b;
-    if (!tail) return;
-    const uint32_t wave_first = blockIdx.x * blockDim.x + w0;      // first entry of this wavefront
-    const uint32_t s0 = bstart[b], s1 = bend[b];
-    if (s0 >= wave_first && s1 <= wave_first + 64) { buckets[b] = C::pack_pt(P); return; }
-    const uint32_t first_lane = s0 > wave_first ? s0 - wave_first : 0;
-    partials[2 * (wave_first >> 6) + (first_lane != 0 ? 1u : 0u)] = C::pack_pt(P);
-}
-template <class C>
-__global__ __launch_bounds__(256) void msm_segscan_merge(const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bend, uint32_t nbuckets,
-                                                           const typename C::PtP* __restrict__ partials, typename C::PtP* __restrict__ buckets) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nbuckets) return;
-    const uint32_t s0 = bstart[b], s1 = bend[b];
-    if (s1 == s0) { buckets[b] = C::pack_pt(C::infinity()); return; }
-    const uint32_t wf = s0 >> 6, wl = (s1 - 1) >> 6;
-    if (wf == wl) return;                                          // the run lies inside one wavefront: already stored
-    typename C::Pt acc = C::infinity();
-    for (uint32_t w = wf; w <= wl; w++) {
-        const uint32_t first_lane = s0 > (w << 6) ? s0 - (w << 6) : 0;
-        acc = C::add(acc, C::unpack_pt(partials[2 * w + (first_lane != 0 ? 1u : 0u)]));
-    }
-    buckets[b] = C::pack_pt(acc);
-}
-
-// 5a. buckets cut into a few tasks: one lane sums the partials
+// 5. partial sums of split buckets -> buckets.  Three shapes by the number of tasks a bucket was cut into: a few (one lane sums
+// them), >= WAVE_COMBINE_MIN (one wavefront per bucket: lanes stride over the partial sums, an LDS tree folds the 64 lane sums),
+// >= HOT_MIN (very hot buckets, e.g. the ones of a boolean-heavy witness: one wavefront per HOT_SLICE partial sums, then a second
+// stage over the slice sums).
 static const uint32_t WAVE_COMBINE_MIN = 17;
-template <class C>
-__global__ __launch_bounds__(256) void msm_combine_small(AccSets<C> as, uint32_t b_lo, uint32_t b_hi) {
-    const MultiBucket* __restrict__ mbs = as.multi[blockIdx.y];
-    const uint32_t* __restrict__ counters = as.counters[blockIdx.y];
-    const typename C::PtP* __restrict__ partials = as.partials[blockIdx.y];
-    typename C::PtP* __restrict__ buckets = as.buckets[blockIdx.y];
-    const uint32_t* __restrict__ bstart = as.bstart[blockIdx.y];
-    const uint32_t* __restrict__ bend = as.bend[blockIdx.y];
-    // (b_lo, b_hi: the buckets this launch is responsible for -- all of them, or one half of a split plan)
-    // empty buckets = infinity (ZZ == 0); the others are written by their task or by a combine step
-    for (uint32_t b = b_lo + blockIdx.x * blockDim.x + threadIdx.x; b < b_hi; b += gridDim.x * blockDim.x)
-        if (bend[b] == bstart[b]) buckets[b] = C::pack_pt(C::infinity());
-    const uint32_t nmb = counters[1];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nmb; i += gridDim.x * blockDim.x) {
-        const MultiBucket h = mbs[i];
-        if (h.ntasks >= WAVE_COMBINE_MIN || h.bucket < b_lo || h.bucket >= b_hi) continue;
-        typename C::Pt acc = C::unpack_pt(partials[h.first_partial]);
-        for (uint32_t k = 1; k < h.ntasks; k++) acc = C::add(acc, C::unpack_pt(partials[h.first_partial + k]));
-        buckets[h.bucket] = C::pack_pt(acc);
-    }
-}
-
-// 5b. hot buckets (many tasks): one wavefront per bucket, lanes stride over the partial sums,
-// then an LDS tree folds the 64 lane sums (wavefront segmented reduction)
-template <class C>
-__global__ __launch_bounds__(64) void msm_combine_wave(AccSets<C> as, uint32_t b_lo, uint32_t b_hi) {
-    const MultiBucket* __restrict__ mbs = as.multi[blockIdx.y];
-    const uint32_t* __restrict__ counters = as.counters[blockIdx.y];
-    const typename C::PtP* __restrict__ partials = as.partials[blockIdx.y];
-    typename C::PtP* __restrict__ buckets = as.buckets[blockIdx.y];
-    __shared__ typename C::PtP sh[64];
-    const uint32_t nmb = counters[1];
-    const uint32_t lane = threadIdx.x;
-    for (uint32_t hb = blockIdx.x; hb < nmb; hb += gridDim.x) {     // uniform per block
-        const MultiBucket h = mbs[hb];
-        if (h.ntasks < WAVE_COMBINE_MIN || h.bucket < b_lo || h.bucket >= b_hi) continue;
-        typename C::Pt acc = C::infinity();
-        for (uint32_t k = lane; k < h.ntasks; k += 64) acc = C::add(acc, C::unpack_pt(partials[h.first_partial + k]));
-        sh[lane] = C::pack_pt(acc);
-        __syncthreads();
-        for (uint32_t step = 32; step >= 1; step >>= 1) {
-            if (lane < step) sh[lane] = C::pack_pt(C::add(C::unpack_pt(sh[lane]), C::unpack_pt(sh[lane + step])));
-            __syncthreads();
-        }
-        if (lane == 0) buckets[h.bucket] = sh[0];
-        __syncthreads();
-    }
-}
-
-// 5c. very hot buckets: stage 1 = one wavefront per HOT_SLICE partial sums (lanes stride, LDS tree), stage 2 = one
-// wavefront per bucket over the slice sums
-template <class C>
-__global__ __launch_bounds__(64) void msm_combine_hot1(AccSets<C> as, uint32_t b_lo, uint32_t b_hi) {
-    const HotBucket* __restrict__ hot = as.hot[blockIdx.y];
-    const uint32_t* __restrict__ counters = as.counters[blockIdx.y];
-    const typename C::PtP* __restrict__ partials = as.partials[blockIdx.y];
-    typename C::PtP* __restrict__ slice_sums = as.hot_sums[blockIdx.y];
-    __shared__ typename C::PtP sh[64];
-    const uint32_t nhot = counters[4], lane = threadIdx.x;
-    for (uint32_t hb = 0; hb < nhot; hb++) {                          // few entries; every workgroup walks them all
-        const HotBucket h = hot[hb];
-        if (h.bucket < b_lo || h.bucket >= b_hi) continue;
-        const uint32_t nsl = (h.ntasks + HOT_SLICE - 1) / HOT_SLICE;
-        // slices are dealt round-robin over the workgroups by their GLOBAL number, so that many moderately hot
-        // buckets spread as well as one very hot one
-        const uint32_t sl0 = (blockIdx.x + gridDim.x - h.slice_base % gridDim.x) % gridDim.x;
-        for (uint32_t sl = sl0; sl < nsl; sl += gridDim.x) {          // uniform per workgroup
-            const uint32_t lo = sl * HOT_SLICE, hi = lo + HOT_SLICE < h.ntasks ? lo + HOT_SLICE : h.ntasks;
-            typename C::Pt acc = C::infinity();
-            for (uint32_t k = lo + lane; k < hi; k += 64) acc = C::add(acc, C::unpack_pt(partials[h.first_partial + k]));
-            sh[lane] = C::pack_pt(acc);
-            __syncthreads();
-            for (uint32_t step = 32; step >= 1; step >>= 1) {
-                if (lane < step) sh[lane] = C::pack_pt(C::add(C::unpack_pt(sh[lane]), C::unpack_pt(sh[lane + step])));
-                __syncthreads();
-            }
-            if (lane == 0) slice_sums[h.slice_base + sl] = sh[0];
-            __syncthreads();
-        }
-    }
-}
-template <class C>
-__global__ __launch_bounds__(64) void msm_combine_hot2(AccSets<C> as, uint32_t b_lo, uint32_t b_hi) {
-    const HotBucket* __restrict__ hot = as.hot[blockIdx.y];
-    const uint32_t* __restrict__ counters = as.counters[blockIdx.y];
-    const typename C::PtP* __restrict__ slice_sums = as.hot_sums[blockIdx.y];
-    typename C::PtP* __restrict__ buckets = as.buckets[blockIdx.y];
-    __shared__ typename C::PtP sh[64];
-    const uint32_t nhot = counters[4], lane = threadIdx.x;
-    for (uint32_t hb = blockIdx.x; hb < nhot; hb += gridDim.x) {
-        const HotBucket h = hot[hb];
-        if (h.bucket < b_lo || h.bucket >= b_hi) continue;
-        const uint32_t nsl = (h.ntasks + HOT_SLICE - 1) / HOT_SLICE;
-        typename C::Pt acc = C::infinity();
-        for (uint32_t k = lane; k < nsl; k += 64) acc = C::add(acc, C::unpack_pt(slice_sums[h.slice_base + k]));
-        sh[lane] = C::pack_pt(acc);
-        __syncthreads();
-        for (uint32_t step = 32; step >= 1; step >>= 1) {
-            if (lane < step) sh[lane] = C::pack_pt(C::add(C::unpack_pt(sh[lane]), C::unpack_pt(sh[lane + step])));
-            __syncthreads();
-        }
-        if (lane == 0) buckets[h.bucket] = sh[0];
-        __syncthreads();
-    }
-}
-
-// 5'. Round 5: the three steps above in ONE launch (four launches before, three of which find nothing to do on a uniform witness
-// and still cost a dependent launch each on the proof's critical queue).  Workgroups of one wavefront; blockIdx.x selects the role:
-//   [0, CB_SMALL)           empty buckets = infinity; buckets cut into < WAVE_COMBINE_MIN tasks: one lane sums the partials (5a)
-//   [.., + CB_WAVE)         buckets cut into more tasks: one wavefront per bucket (5b)
-//   [.., + CB_HOT)          very hot buckets: one wavefront per HOT_SLICE partial sums (5c stage 1); the wavefront that completes a
+// Round 5: ONE launch (four before, three of which found nothing to do on a uniform witness and still cost a dependent launch
+// each on the proof's critical queue).  Workgroups of one wavefront; blockIdx.x selects the role:
+//   [0, CB_SMALL)           buckets cut into < WAVE_COMBINE_MIN tasks: one lane sums the partials
+//   [.., + CB_WAVE)         buckets cut into more tasks: one wavefront per bucket
+//   [.., + CB_HOT)          very hot buckets: one wavefront per HOT_SLICE partial sums (stage 1); the wavefront that completes a
 //                           bucket's LAST slice -- a device-scope counter per hot bucket, zero between launches -- folds the slice
 //                           sums (stage 2) and clears the counter
 // (few workgroups: a launch costs ~5 us plus ~10 us per thousand workgroups it starts, whether they find work or not -- the four
@@ -788,8 +520,7 @@ __device__ __forceinline__ typename C::PtP wave_tree_sum(typename C::PtP* sh, ui
     return r;
 }
 template <class C>
-__global__ __launch_bounds__(64) void msm_combine_all(AccSets<C> as, uint32_t b_lo, uint32_t b_hi) {
-    wave_prio(as.prio);
+__global__ __launch_bounds__(64) void msm_combine_all(AccSets<C> as) {
     const uint32_t* __restrict__ counters = as.counters[blockIdx.y];
     const typename C::PtP* __restrict__ partials = as.partials[blockIdx.y];
     typename C::PtP* __restrict__ buckets = as.buckets[blockIdx.y];
@@ -803,7 +534,7 @@ __global__ __launch_bounds__(64) void msm_combine_all(AccSets<C> as, uint32_t b_
         const uint32_t nmb = counters[1];
         for (uint32_t i = gt; i < nmb; i += gn) {
             const MultiBucket h = mbs[i];
-            if (h.ntasks >= WAVE_COMBINE_MIN || h.bucket < b_lo || h.bucket >= b_hi) continue;
+            if (h.ntasks >= WAVE_COMBINE_MIN) continue;
             typename C::Pt acc = C::unpack_pt(partials[h.first_partial]);
             for (uint32_t k = 1; k < h.ntasks; k++) acc = C::add(acc, C::unpack_pt(partials[h.first_partial + k]));
             buckets[h.bucket] = C::pack_pt(acc);
@@ -815,7 +546,7 @@ __global__ __launch_bounds__(64) void msm_combine_all(AccSets<C> as, uint32_t b_
         const uint32_t nmb = counters[1];
         for (uint32_t hb = blockIdx.x - CB_SMALL; hb < nmb; hb += CB_WAVE) {      // uniform per workgroup
             const MultiBucket h = mbs[hb];
-            if (h.ntasks < WAVE_COMBINE_MIN || h.bucket < b_lo || h.bucket >= b_hi) continue;
+            if (h.ntasks < WAVE_COMBINE_MIN) continue;
             typename C::Pt acc = C::infinity();
             for (uint32_t k = lane; k < h.ntasks; k += 64) acc = C::add(acc, C::unpack_pt(partials[h.first_partial + k]));
             const typename C::PtP r = wave_tree_sum<C>(sh, lane, acc);
@@ -831,7 +562,6 @@ __global__ __launch_bounds__(64) void msm_combine_all(AccSets<C> as, uint32_t b_
     const uint32_t bx = blockIdx.x - CB_SMALL - CB_WAVE;
     for (uint32_t hb = 0; hb < nhot; hb++) {                          // few entries; every workgroup walks them all
         const HotBucket h = hot[hb];
-        if (h.bucket < b_lo || h.bucket >= b_hi) continue;
         const uint32_t nsl = (h.ntasks + HOT_SLICE - 1) / HOT_SLICE;
         const uint32_t sl0 = (bx + CB_HOT - h.slice_base % CB_HOT) % CB_HOT;       // slices dealt round-robin by their GLOBAL number
         for (uint32_t sl = sl0; sl < nsl; sl += CB_HOT) {            // uniform per workgroup
@@ -873,18 +603,15 @@ struct TailSets {
     St* sums[4];         // what leaves for the host (reference format)
     const uint32_t* bstart[4];   // the plan's bucket bounds: an EMPTY bucket (no entry) is infinity whatever its slot still holds from the
     const uint32_t* bend[4];     // launch before -- msm_chunks checks the bounds, so no pass over the buckets has to clear them
-    uint32_t* done[4];   // msm_tree with the piece reduction fused in: per (group, row) the pieces summed so far (zero between launches)
-    uint32_t prio;       // wavefront issue priority of the tail kernels (rt.h: wave_prio)
 };
 
 template <class C>
-__global__ __launch_bounds__(256) void msm_chunks(TailSets<C> ts, uint32_t chunk0, uint32_t nchunks, uint32_t m) {
+__global__ __launch_bounds__(256) void msm_chunks(TailSets<C> ts, uint32_t nchunks, uint32_t m) {
     typedef PointIO<C> IO;
-    wave_prio(ts.prio);
     const typename IO::Stored* __restrict__ buckets = ts.buckets[blockIdx.y];
     typename IO::Stored* __restrict__ chunkS = ts.chunkS[blockIdx.y];
     typename IO::Stored* __restrict__ chunkA = ts.chunkA[blockIdx.y];
-    const uint32_t j = chunk0 + (blockIdx.x * blockDim.x + threadIdx.x) / IO::LPP;      // chunks [chunk0, nchunks): all, or the windows of one half
+    const uint32_t j = (blockIdx.x * blockDim.x + threadIdx.x) / IO::LPP;
     if (j >= nchunks) return;
     typename C::Pt run = C::infinity(), acc = C::infinity();
     const typename IO::Stored* B = buckets + (uint64_t)j * m;
@@ -907,16 +634,14 @@ __global__ __launch_bounds__(256) void msm_chunks(TailSets<C> ts, uint32_t chunk
 // (one lane per 256-byte G2 point: 256 threads at most, so that a wavefront may use the whole register file)
 template <class C> struct TreeBound { static constexpr int value = (PointIO<C>::LPP == 1 && sizeof(typename PointIO<C>::Stored) > 128) ? 256 : 512; };
 template <class C>
-__global__ __launch_bounds__(TreeBound<C>::value) void msm_tree(TailSets<C> ts, uint32_t J, uint32_t logJ, uint32_t w0, uint32_t to_ref, uint32_t fold_P,
-                                                              uint32_t nrows_out) {
+__global__ __launch_bounds__(TreeBound<C>::value) void msm_tree(TailSets<C> ts, uint32_t J, uint32_t logJ, uint32_t to_ref) {
     typedef PointIO<C> IO;
     typedef typename IO::Stored St;
-    wave_prio(ts.prio);
     const St* __restrict__ chunkS = ts.chunkS[blockIdx.z];
     const St* __restrict__ chunkA = ts.chunkA[blockIdx.z];
-    St* rows = to_ref ? ts.sums[blockIdx.z] : ts.rows[blockIdx.z];      // (no __restrict__: the fused piece reduction reads other workgroups' rows)
+    St* __restrict__ rows = to_ref ? ts.sums[blockIdx.z] : ts.rows[blockIdx.z];
     WS_DYN_SMEM(St, sh);
-    const uint32_t q = blockIdx.x, w = w0 + blockIdx.y;              // pieces [w0, w0 + gridDim.y)
+    const uint32_t q = blockIdx.x, w = blockIdx.y;
     const uint32_t slot = threadIdx.x / IO::LPP, nslots = blockDim.x / IO::LPP;
     const St* src = (q == logJ ? chunkA : chunkS) + (uint64_t)w * J;
     typename C::Pt acc = C::infinity();
@@ -941,64 +666,6 @@ __global__ __launch_bounds__(TreeBound<C>::value) void msm_tree(TailSets<C> ts, 
         if (to_ref) IO::store_ref(rows, (uint64_t)w * gridDim.x + q, r);
         else IO::store(rows, (uint64_t)w * gridDim.x + q, r);
     }
-    if (fold_P == 0) return;
-    // ---- round 5: the piece reduction (7' below, msm_rows) fused in.  The workgroup that stores the LAST of a group's P pieces of row
-    // q -- a device-scope counter per (group, row) -- folds that row over the pieces: R_q = sum_v U_{v,q} (q < logJ), R_A (q == logJ),
-    // and for the row of the T_v (q == logJ + 1) the log2 P sums V_p = sum_{v : bit p of v} T_v, all p at once on disjoint slots.
-    __shared__ uint32_t is_last;
-    const uint32_t P = fold_P, g = w / P, nsum_in = gridDim.x;
-    uint32_t* done = ts.done[blockIdx.z] + (uint64_t)g * nsum_in + q;
-    __syncthreads();                                                  // (slot 0's store above is done: both lanes of a pair)
-    if (threadIdx.x == 0) {
-        __threadfence();
-        is_last = atomicAdd(done, 1u) + 1 == P ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();                                                  // the other workgroups' rows are visible from here on
-    const St* all = ts.rows[blockIdx.z];
-    St* __restrict__ out = ts.sums[blockIdx.z];
-    uint32_t logP = 0;
-    while ((1u << logP) < P) logP++;
-    if (q <= logJ) {
-        uint32_t fs = 1;
-        while (fs < P && fs < nslots) fs <<= 1;
-        typename C::Pt f = C::infinity();
-        if (slot < fs) for (uint32_t v = slot; v < P; v += fs) f = C::add(f, IO::load(all, ((uint64_t)g * P + v) * nsum_in + q));
-        if (slot < fs) IO::store(sh, slot, f);
-        __syncthreads();
-        for (uint32_t step = fs >> 1; step >= 1; step >>= 1) {
-            if (slot < step) IO::store(sh, slot, C::add(IO::load(sh, slot), IO::load(sh, slot + step)));
-            __syncthreads();
-        }
-        if (slot == 0) IO::store_ref(out, (uint64_t)g * nrows_out + q, IO::load(sh, 0));
-    } else if (logP * (P >> 1) <= nslots && P >= 2) {
-        // slot = p * P/2 + k: the k-th piece index with bit p set; one segmented tree of depth log2(P / 2)
-        const uint32_t half = P >> 1, p = slot / half, k = slot % half, low = (1u << p) - 1;
-        const bool act = slot < logP * half;
-        if (act) IO::store(sh, slot, IO::load(all, ((uint64_t)g * P + (((k & ~low) << 1) | (1u << p) | (k & low))) * nsum_in + q));
-        __syncthreads();
-        for (uint32_t step = half >> 1; step >= 1; step >>= 1) {
-            if (act && k < step) IO::store(sh, slot, C::add(IO::load(sh, slot), IO::load(sh, slot + step)));
-            __syncthreads();
-        }
-        if (act && k == 0) IO::store_ref(out, (uint64_t)g * nrows_out + logJ + 1 + p, IO::load(sh, slot));
-    } else {
-        for (uint32_t p = 0; p < logP; p++) {
-            typename C::Pt f = C::infinity();
-            for (uint32_t v = slot; v < P; v += nslots)
-                if ((v >> p) & 1u) f = C::add(f, IO::load(all, ((uint64_t)g * P + v) * nsum_in + q));
-            IO::store(sh, slot, f);
-            __syncthreads();
-            for (uint32_t step = nslots >> 1; step >= 1; step >>= 1) {
-                if (slot < step) IO::store(sh, slot, C::add(IO::load(sh, slot), IO::load(sh, slot + step)));
-                __syncthreads();
-            }
-            if (slot == 0) IO::store_ref(out, (uint64_t)g * nrows_out + logJ + 1 + p, IO::load(sh, 0));
-            __syncthreads();
-        }
-    }
-    if (threadIdx.x == 0) *done = 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -1014,7 +681,6 @@ template <class C>
 __global__ __launch_bounds__(TreeBound<C>::value) void msm_rows(TailSets<C> ts, uint32_t P, uint32_t logJ, uint32_t nsum_in, uint32_t nrows_out) {
     typedef PointIO<C> IO;
     typedef typename IO::Stored St;
-    wave_prio(ts.prio);
     const St* __restrict__ rows = ts.rows[blockIdx.z];
     St* __restrict__ out = ts.sums[blockIdx.z];
     WS_DYN_SMEM(St, sh);
@@ -1038,48 +704,14 @@ __global__ __launch_bounds__(TreeBound<C>::value) void msm_rows(TailSets<C> ts, 
 // ---------------------------------------------------------------------------
 // host driver
 // ---------------------------------------------------------------------------
-static int sort_pairs(MsmScratch& S, uint64_t total, int end_bit, hipStream_t s) {
-#ifdef WSNARK_EMUL
-    (void)end_bit; (void)s;
-    std::vector<std::pair<uint32_t, uint32_t>> kv(total);
-    uint32_t* k = S.keys.as<uint32_t>(); uint32_t* v = S.vals.as<uint32_t>();
-    for (uint64_t i = 0; i < total; i++) kv[i] = {k[i], v[i]};
-    std::stable_sort(kv.begin(), kv.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; });
-    uint32_t* ko = S.keys_out.as<uint32_t>(); uint32_t* vo = S.vals_out.as<uint32_t>();
-    for (uint64_t i = 0; i < total; i++) { ko[i] = kv[i].first; vo[i] = kv[i].second; }
-    return WS_OK;
-#elif !defined(WSNARK_WITH_CUB)
-    (void)S; (void)total; (void)end_bit; (void)s;
-    set_last_error("WSNARK_MSM_SORT=cub: this library was built without hipCUB (rebuild with -DWSNARK_WITH_CUB for the A/B path)");
-    return WS_ERR_ARG;
-#else
-    size_t tmp_bytes = 0;
-    WS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, S.keys.as<uint32_t>(), S.keys_out.as<uint32_t>(),
-                                                    S.vals.as<uint32_t>(), S.vals_out.as<uint32_t>(), total, 0, end_bit, s));
-    WS_HIP_CHECK(S.sort_tmp.reserve(tmp_bytes));
-    WS_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(S.sort_tmp.p, tmp_bytes, S.keys.as<uint32_t>(), S.keys_out.as<uint32_t>(),
-                                                    S.vals.as<uint32_t>(), S.vals_out.as<uint32_t>(), total, 0, end_bit, s));
-    return WS_OK;
-#endif
-}
-
 static uint32_t pick_window(uint64_t n) {
-    const char* e = getenv("WSNARK_MSM_C");
-    if (e) { int c = atoi(e); if (c >= 4 && c <= 16) return (uint32_t)c; }
+    { const long c = tuning_get("MSM_C", 0); if (c >= 4 && c <= 16) return (uint32_t)c; }
     int lg = 0;
     while (((uint64_t)1 << (lg + 1)) <= n) lg++;
     int c = lg - 4;
     if (c < 4) c = 4;
     if (c > 16) c = 16;
     return (uint32_t)c;
-}
-
-// which field implementation the heavy kernels use: radix-2^29 (default) or the saturated 8x32
-// multiplier (WSNARK_FIELD=32; kept for A/B measurements)
-bool msm_uses_field29() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("WSNARK_FIELD"); v = (e && atoi(e) == 32) ? 0 : 1; }
-    return v == 1;
 }
 
 // ---- phase 1 (independent of the points and of the curve): digits, sort, bounds, task list ----
@@ -1103,9 +735,6 @@ struct MsmPlanInfo {
     uint32_t tP = 1, groups = 1, nrows = 0;
     bool reduce = false;
     uint32_t ntasks = 0, nmulti = 0;
-    // split plans (per-window plans of one whole MSM call): the high windows [split_k, W) are task segment 0, the low ones
-    // segment 1; 0 = one segment
-    uint32_t split_k = 0;
     bool valid = false;
 };
 // ---- asynchronous completion: the last kernel's W x nsum window sums are copied to pinned host memory
@@ -1122,17 +751,13 @@ struct MsmPending {
     size_t h_bytes = 0;
     hipEvent_t ev = nullptr;
     const void* d_points_used = nullptr;            // the (converted) point array the accumulation reads
-    hipEvent_t ev_hi = nullptr, ev_acc = nullptr;   // split launches: the high windows' sums have reached the host / segment 0 is accumulated
-    bool split = false;
     void release() {
         if (h_sums) (void)hipHostFree(h_sums);
         if (ev) (void)hipEventDestroy(ev);
-        if (ev_hi) (void)hipEventDestroy(ev_hi);
-        if (ev_acc) (void)hipEventDestroy(ev_acc);
-        h_sums = nullptr; ev = nullptr; ev_hi = nullptr; ev_acc = nullptr; h_bytes = 0; active = false;
+        h_sums = nullptr; ev = nullptr; h_bytes = 0; active = false;
         d_sums.release(); d_rows.release();
         S.buckets.release(); S.partials.release(); S.chunkS.release(); S.chunkA.release(); S.points_conv.release(); S.hot_sums.release();
-        S.hot_done.release(); S.tail_done.release();
+        S.hot_done.release();
     }
 };
 
@@ -1179,12 +804,9 @@ static int msm_finish_t(MsmPending& P, typename H::Pt* out_host) {
     const MsmPlanInfo& I = P.info;
     if (I.n == 0) { *out_host = H::infinity(); P.active = false; return WS_OK; }
     struct Done { MsmPending& p; ~Done() { p.active = false; } } done{P};   // the slot is free again whatever happens
-    static const bool trace = [] { const char* e = getenv("WSNARK_TRACE"); return e && atoi(e) == 1; }();
+    static const bool trace = tuning_get("TRACE", 0) == 1;
     const auto t_wait = std::chrono::steady_clock::now();
-    // split launches: the rows of the high windows arrive first (ev_hi); the Horner chain starts on them while the GPU is still
-    // reducing the low windows, and waits for the rest (ev) where it first needs one
-    bool waited_all = !(P.split && P.ev_hi);
-    WS_HIP_CHECK(hipEventSynchronize(waited_all ? P.ev : P.ev_hi));
+    WS_HIP_CHECK(hipEventSynchronize(P.ev));
     const auto t_tail = std::chrono::steady_clock::now();
     const HPt* sums = reinterpret_cast<const HPt*>(P.h_sums);
     if (I.flat && I.reduce) {
@@ -1253,7 +875,6 @@ static int msm_finish_t(MsmPending& P, typename H::Pt* out_host) {
     for (int wg = (int)I.Wall - 1; wg >= 0; wg--) {      // global window index; rows exist for the owned ones
         const bool owned = (uint32_t)wg >= I.w_off && ((uint32_t)wg - I.w_off) % I.w_stride == 0;
         const uint32_t krow = owned ? ((uint32_t)wg - I.w_off) / I.w_stride : 0;
-        if (owned && !waited_all && krow < I.split_k) { WS_HIP_CHECK(hipEventSynchronize(P.ev)); waited_all = true; }
         const HPt* row = owned ? &sums[(size_t)krow * rows_per_window] : nullptr;
         for (int k = (int)I.c - 1; k >= 0; k--) {
             if (started) acc = H::dbl(acc);
@@ -1263,7 +884,6 @@ static int msm_finish_t(MsmPending& P, typename H::Pt* out_host) {
             if (k == 0) { acc = H::add(acc, row[I.logJ]); started = true; }
         }
     }
-    if (!waited_all) WS_HIP_CHECK(hipEventSynchronize(P.ev));       // (nothing left to read, but the launch must be over before its slot is reused)
     *out_host = acc;
     if (trace)
         fprintf(stderr, "[wsnark trace]   msm finish (%s): waited %.3f ms for the GPU, host Horner %.3f ms\n", sizeof(HPt) > 128 ? "G2" : "G1",
@@ -1290,7 +910,7 @@ uint32_t msm_table_rows(uint32_t tc) { return tc ? (255 + tc - 1) / tc : 1; }
 // reduction) break even, and the wider window keeps one task per bucket (14-32 entries each).
 // Capped at 20: 2^21 buckets would need 8-byte grouping entries.  WSNARK_TABLE_C overrides.
 uint32_t msm_table_window(uint64_t n) {
-    if (const char* e = getenv("WSNARK_TABLE_C")) { int c = atoi(e); if (c >= 4 && c <= 22) return (uint32_t)c; }
+    { const long c = tuning_get("TABLE_C", 0); if (c >= 4 && c <= 22) return (uint32_t)c; }
     int lg = 0;
     while (((uint64_t)1 << (lg + 1)) <= n) lg++;
     int c = (n * 4 >= ((uint64_t)5 << lg)) ? lg + 1 : lg;
@@ -1306,7 +926,7 @@ uint32_t msm_table_window(uint64_t n) {
 //                    before the one msm_plan_finish runs on)
 //   msm_plan_finish  scan, scatter, per-bin sort, task list
 // msm_plan_dev is the three in a row.
-int msm_plan_begin(Lane& L, uint64_t n, WindowShard sh, hipStream_t s, uint32_t table_c, bool allow_split) {
+int msm_plan_begin(Lane& L, uint64_t n, WindowShard sh, hipStream_t s, uint32_t table_c) {
     Context* X = ctx();
     if (!X) return WS_ERR_NOINIT;
     if (!s) s = L.stream;
@@ -1334,8 +954,8 @@ int msm_plan_begin(Lane& L, uint64_t n, WindowShard sh, hipStream_t s, uint32_t 
     // trees -- on few wavefronts; its WORK only matters at full size, its DEPTH matters whenever nothing else fills the chip
     // (small sums, a rank's share of a sharded key, a stand-alone MSM).  So: chunks of 8 buckets and 2^15-bucket pieces for
     // large bucket sets (the round-2 / 3 shape), chunks of 4 and 2^11-bucket pieces below 2^18 buckets, and the pieces' rows are
-    // folded on the GPU (msm_rows) so that short pieces do not turn into host work.  WSNARK_MSM_CHUNK / WSNARK_TAIL_BITS /
-    // WSNARK_TAIL_REDUCE override (A/B: profiles/r04_*).
+    // folded on the GPU (msm_rows) so that short pieces do not turn into host work.  WSNARK_MSM_CHUNK / WSNARK_TAIL_BITS[_W]
+    // override (tests of the geometries; A/B: profiles/r04_*).
     const bool big_set = I.NB >= (1u << 18);
     uint32_t chunk = (I.flat && !big_set) ? 4u : CHUNK;
     { const long v = tuning_get("MSM_CHUNK", 0); if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32) chunk = (uint32_t)v; }
@@ -1352,16 +972,14 @@ int msm_plan_begin(Lane& L, uint64_t n, WindowShard sh, hipStream_t s, uint32_t 
     I.J = I.tNB / I.m;
     while ((1u << I.logJ) < I.J) I.logJ++;
     I.nsum = I.logJ + 1 + ((I.flat || I.tP > 1) ? 1 : 0);
-    I.reduce = I.tP > 1 && (!I.flat || tuning_get("TAIL_REDUCE", 1) != 0);
+    I.reduce = I.tP > 1;
     {
         uint32_t logP = 0;
         while ((1u << logP) < I.tP) logP++;
         I.nrows = I.reduce ? I.logJ + 1 + logP : I.nsum;
     }
-    // task length cap: a multiple of the mean bucket load (default 2x); WSNARK_MSM_LMAX_X4 = multiplier * 4 for tuning
-    uint32_t mult4 = 8;
-    if (const char* e = getenv("WSNARK_MSM_LMAX_X4")) { int v = atoi(e); if (v >= 1 && v <= 64) mult4 = (uint32_t)v; }
-    I.lmax = (uint32_t)((mult4 * (((I.flat ? total : n) + I.NB - 1) / I.NB) + 3) / 4);
+    // task length cap: twice the mean bucket load
+    I.lmax = (uint32_t)(2 * (((I.flat ? total : n) + I.NB - 1) / I.NB));
     if (I.flat && I.NB < (1u << 19) && total >= ((uint64_t)1 << 22) && total / I.NB > 64) {
         // one SMALL bucket set under many entries (a forced narrow window; the default width keeps 14-32 entries per
         // bucket): a lane per bucket would leave most of the chip idle (2^15 buckets at 2^20 pairs = 2 wavefronts per CU:
@@ -1374,15 +992,14 @@ int msm_plan_begin(Lane& L, uint64_t n, WindowShard sh, hipStream_t s, uint32_t 
     // msm_combine_small.  2^16-constraint proofs: 2.43 -> 1.95 ms together with the batched accumulation of msm_g1_launch_batch.
     // With 2^16 runs or more every SIMD has work, and sums that run beside each other already fill the issue slots -- cutting
     // further only adds combine work (measured on a rank's share of a 2^20 key over 8 ranks: 2.07 vs 2.12 ms,
-    // profiles/r03_s14_small_sums.txt).  WSNARK_MSM_SMALL_TASKS=0 switches the rule off (A/B).
+    // profiles/r03_s14_small_sums.txt).
     uint32_t lmin = 32;
     {
-        const bool small_tasks = tuning_get("MSM_SMALL_TASKS", 1) != 0;
-        if (small_tasks && I.nbuckets < (1u << 16) && total >= ((uint64_t)1 << 16)) {
+        if (I.nbuckets < (1u << 16) && total >= ((uint64_t)1 << 16)) {
             const uint32_t by_tasks = (uint32_t)((total + (1u << 17) - 1) >> 17);
             if (by_tasks < I.lmax) I.lmax = by_tasks;
             lmin = 8;
-        } else if (small_tasks && I.flat && I.nbuckets == (1u << 16) && I.lmax > 16) {
+        } else if (I.flat && I.nbuckets == (1u << 16) && I.lmax > 16) {
             // Round 4, exactly 2^16 bucket runs (a rank's share of a 2^20 key over 8 ranks, 2^17 proofs): with the shorter reduction
             // tails the accumulations are what is left of such a sum, and a lane's chain of ~30 additions (G2: 0.7 ms whatever the
             // parallelism) is their floor -- runs cut at 16 entries + the G1 sets in one launch (msm_g1_launch_batch): the rank's four
@@ -1406,7 +1023,7 @@ int msm_plan_begin(Lane& L, uint64_t n, WindowShard sh, hipStream_t s, uint32_t 
     WS_HIP_CHECK(S.tasks.reserve((size_t)I.hot_cap * sizeof(Task)));
     WS_HIP_CHECK(S.multi.reserve((size_t)I.hot_cap * sizeof(MultiBucket)));
     uint32_t hot_min = HOT_MIN;      // (WSNARK_MSM_HOT_MIN: lets small tests reach the hot-bucket path)
-    if (const char* e = getenv("WSNARK_MSM_HOT_MIN")) { int v = atoi(e); if (v >= 2) hot_min = (uint32_t)v; }
+    { const long v = tuning_get("MSM_HOT_MIN", 0); if (v >= 2) hot_min = (uint32_t)v; }
     I.hot_min = hot_min;
     WS_HIP_CHECK(S.hot.reserve(((size_t)I.hot_cap / hot_min + 16) * sizeof(HotBucket)));
 
@@ -1414,14 +1031,10 @@ int msm_plan_begin(Lane& L, uint64_t n, WindowShard sh, hipStream_t s, uint32_t 
     // [272..527] cursors
     // (the coarse-bin counts of the grouping pass follow at [1024 ..]: one memset clears both)
     uint32_t* d_cnt = S.counters.as<uint32_t>();
-    const bool use_cub = [] { const char* e = getenv("WSNARK_MSM_SORT"); return e && !strcmp(e, "cub"); }();
-#if !defined(WSNARK_WITH_CUB) && !defined(WSNARK_EMUL)
-    if (use_cub) { set_last_error("WSNARK_MSM_SORT=cub: this library was built without hipCUB (rebuild with -DWSNARK_WITH_CUB for the A/B path)"); return WS_ERR_ARG; }
-#endif
-    const uint32_t env_lo = [] { const char* e = getenv("WSNARK_MSM_LO_BITS"); return e ? (uint32_t)atoi(e) : 8u; }();
-    const uint32_t env_tile = [] { const char* e = getenv("WSNARK_MSM_TILE"); return e ? (uint32_t)atoi(e) : 1024u; }();
-    const uint32_t env_thr = [] { const char* e = getenv("WSNARK_MSM_TILE_THREADS"); return e ? (uint32_t)atoi(e) : 1024u; }();
-    const bool env_e64 = [] { const char* e = getenv("WSNARK_MSM_ENTRY64"); return e && atoi(e) != 0; }();
+    // grouping-pass geometry (swept in rounds 1-2, profiles/r01_sweep_presort_*.txt, r02_sweep_presort_geometry.txt): 1024 scalars per
+    // workgroup of 1024 threads, 8 low bucket bits sorted per bin
+    const uint32_t env_lo = 8, env_tile = 1024, env_thr = 1024;
+    const bool env_e64 = tuning_get("MSM_ENTRY64", 0) != 0;      // (tests: the 8-byte grouping entries a 2^24 table key needs, at small sizes)
     uint32_t lo_bits = env_lo > PRESORT_MAX_LO ? PRESORT_MAX_LO : env_lo;
     if (lo_bits > c - 1) lo_bits = c - 1;
     const uint32_t Wb = I.flat ? 1 : W;        // bucket sets the bins are spread over
@@ -1434,29 +1047,15 @@ int msm_plan_begin(Lane& L, uint64_t n, WindowShard sh, hipStream_t s, uint32_t 
     // large inputs (2^24 pairs): give up low bucket bits while that keeps the entries at 4 bytes and the bin count in range
     while (!env_e64 && idx_bits + 1 + lo_bits > 32 && lo_bits > 1 && (uint64_t)Wb * (I.NB >> (lo_bits - 1)) <= PRESORT_MAX_BINS) lo_bits--;
     const uint32_t HB = I.NB >> lo_bits, nbins = Wb * HB;
-    if (!use_cub && nbins <= PRESORT_MAX_BINS) {
-        // ---- grouping by coarse bins + per-bin LDS counting sort (hand-written; see the kernels above) ----
+    if (nbins > PRESORT_MAX_BINS) { set_last_error("msm: grouping pass geometry out of range"); return WS_ERR_SIZE; }
+    {
+        // ---- grouping by coarse bins + per-bin LDS counting sort (see the kernels above) ----
         const bool e32 = !env_e64 && idx_bits + 1 + lo_bits <= 32;
         WS_HIP_CHECK(S.entries.reserve(total * (e32 ? 4 : 8)));
         WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, (CNT_BINS + (size_t)nbins + 1) * 4, s));
         I.ps_valid = true;
         I.ps_lo_bits = lo_bits; I.ps_idx_bits = idx_bits; I.ps_nbins = nbins; I.ps_e32 = e32;
         I.ps_HB = HB; I.ps_tile = env_tile; I.ps_thr = env_thr;
-        // split plans: only for a whole stand-alone MSM (allow_split), per-window buckets in workgroup-aligned sets
-        // (WSNARK_MSM_SPLIT_MIN: smallest n that splits; tests lower it to reach the path at sizes the oracle finishes)
-        // Measured on MI355X (profiles/r03_s3_msm_split.txt): 2^20 pairs 2.28 ms split against 2.07 ms in one piece -- two half-size
-        // accumulations cost 2 x 0.68 ms instead of 1.21 ms (each ends in its own partly filled last round of wavefronts, and the
-        // second shares the SIMDs with the first one's tail) and that is more than the hidden tail saves.  Kept OFF by default
-        // (WSNARK_MSM_SPLIT=1 turns it on) as the recorded A/B of VERDICT r2 item 4.
-        const bool split_env = [] { const char* e = getenv("WSNARK_MSM_SPLIT"); return e && atoi(e) == 1; }();
-        const uint64_t split_min = [] { const char* e = getenv("WSNARK_MSM_SPLIT_MIN"); return e ? (uint64_t)atoll(e) : (uint64_t)1 << 14; }();
-        if (allow_split && split_env && !I.flat && I.tP == 1 && W >= 4 && I.NB >= 256 && n >= split_min) I.split_k = W / 2;
-    } else {
-        if (I.flat) { set_last_error("msm: table plans need the grouping pass (WSNARK_MSM_SORT=cub or too many bins)"); return WS_ERR_ARG; }
-        WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, (size_t)CNT_BINS * 4, s));
-        WS_HIP_CHECK(S.keys.reserve(total * 4));
-        WS_HIP_CHECK(S.vals.reserve(total * 4));
-        WS_HIP_CHECK(S.keys_out.reserve(total * 4));
     }
     (void)d_cnt; (void)hot_min; (void)lmax; (void)nbuckets;
     I.building = true;
@@ -1465,7 +1064,7 @@ int msm_plan_begin(Lane& L, uint64_t n, WindowShard sh, hipStream_t s, uint32_t 
 
 static PresortArgs plan_presort_args(const MsmPlanInfo& I, const Fe* d_scalars, uint32_t i0, uint32_t i_end) {
     return PresortArgs{d_scalars, (uint32_t)I.n, I.c, I.Wall, I.w_off, I.w_stride, i0, i_end, I.ps_lo_bits, I.ps_HB, I.ps_nbins, I.ps_tile,
-                       I.ps_idx_bits, nullptr, I.flat ? 1u : 0u, (uint32_t)tuning_get("PLAN_PRIO", kPlanPrio)};
+                       I.ps_idx_bits, nullptr, I.flat ? 1u : 0u};
 }
 
 int msm_plan_count(Lane& L, const Fe* d_scalars, uint64_t i0, uint64_t i1, hipStream_t s) {
@@ -1501,17 +1100,14 @@ int msm_plan_finish(Lane& L, const Fe* d_scalars, hipStream_t s) {
     MsmScratch& S = M.plan[M.cur].S;
     KernelTimer& T = X->timer;
     const uint64_t n = I.n, total = n * I.W;
-    const uint32_t c = I.c, nbuckets = I.nbuckets, lmax = I.lmax, hot_min = I.hot_min;
+    const uint32_t nbuckets = I.nbuckets, lmax = I.lmax, hot_min = I.hot_min;
     uint32_t* d_cnt = S.counters.as<uint32_t>();
-    bool have_hist = false;
-    int rc;
     if (I.ps_valid) {
         const uint32_t nbins = I.ps_nbins, lo_bits = I.ps_lo_bits, idx_bits = I.ps_idx_bits;
         const bool e32 = I.ps_e32;
         uint32_t* bin_count = d_cnt + CNT_BINS;
         uint32_t* bin_start = bin_count + (nbins + 1);
         uint32_t* bin_cursor = bin_start + (nbins + 1);
-        const uint32_t split_bin = I.split_k * I.ps_HB;
         const PresortArgs PA = plan_presort_args(I, d_scalars, 0u, (uint32_t)n);
         const dim3 grid(ceil_div_u64(n, I.ps_tile)), blk(I.ps_thr);
         T.begin("msm_presort_scan", s);
@@ -1522,48 +1118,27 @@ int msm_plan_finish(Lane& L, const Fe* d_scalars, hipStream_t s) {
         else hipLaunchKernelGGL(presort_scatter<uint64_t>, grid, blk, 0, s, PA, bin_cursor, S.entries.as<uint64_t>());
         T.end(s);
         // one workgroup per bin, about eight entries per thread (two rounds of four loads in flight)
-        const uint32_t env_bthr = [] { const char* e = getenv("WSNARK_MSM_BIN_THREADS"); return e ? (uint32_t)atoi(e) : 0u; }();
-        uint32_t bthr = env_bthr ? env_bthr : (uint32_t)((total / nbins / 8 + 63) / 64 * 64);
+        uint32_t bthr = (uint32_t)((total / nbins / 8 + 63) / 64 * 64);
         bthr = bthr < 64 ? 64 : bthr > 1024 ? 1024 : bthr;
         const dim3 bblk(bthr);
         T.begin("msm_presort_bins", s);
         if (e32)
             hipLaunchKernelGGL(presort_bins<uint32_t>, dim3(nbins), bblk, 0, s, S.entries.as<uint32_t>(), bin_start, lo_bits,
-                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(), lmax, d_cnt + CNT_HIST, nullptr, 0u, split_bin, PA.prio);
+                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(), lmax, d_cnt + CNT_HIST, nullptr, 0u);
         else
             hipLaunchKernelGGL(presort_bins<uint64_t>, dim3(nbins), bblk, 0, s, S.entries.as<uint64_t>(), bin_start, lo_bits,
-                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(), lmax, d_cnt + CNT_HIST, nullptr, 0u, split_bin, PA.prio);
+                               idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(), lmax, d_cnt + CNT_HIST, nullptr, 0u);
         T.end(s);
         WS_HIP_CHECK(hipGetLastError());
-        have_hist = true;
         I.ps_bthr = bthr;
     } else {
-        // ---- reference pipeline: explicit digit arrays + hipCUB radix sort (WSNARK_MSM_SORT=cub) ----
-        T.begin("msm_digits", s);
-        hipLaunchKernelGGL(msm_digits, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s, d_scalars, (uint32_t)n, c, I.Wall,
-                           I.w_off, I.w_stride, nbuckets, S.keys.as<uint32_t>(), S.vals.as<uint32_t>());
-        T.end(s);
-        WS_HIP_CHECK(hipGetLastError());
-        T.begin("msm_sort", s);
-        int key_bits = 1;
-        while (((uint64_t)1 << key_bits) <= nbuckets) key_bits++;   // keys are 0..nbuckets (nbuckets = "no digit")
-        rc = sort_pairs(S, total, key_bits, s);
-        T.end(s);
-        if (rc) return rc;
-        WS_HIP_CHECK(hipMemsetAsync(S.bstart.p, 0, (size_t)nbuckets * 4, s));
-        WS_HIP_CHECK(hipMemsetAsync(S.bend.p, 0, (size_t)nbuckets * 4, s));
-        T.begin("msm_bounds", s);
-        hipLaunchKernelGGL(msm_bounds, dim3(ceil_div_u64(total, 256)), dim3(256), 0, s, S.keys_out.as<uint32_t>(), total,
-                           nbuckets, S.bstart.as<uint32_t>(), S.bend.as<uint32_t>());
-        T.end(s);
+        set_last_error("msm_plan_finish: the plan has no grouping pass");
+        return WS_ERR_ARG;
     }
     T.begin("msm_plan", s);
-    if (!have_hist)
-        hipLaunchKernelGGL(msm_plan_hist, dim3(ceil_div_u64(nbuckets, 256)), dim3(256), 0, s, S.bstart.as<uint32_t>(),
-                           S.bend.as<uint32_t>(), nbuckets, lmax, d_cnt + CNT_HIST);
     hipLaunchKernelGGL(msm_plan_emit, dim3(ceil_div_u64(nbuckets, 256)), dim3(256), 0, s, S.bstart.as<uint32_t>(),
                        S.bend.as<uint32_t>(), nbuckets, lmax, d_cnt + CNT_HIST, d_cnt + CNT_CURSOR, S.tasks.as<Task>(), d_cnt,
-                       S.multi.as<MultiBucket>(), S.hot.as<HotBucket>(), hot_min, I.split_k * I.NB, (uint32_t)tuning_get("PLAN_PRIO", kPlanPrio));
+                       S.multi.as<MultiBucket>(), S.hot.as<HotBucket>(), hot_min);
     hipLaunchKernelGGL(msm_plan_emit_hot, dim3(64), dim3(256), 0, s, S.hot.as<HotBucket>(), d_cnt, lmax, S.tasks.as<Task>());
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
@@ -1576,9 +1151,9 @@ int msm_plan_finish(Lane& L, const Fe* d_scalars, hipStream_t s) {
 }
 
 
-int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipStream_t s, uint32_t table_c, bool allow_split) {
+int msm_plan_dev(Lane& L, const Fe* d_scalars, uint64_t n, WindowShard sh, hipStream_t s, uint32_t table_c) {
     if (n && !d_scalars) return WS_ERR_ARG;
-    int rc = msm_plan_begin(L, n, sh, s, table_c, allow_split);
+    int rc = msm_plan_begin(L, n, sh, s, table_c);
     if (!rc) rc = msm_plan_count(L, d_scalars, 0, n, s);
     if (!rc) rc = msm_plan_finish(L, d_scalars, s);
     return rc;
@@ -1610,23 +1185,22 @@ int msm_plan_variant(Lane& L, int src_id, int dst_id, const uint8_t* d_mask, hip
     WS_HIP_CHECK(S.hot.reserve(((size_t)src.hot_cap / src.hot_min + 16) * sizeof(HotBucket)));
     uint32_t* d_cnt = S.counters.as<uint32_t>();
     WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, (size_t)CNT_BINS * 4, s));
-    I.split_k = 0;
     const uint32_t* bin_start = SS.counters.as<uint32_t>() + CNT_BINS + (src.ps_nbins + 1);
     KernelTimer& T = X->timer;
     T.begin("msm_presort_bins", s);
     if (src.ps_e32)
         hipLaunchKernelGGL(presort_bins<uint32_t>, dim3(src.ps_nbins), dim3(src.ps_bthr), 0, s, SS.entries.as<uint32_t>(), bin_start,
                            src.ps_lo_bits, src.ps_idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(),
-                           src.lmax, d_cnt + CNT_HIST, d_mask, src.flat ? (uint32_t)src.n : 0u, 0u, (uint32_t)tuning_get("PLAN_PRIO", kPlanPrio));
+                           src.lmax, d_cnt + CNT_HIST, d_mask, src.flat ? (uint32_t)src.n : 0u);
     else
         hipLaunchKernelGGL(presort_bins<uint64_t>, dim3(src.ps_nbins), dim3(src.ps_bthr), 0, s, SS.entries.as<uint64_t>(), bin_start,
                            src.ps_lo_bits, src.ps_idx_bits, S.vals_out.as<uint32_t>(), S.bstart.as<uint32_t>(), S.bend.as<uint32_t>(),
-                           src.lmax, d_cnt + CNT_HIST, d_mask, src.flat ? (uint32_t)src.n : 0u, 0u, (uint32_t)tuning_get("PLAN_PRIO", kPlanPrio));
+                           src.lmax, d_cnt + CNT_HIST, d_mask, src.flat ? (uint32_t)src.n : 0u);
     T.end(s);
     T.begin("msm_plan", s);
     hipLaunchKernelGGL(msm_plan_emit, dim3(ceil_div_u64(src.nbuckets, 256)), dim3(256), 0, s, S.bstart.as<uint32_t>(),
                        S.bend.as<uint32_t>(), src.nbuckets, src.lmax, d_cnt + CNT_HIST, d_cnt + CNT_CURSOR, S.tasks.as<Task>(), d_cnt,
-                       S.multi.as<MultiBucket>(), S.hot.as<HotBucket>(), src.hot_min, 0u, (uint32_t)tuning_get("PLAN_PRIO", kPlanPrio));
+                       S.multi.as<MultiBucket>(), S.hot.as<HotBucket>(), src.hot_min);
     hipLaunchKernelGGL(msm_plan_emit_hot, dim3(64), dim3(256), 0, s, S.hot.as<HotBucket>(), d_cnt, src.lmax, S.tasks.as<Task>());
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
@@ -1635,38 +1209,13 @@ int msm_plan_variant(Lane& L, int src_id, int dst_id, const uint8_t* d_mask, hip
 }
 
 // ---- phase 2: bucket accumulation and reduction for one point set, against the current plan ----
-// accumulation + combine of one task segment of a launch (seg 2 = everything) against the launch's plan
+// accumulation + combine of up to 4 launches (one plan or its variants: same geometry) in ONE launch each
 template <class C>
-static int msm_acc_sets(Lane& L, MsmPending* const* Ps, int nsets, int which, uint32_t seg, hipStream_t s) {
+static int msm_acc_sets(Lane& L, MsmPending* const* Ps, int nsets, int which, hipStream_t s) {
     typedef typename C::PtP Pt;
     Context* X = ctx();
     MsmWorkspace& M = ws(L);
-    MsmPending& P = *Ps[0];
-    const MsmPlanInfo& I = P.info;             // (the sets share the plan's geometry: one plan or its variants)
-    MsmScratch& PS = M.plan[P.plan_id].S;
-    MsmScratch& S = P.S;
     KernelTimer& T = X->timer;
-    // bucket range of the segment: segment 0 = the high windows [split_k, W), segment 1 = the low ones
-    const uint32_t b_split = I.split_k * I.NB;
-    const uint32_t b_lo = seg == 0 ? b_split : 0u, b_hi = seg == 1 ? b_split : I.nbuckets;
-    // A/B only: the wavefront-segmented-scan shape over the same sorted stream (see msm_accumulate_segscan)
-    const bool segscan = [] { const char* e = getenv("WSNARK_ACC_SHAPE"); return e && !strcmp(e, "segscan"); }();
-    if (segscan && seg == 2 && I.ps_valid && nsets == 1) {
-        const uint64_t total_max = (uint64_t)I.n * I.W;            // worst case: no zero digit
-        WS_HIP_CHECK(S.partials.reserve((size_t)(2 * (total_max / 64 + 2)) * sizeof(Pt)));
-        const uint32_t* total_ptr = PS.counters.as<uint32_t>() + CNT_BINS + (I.ps_nbins + 1) + I.ps_nbins;      // bin_start[nbins]
-        T.begin(which ? "msm_accumulate_g2" : "msm_accumulate_g1", s);
-        hipLaunchKernelGGL(msm_accumulate_segscan<C>, dim3(ceil_div_u64(total_max, 256)), dim3(256), 0, s,
-                           reinterpret_cast<const typename C::AffP*>(P.d_points_used), PS.vals_out.as<uint32_t>(), PS.bstart.as<uint32_t>(),
-                           PS.bend.as<uint32_t>(), I.nbuckets, total_ptr, S.buckets.as<Pt>(), S.partials.as<Pt>());
-        T.end(s);
-        T.begin("msm_combine", s);
-        hipLaunchKernelGGL(msm_segscan_merge<C>, dim3(ceil_div_u64(I.nbuckets, 256)), dim3(256), 0, s, PS.bstart.as<uint32_t>(), PS.bend.as<uint32_t>(),
-                           I.nbuckets, S.partials.as<Pt>(), S.buckets.as<Pt>());
-        T.end(s);
-        WS_HIP_CHECK(hipGetLastError());
-        return WS_OK;
-    }
     AccSets<C> as;
     uint32_t ntasks = 0;
     for (int k = 0; k < 4; k++) {
@@ -1678,44 +1227,30 @@ static int msm_acc_sets(Lane& L, MsmPending* const* Ps, int nsets, int which, ui
         as.counters[k] = QS.counters.as<uint32_t>();
         as.multi[k] = QS.multi.as<MultiBucket>();
         as.hot[k] = QS.hot.as<HotBucket>();
-        as.bstart[k] = QS.bstart.as<uint32_t>();
-        as.bend[k] = QS.bend.as<uint32_t>();
         as.buckets[k] = Q.S.buckets.template as<Pt>();
         as.partials[k] = Q.S.partials.template as<Pt>();
         as.hot_sums[k] = Q.S.hot_sums.template as<Pt>();
         as.hot_done[k] = Q.S.hot_done.template as<uint32_t>();
         if (k < nsets && Q.info.ntasks > ntasks) ntasks = Q.info.ntasks;
     }
-    as.prio = (uint32_t)tuning_get("TAIL_PRIO", kTailPrio);
     const uint32_t ny = (uint32_t)nsets;
     T.begin(which ? "msm_accumulate_g2" : "msm_accumulate_g1", s);
-    hipLaunchKernelGGL(msm_accumulate<C>, dim3(ceil_div_u64(ntasks, 256), ny), dim3(256), 0, s, as, seg);
+    hipLaunchKernelGGL(msm_accumulate<C>, dim3(ceil_div_u64(ntasks, 256), ny), dim3(256), 0, s, as);
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
     T.begin("msm_combine", s);
-    if (tuning_get("COMBINE_FUSED", 1)) {
-        hipLaunchKernelGGL(msm_combine_all<C>, dim3(CB_SMALL + CB_WAVE + CB_HOT, ny), dim3(64), 0, s, as, b_lo, b_hi);
-    } else {
-        hipLaunchKernelGGL(msm_combine_small<C>, dim3(256, ny), dim3(256), 0, s, as, b_lo, b_hi);
-        hipLaunchKernelGGL(msm_combine_wave<C>, dim3(2048, ny), dim3(64), 0, s, as, b_lo, b_hi);
-        hipLaunchKernelGGL(msm_combine_hot1<C>, dim3(1024, ny), dim3(64), 0, s, as, b_lo, b_hi);
-        hipLaunchKernelGGL(msm_combine_hot2<C>, dim3(64, ny), dim3(64), 0, s, as, b_lo, b_hi);
-    }
+    hipLaunchKernelGGL(msm_combine_all<C>, dim3(CB_SMALL + CB_WAVE + CB_HOT, ny), dim3(64), 0, s, as);
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
     return WS_OK;
 }
-template <class C>
-static int msm_acc_segment(Lane& L, MsmPending& P, int which, uint32_t seg, hipStream_t s) {
-    MsmPending* one[1] = {&P};
-    return msm_acc_sets<C>(L, one, 1, which, seg, s);
-}
 
 // C = device curve (arithmetic of the kernels), H = host curve (reference-format results, host tail).
 // `prepared`: d_points are already in C's internal domain (msm_prepare_points).
+// defer_kernels: only the launch slot and its buffers are set up; the caller accumulates several such launches in ONE batched
+// launch (msm_acc_sets)
 template <class C, class H>
-static int msm_launch_acc(Lane& L, int which, const typename H::Aff* d_points_ref, bool prepared, int* slot_out, hipStream_t s, bool split_first = false,
-                          bool defer_kernels = false) {
+static int msm_launch_acc(Lane& L, int which, const typename H::Aff* d_points_ref, bool prepared, int* slot_out, hipStream_t s, bool defer_kernels = false) {
     typedef typename C::PtP Pt;      // packed accumulator in global memory (same bytes as H::Pt)
     static_assert(sizeof(typename C::PtP) == sizeof(typename H::Pt) && sizeof(typename C::AffP) == sizeof(typename H::Aff), "layouts");
     Context* X = ctx();
@@ -1737,10 +1272,9 @@ static int msm_launch_acc(Lane& L, int which, const typename H::Aff* d_points_re
     const uint64_t n = I.n;
     const uint32_t W = I.tW, nbuckets = I.nbuckets, J = I.J, nsum = I.nsum;
 
-    MsmScratch& S = P.S;                        // this launch's accumulation buffers (the plan's own are read by msm_acc_segment)
-    // Everything runs in order on the caller's stream.  Tried and measured slower on MI355X (round 1, sessions
-    // 7, 8, 11): accumulations on concurrent streams (cache thrash), and the reduction tail on a second,
-    // high-priority stream (the kernels starve each other: prove 2^20 16.4-16.7 ms vs 14.6 ms in order).
+    MsmScratch& S = P.S;                        // this launch's accumulation buffers (the plan's own are read by the kernels)
+    // Everything runs in order on the caller's stream.  Tried and measured slower on MI355X (rounds 1, 3, 5): accumulations on
+    // concurrent streams (cache thrash), and the reduction tail on another (or a high-priority) stream: docs/HISTORY.md, DESIGN.md section 5.
     WS_HIP_CHECK(S.buckets.reserve((size_t)nbuckets * sizeof(Pt)));
     WS_HIP_CHECK(S.partials.reserve((size_t)I.hot_cap * sizeof(Pt)));
     WS_HIP_CHECK(S.chunkS.reserve((size_t)W * J * sizeof(Pt)));
@@ -1759,11 +1293,10 @@ static int msm_launch_acc(Lane& L, int which, const typename H::Aff* d_points_re
     if (!P.ev) WS_HIP_CHECK(hipEventCreate(&P.ev));
     // (slots wait for hot-bucket slice sums: at most one per HOT_SLICE tasks plus one per hot bucket)
     WS_HIP_CHECK(S.hot_sums.reserve(((size_t)I.hot_cap / HOT_SLICE + (size_t)I.hot_cap / I.hot_min + 32) * sizeof(Pt)));
-    // completion counters of the fused combine / tree kernels: cleared when (re)allocated, left at zero by every launch
+    // completion counters of the combine kernel's hot-bucket stage: cleared when (re)allocated, left at zero by every launch
     {
-        const size_t hot_bytes = ((size_t)I.hot_cap / I.hot_min + 16) * 4, tail_bytes = ((size_t)I.groups * nsum + 16) * 4;
+        const size_t hot_bytes = ((size_t)I.hot_cap / I.hot_min + 16) * 4;
         if (!S.hot_done.p || S.hot_done.bytes < hot_bytes) { WS_HIP_CHECK(S.hot_done.alloc(hot_bytes)); WS_HIP_CHECK(hipMemsetAsync(S.hot_done.p, 0, hot_bytes, s)); }
-        if (!S.tail_done.p || S.tail_done.bytes < tail_bytes) { WS_HIP_CHECK(S.tail_done.alloc(tail_bytes)); WS_HIP_CHECK(hipMemsetAsync(S.tail_done.p, 0, tail_bytes, s)); }
     }
 
     KernelTimer& T = X->timer;
@@ -1777,9 +1310,9 @@ static int msm_launch_acc(Lane& L, int which, const typename H::Aff* d_points_re
         d_points = S.points_conv.as<typename C::AffP>();
     }
     P.d_points_used = d_points;
-    P.split = false;
-    if (!defer_kernels) {      // (deferred: the caller accumulates several prepared launches in ONE batched launch, msm_acc_sets)
-        int rc = msm_acc_segment<C>(L, P, which, split_first ? 0u : 2u, s);
+    if (!defer_kernels) {
+        MsmPending* one[1] = {&P};
+        int rc = msm_acc_sets<C>(L, one, 1, which, s);
         if (rc) return rc;
     }
     // the slot is taken only now: an error above (null points, a failed reserve) leaves it free
@@ -1788,21 +1321,13 @@ static int msm_launch_acc(Lane& L, int which, const typename H::Aff* d_points_re
     return WS_OK;
 }
 
-// which curve type the tail kernels are instantiated with: G1 on the radix-2^29 field uses the variant with
-// inlined products (same packed layouts), everything else the accumulation's own type
+// reduction tail (chunks, trees, [piece reduction,] copy of the rows, completion event) for up to 4 launches of one geometry.
+// G1 runs on the curve variant with inlined products, G2 on the lane-paired curve (fp2.h; same buffers, same results).
 template <class C> struct TailCurve { typedef C type; };
-#ifndef WS_TAIL_INLINE
-#define WS_TAIL_INLINE 1
-#endif
-#if WS_TAIL_INLINE
 template <> struct TailCurve<G1R29> { typedef G1R29I type; };
-#endif
-
-// reduction tail (chunks, trees, [piece reduction,] copy of the rows, completion event) for up to 4 launches of one plan
-// w0, w1: the windows [w0, w1) only -- one half of a split launch (split plans keep whole windows as pieces); its rows are
-// copied and `done` recorded
+template <> struct TailCurve<G2R29> { typedef G2P29 type; };
 template <class C>
-static int msm_launch_tail(Lane& L, const int* slot_ids, int nslots, hipStream_t s, uint32_t w0 = 0, uint32_t w1 = 0xffffffffu, hipEvent_t done = nullptr) {
+static int msm_launch_tail(Lane& L, const int* slot_ids, int nslots, hipStream_t s) {
     typedef PointIO<C> IO;
     typedef typename IO::Stored St;
     Context* X = ctx();
@@ -1818,40 +1343,26 @@ static int msm_launch_tail(Lane& L, const int* slot_ids, int nslots, hipStream_t
         ts.chunkA[k] = P.S.chunkA.template as<St>();
         ts.rows[k] = P.d_rows.template as<St>();
         ts.sums[k] = P.d_sums.template as<St>();
-        ts.done[k] = P.S.tail_done.template as<uint32_t>();
         ts.bstart[k] = ws(L).plan[P.plan_id].S.bstart.template as<uint32_t>();
         ts.bend[k] = ws(L).plan[P.plan_id].S.bend.template as<uint32_t>();
     }
-    ts.prio = (uint32_t)tuning_get("TAIL_PRIO", kTailPrio);
-    const uint32_t J = I.J, logJ = I.logJ, nsum = I.nsum, m = I.m, LPP = IO::LPP;
-    if (w1 > I.tW) w1 = I.tW;
-    const uint32_t W = w1 - w0;
+    const uint32_t J = I.J, logJ = I.logJ, nsum = I.nsum, m = I.m, LPP = IO::LPP, W = I.tW;
     KernelTimer& T = X->timer;
     T.begin("msm_chunks", s);
-    hipLaunchKernelGGL(msm_chunks<C>, dim3(ceil_div_u64((uint64_t)W * J * LPP, 256), nslots), dim3(256), 0, s, ts, w0 * J, w1 * J, m);
+    hipLaunchKernelGGL(msm_chunks<C>, dim3(ceil_div_u64((uint64_t)W * J * LPP, 256), nslots), dim3(256), 0, s, ts, W * J, m);
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
-    // one slot per element of the longest strided sum (J/2 for the masked rows), at most 64 KiB of LDS and 512 threads
+    // one slot per element of the longest strided sum (J/2 for the masked rows); 256 slots per workgroup (at 152 VGPRs a 512-thread
+    // workgroup is one per CU and a full-size tree launch takes three rounds of them; 256 threads fit three per CU: profiles/r04_s6_*)
     uint32_t tslots = 1;
-    // (256 slots per workgroup for G1 as well: at 152 VGPRs a 512-thread workgroup is one per CU and a full-size tree launch takes
-    //  three rounds of them; 256 threads fit three per CU -- prove 2^20 9.53 -> 9.51 ms, 2^16 1.55 -> 1.51-1.54, profiles/r04_s6_*)
-    uint32_t smax = 256;
-    { const long v = tuning_get("TREE_SLOTS", 0); if (v >= 32 && v <= 512) smax = (uint32_t)v; }
-    if (sizeof(St) > 128 && smax > 256) smax = 256;
+    const uint32_t smax = 256;
     while (tslots < (J > 1 ? J / 2 : 1) && tslots < smax && tslots * LPP < (uint32_t)TreeBound<C>::value) tslots <<= 1;
     T.begin("msm_tree", s);
-    // (the piece reduction fused into the tree kernel needs the whole group in ONE launch and a slot per (bit, piece) pair or a
-    //  generic loop; WSNARK_TAIL_FUSE_ROWS=0: the separate msm_rows launch of round 4)
-    const bool fuse_rows = I.reduce && w0 == 0 && W == I.tW && tuning_get("TAIL_FUSE_ROWS", 0) != 0;
-    hipLaunchKernelGGL(msm_tree<C>, dim3(nsum, W, nslots), dim3(tslots * LPP), (size_t)tslots * sizeof(St), s, ts, J, logJ, w0, I.reduce ? 0u : 1u,
-                       fuse_rows ? I.tP : 0u, I.nrows);
+    hipLaunchKernelGGL(msm_tree<C>, dim3(nsum, W, nslots), dim3(tslots * LPP), (size_t)tslots * sizeof(St), s, ts, J, logJ, I.reduce ? 0u : 1u);
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
-    size_t sums_bytes, off;
-    if (fuse_rows) {
-        sums_bytes = (size_t)I.groups * I.nrows * sizeof(St);
-        off = 0;
-    } else if (I.reduce) {
+    size_t sums_bytes;
+    if (I.reduce) {
         uint32_t rslots = 1;
         while (rslots < I.tP && rslots < smax && rslots * LPP < (uint32_t)TreeBound<C>::value) rslots <<= 1;
         T.begin("msm_rows", s);
@@ -1859,80 +1370,30 @@ static int msm_launch_tail(Lane& L, const int* slot_ids, int nslots, hipStream_t
         T.end(s);
         WS_HIP_CHECK(hipGetLastError());
         sums_bytes = (size_t)I.groups * I.nrows * sizeof(St);
-        off = 0;
     } else {
-        const size_t row_bytes = (size_t)nsum * sizeof(St);
-        sums_bytes = (size_t)W * row_bytes;
-        off = (size_t)w0 * row_bytes;
+        sums_bytes = (size_t)W * nsum * sizeof(St);
     }
     for (int k = 0; k < nslots; k++) {
         MsmPending& P = slots[slot_ids[k]];
-        WS_HIP_CHECK(hipMemcpyAsync((uint8_t*)P.h_sums + off, (const uint8_t*)P.d_sums.p + off, sums_bytes, hipMemcpyDeviceToHost, s));
-        WS_HIP_CHECK(hipEventRecord(done ? done : P.ev, s));
+        WS_HIP_CHECK(hipMemcpyAsync(P.h_sums, P.d_sums.p, sums_bytes, hipMemcpyDeviceToHost, s));
+        WS_HIP_CHECK(hipEventRecord(P.ev, s));
     }
     return WS_OK;
-}
-
-// The reduction tail of launches accumulated on `s`, enqueued on `ts` (another queue of the lane) behind an event: the next
-// full-width kernel on `s` then starts at once instead of behind a chain of ~33 dependent additions on a few hundred wavefronts.
-// (G2: the tail kernels run on the lane-paired curve unless WSNARK_G2_TAIL_PAIR=0 -- same buffers, same results)
-template <class TC> struct PairedTail { typedef TC type; static constexpr bool has = false; };
-template <> struct PairedTail<G2R29> { typedef G2P29 type; static constexpr bool has = true; };
-template <class TC>
-static int msm_launch_tail_sel(Lane& L, const int* slot_ids, int nslots, hipStream_t s, uint32_t w0 = 0, uint32_t w1 = 0xffffffffu, hipEvent_t done = nullptr) {
-    if (PairedTail<TC>::has && tuning_get("G2_TAIL_PAIR", 1) != 0)
-        return msm_launch_tail<typename PairedTail<TC>::type>(L, slot_ids, nslots, s, w0, w1, done);
-    return msm_launch_tail<TC>(L, slot_ids, nslots, s, w0, w1, done);
-}
-template <class TC>
-static int msm_tail_on(Lane& L, const int* slot_ids, int nslots, hipStream_t s, hipStream_t ts) {
-    if (!ts || ts == s) return msm_launch_tail_sel<TC>(L, slot_ids, nslots, s);
-    MsmPending& P0 = ws(L).slot[slot_ids[0]];
-    if (P0.info.n == 0) return WS_OK;
-    if (!P0.ev_acc) WS_HIP_CHECK(hipEventCreateWithFlags(&P0.ev_acc, hipEventDisableTiming));
-    WS_HIP_CHECK(hipEventRecord(P0.ev_acc, s));
-    WS_HIP_CHECK(hipStreamWaitEvent(ts, P0.ev_acc, 0));
-    return msm_launch_tail_sel<TC>(L, slot_ids, nslots, ts);
 }
 
 template <class C, class H>
-static int msm_launch(Lane& L, int which, const typename H::Aff* d_points_ref, bool prepared, int* slot_out, hipStream_t s,
-                      hipEvent_t before_tail = nullptr, hipStream_t tail_stream = nullptr) {
+static int msm_launch(Lane& L, int which, const typename H::Aff* d_points_ref, bool prepared, int* slot_out, hipStream_t s) {
     if (!s) s = L.stream;
-    typedef typename TailCurve<C>::type TC;
-    MsmWorkspace& M = ws(L);
-    // A split plan (one whole stand-alone MSM): the accumulation of the HIGH windows, then -- on the lane's second queue -- their
-    // reduction tail beside the accumulation of the LOW windows on this one.  The tail is a latency chain on a few hundred
-    // wavefronts (0.33 ms of 2.04 at 2^20); beside a full-width kernel it is hidden instead of exposed, and the host starts its
-    // Horner chain on the high rows while the low windows are still being reduced.  Only plans built with WSNARK_MSM_SPLIT=1
-    // have two segments (msm_plan_dev: measured slower than one piece, off by default).
-    const MsmPlanInfo& I = M.plan[M.cur].info;
-    const bool split = I.valid && I.n && I.split_k && !before_tail && s != L.stream2 && L.stream2;
-    int rc = msm_launch_acc<C, H>(L, which, d_points_ref, prepared, slot_out, s, split);
+    int rc = msm_launch_acc<C, H>(L, which, d_points_ref, prepared, slot_out, s);
     if (rc) return rc;
-    MsmPending& P = M.slot[*slot_out];
-    if (!split || P.info.n == 0) {
-        if (before_tail) WS_HIP_CHECK(hipEventRecord(before_tail, s));
-        rc = msm_tail_on<TC>(L, slot_out, 1, s, tail_stream);
-        if (rc) msm_abort_slots(L, slot_out, 1, s, tail_stream);
-        return rc;
-    }
-    hipStream_t s2 = L.stream2;
-    auto fail = [&](int code) { msm_abort_slots(L, slot_out, 1, s, s2); return code; };
-    if (!P.ev_hi && hipEventCreate(&P.ev_hi) != hipSuccess) return fail(WS_ERR_HIP);
-    if (!P.ev_acc && hipEventCreateWithFlags(&P.ev_acc, hipEventDisableTiming) != hipSuccess) return fail(WS_ERR_HIP);
-    P.split = true;
-    if (hipEventRecord(P.ev_acc, s) != hipSuccess || hipStreamWaitEvent(s2, P.ev_acc, 0) != hipSuccess) return fail(WS_ERR_HIP);
-    if ((rc = msm_launch_tail_sel<TC>(L, slot_out, 1, s2, P.info.split_k, P.info.tW, P.ev_hi))) return fail(rc);      // high windows: tail on queue 2
-    if ((rc = msm_acc_segment<C>(L, P, which, 1u, s))) return fail(rc);                                            // low windows: accumulate on queue 1
-    if (hipStreamWaitEvent(s, P.ev_hi, 0) != hipSuccess) return fail(WS_ERR_HIP);                                  // P.ev (recorded next) then covers both queues
-    if ((rc = msm_launch_tail_sel<TC>(L, slot_out, 1, s, 0, P.info.split_k))) return fail(rc);
-    return WS_OK;
+    rc = msm_launch_tail<typename TailCurve<C>::type>(L, slot_out, 1, s);
+    if (rc) msm_abort_slots(L, slot_out, 1, s, nullptr);
+    return rc;
 }
 
-// several G1 point sets against the current plan: accumulations back to back, then ONE batched tail
-int msm_g1_launch_batch(Lane& L, const Affine<Fq>* const* d_points, int nsets, bool prepared, int* slots, hipStream_t s,
-                        hipEvent_t before_tail, const int* plan_ids, hipStream_t tail_stream) {
+// several G1 point sets against the current plan (or, with plan_ids, against variants of one plan: same geometry): accumulations
+// back to back -- small sums: in ONE launch --, then ONE batched tail
+int msm_g1_launch_batch(Lane& L, const Affine<Fq>* const* d_points, int nsets, bool prepared, int* slots, hipStream_t s, const int* plan_ids) {
     if (!ctx()) return WS_ERR_NOINIT;
     if (nsets < 1 || nsets > 4) return WS_ERR_ARG;
     if (!s) s = L.stream;
@@ -1940,62 +1401,35 @@ int msm_g1_launch_batch(Lane& L, const Affine<Fq>* const* d_points, int nsets, b
     const int keep = M.cur;
     for (int k = 0; k < nsets; k++) slots[k] = -1;
     int rc = WS_OK;
-    // Very small sums (fewer bucket runs than the chip has lanes in one wavefront per SIMD, see msm_plan_dev): the sets are
+    // Very small sums (fewer bucket runs than the chip has lanes in one wavefront per SIMD, see msm_plan_begin): the sets are
     // accumulated by ONE launch (blockIdx.y = set) and run beside each other; from 2^16 runs on one launch per set, back to
     // back, measures better (same box, profiles/r03_s14_small_sums.txt: a rank's share of a 2^20 key over 8 ranks 2.08 vs 2.33 ms,
     // 2^18 proofs 4.15 vs 4.45 ms, 2^19 6.2 vs 6.43 ms; 2^14 / 2^16 proofs the other way: 1.55 vs 2.1 ms, 1.93 vs 2.4 ms with the
-    // shorter tasks).  WSNARK_MSM_BATCH_ACC: 0 never, 1 always, unset = by size.
+    // shorter tasks)
     const MsmPlanInfo& I0 = M.plan[plan_ids ? plan_ids[0] : M.cur].info;
-    const int batch_env = (int)tuning_get("MSM_BATCH_ACC", -1);
-    const bool batched = nsets > 1 && I0.valid && I0.n && (batch_env >= 0 ? batch_env != 0 : I0.nbuckets <= (1u << 16));
+    const bool batched = nsets > 1 && I0.valid && I0.n && I0.nbuckets <= (1u << 16);
     for (int k = 0; k < nsets && !rc; k++) {
         if (plan_ids) msm_select_plan(L, plan_ids[k]);
-        rc = msm_uses_field29() ? msm_launch_acc<G1R29, G1>(L, 0, d_points[k], prepared, &slots[k], s, false, batched)
-                                : msm_launch_acc<G1, G1>(L, 0, d_points[k], prepared, &slots[k], s, false, batched);
+        rc = msm_launch_acc<G1R29, G1>(L, 0, d_points[k], prepared, &slots[k], s, batched);
         if (plan_ids) msm_select_plan(L, keep);
     }
     if (!rc && batched) {
         MsmPending* Ps[4];
         for (int k = 0; k < nsets; k++) Ps[k] = &M.slot[slots[k]];
-        rc = msm_uses_field29() ? msm_acc_sets<G1R29>(L, Ps, nsets, 0, 2u, s) : msm_acc_sets<G1>(L, Ps, nsets, 0, 2u, s);
+        rc = msm_acc_sets<G1R29>(L, Ps, nsets, 0, s);
     }
-    if (!rc && before_tail && hipEventRecord(before_tail, s) != hipSuccess) rc = WS_ERR_HIP;
-    if (!rc) rc = msm_uses_field29() ? msm_tail_on<TailCurve<G1R29>::type>(L, slots, nsets, s, tail_stream) : msm_tail_on<G1>(L, slots, nsets, s, tail_stream);
-    if (rc) msm_abort_slots(L, slots, nsets, s, tail_stream);
+    if (!rc) rc = msm_launch_tail<TailCurve<G1R29>::type>(L, slots, nsets, s);
+    if (rc) msm_abort_slots(L, slots, nsets, s, nullptr);
     return rc;
 }
 
-// the two halves of msm_g1_launch on their own (round 5, prove.hip order 6): accumulation + combine of one point set against the
-// current plan on `s`; later ONE batched reduction tail for up to 4 such launches -- of the same tail geometry, whatever their
-// plans -- on `s` (or on tail_stream behind the accumulations queued on s so far)
-int msm_g1_acc_only(Lane& L, const Affine<Fq>* d_points, bool prepared, int* slot, hipStream_t s) {
+int msm_g1_launch(Lane& L, const Affine<Fq>* d_points, bool prepared, int* slot, hipStream_t s) {
     if (!ctx()) return WS_ERR_NOINIT;
-    if (msm_uses_field29()) return msm_launch_acc<G1R29, G1>(L, 0, d_points, prepared, slot, s);
-    return msm_launch_acc<G1, G1>(L, 0, d_points, prepared, slot, s);
+    return msm_launch<G1R29, G1>(L, 0, d_points, prepared, slot, s);
 }
-bool msm_same_tail_geometry(Lane& L, int slot_a, int slot_b) {
-    if (!L.msm || slot_a < 0 || slot_b < 0 || slot_a >= kPendingSlots || slot_b >= kPendingSlots) return false;
-    const MsmPlanInfo &A = L.msm->slot[slot_a].info, &B = L.msm->slot[slot_b].info;
-    return A.n && B.n && A.flat == B.flat && A.c == B.c && A.m == B.m && A.J == B.J && A.tW == B.tW && A.tP == B.tP && A.groups == B.groups &&
-           A.nsum == B.nsum && A.nrows == B.nrows && A.reduce == B.reduce && A.nbuckets == B.nbuckets;
-}
-int msm_g1_tail(Lane& L, const int* slots, int nslots, hipStream_t s, hipStream_t tail_stream) {
+int msm_g2_launch(Lane& L, const Affine<Fq2>* d_points, bool prepared, int* slot, hipStream_t s) {
     if (!ctx()) return WS_ERR_NOINIT;
-    if (nslots < 1 || nslots > 4) return WS_ERR_ARG;
-    if (!s) s = L.stream;
-    int rc = msm_uses_field29() ? msm_tail_on<TailCurve<G1R29>::type>(L, slots, nslots, s, tail_stream) : msm_tail_on<G1>(L, slots, nslots, s, tail_stream);
-    if (rc) msm_abort_slots(L, slots, nslots, s, tail_stream);
-    return rc;
-}
-int msm_g1_launch(Lane& L, const Affine<Fq>* d_points, bool prepared, int* slot, hipStream_t s, hipStream_t tail_stream) {
-    if (!ctx()) return WS_ERR_NOINIT;
-    if (msm_uses_field29()) return msm_launch<G1R29, G1>(L, 0, d_points, prepared, slot, s, nullptr, tail_stream);
-    return msm_launch<G1, G1>(L, 0, d_points, prepared, slot, s, nullptr, tail_stream);
-}
-int msm_g2_launch(Lane& L, const Affine<Fq2>* d_points, bool prepared, int* slot, hipStream_t s, hipEvent_t before_tail, hipStream_t tail_stream) {
-    if (!ctx()) return WS_ERR_NOINIT;
-    if (msm_uses_field29()) return msm_launch<G2R29, G2>(L, 1, d_points, prepared, slot, s, before_tail, tail_stream);
-    return msm_launch<G2, G2>(L, 1, d_points, prepared, slot, s, before_tail, tail_stream);
+    return msm_launch<G2R29, G2>(L, 1, d_points, prepared, slot, s);
 }
 static MsmPending* live_slot(Lane& L, int slot, int which) {
     if (!L.msm || slot < 0 || slot >= kPendingSlots) return nullptr;
@@ -2050,7 +1484,7 @@ int msm_prepare_points(int which, void* d_points, uint64_t n, hipStream_t s) {
     Context* X = ctx();
     if (!X) return WS_ERR_NOINIT;
     if (!s) s = X->stream;
-    if (!msm_uses_field29() || n == 0) return WS_OK;
+    if (n == 0) return WS_OK;
     if (which == 0) {
         hipLaunchKernelGGL(msm_convert_points<G1R29>, dim3(ceil_div_u64(n, 256)), dim3(256), 0, s,
                            (const G1R29::AffP*)d_points, (G1R29::AffP*)d_points, n);
@@ -2151,57 +1585,10 @@ __global__ __launch_bounds__(256) void msm_table_norm_kernel(typename C::AffP* _
         table[(uint64_t)(w0 + k) * n + base + i] = C::pack_aff(typename C::Aff{F::mul(q.x, izz), F::mul(q.y, izzz)});
     }
 }
-// The same two launches on Jacobian coordinates (curve.h: dbl_jac -- a third fewer multiply-adds per doubling; the slab holds X, Y, Z):
-// rows are normalised through 1/Z (x = X / Z^2, y = Y / Z^3), one inversion per lane behind the product of the group's Z as before.
-// The affine rows are canonical field elements either way: bit-identical tables.
-template <class C>
-__global__ __launch_bounds__(256) void msm_table_step_jac_kernel(const typename C::AffP* __restrict__ row0, Jac<typename C::Field>* __restrict__ tmp,
-                                                                 uint64_t cnt, uint64_t S, uint32_t c, int src, uint32_t dst) {
-    typedef typename C::Field F;
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cnt) return;
-    const typename C::Aff p0 = C::unpack_aff(row0[i]);
-    if (C::aff_is_inf(p0)) return;
-    Jac<F> P = src < 0 ? Jac<F>{p0.x, p0.y, F::one()} : tmp[(uint64_t)src * S + i];
-    for (uint32_t d = 0; d < c; d++) P = C::dbl_jac(P);
-    tmp[(uint64_t)dst * S + i] = P;
-}
-template <class C>
-__global__ __launch_bounds__(256) void msm_table_norm_jac_kernel(typename C::AffP* __restrict__ table, uint64_t n, uint64_t base, uint64_t cnt,
-                                                                 const Jac<typename C::Field>* __restrict__ tmp, uint64_t S, uint32_t w0, uint32_t g) {
-    typedef typename C::Field F;
-    typedef typename F::El El;
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cnt) return;
-    const typename C::AffP p0p = table[base + i];
-    if (C::aff_is_inf(C::unpack_aff(p0p))) {
-        for (uint32_t k = 0; k < g; k++) table[(uint64_t)(w0 + k) * n + base + i] = p0p;
-        return;
-    }
-    El pre[TABLE_GROUP];
-    El run = F::one();
-    for (uint32_t k = 0; k < g; k++) {
-        pre[k] = run;
-        run = F::mul(run, tmp[(uint64_t)k * S + i].z);
-    }
-    El inv = F::inv(run);
-    for (int k = (int)g - 1; k >= 0; k--) {
-        const Jac<F> q = tmp[(uint64_t)k * S + i];
-        const El iz = F::mul(inv, pre[k]);
-        inv = F::mul(inv, q.z);
-        const El izz = F::sqr(iz);
-        table[(uint64_t)(w0 + k) * n + base + i] = C::pack_aff(typename C::Aff{F::mul(q.x, izz), F::mul(q.y, F::mul(izz, iz))});
-    }
-}
 size_t msm_table_scratch_bytes(uint64_t lanes) { return (size_t)TABLE_GROUP * lanes * sizeof(G2R29::Pt); }
 template <class C>
 static void table_stepped(typename C::AffP* table, uint64_t n, uint32_t tc, uint32_t rows, hipStream_t s, void* d_tmp, size_t tmp_bytes) {
     typename C::Pt* tmp = (typename C::Pt*)d_tmp;
-    Jac<typename C::Field>* tmpj = (Jac<typename C::Field>*)d_tmp;      // (three coordinates instead of four: the same slab, same S)
-    // OFF by default: the one A/B this round had GPU time for (profiles/r04_s10_build_slab_ab.txt, a noisy box, proofs running beside
-    // the build) gave 219.6 ms against the XYZZ build's 211.3 -- under 2^16-lane slabs the build runs at 1-2 wavefronts per SIMD and is
-    // latency-bound, so a third fewer instructions did not show.  Same rows, bit for bit (tests/test_prove_cpu.py); to be re-measured.
-    const bool jac = tuning_get("TABLE_JACOBIAN", 0) != 0;
     uint64_t S = tmp_bytes / ((size_t)TABLE_GROUP * sizeof(typename C::Pt));
     S &= ~(uint64_t)63;
     for (uint64_t base = 0; base < n; base += S) {
@@ -2211,12 +1598,10 @@ static void table_stepped(typename C::AffP* table, uint64_t n, uint32_t tc, uint
         for (uint32_t w0 = 1; w0 < rows; w0 += TABLE_GROUP) {
             const uint32_t g = rows - w0 < TABLE_GROUP ? rows - w0 : TABLE_GROUP;
             for (uint32_t k = 0; k < g; k++) {
-                if (jac) hipLaunchKernelGGL(msm_table_step_jac_kernel<C>, grid, dim3(256), 0, s, table + base, tmpj, cnt, S, tc, src, k);
-                else hipLaunchKernelGGL(msm_table_step_kernel<C>, grid, dim3(256), 0, s, table + base, tmp, cnt, S, tc, src, k);
+                hipLaunchKernelGGL(msm_table_step_kernel<C>, grid, dim3(256), 0, s, table + base, tmp, cnt, S, tc, src, k);
                 src = (int)k;
             }
-            if (jac) hipLaunchKernelGGL(msm_table_norm_jac_kernel<C>, grid, dim3(256), 0, s, table, n, base, cnt, tmpj, S, w0, g);
-            else hipLaunchKernelGGL(msm_table_norm_kernel<C>, grid, dim3(256), 0, s, table, n, base, cnt, tmp, S, w0, g);
+            hipLaunchKernelGGL(msm_table_norm_kernel<C>, grid, dim3(256), 0, s, table, n, base, cnt, tmp, S, w0, g);
         }
     }
 }
@@ -2228,7 +1613,6 @@ int msm_build_table(int which, void* d_table, uint64_t n, uint32_t tc, hipStream
     if (!s) s = X->stream;
     const uint32_t rows = msm_table_rows(tc);
     if (n == 0 || rows < 2) return WS_OK;
-    if (!msm_uses_field29()) { set_last_error("msm: fixed-base tables are built on the radix-2^29 field"); return WS_ERR_ARG; }
     if (d_tmp && tmp_bytes >= msm_table_scratch_bytes(64)) {
         if (which == 0) table_stepped<G1R29>((G1R29::AffP*)d_table, n, tc, rows, s, d_tmp, tmp_bytes);
         else table_stepped<G2R29>((G2R29::AffP*)d_table, n, tc, rows, s, d_tmp, tmp_bytes);
@@ -2246,7 +1630,7 @@ template <class CD, class AffT>
 static int convert_beside_plan(Lane& L, const AffT* d_points, uint64_t n, hipStream_t s, const AffT** out, bool* prepared) {
     Context* X = ctx();
     *out = d_points;
-    if (*prepared || !msm_uses_field29() || !CD::Field::kInternalDomain || n < (1u << 14) || s == L.stream2) return WS_OK;
+    if (*prepared || !CD::Field::kInternalDomain || n < (1u << 14) || s == L.stream2) return WS_OK;
     MsmWorkspace& M = ws(L);
     for (auto& e : M.conv_ev) if (!e) WS_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     WS_HIP_CHECK(M.conv_buf.reserve((size_t)n * sizeof(typename CD::AffP)));
@@ -2274,7 +1658,7 @@ static int msm_dev_t(Lane& L, int which, const Fe* d_scalars, const typename H::
     msm_select_plan(L, 0);
     int rc = convert_beside_plan<CD>(L, d_points, n, s, &pts, &prepared);
     if (rc) return rc;
-    if ((rc = msm_plan_dev(L, d_scalars, n, sh, s, 0, true))) return rc;
+    if ((rc = msm_plan_dev(L, d_scalars, n, sh, s, 0))) return rc;
     if (prepared) WS_HIP_CHECK(hipStreamWaitEvent(s, ws(L).conv_ev[1], 0));
     int slot = -1;
     rc = which == 0 ? msm_g1_launch(L, reinterpret_cast<const Affine<Fq>*>(pts), prepared, &slot, s)
@@ -2311,7 +1695,7 @@ static int msm_host_t(Lane& L, int which, const void* h_scalars, const void* h_p
     int rc = upload_staged(L.host_in[0].p, h_scalars, (size_t)n * 32, s);
     if (rc) return rc;
     msm_select_plan(L, 0);
-    if ((rc = msm_plan_dev(L, L.host_in[0].as<Fe>(), n, sh, s, 0, true))) return rc;
+    if ((rc = msm_plan_dev(L, L.host_in[0].as<Fe>(), n, sh, s, 0))) return rc;
     if ((rc = upload_staged(L.host_in[1].p, h_points, (size_t)n * sizeof(typename H::Aff), s2))) return rc;
     WS_HIP_CHECK(hipEventRecord(M.host_ev, s2));
     WS_HIP_CHECK(hipStreamWaitEvent(s, M.host_ev, 0));

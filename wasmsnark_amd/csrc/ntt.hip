@@ -361,12 +361,13 @@ static int upload(DevBuf& b, const std::vector<Fe>& v, hipStream_t s) {
 static int build_plan(int bits, NttPlan& P, hipStream_t s) {
     P.bits = bits;
     P.np = bits <= LOG_LMAX ? 1 : (bits <= 16 ? 2 : (bits <= 24 ? 3 : 4));
-    { const long v = tuning_get("NTT_NP", 0); if (v >= 1 && v <= 4 && (int)v * LOG_LMAX >= bits && (int)v <= bits) P.np = (int)v; }   // (A/B: fewer, longer passes)
+    // (2^20 in TWO passes of 2^10 was measured in round 5: 0.164 ms per transform against 0.157 in three, whole proofs 9.98 against
+    //  9.70 ms -- profiles/r05_schedule_experiments.txt: ten butterfly stages per tile cost a pass more LDS round trips than they save)
     int basek = bits / P.np, rem = bits % P.np;
     for (int d = 0; d < P.np; d++) P.k[d] = basek + (d < rem ? 1 : 0);
     P.h = (bits + 1) / 2;
     P.hc = (bits + 1) / 2;
-    P.field29 = msm_uses_field29();
+    P.field29 = true;       // (the saturated 4 x 64 transform kernels were an A/B path of rounds 1-3; the default build no longer carries them)
     const bool f29 = P.field29;
     std::vector<Fe> tmp;
     for (int dir = 0; dir < 2; dir++) {
@@ -570,7 +571,7 @@ int ntt_run(Lane& L, const Fe* d_src, const Fe* d_in2, Fe* d_data, const Fe* com
             }
         }
         // tile: 2^tile_log elements of LDS
-        static const int tile_log = [] { const char* e = getenv("WSNARK_NTT_TILE_LOG"); int v = e ? atoi(e) : 10; return (v >= 9 && v <= 11) ? v : 10; }();   // 1024-element tiles (36 KiB): four workgroups per CU hide each other's load/store phases (2^22 pair 1.34 -> 1.30 ms vs 2048)
+        static const int tile_log = 10;   // 1024-element tiles (36 KiB): four workgroups per CU hide each other's load/store phases (2^22 pair 1.34 -> 1.30 ms vs 2048)
         int log_T = tile_log - (int)A.log_L;
         if (log_T > 5) log_T = 5;
         if (log_T < 0) log_T = 0;
@@ -587,16 +588,12 @@ int ntt_run(Lane& L, const Fe* d_src, const Fe* d_in2, Fe* d_data, const Fe* com
         C->timer.begin(last ? "ntt_pass_last" : "ntt_pass", s);
         if (P->field29) {
             const size_t smem = elems * LdsTile<Fr29>::kBytes;
-            static std::atomic<bool> attr_set{false};   // (two lanes may both set it once: same value)
-            if (!attr_set) {   // 2048-element tiles need 72 KiB of dynamic LDS (> the 64 KiB default cap)
+            if (!C->ntt_attr_set) {   // (per device; two lanes may both set it once: same value)  2048-element tiles would need 72 KiB of dynamic LDS (> the 64 KiB default cap)
                 WS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<Fr29>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * 36));
-                attr_set = true;
+                C->ntt_attr_set = true;
             }
             hipLaunchKernelGGL(ntt_pass_kernel<Fr29>, dim3(grid, (uint32_t)count), dim3(512 >> (11 - tile_log)), smem, s, A);
-        } else {
-            const size_t smem = elems * LdsTile<Fr>::kBytes;
-            hipLaunchKernelGGL(ntt_pass_kernel<Fr>, dim3(grid, (uint32_t)count), dim3(512), smem, s, A);
         }
         C->timer.end(s);
         WS_HIP_CHECK(hipGetLastError());

@@ -20,6 +20,7 @@
 namespace wsnark {
 
 struct ProvingKey {
+    Context* owner = nullptr;      // the context (device) the key is resident on: every call on the handle runs there
     uint32_t n_vars = 0, n_public = 0, domain = 0;
     Affine<Fq> alfa1, beta1, delta1;
     Affine<Fq2> beta2, delta2;
@@ -64,46 +65,38 @@ struct ProvingKey {
 
 // which window width a call that starts NOW may plan with: the tables' once they are built (wait = block until they are: calls
 // whose partial results must mean the same on every rank), 0 = the plain sections
-static void pkey_table_state(ProvingKey* K, bool wait, uint32_t* cw, uint32_t* ch) {
+// A call that WAITS does so because its partial sums must mean the same on every rank (window shards): if the rows cannot be had,
+// it fails instead of falling back to the plain sections' window width behind its peers' backs.
+static int pkey_table_state(ProvingKey* K, bool wait, uint32_t* cw, uint32_t* ch) {
     *cw = K->table_cw; *ch = K->table_ch;
-    if (!K->table_cw) return;
+    if (!K->table_cw && !K->table_ch) return WS_OK;
     int st = K->tables_ready.load(std::memory_order_acquire);
 #ifdef WSNARK_EMUL
     // (the emulator's "queue" has run the build by the time the load returns; tests hold a key in the not-yet-ready state with this
     //  switch to drive the plain-sections path of a table-layout key and the calls that wait)
-    if (!wait && tuning_get("EMUL_TABLES_PENDING", 0)) { *cw = *ch = 0; return; }
+    if (!wait && tuning_get("EMUL_TABLES_PENDING", 0)) { *cw = *ch = 0; return WS_OK; }
 #endif
-    if (st == 1) return;
+    if (st == 1) return WS_OK;
     if (st == 0) {
         if (wait ? hipEventSynchronize(K->ev_tables) == hipSuccess : hipEventQuery(K->ev_tables) == hipSuccess) {
             K->tables_ready.store(1, std::memory_order_release);
-            return;
+            return WS_OK;
         }
         (void)hipGetLastError();      // (hipErrorNotReady is not an error here)
     }
     *cw = *ch = 0;
+    if (wait) { set_last_error("proving key: the fixed-base table rows could not be built (the key serves whole proofs from its plain sections)"); return WS_ERR_HIP; }
+    return WS_OK;
 }
+Context* pkey_context(const ProvingKey* K) { return K ? K->owner : nullptr; }
 int pkey_wait_tables(ProvingKey* K) {
     uint32_t cw, ch;
-    pkey_table_state(K, true, &cw, &ch);
-    if (K->table_cw && !cw) { set_last_error("proving key: the fixed-base table rows could not be built (the key serves proofs from its plain sections)"); return WS_ERR_HIP; }
-    return WS_OK;
+    return pkey_table_state(K, true, &cw, &ch);
 }
 
 const std::string& get_last_error();
 
 static bool range_ok(uint64_t off, uint64_t bytes, size_t len) { return off <= len && bytes <= len - off; }
-
-struct KeySections {      // everything wsnark_pkey_load reads from proving_key.bin, as separate host buffers
-    uint32_t n_vars, n_public, domain;
-    const uint8_t *alfa1, *beta1, *delta1, *beta2, *delta2;
-    const uint8_t* polsA; uint64_t lenA;
-    const uint8_t* polsB; uint64_t lenB;
-    const uint8_t *A, *B1, *B2, *Cpts, *H;     // nVars, nVars, nVars, nVars-nPublic-1, domain points
-    uint64_t lenPA, lenPB1, lenPB2, lenPC, lenPH;   // bytes the caller vouches for behind each of those
-};
-
-struct KeyShard { uint32_t rank = 0, world = 1, h_log_m = 0; };
 
 int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
     Context* C = ctx();
@@ -119,6 +112,7 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
         return WS_ERR_FORMAT;
     }
     std::unique_ptr<ProvingKey> K(new ProvingKey());
+    K->owner = C;
     K->n_vars = nv; K->n_public = np; K->domain = dom;
     // the rank's share: floor(n / world) pairs per rank, the remainder to the last one (src/bn128.js:354-361)
     K->shard_rank = shard.rank; K->shard_world = shard.world;
@@ -147,15 +141,15 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
     memcpy(&K->delta2, S.delta2, 128);
     hipStream_t s = C->stream;
     size_t used = 0;
-    // WSNARK_KEY_TABLE=0: plain sections.  Otherwise tables, when they fit: at most WSNARK_TABLE_MAX_GB (default 160) and
-    // half of the memory that is free now
+    // Which sections become fixed-base tables -- what the key's resident memory buys (the sweep: profiles/r05_table_sweep.txt):
+    // WSNARK_KEY_TABLE=1 (default) all five, 0 none (plain sections), 2 the hExps only, 3 A / B1 / B2 / C only.  Tables must fit:
+    // at most WSNARK_TABLE_MAX_GB (default 160) and half of the memory that is free now.
     {
-        const char* e = getenv("WSNARK_KEY_TABLE");
-        if ((!e || atoi(e) != 0) && msm_uses_field29() && !(getenv("WSNARK_MSM_SORT") && !strcmp(getenv("WSNARK_MSM_SORT"), "cub"))) {
-            const uint32_t cw = msm_table_window(nl ? nl : 1), ch = msm_table_window(hl ? hl : 1);
+        const long which = tuning_get("KEY_TABLE", 1);
+        if (which != 0) {
+            const uint32_t cw = (which == 1 || which == 3) ? msm_table_window(nl ? nl : 1) : 0, ch = (which == 1 || which == 2) ? msm_table_window(hl ? hl : 1) : 0;
             const uint64_t bytes = (uint64_t)nl * 320 * msm_table_rows(cw) + (uint64_t)hl * 64 * msm_table_rows(ch);
-            const char* g = getenv("WSNARK_TABLE_MAX_GB");
-            const uint64_t cap = (uint64_t)((g ? atof(g) : 160.0) * 1073741824.0);
+            const uint64_t cap = (uint64_t)tuning_get("TABLE_MAX_GB", 160) << 30;
             size_t free_b = 0, total_b = 0;
             WS_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
             if (bytes <= cap && bytes <= free_b / 2 && (uint64_t)msm_table_rows(cw) * nl < ((uint64_t)1 << 31) &&
@@ -167,8 +161,9 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
     }
     typedef std::chrono::steady_clock Clock;
     const auto t_begin = Clock::now();
+    bool lap_failed = false;                       // an asynchronous fault of the uploads / conversion kernels surfaces in these drains
     auto lap = [&](Clock::time_point& from) {      // ms since `from`, after the queue has drained; `from` moves on
-        (void)hipStreamSynchronize(s);
+        if (hipStreamSynchronize(s) != hipSuccess) { lap_failed = true; (void)hipGetLastError(); }
         const auto now = Clock::now();
         const double ms = std::chrono::duration<double, std::milli>(now - from).count();
         from = now;
@@ -198,11 +193,11 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
         }
         if (err == hipSuccess) break;
         (void)hipGetLastError();
-        if (!K->table_cw) { set_last_error("proving key: device allocation of the point sections failed"); return WS_ERR_HIP; }
+        if (!K->table_cw && !K->table_ch) { set_last_error("proving key: device allocation of the point sections failed"); return WS_ERR_HIP; }
         for (auto& sc : secs) sc.d->release();
         K->table_cw = K->table_ch = 0;
     }
-    const bool trace_load = getenv("WSNARK_TRACE") && atoi(getenv("WSNARK_TRACE")) == 1;
+    const bool trace_load = tuning_get("TRACE", 0) == 1;
     auto since = [&](Clock::time_point from) { return std::chrono::duration<double, std::milli>(Clock::now() - from).count(); };
     if (trace_load) fprintf(stderr, "[wsnark trace] key load: device buffers allocated at %.2f ms\n", since(t_begin));
     std::vector<uint8_t> h_gather;
@@ -237,8 +232,7 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
     if ((rc = msm_points_mask(K->pointsA.as<Affine<Fq>>(), nullptr, nl, K->maskA.as<uint8_t>(), &K->infA, s))) return rc;
     if ((rc = msm_points_mask(K->pointsB1.as<Affine<Fq>>(), K->pointsB2.as<Affine<Fq2>>(), nl, K->maskB.as<uint8_t>(), &K->infB, s))) return rc;
     {
-        const char* e = getenv("WSNARK_PROVE_SPARSE");
-        const int mode = e ? atoi(e) : 1;
+        const int mode = (int)tuning_get("PROVE_SPARSE", 1);
         const bool big = nl >= (1u << 14);
         K->sparseA = mode == 2 || (mode == 1 && big && (uint64_t)K->infA * 100 >= (uint64_t)nl * 15);   // saves a share of one G1 sum
         K->sparseB = mode == 2 || (mode == 1 && big && (uint64_t)K->infB * 100 >= (uint64_t)nl * 5);    // ... of a G1 and a G2 sum
@@ -273,11 +267,12 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
         if (rcb) { set_last_error(err_b); return rcb; }
     }
     K->load_ms[0] = lap(t_phase);               // (also drains `s`: sections resident and converted -- proofs may start)
+    if (lap_failed) { set_last_error("proving key: a HIP error surfaced while the sections were uploaded and converted"); return WS_ERR_HIP; }
     if (trace_load) fprintf(stderr, "[wsnark trace] key load: matrices transposed at %.2f ms\n", since(t_begin));
-    if (K->table_cw) {
+    if (K->table_cw || K->table_ch) {
         // Rows 1.. of the tables, from row 0, in that domain: queued on the CONTEXT's build queue (lowest stream priority; `s` is
         // drained by the lap above), one key's build after the other, in short launches (a row per launch) through the context's
-        // scratch slab.  TABLE_STEPPED=0: the one long kernel per section.  No stream-ordered allocation anywhere near this: an earlier
+        // scratch slab (the one long kernel per section only if the slab cannot be had).  No stream-ordered allocation anywhere near this: an earlier
         // version of this round took the slab from hipMallocAsync / hipFreeAsync (and the matrices' temporaries likewise), and the Node
         // suite -- many small keys loaded back to back, their builds still running under later proofs -- then produced a WRONG proof in
         // 3 to 36 of 60 runs, depending on how long the builds overlapped later loads and proofs; with plain allocations 0 of 120
@@ -288,7 +283,7 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
         hipStream_t b = C->build_q;
         void* tmp = nullptr;
         size_t tmp_bytes = 0;
-        if (tuning_get("TABLE_STEPPED", 1)) {
+        {
             // lanes per slab = how much of the chip the build holds at a time.  Measured at 2^20 (tools/build_slab_ab.sh): 2^18 lanes
             // (1024-2048 workgroups in flight) -- proofs beside the build 19-23 ms, build 166 ms; 2^16 -- 16-17 ms, 189 ms; 2^15 --
             // 14-15 ms, 264 ms (and 8x the launches).  Default 2^16, growing with the key so that the build stays ~2 700 launches
@@ -319,7 +314,7 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
             return rc ? rc : (int)WS_ERR_HIP;
         }
     }
-    if (K->table_cw && tuning_get("TABLE_ASYNC", 1) == 0) {
+    if ((K->table_cw || K->table_ch) && tuning_get("TABLE_ASYNC", 1) == 0) {
         if (K->tables_ready.load() == 0) {
             WS_HIP_CHECK(hipEventSynchronize(K->ev_tables));
             K->tables_ready.store(1);
@@ -331,8 +326,8 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
     return WS_OK;
 }
 
-int pkey_load(const uint8_t* buf, size_t len, ProvingKey** out) {
-    if (!ctx()) return WS_ERR_NOINIT;
+// the sections of a proving_key.bin image (the reference's file format, tools/buildpkey.js:124-240), bounds checked
+int pkey_parse(const uint8_t* buf, size_t len, KeySections* out) {
     if (!buf || !out) return WS_ERR_ARG;
     // 10 x u32 header (src/bn128.js:581-591), then alfa1, beta1, delta1 (3 x 64 B), beta2, delta2 (2 x 128 B)
     if (len < 40 + 448) { set_last_error("proving key shorter than its fixed header"); return WS_ERR_FORMAT; }
@@ -349,10 +344,18 @@ int pkey_load(const uint8_t* buf, size_t len, ProvingKey** out) {
         return WS_ERR_FORMAT;
     }
     // true section bounds from the header (the reference slices over-long: src/bn128.js:592-593)
-    KeySections S{nv, np, dom, buf + 40, buf + 104, buf + 168, buf + 232, buf + 360,
-                  buf + pPolsA, pPolsB - pPolsA, buf + pPolsB, pA - pPolsB,
-                  buf + pA, buf + pB1, buf + pB2, buf + pC, buf + pH,
-                  len - pA, len - pB1, len - pB2, len - pC, len - pH};
+    *out = KeySections{nv, np, dom, buf + 40, buf + 104, buf + 168, buf + 232, buf + 360,
+                       buf + pPolsA, pPolsB - pPolsA, buf + pPolsB, pA - pPolsB,
+                       buf + pA, buf + pB1, buf + pB2, buf + pC, buf + pH,
+                       len - pA, len - pB1, len - pB2, len - pC, len - pH};
+    return WS_OK;
+}
+int pkey_load(const uint8_t* buf, size_t len, ProvingKey** out) {
+    if (!ctx()) return WS_ERR_NOINIT;
+    if (!out) return WS_ERR_ARG;
+    KeySections S;
+    int rc = pkey_parse(buf, len, &S);
+    if (rc) return rc;
     return pkey_load_sections(S, out, KeyShard{});
 }
 
@@ -374,7 +377,7 @@ void pkey_load_stats(const ProvingKey* K, double* out5) {
     memcpy(out5, K->load_ms, sizeof K->load_ms);
     // a background build reports its duration once it is over (0 until then)
     const int st = K->tables_ready.load(std::memory_order_acquire);      // (2: the event is not recorded yet; -1: never will be)
-    if (K->table_cw && out5[3] == 0 && K->ev_tables && (st == 0 || st == 1) && hipEventQuery(K->ev_tables) == hipSuccess) {
+    if ((K->table_cw || K->table_ch) && out5[3] == 0 && K->ev_tables && (st == 0 || st == 1) && hipEventQuery(K->ev_tables) == hipSuccess) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, K->ev_build0, K->ev_tables) == hipSuccess) out5[3] = ms;
     } else {
@@ -423,7 +426,7 @@ static void store_plain(uint8_t* dst, const Fe& mont) {
 struct Trace {
     bool on;
     std::chrono::steady_clock::time_point t0, last;
-    Trace() : on(getenv("WSNARK_TRACE") && atoi(getenv("WSNARK_TRACE")) == 1) { t0 = last = std::chrono::steady_clock::now(); }
+    Trace() : on(tuning_get("TRACE", 0) == 1) { t0 = last = std::chrono::steady_clock::now(); }
     void mark(const char* what) {
         if (!on) return;
         auto now = std::chrono::steady_clock::now();
@@ -467,16 +470,14 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
     // tables or plain sections: decided once per proof (a window-sharded call waits for the tables: its partial sums must mean
     // the same on every rank)
     uint32_t table_cw, table_ch;
-    pkey_table_state(K, sh.off != 0 || sh.stride != 1, &table_cw, &table_ch);
+    int rc = pkey_table_state(K, sh.off != 0 || sh.stride != 1, &table_cw, &table_ch);
+    if (rc) return rc;
     const Fe* d_witness_all = d_witness;
     d_witness += K->lo;
     if (K->shard_world > 1 && (sh.off != 0 || sh.stride != 1)) { set_last_error("prove: a points-sharded key cannot be window-sharded as well"); return WS_ERR_ARG; }
     if (K->h_log_m && !skip_h && !calc_h) { set_last_error("prove: this handle holds an interleaved hExps slice (distributed CALC_H only)"); return WS_ERR_ARG; }
-    int rc;
-    // WSNARK_PROVE_OVERLAP: 0 = one queue; 1 = the second queue (CALC_H, H) is released when the first batched tail starts;
-    // 2 (default) = released at once.  Round-2 sweep on the dense 2^20 key, after the finish-order fix below:
-    // 2: 11.26 ms, 1: 11.34 ms (plain queues); with a high-priority second queue 2: 11.6 ms, 1: 11.3 ms.
-    const int overlap = (int)tuning_get("PROVE_OVERLAP", 2);
+    // WSNARK_PROVE_OVERLAP=0: everything on one queue (bench.py's pass that times every kernel alone); default: two queues.
+    const bool overlap = tuning_get("PROVE_OVERLAP", 2) != 0;
     hipStream_t s2 = overlap ? L.stream2 : s;
     // launch slots: A, B1, C, B2, H.  On an error path the launches of THIS proof are forgotten (other lanes' are not touched)
     int slots[5] = {-1, -1, -1, -1, -1};
@@ -485,18 +486,17 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
         Lane& L; int* slots; hipStream_t a, b; bool armed;
         ~Abort() { if (armed) { msm_select_plan(L, 0); if (L.stream3) (void)hipStreamSynchronize(L.stream3); msm_abort_slots(L, slots, 5, a, b); } }
     } guard{L, slots, s, s2, true};
-    for (hipEvent_t* e : {&L.ev_start, &L.ev_tail, &L.ev_h})
+    for (hipEvent_t* e : {&L.ev_start, &L.ev_h})
         if (!*e) WS_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     // the four sums whose scalars are the witness (:617-620)
     msm_select_plan(L, 0);
-    if (h_witness && tuning_get("PROVE_CHUNKED_UPLOAD", 1)) {
+    if (h_witness) {
         hipStream_t sc = L.stream_copy;
         for (hipEvent_t* e : {&L.ev_chunk[0], &L.ev_chunk[1]})
             if (!*e) WS_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
         // the copy queue starts behind whatever the caller's queue still holds for this lane's witness buffer
         WS_HIP_CHECK(hipEventRecord(L.ev_start, s));
         WS_HIP_CHECK(hipStreamWaitEvent(sc, L.ev_start, 0));
-        WS_HIP_CHECK(hipStreamWaitEvent(L.stream_copy2, L.ev_start, 0));
         if ((rc = msm_plan_begin(L, nv, sh, s, table_cw))) return rc;
         unsigned k = 0;
         const uint64_t lo_sig = K->lo, hi_sig = (uint64_t)K->lo + nv;
@@ -508,129 +508,59 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
             if (e0 < lo_sig) e0 = lo_sig;
             if (e1 > hi_sig) e1 = hi_sig;
             return e0 < e1 ? msm_plan_count(L, d_witness, e0 - lo_sig, e1 - lo_sig, s) : (int)WS_OK;
-        }, L.stream_copy2);
+        });
         if (rc) return rc;
         tr.mark("witness staged, histogram enqueued per chunk");
         WS_HIP_CHECK(hipEventRecord(L.ev_start, s));      // the whole witness is resident (s has waited for every chunk)
         if ((rc = msm_plan_finish(L, d_witness, s))) return rc;
     } else {
-        if (h_witness && (rc = upload_staged(const_cast<Fe*>(d_witness_all), h_witness, (size_t)K->n_vars * 32, s))) return rc;
         WS_HIP_CHECK(hipEventRecord(L.ev_start, s));      // the witness is ready on s
         if ((rc = msm_plan_dev(L, d_witness, nv, sh, s, table_cw))) return rc;
     }
-    // Round 5: CALC_H goes to the second queue HERE -- right behind the witness plan's few launches, before the host enqueues the
-    // dozens of launches of the four sums.  The kernel trace of a 2^20 proof (profiles/r05_*) showed why: queued last, its first
-    // kernel reached the GPU 0.3-0.4 ms into the proof, when the G2 accumulation had just filled every SIMD with workgroups that
-    // live for ~1 ms, and did not START before 1.6 ms; the grouping pass before that (0.4 ms, LDS-atomic bound) ran alone on the
-    // chip.  Queued here the sparse products and the first transforms run beside the grouping pass.  WSNARK_PROVE_CALCH_FIRST=0: as before.
+    // CALC_H goes to the second queue HERE -- right behind the witness plan's few launches, before the host enqueues the dozens of
+    // launches of the four sums (round 5).  The kernel trace of a 2^20 proof (profiles/r05_timeline_*) showed why: queued last, its
+    // first kernel reached the GPU 0.3-0.4 ms into the proof, when the G2 accumulation had just filled every SIMD with workgroups
+    // that live for ~1 ms, and did not START before 1.6 ms, while the grouping pass before that (0.4 ms, LDS-atomic bound) had the chip
+    // to itself.  Queued here the sparse products and the first transforms run beside the grouping pass.  (Whole proofs measure the
+    // same either way, profiles/r05_schedule_experiments.txt: time on this chip is the sum of the kernels' own times, section 5 of
+    // DESIGN.md; the H sum's inputs are ready ~1 ms earlier.)
+    // (the distributed CALC_H keeps its place behind the sums: its exchanges are host callbacks that may block this thread)
     Fe* d_h = nullptr;
     bool calc_h_done = false;
     auto enqueue_calc_h = [&]() -> int {
-        if (s2 != s) WS_HIP_CHECK(hipStreamWaitEvent(s2, overlap == 2 ? L.ev_start : L.ev_tail, 0));
+        if (s2 != s) WS_HIP_CHECK(hipStreamWaitEvent(s2, L.ev_start, 0));
         WS_HIP_CHECK(L.h.reserve((size_t)dom * 32));
         d_h = L.h.as<Fe>();
         int r = calc_h ? calc_h(s2, d_h) : calc_h_dev(L, d_witness_all, K->n_vars, K->polsA, K->polsB, dom, d_h, s2);
         calc_h_done = true;
         return r;
     };
-    // (the distributed CALC_H keeps its place: its exchanges are host callbacks that may block this thread)
-    if (!skip_h && !calc_h && s2 != s && overlap == 2 && tuning_get("PROVE_CALCH_FIRST", 1)) {
+    if (!skip_h && !calc_h && s2 != s) {
         if ((rc = enqueue_calc_h())) return rc;
-        tr.mark("calc_h enqueued (first)");
+        tr.mark("calc_h enqueued");
     }
     // one grouping pass for all four; A and B1/B2 may run on variants of the plan that leave out the variables
-    // absent from their matrix (plan 0 = full, 2 = without B's absentees, 3 = without A's).  A, B1 and C: three
-    // accumulations back to back, then ONE batched reduction tail
+    // absent from their matrix (plan 0 = full, 2 = without B's absentees, 3 = without A's)
     int planA = 0, planB = 0;
-    if (K->sparseB && msm_plan_variant(L, 0, 2, K->maskB.as<uint8_t>(), s) == WS_OK) planB = 2;   // (hipCUB pipeline: no variants,
-    if (K->sparseA && msm_plan_variant(L, 0, 3, K->maskA.as<uint8_t>(), s) == WS_OK) planA = 3;   //  everything on the full plan)
-    // Order on this queue: B2 first, then A and B1 (accumulations back to back, ONE batched tail), C last.  The G2 tail is
-    // the slowest chain of the proof (a G2 addition on a lone wavefront: ~23 us, G1: ~7 us); early in the queue it runs
-    // beside CALC_H's full-width kernels instead of at the end of the proof, where nothing is left to fill the SIMDs
-    // (WSNARK_PROVE_ORDER=0: the round-1 order A, B1, C, B2).  A and B1 reach the host before C's accumulation ends,
-    // so the host's share of pi_c (after_ab1) still overlaps GPU work.
-    const int order_env = (int)tuning_get("PROVE_ORDER", -1);
-    // Order 3 (round 3; small sums: a rank's share of a points-sharded key, small circuits): every sum of such a proof is a
-    // latency chain -- grouping, a sub-millisecond accumulation on a fraction of the SIMDs, a reduction tail of ~33 dependent
-    // additions -- so the chains run BESIDE each other instead of behind each other: B2 with its tail on a third queue, A, B1
-    // and C under ONE batched tail on the first, CALC_H and H on the second.  At full size the accumulations fill the chip and
-    // the same arrangement loses (round 1 / 2 sweeps: kernels that share the SIMDs starve each other), hence the size switch:
-    // fewer than 2^23 (row, pair) entries per G1 sum.  Measured on the 8 shards of a 2^20 key, one GPU, rank after rank
-    // (tools/shard_probe.py): 3.7 -> see profiles/r03_s11_shard_probe_2p20.json.
-    const bool small = (uint64_t)nv * msm_table_rows(table_cw ? table_cw : 16) < ((uint64_t)1 << 23);
-    const int order = order_env >= 0 ? order_env : (small && L.stream3 && s != L.stream3 ? 3 : 1);
-    const bool g2_first = order != 0;
-    // Order 4 (round 3, full-size sums): order 1 with the reduction tails of B2 and of A + B1 on the THIRD queue, so that the
-    // next accumulation on the first queue starts at once instead of behind the tail (kernel timeline of a 2^20 proof: the
-    // batched A + B1 tail held queue 1 for 1.6 ms while only the H plan ran beside it).
-    // Order 5 (round 5): order 4 with C's tail on the third queue as well -- queue 1 is then accumulations only.  With the tail
-    // kernels at a raised wavefront priority (rt.h: wave_prio) a chain beside a full-width accumulation keeps its own pace.
-    // Order 6 (round 5): every accumulation on queue 1, back to back -- B2, A, B1, C, H --, the tails of B2 and of A + B1 on the
-    // third queue beside the accumulations that follow them, CALC_H and the H plan on the second queue (CALC_H queued first, above),
-    // and ONE batched tail for C and H at the end: the proof ends in one exposed G1 tail instead of two in a row, and no
-    // accumulation waits behind a tail.
-    const bool order6 = order == 6 && !skip_h && !calc_h && L.stream3 && s != L.stream3 && s2 != s;
-    hipStream_t tail_q = ((order == 4 || order == 5 || order6) && L.stream3 && s != L.stream3) ? L.stream3 : nullptr;
-    auto launch_b2 = [&]() -> int {
-        msm_select_plan(L, planB);
-        int r = msm_g2_launch(L, K->pointsB2.as<Affine<Fq2>>(), true, &hB2, s, nullptr, tail_q);           // :619
-        msm_select_plan(L, 0);
-        return r;
-    };
-    bool h_launched = false;
-    if ((order == 7 || order == 8) && !skip_h && !calc_h && L.stream3 && s != L.stream3 && s2 != s) {
-        // Order 8: the same with the G2 sum in the MIDDLE -- A, B1, then B2, then C, H.  The G1 accumulation holds 3 x 131 of a SIMD's
-        // 512 registers per lane, so CALC_H's transform passes (113) and the grouping kernels (35) fit BESIDE its wavefronts, whereas
-        // nothing fits beside the G2 accumulation's 2 x 243: the transforms run under A and B1, and B2's tail under C and H.
-        const bool b2_mid = order == 8;
-        // Order 7 (round 5): order 6 with the H plan queued BEFORE the sums and an explicit gate, because a chain of small dependent
-        // kernels (CALC_H: 20 launches; the H plan: 6) beside back-to-back accumulations is starved -- each of its launches waits for
-        // workgroup slots that free up one accumulation workgroup at a time (kernel trace of order 6: CALC_H ended 8 ms into the
-        // proof and the H accumulation ran alone behind everything else).  WSNARK_PROVE_GATE: 1 = the B2 accumulation waits for
-        // CALC_H, 2 = the A accumulation waits for the H plan, 0 = no gate.
-        hipStream_t s3 = L.stream3;
-        for (hipEvent_t* e : {&L.ev_plan, &L.ev_g2})
-            if (!*e) WS_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-        const long gate = tuning_get("PROVE_GATE", 1);
-        if (!calc_h_done && (rc = enqueue_calc_h())) return rc;
-        WS_HIP_CHECK(hipEventRecord(L.ev_plan, s2));                  // CALC_H is complete on s2
-        msm_select_plan(L, 1);
-        rc = msm_plan_dev(L, d_h + K->hlo, K->h_local, sh, s2, table_ch);
-        msm_select_plan(L, 0);
-        if (rc) return rc;
-        WS_HIP_CHECK(hipEventRecord(L.ev_h, s2));                     // the H plan is complete on s2
-        if (gate == 1) WS_HIP_CHECK(hipStreamWaitEvent(s, L.ev_plan, 0));
-        auto b2 = [&]() -> int {
-            msm_select_plan(L, planB);
-            int r = msm_g2_launch(L, K->pointsB2.as<Affine<Fq2>>(), true, &hB2, s, nullptr, s3);           // :619; its tail on queue 3
-            msm_select_plan(L, 0);
-            return r;
-        };
-        if (!b2_mid && (rc = b2())) return rc;
-        if (gate == 2) WS_HIP_CHECK(hipStreamWaitEvent(s, L.ev_h, 0));
-        const Affine<Fq>* g1sets[2] = {K->pointsA.as<Affine<Fq>>(), K->pointsB1.as<Affine<Fq>>()};
-        const int plans[2] = {planA, planB};
-        int g1slots[2] = {-1, -1};
-        rc = msm_g1_launch_batch(L, g1sets, 2, true, g1slots, s, L.ev_tail, plans, s3);                    // :617, :618; one tail on queue 3
-        hA = g1slots[0]; hB1 = g1slots[1];
-        if (rc) return rc;
-        msm_select_plan(L, 0);
-        if (b2_mid && (rc = b2())) return rc;
-        if ((rc = msm_g1_acc_only(L, K->pointsC.as<Affine<Fq>>(), true, &hC, s))) return rc;              // :620
-        WS_HIP_CHECK(hipStreamWaitEvent(s, L.ev_h, 0));
-        msm_select_plan(L, 1);
-        rc = msm_g1_acc_only(L, K->pointsH.as<Affine<Fq>>(), true, &hH, s);                               // :614
-        msm_select_plan(L, 0);
-        if (rc) return rc;
-        const int both[2] = {hC, hH};
-        if (msm_same_tail_geometry(L, hC, hH)) rc = msm_g1_tail(L, both, 2, s);
-        else { rc = msm_g1_tail(L, &hC, 1, s); if (!rc) rc = msm_g1_tail(L, &hH, 1, s); }
-        if (rc) return rc;
-        WS_HIP_CHECK(hipEventRecord(L.ev_g2, s3));
-        WS_HIP_CHECK(hipStreamWaitEvent(s, L.ev_g2, 0));              // s stays the caller's ordering point
-        h_launched = true;
-        tr.mark("order 7: everything enqueued");
-    } else if (order == 3) {
+    if (K->sparseB && msm_plan_variant(L, 0, 2, K->maskB.as<uint8_t>(), s) == WS_OK) planB = 2;
+    if (K->sparseA && msm_plan_variant(L, 0, 3, K->maskA.as<uint8_t>(), s) == WS_OK) planA = 3;
+    // Two arrangements of the sums, by size.
+    // FULL SIZE (>= 2^23 (row, pair) entries per G1 sum): everything on this queue -- B2 with its tail first, then the accumulations
+    // of A and B1 under ONE batched tail, C last; CALC_H and the H sum on the second queue.  The G2 tail is the slowest chain of the
+    // proof (a G2 addition on a lone wavefront: ~23 us, G1: ~7 us); early in the queue it runs beside CALC_H's kernels instead of
+    // at the end of the proof, where nothing is left to fill the SIMDs.  A and B1 reach the host before C's accumulation ends, so
+    // the host's share of pi_c (after_ab1) overlaps GPU work.  Every other arrangement tried -- tails on a third queue, all
+    // accumulations back to back, the G2 sum in the middle or last, gates between the queues, stream and wavefront priorities --
+    // measured the same or worse (rounds 1-3 and profiles/r05_schedule_experiments.txt).
+    // SMALL (round 3; a rank's share of a points-sharded key, circuits up to 2^19): every sum of such a proof is a latency chain --
+    // grouping, a sub-millisecond accumulation on a fraction of the SIMDs, a reduction tail of ~33 dependent additions -- so the
+    // chains run BESIDE each other: B2 with its tail on a third queue, A, B1 and C under ONE batched tail on the first, CALC_H and
+    // H on the second (profiles/r03_s12_prove_order3.txt: 2^16 proofs -31 %, 2^18 -35 %, 2^19 -8 %, 2^20 +3 %).
+    const bool small = overlap && (uint64_t)nv * msm_table_rows(table_cw ? table_cw : 16) < ((uint64_t)1 << 23) && L.stream3 && s != L.stream3;
+    const Affine<Fq>* g1sets[3] = {K->pointsA.as<Affine<Fq>>(), K->pointsB1.as<Affine<Fq>>(), K->pointsC.as<Affine<Fq>>()};
+    const int plans[3] = {planA, planB, 0};
+    int g1slots[3] = {-1, -1, -1};
+    if (small) {
         hipStream_t s3 = L.stream3;
         for (hipEvent_t* e : {&L.ev_plan, &L.ev_g2})
             if (!*e) WS_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -641,50 +571,23 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
         msm_select_plan(L, 0);
         if (rc) return rc;
         WS_HIP_CHECK(hipEventRecord(L.ev_g2, s3));
-        const Affine<Fq>* g1sets[3] = {K->pointsA.as<Affine<Fq>>(), K->pointsB1.as<Affine<Fq>>(), K->pointsC.as<Affine<Fq>>()};
-        const int plans[3] = {planA, planB, 0};
-        int g1slots[3] = {-1, -1, -1};
-        rc = msm_g1_launch_batch(L, g1sets, 3, true, g1slots, s, L.ev_tail, plans);                        // :617, :618, :620: one tail
+        rc = msm_g1_launch_batch(L, g1sets, 3, true, g1slots, s, plans);                                   // :617, :618, :620: one tail
         hA = g1slots[0]; hB1 = g1slots[1]; hC = g1slots[2];
         if (rc) return rc;
         WS_HIP_CHECK(hipStreamWaitEvent(s, L.ev_g2, 0));              // s stays the caller's ordering point
         tr.mark("plan(w) + B2 on queue 3 + A, B1, C batched");
-    } else if (g2_first) {
-        if ((rc = launch_b2())) return rc;
-        tr.mark("plan(w) [+ variants] + launch B2");
-        const Affine<Fq>* g1sets[3] = {K->pointsA.as<Affine<Fq>>(), K->pointsB1.as<Affine<Fq>>(), K->pointsC.as<Affine<Fq>>()};
-        const int plans[3] = {planA, planB, 0};
-        int g1slots[3] = {-1, -1, -1};
-        if (order == 2) {        // (A, B1 and C under one batched tail: one chain fewer, but A and B1 reach the host last)
-            rc = msm_g1_launch_batch(L, g1sets, 3, true, g1slots, s, L.ev_tail, plans);
-            hA = g1slots[0]; hB1 = g1slots[1]; hC = g1slots[2];
-            if (rc) return rc;
-        } else {
-            rc = msm_g1_launch_batch(L, g1sets, 2, true, g1slots, s, L.ev_tail, plans, tail_q);           // :617, :618
-            hA = g1slots[0]; hB1 = g1slots[1];
-            if (rc) return rc;
-            msm_select_plan(L, 0);
-            if (order6) rc = msm_g1_acc_only(L, K->pointsC.as<Affine<Fq>>(), true, &hC, s);                     // (its tail: with H's, below)
-            else rc = msm_g1_launch(L, K->pointsC.as<Affine<Fq>>(), true, &hC, s, order == 5 ? tail_q : nullptr);   // :620 (padded)
-            if (rc) return rc;
-            if (tail_q) {                                                                                  // s stays the caller's ordering point
-                for (hipEvent_t* e : {&L.ev_g2})
-                    if (!*e) WS_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-                WS_HIP_CHECK(hipEventRecord(L.ev_g2, tail_q));
-                WS_HIP_CHECK(hipStreamWaitEvent(s, L.ev_g2, 0));
-            }
-        }
-        tr.mark("launch A, B1, C");
     } else {
-        const Affine<Fq>* g1sets[3] = {K->pointsA.as<Affine<Fq>>(), K->pointsB1.as<Affine<Fq>>(), K->pointsC.as<Affine<Fq>>()};
-        const int plans[3] = {planA, planB, 0};
-        int g1slots[3] = {-1, -1, -1};
-        rc = msm_g1_launch_batch(L, g1sets, 3, true, g1slots, s, L.ev_tail, plans);       // :617, :618, :620 (padded)
-        hA = g1slots[0]; hB1 = g1slots[1]; hC = g1slots[2];
+        msm_select_plan(L, planB);
+        rc = msm_g2_launch(L, K->pointsB2.as<Affine<Fq2>>(), true, &hB2, s);                               // :619
+        msm_select_plan(L, 0);
         if (rc) return rc;
-        tr.mark("plan(w) [+ variants] + launch A,B1,C");
-        if ((rc = launch_b2())) return rc;
-        tr.mark("launch B2");
+        tr.mark("plan(w) [+ variants] + launch B2");
+        rc = msm_g1_launch_batch(L, g1sets, 2, true, g1slots, s, plans);                                   // :617, :618
+        hA = g1slots[0]; hB1 = g1slots[1];
+        if (rc) return rc;
+        msm_select_plan(L, 0);
+        if ((rc = msm_g1_launch(L, K->pointsC.as<Affine<Fq>>(), true, &hC, s))) return rc;                // :620 (padded)
+        tr.mark("launch A, B1, C");
     }
     if (skip_h) {
         // distributed proving with the four-step CALC_H (wasmsnark_amd/dist.py): h and the H sum are the caller's
@@ -697,47 +600,31 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
         guard.armed = false;
         return WS_OK;
     }
-    // CALC_H, then the H MSM over domainSize pairs (src/bn128.js:607-615)
-    if (!h_launched) {
+    // CALC_H (unless queued above), then the H MSM over domainSize pairs (src/bn128.js:607-615)
     if (!calc_h_done) {
         if ((rc = enqueue_calc_h())) return rc;
         tr.mark("calc_h enqueued");
     }
     msm_select_plan(L, s2 != s ? 1 : 0);
     rc = msm_plan_dev(L, d_h + K->hlo, K->h_local, sh, s2, table_ch);
-    if (!rc && order6) {
-        // the H accumulation joins queue 1 behind C's; one reduction tail for the two (or one each, should their geometries differ)
-        if (hipEventRecord(L.ev_h, s2) != hipSuccess || hipStreamWaitEvent(s, L.ev_h, 0) != hipSuccess) rc = WS_ERR_HIP;
-        if (!rc) rc = msm_g1_acc_only(L, K->pointsH.as<Affine<Fq>>(), true, &hH, s);                      // :614
-        if (!rc) {
-            const int both[2] = {hC, hH};
-            if (msm_same_tail_geometry(L, hC, hH)) rc = msm_g1_tail(L, both, 2, s);
-            else { rc = msm_g1_tail(L, &hC, 1, s); if (!rc) rc = msm_g1_tail(L, &hH, 1, s); }
-        }
-    } else if (!rc) {
-        rc = msm_g1_launch(L, K->pointsH.as<Affine<Fq>>(), true, &hH, s2);                                // :614
-    }
+    if (!rc) rc = msm_g1_launch(L, K->pointsH.as<Affine<Fq>>(), true, &hH, s2);                           // :614
     msm_select_plan(L, 0);
     if (rc) return rc;
     if (s2 != s) { WS_HIP_CHECK(hipEventRecord(L.ev_h, s2)); WS_HIP_CHECK(hipStreamWaitEvent(s, L.ev_h, 0)); }   // s stays the caller's ordering point
     tr.mark("plan(h) + launch H");
-    }
-    const bool g2_late = order == 8 && h_launched;   // (order 8: B2's tail runs behind A + B1's, under the C and H accumulations)
-    const bool g2_fin = g2_first && order != 3 && !g2_late;      // (order 3: B2 ends on its own queue, A / B1 / C come first)
+    const bool g2_fin = !small;                      // (small proofs: B2 ends on its own queue, A / B1 / C come first)
     if (g2_fin && (rc = msm_g2_finish(L, hB2, &out->B2))) return rc;
     if ((rc = msm_g1_finish(L, hA, &out->A))) return rc;
     if ((rc = msm_g1_finish(L, hB1, &out->B1))) return rc;
     tr.mark(g2_fin ? "finish B2, A, B1" : "finish A, B1");
     if (after_ab1) after_ab1(*out);
-    if (g2_late && (rc = msm_g2_finish(L, hB2, &out->B2))) return rc;
-    if (!g2_fin && !g2_late && (rc = msm_g1_finish(L, hC, &out->C))) return rc;
+    if (!g2_fin && (rc = msm_g1_finish(L, hC, &out->C))) return rc;
     tr.mark(g2_fin ? "host work on A, B1" : "host work on A, B1; finish C");
     // the two queues end independently: finish whichever sum reaches the host first (its serial host tail then runs while
     // the GPU still works on the other one), so poll both instead of blocking on one
     {
-        const bool x_is_c = g2_fin || g2_late;
-        const int hX = x_is_c ? hC : hB2;                 // the first queue's last sum
-        auto finish_x = [&]() -> int { return x_is_c ? msm_g1_finish(L, hC, &out->C) : msm_g2_finish(L, hB2, &out->B2); };
+        const int hX = g2_fin ? hC : hB2;                 // the first queue's last sum
+        auto finish_x = [&]() -> int { return g2_fin ? msm_g1_finish(L, hC, &out->C) : msm_g2_finish(L, hB2, &out->B2); };
         bool doneX = false, doneH = false;
         for (unsigned spins = 0; !(doneX && doneH); spins++) {
             if (!doneX && (doneH || msm_ready(L, hX))) { if ((rc = finish_x())) return rc; doneX = true; continue; }
@@ -749,7 +636,7 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
             }
         }
     }
-    tr.mark(g2_first && order != 3 ? "finish H, C" : "finish H, B2");
+    tr.mark(g2_fin ? "finish H, C" : "finish H, B2");
     guard.armed = false;
     return WS_OK;
 }
@@ -955,8 +842,8 @@ int pkey_h_msm_dev(ProvingKey* K, const Fe* d_h_local, uint64_t n, uint8_t* out9
     if (!s) s = L->stream;
     msm_select_plan(*L, 0);
     uint32_t table_cw, table_ch;
-    pkey_table_state(K, false, &table_cw, &table_ch);
-    int rc = msm_plan_dev(*L, d_h_local, n, WindowShard{}, s, table_ch);
+    int rc = pkey_table_state(K, false, &table_cw, &table_ch);
+    if (!rc) rc = msm_plan_dev(*L, d_h_local, n, WindowShard{}, s, table_ch);
     if (rc) return rc;
     int slot = -1;
     if ((rc = msm_g1_launch(*L, K->pointsH.as<Affine<Fq>>(), true, &slot, s))) return rc;

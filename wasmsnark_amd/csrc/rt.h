@@ -48,20 +48,6 @@ void set_last_error(const std::string& s);
 
 static inline uint32_t ceil_div_u64(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
-// Wavefront issue priority (s_setprio, 0..3, lasts for the wavefront's life).  The proof's latency-bound kernels -- reduction tails,
-// grouping passes: dependent chains on one wavefront per SIMD -- raise theirs, so that a chain which shares its SIMD with the
-// wavefronts of a full-width accumulation keeps issuing at the rate it has alone and the accumulation takes the slots it leaves
-// (round 5; the arbiter otherwise serves the OLDEST wavefront first, and a tail beside an accumulation ran 2-3x longer).
-#ifdef WSNARK_EMUL
-static inline void wave_prio(uint32_t) {}
-#else
-__device__ __forceinline__ void wave_prio(uint32_t p) {
-    if (p == 1) __builtin_amdgcn_s_setprio(1);
-    else if (p == 2) __builtin_amdgcn_s_setprio(2);
-    else if (p >= 3) __builtin_amdgcn_s_setprio(3);
-}
-#endif
-
 // simple RAII device buffer
 struct DevBuf {
     void* p = nullptr;

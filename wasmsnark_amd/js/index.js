@@ -3,6 +3,10 @@
  *
  * Same names and shapes as the reference:
  *   buildBn128() -> Promise<Bn128>                          (reference index.js:21, src/bn128.js:173-265)
+ *   buildBn128({devices: [0, 1, ...]}) -> the same object over SEVERAL GPUs of this one process: the reference's worker pool
+ *       (src/bn128.js:173-265: `build()` starts its workers; :353-415, :607-622: every sum is cut into one contiguous range of the
+ *       pairs per worker and the partial results are added) with GPUs as the workers -- a points shard of the key per device,
+ *       CALC_H on the distributed transform, the transport inside libwsnark.so (csrc/group.hip)
  *   Bn128.groth16GenProof(signals, pkey) -> Promise<{pi_a, pi_b, pi_c}> of decimal strings (src/bn128.js:580-720)
  *   Bn128.g1_multiexp / g2_multiexp / calcH / terminate      (src/bn128.js:353-415, 569-578, 562-566)
  *   groth16GenProof(witness, provingKey[, cb]) and the README name genZKSnarkProof (main_bn128.js:26-39, README.md:28-30)
@@ -26,12 +30,14 @@ function proofFromBytes(ab) {       // bin2g1 / bin2g2, src/bn128.js:329-351, 71
 
 /* Two checks that a cached key handle still describes the bytes the caller is holding.
  *   fingerprint(u8): synchronous, a few KiB -- the 488-byte header + fixed points, 64 samples of 32 bytes spread over the buffer and
- *                    its tail.  Run on EVERY cache hit: it catches a buffer that was refilled with another key.
- *   digest(u8):      ALL of the bytes (addon.hashBytes, off the event loop, several threads; ~10 ms for a 0.6 GB key -- a proof's worth).
- *                    Run when the key is first seen (beside the load) and, after that, only when the caller asks:
- *                    {trustCache: false}, or invalidateKey(pkey) after rewriting bytes in place.
- * The reference re-parses pkey inside every call (src/bn128.js:581-604), so for IT a caller may patch a few bytes of a key between
- * two proofs and be served; here such a caller has to say so.  A caller that wants no check at all holds the handle of loadKey(). */
+ *                    its tail.  It catches a buffer that was refilled with another key.
+ *   digest(u8):      ALL of the bytes (addon.hashBytes, off the event loop, several threads; ~10 ms for a 0.6 GB key).
+ * The reference re-parses pkey inside every call (src/bn128.js:581-604): a caller may patch a few bytes of a key between two proofs
+ * and is served with the new key.  The DEFAULT here gives the same guarantee (round 5): every call that is handed key BYTES takes
+ * the digest of all of them -- groth16GenProof takes it BESIDE the proof on the cached handle and, should it differ from the
+ * digest taken when that handle was loaded, loads the new bytes and proves again (the stale proof is never returned).  Callers who
+ * know their key bytes do not change opt into the sampled check alone with {trustCache: true}; callers who want no check at all hold
+ * the handle of loadKey() and pass that. */
 async function digest(u8) {
     return Buffer.from(await addon.hashBytes(u8)).toString("hex");
 }
@@ -62,8 +68,10 @@ function asBytes(x) {
 }
 
 class Bn128 {
-    constructor(deviceInfo) {
+    constructor(deviceInfo, group, devices) {
         this.deviceInfo = deviceInfo;
+        this._group = group || null;      // several GPUs: wsnark_group_* (keys are points shards over the devices, proofs run on all of them)
+        this.devices = devices || null;
         // proving-key OBJECT (the exact ArrayBuffer / view the caller passed) -> {handle (a Promise), byteOffset, byteLength,
         // fp (sampled fingerprint), digest (Promise of the whole-buffer digest taken at load time)}.
         // Two views of one ArrayBuffer (sub-arrays of a bundle, Node's pooled small Buffers) are different keys here.
@@ -75,20 +83,25 @@ class Bn128 {
         this._ps = null;
         this._live = true;
     }
-    g1_multiexp(scalars, points) { return addon.g1Multiexp(scalars, points); }
-    g2_multiexp(scalars, points) { return addon.g2Multiexp(scalars, points); }
+    g1_multiexp(scalars, points) { return this._group ? addon.groupMultiexp(this._group, 0, scalars, points) : addon.g1Multiexp(scalars, points); }
+    g2_multiexp(scalars, points) { return this._group ? addon.groupMultiexp(this._group, 1, scalars, points) : addon.g2Multiexp(scalars, points); }
     calcH(signals, polsA, polsB, nSignals, domainSize) { return addon.calcH(signals, polsA, polsB, nSignals, domainSize); }
     fft(buf, odd) { return addon.fft(buf, odd | 0, false); }
     ifft(buf, odd) { return addon.fft(buf, odd | 0, true); }
+    /* the cache entry of a key object if offset, length and the sampled fingerprint still match its bytes */
+    _cached(pkey, u8) {
+        const hit = this._keys.get(pkey);
+        return hit && hit.byteOffset === u8.byteOffset && hit.byteLength === u8.byteLength && hit.fp === fingerprint(u8) ? hit : null;
+    }
     /* pkey bytes -> device-resident key handle (stays in HBM across proofs; freed by the GC).
-     * opts.trustCache === false: compare the digest of ALL bytes with the one taken when the key was loaded (default: the sampled
-     * fingerprint only).  Concurrent callers with the same key object share ONE load: the entry is in the map before it is awaited. */
+     * A cached handle is returned when the digest of ALL bytes equals the one taken when it was loaded; opts.trustCache === true: when
+     * the sampled fingerprint does.  Concurrent callers with the same key object share ONE load: the entry is in the map before it is awaited. */
     async loadKey(pkey, opts) {
         if (pkey !== null && typeof pkey === "object" && !(pkey instanceof ArrayBuffer) && !ArrayBuffer.isView(pkey)) return pkey;   // already a handle
         const u8 = asBytes(pkey);
-        const hit = this._keys.get(pkey);
-        if (hit && hit.byteOffset === u8.byteOffset && hit.byteLength === u8.byteLength && hit.fp === fingerprint(u8)) {
-            if (!(opts && opts.trustCache === false)) return hit.handle;                 // (a Promise: resolved, or the load in flight)
+        const hit = this._cached(pkey, u8);
+        if (hit) {
+            if (opts && opts.trustCache === true) return hit.handle;                     // (a Promise: resolved, or the load in flight)
             this.fullDigests++;
             if ((await hit.digest) === (await digest(u8))) return hit.handle;
         }
@@ -96,7 +109,8 @@ class Bn128 {
         // key, a quarter of the load) and loadKey() resolves only when BOTH are done: a caller who rewrites bytes in place as
         // soon as the first call returns must find them compared against the bytes that were loaded, not against a digest that
         // was still being taken while they changed.
-        const entry = { byteOffset: u8.byteOffset, byteLength: u8.byteLength, fp: fingerprint(u8), handle: addon.loadKey(pkey), digest: digest(u8) };
+        const load = this._group ? addon.groupLoadKey(this._group, pkey) : addon.loadKey(pkey);
+        const entry = { byteOffset: u8.byteOffset, byteLength: u8.byteLength, fp: fingerprint(u8), handle: load, digest: digest(u8) };
         this.fullDigests++;
         this._keys.set(pkey, entry);
         entry.digest.catch(() => {});
@@ -112,11 +126,11 @@ class Bn128 {
     /* forget the cached handle of a key object (its bytes were rewritten in place, or its HBM should go back) */
     invalidateKey(pkey) { return this._keys.delete(pkey); }
     /* {nVars, nPublic, domainSize, loadMs: {polsToCsr, pointsH2d, masksConvert, tableBuild, total}} of a key (bytes or handle) */
-    async keyInfo(pkey) { return addon.keyInfo(await this.loadKey(pkey)); }
+    async keyInfo(pkey) { const h = await this.loadKey(pkey); return this._group ? addon.groupKeyInfo(h) : addon.keyInfo(h); }
     /* loadKey() returns once the key's sections are resident: proofs may start at once and run on the plain sections while the rows
      * of the fixed-base tables are built behind them (about 0.2 s for a 2^20 key).  A caller that wants its first timed proof at the
      * steady-state rate awaits this first. */
-    async waitTables(pkey) { return addon.waitTables(await this.loadKey(pkey)).then(() => true); }
+    async waitTables(pkey) { const h = await this.loadKey(pkey); return (this._group ? addon.groupWaitTables(h) : addon.waitTables(h)).then(() => true); }
     /* an ArrayBuffer of `bytes` bytes in PINNED host memory: a witness written into it is DMA'd to the GPU in place, chunk by
      * chunk, instead of being copied through the library's staging ring first (no counterpart in the reference) */
     allocInput(bytes) { return addon.allocPinned(bytes); }
@@ -125,9 +139,31 @@ class Bn128 {
      * opts.trustCache: see loadKey.  opts.timing: an object that receives {loadKey_ms, prove_ms, format_ms} of this call */
     async groth16GenProof(signals, pkey, opts) {
         const t0 = process.hrtime.bigint();
-        const h = await this.loadKey(pkey, opts);
-        const t1 = process.hrtime.bigint();
-        const out = await addon.prove(h, signals, opts && opts.r ? opts.r : null, opts && opts.s ? opts.s : null);
+        const prove = (h) => (this._group ? addon.groupProve : addon.prove)(h, signals, opts && opts.r ? opts.r : null, opts && opts.s ? opts.s : null);
+        const isBytes = pkey instanceof ArrayBuffer || ArrayBuffer.isView(pkey);
+        let t1, out;
+        const hit = isBytes && !(opts && opts.trustCache === true) ? this._cached(pkey, asBytes(pkey)) : null;
+        if (hit) {
+            // key BYTES with a cached handle: prove on it at once, take the digest of all bytes beside the proof, and only return the
+            // proof if those are the bytes the handle was loaded from (else: load what the caller holds now and prove again)
+            this.fullDigests++;
+            const now = digest(asBytes(pkey));
+            now.catch(() => {});
+            const h = await hit.handle;
+            t1 = process.hrtime.bigint();
+            const first = prove(h);
+            first.catch(() => {});
+            if ((await now) === (await hit.digest)) out = await first;
+            else {
+                await first.catch(() => {});
+                if (this._keys.get(pkey) === hit) this._keys.delete(pkey);
+                out = await prove(await this.loadKey(pkey, opts));
+            }
+        } else {
+            const h = await this.loadKey(pkey, opts);
+            t1 = process.hrtime.bigint();
+            out = await prove(h);
+        }
         const t2 = process.hrtime.bigint();
         this._pr = new Uint8Array(out.slice(384, 416));
         this._ps = new Uint8Array(out.slice(416, 448));
@@ -158,6 +194,7 @@ class Bn128 {
     terminate() {
         if (!this._live) return;
         this._live = false;
+        if (this._group) { addon.groupFree(this._group); this._group = null; }     // (a group's contexts belong to this object alone)
         if (--liveInstances === 0) addon.shutdown();
     }
 }
@@ -172,9 +209,19 @@ let singleton = null;
 /* opts.lib: load this build of the C ABI instead of the in-tree libwsnark.so.  The test-suite passes the CPU
  * thread-emulator build; nothing else should: there is no CPU path in the product. */
 async function buildBn128(device, opts) {
-    const info = addon.init(device === undefined || device === null ? -1 : device, opts && opts.lib ? String(opts.lib) : undefined);
+    if (device !== null && typeof device === "object") { opts = device; device = undefined; }      // buildBn128({devices: [...]})
+    const devices = opts && opts.devices ? Array.from(opts.devices, (d) => d | 0) : null;
+    if (devices && devices.length === 0) throw new TypeError("devices: expected at least one device ordinal");
+    // (the default context serves calcH / fft and the pinned input buffers; with a group it sits on the group's first device)
+    const info = addon.init(devices ? devices[0] : (device === undefined || device === null ? -1 : device), opts && opts.lib ? String(opts.lib) : undefined);
     liveInstances++;
-    return new Bn128(info);
+    if (!devices) return new Bn128(info);
+    try {
+        return new Bn128(info + " x" + devices.length + " (devices " + devices.join(", ") + ")", addon.groupCreate(devices), devices);
+    } catch (e) {
+        if (--liveInstances === 0) addon.shutdown();
+        throw e;
+    }
 }
 /* The module-level calls share one Bn128 object that is never terminated on its own, exactly like the reference's
  * (main_bn128.js:26-39 builds its singleton and leaves the workers running; src/bn128.js:562-566 needs an explicit call): a

@@ -21,6 +21,8 @@
 #include <string.h>
 
 typedef struct wsnark_pkey wsnark_pkey_t;
+typedef struct wsnark_group wsnark_group_t;
+typedef struct wsnark_group_pkey wsnark_group_pkey_t;
 static struct {
     void* h;
     int (*init)(int);
@@ -41,6 +43,17 @@ static struct {
     void (*host_free)(void*);
     int (*pkey_load_stats)(const wsnark_pkey_t*, double*);
     int (*pkey_wait_tables)(wsnark_pkey_t*);
+    /* several GPUs in this one process (include/wsnark.h: wsnark_group_*) */
+    int (*group_create)(const int*, uint32_t, wsnark_group_t**);
+    void (*group_free)(wsnark_group_t*);
+    int (*group_pkey_load)(wsnark_group_t*, const void*, size_t, wsnark_group_pkey_t**);
+    void (*group_pkey_free)(wsnark_group_pkey_t*);
+    int (*group_pkey_info)(const wsnark_group_pkey_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int*);
+    int (*group_pkey_wait_tables)(wsnark_group_pkey_t*);
+    int (*group_prove)(wsnark_group_pkey_t*, const void*, size_t, const void*, const void*, void*);
+    int (*group_last_blinding)(wsnark_group_t*, void*, void*);
+    int (*group_g1_msm)(wsnark_group_t*, const void*, const void*, uint64_t, void*);
+    int (*group_g2_msm)(wsnark_group_t*, const void*, const void*, uint64_t, void*);
     char dir[4096];
 } L;
 
@@ -69,6 +82,10 @@ static int load_lib(const char* explicit_path, char* err, size_t errlen) {
     SYM(last_blinding, "wsnark_last_blinding") SYM(verify, "wsnark_groth16_verify")
     SYM(host_alloc, "wsnark_host_alloc") SYM(host_free, "wsnark_host_free")
     SYM(pkey_load_stats, "wsnark_pkey_load_stats") SYM(pkey_wait_tables, "wsnark_pkey_wait_tables")
+    SYM(group_create, "wsnark_group_create") SYM(group_free, "wsnark_group_free") SYM(group_pkey_load, "wsnark_group_pkey_load")
+    SYM(group_pkey_free, "wsnark_group_pkey_free") SYM(group_pkey_info, "wsnark_group_pkey_info")
+    SYM(group_pkey_wait_tables, "wsnark_group_pkey_wait_tables") SYM(group_prove, "wsnark_group_prove")
+    SYM(group_last_blinding, "wsnark_group_last_blinding") SYM(group_g1_msm, "wsnark_group_g1_msm") SYM(group_g2_msm, "wsnark_group_g2_msm")
 #undef SYM
     return 0;
 }
@@ -94,7 +111,14 @@ static int get_bytes(napi_env env, napi_value v, uint8_t** p, size_t* n) {
     return 0;
 }
 
-enum { OP_G1, OP_G2, OP_NTT, OP_CALCH, OP_PROVE, OP_LOADKEY, OP_VERIFY, OP_HASH, OP_WAIT_TABLES };
+enum { OP_G1, OP_G2, OP_NTT, OP_CALCH, OP_PROVE, OP_LOADKEY, OP_VERIFY, OP_HASH, OP_WAIT_TABLES,
+       OP_GROUP_G1, OP_GROUP_G2, OP_GROUP_LOADKEY, OP_GROUP_PROVE, OP_GROUP_WAIT_TABLES };
+/* A group and the keys loaded on it.  The JS side holds them as externals; a key's finalizer must not touch a group that
+ * terminate() has already freed (wsnark_group_free frees the keys that are left), so every group handle carries a `live` flag
+ * that outlives the group itself and every key handle points at its group's handle. */
+typedef struct { wsnark_group_t* g; int live; int refs; } group_ref_t;
+typedef struct { wsnark_group_pkey_t* k; group_ref_t* gr; } gkey_ref_t;
+static void group_ref_drop(group_ref_t* gr) { if (--gr->refs == 0) free(gr); }
 typedef struct {
     int op, rc;
     napi_async_work work;
@@ -106,6 +130,8 @@ typedef struct {
     uint32_t u0, u1;
     int i0, i1;
     wsnark_pkey_t* key;
+    group_ref_t* gr;
+    gkey_ref_t* gk;
     uint8_t* out;
     size_t nout;
     char err[512];
@@ -188,6 +214,14 @@ static void job_execute(napi_env env, void* data) {
     case OP_LOADKEY: j->rc = L.pkey_load(j->a, j->na, &j->key); break;
     case OP_VERIFY: j->rc = L.verify(j->a, j->na, j->b, j->nb / 32, j->c, &j->i0); break;
     case OP_WAIT_TABLES: j->rc = L.pkey_wait_tables(j->key); break;
+    case OP_GROUP_G1: j->rc = L.group_g1_msm(j->gr->g, j->a, j->b, j->na / 32, j->out); break;
+    case OP_GROUP_G2: j->rc = L.group_g2_msm(j->gr->g, j->a, j->b, j->na / 32, j->out); break;
+    case OP_GROUP_LOADKEY: j->rc = L.group_pkey_load(j->gr->g, j->a, j->na, &j->gk->k); break;
+    case OP_GROUP_PROVE:
+        j->rc = L.group_prove(j->gk->k, j->a, j->na, j->r32, j->s32, j->out);
+        if (!j->rc) j->rc = L.group_last_blinding(j->gk->gr->g, j->out + 384, j->out + 416);
+        break;
+    case OP_GROUP_WAIT_TABLES: j->rc = L.group_pkey_wait_tables(j->gk->k); break;
     case OP_HASH:
         if (hash_bytes(j->a, j->na, j->out)) { j->rc = -1; snprintf(j->err, sizeof j->err, "hashBytes: out of memory"); return; }
         break;
@@ -200,6 +234,22 @@ static void key_finalize(napi_env env, void* data, void* hint) {
     if (data) L.pkey_free((wsnark_pkey_t*)data);
 }
 
+static void gkey_finalize(napi_env env, void* data, void* hint) {
+    (void)env; (void)hint;
+    gkey_ref_t* gk = (gkey_ref_t*)data;
+    if (!gk) return;
+    if (gk->k && gk->gr->live) L.group_pkey_free(gk->k);      /* (a freed group took its keys with it) */
+    group_ref_drop(gk->gr);
+    free(gk);
+}
+static void group_finalize(napi_env env, void* data, void* hint) {
+    (void)env; (void)hint;
+    group_ref_t* gr = (group_ref_t*)data;
+    if (!gr) return;
+    if (gr->live) { gr->live = 0; L.group_free(gr->g); }
+    group_ref_drop(gr);
+}
+
 static void job_complete(napi_env env, napi_status status, void* data) {
     job_t* j = (job_t*)data;
     napi_value res;
@@ -208,6 +258,10 @@ static void job_complete(napi_env env, napi_status status, void* data) {
         napi_create_string_utf8(env, j->rc ? j->err : "async work cancelled", NAPI_AUTO_LENGTH, &msg);
         napi_create_error(env, NULL, msg, &e);
         napi_reject_deferred(env, j->deferred, e);
+        if (j->op == OP_GROUP_LOADKEY && j->gk) { group_ref_drop(j->gk->gr); free(j->gk); }
+    } else if (j->op == OP_GROUP_LOADKEY) {
+        napi_create_external(env, j->gk, gkey_finalize, NULL, &res);
+        napi_resolve_deferred(env, j->deferred, res);
     } else if (j->op == OP_VERIFY) {
         napi_get_boolean(env, j->i0 != 0, &res);
         napi_resolve_deferred(env, j->deferred, res);
@@ -406,6 +460,128 @@ static napi_value js_keyinfo(napi_env env, napi_callback_info info) {
     return o;
 }
 
+/* ---- several GPUs in this one process ----
+ * groupCreate([device, ...]) -> group handle (synchronous: contexts and worker threads are created at once) */
+static napi_value js_group_create(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1], res;
+    uint32_t n = 0;
+    bool is_arr = false;
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (!L.h) { napi_throw_error(env, NULL, "wsnark_napi: init() has not been called (use buildBn128())"); return NULL; }
+    if (argc < 1 || napi_is_array(env, argv[0], &is_arr) != napi_ok || !is_arr || napi_get_array_length(env, argv[0], &n) != napi_ok || n == 0 || n > 64) {
+        napi_throw_type_error(env, NULL, "expected a non-empty array of device ordinals");
+        return NULL;
+    }
+    int devs[64];
+    for (uint32_t i = 0; i < n; i++) {
+        napi_value e; int32_t d = 0;
+        if (napi_get_element(env, argv[0], i, &e) != napi_ok || napi_get_value_int32(env, e, &d) != napi_ok || d < 0) { napi_throw_type_error(env, NULL, "device ordinals must be non-negative integers"); return NULL; }
+        devs[i] = d;
+    }
+    group_ref_t* gr = (group_ref_t*)calloc(1, sizeof *gr);
+    int rc = L.group_create(devs, n, &gr->g);
+    if (rc) {
+        char msg[600];
+        snprintf(msg, sizeof msg, "wsnark_group_create failed (%d): %s -- there is no CPU fallback", rc, L.last_error());
+        free(gr);
+        napi_throw_error(env, NULL, msg);
+        return NULL;
+    }
+    gr->live = 1; gr->refs = 1;
+    if (napi_create_external(env, gr, group_finalize, NULL, &res) != napi_ok) { L.group_free(gr->g); free(gr); napi_throw_error(env, NULL, "wsnark_napi: cannot wrap the group"); return NULL; }
+    return res;
+}
+/* groupFree(group): frees the contexts now (and the keys still loaded on them); the handle stays valid as a dead one */
+static napi_value js_group_free(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1], u;
+    group_ref_t* gr = NULL;
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc >= 1 && napi_get_value_external(env, argv[0], (void**)&gr) == napi_ok && gr && gr->live) { gr->live = 0; L.group_free(gr->g); }
+    napi_get_undefined(env, &u);
+    return u;
+}
+static group_ref_t* live_group(napi_env env, napi_value v) {
+    group_ref_t* gr = NULL;
+    if (napi_get_value_external(env, v, (void**)&gr) != napi_ok || !gr || !gr->live) return NULL;
+    return gr;
+}
+static gkey_ref_t* live_gkey(napi_env env, napi_value v) {
+    gkey_ref_t* gk = NULL;
+    if (napi_get_value_external(env, v, (void**)&gk) != napi_ok || !gk || !gk->k || !gk->gr->live) return NULL;
+    return gk;
+}
+/* groupMultiexp(group, which, scalars, points) -> Promise<ArrayBuffer 96/192> */
+static napi_value js_group_msm(napi_env env, napi_callback_info info) {
+    size_t argc = 4; napi_value argv[4];
+    int32_t which = 0;
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    job_t* j = (job_t*)calloc(1, sizeof *j);
+    if (argc < 4 || !(j->gr = live_group(env, argv[0])) || napi_get_value_int32(env, argv[1], &which) != napi_ok ||
+        !get_bytes(env, argv[2], &j->a, &j->na) || !get_bytes(env, argv[3], &j->b, &j->nb))
+        FAIL(env, j, "expected (group, which, scalars, points)");
+    j->op = which ? OP_GROUP_G2 : OP_GROUP_G1; j->nout = which ? 192 : 96; j->out = (uint8_t*)malloc(j->nout);
+    if (j->nb < (j->na / 32) * (which ? 128 : 64)) FAIL(env, j, "points buffer too short for the number of scalars");
+    keep(env, j, argv[0]); keep(env, j, argv[2]); keep(env, j, argv[3]);
+    return start_job(env, j, "wsnark_group_msm");
+}
+/* groupLoadKey(group, pkey) -> Promise<group key handle> */
+static napi_value js_group_loadkey(napi_env env, napi_callback_info info) {
+    size_t argc = 2; napi_value argv[2];
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    job_t* j = (job_t*)calloc(1, sizeof *j);
+    j->op = OP_GROUP_LOADKEY;
+    if (argc < 2 || !(j->gr = live_group(env, argv[0])) || !get_bytes(env, argv[1], &j->a, &j->na)) FAIL(env, j, "expected (group, proving_key.bin bytes)");
+    j->gk = (gkey_ref_t*)calloc(1, sizeof *j->gk);
+    j->gk->gr = j->gr; j->gr->refs++;
+    keep(env, j, argv[0]); keep(env, j, argv[1]);
+    return start_job(env, j, "wsnark_group_pkey_load");
+}
+/* groupProve(groupKey, witness, r32|null, s32|null) -> Promise<ArrayBuffer 448>: proof | r | s used */
+static napi_value js_group_prove(napi_env env, napi_callback_info info) {
+    size_t argc = 4; napi_value argv[4];
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    job_t* j = (job_t*)calloc(1, sizeof *j);
+    j->op = OP_GROUP_PROVE; j->nout = 448; j->out = (uint8_t*)malloc(448);
+    if (argc < 2 || !(j->gk = live_gkey(env, argv[0])) || !get_bytes(env, argv[1], &j->a, &j->na)) FAIL(env, j, "expected (groupKey, witness[, r32, s32])");
+    keep(env, j, argv[0]); keep(env, j, argv[1]);
+    size_t n;
+    napi_valuetype t;
+    if (argc > 2 && napi_typeof(env, argv[2], &t) == napi_ok && t != napi_null && t != napi_undefined) {
+        if (!get_bytes(env, argv[2], &j->r32, &n) || n != 32) FAIL(env, j, "r must be 32 bytes");
+        keep(env, j, argv[2]);
+    }
+    if (argc > 3 && napi_typeof(env, argv[3], &t) == napi_ok && t != napi_null && t != napi_undefined) {
+        if (!get_bytes(env, argv[3], &j->s32, &n) || n != 32) FAIL(env, j, "s must be 32 bytes");
+        keep(env, j, argv[3]);
+    }
+    return start_job(env, j, "wsnark_group_prove");
+}
+static napi_value js_group_wait_tables(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1];
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    job_t* j = (job_t*)calloc(1, sizeof *j);
+    j->op = OP_GROUP_WAIT_TABLES; j->nout = 1; j->out = (uint8_t*)calloc(1, 1);
+    if (argc < 1 || !(j->gk = live_gkey(env, argv[0]))) FAIL(env, j, "expected a group key handle");
+    keep(env, j, argv[0]);
+    return start_job(env, j, "wsnark_group_pkey_wait_tables");
+}
+/* groupKeyInfo(groupKey) -> {nVars, nPublic, domainSize, world, distributedCalcH} */
+static napi_value js_group_keyinfo(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1], o, v;
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    gkey_ref_t* gk = argc >= 1 ? live_gkey(env, argv[0]) : NULL;
+    if (!gk) { napi_throw_type_error(env, NULL, "expected a group key handle"); return NULL; }
+    uint32_t nv, np, dom, world; int dist;
+    L.group_pkey_info(gk->k, &nv, &np, &dom, &world, &dist);
+    napi_create_object(env, &o);
+    napi_create_uint32(env, nv, &v); napi_set_named_property(env, o, "nVars", v);
+    napi_create_uint32(env, np, &v); napi_set_named_property(env, o, "nPublic", v);
+    napi_create_uint32(env, dom, &v); napi_set_named_property(env, o, "domainSize", v);
+    napi_create_uint32(env, world, &v); napi_set_named_property(env, o, "world", v);
+    napi_get_boolean(env, dist != 0, &v); napi_set_named_property(env, o, "distributedCalcH", v);
+    return o;
+}
+
 /* init(device[, libPath]) -> device info string */
 static napi_value js_init(napi_env env, napi_callback_info info) {
     size_t argc = 2; napi_value argv[2], s;
@@ -454,6 +630,13 @@ static napi_value module_init(napi_env env, napi_value exports) {
         {"prove", NULL, js_prove, NULL, NULL, NULL, napi_default, NULL},
         {"waitTables", NULL, js_wait_tables, NULL, NULL, NULL, napi_default, NULL},
         {"verify", NULL, js_verify, NULL, NULL, NULL, napi_default, NULL},
+        {"groupCreate", NULL, js_group_create, NULL, NULL, NULL, napi_default, NULL},
+        {"groupFree", NULL, js_group_free, NULL, NULL, NULL, napi_default, NULL},
+        {"groupMultiexp", NULL, js_group_msm, NULL, NULL, NULL, napi_default, NULL},
+        {"groupLoadKey", NULL, js_group_loadkey, NULL, NULL, NULL, napi_default, NULL},
+        {"groupProve", NULL, js_group_prove, NULL, NULL, NULL, napi_default, NULL},
+        {"groupWaitTables", NULL, js_group_wait_tables, NULL, NULL, NULL, napi_default, NULL},
+        {"groupKeyInfo", NULL, js_group_keyinfo, NULL, NULL, NULL, napi_default, NULL},
     };
     CHECK(env, napi_define_properties(env, exports, sizeof props / sizeof props[0], props));
     return exports;
