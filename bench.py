@@ -122,7 +122,7 @@ def main():
     ap.add_argument("--key-container", choices=["auto", "file", "sections"], default="auto",
                     help="proving_key.bin (u32 offsets: up to 4 GiB) or the section container (wsnark_pkey_load_sections); auto = sections from 2^23")
     ap.add_argument("--log-n", type=int, default=20, help="--workload msm / extras: pairs per MSM")
-    ap.add_argument("--extras", default="msm,ntt,cold,inflight,sparse", help="comma list (N=1 only): msm, ntt, cold, inflight, sparse")
+    ap.add_argument("--extras", default="msm,ntt,cold,inflight,sparse,node", help="comma list (N=1 only): msm, ntt, cold, inflight, sparse, node")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alone-pass", action="store_true",
@@ -132,6 +132,12 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="N>1 transport: nccl (= RCCL over xGMI; one GPU per rank) or gloo with host staging -- the latter lets "
                          "several ranks SHARE one GPU (functional check of the N>1 path on a one-GPU box; not a scaling measurement)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--gpus N > 1 WITHOUT torch.distributed: this ONE process drives N devices through wsnark_group_* (csrc/group.hip: "
+                         "a context and a host thread per device, points shards, the transport inside the library) -- what the Node drop-in's "
+                         "buildBn128({devices}) uses.  Run it plainly: python bench.py --gpus N --single-process")
+    ap.add_argument("--group-devices", default="", help="--single-process: comma list of device ordinals (default 0..N-1; an ordinal may repeat: "
+                                                        "several contexts on one GPU, a functional check)")
     ap.add_argument("--calc-h", choices=["replicated", "dist", "native"], default="native",
                     help="N>1: 'native' = wsnark_groth16_prove_dist: points-sharded key (1/N resident per rank), distributed CALC_H, one C call "
                          "per proof with the transport as callbacks; 'dist' = the same algorithm orchestrated from Python on window shards of "
@@ -164,7 +170,10 @@ def main():
     import wasmsnark_amd
     bn = wasmsnark_amd.build(device=local_rank)
     ctx = {"args": args, "bn": bn, "rank": rank, "world": world, "dev": dev, "torch": torch, "dist": dist}
-    out = bench_msm(ctx) if args.workload == "msm" else bench_prove(ctx)
+    if args.single_process and world == 1 and args.gpus > 1:
+        out = bench_group(ctx)
+    else:
+        out = bench_msm(ctx) if args.workload == "msm" else bench_prove(ctx)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -522,6 +531,9 @@ def bench_prove(ctx):
                        "callers hold it (src/bn128.js:580; key handle resident): the %d-byte H2D copy is inside every proof" % len(wit),
                "ms": round(host_ms, 3), "proofs_per_s": round(1e3 / host_ms, 2), "steps": args.steps, "same_proof": host_ok,
                "over_resident_witness_ms": round(host_ms - ms, 3)},
+           "drop_in_call_ms": None if host_ms is None else round(host_ms, 3),      # (= drop_in_call.ms: the call the north star names, PCIe included)
+           "js_drop_in_call_ms": None,                                            # filled by the `node` extra: the same call through the Node.js addon
+           "table_memory": table_memory(key, nv, dom) if world == 1 else None,
            "cold": cold if world == 1 else None,
            "shard": shard_info,
            "int_alu_peaks_this_run": peak,
@@ -542,9 +554,28 @@ def bench_prove(ctx):
         run_extra(extras, "g1_msm_2p%d" % args.log_n, lambda: extra_msm(ctx, "cold" in want_extras))
     if "ntt" in want_extras:
         run_extra(extras, "ntt_2p22", lambda: extra_ntt(ctx))
+        nt = extras.get("ntt_2p22", {})
+        live_peak = max([v for k, v in (peak or {}).items() if k.startswith("modmul") and v] or [0])
+        if "fwd_plus_inv_ms" in nt:
+            # BASELINE config 3 as an object of its own: the one sub-path where the HBM fraction is informative
+            m = 1 << 22
+            out["roofline_c3"] = {"workload": "BN128 Fr NTT + iNTT, 2^22 coefficients, in place, resident", "bound": "hbm",
+                                  "achieved": nt["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nt["hbm_frac"], "traffic": None,
+                                  "ms": {"forward_odd0": nt["fwd_odd0_ms"], "forward_odd1": nt["fwd_odd1_ms"], "inverse": nt["inv_ms"], "forward_plus_inverse": nt["fwd_plus_inv_ms"]},
+                                  "algorithmic_bytes": 2 * 64 * m,
+                                  "int_alu": {"products": int(2 * 13.0 * m),
+                                              "note": "11 butterfly + 2 inter-digit twiddle products per coefficient and transform (three passes): the passes are "
+                                                      "issue-bound (0.83 of the VALU issue slots, profiles/r04_s9_pmc_sq_counters.json), not HBM-bound",
+                                              "G_modmul_per_s": round(2 * 13.0 * m / (nt["fwd_plus_inv_ms"] / 1e3) / 1e9, 1),
+                                              "frac_of_product_peak": round(2 * 13.0 * m / (nt["fwd_plus_inv_ms"] / 1e3) / 1e9 / live_peak, 4) if live_peak else None}}
     if "sparse" in want_extras and args.circuit == "columns" and logd <= 20:
         key.free()
         run_extra(extras, "prove_sparse_rows_circuit", lambda: extra_prove_sparse(ctx, logd))
+    if "node" in want_extras and logd == 20:
+        run_extra(extras, "node_drop_in", lambda: extra_node(ctx, circ, wit, sec))
+        nd = extras.get("node_drop_in", {})
+        if "key_bytes_call_ms" in nd:
+            out["js_drop_in_call_ms"] = nd["key_bytes_call_ms"]
     if extras:
         out["extras"] = extras
     # cpu_baseline: timed on rank 0 at N = 1 only (the contract); an N > 1 line carries the last N = 1 measurement of this
@@ -560,6 +591,109 @@ def bench_prove(ctx):
             pass
     elif world > 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cached_cpu_baseline(cache, logd)
+    return out
+
+
+def table_rows_bytes(n, h):
+    """the library's table geometry (csrc/msm.hip: msm_table_window / msm_table_rows): bytes of the five sections as fixed-base tables"""
+    def c(n):
+        lg = max(n, 1).bit_length() - 1
+        w = lg + 1 if n * 4 >= (5 << lg) else lg
+        return min(max(w, 4), 20)
+    rows = lambda n: -(-255 // c(n))
+    return n * 320 * rows(n) + h * 64 * rows(h), rows(n), rows(h)
+
+
+def table_memory(key, nv, dom):
+    """What the resident key costs and what it buys: this key's bytes as tables / as plain sections, the 2^24 figures on
+    one GPU and per points shard of 8, and the measured sweep over which sections are tables (profiles/r05_table_sweep.txt)."""
+    gb = lambda b: round(b / 2.0**30, 2)
+    b24, _, _ = table_rows_bytes((1 << 24) + 2, 1 << 24)
+    b24s, _, _ = table_rows_bytes(((1 << 24) + 2) // 8, (1 << 24) // 8)
+    return {"this_key_table_GiB": gb(key.table["bytes"]), "this_key_plain_sections_GiB": gb(nv * 320 + dom * 64),
+            "rows": [key.table["rows_w"], key.table["rows_h"]],
+            "2p24_one_gpu_table_GiB": gb(b24), "2p24_per_shard_of_8_table_GiB": gb(b24s), "2p24_plain_sections_GiB": gb(((1 << 24) + 2) * 320 + (1 << 24) * 64),
+            "choice": "WSNARK_KEY_TABLE: 1 = all five sections (default), 0 = none, 2 = hExps only, 3 = A / B1 / B2 / C only; measured ms per proof and GiB "
+                      "for each at 2^20: profiles/r05_table_sweep.txt"}
+
+
+def extra_node(ctx, circ, wit, sec):
+    """The drop-in call as a Node.js caller makes it (wasmsnark_amd/js: groth16GenProof(witness, keyBytes)): tools/node_bench.js in a
+    process of its own on the same GPU, on the benchmark's own key and witness written to a scratch directory."""
+    import shutil
+    import subprocess
+    import tempfile
+    from wasmsnark_amd import synth
+    if shutil.which("node") is None:
+        return {"skipped": "no node on this box"}
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "wasmsnark_amd", "js"), "-s"])
+    d = tempfile.mkdtemp(prefix="wsnark_bench_node_")
+    try:
+        kp, wp = os.path.join(d, "proving_key.bin"), os.path.join(d, "witness.bin")
+        open(kp, "wb").write(synth.sections_to_pkey(sec))
+        open(wp, "wb").write(wit)
+        r = subprocess.run(["node", os.path.join(ROOT, "tools", "node_bench.js"), kp, wp, str(min(20, EXTRA_REPS))], capture_output=True, text=True, timeout=600)
+        line = [x for x in r.stdout.splitlines() if x.startswith("NODE_BENCH ")]
+        if r.returncode or not line:
+            return {"error": (r.stdout + r.stderr)[-400:]}
+        nb = json.loads(line[0][len("NODE_BENCH "):])
+        keep = ("key_bytes_call_ms", "key_bytes_call_trusted_ms", "key_handle_call_ms", "pinned_witness_call_ms", "first_call_ms", "whole_buffer_digest_ms", "reps")
+        out = {k: nb[k] for k in keep if k in nb}
+        out["what"] = ("key_bytes_call_ms = groth16GenProof(witness, keyBytes) in steady state, all key bytes digested beside every proof (the default); "
+                       "..._trusted_ms = {trustCache: true}; key_handle = a loadKey() handle; pinned = the witness in an allocInput() buffer; first_call = key load + first proof of a fresh process")
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def bench_group(ctx):
+    """--gpus N --single-process: ONE process, N devices, wsnark_group_* (csrc/group.hip).  A step is one proof of the 2^logd circuit
+    from a witness in HOST memory (the group call's boundary: every device uploads the whole witness inside the call -- there is no
+    resident-witness form of it), so the figure compares with drop_in_call_ms of the N = 1 line, not with its `value`."""
+    args, bn, torch = ctx["args"], ctx["bn"], ctx["torch"]
+    from wasmsnark_amd import bn128, synth
+    logd = args.prove_log_domain
+    devs = [int(x) for x in args.group_devices.split(",") if x] or list(range(args.gpus))
+    circ = synth.NativeCircuit(bn.lib, logd, n_public=5, seed=1, style=args.circuit)
+    sec, _ = circ.build_sections()
+    wit = circ.witness_bin()
+    r32, s32 = bytes(range(32)), bytes(range(32, 64))
+    want = circ.expected_proof(r32, s32)
+    g = bn128.Group(lib=bn.lib, devices=devs)
+    t0 = time.perf_counter()
+    key = g.load_key(sections=sec)
+    t_load = time.perf_counter() - t0
+    step = lambda: g.groth16GenProof(wit, key, r=r32, s=s32)
+    first = step()
+    for _ in range(args.warmup):
+        last = step()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    dt = time.perf_counter() - t0
+    ms = dt / args.steps * 1e3
+    # the one-GPU call on the same inputs, same process, for the ratio
+    one = bn.load_key(sections=sec)
+    for _ in range(3):
+        p1 = bn.groth16GenProof(wit, one, r=r32, s=s32)
+    t0 = time.perf_counter()
+    for _ in range(max(4, args.steps // 2)):
+        p1 = bn.groth16GenProof(wit, one, r=r32, s=s32)
+    ms1 = (time.perf_counter() - t0) / max(4, args.steps // 2) * 1e3
+    out = {"metric": "BN128 Groth16 prove ms @ 2^%d constraints" % logd, "value": round(ms, 3), "unit": "ms", "n_gpus": len(devs),
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": False, "scaling": "strong",
+           "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+           "config": {"workload": "BN128 full Groth16 prove, synthetic 2^%d-constraint R1CS, key resident as one points shard per device, witness in HOST "
+                                  "memory (uploaded to every device inside the call), r and s injected" % logd,
+                      "parallelism": "ONE process, %d devices %s: wsnark_group_prove (a context + host thread per device, %s, 1 gather of 576 B records in host memory)"
+                                     % (len(devs), devs, "CALC_H on the distributed four-step NTT: 3 device-to-device exchanges (hipMemcpyPeerAsync) per proof"
+                                        if key.distributed_calc_h else "CALC_H complete on every device"),
+                      "device": bn.device_info},
+           "proofs_match_toxic_waste_closed_form": bool(first == want and last == want),
+           "proofs_per_s": round(1e3 / ms, 2), "group_key_load_s": round(t_load, 2),
+           "one_gpu_same_call_ms": round(ms1, 3), "one_gpu_proof_matches": bool(p1 == want), "speedup_over_one_gpu_same_call": round(ms1 / ms, 3),
+           "note": ("several contexts share device(s) %s: a functional check, not a scaling figure" % sorted(set(devs))) if len(set(devs)) < len(devs) else None}
+    key.free(); one.free(); g.terminate()
     return out
 
 
@@ -801,7 +935,24 @@ def cpu_baseline_prove(ctx, logd, circ, wit, sec):
         t0 = time.perf_counter()
         orc.multiexp(2, "multiexp", wit[:n2 * 32], bytes(sec["pointsB2"][:n2 * 128]), n2)
         t_g2 = time.perf_counter() - t0
-        return {"value": round(t_all * 1e3, 1), "unit": "ms", "cores": cores, "host_cores": host_threads, "kind": "port",
+        # the reference's own shape -- 8 workers (src/bn128.js:214) -- on a bounded sample: a whole proof of the same generator's 2^17
+        # circuit (1/8 of the pairs: ~20 s here; the 2^20 proof on 8 threads would take minutes)
+        eight = None
+        try:
+            c17 = synth.NativeCircuit(bn.lib, max(4, logd - 3), n_public=5 if logd >= 8 else 1, seed=1, style="columns")
+            s17, _ = c17.build_sections()
+            k17, w17 = bytearray(synth.sections_to_pkey(s17)), bytearray(c17.witness_bin())
+            o17 = (C.c_uint8 * 384)()
+            t0 = time.perf_counter()
+            rc17 = L.orc_groth16_prove(cb(w17), C.c_size_t(len(w17)), cb(k17), C.c_size_t(len(k17)), cb(bytearray(r32)), cb(bytearray(s32)), 8, o17)
+            t17 = time.perf_counter() - t0
+            eight = {"cores": 8, "ms": round(t17 * 1e3, 1), "sample": "one whole proof of a smaller circuit of the same generator (n_vars %d) on 8 threads: the "
+                                                                      "reference's worker count, src/bn128.js:214 (2^%d: 1/8 of the benchmark's pairs)" % (c17.n_vars, max(4, logd - 3)),
+                     "cpu_proof_matches_closed_form": bool(rc17 == 0 and orc.proof_from_bytes(bytes(o17)) == c17.expected_proof(r32, s32)),
+                     "note": "the sums scale with the pairs (x8 to 2^20), CALC_H with n log n: the survey's reference run at 2^20 on 8 vCPU was %.1f s" % REF_WASM_PROVE_2P20_S}
+        except Exception as e17:  # noqa: BLE001
+            eight = {"error": repr(e17)}
+        return {"value": round(t_all * 1e3, 1), "unit": "ms", "cores": cores, "host_cores": host_threads, "kind": "port", "eight_threads_sample": eight,
                 "sample": "one whole proof of the benchmark's own 2^%d circuit and witness (n_vars %d, nnz %d) by the oracle's groth16GenProof "
                           "restatement: every sum split over %d threads, CALC_H on one thread like the reference's worker; %.2f s"
                           % (logd, nv, circ.nnz, cores, t_all),

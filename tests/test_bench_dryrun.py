@@ -34,6 +34,11 @@ def test_bench_single_gpu_line():
     assert ex["g1_msm_2p8"]["two_in_flight"]["same_results"]
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cpu_proof_matches_closed_form"] is True
     assert "x 16" not in d["cpu_baseline"]["sample"] and d["cpu_baseline"]["one_thread"]["cores"] == 1
+    e8 = d["cpu_baseline"]["eight_threads_sample"]                  # the reference's worker count, on a stated smaller sample
+    assert e8["cores"] == 8 and e8["cpu_proof_matches_closed_form"] is True and e8["ms"] > 0
+    # round 5: the drop-in call's figure at the top level beside `value`, the table memory, the slot of the JS figure
+    assert d["drop_in_call_ms"] == d["drop_in_call"]["ms"] and "js_drop_in_call_ms" in d
+    assert d["table_memory"]["2p24_one_gpu_table_GiB"] > 70 and d["table_memory"]["2p24_per_shard_of_8_table_GiB"] < 12
     assert d["drop_in_call"]["same_proof"] is True and d["drop_in_call"]["ms"] > 0
     cold = d["cold"]
     assert cold["first_proof_matches_closed_form"] is True and cold["table_bytes"] > 0
@@ -74,3 +79,16 @@ def test_bench_two_ranks_falls_through_when_an_orchestration_fails():
         par = d["config"]["parallelism"]
         assert d["proofs_match_toxic_waste_closed_form"] is True and "fell through: native: RuntimeError" in par and ran in par, par
         assert "wsnark_groth16_prove_dist" not in par and d["shard"] is None
+
+
+def test_bench_single_process_group_line():
+    """python bench.py --gpus 2 --single-process: ONE process drives the devices through wsnark_group_* (here: two contexts on the
+    emulator's one device)"""
+    from emul_util import emul_bn128
+    emul_bn128()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_dryrun.py"), "--gpus", "2", "--single-process", "--group-devices", "0,0",
+                          "--prove-log-domain", "6", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900)
+    d = _line(out)
+    assert d["n_gpus"] == 2 and d["proofs_match_toxic_waste_closed_form"] is True and d["one_gpu_proof_matches"] is True
+    assert "wsnark_group_prove" in d["config"]["parallelism"] and "four-step" in d["config"]["parallelism"]
+    assert "functional check" in d["note"]
