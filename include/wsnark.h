@@ -372,7 +372,8 @@ enum {
     WSNARK_ST_MULSUB2 = 11,      /* (a - b)*a - b*a: fused, first operand an uncorrected difference   */
     WSNARK_ST_EQ = 12,           /* out = 1 if a == b else 0 (zero test of the strict difference)    */
     WSNARK_ST_EQ_WEAK = 13,      /* the same through the uncorrected difference                      */
-    WSNARK_ST_INVERSE = 14,      /* 1/a (a != 0); host field only (impl 2): f1m_inverse is per-proof host work */
+    WSNARK_ST_INVERSE = 14,      /* 1/a (a != 0): impl 2 = the host's inversion (proof assembly), impl 0 / 1 (Fq, Fr) = the DEVICE's Fermat
+                                    inversion a^(p-2) on that field -- what the table build's normalisation runs (msm_table_norm_kernel) */
     WSNARK_ST_SQR_WEAK = 15,     /* (a - b)^2 with the uncorrected difference as the operand of the squaring        */
     WSNARK_ST_MUL_WEAK_A = 16,   /* (a - b) * b with the uncorrected difference as the FIRST operand of the product */
     WSNARK_ST_MULSUB2_WEAK_B = 17 /* a*(a - b) - b*a: fused, second operand an uncorrected difference              */
@@ -386,7 +387,8 @@ int wsnark_selftest_field(int which, int impl, int op, const void* a, const void
  *   op: 0 = p + q (full addition), 1 = 2p, 2 = -p, 3 = p (normalisation only), 4 = p + q as a MIXED addition
  *   (q must be affine: z == 1, or infinity), 5 = p - q as a mixed addition with the negate flag,
  *   6 = p + q + q and 7 = p + q - q as two mixed additions of the ACCUMULATION LOOP's lazy form (x kept "wide" between
- *   them, field29.h) followed by its narrowing. */
+ *   them, field29.h) followed by its narrowing, 8 = timesScalar (src/build_timesscalar.js:20-80): q's bytes are NOT a point
+ *   but a little-endian scalar in bytes [0, 64) and its length -- 32 or 64 -- in byte 64 (impl 0-3). */
 int wsnark_selftest_curve(int g, int impl, int op, const void* p, const void* q, void* out, uint64_t n);
 
 /* ---- measurement hooks (bench.py) ---- */

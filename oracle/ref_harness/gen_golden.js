@@ -5,6 +5,7 @@
  *
  *   node oracle/ref_harness/gen_golden.js            # primitives
  *   node oracle/ref_harness/gen_golden.js proofs     # proofs for tests/golden/keys/*.bin
+ *   node oracle/ref_harness/gen_golden.js unreduced  # CALC_H and proofs with witness values / key coefficients in [r, 2^256)
  *
  * The vectors are DATA (inputs + the reference's outputs); no reference source
  * is copied.  Runs only in the build container (the reference is absent on the
@@ -268,5 +269,84 @@ async function proofs() {
     bn.terminate();
 }
 
+/* Inputs the reference accepts but nothing canonicalises before the prover sees them: witness values and key coefficients in
+ * [r, 2^256).  fft_toMontgomeryN (src/build_fft.js:418-458) reduces the signals, g1m_multiexp2 / g2m_multiexp take the raw
+ * 256-bit scalars (src/build_multiexp.js:651-744, 498-580), pol_constructLC multiplies whatever the key holds
+ * (src/build_pol.js:62-144).  CALC_H instances and whole proofs on the t6 key, both with such values, from the reference itself. */
+async function unreduced() {
+    const { bn } = await E.buildRef();
+    const rng = new Rng(5151);
+    const top = (1n << 256n) - 1n;
+    const lift = (v) => {                       // the same residue, somewhere in [r, 2^256)
+        const kmax = (top - v) / R;             // >= 5
+        const k = 1n + rng.next64() % kmax;
+        return v + k * R;
+    };
+    const calch = [];
+    for (const [nSignals, domain, maxnnz] of [[20, 16, 3], [100, 64, 3]]) {
+        const sig = new Uint8Array(nSignals * 32);
+        for (let i = 0; i < nSignals; i++) {
+            const v = i === 0 ? 1n : rng.below(R);
+            sig.set(le32(i % 3 === 1 ? lift(v) : (i % 7 === 3 ? top - BigInt(i) : v)), i * 32);
+        }
+        const mkPols = () => {
+            const parts = [];
+            for (let s = 0; s < nSignals; s++) {
+                const k = Number(rng.next64() % BigInt(maxnnz + 1));
+                const hdr = new Uint8Array(4); new DataView(hdr.buffer).setUint32(0, k, true); parts.push(hdr);
+                const used = new Set();
+                for (let j = 0; j < k; j++) {
+                    let idx; do { idx = Number(rng.next64() % BigInt(domain)); } while (used.has(idx)); used.add(idx);
+                    const rec = new Uint8Array(36); new DataView(rec.buffer).setUint32(0, idx, true);
+                    const c = (rng.below(R) << 256n) % R;
+                    rec.set(le32((s + j) % 2 ? lift(c) : c), 4);   // every other coefficient NOT canonical
+                    parts.push(rec);
+                }
+            }
+            return Buffer.concat(parts.map((p) => Buffer.from(p)));
+        };
+        const pA = mkPols(), pB = mkPols();
+        const h = await bn.calcH(toAB(sig), toAB(pA), toAB(pB), nSignals, domain);
+        calch.push({ nSignals, domain, signals: Buffer.from(sig).toString("base64"), polsA: pA.toString("base64"),
+            polsB: pB.toString("base64"), h: Buffer.from(new Uint8Array(h)).toString("base64") });
+    }
+    // whole proofs on the t6 key: (a) witness values lifted, (b) the key's coefficients lifted, (c) both
+    const dir = path.join(OUT, "keys");
+    const pkey = new Uint8Array(fs.readFileSync(path.join(dir, "t6.pkey.bin")));
+    const wit = new Uint8Array(fs.readFileSync(path.join(dir, "t6.witness.bin")));
+    const vk = JSON.parse(fs.readFileSync(path.join(dir, "t6.vk.json"), "utf8"));
+    const pub = JSON.parse(fs.readFileSync(path.join(dir, "t6.public.json"), "utf8"));
+    if (!vk.vk_alfabeta_12) vk.vk_alfabeta_12 = [[["0", "0"], ["0", "0"], ["0", "0"]], [["0", "0"], ["0", "0"], ["0", "0"]]];
+    const wit2 = new Uint8Array(wit);
+    for (let i = 1; i < wit2.length / 32; i++) if (i % 2) wit2.set(le32(lift(fromLE(wit.subarray(i * 32, i * 32 + 32)))), i * 32);
+    const u32 = new DataView(pkey.buffer, pkey.byteOffset, 40);
+    const nVars = u32.getUint32(0, true), pPolsA = u32.getUint32(12, true);
+    const pkey2 = new Uint8Array(pkey);
+    let off = pPolsA, lifted = 0;
+    for (let m = 0; m < 2; m++) {               // polsA, then polsB right behind it (tools/buildpkey.js:124-186)
+        for (let sgn = 0; sgn < nVars; sgn++) {
+            const k = new DataView(pkey2.buffer, off, 4).getUint32(0, true); off += 4;
+            for (let j = 0; j < k; j++) {
+                if ((sgn + j) % 2 === 0) { pkey2.set(le32(lift(fromLE(pkey2.subarray(off + 4, off + 36)))), off + 4); lifted++; }
+                off += 36;
+            }
+        }
+    }
+    const proofsOut = [];
+    const rs = [[7n, 9n], [(1n << 256n) - 1n, (1n << 256n) - 2n]];
+    for (const [label, w, k] of [["witness lifted", wit2, pkey], ["coefficients lifted", wit, pkey2], ["both lifted", wit2, pkey2]]) {
+        for (const [r, s] of rs) {
+            E.setRS(le32(r), le32(s));
+            const proof = await bn.groth16GenProof(toAB(new Uint8Array(w)), toAB(new Uint8Array(k)));
+            const ok = await bn.groth16Verify(vk, pub, proof);
+            proofsOut.push({ label, r: hex(le32(r)), s: hex(le32(s)), proof, reference_verifies: ok });
+            console.log(label, "verify:", ok);
+        }
+    }
+    fs.writeFileSync(path.join(OUT, "unreduced.json"), JSON.stringify({ calch, key: "t6", coefficients_lifted: lifted,
+        witness_lifted: Buffer.from(wit2).toString("base64"), pkey_lifted: Buffer.from(pkey2).toString("base64"), proofs: proofsOut }, null, 0));
+    bn.terminate();
+}
+
 const mode = process.argv[2] || "primitives";
-(mode === "proofs" ? proofs() : primitives()).catch((e) => { console.error(e); process.exit(1); });
+(mode === "proofs" ? proofs() : mode === "unreduced" ? unreduced() : primitives()).catch((e) => { console.error(e); process.exit(1); });

@@ -58,11 +58,15 @@ def check_base_field(bn, fname, which, impl):
     assert st_field(bn, which, impl, NEG, ua, ua) == [H(c["neg"]) for c in un]
     assert st_field(bn, which, impl, TOMONT, ua, ua) == [H(c["toMontgomery"]) for c in un]
     assert st_field(bn, which, impl, FROMMONT, ua, ua) == [H(c["fromMontgomery"]) for c in un]
-    if impl == 2:
-        inv = [c for c in un if "inverse" in c]
-        assert inv
-        ia = [H(c["a"]) for c in inv]
-        assert st_field(bn, which, impl, INVERSE, ia, ia) == [H(c["inverse"]) for c in inv]
+    # f1m_inverse vectors: the host's inversion (impl 2) and the DEVICE's Fermat inversion on both device fields (impl 0: the one the
+    # table build's normalisation runs, msm_table_norm_kernel; src/build_f1m.js:772-782 gives the same unique value)
+    inv = [c for c in un if "inverse" in c]
+    assert inv
+    ia = [H(c["a"]) for c in inv]
+    assert st_field(bn, which, impl, INVERSE, ia, ia) == [H(c["inverse"]) for c in inv]
+    rnd_inv = random.Random(900 + which * 10 + impl)
+    xs = [rnd_inv.randrange(1, p) for _ in range(64)]
+    assert st_field(bn, which, impl, INVERSE, [_le(x) for x in xs], [_le(x) for x in xs]) == [_le(pow(x, p - 2, p) * pow(1 << 256, 2, p) % p) for x in xs]
     ba, bb = [H(c["a"]) for c in bi], [H(c["b"]) for c in bi]
     assert st_field(bn, which, impl, MUL, ba, bb) == [H(c["mul"]) for c in bi]
     assert st_field(bn, which, impl, ADD, ba, bb) == [H(c["add"]) for c in bi]
@@ -167,6 +171,14 @@ def check_group(bn, orc, g, impl):
     assert multiples[3] == four_d
     ten = [c for c in G["times_scalar"] if _int(H(c["scalar"])) == 10 and c["bytes"] == 32]
     assert ten and multiples[9] == H(ten[0]["affine"])
+    # g{1,2}m_timesScalar itself (src/build_timesscalar.js:20-80; the reference calls it with 32- AND 64-byte scalars,
+    # src/bn128.js:672-702): every reference vector, incl. the 64-byte one, through this implementation's double-and-add
+    if impl != 4:
+        sz = 96 if g == 1 else 192
+        ts = G["times_scalar"]
+        assert any(c["bytes"] == 64 for c in ts)
+        ops = [H(c["scalar"]).ljust(64, b"\0") + bytes([c["bytes"]]) + bytes(sz - 65) for c in ts]
+        assert st_curve(bn, g, impl, 8, [gen] * len(ts), ops) == [H(c["affine"]) for c in ts]
     mixed = gen
     for _ in range(9):
         mixed = st_curve(bn, g, impl, 4, [mixed], [gen])[0]

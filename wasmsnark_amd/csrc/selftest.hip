@@ -48,6 +48,9 @@ __host__ __device__ inline Fe st_base_op(int op, const Fe& ap, const Fe& bp, con
         case WSNARK_ST_MULSUB2_WEAK_B: return F::from_internal(F::mulsub2(a, F::sub_weak(a, b), b, a));
         case WSNARK_ST_EQ: return st_flag<Fe>(F::is_zero(F::sub(a, b)));
         case WSNARK_ST_EQ_WEAK: return st_flag<Fe>(F::is_zero_weak(F::sub_weak(a, b)));
+        // the DEVICE inversion: a^(p-2) on the field the kernels use (msm_table_norm_kernel: one per point and group of table rows);
+        // the reference's f1m_inverse (src/build_f1m.js:772-782, extended Euclid) gives the same unique value
+        case WSNARK_ST_INVERSE: return F::from_internal(F::inv(a));
         default: break;
     }
     if constexpr (F::kHasMul2Add) {
@@ -181,7 +184,7 @@ int selftest_field(int which, int impl, int op, const uint8_t* a, const uint8_t*
         }
         return WS_ERR_ARG;
     }
-    if (op == WSNARK_ST_INVERSE) { set_last_error("selftest: inversion is host work (impl 2)"); return WS_ERR_ARG; }
+    if (op == WSNARK_ST_INVERSE && which == 2) { set_last_error("selftest: the extension field is inverted on the host only (impl 2)"); return WS_ERR_ARG; }
     if (which == 0 && impl == 0) return st_base_dev<Fq29, FqParams>(op, a, b, out, n, s);
     if (which == 0 && impl == 1) return st_base_dev<Fq, FqParams>(op, a, b, out, n, s);
     if (which == 1 && impl == 0) return st_base_dev<Fr29, FrParams>(op, a, b, out, n, s);
@@ -231,6 +234,12 @@ __host__ __device__ inline typename C::PtP st_curve_op(int op, const typename C:
         case 5: r = from_jac(pj); C::madd(r, affine_of(qj), true); break;
         case 6: r = from_jac(pj); C::madd_wide(r, affine_of(qj), false); C::madd_wide(r, affine_of(qj), false); C::narrow_x(r); break;
         case 7: r = from_jac(pj); C::madd_wide(r, affine_of(qj), false); C::madd_wide(r, affine_of(qj), true); C::narrow_x(r); break;
+        case 8: {   // timesScalar (src/build_timesscalar.js:20-80): the second operand's bytes are a little-endian scalar of q[64] = 32 or 64 bytes
+            const uint8_t* sc = reinterpret_cast<const uint8_t*>(qj);
+            const int nb = sc[64] == 64 ? 64 : 32;
+            r = C::mul_bytes(from_jac(pj), sc, nb);
+            break;
+        }
         default: *ok = false; break;
     }
     return C::pt_from_internal(r);
@@ -313,7 +322,7 @@ int selftest_curve(int g, int impl, int op, const uint8_t* p, const uint8_t* q, 
     Context* X = ctx();
     if (!X) return WS_ERR_NOINIT;
     if (n == 0) return WS_OK;
-    if (n > (1u << 20) || op < 0 || op > 7) return WS_ERR_ARG;
+    if (n > (1u << 20) || op < 0 || op > 8 || (op == 8 && impl == 4)) return WS_ERR_ARG;
     hipStream_t s = X->stream;
     if (g == 1) {
         if (impl == 0) return st_curve_dev<G1R29, G1>(op, p, q, out, n, s);
