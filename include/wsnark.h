@@ -290,6 +290,21 @@ typedef struct {
 int wsnark_groth16_prove_dist(wsnark_pkey_t* handle, const void* d_witness, size_t witness_len, const wsnark_comm_t* comm,
                               const void* r32, const void* s32, void* out384_host, void* stream);
 
+/* ---- resident bases (round 5; csrc/fixedbase.hip): NO reference counterpart ----
+ * The reference's g1_multiexp / g2_multiexp (src/bn128.js:353-415) take the points with every call.  A caller that sums over the
+ * SAME bases repeatedly can make them resident once -- as fixed-base window tables, the layout a resident proving key's sections
+ * have: rows x n points, row w = 2^(c w) * P, c = log2 n (13 rows and 13 x the bytes at 2^20) -- and then pays neither the points'
+ * H2D copy nor the per-window plans and the host's doubling chain: every sum is one bucket set and one reduction tail.
+ *   group: 1 = G1 (64-byte affine Montgomery points), 2 = G2 (128-byte); x == 0 is infinity, as everywhere.
+ *   wsnark_points_msm[_dev]: n must be the set's size (one raw 256-bit scalar per point); out = the Jacobian-Montgomery triple
+ *   (96 / 192 bytes, affine-normalised) that wsnark_g{1,2}_msm returns for the same pairs. */
+typedef struct wsnark_points wsnark_points_t;
+int wsnark_points_load(int group, const void* points, uint64_t n, wsnark_points_t** out_handle);
+void wsnark_points_free(wsnark_points_t* handle);
+int wsnark_points_info(const wsnark_points_t* handle, int* group, uint64_t* n, uint32_t* window_bits, uint32_t* rows, uint64_t* table_bytes);
+int wsnark_points_msm(wsnark_points_t* handle, const void* scalars, uint64_t n, void* out);
+int wsnark_points_msm_dev(wsnark_points_t* handle, const void* d_scalars, uint64_t n, void* out_host, void* stream);
+
 /* ---- several GPUs in ONE process (csrc/group.hip; round 5) ----
  * The reference's host is one process that starts W workers (src/bn128.js:173-265, `build()`), cuts every multi-exponentiation
  * into W contiguous ranges of the pairs, posts one to each worker and adds the partial results (:353-415), and runs the five

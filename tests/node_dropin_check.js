@@ -42,6 +42,16 @@ const toAB = (b) => b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength);
         if (Buffer.from(h).toString("base64") !== c.h) throw new Error("calcH mismatch domain=" + c.domain);
         checked++;
     }
+    // bases made resident once (loadPoints: fixed-base tables): the same sums from the handle
+    for (const [g, list] of [[1, msm.g1], [2, msm.g2]]) {
+        for (const c of list) {
+            if (c.flavour === "accumulate_into_3G" || c.n === 0) continue;
+            const h = await bn.loadPoints(g, Buffer.from(c.points, "base64"));
+            const r = await (g === 1 ? bn.g1_multiexp : bn.g2_multiexp).call(bn, Buffer.from(c.scalars, "base64"), h);
+            if (Buffer.from(r).toString("hex") !== c.multiexp_affine) throw new Error("resident-points msm mismatch g" + g + " n=" + c.n);
+            checked++;
+        }
+    }
     const fft = JSON.parse(fs.readFileSync(path.join(gold, "fft.json"), "utf8"));
     for (const c of fft.cases) {
         if (c.n < 2) continue;

@@ -220,3 +220,31 @@ def test_new_entry_points_reject_bad_arguments(bn):
     assert c.wsnark_pkey_eval_ab_dev(key._h, wit, 32, a, a, None) == 1
     r = (C.c_uint8 * 32)()
     assert c.wsnark_groth16_verify(None, 0, None, 0, out, C.byref(C.c_int())) == 4
+
+
+def test_resident_points_give_the_reference_sums(bn, orc):
+    """wsnark_points_load / wsnark_points_msm: a point set resident as fixed-base window tables (no reference counterpart; the layout
+    of a resident key's sections) must give the REFERENCE's g1m_multiexp2 / g2m_multiexp results on the golden cases -- x = 0 points,
+    duplicates, P / -P pairs, zero scalars, raw scalars up to 2^256 - 1 -- and the oracle's on seeded sets; wrong sizes are errors."""
+    import base64
+    from wasmsnark_amd import WsnarkError
+    for g in (1, 2):
+        for c in load_golden("msm.json")["g%d" % g]:
+            if c["flavour"] == "accumulate_into_3G" or c["n"] == 0:
+                continue
+            sc, pts = base64.b64decode(c["scalars"]), base64.b64decode(c["points"])
+            h = bn.load_points(g, pts)
+            assert h.n == c["n"] and h.table["rows"] == -(-255 // h.table["c"])
+            assert h.multiexp(sc) == bytes.fromhex(c["multiexp_affine"]), (g, c["n"], c["flavour"])
+            assert h.multiexp(sc) == bytes.fromhex(c["multiexp_affine"])           # (again: the handle is reusable)
+            h.free()
+    rnd = random.Random(4242)
+    for g, n in ((1, 1300), (2, 300)):
+        pts = _points(orc, g, [rnd.randrange(1, orc.R) for _ in range(n)])
+        h = bn.load_points(g, pts)
+        for _ in range(2):
+            sc = b"".join((rnd.randrange(1 << 256) if i % 5 else i % 3).to_bytes(32, "little") for i in range(n))
+            assert h.multiexp(sc) == orc.g_affine(g, orc.multiexp(g, "multiexp2" if g == 1 else "multiexp", sc, pts, n))
+        with pytest.raises(WsnarkError):
+            h.multiexp(sc[:-32])                                                   # one scalar per point
+        h.free()

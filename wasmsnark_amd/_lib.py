@@ -28,6 +28,7 @@ SYMBOLS = [
     "wsnark_synth_key_scalars", "wsnark_synth_expected",
     "wsnark_selftest_field", "wsnark_selftest_curve",
     "wsnark_timing_enable", "wsnark_timing_reset", "wsnark_timing_report", "wsnark_peak_probe", "wsnark_tuning_set", "wsnark_host_alloc", "wsnark_host_free",
+    "wsnark_points_load", "wsnark_points_free", "wsnark_points_info", "wsnark_points_msm", "wsnark_points_msm_dev",
     "wsnark_group_create", "wsnark_group_free", "wsnark_group_size", "wsnark_group_pkey_load", "wsnark_group_pkey_load_sections", "wsnark_group_pkey_free",
     "wsnark_group_pkey_info", "wsnark_group_pkey_wait_tables", "wsnark_group_prove", "wsnark_group_last_blinding", "wsnark_group_g1_msm", "wsnark_group_g2_msm",
 ]
@@ -122,6 +123,12 @@ class Lib:
         c.wsnark_synth_pols.argtypes = [vp, C.c_int, vp, u64]
         c.wsnark_synth_key_scalars.argtypes = [vp, C.c_int, vp]
         c.wsnark_synth_expected.argtypes = [vp, vp, vp, vp]
+        c.wsnark_points_load.argtypes = [C.c_int, vp, u64, C.POINTER(vp)]
+        c.wsnark_points_free.argtypes = [vp]
+        c.wsnark_points_free.restype = None
+        c.wsnark_points_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(u64), C.POINTER(u32), C.POINTER(u32), C.POINTER(u64)]
+        c.wsnark_points_msm.argtypes = [vp, vp, u64, vp]
+        c.wsnark_points_msm_dev.argtypes = [vp, vp, u64, vp, vp]
         c.wsnark_group_create.argtypes = [C.POINTER(C.c_int), u32, C.POINTER(vp)]
         c.wsnark_group_free.argtypes = [vp]
         c.wsnark_group_free.restype = None

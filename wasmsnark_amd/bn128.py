@@ -130,6 +130,46 @@ class ProvingKey:
             pass
 
 
+class ResidentPoints:
+    """A point set kept on the device as fixed-base window tables (wsnark_points_load): sums over the same bases without the
+    points' H2D copy, the per-window plans and the host's doubling chain.  g: 1 (G1) or 2 (G2)."""
+
+    def __init__(self, lib, g, points):
+        self._lib, self.g = lib, g
+        b, nbytes = _ro(points)
+        sz = 128 if g == 2 else 64
+        if nbytes % sz:
+            raise ValueError("points: not a whole number of %d-byte points" % sz)
+        self.n = nbytes // sz
+        self._h = C.c_void_p()
+        lib.check(lib.c.wsnark_points_load(g, b, self.n, C.byref(self._h)))
+        gg, n, c, rows, nb = C.c_int(), C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint64()
+        lib.check(lib.c.wsnark_points_info(self._h, C.byref(gg), C.byref(n), C.byref(c), C.byref(rows), C.byref(nb)))
+        self.table = {"c": c.value, "rows": rows.value, "bytes": nb.value}
+
+    def multiexp(self, scalars):
+        b, n = _ro(scalars)
+        out = (C.c_uint8 * (192 if self.g == 2 else 96))()
+        self._lib.check(self._lib.c.wsnark_points_msm(self._h, b, n // 32, out))
+        return bytes(out)
+
+    def multiexp_dev(self, d_scalars, n, stream=None):
+        out = (C.c_uint8 * (192 if self.g == 2 else 96))()
+        self._lib.check(self._lib.c.wsnark_points_msm_dev(self._h, d_scalars, n, out, stream))
+        return bytes(out)
+
+    def free(self):
+        if self._h:
+            self._lib.c.wsnark_points_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 def _key_sections(sections):
     """dict of byte strings -> (the C struct wsnark_key_sections_t, the buffers it points into)"""
     ks = _KeySections(sections["n_vars"], sections["n_public"], sections["domain"])
@@ -339,6 +379,10 @@ class Bn128:
         fn = self.lib.c.wsnark_g1_mul_base_batch if g == 1 else self.lib.c.wsnark_g2_mul_base_batch
         self.lib.check(fn(b, s, n, out))
         return bytes(out)[: n * sz]
+
+    def load_points(self, g, points):
+        """Make a point set resident as fixed-base tables (no reference counterpart): see ResidentPoints."""
+        return ResidentPoints(self.lib, g, points)
 
     def load_key(self, pkey=None, sections=None, shard=None, h_interleave_log=0, wait_tables=True):
         return ProvingKey(self.lib, pkey, sections, shard, h_interleave_log, wait_tables)

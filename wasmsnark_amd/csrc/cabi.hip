@@ -40,6 +40,12 @@ void g2_sum_host(const uint8_t* pts, uint64_t count, uint8_t* out192);
 int g1_mul_base_batch(const void* base, const void* scalars, uint64_t n, void* out);
 int g2_mul_base_batch(const void* base, const void* scalars, uint64_t n, void* out);
 int peak_probe(int probe, double* gops);
+struct ResidentPoints;
+Context* points_context(const ResidentPoints* H);
+int points_load(int which, const void* h_points, uint64_t n, ResidentPoints** out);
+void points_free(ResidentPoints* H);
+void points_info(const ResidentPoints* H, int* which, uint64_t* n, uint32_t* table_c, uint32_t* rows, uint64_t* bytes);
+int points_msm(ResidentPoints* H, const void* scalars, bool on_device, uint64_t n, void* out, hipStream_t s);
 int selftest_field(int which, int impl, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, uint64_t n);
 int selftest_curve(int g, int impl, int op, const uint8_t* p, const uint8_t* q, uint8_t* out, uint64_t n);
 }  // namespace wsnark
@@ -134,6 +140,43 @@ int wsnark_g2_sum(const void* jac_points, uint64_t count, void* out192) {
     if (!out192 || (count && !jac_points)) return WSNARK_ERR_ARG;
     g2_sum_host((const uint8_t*)jac_points, count, (uint8_t*)out192);
     return WSNARK_OK;
+}
+
+// ---- resident bases: a point set kept on the device as fixed-base window tables (fixedbase.hip) ----
+int wsnark_points_load(int group, const void* points, uint64_t n, wsnark_points_t** out_handle) {
+    REQUIRE_CTX();
+    if (group != 1 && group != 2) return WSNARK_ERR_ARG;
+    ResidentPoints* H = nullptr;
+    int rc = points_load(group - 1, points, n, &H);
+    if (rc) return rc;
+    *out_handle = reinterpret_cast<wsnark_points_t*>(H);
+    return WSNARK_OK;
+}
+void wsnark_points_free(wsnark_points_t* h) {
+    if (!h) return;
+    CtxScope scope(points_context(reinterpret_cast<const ResidentPoints*>(h)));
+    points_free(reinterpret_cast<ResidentPoints*>(h));
+}
+int wsnark_points_info(const wsnark_points_t* h, int* group, uint64_t* n, uint32_t* window_bits, uint32_t* rows, uint64_t* table_bytes) {
+    if (!h) return WSNARK_ERR_ARG;
+    int which = 0;
+    points_info(reinterpret_cast<const ResidentPoints*>(h), &which, n, window_bits, rows, table_bytes);
+    if (group) *group = which + 1;
+    return WSNARK_OK;
+}
+int wsnark_points_msm(wsnark_points_t* h, const void* scalars, uint64_t n, void* out) {
+    if (!h) return WSNARK_ERR_ARG;
+    Context* C = points_context(reinterpret_cast<const ResidentPoints*>(h));
+    if (!C) return WSNARK_ERR_NOINIT;
+    CtxScope scope(C);
+    return points_msm(reinterpret_cast<ResidentPoints*>(h), scalars, false, n, out, nullptr);
+}
+int wsnark_points_msm_dev(wsnark_points_t* h, const void* d_scalars, uint64_t n, void* out_host, void* stream) {
+    if (!h) return WSNARK_ERR_ARG;
+    Context* C = points_context(reinterpret_cast<const ResidentPoints*>(h));
+    if (!C) return WSNARK_ERR_NOINIT;
+    CtxScope scope(C);
+    return points_msm(reinterpret_cast<ResidentPoints*>(h), d_scalars, true, n, out_host, (hipStream_t)stream);
 }
 
 // ---- NTT ----

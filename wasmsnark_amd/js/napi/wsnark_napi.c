@@ -21,6 +21,7 @@
 #include <string.h>
 
 typedef struct wsnark_pkey wsnark_pkey_t;
+typedef struct wsnark_points wsnark_points_t;
 typedef struct wsnark_group wsnark_group_t;
 typedef struct wsnark_group_pkey wsnark_group_pkey_t;
 static struct {
@@ -43,6 +44,10 @@ static struct {
     void (*host_free)(void*);
     int (*pkey_load_stats)(const wsnark_pkey_t*, double*);
     int (*pkey_wait_tables)(wsnark_pkey_t*);
+    int (*points_load)(int, const void*, uint64_t, wsnark_points_t**);
+    void (*points_free)(wsnark_points_t*);
+    int (*points_info)(const wsnark_points_t*, int*, uint64_t*, uint32_t*, uint32_t*, uint64_t*);
+    int (*points_msm)(wsnark_points_t*, const void*, uint64_t, void*);
     /* several GPUs in this one process (include/wsnark.h: wsnark_group_*) */
     int (*group_create)(const int*, uint32_t, wsnark_group_t**);
     void (*group_free)(wsnark_group_t*);
@@ -82,6 +87,7 @@ static int load_lib(const char* explicit_path, char* err, size_t errlen) {
     SYM(last_blinding, "wsnark_last_blinding") SYM(verify, "wsnark_groth16_verify")
     SYM(host_alloc, "wsnark_host_alloc") SYM(host_free, "wsnark_host_free")
     SYM(pkey_load_stats, "wsnark_pkey_load_stats") SYM(pkey_wait_tables, "wsnark_pkey_wait_tables")
+    SYM(points_load, "wsnark_points_load") SYM(points_free, "wsnark_points_free") SYM(points_info, "wsnark_points_info") SYM(points_msm, "wsnark_points_msm")
     SYM(group_create, "wsnark_group_create") SYM(group_free, "wsnark_group_free") SYM(group_pkey_load, "wsnark_group_pkey_load")
     SYM(group_pkey_free, "wsnark_group_pkey_free") SYM(group_pkey_info, "wsnark_group_pkey_info")
     SYM(group_pkey_wait_tables, "wsnark_group_pkey_wait_tables") SYM(group_prove, "wsnark_group_prove")
@@ -112,7 +118,7 @@ static int get_bytes(napi_env env, napi_value v, uint8_t** p, size_t* n) {
 }
 
 enum { OP_G1, OP_G2, OP_NTT, OP_CALCH, OP_PROVE, OP_LOADKEY, OP_VERIFY, OP_HASH, OP_WAIT_TABLES,
-       OP_GROUP_G1, OP_GROUP_G2, OP_GROUP_LOADKEY, OP_GROUP_PROVE, OP_GROUP_WAIT_TABLES };
+       OP_GROUP_G1, OP_GROUP_G2, OP_GROUP_LOADKEY, OP_GROUP_PROVE, OP_GROUP_WAIT_TABLES, OP_POINTS_LOAD, OP_POINTS_MSM };
 /* A group and the keys loaded on it.  The JS side holds them as externals; a key's finalizer must not touch a group that
  * terminate() has already freed (wsnark_group_free frees the keys that are left), so every group handle carries a `live` flag
  * that outlives the group itself and every key handle points at its group's handle. */
@@ -132,6 +138,7 @@ typedef struct {
     wsnark_pkey_t* key;
     group_ref_t* gr;
     gkey_ref_t* gk;
+    wsnark_points_t* pts;
     uint8_t* out;
     size_t nout;
     char err[512];
@@ -222,6 +229,8 @@ static void job_execute(napi_env env, void* data) {
         if (!j->rc) j->rc = L.group_last_blinding(j->gk->gr->g, j->out + 384, j->out + 416);
         break;
     case OP_GROUP_WAIT_TABLES: j->rc = L.group_pkey_wait_tables(j->gk->k); break;
+    case OP_POINTS_LOAD: j->rc = L.points_load(j->i0, j->a, j->na / (j->i0 == 2 ? 128 : 64), &j->pts); break;
+    case OP_POINTS_MSM: j->rc = L.points_msm(j->pts, j->a, j->na / 32, j->out); break;
     case OP_HASH:
         if (hash_bytes(j->a, j->na, j->out)) { j->rc = -1; snprintf(j->err, sizeof j->err, "hashBytes: out of memory"); return; }
         break;
@@ -234,6 +243,10 @@ static void key_finalize(napi_env env, void* data, void* hint) {
     if (data) L.pkey_free((wsnark_pkey_t*)data);
 }
 
+static void points_finalize(napi_env env, void* data, void* hint) {
+    (void)env; (void)hint;
+    if (data) L.points_free((wsnark_points_t*)data);
+}
 static void gkey_finalize(napi_env env, void* data, void* hint) {
     (void)env; (void)hint;
     gkey_ref_t* gk = (gkey_ref_t*)data;
@@ -261,6 +274,9 @@ static void job_complete(napi_env env, napi_status status, void* data) {
         if (j->op == OP_GROUP_LOADKEY && j->gk) { group_ref_drop(j->gk->gr); free(j->gk); }
     } else if (j->op == OP_GROUP_LOADKEY) {
         napi_create_external(env, j->gk, gkey_finalize, NULL, &res);
+        napi_resolve_deferred(env, j->deferred, res);
+    } else if (j->op == OP_POINTS_LOAD) {
+        napi_create_external(env, j->pts, points_finalize, NULL, &res);
         napi_resolve_deferred(env, j->deferred, res);
     } else if (j->op == OP_VERIFY) {
         napi_get_boolean(env, j->i0 != 0, &res);
@@ -460,6 +476,34 @@ static napi_value js_keyinfo(napi_env env, napi_callback_info info) {
     return o;
 }
 
+/* ---- resident bases ----
+ * loadPoints(group 1|2, points) -> Promise<handle>: the set resident as fixed-base window tables (wsnark_points_load) */
+static napi_value js_points_load(napi_env env, napi_callback_info info) {
+    size_t argc = 2; napi_value argv[2];
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    job_t* j = (job_t*)calloc(1, sizeof *j);
+    j->op = OP_POINTS_LOAD;
+    if (argc < 2 || napi_get_value_int32(env, argv[0], &j->i0) != napi_ok || (j->i0 != 1 && j->i0 != 2) || !get_bytes(env, argv[1], &j->a, &j->na) ||
+        j->na == 0 || j->na % (j->i0 == 2 ? 128 : 64))
+        FAIL(env, j, "expected (1 | 2, a whole number of affine points)");
+    keep(env, j, argv[1]);
+    return start_job(env, j, "wsnark_points_load");
+}
+/* pointsMultiexp(handle, scalars) -> Promise<ArrayBuffer 96/192> */
+static napi_value js_points_msm(napi_env env, napi_callback_info info) {
+    size_t argc = 2; napi_value argv[2];
+    int g = 0;
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    job_t* j = (job_t*)calloc(1, sizeof *j);
+    j->op = OP_POINTS_MSM;
+    if (argc < 2 || napi_get_value_external(env, argv[0], (void**)&j->pts) != napi_ok || !j->pts || !get_bytes(env, argv[1], &j->a, &j->na))
+        FAIL(env, j, "expected (points handle, scalars)");
+    L.points_info(j->pts, &g, NULL, NULL, NULL, NULL);
+    j->nout = g == 2 ? 192 : 96; j->out = (uint8_t*)malloc(j->nout);
+    keep(env, j, argv[0]); keep(env, j, argv[1]);
+    return start_job(env, j, "wsnark_points_msm");
+}
+
 /* ---- several GPUs in this one process ----
  * groupCreate([device, ...]) -> group handle (synchronous: contexts and worker threads are created at once) */
 static napi_value js_group_create(napi_env env, napi_callback_info info) {
@@ -630,6 +674,8 @@ static napi_value module_init(napi_env env, napi_value exports) {
         {"prove", NULL, js_prove, NULL, NULL, NULL, napi_default, NULL},
         {"waitTables", NULL, js_wait_tables, NULL, NULL, NULL, napi_default, NULL},
         {"verify", NULL, js_verify, NULL, NULL, NULL, napi_default, NULL},
+        {"loadPoints", NULL, js_points_load, NULL, NULL, NULL, napi_default, NULL},
+        {"pointsMultiexp", NULL, js_points_msm, NULL, NULL, NULL, napi_default, NULL},
         {"groupCreate", NULL, js_group_create, NULL, NULL, NULL, napi_default, NULL},
         {"groupFree", NULL, js_group_free, NULL, NULL, NULL, napi_default, NULL},
         {"groupMultiexp", NULL, js_group_msm, NULL, NULL, NULL, napi_default, NULL},
