@@ -796,6 +796,28 @@ def extra_msm(ctx, cold):
     res = {"ms": round(t * 1e3, 4), "Mpoints_per_s": round(n / t / 1e6, 2), "kernel_ms": kernel_ms(bn.lib.timing_report(), 3),
            "roofline": hbm, "roofline_int_alu": alu,
            "whole_msm_frac_of_multiplier_peak": round(10 * 16 * n / t / 1e9 / live, 4) if args.log_n == 20 else None}
+    # the same bases made resident once (wsnark_points_load: fixed-base window tables) -- what a caller that sums over one base
+    # set again and again pays per call: no points upload / preparation, ceil(254 / table c) windows instead of 16
+    if args.log_n >= 16:
+        t0 = time.perf_counter()
+        rp = bn.load_points(1, pts)
+        t_load = time.perf_counter() - t0
+        rcall = lambda: rp.multiexp_dev(d_s.data_ptr(), n)
+        same = all(rcall() == ref for _ in range(min(10, EXTRA_REPS)))
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps):
+            rcall()
+        torch.cuda.synchronize()
+        tr = (time.perf_counter() - t0) / reps
+        rows = rp.table["rows"]
+        res["resident_bases"] = {"ms": round(tr * 1e3, 4), "Mpoints_per_s": round(n / tr / 1e6, 2), "same_result_as_per_call": same,
+                                 "table": rp.table, "load_ms": round(t_load * 1e3, 2),
+                                 "frac_of_multiplier_peak": round(10 * rows * n / tr / 1e9 / live, 4),
+                                 "frac_priced_as_the_per_call_sum": round(10 * 16 * n / tr / 1e9 / live, 4) if args.log_n == 20 else None,
+                                 "note": "frac_of_multiplier_peak counts the additions this path performs (rows windows x n x 10 products); "
+                                         "frac_priced_as_the_per_call_sum prices the same call at the 16 windows the per-call sum needs, "
+                                         "i.e. whole_msm_frac_of_multiplier_peak's numerator over this path's time"}
+        rp.free()
     # two MSMs in flight (two host threads, two lanes)
     bad = []
 

@@ -822,3 +822,30 @@ def test_dist_prover_world_of_one_on_gpu(bn, logd):
     assert dp.prove(d_w.data_ptr(), len(wit), r=r, s=s) == want
     assert bn.groth16GenProof(wit, key, r=r, s=s) == want
     key.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("g", [1, 2])
+def test_resident_bases_give_the_per_call_sums(bn, g):
+    """wsnark_points_load: the bases resident as fixed-base tables; sums from the handle == sums from the bytes (reference
+    src/bn128.js:353-415 semantics), for uniform, skewed and all-zero scalars, from host and from device scalars."""
+    import numpy as np
+    import torch
+    n = 1 << (18 if g == 1 else 16)
+    rng = np.random.default_rng(77 + g)
+    ks = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); ks[:, 31] &= 0x1F
+    pts = bn.mul_base(g, ks.tobytes())
+    rp = bn.load_points(g, pts)
+    assert rp.n == n and rp.table["rows"] * rp.table["c"] >= 254
+    per_call = bn.g1_multiexp if g == 1 else bn.g2_multiexp
+    sc = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); sc[:, 31] &= 0x1F
+    skew = sc.copy(); u = rng.random(n); skew[u < 0.07] = 0; skew[(u >= 0.07) & (u < 0.10)] = 0; skew[(u >= 0.07) & (u < 0.10), 0] = 1
+    skew[u > 0.9, 4:] = 0
+    for s_ in (sc, skew, np.zeros_like(sc)):
+        want = per_call(s_.tobytes(), pts)
+        assert rp.multiexp(s_.tobytes()) == want
+        d = torch.from_numpy(s_.reshape(-1)).cuda()
+        assert rp.multiexp_dev(d.data_ptr(), n) == want
+    with pytest.raises(Exception):
+        rp.multiexp(sc[: n // 2].tobytes())          # a handle sums over the whole set
+    rp.free()

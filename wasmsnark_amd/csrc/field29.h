@@ -49,6 +49,7 @@ template <class P> WS_NOINLINE_DEV F29 mont_mul29(WS_L9(a), WS_L9(b));
 template <class P> WS_NOINLINE_DEV F29 mont_sqr29(WS_L9(a));
 template <class P> WS_NOINLINE_DEV F29 mont_mul2add29(WS_L9(a), WS_L9(b), WS_L9(c), WS_L9(d));
 template <class P> WS_HD F29 mont_mul29_body(const F29& a, const F29& b);
+template <class P> WS_HD F29 mont_sqr29_body(const F29& a);
 
 #define WS_M29 0x1FFFFFFFu
 #ifndef WS_F29_MULSUB_INLINE
@@ -561,11 +562,11 @@ WS_NOINLINE_DEV F29 mont_mul2add29(WS_L9(a), WS_L9(b), WS_L9(c), WS_L9(d)) {
     return r;
 }
 
-// squaring: off-diagonal products once, doubled (45 instead of 81 a*a products)
+// squaring: off-diagonal products once, doubled (45 instead of 81 a*a products).  Operands up to 10p ("wide"): the doubled limbs
+// stay below 2^30 (top one 2^26), a column holds at most 4 doubled products + a square + 9 reduction terms < 2^63.
 template <class P>
-WS_NOINLINE_DEV F29 mont_sqr29(WS_L9(a)) {
+WS_HD F29 mont_sqr29_body(const F29& a) {
     typedef Field29<P> F;
-    const F29 a = {{a0, a1, a2, a3, a4, a5, a6, a7, a8}};
     uint32_t m[9], ad[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) ad[i] = a.v[i] << 1;
@@ -595,12 +596,24 @@ WS_NOINLINE_DEV F29 mont_sqr29(WS_L9(a)) {
     r.v[8] = (uint32_t)acc;
     return r;
 }
+template <class P>
+WS_NOINLINE_DEV F29 mont_sqr29(WS_L9(a)) {
+    const F29 a = {{a0, a1, a2, a3, a4, a5, a6, a7, a8}};
+    return mont_sqr29_body<P>(a);
+}
 
 // variant whose products are inlined (see mont_mul29_body)
 template <class P>
 struct Field29I : Field29<P> {
     WS_HD static F29 mul(const F29& a, const F29& b) { return mont_mul29_body<P>(a, b); }
+#ifndef WS_SQR_INL_DEDICATED
+#define WS_SQR_INL_DEDICATED 1
+#endif
+#if WS_SQR_INL_DEDICATED
+    WS_HD static F29 sqr(const F29& a) { return mont_sqr29_body<P>(a); }
+#else
     WS_HD static F29 sqr(const F29& a) { return mont_mul29_body<P>(a, a); }
+#endif
     WS_HD static F29 mulsub2(const F29& a, const F29& b, const F29& c, const F29& d) {
         return Field29<P>::mul2add_inl(a, b, Field29<P>::neg_weak(c), d);   // fused, like Field29's, but inlined
     }

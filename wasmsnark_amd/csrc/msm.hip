@@ -198,6 +198,104 @@ __global__ __launch_bounds__(1024) void presort_scatter(PresortArgs A, uint32_t*
     }
 }
 
+// The same scatter for plans of <= 16 windows (every plan of 2^14 pairs and more), one scalar per thread: the digits are taken
+// ONCE, statically unrolled -- no run-time indexing of the scalar's limbs (48 bytes of scratch per lane in the kernel above), no
+// second extraction -- and the LDS atomic that counts an entry is also the one that ranks it; entries wait in registers for
+// the workgroup's bin reservations.  The exclusive scan of the bin counts is taken by every workgroup for itself (4096 counters,
+// a few microseconds beside the digit work; one launch and one dependency less than a scan kernel in between); workgroup 0
+// leaves the starts behind for presort_bins.  bin_cursor: zero at launch, counts RELATIVE to the bin's start.
+static const uint32_t PRESORT_ONCE_W = 16;
+// exclusive scan of one value per thread over a workgroup of up to 1024 threads; *total = the sum.  wsum: 17 words of LDS.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wsum, uint32_t* total) {
+    const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    uint32_t x = v;
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl(x, (int)(lane >= d ? lane - d : lane));
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) wsum[wid] = x;
+    __syncthreads();
+    if (wid == 0) {
+        const uint32_t w = lane < nw ? wsum[lane] : 0;
+        uint32_t t = w;
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl(t, (int)(lane >= d ? lane - d : lane));
+            if (lane >= d) t += y;
+        }
+        if (lane < nw) wsum[lane] = t - w;
+        if (lane == 63) wsum[16] = t;
+    }
+    __syncthreads();
+    *total = wsum[16];
+    return wsum[wid] + x - v;
+}
+template <class E>
+__global__ __launch_bounds__(1024) void presort_scatter_once(PresortArgs A, const uint32_t* __restrict__ bin_count,
+                                                               uint32_t* __restrict__ bin_start, uint32_t* __restrict__ bin_cursor,
+                                                               E* __restrict__ entries) {
+    __shared__ uint32_t cnt[PRESORT_MAX_BINS];
+    __shared__ uint32_t gbase[PRESORT_MAX_BINS];
+    __shared__ uint32_t wsum[17];
+    {
+        // gbase[b] = start of bin b (thread t owns `per` consecutive bins)
+        const uint32_t per = (A.nbins + blockDim.x - 1) / blockDim.x, b0 = threadIdx.x * per;
+        uint32_t mine = 0, total;
+        for (uint32_t b = b0; b < b0 + per && b < A.nbins; b++) mine += bin_count[b];
+        uint32_t run = block_exclusive_scan(mine, wsum, &total);
+        for (uint32_t b = b0; b < b0 + per && b < A.nbins; b++) {
+            gbase[b] = run;
+            if (blockIdx.x == 0) bin_start[b] = run;
+            run += bin_count[b];
+            cnt[b] = 0;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) bin_start[A.nbins] = total;
+    }
+    __syncthreads();
+    const uint32_t i = A.i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < A.i_end && (!A.mask || A.mask[i]);
+    const uint32_t NONE = 0xFFFFFFFFu;
+    E ent[PRESORT_ONCE_W];
+    uint32_t where[PRESORT_ONCE_W];          // bin | rank within this workgroup's share of the bin << 12
+    {
+        const Fe s = live ? Fr::reduce_full(A.scalars[i]) : Fe{{0, 0, 0, 0}};
+        const uint32_t c = A.c, NB = 1u << (c - 1), lo_mask = (1u << A.lo_bits) - 1;
+        uint32_t carry = 0, k = 0, next_own = A.w_off;
+#pragma unroll
+        for (uint32_t w = 0; w < PRESORT_ONCE_W; w++) {
+            where[w] = NONE;
+            ent[w] = 0;
+            if (w < A.Wall) {
+                const uint32_t bit = w * c, limb = bit >> 6, off = bit & 63;
+                const uint64_t lo = limb == 0 ? s.l[0] : limb == 1 ? s.l[1] : limb == 2 ? s.l[2] : limb == 3 ? s.l[3] : 0;
+                const uint64_t hi = limb == 0 ? s.l[1] : limb == 1 ? s.l[2] : limb == 2 ? s.l[3] : 0;
+                uint64_t v = lo >> off;
+                if (off + c > 64) v |= hi << (64 - off);
+                uint32_t d = (uint32_t)(v & ((1u << c) - 1)) + carry;
+                uint32_t neg = 0;
+                if (d > NB) { d = (1u << c) - d; neg = 1; carry = 1; } else carry = 0;
+                if (w == next_own) {
+                    if (live && d) {
+                        const uint32_t b = presort_bin(A, k, d);
+                        where[w] = b | (atomicAdd(&cnt[b], 1u) << 12);
+                        ent[w] = PresortEntry<E>::make(A.flat ? w * A.n + i : i, neg, (d - 1) & lo_mask, A.idx_bits);
+                    }
+                    k++;
+                    next_own += A.w_stride;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < A.nbins; b += blockDim.x) {
+        const uint32_t c0 = cnt[b];
+        if (c0) gbase[b] += atomicAdd(&bin_cursor[b], c0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t w = 0; w < PRESORT_ONCE_W; w++)
+        if (where[w] != NONE) entries[gbase[where[w] & 0xFFFu] + (where[w] >> 12)] = ent[w];
+}
+
 // 1..255, monotone in len: the task planner's length key (see msm_plan_* below)
 __device__ __forceinline__ uint32_t len_key(uint32_t len, uint32_t lmax) {
     uint32_t k = (len * 255u + lmax - 1) / lmax;
@@ -237,7 +335,7 @@ __global__ __launch_bounds__(1024) void presort_bins(const E* __restrict__ entri
                                                        const uint8_t* __restrict__ mask, uint32_t mask_mod) {
     __shared__ uint32_t sub[1u << PRESORT_MAX_LO];
     __shared__ uint32_t off[1u << PRESORT_MAX_LO];
-    __shared__ uint32_t part[1024];
+    __shared__ uint32_t wsum[17];
     __shared__ uint32_t lhist[256];
     const uint32_t bin = blockIdx.x, SUB = 1u << lo_bits;
     const uint32_t s = bin_start[bin], e = bin_start[bin + 1];
@@ -267,19 +365,11 @@ __global__ __launch_bounds__(1024) void presort_bins(const E* __restrict__ entri
         }
     }
     __syncthreads();
-    // exclusive scan of sub[0..SUB): thread t owns `per` consecutive counters, Hillis-Steele over the partials
+    // exclusive scan of sub[0..SUB): thread t owns `per` consecutive counters
     const uint32_t per = (SUB + blockDim.x - 1) / blockDim.x, t0 = threadIdx.x * per;
-    uint32_t mine = 0;
+    uint32_t mine = 0, bin_total;
     for (uint32_t t = t0; t < t0 + per && t < SUB; t++) mine += sub[t];
-    part[threadIdx.x] = mine;
-    __syncthreads();
-    for (uint32_t d = 1; d < blockDim.x; d <<= 1) {
-        const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t run = s + part[threadIdx.x] - mine;
+    uint32_t run = s + block_exclusive_scan(mine, wsum, &bin_total);
     for (uint32_t t = t0; t < t0 + per && t < SUB; t++) {
         const uint32_t cnt = sub[t];
         const uint32_t bucket = (bin << lo_bits) + t;   // == k*NB + (hi << lo_bits | lo)
@@ -1052,7 +1142,7 @@ int msm_plan_begin(Lane& L, uint64_t n, WindowShard sh, hipStream_t s, uint32_t 
         // ---- grouping by coarse bins + per-bin LDS counting sort (see the kernels above) ----
         const bool e32 = !env_e64 && idx_bits + 1 + lo_bits <= 32;
         WS_HIP_CHECK(S.entries.reserve(total * (e32 ? 4 : 8)));
-        WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, (CNT_BINS + (size_t)nbins + 1) * 4, s));
+        WS_HIP_CHECK(hipMemsetAsync(S.counters.p, 0, (CNT_BINS + 3 * ((size_t)nbins + 1)) * 4, s));   // (counts, starts, cursors)
         I.ps_valid = true;
         I.ps_lo_bits = lo_bits; I.ps_idx_bits = idx_bits; I.ps_nbins = nbins; I.ps_e32 = e32;
         I.ps_HB = HB; I.ps_tile = env_tile; I.ps_thr = env_thr;
@@ -1110,11 +1200,16 @@ int msm_plan_finish(Lane& L, const Fe* d_scalars, hipStream_t s) {
         uint32_t* bin_cursor = bin_start + (nbins + 1);
         const PresortArgs PA = plan_presort_args(I, d_scalars, 0u, (uint32_t)n);
         const dim3 grid(ceil_div_u64(n, I.ps_tile)), blk(I.ps_thr);
-        T.begin("msm_presort_scan", s);
-        hipLaunchKernelGGL(presort_scan, dim3(1), dim3(256), 0, s, bin_count, nbins, bin_start, bin_cursor);
-        T.end(s);
+        const bool once = I.Wall <= PRESORT_ONCE_W && I.ps_tile == I.ps_thr;
+        if (!once) {
+            T.begin("msm_presort_scan", s);
+            hipLaunchKernelGGL(presort_scan, dim3(1), dim3(256), 0, s, bin_count, nbins, bin_start, bin_cursor);
+            T.end(s);
+        }
         T.begin("msm_presort_scatter", s);
-        if (e32) hipLaunchKernelGGL(presort_scatter<uint32_t>, grid, blk, 0, s, PA, bin_cursor, S.entries.as<uint32_t>());
+        if (once && e32) hipLaunchKernelGGL(presort_scatter_once<uint32_t>, grid, blk, 0, s, PA, bin_count, bin_start, bin_cursor, S.entries.as<uint32_t>());
+        else if (once) hipLaunchKernelGGL(presort_scatter_once<uint64_t>, grid, blk, 0, s, PA, bin_count, bin_start, bin_cursor, S.entries.as<uint64_t>());
+        else if (e32) hipLaunchKernelGGL(presort_scatter<uint32_t>, grid, blk, 0, s, PA, bin_cursor, S.entries.as<uint32_t>());
         else hipLaunchKernelGGL(presort_scatter<uint64_t>, grid, blk, 0, s, PA, bin_cursor, S.entries.as<uint64_t>());
         T.end(s);
         // one workgroup per bin, about eight entries per thread (two rounds of four loads in flight)
