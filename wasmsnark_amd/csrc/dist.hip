@@ -87,18 +87,6 @@ static int dist_ntt_native(Lane& L, const DistComm& cm, Fe* x, Fe* y, uint32_t l
     const uint64_t total = k * r1 * n2;
     if (total * sizeof(Fe) > cm.buf_bytes) { set_last_error("prove_dist: exchange buffers too small"); return WS_ERR_SIZE; }
     int rc;
-    // x[t] *= w_2n^t (odd), then the column step.  Round 4: the factors are applied by the column step's own first load (row b of
-    // the batch knows its t: NttRowCoset) -- the separate pass over the stack (saturated field, 64-bit divisions: 0.33 ms for two
-    // 2^20 vectors in rocprofv3, more than the pack and unpack passes together) is kept for blocks the batch cannot describe
-    if (odd && log_n2 >= 1 && (r1 & (r1 - 1)) == 0) {
-        NttRowCoset pre;
-        if ((rc = ntt_coset_tables_kernel_format((int)log_n, &pre.lo, &pre.hi, &pre.hc, s))) return rc;
-        pre.shift = log_n1; pre.row0 = (uint32_t)row0; pre.row_mask = (uint32_t)(r1 - 1);
-        if ((rc = ntt_run(L, x, nullptr, x, nullptr, n2, 0, inverse, s, k * r1, &pre))) return rc;
-    } else {
-        if (odd && (rc = dist_scale_dev(x, k, r1, n2, row0, log_n1, log_n, 1, 0, s))) return rc;
-        if (log_n2 >= 1 && (rc = ntt_dev(L, x, n2, 0, inverse, s, k * r1))) return rc;                // column step
-    }
     const Fe *lo, *hi;
     int h;
     if ((rc = ntt_twiddle_tables((int)log_n, inverse, &lo, &hi, &h, s, /* internal form of the radix-2^29 field */ true))) return rc;
@@ -107,10 +95,29 @@ static int dist_ntt_native(Lane& L, const DistComm& cm, Fe* x, Fe* y, uint32_t l
     while (((uint64_t)1 << lw) < P) lw++;
     const uint32_t lr1 = log_n1 - lw, lr2 = log_n2 - lw;
     const uint64_t per_vec = r1 * n2;
-    C->timer.begin("dist_pack", s);
-    hipLaunchKernelGGL(dist_pack_kernel, dim3(ceil_div_u64(per_vec, 256), (uint32_t)k), dim3(256), 0, s, x, cm.d_send, (uint32_t)k, lr1, lr2, lw, row0, lo, hi, (uint32_t)h);
-    C->timer.end(s);
-    WS_HIP_CHECK(hipGetLastError());
+    // Round 5: the inter-step twiddle and the block order of the exchange ride on the column step's LAST pass (NttRowPost) -- the
+    // packing pass below (two products, a read and a write of the whole stack, a launch) is left for the one shape without a
+    // column step (n2 == 1)
+    const NttRowPost post{cm.d_send, lo, hi, (uint32_t)h, lr1, lr2, (uint32_t)k, row0};
+    const bool fused_pack = log_n2 >= 1;
+    // x[t] *= w_2n^t (odd), then the column step.  Round 4: the factors are applied by the column step's own first load (row b of
+    // the batch knows its t: NttRowCoset) -- the separate pass over the stack (saturated field, 64-bit divisions: 0.33 ms for two
+    // 2^20 vectors in rocprofv3, more than the pack and unpack passes together) is kept for blocks the batch cannot describe
+    if (odd && log_n2 >= 1 && (r1 & (r1 - 1)) == 0) {
+        NttRowCoset pre;
+        if ((rc = ntt_coset_tables_kernel_format((int)log_n, &pre.lo, &pre.hi, &pre.hc, s))) return rc;
+        pre.shift = log_n1; pre.row0 = (uint32_t)row0; pre.row_mask = (uint32_t)(r1 - 1);
+        if ((rc = ntt_run(L, x, nullptr, x, nullptr, n2, 0, inverse, s, k * r1, &pre, &post))) return rc;
+    } else {
+        if (odd && (rc = dist_scale_dev(x, k, r1, n2, row0, log_n1, log_n, 1, 0, s))) return rc;
+        if (log_n2 >= 1 && (rc = ntt_run(L, x, nullptr, x, nullptr, n2, 0, inverse, s, k * r1, nullptr, &post))) return rc;   // column step
+    }
+    if (!fused_pack) {
+        C->timer.begin("dist_pack", s);
+        hipLaunchKernelGGL(dist_pack_kernel, dim3(ceil_div_u64(per_vec, 256), (uint32_t)k), dim3(256), 0, s, x, cm.d_send, (uint32_t)k, lr1, lr2, lw, row0, lo, hi, (uint32_t)h);
+        C->timer.end(s);
+        WS_HIP_CHECK(hipGetLastError());
+    }
     const Fe* recv = cm.d_send;                                                                        // a world of one: the exchange is the identity
     if (P > 1) {
         if (!cm.all_to_all) { set_last_error("prove_dist: no all-to-all callback"); return WS_ERR_ARG; }

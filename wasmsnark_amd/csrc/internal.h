@@ -193,8 +193,12 @@ int ntt_dev(Lane& L, Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s
 // block of a longer vector; its element g is multiplied on load by that vector's coset factor w_2N^(row0 + row + (g << shift))
 // (tables of the LONGER length, ntt_coset_tables_kernel_format) -- the coset pre-scale without a pass of its own
 struct NttRowCoset { const Fe* lo; const Fe* hi; uint32_t hc, shift, row0, row_mask; };
+// rc_post (the same column step's LAST pass): element c of transform b = (vector << lr1 | row r) leaves multiplied by the four-step
+// twiddle w_N^(+-(row0 + r) c) (lo / hi: ntt_twiddle_tables of the longer length N, internal form) at out[q][vector][r][c2],
+// c = q 2^lr2 + c2 -- the block order of the exchange -- instead of being stored in place and re-read by a packing pass
+struct NttRowPost { Fe* out; const Fe* lo; const Fe* hi; uint32_t h, lr1, lr2, k; uint64_t row0; };
 int ntt_run(Lane& L, const Fe* d_src, const Fe* d_in2, Fe* d_dst, const Fe* combine_e, uint64_t n, int odd, int inverse,
-            hipStream_t s, uint64_t count = 1, const NttRowCoset* rc_pre = nullptr);
+            hipStream_t s, uint64_t count = 1, const NttRowCoset* rc_pre = nullptr, const NttRowPost* rc_post = nullptr);
 int ntt_coset_tables_kernel_format(int bits, const Fe** lo, const Fe** hi, uint32_t* hc, hipStream_t s);
 // internal = true: the same tables in the internal form of the radix-2^29 field (entries x 2^5), as the transform kernels read them
 int ntt_twiddle_tables(int bits, int inverse, const Fe** lo, const Fe** hi, int* h, hipStream_t s, bool internal = false);

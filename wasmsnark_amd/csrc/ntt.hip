@@ -57,6 +57,12 @@ struct PassArgs {
     const Fe* comb_e; const Fe* comb_lo; const Fe* comb_hi; uint32_t comb_hc;
     Fe k271;        // 2^10 in the internal domain (raw 2^271 mod r): product-on-load without a folding table
     Fe comb_c;      // epilogue constant: radix-2^29 path raw 16 (x 2^-257 = halve + leave Montgomery), 4x64 path 1/2 (Montgomery)
+    // POST instantiation (distributed column step, dist.hip): the last pass multiplies element c of transform b = (vector, row r)
+    // by the four-step twiddle w_N^(+-(post_row0 + r) c) of the LONGER length N (post_lo / post_hi: two-level, internal form) and
+    // stores it where the exchange wants it -- post_out[q][vector][r][c2], c = q 2^lr2 + c2 -- instead of a pass of its own.
+    Fe* post_out; const Fe* post_lo; const Fe* post_hi;
+    uint32_t post_h, post_lr1, post_lr2, post_k;
+    uint64_t post_row0;
 };
 
 // h[t] from the inverse transform's value v (reference Montgomery form, canonical) and e[t]: the CALC_H epilogue
@@ -138,7 +144,7 @@ template <class P> struct LdsTile<Field29<P>> {
 // Field29<Fr29Params> (values in [0,2p), internal domain R' = 2^261; the host scales every table by
 // 2^5 so that table products land in the internal domain, and the conversions from / to the
 // reference format are folded into the first load and the last store).
-template <class F>
+template <class F, bool POST>
 __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
     typedef typename F::El El;
     WS_DYN_SMEM(unsigned char, sm);
@@ -276,6 +282,15 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
             El v = tile.get((r << log_T) + t);
             Fe o;
             const uint64_t at = ((uint64_t)kk << log_rest) + revmid + a0 + t;
+            if (POST) {
+                const uint32_t r = blockIdx.y & ((1u << A.post_lr1) - 1), vec = blockIdx.y >> A.post_lr1;
+                const uint64_t e = (A.post_row0 + r) * at;
+                const El f = F::mul(F::unpack(A.post_hi[e >> A.post_h]), F::unpack(A.post_lo[e & (((uint64_t)1 << A.post_h) - 1)]));
+                v = A.out_plain ? F::fold4to2(v) : F::mul(v, F::unpack(A.out_scale));      // the value in the reference form
+                const uint64_t q = at >> A.post_lr2, c2 = at & (((uint64_t)1 << A.post_lr2) - 1);
+                A.post_out[((((q * A.post_k + vec) << A.post_lr1) + r) << A.post_lr2) + c2] = F::pack(F::canonical(F::mul(v, f)));
+                continue;
+            }
             if (F::kInternalDomain && A.out_plain) {
                 v = F::canonical(F::fold4to2(v));   // already in the reference domain (folded upstream)
             } else if (F::kInternalDomain) {
@@ -475,11 +490,11 @@ int ntt_dev(Lane& L, Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s
 
 // src (x in2) -> dst; combine_e != nullptr: the last pass stores CALC_H's h instead of the transform (inverse only)
 int ntt_run(Lane& L, const Fe* d_src, const Fe* d_in2, Fe* d_data, const Fe* combine_e, uint64_t n, int odd, int inverse,
-            hipStream_t s, uint64_t count, const NttRowCoset* rc_pre) {
+            hipStream_t s, uint64_t count, const NttRowCoset* rc_pre, const NttRowPost* rc_post) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
     if (!d_data || !d_src) return WS_ERR_ARG;
-    if ((d_in2 && odd) || (combine_e && (!inverse || count != 1)) || (rc_pre && (odd || d_in2))) return WS_ERR_ARG;
+    if ((d_in2 && odd) || (combine_e && (!inverse || count != 1)) || (rc_pre && (odd || d_in2)) || (rc_post && combine_e)) return WS_ERR_ARG;
     if (!s) s = L.stream;
     // src/build_fft.js:92-157: n must be a power of two <= 2^28 (the reference traps otherwise)
     if (n == 0 || (n & (n - 1)) || n > ((uint64_t)1 << 28)) return WS_ERR_SIZE;
@@ -537,6 +552,11 @@ int ntt_run(Lane& L, const Fe* d_src, const Fe* d_in2, Fe* d_data, const Fe* com
             A.cs_lo = rc_pre->lo; A.cs_hi = rc_pre->hi; A.hc = rc_pre->hc;
             A.prescale = 2; A.pre_shift = rc_pre->shift; A.pre_row0 = rc_pre->row0; A.pre_row_mask = rc_pre->row_mask;
         }
+        A.post_out = nullptr; A.post_lo = A.post_hi = nullptr; A.post_h = A.post_lr1 = A.post_lr2 = A.post_k = 0; A.post_row0 = 0;
+        if (rc_post && last) {
+            A.post_out = rc_post->out; A.post_lo = rc_post->lo; A.post_hi = rc_post->hi; A.post_h = rc_post->h;
+            A.post_lr1 = rc_post->lr1; A.post_lr2 = rc_post->lr2; A.post_k = rc_post->k; A.post_row0 = rc_post->row0;
+        }
         A.scale = (inverse && last) ? 1 : 0;
         A.first = (p == 0) ? 1 : 0;
         A.out_scale = A.scale ? P->n_inv : Fr::one();
@@ -589,11 +609,14 @@ int ntt_run(Lane& L, const Fe* d_src, const Fe* d_in2, Fe* d_data, const Fe* com
         if (P->field29) {
             const size_t smem = elems * LdsTile<Fr29>::kBytes;
             if (!C->ntt_attr_set) {   // (per device; two lanes may both set it once: same value)  2048-element tiles would need 72 KiB of dynamic LDS (> the 64 KiB default cap)
-                WS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<Fr29>),
+                WS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<Fr29, false>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * 36));
+                WS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<Fr29, true>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * 36));
                 C->ntt_attr_set = true;
             }
-            hipLaunchKernelGGL(ntt_pass_kernel<Fr29>, dim3(grid, (uint32_t)count), dim3(512 >> (11 - tile_log)), smem, s, A);
+            if (A.post_out) hipLaunchKernelGGL((ntt_pass_kernel<Fr29, true>), dim3(grid, (uint32_t)count), dim3(512 >> (11 - tile_log)), smem, s, A);
+            else hipLaunchKernelGGL((ntt_pass_kernel<Fr29, false>), dim3(grid, (uint32_t)count), dim3(512 >> (11 - tile_log)), smem, s, A);
         }
         C->timer.end(s);
         WS_HIP_CHECK(hipGetLastError());
