@@ -342,7 +342,7 @@ def test_reduction_tail_geometries(orc):
     import random
     bn = emul_bn128()
     tune = bn.lib.tune
-    names = ("MSM_CHUNK", "TAIL_BITS", "TAIL_BITS_W")
+    names = ("MSM_CHUNK", "TAIL_BITS")
     try:
         rnd = random.Random(5)
         for g, n in ((1, 1500), (2, 400)):
@@ -352,7 +352,7 @@ def test_reduction_tail_geometries(orc):
             want = orc.g_affine(g, orc.multiexp(g, "multiexp2" if g == 1 else "multiexp", sc, pts, n))
             msm = bn.g1_multiexp if g == 1 else bn.g2_multiexp
             for chunk, bits_w in ((2, 3), (4, None), (4, 4), (8, 3), (8, None)):
-                tune("MSM_CHUNK", chunk); tune("TAIL_BITS_W", bits_w)
+                tune("MSM_CHUNK", chunk); tune("TAIL_BITS", bits_w)
                 assert msm(sc, pts) == want, (g, chunk, bits_w)
         for name in names:
             tune(name, None)

@@ -1,17 +1,4 @@
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r05_c15; mkdir -p $O
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r05_c18; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-P="timeout 300 python tools/msm_probe.py"
-$P > $O/probe.txt 2> $O/err.txt
-$P --set PS_ONCE=0 >> $O/probe.txt 2>> $O/err.txt
-timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "resident_bases or msm" 2>&1 | tail -3 > $O/pytest.txt
-timeout 600 python bench.py --no-extras --no-cpu-baseline > $O/bench.json 2>> $O/err.txt
-tail -5 $O/err.txt; cat $O/pytest.txt
-python - <<'PY'
-import json
-for l in open('gpurun_out/r05_c15/probe.txt'):
-    d=json.loads(l)
-    for k in ("per_call","resident"):
-        print(d["tag"],k,d[k]["ms"],d[k]["same"],d[k]["kernels_us"])
-d=json.load(open('gpurun_out/r05_c15/bench.json'))
-print(d["value"], d.get("serialised_one_queue_ms_per_proof"), d.get("kernel_ms_per_proof"))
-PY
+for v in 1 0 1 0; do WSNARK_DIST_CALCH_FIRST=$v timeout 300 python tools/dist_probe.py 20 > $O/dist_$v.json 2>> $O/err.txt; python -c "
+import json; d=json.load(open('$O/dist_$v.json')); print('first=$v', d['one_call_prove_ms'], d['native_dist_prover_world1_ms'], d['native_minus_one_call_ms'], d['proofs_ok'])"; done

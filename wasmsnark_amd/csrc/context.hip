@@ -462,13 +462,6 @@ void KernelTimer::begin(const char* name, hipStream_t s) {
     t_gen = generation;
 }
 void KernelTimer::end(hipStream_t s) {
-    // WSNARK_SYNC_DEBUG=1 (with timing enabled): wait for every bracket and name it on stderr -- a faulting kernel is then the
-    // last name printed
-    static const bool sync_debug = tuning_get("SYNC_DEBUG", 0) == 1;
-    if (sync_debug && enabled && t_rec >= 0) {
-        const hipError_t e = hipStreamSynchronize(s);
-        fprintf(stderr, "[wsnark sync] %s -> %s\n", recs[(size_t)t_rec].name, hipGetErrorString(e));
-    }
     if (!enabled || t_rec < 0) return;
     std::lock_guard<std::mutex> lk(mu);
     if (t_gen == generation && (size_t)t_rec < recs.size()) (void)hipEventRecord(recs[(size_t)t_rec].b, s);

@@ -107,10 +107,10 @@ static int dist_ntt_native(Lane& L, const DistComm& cm, Fe* x, Fe* y, uint32_t l
         NttRowCoset pre;
         if ((rc = ntt_coset_tables_kernel_format((int)log_n, &pre.lo, &pre.hi, &pre.hc, s))) return rc;
         pre.shift = log_n1; pre.row0 = (uint32_t)row0; pre.row_mask = (uint32_t)(r1 - 1);
-        if ((rc = ntt_run(L, x, nullptr, x, nullptr, n2, 0, inverse, s, k * r1, &pre, &post))) return rc;
+        if ((rc = ntt_run(L, x, nullptr, x, nullptr, n2, 0, inverse, s, k * r1, &pre, fused_pack ? &post : nullptr))) return rc;
     } else {
         if (odd && (rc = dist_scale_dev(x, k, r1, n2, row0, log_n1, log_n, 1, 0, s))) return rc;
-        if (log_n2 >= 1 && (rc = ntt_run(L, x, nullptr, x, nullptr, n2, 0, inverse, s, k * r1, nullptr, &post))) return rc;   // column step
+        if (log_n2 >= 1 && (rc = ntt_run(L, x, nullptr, x, nullptr, n2, 0, inverse, s, k * r1, nullptr, fused_pack ? &post : nullptr))) return rc;   // column step
     }
     if (!fused_pack) {
         C->timer.begin("dist_pack", s);

@@ -596,7 +596,10 @@ static const uint32_t WAVE_COMBINE_MIN = 17;
 //                           sums (stage 2) and clears the counter
 // (few workgroups: a launch costs ~5 us plus ~10 us per thousand workgroups it starts, whether they find work or not -- the four
 //  launches this one replaces started 3 400 workgroups per sum to find nothing on a uniform witness)
-static const uint32_t CB_SMALL = 256, CB_WAVE = 256, CB_HOT = 256;
+// (cb_small: 256 workgroups -- a uniform full-size sum cuts next to no bucket --, but one lane per bucket where the plan cuts MOST of
+//  them: a rank's share of a sharded key runs 2^16 buckets at a task cap of 16 under ~30 entries each, and 256 workgroups would
+//  leave every lane a chain of four buckets: +0.09 ms on the rank's four sums, profiles/r05_s1_shard_probe_2p20.json vs r05_s2)
+static const uint32_t CB_SMALL_MIN = 256, CB_SMALL_MAX = 4096, CB_WAVE = 256, CB_HOT = 256;
 template <class C>
 __device__ __forceinline__ typename C::PtP wave_tree_sum(typename C::PtP* sh, uint32_t lane, const typename C::Pt& mine) {
     sh[lane] = C::pack_pt(mine);
@@ -610,7 +613,7 @@ __device__ __forceinline__ typename C::PtP wave_tree_sum(typename C::PtP* sh, ui
     return r;
 }
 template <class C>
-__global__ __launch_bounds__(64) void msm_combine_all(AccSets<C> as) {
+__global__ __launch_bounds__(64) void msm_combine_all(AccSets<C> as, uint32_t CB_SMALL) {
     const uint32_t* __restrict__ counters = as.counters[blockIdx.y];
     const typename C::PtP* __restrict__ partials = as.partials[blockIdx.y];
     typename C::PtP* __restrict__ buckets = as.buckets[blockIdx.y];
@@ -1044,14 +1047,14 @@ int msm_plan_begin(Lane& L, uint64_t n, WindowShard sh, hipStream_t s, uint32_t 
     // trees -- on few wavefronts; its WORK only matters at full size, its DEPTH matters whenever nothing else fills the chip
     // (small sums, a rank's share of a sharded key, a stand-alone MSM).  So: chunks of 8 buckets and 2^15-bucket pieces for
     // large bucket sets (the round-2 / 3 shape), chunks of 4 and 2^11-bucket pieces below 2^18 buckets, and the pieces' rows are
-    // folded on the GPU (msm_rows) so that short pieces do not turn into host work.  WSNARK_MSM_CHUNK / WSNARK_TAIL_BITS[_W]
+    // folded on the GPU (msm_rows) so that short pieces do not turn into host work.  WSNARK_MSM_CHUNK / WSNARK_TAIL_BITS
     // override (tests of the geometries; A/B: profiles/r04_*).
     const bool big_set = I.NB >= (1u << 18);
     uint32_t chunk = (I.flat && !big_set) ? 4u : CHUNK;
     { const long v = tuning_get("MSM_CHUNK", 0); if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32) chunk = (uint32_t)v; }
     {
         uint32_t tbits = I.flat ? (big_set ? 15u : 11u) : 31u;      // buckets per tail piece; per-window plans: the whole window
-        { const long v = tuning_get(I.flat ? "TAIL_BITS" : "TAIL_BITS_W", 0); if (v >= 3 && v <= 20) tbits = (uint32_t)v; }
+        { const long v = tuning_get("TAIL_BITS", 0); if (v >= 3 && v <= 20) tbits = (uint32_t)v; }
         I.tNB = (tbits >= 31 || I.NB < (1u << tbits)) ? I.NB : (1u << tbits);
         I.tP = I.NB / I.tNB;
         if (I.tP > 256) { I.tP = 256; I.tNB = I.NB / 256; }        // (msm_rows folds a group's pieces in one workgroup)
@@ -1312,7 +1315,7 @@ static int msm_acc_sets(Lane& L, MsmPending* const* Ps, int nsets, int which, hi
     MsmWorkspace& M = ws(L);
     KernelTimer& T = X->timer;
     AccSets<C> as;
-    uint32_t ntasks = 0;
+    uint32_t ntasks = 0, cb_small = CB_SMALL_MIN;
     for (int k = 0; k < 4; k++) {
         MsmPending& Q = *Ps[k < nsets ? k : 0];
         MsmScratch& QS = M.plan[Q.plan_id].S;
@@ -1327,6 +1330,14 @@ static int msm_acc_sets(Lane& L, MsmPending* const* Ps, int nsets, int which, hi
         as.hot_sums[k] = Q.S.hot_sums.template as<Pt>();
         as.hot_done[k] = Q.S.hot_done.template as<uint32_t>();
         if (k < nsets && Q.info.ntasks > ntasks) ntasks = Q.info.ntasks;
+        if (k < nsets) {
+            const MsmPlanInfo& QI = Q.info;
+            const uint64_t mean = (QI.n * QI.W + QI.nbuckets - 1) / (QI.nbuckets ? QI.nbuckets : 1);
+            if (2 * (uint64_t)QI.lmax < 3 * mean) {        // task cap below 1.5 x the mean load: most buckets are cut
+                const uint32_t want = (QI.nbuckets + 63) / 64;
+                if (want > cb_small) cb_small = want > CB_SMALL_MAX ? CB_SMALL_MAX : want;
+            }
+        }
     }
     const uint32_t ny = (uint32_t)nsets;
     T.begin(which ? "msm_accumulate_g2" : "msm_accumulate_g1", s);
@@ -1334,7 +1345,7 @@ static int msm_acc_sets(Lane& L, MsmPending* const* Ps, int nsets, int which, hi
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
     T.begin("msm_combine", s);
-    hipLaunchKernelGGL(msm_combine_all<C>, dim3(CB_SMALL + CB_WAVE + CB_HOT, ny), dim3(64), 0, s, as);
+    hipLaunchKernelGGL(msm_combine_all<C>, dim3(cb_small + CB_WAVE + CB_HOT, ny), dim3(64), 0, s, as, cb_small);
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
     return WS_OK;

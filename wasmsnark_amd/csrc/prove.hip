@@ -524,7 +524,8 @@ static int prove_msms(ProvingKey* K, Lane& L, const Fe* d_witness, WindowShard s
     // to itself.  Queued here the sparse products and the first transforms run beside the grouping pass.  (Whole proofs measure the
     // same either way, profiles/r05_schedule_experiments.txt: time on this chip is the sum of the kernels' own times, section 5 of
     // DESIGN.md; the H sum's inputs are ready ~1 ms earlier.)
-    // (the distributed CALC_H keeps its place behind the sums: its exchanges are host callbacks that may block this thread)
+    // (the distributed CALC_H keeps its place behind the sums: its exchanges are host callbacks that may block this thread; queued
+    //  first at a world of one it measured the same, +0.67 / +0.86 against +0.83 / +0.63 ms over the one-call prover in four runs)
     Fe* d_h = nullptr;
     bool calc_h_done = false;
     auto enqueue_calc_h = [&]() -> int {
