@@ -126,11 +126,15 @@ static int dist_ntt_native(Lane& L, const DistComm& cm, Fe* x, Fe* y, uint32_t l
         if (xrc != 0) { set_last_error("prove_dist: the all-to-all callback failed"); return WS_ERR_ARG; }
         recv = cm.d_recv;
     }
+    // ... and the transposition rides on the row step's FIRST load (NttRowGather); the unpacking pass is left for n1 == 1
+    if (log_n1 >= 1) {
+        const NttRowGather gather{recv, lr1, lr2, (uint32_t)k};
+        return ntt_run(L, recv, nullptr, y, nullptr, n1, 0, inverse, s, k * r2, nullptr, nullptr, &gather);   // row step
+    }
     C->timer.begin("dist_unpack", s);
     hipLaunchKernelGGL(dist_unpack_kernel, dim3(ceil_div_u64(per_vec, 256), (uint32_t)k), dim3(256), 0, s, recv, y, (uint32_t)k, lr1, lr2, lw);
     C->timer.end(s);
     WS_HIP_CHECK(hipGetLastError());
-    if (log_n1 >= 1 && (rc = ntt_dev(L, y, n1, 0, inverse, s, k * r2))) return rc;                    // row step
     return WS_OK;
 }
 

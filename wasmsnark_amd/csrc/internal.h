@@ -197,8 +197,12 @@ struct NttRowCoset { const Fe* lo; const Fe* hi; uint32_t hc, shift, row0, row_m
 // twiddle w_N^(+-(row0 + r) c) (lo / hi: ntt_twiddle_tables of the longer length N, internal form) at out[q][vector][r][c2],
 // c = q 2^lr2 + c2 -- the block order of the exchange -- instead of being stored in place and re-read by a packing pass
 struct NttRowPost { Fe* out; const Fe* lo; const Fe* hi; uint32_t h, lr1, lr2, k; uint64_t row0; };
+// rc_gather (the row step's FIRST pass): transform b = (vector << lr2 | c2) reads its element i1 = q 2^lr1 + r from in[q][vector][r][c2],
+// the receive buffer of the exchange, instead of from a transposed copy
+struct NttRowGather { const Fe* in; uint32_t lr1, lr2, k; };
 int ntt_run(Lane& L, const Fe* d_src, const Fe* d_in2, Fe* d_dst, const Fe* combine_e, uint64_t n, int odd, int inverse,
-            hipStream_t s, uint64_t count = 1, const NttRowCoset* rc_pre = nullptr, const NttRowPost* rc_post = nullptr);
+            hipStream_t s, uint64_t count = 1, const NttRowCoset* rc_pre = nullptr, const NttRowPost* rc_post = nullptr,
+            const struct NttRowGather* rc_gather = nullptr);
 int ntt_coset_tables_kernel_format(int bits, const Fe** lo, const Fe** hi, uint32_t* hc, hipStream_t s);
 // internal = true: the same tables in the internal form of the radix-2^29 field (entries x 2^5), as the transform kernels read them
 int ntt_twiddle_tables(int bits, int inverse, const Fe** lo, const Fe** hi, int* h, hipStream_t s, bool internal = false);

@@ -63,7 +63,11 @@ struct PassArgs {
     Fe* post_out; const Fe* post_lo; const Fe* post_hi;
     uint32_t post_h, post_lr1, post_lr2, post_k;
     uint64_t post_row0;
+    // GATHER instantiation (distributed row step): transform b = (vector << lr2 | c2) loads its element i1 = q 2^lr1 + r from the
+    // exchange's receive buffer gather_in[q][vector][r][c2] -- the transposition without a pass (and a buffer) of its own
+    const Fe* gather_in;
 };
+enum { NTT_PLAIN = 0, NTT_POST = 1, NTT_GATHER = 2 };
 
 // h[t] from the inverse transform's value v (reference Montgomery form, canonical) and e[t]: the CALC_H epilogue
 //   h[t] = fromMontgomery((e[t] - w_2n^-t o[t]) / 2),   w_2n^-t = -w_2n^(n-t) for t >= 1   (derivation: calch.hip header)
@@ -144,8 +148,9 @@ template <class P> struct LdsTile<Field29<P>> {
 // Field29<Fr29Params> (values in [0,2p), internal domain R' = 2^261; the host scales every table by
 // 2^5 so that table products land in the internal domain, and the conversions from / to the
 // reference format are folded into the first load and the last store).
-template <class F, bool POST>
+template <class F, int MODE>
 __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
+    constexpr bool POST = MODE == NTT_POST;
     typedef typename F::El El;
     WS_DYN_SMEM(unsigned char, sm);
     const uint32_t log_L = A.log_L, log_T = A.log_T;
@@ -183,7 +188,13 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
             j = idx & (L - 1); t = idx >> log_L;
             g = ((uint64_t)(a0 + t) << A.log_S0) + ((uint64_t)mid << log_L) + j;
         }
-        El v = F::unpack(src[g]);
+        const Fe* from = &src[g];
+        if (MODE == NTT_GATHER && A.first) {
+            const uint64_t vec = blockIdx.y >> A.post_lr2, c2 = blockIdx.y & ((1u << A.post_lr2) - 1);
+            const uint64_t q = g >> A.post_lr1, r = g & (((uint64_t)1 << A.post_lr1) - 1);
+            from = &A.gather_in[((((q * A.post_k + vec) << A.post_lr1) + r) << A.post_lr2) + c2];
+        }
+        El v = F::unpack(*from);
         if (A.in2) {        // pass 0 of a product transform: v = in[g] * in2[g] (Montgomery product of the reference format)
             v = F::mul(v, F::unpack(A.in2[g]));
             if (F::kInternalDomain && A.fold_in != 2) v = F::mul(v, F::unpack(A.k271));
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
             El f = F::mul(F::unpack(A.cs_hi[e >> A.hc]), F::unpack(A.cs_lo[e & ((1u << A.hc) - 1)]));
             v = F::mul(v, f);          // (radix-2^29: cs_lo carries the extra 2^5 => also converts the domain)
         } else if (F::kInternalDomain && A.first && !A.fold_in) {
-            v = F::to_internal(src[g]);
+            v = F::to_internal(*from);
         }
         tile.put((j << log_T) + t, v);
     }
@@ -490,11 +501,12 @@ int ntt_dev(Lane& L, Fe* d_data, uint64_t n, int odd, int inverse, hipStream_t s
 
 // src (x in2) -> dst; combine_e != nullptr: the last pass stores CALC_H's h instead of the transform (inverse only)
 int ntt_run(Lane& L, const Fe* d_src, const Fe* d_in2, Fe* d_data, const Fe* combine_e, uint64_t n, int odd, int inverse,
-            hipStream_t s, uint64_t count, const NttRowCoset* rc_pre, const NttRowPost* rc_post) {
+            hipStream_t s, uint64_t count, const NttRowCoset* rc_pre, const NttRowPost* rc_post, const NttRowGather* rc_gather) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
     if (!d_data || !d_src) return WS_ERR_ARG;
-    if ((d_in2 && odd) || (combine_e && (!inverse || count != 1)) || (rc_pre && (odd || d_in2)) || (rc_post && combine_e)) return WS_ERR_ARG;
+    if ((d_in2 && odd) || (combine_e && (!inverse || count != 1)) || (rc_pre && (odd || d_in2)) || (rc_post && combine_e) ||
+        (rc_gather && (rc_post || rc_pre || odd || d_in2))) return WS_ERR_ARG;
     if (!s) s = L.stream;
     // src/build_fft.js:92-157: n must be a power of two <= 2^28 (the reference traps otherwise)
     if (n == 0 || (n & (n - 1)) || n > ((uint64_t)1 << 28)) return WS_ERR_SIZE;
@@ -557,6 +569,8 @@ int ntt_run(Lane& L, const Fe* d_src, const Fe* d_in2, Fe* d_data, const Fe* com
             A.post_out = rc_post->out; A.post_lo = rc_post->lo; A.post_hi = rc_post->hi; A.post_h = rc_post->h;
             A.post_lr1 = rc_post->lr1; A.post_lr2 = rc_post->lr2; A.post_k = rc_post->k; A.post_row0 = rc_post->row0;
         }
+        A.gather_in = nullptr;
+        if (rc_gather && p == 0) { A.gather_in = rc_gather->in; A.post_lr1 = rc_gather->lr1; A.post_lr2 = rc_gather->lr2; A.post_k = rc_gather->k; }
         A.scale = (inverse && last) ? 1 : 0;
         A.first = (p == 0) ? 1 : 0;
         A.out_scale = A.scale ? P->n_inv : Fr::one();
@@ -609,14 +623,18 @@ int ntt_run(Lane& L, const Fe* d_src, const Fe* d_in2, Fe* d_data, const Fe* com
         if (P->field29) {
             const size_t smem = elems * LdsTile<Fr29>::kBytes;
             if (!C->ntt_attr_set) {   // (per device; two lanes may both set it once: same value)  2048-element tiles would need 72 KiB of dynamic LDS (> the 64 KiB default cap)
-                WS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<Fr29, false>),
+                WS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<Fr29, NTT_PLAIN>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * 36));
-                WS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<Fr29, true>),
+                WS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<Fr29, NTT_POST>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * 36));
+                WS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<Fr29, NTT_GATHER>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * 36));
                 C->ntt_attr_set = true;
             }
-            if (A.post_out) hipLaunchKernelGGL((ntt_pass_kernel<Fr29, true>), dim3(grid, (uint32_t)count), dim3(512 >> (11 - tile_log)), smem, s, A);
-            else hipLaunchKernelGGL((ntt_pass_kernel<Fr29, false>), dim3(grid, (uint32_t)count), dim3(512 >> (11 - tile_log)), smem, s, A);
+            const dim3 g3(grid, (uint32_t)count), b3(512 >> (11 - tile_log));
+            if (A.post_out) hipLaunchKernelGGL((ntt_pass_kernel<Fr29, NTT_POST>), g3, b3, smem, s, A);
+            else if (A.gather_in) hipLaunchKernelGGL((ntt_pass_kernel<Fr29, NTT_GATHER>), g3, b3, smem, s, A);
+            else hipLaunchKernelGGL((ntt_pass_kernel<Fr29, NTT_PLAIN>), g3, b3, smem, s, A);
         }
         C->timer.end(s);
         WS_HIP_CHECK(hipGetLastError());
