@@ -1,13 +1,14 @@
 #!/bin/bash
 # One command for the first box with >= 2 GPUs: everything about N > 1 that has never run on RCCL, with its
 # records under gpurun_out/<TAG>/ (copy what should be judged into profiles/).
-#   TAG=r04_multi tools/multigpu_preflight.sh            (from the repository root; needs torch.distributed + RCCL)
+#   TAG=r05_multi tools/multigpu_preflight.sh            (from the repository root; needs torch.distributed + RCCL)
 # 1. the two nccl tests that skip themselves on a one-GPU box (sharded MSM + prove over RCCL; entry points from another thread
 #    on device 1)
 # 2. bench.py --gpus 2 / 4 / 8 at 2^20 (strong scaling of the headline proof: points-sharded key, distributed CALC_H,
 #    wsnark_groth16_prove_dist), one JSON line each -- the line says which orchestration ran and whether one fell through
 # 3. BASELINE config 5: bench.py --prove-log-domain 24 on every GPU of the box, and on ONE GPU for the ratio
 # 4. the all-gather / all-to-all transport on its own (tools/nccl_allgather_check.py)
+# 5. ONE process over all GPUs (wsnark_group_*): tests/test_gpu_group.py, bench.py --single-process, the Node drop-in (NODE_BENCH_DEVICES)
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 TAG=${TAG:-multi}
 O=gpurun_out/$TAG
@@ -37,9 +38,18 @@ for n in 2 4 8; do
 done
 run_bench "$NG" --prove-log-domain 24 --no-extras > "$O/bench_2p24_n$NG.json" 2> "$O/bench_2p24_n$NG.err"; echo "bench 2^24 n=$NG rc=$?" | tee -a "$O/env.log"
 run_bench 1 --prove-log-domain 24 --no-extras --no-cpu-baseline > "$O/bench_2p24_n1.json" 2> "$O/bench_2p24_n1.err"; echo "bench 2^24 n=1 rc=$?" | tee -a "$O/env.log"
+# 5. (round 5) several GPUs in ONE process: the group tests on real peers, bench.py --single-process, and the Node drop-in over all devices
+timeout 1800 python -m pytest tests/test_gpu_group.py -m gpu -q --timeout 900 -p no:cacheprovider > "$O/pytest_gpu_group.txt" 2>&1
+echo "pytest group rc=$?" | tee -a "$O/env.log"
+for n in 2 4 8; do
+  [ "$n" -le "$NG" ] || continue
+  timeout 1800 python bench.py --gpus "$n" --single-process --steps 20 --warmup 5 > "$O/bench_group_n$n.json" 2> "$O/bench_group_n$n.err"; echo "bench group n=$n rc=$?" | tee -a "$O/env.log"
+done
+DEVS=$(python -c "print(','.join(str(i) for i in range($NG)))")
+NODE_BENCH_DEVICES=$DEVS timeout 900 python tools/node_bench.py 20 20 > "$O/node_bench_group.json" 2> "$O/node_bench_group.err"; echo "node group rc=$?" | tee -a "$O/env.log"
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $((PORT + 7)) tools/nccl_allgather_check.py > "$O/nccl_allgather_check.txt" 2>&1
 echo "transport check rc=$?" | tee -a "$O/env.log"
-grep -h '^{"metric"' "$O"/bench_n*.json "$O"/bench_2p24_*.json 2>/dev/null | python -c "
+grep -h '^{"metric"' "$O"/bench_n*.json "$O"/bench_group_n*.json "$O"/bench_2p24_*.json 2>/dev/null | python -c "
 import json, sys
 for l in sys.stdin:
     d = json.loads(l)
