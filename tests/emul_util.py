@@ -6,7 +6,7 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "wasmsnark_amd", "csrc")
-SO = os.path.join(ROOT, "tests", "emul", "libwsnark_emul.so")
+SO = SO_PATH = os.path.join(ROOT, "tests", "emul", "libwsnark_emul.so")
 
 _bn = None
 
@@ -16,5 +16,9 @@ def emul_bn128():
     if _bn is None:
         subprocess.check_call(["make", "-C", CSRC, "-s", "-j8", "emul"])
         from wasmsnark_amd import _lib, bn128
-        _bn = bn128.Bn128(lib=_lib.load(SO))
+
+        class EmulLib(_lib.Lib):          # tests only: the same ctypes binding over the emulator build of the same ABI
+            SO = SO_PATH
+
+        _bn = bn128.Bn128(lib=EmulLib())
     return _bn

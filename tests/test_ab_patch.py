@@ -34,7 +34,7 @@ def test_committed_fixture_says_identical_and_verified():
 def test_rerun_in_the_reference_caller(tmp_path):
     from emul_util import emul_bn128, SO
     emul_bn128()
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "wasmsnark_amd", "js"), "-s"])
-    out = subprocess.run(["node", os.path.join(ROOT, "oracle", "ref_harness", "ab_patch.js"), SO],
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "wasmsnark_amd", "js"), "-s", "all", "emul"])
+    out = subprocess.run(["node", os.path.join(ROOT, "oracle", "ref_harness", "ab_patch.js"), "emul"],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "AB_PATCH_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

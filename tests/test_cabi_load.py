@@ -25,15 +25,23 @@ def test_library_loads_and_exports_all():
         import __graft_entry__
         __graft_entry__.build()
     from wasmsnark_amd import _lib
-    lib = _lib.Lib(so)
+    lib = _lib.Lib()
+    assert lib.path == so
     for s in _declared():
         assert hasattr(lib.c, s)
 
 
 def test_no_silent_fallback(tmp_path):
+    """A missing library is an ImportError, not a CPU path; and the product's binding takes no path and reads no environment."""
+    import inspect
     from wasmsnark_amd import _lib
+
+    class Missing(_lib.Lib):
+        SO = str(tmp_path / "missing.so")
     with pytest.raises(ImportError):
-        _lib.Lib(str(tmp_path / "missing.so"))
+        Missing()
+    assert list(inspect.signature(_lib.Lib.__init__).parameters) == ["self"] and not inspect.signature(_lib.load).parameters
+    assert "environ" not in inspect.getsource(_lib.Lib.__init__)
 
 
 def test_product_never_imports_oracle():
@@ -51,7 +59,7 @@ def test_uninitialised_calls_fail_loudly():
         pytest.skip("GPU present")
     so = os.path.join(ROOT, "wasmsnark_amd", "libwsnark.so")
     from wasmsnark_amd import _lib, WsnarkError
-    lib = _lib.Lib(so)
+    lib = _lib.Lib()
     import ctypes as C
     buf = (C.c_uint8 * 64)()
     assert lib.c.wsnark_fr_ntt(buf, 2, 0, 0) == 5          # WSNARK_ERR_NOINIT

@@ -15,8 +15,8 @@ needs_node = pytest.mark.skipif(shutil.which("node") is None or not os.path.exis
                                 reason="node / N-API headers not available")
 
 
-def _build_addon():
-    subprocess.check_call(["make", "-C", JS, "-s"])
+def _build_addon(emul=False):
+    subprocess.check_call(["make", "-C", JS, "-s"] + (["all", "emul"] if emul else []))
 
 
 def _run(lib=None):
@@ -28,7 +28,7 @@ def _run(lib=None):
 def test_node_dropin_against_emulated_kernels():
     from emul_util import emul_bn128, SO
     emul_bn128()
-    _build_addon()
+    _build_addon(emul=True)       # + tests/emul/wsnark_napi_emul.node: the addon's test-only build bound to the emulator library
     out = _run(SO)
     assert out.returncode == 0 and "NODE_DROPIN_OK" in out.stdout, out.stdout + out.stderr
 
@@ -40,6 +40,11 @@ def test_node_addon_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     _build_addon()
     code = "require('%s/index.js').buildBn128().then(()=>{console.log('UNEXPECTED_OK')},e=>{console.log('REJECTED',e.message)})" % JS
+    out = subprocess.run(["node", "-e", code], capture_output=True, text=True, timeout=120)
+    assert "REJECTED" in out.stdout and "no CPU fallback" in out.stdout, out.stdout + out.stderr
+    # ... and no option of the product's API reaches another library: a `lib` the round-4 API accepted is ignored
+    code = ("require('%s/index.js').buildBn128(undefined, {lib: '%s'}).then(()=>{console.log('UNEXPECTED_OK')},e=>{console.log('REJECTED',e.message)})"
+            % (JS, os.path.join(ROOT, "tests", "emul", "libwsnark_emul.so")))
     out = subprocess.run(["node", "-e", code], capture_output=True, text=True, timeout=120)
     assert "REJECTED" in out.stdout and "no CPU fallback" in out.stdout, out.stdout + out.stderr
 

@@ -24,7 +24,7 @@ def lib(request):
         if not os.path.exists(so):
             import __graft_entry__
             __graft_entry__.build()
-        return _lib.Lib(so)            # no init(): verification needs no GPU
+        return _lib.Lib()              # no init(): verification needs no GPU
     from emul_util import emul_bn128
     return emul_bn128().lib
 

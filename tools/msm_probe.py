@@ -1,5 +1,5 @@
 """Per-kernel times of one 2^k G1 sum: the per-call path (wsnark_g1_msm_dev) and the resident-bases path (wsnark_points_msm_dev,
-fixed-base table plan).  Usage: python tools/msm_probe.py [--log-n 20] [--lib path] [--reps 30]; switches through WSNARK_* as usual."""
+fixed-base table plan).  Usage: python tools/msm_probe.py [--log-n 20] [--reps 30]; switches through WSNARK_* as usual."""
 import argparse
 import json
 import os
@@ -12,15 +12,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log-n", type=int, default=20)
-    ap.add_argument("--lib", default=None)
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--tag", default="")
     ap.add_argument("--set", action="append", default=[], help="NAME=value through wsnark_tuning_set (repeatable)")
     a = ap.parse_args()
     import numpy as np
     import torch
-    from wasmsnark_amd import bn128, _lib
-    bn = bn128.Bn128(_lib.Lib(a.lib)) if a.lib else bn128.build()
+    from wasmsnark_amd import bn128
+    bn = bn128.build()
     for kv in a.set:
         k, v = kv.split("=")
         bn.lib.tune(k, int(v))

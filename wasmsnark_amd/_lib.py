@@ -41,8 +41,12 @@ class WsnarkError(RuntimeError):
 
 
 class Lib:
-    def __init__(self, path=None):
-        path = path or DEFAULT_SO     # (no environment override: the product never loads anything but its own library)
+    # The product binds ITS OWN library and nothing else: no path argument, no environment override.  (The test-suite's CPU
+    # thread-emulator build of the same ABI is bound by a subclass that lives under tests/: tests/emul_util.py.)
+    SO = DEFAULT_SO
+
+    def __init__(self):
+        path = type(self).SO
         if not os.path.exists(path):
             raise ImportError(
                 "libwsnark.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -178,11 +182,9 @@ class Lib:
 _default = None
 
 
-def load(path=None):
-    """Returns the process-wide Lib for `path` (default: wasmsnark_amd/libwsnark.so)."""
+def load():
+    """Returns the process-wide Lib (wasmsnark_amd/libwsnark.so)."""
     global _default
-    if path is not None:
-        return Lib(path)
     if _default is None:
         _default = Lib()
     return _default

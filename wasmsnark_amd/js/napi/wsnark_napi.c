@@ -6,9 +6,8 @@
  * loop is never blocked), with the reference's byte layouts (Jacobian-Montgomery 96/192 B,
  * plain-form h, ...).  Reference seam: src/bn128.js:102-166 (worker commands), :353-415, :569-720.
  * libwsnark.so (../libwsnark.so next to this addon: the in-tree hipcc build) is dlopen'ed by init();
- * there is no fallback and no environment override: if it cannot be loaded or finds no GPU, init() throws.
- * (init's optional second argument names another build of the same ABI explicitly; only the test-suite
- * passes one: the CPU thread-emulator build of the kernel sources.)
+ * there is no fallback, no path argument and no environment override: if it cannot be loaded or finds no GPU,
+ * init() throws.
  */
 #define NAPI_VERSION 4
 #define _GNU_SOURCE
@@ -70,11 +69,16 @@ static struct {
         }                                                                       \
     } while (0)
 
-static int load_lib(const char* explicit_path, char* err, size_t errlen) {
+/* The library this addon binds, relative to the addon's own directory: the in-tree hipcc build.  No argument and no environment
+ * variable changes it; the test-suite's emulator host is a SEPARATE build of this file (make -C wasmsnark_amd/js emul ->
+ * tests/emul/wsnark_napi_emul.node, compiled with another WSNARK_NAPI_LIB_RELPATH) that the product never loads. */
+#ifndef WSNARK_NAPI_LIB_RELPATH
+#define WSNARK_NAPI_LIB_RELPATH "../../libwsnark.so"
+#endif
+static int load_lib(char* err, size_t errlen) {
     char path[4200];
     if (L.h) return 0;
-    if (explicit_path && *explicit_path) snprintf(path, sizeof path, "%s", explicit_path);
-    else snprintf(path, sizeof path, "%s/../../libwsnark.so", L.dir);
+    snprintf(path, sizeof path, "%s/%s", L.dir, WSNARK_NAPI_LIB_RELPATH);
     L.h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
     if (!L.h) { snprintf(err, errlen, "cannot load %s: %s", path, dlerror()); return -1; }
 #define SYM(field, name)                                                            \
@@ -626,15 +630,63 @@ static napi_value js_group_keyinfo(napi_env env, napi_callback_info info) {
     return o;
 }
 
-/* init(device[, libPath]) -> device info string */
+/* ---- bin2int / bin2g1 / bin2g2 of the reference (src/bn128.js:319-351, 714-718) in native code ----
+ * proofToObject(ArrayBuffer 384) -> {pi_a: [x, y, z], pi_b: [[x0, x1], [y0, y1], [z0, z1]], pi_c: [x, y, z]} of decimal strings */
+static void le256_to_decimal(const uint8_t* le, char* out /* >= 80 bytes */) {
+    uint32_t w[8];
+    char rev[96];
+    int n = 0;
+    for (int i = 0; i < 8; i++) w[i] = (uint32_t)le[4 * i] | ((uint32_t)le[4 * i + 1] << 8) | ((uint32_t)le[4 * i + 2] << 16) | ((uint32_t)le[4 * i + 3] << 24);
+    for (;;) {
+        uint64_t rem = 0;
+        int nonzero = 0;
+        for (int i = 7; i >= 0; i--) {                 /* w /= 10^9 */
+            const uint64_t cur = (rem << 32) | w[i];
+            w[i] = (uint32_t)(cur / 1000000000u);
+            rem = cur % 1000000000u;
+            nonzero |= w[i] != 0;
+        }
+        for (int k = 0; k < 9; k++) { rev[n++] = (char)('0' + rem % 10); rem /= 10; if (!nonzero && rem == 0) break; }
+        if (!nonzero) break;
+    }
+    while (n > 1 && rev[n - 1] == '0') n--;
+    for (int i = 0; i < n; i++) out[i] = rev[n - 1 - i];
+    out[n] = 0;
+}
+static napi_value js_proof_to_object(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1];
+    uint8_t* p = NULL; size_t n = 0;
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 1 || !get_bytes(env, argv[0], &p, &n) || n != 384) { napi_throw_type_error(env, NULL, "expected the 384 proof bytes"); return NULL; }
+    napi_value v[12], o, a, b, c, pair;
+    char dec[96];
+    for (int i = 0; i < 12; i++) { le256_to_decimal(p + 32 * i, dec); napi_create_string_utf8(env, dec, NAPI_AUTO_LENGTH, &v[i]); }
+    napi_create_object(env, &o);
+    napi_create_array_with_length(env, 3, &a);
+    for (uint32_t i = 0; i < 3; i++) napi_set_element(env, a, i, v[i]);
+    napi_create_array_with_length(env, 3, &b);
+    for (uint32_t i = 0; i < 3; i++) {
+        napi_create_array_with_length(env, 2, &pair);
+        napi_set_element(env, pair, 0, v[3 + 2 * i]);
+        napi_set_element(env, pair, 1, v[4 + 2 * i]);
+        napi_set_element(env, b, i, pair);
+    }
+    napi_create_array_with_length(env, 3, &c);
+    for (uint32_t i = 0; i < 3; i++) napi_set_element(env, c, i, v[9 + i]);
+    napi_set_named_property(env, o, "pi_a", a);
+    napi_set_named_property(env, o, "pi_b", b);
+    napi_set_named_property(env, o, "pi_c", c);
+    return o;
+}
+
+/* init(device) -> device info string */
 static napi_value js_init(napi_env env, napi_callback_info info) {
-    size_t argc = 2; napi_value argv[2], s;
+    size_t argc = 1; napi_value argv[1], s;
     int32_t dev = -1;
-    char lib[4096] = "", err[4600];
+    char err[4600];
     CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     if (argc > 0) napi_get_value_int32(env, argv[0], &dev);
-    if (argc > 1) { size_t n = 0; napi_valuetype t; if (napi_typeof(env, argv[1], &t) == napi_ok && t == napi_string) napi_get_value_string_utf8(env, argv[1], lib, sizeof lib, &n); }
-    if (load_lib(lib, err, sizeof err)) { napi_throw_error(env, NULL, err); return NULL; }
+    if (load_lib(err, sizeof err)) { napi_throw_error(env, NULL, err); return NULL; }
     int rc = L.init(dev);
     if (rc) {
         char msg[600];
@@ -674,6 +726,7 @@ static napi_value module_init(napi_env env, napi_value exports) {
         {"prove", NULL, js_prove, NULL, NULL, NULL, napi_default, NULL},
         {"waitTables", NULL, js_wait_tables, NULL, NULL, NULL, napi_default, NULL},
         {"verify", NULL, js_verify, NULL, NULL, NULL, napi_default, NULL},
+        {"proofToObject", NULL, js_proof_to_object, NULL, NULL, NULL, napi_default, NULL},
         {"loadPoints", NULL, js_points_load, NULL, NULL, NULL, napi_default, NULL},
         {"pointsMultiexp", NULL, js_points_msm, NULL, NULL, NULL, napi_default, NULL},
         {"groupCreate", NULL, js_group_create, NULL, NULL, NULL, napi_default, NULL},
