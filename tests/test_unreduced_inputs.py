@@ -67,12 +67,13 @@ def test_gpu_on_unreduced_inputs():
 
 NODE_SCRIPT = r"""
 const fs = require("fs"), path = require("path");
-const root = process.argv[1], lib = process.argv[2] || undefined;   // (node -e: the arguments start at argv[1])
+const root = process.argv[1];                                       // (node -e: the arguments start at argv[1])
+if (process.argv[2]) require(path.join(root, "tests", "emul", "use_emulator_addon.js"));   // tests only: the emulator build of the addon
 const ws = require(path.join(root, "wasmsnark_amd", "js", "index.js"));
 const gold = path.join(root, "tests", "golden");
 (async () => {
     const U = JSON.parse(fs.readFileSync(path.join(gold, "unreduced.json"), "utf8"));
-    const bn = await ws.buildBn128(undefined, lib ? { lib } : undefined);
+    const bn = await ws.buildBn128();
     for (const c of U.calch) {
         const h = await bn.calcH(Buffer.from(c.signals, "base64"), Buffer.from(c.polsA, "base64"), Buffer.from(c.polsB, "base64"), c.nSignals, c.domain);
         if (Buffer.from(h).toString("base64") !== c.h) throw new Error("calcH on unreduced inputs");
@@ -92,7 +93,7 @@ const gold = path.join(root, "tests", "golden");
 
 
 def _node(lib=None):
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "wasmsnark_amd", "js"), "-s"])
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "wasmsnark_amd", "js"), "-s", "all"] + (["emul"] if lib else []))
     return subprocess.run(["node", "-e", NODE_SCRIPT, ROOT] + ([lib] if lib else []), capture_output=True, text=True, timeout=600)
 
 

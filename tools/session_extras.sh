@@ -10,3 +10,4 @@ timeout 900 python bench.py --prove-log-domain 24 --no-extras --no-cpu-baseline 
 timeout 300 python tools/msm_probe.py > $O/msm_probe.json 2> $O/msm_probe.err
 timeout 600 python bench.py --gpus 2 --single-process --group-devices 0,0 --steps 10 --warmup 3 > $O/bench_group_2x_same_gpu.json 2> $O/bench_group.err
 NODE_BENCH_DEVICES=0,0 timeout 400 python tools/node_bench.py 20 10 > $O/node_bench_group.json 2> $O/node_bench_group.err
+timeout 600 python __graft_entry__.py smoke > $O/smoke.txt 2>&1; echo "smoke rc=$?" >> $O/smoke.txt
