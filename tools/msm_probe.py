@@ -14,12 +14,20 @@ def main():
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--tag", default="")
+    ap.add_argument("--lib", default=None, help="A/B: another build of the library (a subclass of the binding made here: the product's takes no path)")
     ap.add_argument("--set", action="append", default=[], help="NAME=value through wsnark_tuning_set (repeatable)")
     a = ap.parse_args()
     import numpy as np
     import torch
     from wasmsnark_amd import bn128
-    bn = bn128.build()
+    if a.lib:
+        from wasmsnark_amd import _lib
+
+        class Other(_lib.Lib):
+            SO = os.path.abspath(a.lib)
+        bn = bn128.Bn128(lib=Other())
+    else:
+        bn = bn128.build()
     for kv in a.set:
         k, v = kv.split("=")
         bn.lib.tune(k, int(v))

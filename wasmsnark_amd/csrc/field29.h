@@ -50,6 +50,16 @@ template <class P> WS_NOINLINE_DEV F29 mont_sqr29(WS_L9(a));
 template <class P> WS_NOINLINE_DEV F29 mont_mul2add29(WS_L9(a), WS_L9(b), WS_L9(c), WS_L9(d));
 template <class P> WS_HD F29 mont_mul29_body(const F29& a, const F29& b);
 template <class P> WS_HD F29 mont_sqr29_body(const F29& a);
+// On the device every product below runs as mad_chain.h's form of it (generated: the same columns with their multiply-adds as
+// explicit v_mad_u64_u32 chains); the C bodies in this file are the host's, the emulator's, and the specification of the generated ones.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(WSNARK_EMUL) && !defined(WS_NO_MAD_CHAIN)
+#define WS_USE_MAD_CHAIN 1
+template <class P> __device__ __forceinline__ F29 mont_mul29_chain(const F29& a, const F29& b);
+template <class P> __device__ __forceinline__ F29 mont_sqr29_chain(const F29& a);
+template <class P> __device__ __forceinline__ F29 mont_mul2add29_chain(const F29& a, const F29& b, const F29& c, const F29& d);
+template <class P> __device__ __forceinline__ F29 mont_mul4add29_chain(const F29& a, const F29& b, const F29& c, const F29& d, const F29& e, const F29& f,
+                                                                       const F29& g, const F29& h);
+#endif
 
 #define WS_M29 0x1FFFFFFFu
 #ifndef WS_F29_MULSUB_INLINE
@@ -380,6 +390,9 @@ struct Field29 {
     // mul2add as an inlinable body (the quadratic extension's products: the call passes 36 operands, four of
     // them through scratch memory)
     WS_HD static F29 mul2add_inl(const F29& a, const F29& b, const F29& c, const F29& d) {
+#ifdef WS_USE_MAD_CHAIN
+        return mont_mul2add29_chain<P>(a, b, c, d);
+#endif
         uint32_t m[9];
         uint64_t acc = 0;
         F29 r;
@@ -417,6 +430,9 @@ struct Field29 {
     // of the calling convention).
     WS_HD static F29 mul4add(const F29& a, const F29& b, const F29& c, const F29& d, const F29& e, const F29& f,
                              const F29& g, const F29& h) {
+#ifdef WS_USE_MAD_CHAIN
+        return mont_mul4add29_chain<P>(a, b, c, d, e, f, g, h);
+#endif
         uint32_t m[9];
         uint64_t acc = 0;
         F29 r;
@@ -500,6 +516,9 @@ WS_NOINLINE_DEV F29 mont_mul29(WS_L9(a), WS_L9(b)) {
 // per SIMD) let the compiler interleave the independent products of one group addition
 template <class P>
 WS_HD F29 mont_mul29_body(const F29& a, const F29& b) {
+#ifdef WS_USE_MAD_CHAIN
+    return mont_mul29_chain<P>(a, b);
+#endif
     typedef Field29<P> F;
     uint32_t m[9];
     uint64_t acc = 0;
@@ -532,6 +551,9 @@ WS_NOINLINE_DEV F29 mont_mul2add29(WS_L9(a), WS_L9(b), WS_L9(c), WS_L9(d)) {
     typedef Field29<P> F;
     const F29 a = {{a0, a1, a2, a3, a4, a5, a6, a7, a8}}, b = {{b0, b1, b2, b3, b4, b5, b6, b7, b8}};
     const F29 c = {{c0, c1, c2, c3, c4, c5, c6, c7, c8}}, d = {{d0, d1, d2, d3, d4, d5, d6, d7, d8}};
+#ifdef WS_USE_MAD_CHAIN
+    return mont_mul2add29_chain<P>(a, b, c, d);
+#endif
     uint32_t m[9];
     uint64_t acc = 0;
     F29 r;
@@ -566,6 +588,9 @@ WS_NOINLINE_DEV F29 mont_mul2add29(WS_L9(a), WS_L9(b), WS_L9(c), WS_L9(d)) {
 // stay below 2^30 (top one 2^26), a column holds at most 4 doubled products + a square + 9 reduction terms < 2^63.
 template <class P>
 WS_HD F29 mont_sqr29_body(const F29& a) {
+#ifdef WS_USE_MAD_CHAIN
+    return mont_sqr29_chain<P>(a);
+#endif
     typedef Field29<P> F;
     uint32_t m[9], ad[9];
 #pragma unroll
@@ -624,3 +649,4 @@ typedef Field29I<Fq29Params> Fq29I;
 typedef Field29<Fr29Params> Fr29;
 
 }  // namespace wsnark
+#include "mad_chain.h"
