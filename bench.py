@@ -366,7 +366,7 @@ def rooflines(kt, kernel, pairs_per_launch, windows_owned, bytes_per_pair, modmu
            "in_situ": {"achieved": round(modmul / (situ_ms / 1e3) / 1e9, 1), "frac": round(modmul / (situ_ms / 1e3) / 1e9 / pk, 4)},
            "modmul_per_launch": int(modmul), "windows_per_launch": windows_owned,
            "peak_source": ("wsnark_peak_probe in this run on this box: dependent chain of the library's radix-2^29 Montgomery product "
-                           "(162 v_mad_u64_u32 each) on 8 x 256 lanes per CU; best of 3 after a warm-up launch" if live else
+                           "(205 instructions, 162 of them v_mad_u64_u32) on 8 x 256 lanes per CU; best of 3 after a warm-up launch" if live else
                            "tools/microbench.hip on MI355X, round 1 (profiles/r01_session17_microbench.jsonl): not re-measured in this run"),
            "peaks_measured_in_this_run": peak}
     return hbm, alu

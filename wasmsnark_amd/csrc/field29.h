@@ -4,8 +4,10 @@
 // and register moves than on products (584 VALU instructions per product, 96 G modmul/s measured),
 // and every carry chain through VCC pays wait states.  With 9 limbs of 29 bits every column of the
 // schoolbook product (<= 9 a*b + 9 m*p terms of < 2^58) fits one 64-bit accumulator, so a whole
-// Montgomery product is a chain of v_mad_u64_u32 (162) plus 9 v_mul_lo, 17 shifts and 18 masks:
-// no carries, no moves (221 instructions, 172 G modmul/s measured; tools/microbench.hip).
+// Montgomery product is a chain of v_mad_u64_u32 (162) plus 9 v_mul_lo, 16 shifts and 17 masks:
+// no carries, no moves -- 205 instructions, 178-183 G modmul/s measured (wsnark_peak_probe), in the form the device runs:
+// mad_chain.h, generated from the column structure below (the compiler's own arrangement of these loops is 221 instructions,
+// 172 G/s: one 64-bit addition per column more).
 //
 // Semantics.  Same field, same results: this is an internal representation of the heavy kernels
 // (MSM curve arithmetic, NTT butterflies).  It replaces the same reference functions as field.h
