@@ -54,6 +54,7 @@ struct MsmScratch {
     DevBuf bstart, bend, buckets, counters, tasks, multi, partials;
     DevBuf chunkS, chunkA, sums, points_conv;
     DevBuf hot_done;                 // device-scope completion counters of msm_combine_all (zero between launches)
+    DevBuf tree_half, tree_done;     // msm_tree: halves of the unmasked rows and their completion counters (zero between launches)
 };
 
 // ---------------------------------------------------------------------------
@@ -696,6 +697,8 @@ struct TailSets {
     St* sums[4];         // what leaves for the host (reference format)
     const uint32_t* bstart[4];   // the plan's bucket bounds: an EMPTY bucket (no entry) is infinity whatever its slot still holds from the
     const uint32_t* bend[4];     // launch before -- msm_chunks checks the bounds, so no pass over the buckets has to clear them
+    St* half[4];                 // msm_tree: the two halves of the unmasked rows (per piece: [A half 0, A half 1, T half 0, T half 1])
+    uint32_t* half_done[4];      // ... and their completion counters (per piece and row; zero between launches)
 };
 
 template <class C>
@@ -727,19 +730,26 @@ __global__ __launch_bounds__(256) void msm_chunks(TailSets<C> ts, uint32_t nchun
 // (one lane per 256-byte G2 point: 256 threads at most, so that a wavefront may use the whole register file)
 template <class C> struct TreeBound { static constexpr int value = (PointIO<C>::LPP == 1 && sizeof(typename PointIO<C>::Stored) > 128) ? 256 : 512; };
 template <class C>
-__global__ __launch_bounds__(TreeBound<C>::value) void msm_tree(TailSets<C> ts, uint32_t J, uint32_t logJ, uint32_t to_ref) {
+__global__ __launch_bounds__(TreeBound<C>::value) void msm_tree(TailSets<C> ts, uint32_t J, uint32_t logJ, uint32_t to_ref, uint32_t nsum) {
     typedef PointIO<C> IO;
     typedef typename IO::Stored St;
     const St* __restrict__ chunkS = ts.chunkS[blockIdx.z];
     const St* __restrict__ chunkA = ts.chunkA[blockIdx.z];
     St* __restrict__ rows = to_ref ? ts.sums[blockIdx.z] : ts.rows[blockIdx.z];
     WS_DYN_SMEM(St, sh);
-    const uint32_t q = blockIdx.x, w = blockIdx.y;
+    // blockIdx.x < logJ: the masked row q.  Beyond: the UNMASKED rows (sum of all A_j; sum of all S_j), which add up twice as many
+    // elements as a masked one -- each is cut into two halves on two workgroups (round 5: a launch lasted as long as these rows'
+    // 2 J / slots + log2(slots) additions; now every workgroup has J / 2 elements), and the workgroup that finishes second adds the
+    // halves: a device-scope counter per piece and row, left at zero.
+    const uint32_t w = blockIdx.y;
+    const bool masked = blockIdx.x < logJ;
+    const uint32_t q = masked ? blockIdx.x : logJ + ((blockIdx.x - logJ) >> 1), half = masked ? 0 : (blockIdx.x - logJ) & 1u;
     const uint32_t slot = threadIdx.x / IO::LPP, nslots = blockDim.x / IO::LPP;
     const St* src = (q == logJ ? chunkA : chunkS) + (uint64_t)w * J;
     typename C::Pt acc = C::infinity();
-    if (q >= logJ) {
-        for (uint32_t j = slot; j < J; j += nslots) acc = C::add(acc, IO::load(src, j));
+    if (!masked) {
+        const uint32_t Jh = (J + 1) >> 1, lo = half ? Jh : 0, hi = half ? J : Jh;
+        for (uint32_t j = lo + slot; j < hi; j += nslots) acc = C::add(acc, IO::load(src, j));
     } else {
         // enumerate only the J/2 indices whose bit q is set (insert a 1 at bit q): every lane stays busy
         const uint32_t low = (1u << q) - 1;
@@ -754,10 +764,30 @@ __global__ __launch_bounds__(TreeBound<C>::value) void msm_tree(TailSets<C> ts, 
         if (slot < step) IO::store(sh, slot, C::add(IO::load(sh, slot), IO::load(sh, slot + step)));
         __syncthreads();
     }
-    if (slot == 0) {
-        const typename C::Pt r = IO::load(sh, 0);
-        if (to_ref) IO::store_ref(rows, (uint64_t)w * gridDim.x + q, r);
-        else IO::store(rows, (uint64_t)w * gridDim.x + q, r);
+    // (every lane stays to the end: the wavefront-wide exchange below wants all of them)
+    typename C::Pt r = IO::load(sh, 0);
+    uint32_t finish = masked ? 1u : 0u;
+    if (!masked) {
+        const uint32_t hrow = q - logJ;                              // 0: A, 1: T
+        St* hv = ts.half[blockIdx.z] + ((uint64_t)w * 2 + hrow) * 2;
+        uint32_t* done = ts.half_done[blockIdx.z] + (uint64_t)w * 2 + hrow;
+        uint32_t second = 0;
+        if (slot == 0) {
+            IO::store(hv, half, r);
+            __threadfence();
+            if (threadIdx.x == 0) second = atomicAdd(done, 1u);
+        }
+        second = __shfl(second, 0);                                  // (lane 0 of the first wavefront asked; the others' copies are not used)
+        if (slot == 0 && second) {                                   // the other half is there: this workgroup finishes the row
+            __threadfence();
+            r = C::add(r, IO::load(hv, half ^ 1u));
+            if (threadIdx.x == 0) *done = 0;
+            finish = 1;
+        }
+    }
+    if (slot == 0 && finish) {
+        if (to_ref) IO::store_ref(rows, (uint64_t)w * nsum + q, r);
+        else IO::store(rows, (uint64_t)w * nsum + q, r);
     }
 }
 
@@ -850,7 +880,7 @@ struct MsmPending {
         h_sums = nullptr; ev = nullptr; h_bytes = 0; active = false;
         d_sums.release(); d_rows.release();
         S.buckets.release(); S.partials.release(); S.chunkS.release(); S.chunkA.release(); S.points_conv.release(); S.hot_sums.release();
-        S.hot_done.release();
+        S.hot_done.release(); S.tree_half.release(); S.tree_done.release();
     }
 };
 
@@ -1390,6 +1420,11 @@ static int msm_launch_acc(Lane& L, int which, const typename H::Aff* d_points_re
     const size_t sums_bytes = (I.reduce ? (size_t)I.groups * I.nrows : (size_t)W * nsum) * sizeof(Pt);
     WS_HIP_CHECK(P.d_sums.reserve(sums_bytes));
     if (I.reduce) WS_HIP_CHECK(P.d_rows.reserve((size_t)W * nsum * sizeof(Pt)));
+    WS_HIP_CHECK(S.tree_half.reserve((size_t)W * 4 * sizeof(Pt)));
+    {
+        const size_t db = (size_t)W * 2 * sizeof(uint32_t);
+        if (!S.tree_done.p || S.tree_done.bytes < db) { WS_HIP_CHECK(S.tree_done.alloc(db)); WS_HIP_CHECK(hipMemsetAsync(S.tree_done.p, 0, db, s)); }
+    }
     if (P.h_bytes < sums_bytes) {
         if (P.h_sums) (void)hipHostFree(P.h_sums);
         P.h_sums = nullptr; P.h_bytes = 0;
@@ -1451,6 +1486,8 @@ static int msm_launch_tail(Lane& L, const int* slot_ids, int nslots, hipStream_t
         ts.sums[k] = P.d_sums.template as<St>();
         ts.bstart[k] = ws(L).plan[P.plan_id].S.bstart.template as<uint32_t>();
         ts.bend[k] = ws(L).plan[P.plan_id].S.bend.template as<uint32_t>();
+        ts.half[k] = P.S.tree_half.template as<St>();
+        ts.half_done[k] = P.S.tree_done.template as<uint32_t>();
     }
     const uint32_t J = I.J, logJ = I.logJ, nsum = I.nsum, m = I.m, LPP = IO::LPP, W = I.tW;
     KernelTimer& T = X->timer;
@@ -1464,7 +1501,8 @@ static int msm_launch_tail(Lane& L, const int* slot_ids, int nslots, hipStream_t
     const uint32_t smax = 256;
     while (tslots < (J > 1 ? J / 2 : 1) && tslots < smax && tslots * LPP < (uint32_t)TreeBound<C>::value) tslots <<= 1;
     T.begin("msm_tree", s);
-    hipLaunchKernelGGL(msm_tree<C>, dim3(nsum, W, nslots), dim3(tslots * LPP), (size_t)tslots * sizeof(St), s, ts, J, logJ, I.reduce ? 0u : 1u);
+    hipLaunchKernelGGL(msm_tree<C>, dim3(logJ + 2 * (nsum - logJ), W, nslots), dim3(tslots * LPP), (size_t)tslots * sizeof(St), s, ts, J, logJ, I.reduce ? 0u : 1u,
+                       nsum);
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
     size_t sums_bytes;
