@@ -1498,7 +1498,10 @@ static int msm_launch_tail(Lane& L, const int* slot_ids, int nslots, hipStream_t
     // one slot per element of the longest strided sum (J/2 for the masked rows); 256 slots per workgroup (at 152 VGPRs a 512-thread
     // workgroup is one per CU and a full-size tree launch takes three rounds of them; 256 threads fit three per CU: profiles/r04_s6_*)
     uint32_t tslots = 1;
-    const uint32_t smax = 256;
+    // (512 slots where the whole launch is one round of workgroups anyway -- a single G1 set at full size: 16 rows x 16 pieces --:
+    //  4 + 9 dependent additions per lane instead of 8 + 8)
+    const uint32_t tree_wgs = (logJ + 2 * (nsum - logJ)) * W * (uint32_t)nslots;
+    const uint32_t smax = (LPP == 1 && tree_wgs <= 256) ? 512 : 256;
     while (tslots < (J > 1 ? J / 2 : 1) && tslots < smax && tslots * LPP < (uint32_t)TreeBound<C>::value) tslots <<= 1;
     T.begin("msm_tree", s);
     hipLaunchKernelGGL(msm_tree<C>, dim3(logJ + 2 * (nsum - logJ), W, nslots), dim3(tslots * LPP), (size_t)tslots * sizeof(St), s, ts, J, logJ, I.reduce ? 0u : 1u,
