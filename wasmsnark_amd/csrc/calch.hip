@@ -29,16 +29,20 @@ __global__ __launch_bounds__(256) void fr_map_kernel(const Fe* __restrict__ in, 
     out[i] = to_mont ? Fr::to_mont(in[i]) : Fr::from_mont(in[i]);
 }
 
-// res[row] = sum_k coef[k] * sig[col[k]]   (pol_constructLC, row-major)
-__global__ __launch_bounds__(256) void lc_spmv_kernel(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
-                                                        const Fe* __restrict__ coef, const Fe* __restrict__ sig,
-                                                        uint32_t n_rows, Fe* __restrict__ res) {
+// res[row] = sum_k coef[k] * sig[col[k]]   (pol_constructLC, row-major), for the two matrices of a proof in ONE launch (blockIdx.y
+// selects A or B): the rows are gather-latency bound (1-3 terms per lane), so twice the lanes in flight take about as long as one
+// matrix alone -- and CALC_H's transforms start one launch earlier, in the stretch of a proof where the grouping pass leaves most of the chip idle
+struct SpmvPair { const uint32_t* row_ptr[2]; const uint32_t* col[2]; const Fe* coef[2]; Fe* res[2]; };
+__global__ __launch_bounds__(256) void lc_spmv2_kernel(SpmvPair M, const Fe* __restrict__ sig, uint32_t n_rows) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
+    const uint32_t* __restrict__ row_ptr = M.row_ptr[blockIdx.y];
+    const uint32_t* __restrict__ col = M.col[blockIdx.y];
+    const Fe* __restrict__ coef = M.coef[blockIdx.y];
     Fe acc = Fr::zero();
     const uint32_t e = row_ptr[r + 1];
     for (uint32_t k = row_ptr[r]; k < e; k++) acc = Fr::add(acc, Fr::mul(coef[k], sig[col[k]]));
-    res[r] = acc;
+    M.res[blockIdx.y][r] = acc;
 }
 
 __global__ __launch_bounds__(256) void fr_mul_kernel(const Fe* __restrict__ a, const Fe* __restrict__ b, Fe* __restrict__ out, uint64_t n) {
@@ -141,8 +145,8 @@ int eval_ab_dev(Lane& L, const Fe* d_signals_plain, uint32_t n_signals, const Cs
     (void)L;
     const dim3 blk(256), grd(ceil_div_u64(domain, 256));
     // (the resident coefficients are pre-scaled by R: plain signals in, Montgomery sums out -- see pols_to_csr)
-    hipLaunchKernelGGL(lc_spmv_kernel, grd, blk, 0, s, A.row_ptr.as<uint32_t>(), A.col.as<uint32_t>(), A.coef.as<Fe>(), d_signals_plain, domain, d_a);
-    hipLaunchKernelGGL(lc_spmv_kernel, grd, blk, 0, s, B.row_ptr.as<uint32_t>(), B.col.as<uint32_t>(), B.coef.as<Fe>(), d_signals_plain, domain, d_b);
+    const SpmvPair M{{A.row_ptr.as<uint32_t>(), B.row_ptr.as<uint32_t>()}, {A.col.as<uint32_t>(), B.col.as<uint32_t>()}, {A.coef.as<Fe>(), B.coef.as<Fe>()}, {d_a, d_b}};
+    hipLaunchKernelGGL(lc_spmv2_kernel, dim3(grd.x, 2), blk, 0, s, M, d_signals_plain, domain);
     WS_HIP_CHECK(hipGetLastError());
     return WS_OK;
 }
@@ -344,8 +348,8 @@ int calc_h_dev(Lane& L, const Fe* d_signals_plain, uint32_t n_signals, const Csr
     // bn128.js:139 (fft_toMontgomeryN of the signals) has no counterpart per proof: the key's coefficients were scaled once
     // at load time (pols_to_csr), so the sparse products read the plain witness and still leave Montgomery sums
     T.begin("lc_spmv", s);                                           // bn128.js:141-145
-    hipLaunchKernelGGL(lc_spmv_kernel, grd, blk, 0, s, A.row_ptr.as<uint32_t>(), A.col.as<uint32_t>(), A.coef.as<Fe>(), d_signals_plain, domain, a);
-    hipLaunchKernelGGL(lc_spmv_kernel, grd, blk, 0, s, B.row_ptr.as<uint32_t>(), B.col.as<uint32_t>(), B.coef.as<Fe>(), d_signals_plain, domain, b);
+    const SpmvPair M{{A.row_ptr.as<uint32_t>(), B.row_ptr.as<uint32_t>()}, {A.col.as<uint32_t>(), B.col.as<uint32_t>()}, {A.coef.as<Fe>(), B.coef.as<Fe>()}, {a, b}};
+    hipLaunchKernelGGL(lc_spmv2_kernel, dim3(grd.x, 2), blk, 0, s, M, d_signals_plain, domain);
     T.end(s);
     // The pointwise products and the final combination are fused into the transforms next to them: E = A.B is formed by the FIRST pass of its inverse transform while it loads,
     // O = A.B on the coset likewise, and the last pass of that second transform stores h directly.  Saves three
