@@ -320,7 +320,11 @@ int wsnark_points_msm_dev(wsnark_points_t* handle, const void* d_scalars, uint64
  *                            distributed four-step transform when N is a power of two <= 2^floor(log2(domain) / 2)
  *                            (wsnark_group_pkey_info reports which), otherwise complete on every device.
  *   wsnark_group_g{1,2}_msm  = wsnark_g{1,2}_msm with the reference's split of the pairs over the devices
- * Calls on one group are serialised (one collective at a time); different groups are independent. */
+ * Calls on one group are serialised (one collective at a time); different groups are independent.
+ * OWNERSHIP: a group owns its keys.  wsnark_group_free waits for the group's call in flight, then frees the group AND every key
+ * handle still loaded on it: those handles are invalid afterwards and must not be passed to wsnark_group_pkey_free (the Python and
+ * Node hosts forget them when the group dies).  The caller must not free a group while another thread may still START a call on
+ * it (the Node addon counts its queued jobs and defers the free to the last one). */
 typedef struct wsnark_group wsnark_group_t;
 typedef struct wsnark_group_pkey wsnark_group_pkey_t;
 int wsnark_group_create(const int* devices, uint32_t n, wsnark_group_t** out_group);

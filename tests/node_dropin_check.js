@@ -223,6 +223,31 @@ const toAB = (b) => b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength);
         const still = await bn.groth16GenProof(wit, pkey, { r: Buffer.from(c3.r, "hex"), s: Buffer.from(c3.s, "hex") });
         if (JSON.stringify(still) !== JSON.stringify(c3.proof)) throw new Error("proof after a group's terminate()");
     }
+    // terminate() with calls queued and in flight on a group (ADVICE r5: the addon freed the library's group under them -- a
+    // use-after-free, not a rejected Promise).  Every such call must SETTLE: the ones that had started finish with the right proof,
+    // the ones still queued are rejected; nothing crashes, and terminate() itself returns at once.
+    {
+        const grp = await ws.buildBn128({ devices: [0, 0] });
+        const pk3 = fs.readFileSync(path.join(gold, "keys", "t3.pkey.bin")), wt3 = fs.readFileSync(path.join(gold, "keys", "t3.witness.bin"));
+        const c3 = proofs.t3[0], o3 = { r: Buffer.from(c3.r, "hex"), s: Buffer.from(c3.s, "hex") };
+        const h = await grp.loadKey(pk3);
+        const pending = [];
+        for (let i = 0; i < 12; i++) pending.push(grp.groth16GenProof(wt3, h, o3).then((p) => ({ ok: p }), (e) => ({ err: e })));
+        const t0 = Date.now();
+        grp.terminate();
+        if (Date.now() - t0 > 2000) throw new Error("terminate() blocked the event loop behind the calls in flight");
+        const settled = await Promise.all(pending);
+        let ok = 0, rej = 0;
+        for (const r of settled) {
+            if (r.ok) { if (JSON.stringify(r.ok) !== JSON.stringify(c3.proof)) throw new Error("a proof that survived terminate() is wrong"); ok++; }
+            else { if (!/terminated|group/.test(String(r.err && r.err.message))) throw new Error("unexpected rejection: " + (r.err && r.err.message)); rej++; }
+        }
+        if (ok + rej !== 12) throw new Error("calls lost across terminate()");
+        let refused = false;
+        try { await grp.groth16GenProof(wt3, h, o3); } catch (e) { refused = true; }
+        if (!refused) throw new Error("a dead group accepted a call");
+        checked++;
+    }
     // error path: rejected Promise, not a hang (the reference hangs: SURVEY section 5)
     let rejected = false;
     try { await bn.fft(new Uint8Array(96), 0); } catch (e) { rejected = true; }

@@ -83,5 +83,6 @@ def test_group_survives_a_failed_call_and_frees_what_is_left(bn):
         g.groth16GenProof(wit[:-32], key, r=bytes(32), s=bytes(32))
     c = load_golden("proofs.json")["t6"][0]
     assert g.groth16GenProof(wit, key, r=bytes.fromhex(c["r"]), s=bytes.fromhex(c["s"])) == c["proof"]
-    g.terminate()                                           # with the key still loaded: the group frees it
-    key._h = None
+    g.terminate()                                           # with the key still loaded: the group frees it ...
+    assert not key._h                                       # ... and the wrapper forgets the handle, so that
+    key.free()                                              # a late free() is a no-op (it was a use-after-free)

@@ -75,3 +75,23 @@ def test_group_errors_are_agreed_and_the_group_survives():
         key.free()
     finally:
         g.terminate()
+
+
+def test_terminate_with_a_live_key_then_free_is_a_no_op():
+    """wsnark_group_free deletes the group's keys; a GroupKey.free() / __del__ after Group.terminate() used to hand the
+    dead handle to wsnark_group_pkey_free (use-after-free + double free).  The group now forgets its keys' handles when it dies."""
+    bn = emul_bn128()
+    pkey, wit, _ = _key("t3")
+    g = bn128.Group(lib=bn.lib, devices=[0, 0])
+    key, key2 = g.load_key(pkey), g.load_key(pkey)
+    c = load_golden("proofs.json")["t3"][0]
+    assert g.groth16GenProof(wit, key, r=bytes.fromhex(c["r"]), s=bytes.fromhex(c["s"])) == c["proof"]
+    key2.free()                      # an explicit free while the group lives is the library's
+    g.terminate()
+    assert not key._h and not key2._h
+    key.free(); key.free(); del key  # no-ops
+    g.terminate()                    # idempotent
+    g2 = bn128.Group(lib=bn.lib, devices=[0])          # the library is still healthy
+    k2 = g2.load_key(pkey)
+    assert g2.groth16GenProof(wit, k2, r=bytes.fromhex(c["r"]), s=bytes.fromhex(c["s"])) == c["proof"]
+    g2.terminate()

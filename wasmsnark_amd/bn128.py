@@ -8,6 +8,7 @@ proofs).  The Node.js drop-in (wasmsnark_amd/js) binds the same C ABI through N-
 Python mirror exists so the parity tests read like the reference's own tests.
 """
 import ctypes as C
+import weakref
 
 from . import _lib
 
@@ -201,13 +202,16 @@ class GroupKey:
         lib.check(lib.c.wsnark_group_pkey_info(self._h, C.byref(nv), C.byref(npub), C.byref(dom), C.byref(world), C.byref(dist)))
         self.n_vars, self.n_public, self.domain, self.world = nv.value, npub.value, dom.value, world.value
         self.distributed_calc_h = bool(dist.value)      # CALC_H on the four-step transform (else complete on every device)
+        group._keys.add(self)       # wsnark_group_free deletes every key of the group: terminate() forgets their handles first
         if wait_tables:
             lib.check(lib.c.wsnark_group_pkey_wait_tables(self._h))
 
     def free(self):
-        if self._h:
+        """Frees the shard on every device.  A no-op once the group is gone: wsnark_group_free has freed the group's keys with it
+        (include/wsnark.h: "group_free invalidates every key handle of the group")."""
+        if self._h and self._group._h:
             self._lib.c.wsnark_group_pkey_free(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -225,6 +229,7 @@ class Group:
         self.devices = [int(d) for d in devices]
         arr = (C.c_int * len(self.devices))(*self.devices)
         self._h = C.c_void_p()
+        self._keys = weakref.WeakSet()
         self._lib.check(self._lib.c.wsnark_group_create(arr, len(self.devices), C.byref(self._h)))
 
     def load_key(self, pkey=None, sections=None, wait_tables=True):
@@ -265,6 +270,8 @@ class Group:
 
     def terminate(self):                         # src/bn128.js:562-566
         if self._h:
+            for k in list(self._keys):           # the library frees the group's keys with the group: their handles die here
+                k._h = C.c_void_p()
             self._lib.c.wsnark_group_free(self._h)
             self._h = C.c_void_p()
 

@@ -425,10 +425,109 @@ __global__ __launch_bounds__(256) void probe_inverse_kernel(const Fe* __restrict
     out[t] = Fq29::from_internal(x);
 }
 
+// probes 6..14: VALU ISSUE COST PER INSTRUCTION CLASS (round 6).  One instruction class per kernel, written in inline assembly so
+// that the compiler neither folds nor re-schedules it: eight independent chains per lane (no dependent-issue stall: the next
+// instruction never reads the result of the one before), 64 instructions per loop trip, eight wavefronts per SIMD.  The result is
+// the class's lane-operation rate in G/s (wave-instructions/s = that / 64).  bench.py prices a kernel's instruction stream as
+// sum over classes of (count / rate) instead of a flat "4 cycles per VALU instruction" -- the classes are those of
+// tools/isa_histogram.py.   6 v_add_u32 (bit32: add / and / or / 32-bit shifts)   7 v_lshrrev_b64 (shift64)   8 v_and_b32
+// 9 v_mul_lo_u32 (mul32)   10 v_mad_u64_u32 (mad64)   11 v_add_co_u32 + v_addc_co_u32 pairs (add64c: two instructions counted)
+// 12 v_mov_b32 (mov)   13 v_cndmask_b32 (cmp_sel)   14 v_mov_b32 quad_perm DPP (dpp)
+#ifndef WSNARK_EMUL
+#define WS_ISSUE8(INS) INS(0) INS(1) INS(2) INS(3) INS(4) INS(5) INS(6) INS(7)
+template <int CLASS>
+__global__ __launch_bounds__(256) void probe_issue_kernel(uint64_t* __restrict__ out, uint32_t a, uint32_t b, int iters) {
+    uint32_t x0 = a + threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    uint64_t w0 = x0, w1 = x1, w2 = x2, w3 = x3, w4 = x4, w5 = x5, w6 = x6, w7 = x7;
+    uint32_t y = b | 1;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (CLASS == 6) {
+#define WS_I(k) "v_add_u32 %" #k ", %" #k ", %8\n\t"
+                asm volatile(WS_ISSUE8(WS_I) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(y));
+#undef WS_I
+            } else if (CLASS == 7) {
+#define WS_I(k) "v_lshrrev_b64 %" #k ", 1, %" #k "\n\t"
+                asm volatile(WS_ISSUE8(WS_I) : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5), "+v"(w6), "+v"(w7));
+#undef WS_I
+            } else if (CLASS == 8) {
+#define WS_I(k) "v_and_b32 %" #k ", %" #k ", %8\n\t"
+                asm volatile(WS_ISSUE8(WS_I) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(y));
+#undef WS_I
+            } else if (CLASS == 9) {
+#define WS_I(k) "v_mul_lo_u32 %" #k ", %" #k ", %8\n\t"
+                asm volatile(WS_ISSUE8(WS_I) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(y));
+#undef WS_I
+            } else if (CLASS == 10) {
+#define WS_I(k) "v_mad_u64_u32 %" #k ", vcc, %8, %9, %" #k "\n\t"
+                asm volatile(WS_ISSUE8(WS_I) : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5), "+v"(w6), "+v"(w7) : "v"(y), "v"(x0) : "vcc");
+#undef WS_I
+            } else if (CLASS == 11) {
+#define WS_I(k) "v_add_co_u32 %" #k ", vcc, %" #k ", %8\n\tv_addc_co_u32 %" #k ", vcc, %" #k ", %8, vcc\n\t"
+                asm volatile(WS_I(0) WS_I(1) WS_I(2) WS_I(3) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(y) : "vcc");
+#undef WS_I
+            } else if (CLASS == 12) {
+                // moves between two register sets: a chain of length one (the destination of one is never the source of the next)
+                asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7\n\t"
+                             "v_mov_b32 %4, %0\n\tv_mov_b32 %5, %1\n\tv_mov_b32 %6, %2\n\tv_mov_b32 %7, %3\n\t"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+            } else if (CLASS == 13) {
+#define WS_I(k) "v_cndmask_b32 %" #k ", %" #k ", %8, vcc\n\t"
+                asm volatile("v_cmp_lt_u32 vcc, %0, %8\n\t" WS_I(1) WS_I(2) WS_I(3) WS_I(4) WS_I(5) WS_I(6) WS_I(7)
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(y) : "vcc");
+#undef WS_I
+            } else {
+                asm volatile("v_mov_b32_dpp %0, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                             "v_mov_b32_dpp %2, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %3, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                             "v_mov_b32_dpp %4, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %5, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                             "v_mov_b32_dpp %6, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %7, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+            }
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7) + (w0 ^ w1 ^ w2 ^ w3 ^ w4 ^ w5 ^ w6 ^ w7);
+}
+// probe 15: the shader clock UNDER THE MULTIPLY-ADD LOAD, in GHz: the class-10 loop with s_memtime stamps (tick = shader cycle,
+// MI355X_MICROARCH.md) taken by one wavefront that lives as long as the kernel (the grid is exactly one resident set), over the
+// kernel's duration by HIP events.  Only used to EXPRESS the class rates as cycles per wave-instruction; the roofline itself is
+// rate-based and needs no clock.
+__global__ __launch_bounds__(256) void probe_clock_kernel(uint64_t* __restrict__ out, uint64_t* __restrict__ ticks, uint32_t a, uint32_t b, int iters) {
+    uint32_t x0 = a + threadIdx.x;
+    uint64_t w0 = x0, w1 = x0 + 1, w2 = x0 + 2, w3 = x0 + 3, w4 = x0 + 4, w5 = x0 + 5, w6 = x0 + 6, w7 = x0 + 7;
+    uint32_t y = b | 1;
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+#define WS_I(k) "v_mad_u64_u32 %" #k ", vcc, %8, %9, %" #k "\n\t"
+            asm volatile(WS_ISSUE8(WS_I) : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5), "+v"(w6), "+v"(w7) : "v"(y), "v"(x0) : "vcc");
+#undef WS_I
+        }
+    }
+    const uint64_t t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = w0 ^ w1 ^ w2 ^ w3 ^ w4 ^ w5 ^ w6 ^ w7;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ticks[0] = t0; ticks[1] = t1; }
+}
+static void launch_issue_probe(int cls, uint32_t blocks, uint32_t threads, hipStream_t s, uint64_t* out, int iters) {
+    switch (cls) {
+#define WS_CASE(c) case c: hipLaunchKernelGGL(probe_issue_kernel<c>, dim3(blocks), dim3(threads), 0, s, out, 12345u, 777u, iters); break;
+        WS_CASE(6) WS_CASE(7) WS_CASE(8) WS_CASE(9) WS_CASE(10) WS_CASE(11) WS_CASE(12) WS_CASE(13) WS_CASE(14)
+#undef WS_CASE
+    }
+}
+static void launch_clock_probe(uint32_t blocks, uint32_t threads, hipStream_t s, uint64_t* out, uint64_t* ticks, int iters) {
+    hipLaunchKernelGGL(probe_clock_kernel, dim3(blocks), dim3(threads), 0, s, out, ticks, 12345u, 777u, iters);
+}
+#else
+static void launch_issue_probe(int, uint32_t, uint32_t, hipStream_t, uint64_t*, int) {}       // (inline assembly: device only)
+static void launch_clock_probe(uint32_t, uint32_t, hipStream_t, uint64_t*, uint64_t*, int) {}
+#endif
+
 int peak_probe(int probe, double* gops) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
-    if (!gops || probe < 0 || probe > 5) return WS_ERR_ARG;
+    if (!gops || probe < 0 || probe > 15) return WS_ERR_ARG;
     if (probe == 3 || probe == 4) return traffic_probe(C, probe, gops);
     hipStream_t s = C->stream;
 #ifdef WSNARK_EMUL
@@ -446,7 +545,7 @@ int peak_probe(int probe, double* gops) {
 #ifdef WSNARK_EMUL
     const int iters = 2;
 #else
-    const int iters = probe == 2 ? 20000 : probe == 5 ? 8 : 2000;
+    const int iters = probe == 2 ? 20000 : probe == 5 ? 8 : probe >= 6 ? 4000 : 2000;
 #endif
     double best = 0;
     for (int rep = 0; rep < 4; rep++) {          // the first repetition warms the clocks; the best of the rest counts
@@ -454,12 +553,20 @@ int peak_probe(int probe, double* gops) {
         if (probe == 0) hipLaunchKernelGGL(probe_modmul_kernel<Fq29>, dim3(blocks), dim3(threads), 0, s, in.as<Fe>(), out.as<Fe>(), iters);
         else if (probe == 1) hipLaunchKernelGGL(probe_modmul_kernel<Fq29I>, dim3(blocks), dim3(threads), 0, s, in.as<Fe>(), out.as<Fe>(), iters);
         else if (probe == 5) hipLaunchKernelGGL(probe_inverse_kernel, dim3(blocks), dim3(threads), 0, s, in.as<Fe>(), out.as<Fe>(), iters);
+        else if (probe == 15) launch_clock_probe(blocks, threads, s, out.as<uint64_t>(), in.as<uint64_t>(), iters);
+        else if (probe >= 6) launch_issue_probe(probe, blocks, threads, s, out.as<uint64_t>(), iters);
         else hipLaunchKernelGGL(probe_mad_kernel, dim3(blocks), dim3(threads), 0, s, out.as<uint64_t>(), 12345u, 777u, iters);
         (void)hipEventRecord(b, s);
         if (hipEventSynchronize(b) != hipSuccess) break;
         float ms = 0;
         (void)hipEventElapsedTime(&ms, a, b);
-        const double ops = (probe == 2 ? 8.0 : 1.0) * iters * (double)total;
+        const double ops = (probe == 2 ? 8.0 : probe >= 6 ? 64.0 : 1.0) * iters * (double)total;
+        if (probe == 15) {                          // GHz = ticks of the stamped wavefront / the kernel's duration
+            uint64_t tk[2] = {0, 0};
+            if (hipMemcpy(tk, in.p, sizeof tk, hipMemcpyDeviceToHost) != hipSuccess) break;
+            if (rep && ms > 0) best = (double)(tk[1] - tk[0]) / ms / 1e6;
+            continue;
+        }
         if (rep && ms > 0 && ops / ms / 1e6 > best) best = ops / ms / 1e6;
     }
     (void)hipEventDestroy(a);

@@ -80,6 +80,7 @@ class Bn128 {
     g1_multiexp(scalars, points) { return this._msm(0, scalars, points); }
     g2_multiexp(scalars, points) { return this._msm(1, scalars, points); }
     _msm(which, scalars, points) {
+        if (!this._live) return Promise.reject(new Error("wsnark: this Bn128 object has been terminated"));
         if (points !== null && typeof points === "object" && !(points instanceof ArrayBuffer) && !ArrayBuffer.isView(points)) return addon.pointsMultiexp(points, scalars);
         return this._group ? addon.groupMultiexp(this._group, which, scalars, points) : addon.g1g2(which, scalars, points);
     }
@@ -99,6 +100,7 @@ class Bn128 {
      * A cached handle is returned when the digest of ALL bytes equals the one taken when it was loaded; opts.trustCache === true: when
      * the sampled fingerprint does.  Concurrent callers with the same key object share ONE load: the entry is in the map before it is awaited. */
     async loadKey(pkey, opts) {
+        if (!this._live) throw new Error("wsnark: this Bn128 object has been terminated");
         if (pkey !== null && typeof pkey === "object" && !(pkey instanceof ArrayBuffer) && !ArrayBuffer.isView(pkey)) return pkey;   // already a handle
         const u8 = asBytes(pkey);
         const hit = this._cached(pkey, u8);
@@ -140,8 +142,12 @@ class Bn128 {
      * opts.r / opts.s: optional 32-byte blinding values (the reference draws them from crypto.randomBytes)
      * opts.trustCache: see loadKey.  opts.timing: an object that receives {loadKey_ms, prove_ms, format_ms} of this call */
     async groth16GenProof(signals, pkey, opts) {
+        if (!this._live) throw new Error("wsnark: this Bn128 object has been terminated");
         const t0 = process.hrtime.bigint();
-        const prove = (h) => (this._group ? addon.groupProve : addon.prove)(h, signals, opts && opts.r ? opts.r : null, opts && opts.s ? opts.s : null);
+        // which entry point a handle goes to is fixed when the call STARTS: terminate() clears this._group while calls may still be
+        // awaiting their key, and a group key must never reach the single-context prove()
+        const proveFn = this._group ? addon.groupProve : addon.prove;
+        const prove = (h) => proveFn(h, signals, opts && opts.r ? opts.r : null, opts && opts.s ? opts.s : null);
         const isBytes = pkey instanceof ArrayBuffer || ArrayBuffer.isView(pkey);
         let t1, out;
         const hit = isBytes && !(opts && opts.trustCache === true) ? this._cached(pkey, asBytes(pkey)) : null;

@@ -126,9 +126,37 @@ enum { OP_G1, OP_G2, OP_NTT, OP_CALCH, OP_PROVE, OP_LOADKEY, OP_VERIFY, OP_HASH,
 /* A group and the keys loaded on it.  The JS side holds them as externals; a key's finalizer must not touch a group that
  * terminate() has already freed (wsnark_group_free frees the keys that are left), so every group handle carries a `live` flag
  * that outlives the group itself and every key handle points at its group's handle. */
-typedef struct { wsnark_group_t* g; int live; int refs; } group_ref_t;
-typedef struct { wsnark_group_pkey_t* k; group_ref_t* gr; } gkey_ref_t;
-static void group_ref_drop(group_ref_t* gr) { if (--gr->refs == 0) free(gr); }
+/* Lifetime: jobs queued on the libuv pool hold raw pointers into the group, so the library's group must outlive every
+ * job that was queued while it was live.  `inflight` counts them (touched on the JS thread only: start_job / job_complete);
+ * groupFree / terminate() / the finalizer only mark the group dead (`live` = 0, read by the pool threads) and the LAST job's
+ * completion frees it -- at once when nothing is in flight.  A job that reaches the pool after the group died is rejected
+ * without entering the library. */
+/* Every external this addon hands to JS starts with a tag naming its kind (Node 12 has no napi_type_tag_object): a group key passed
+ * where a key handle is expected -- index.js once did that after terminate() -- is refused instead of being read as the other struct. */
+#define TAG_KEY 0x77736e4b45593031ull
+#define TAG_POINTS 0x77736e5054533031ull
+#define TAG_GROUP 0x77736e4752503031ull
+#define TAG_GKEY 0x77736e474b593031ull
+typedef struct { uint64_t tag; void* p; } handle_t;                 /* a key (wsnark_pkey_t*) or a point set (wsnark_points_t*) */
+typedef struct { uint64_t tag; wsnark_group_t* g; int live; int inflight; int refs; } group_ref_t;
+typedef struct { uint64_t tag; wsnark_group_pkey_t* k; group_ref_t* gr; } gkey_ref_t;
+static void* get_handle(napi_env env, napi_value v, uint64_t tag) {
+    void* p = NULL;
+    napi_valuetype t;
+    if (napi_typeof(env, v, &t) != napi_ok || t != napi_external || napi_get_value_external(env, v, &p) != napi_ok || !p) return NULL;
+    return *(const uint64_t*)p == tag ? p : NULL;
+}
+static void* get_plain(napi_env env, napi_value v, uint64_t tag) {   /* the library pointer inside a key / points handle */
+    handle_t* h = (handle_t*)get_handle(env, v, tag);
+    return h ? h->p : NULL;
+}
+static handle_t* new_handle(uint64_t tag, void* p) {
+    handle_t* h = (handle_t*)calloc(1, sizeof *h);
+    if (h) { h->tag = tag; h->p = p; }
+    return h;
+}
+static void group_ref_drop(group_ref_t* gr) { if (--gr->refs == 0) { gr->tag = 0; free(gr); } }
+static void group_release(group_ref_t* gr);
 typedef struct {
     int op, rc;
     napi_async_work work;
@@ -142,6 +170,7 @@ typedef struct {
     wsnark_pkey_t* key;
     group_ref_t* gr;
     gkey_ref_t* gk;
+    group_ref_t* gr_used;       /* the group this job runs on (counted in its `inflight`), or NULL */
     wsnark_points_t* pts;
     uint8_t* out;
     size_t nout;
@@ -213,6 +242,11 @@ static int hash_bytes(const uint8_t* p, size_t n, uint8_t out[16]) {
 static void job_execute(napi_env env, void* data) {
     (void)env;
     job_t* j = (job_t*)data;
+    if (j->gr_used && !__atomic_load_n(&j->gr_used->live, __ATOMIC_ACQUIRE)) {      /* terminate() ran after this job was queued */
+        j->rc = -1;
+        snprintf(j->err, sizeof j->err, "wsnark: the group was terminated before this call ran");
+        return;
+    }
     switch (j->op) {
     case OP_G1: j->rc = L.g1_msm(j->a, j->b, j->na / 32, j->out); break;
     case OP_G2: j->rc = L.g2_msm(j->a, j->b, j->na / 32, j->out); break;
@@ -242,28 +276,46 @@ static void job_execute(napi_env env, void* data) {
     if (j->rc) snprintf(j->err, sizeof j->err, "wsnark error %d: %s", j->rc, L.last_error());
 }
 
+/* JS thread.  The group dies now if no job is in flight on it, otherwise with the last of them (job_complete). */
+static void group_release(group_ref_t* gr) {
+    __atomic_store_n(&gr->live, 0, __ATOMIC_RELEASE);
+    if (gr->g && gr->inflight == 0) { L.group_free(gr->g); gr->g = NULL; }
+}
+static void job_use_group(job_t* j, group_ref_t* gr) { j->gr_used = gr; gr->inflight++; gr->refs++; }
+static void job_done_with_group(job_t* j) {
+    group_ref_t* gr = j->gr_used;
+    if (!gr) return;
+    j->gr_used = NULL;
+    gr->inflight--;
+    if (!gr->live && gr->inflight == 0 && gr->g) { L.group_free(gr->g); gr->g = NULL; }
+    group_ref_drop(gr);
+}
+
 static void key_finalize(napi_env env, void* data, void* hint) {
     (void)env; (void)hint;
-    if (data) L.pkey_free((wsnark_pkey_t*)data);
+    handle_t* h = (handle_t*)data;
+    if (h) { if (h->p) L.pkey_free((wsnark_pkey_t*)h->p); h->tag = 0; free(h); }
 }
 
 static void points_finalize(napi_env env, void* data, void* hint) {
     (void)env; (void)hint;
-    if (data) L.points_free((wsnark_points_t*)data);
+    handle_t* h = (handle_t*)data;
+    if (h) { if (h->p) L.points_free((wsnark_points_t*)h->p); h->tag = 0; free(h); }
 }
 static void gkey_finalize(napi_env env, void* data, void* hint) {
     (void)env; (void)hint;
     gkey_ref_t* gk = (gkey_ref_t*)data;
     if (!gk) return;
-    if (gk->k && gk->gr->live) L.group_pkey_free(gk->k);      /* (a freed group took its keys with it) */
+    if (gk->k && gk->gr->live) L.group_pkey_free(gk->k);      /* (a dead or dying group takes its keys with it) */
     group_ref_drop(gk->gr);
+    gk->tag = 0;
     free(gk);
 }
 static void group_finalize(napi_env env, void* data, void* hint) {
     (void)env; (void)hint;
     group_ref_t* gr = (group_ref_t*)data;
     if (!gr) return;
-    if (gr->live) { gr->live = 0; L.group_free(gr->g); }
+    group_release(gr);          /* (jobs in flight keep `gr` alive through their own reference and free the group when they finish) */
     group_ref_drop(gr);
 }
 
@@ -280,13 +332,13 @@ static void job_complete(napi_env env, napi_status status, void* data) {
         napi_create_external(env, j->gk, gkey_finalize, NULL, &res);
         napi_resolve_deferred(env, j->deferred, res);
     } else if (j->op == OP_POINTS_LOAD) {
-        napi_create_external(env, j->pts, points_finalize, NULL, &res);
+        napi_create_external(env, new_handle(TAG_POINTS, j->pts), points_finalize, NULL, &res);
         napi_resolve_deferred(env, j->deferred, res);
     } else if (j->op == OP_VERIFY) {
         napi_get_boolean(env, j->i0 != 0, &res);
         napi_resolve_deferred(env, j->deferred, res);
     } else if (j->op == OP_LOADKEY) {
-        napi_create_external(env, j->key, key_finalize, NULL, &res);
+        napi_create_external(env, new_handle(TAG_KEY, j->key), key_finalize, NULL, &res);
         napi_resolve_deferred(env, j->deferred, res);
     } else {
         void* dst;
@@ -296,17 +348,22 @@ static void job_complete(napi_env env, napi_status status, void* data) {
     }
     for (int i = 0; i < j->nrefs; i++) napi_delete_reference(env, j->refs[i]);
     napi_delete_async_work(env, j->work);
+    job_done_with_group(j);
     free(j->out);
     free(j);
 }
 
 static napi_value start_job(napi_env env, job_t* j, const char* name) {
     napi_value promise, rname;
-    if (!L.h) { free(j->out); free(j); napi_throw_error(env, NULL, "wsnark_napi: init() has not been called (use buildBn128())"); return NULL; }
-    CHECK(env, napi_create_promise(env, &j->deferred, &promise));
-    CHECK(env, napi_create_string_utf8(env, name, NAPI_AUTO_LENGTH, &rname));
-    CHECK(env, napi_create_async_work(env, NULL, rname, job_execute, job_complete, j, &j->work));
-    CHECK(env, napi_queue_async_work(env, j->work));
+    if (!L.h) { job_done_with_group(j); free(j->out); free(j); napi_throw_error(env, NULL, "wsnark_napi: init() has not been called (use buildBn128())"); return NULL; }
+    if (napi_create_promise(env, &j->deferred, &promise) != napi_ok || napi_create_string_utf8(env, name, NAPI_AUTO_LENGTH, &rname) != napi_ok ||
+        napi_create_async_work(env, NULL, rname, job_execute, job_complete, j, &j->work) != napi_ok || napi_queue_async_work(env, j->work) != napi_ok) {
+        for (int i = 0; i < j->nrefs; i++) napi_delete_reference(env, j->refs[i]);
+        job_done_with_group(j);           /* (never queued: nothing will complete it) */
+        free(j->out); free(j);
+        napi_throw_error(env, NULL, "wsnark_napi: cannot queue the call");
+        return NULL;
+    }
     return promise;
 }
 static int keep(napi_env env, job_t* j, napi_value v) {   /* inputs stay referenced until completion */
@@ -388,7 +445,7 @@ static napi_value js_wait_tables(napi_env env, napi_callback_info info) {
     CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     job_t* j = (job_t*)calloc(1, sizeof *j);
     j->op = OP_WAIT_TABLES; j->nout = 1; j->out = (uint8_t*)calloc(1, 1);
-    if (argc < 1 || napi_get_value_external(env, argv[0], (void**)&j->key) != napi_ok || !j->key) FAIL(env, j, "expected a key handle");
+    if (argc < 1 || !(j->key = (wsnark_pkey_t*)get_plain(env, argv[0], TAG_KEY))) FAIL(env, j, "expected a key handle");
     keep(env, j, argv[0]);
     return start_job(env, j, "wsnark_pkey_wait_tables");
 }
@@ -399,7 +456,7 @@ static napi_value js_prove(napi_env env, napi_callback_info info) {
     CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     job_t* j = (job_t*)calloc(1, sizeof *j);
     j->op = OP_PROVE; j->nout = 448; j->out = (uint8_t*)malloc(448);
-    if (argc < 2 || napi_get_value_external(env, argv[0], (void**)&j->key) != napi_ok || !j->key ||
+    if (argc < 2 || !(j->key = (wsnark_pkey_t*)get_plain(env, argv[0], TAG_KEY)) ||
         !get_bytes(env, argv[1], &j->a, &j->na))
         FAIL(env, j, "expected (keyHandle, witness[, r32, s32])");
     keep(env, j, argv[0]); keep(env, j, argv[1]);
@@ -461,7 +518,7 @@ static napi_value js_keyinfo(napi_env env, napi_callback_info info) {
     size_t argc = 1; napi_value argv[1], o, v;
     wsnark_pkey_t* k = NULL;
     CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-    if (argc < 1 || napi_get_value_external(env, argv[0], (void**)&k) != napi_ok || !k) { napi_throw_type_error(env, NULL, "expected a key handle"); return NULL; }
+    if (argc < 1 || !(k = (wsnark_pkey_t*)get_plain(env, argv[0], TAG_KEY))) { napi_throw_type_error(env, NULL, "expected a key handle"); return NULL; }
     uint32_t nv, np, dom;
     L.pkey_info(k, &nv, &np, &dom);
     napi_create_object(env, &o);
@@ -500,7 +557,7 @@ static napi_value js_points_msm(napi_env env, napi_callback_info info) {
     CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     job_t* j = (job_t*)calloc(1, sizeof *j);
     j->op = OP_POINTS_MSM;
-    if (argc < 2 || napi_get_value_external(env, argv[0], (void**)&j->pts) != napi_ok || !j->pts || !get_bytes(env, argv[1], &j->a, &j->na))
+    if (argc < 2 || !(j->pts = (wsnark_points_t*)get_plain(env, argv[0], TAG_POINTS)) || !get_bytes(env, argv[1], &j->a, &j->na))
         FAIL(env, j, "expected (points handle, scalars)");
     L.points_info(j->pts, &g, NULL, NULL, NULL, NULL);
     j->nout = g == 2 ? 192 : 96; j->out = (uint8_t*)malloc(j->nout);
@@ -535,28 +592,28 @@ static napi_value js_group_create(napi_env env, napi_callback_info info) {
         napi_throw_error(env, NULL, msg);
         return NULL;
     }
-    gr->live = 1; gr->refs = 1;
+    gr->tag = TAG_GROUP; gr->live = 1; gr->refs = 1;
     if (napi_create_external(env, gr, group_finalize, NULL, &res) != napi_ok) { L.group_free(gr->g); free(gr); napi_throw_error(env, NULL, "wsnark_napi: cannot wrap the group"); return NULL; }
     return res;
 }
-/* groupFree(group): frees the contexts now (and the keys still loaded on them); the handle stays valid as a dead one */
+/* groupFree(group): the group is dead from here on (new calls are refused, queued ones are rejected when they reach the pool);
+ * its contexts and the keys still loaded on them are freed now, or by the completion of the last call in flight.  Never blocks
+ * the event loop behind a running proof.  The handle stays valid as a dead one. */
 static napi_value js_group_free(napi_env env, napi_callback_info info) {
     size_t argc = 1; napi_value argv[1], u;
     group_ref_t* gr = NULL;
     CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-    if (argc >= 1 && napi_get_value_external(env, argv[0], (void**)&gr) == napi_ok && gr && gr->live) { gr->live = 0; L.group_free(gr->g); }
+    if (argc >= 1 && (gr = (group_ref_t*)get_handle(env, argv[0], TAG_GROUP)) && gr->live) group_release(gr);
     napi_get_undefined(env, &u);
     return u;
 }
 static group_ref_t* live_group(napi_env env, napi_value v) {
-    group_ref_t* gr = NULL;
-    if (napi_get_value_external(env, v, (void**)&gr) != napi_ok || !gr || !gr->live) return NULL;
-    return gr;
+    group_ref_t* gr = (group_ref_t*)get_handle(env, v, TAG_GROUP);
+    return gr && gr->live ? gr : NULL;
 }
 static gkey_ref_t* live_gkey(napi_env env, napi_value v) {
-    gkey_ref_t* gk = NULL;
-    if (napi_get_value_external(env, v, (void**)&gk) != napi_ok || !gk || !gk->k || !gk->gr->live) return NULL;
-    return gk;
+    gkey_ref_t* gk = (gkey_ref_t*)get_handle(env, v, TAG_GKEY);
+    return gk && gk->k && gk->gr->live ? gk : NULL;
 }
 /* groupMultiexp(group, which, scalars, points) -> Promise<ArrayBuffer 96/192> */
 static napi_value js_group_msm(napi_env env, napi_callback_info info) {
@@ -570,6 +627,7 @@ static napi_value js_group_msm(napi_env env, napi_callback_info info) {
     j->op = which ? OP_GROUP_G2 : OP_GROUP_G1; j->nout = which ? 192 : 96; j->out = (uint8_t*)malloc(j->nout);
     if (j->nb < (j->na / 32) * (which ? 128 : 64)) FAIL(env, j, "points buffer too short for the number of scalars");
     keep(env, j, argv[0]); keep(env, j, argv[2]); keep(env, j, argv[3]);
+    job_use_group(j, j->gr);
     return start_job(env, j, "wsnark_group_msm");
 }
 /* groupLoadKey(group, pkey) -> Promise<group key handle> */
@@ -580,8 +638,9 @@ static napi_value js_group_loadkey(napi_env env, napi_callback_info info) {
     j->op = OP_GROUP_LOADKEY;
     if (argc < 2 || !(j->gr = live_group(env, argv[0])) || !get_bytes(env, argv[1], &j->a, &j->na)) FAIL(env, j, "expected (group, proving_key.bin bytes)");
     j->gk = (gkey_ref_t*)calloc(1, sizeof *j->gk);
-    j->gk->gr = j->gr; j->gr->refs++;
+    j->gk->tag = TAG_GKEY; j->gk->gr = j->gr; j->gr->refs++;
     keep(env, j, argv[0]); keep(env, j, argv[1]);
+    job_use_group(j, j->gr);
     return start_job(env, j, "wsnark_group_pkey_load");
 }
 /* groupProve(groupKey, witness, r32|null, s32|null) -> Promise<ArrayBuffer 448>: proof | r | s used */
@@ -602,6 +661,7 @@ static napi_value js_group_prove(napi_env env, napi_callback_info info) {
         if (!get_bytes(env, argv[3], &j->s32, &n) || n != 32) FAIL(env, j, "s must be 32 bytes");
         keep(env, j, argv[3]);
     }
+    job_use_group(j, j->gk->gr);
     return start_job(env, j, "wsnark_group_prove");
 }
 static napi_value js_group_wait_tables(napi_env env, napi_callback_info info) {
@@ -611,6 +671,7 @@ static napi_value js_group_wait_tables(napi_env env, napi_callback_info info) {
     j->op = OP_GROUP_WAIT_TABLES; j->nout = 1; j->out = (uint8_t*)calloc(1, 1);
     if (argc < 1 || !(j->gk = live_gkey(env, argv[0]))) FAIL(env, j, "expected a group key handle");
     keep(env, j, argv[0]);
+    job_use_group(j, j->gk->gr);
     return start_job(env, j, "wsnark_group_pkey_wait_tables");
 }
 /* groupKeyInfo(groupKey) -> {nVars, nPublic, domainSize, world, distributedCalcH} */
