@@ -337,9 +337,12 @@ int calc_h_dev(Lane& L, const Fe* d_signals_plain, uint32_t n_signals, const Csr
     while ((1u << bits) < domain) bits++;
     const size_t nb = (size_t)domain * sizeof(Fe);
     ScratchGuard scratch_turn(L.calch_chain, s);   // the work arrays below are shared by every CALC_H on this lane
-    for (int i = 1; i < 4; i++) WS_HIP_CHECK(L.calch_buf[i].reserve(nb));
+    // a and b back to back: their two inverse and their two coset transforms run as ONE batch of two each (round 6: a 2^20 pass
+    // is exactly one resident set of workgroups, all in the same phase; twice the workgroups let loads overlap butterflies)
+    WS_HIP_CHECK(L.calch_buf[1].reserve(2 * nb));
+    WS_HIP_CHECK(L.calch_buf[3].reserve(nb));
     Fe* a = L.calch_buf[1].as<Fe>();
-    Fe* b = L.calch_buf[2].as<Fe>();
+    Fe* b = a + domain;
     Fe* e = L.calch_buf[3].as<Fe>();
     KernelTimer& T = C->timer;
     const dim3 blk(256), grd(ceil_div_u64(domain, 256));
@@ -356,10 +359,15 @@ int calc_h_dev(Lane& L, const Fe* d_signals_plain, uint32_t n_signals, const Csr
     // element-wise kernels (4 x 32 B x domain of traffic each) and their slow saturated-field products.
     {
         if ((rc = ntt_run(L, a, b, e, nullptr, domain, 0, 1, s))) return rc;   // e = iNTT(A.B)            (bn128.js:148, 160)
-        if ((rc = ntt_dev(L, a, domain, 0, 1, s))) return rc;                  // bn128.js:150-151  evaluations -> coefficients
-        if ((rc = ntt_dev(L, b, domain, 0, 1, s))) return rc;
-        if ((rc = ntt_dev(L, a, domain, 1, 0, s))) return rc;                  // bn128.js:152-153  -> odd-coset evaluations
-        if ((rc = ntt_dev(L, b, domain, 1, 0, s))) return rc;
+        if (tuning_get("CALCH_BATCH", 1)) {
+            if ((rc = ntt_dev(L, a, domain, 0, 1, s, 2))) return rc;           // bn128.js:150-151  evaluations -> coefficients (a, b)
+            if ((rc = ntt_dev(L, a, domain, 1, 0, s, 2))) return rc;           // bn128.js:152-153  -> odd-coset evaluations (a, b)
+        } else {
+            if ((rc = ntt_dev(L, a, domain, 0, 1, s))) return rc;
+            if ((rc = ntt_dev(L, b, domain, 0, 1, s))) return rc;
+            if ((rc = ntt_dev(L, a, domain, 1, 0, s))) return rc;
+            if ((rc = ntt_dev(L, b, domain, 1, 0, s))) return rc;
+        }
         return ntt_run(L, a, b, d_h_out, e, domain, 0, 1, s);                  // o = iNTT(A.B on the coset), h = combine(e, o)   (:158-164)
     }
 }

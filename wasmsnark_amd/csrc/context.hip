@@ -24,7 +24,6 @@ const std::string& get_last_error() { return t_last_error; }
 
 static Context* g_ctx = nullptr;                  // the default context (wsnark_init)
 static std::mutex g_ctx_mu;
-static std::string g_devinfo;
 static thread_local Context* t_ctx = nullptr;      // the calling thread's selection (CtxScope); nullptr = the default context
 
 Context* ctx() { return t_ctx ? t_ctx : g_ctx; }
@@ -37,27 +36,82 @@ Context* ctx_set_current(Context* c) { Context* p = t_ctx; t_ctx = c; return p; 
 static std::mutex g_tune_mu;
 static std::map<std::string, long> g_tune;                       // overrides
 static std::map<std::string, std::pair<bool, long>> g_env;       // name -> (set in the environment, value), filled on first use
-long tuning_get(const char* name, long dflt) {
+// Fast path: the switches are read many times per proof from every prover thread, so a reader first looks into a small
+// per-thread table keyed by the NAME'S ADDRESS (every caller passes a string literal) and stamped with the generation of the
+// override map; only a miss -- first use on this thread, or any wsnark_tuning_set since -- takes the mutex and the two map lookups.
+// Nothing caches a switch in a `static` any more, so wsnark_tuning_set reaches every reader with its next call.
+static std::atomic<uint64_t> g_tune_gen{1};
+static long tuning_lookup(const char* name, bool* is_set) {
     std::lock_guard<std::mutex> lk(g_tune_mu);
     auto it = g_tune.find(name);
-    if (it != g_tune.end()) return it->second;
+    if (it != g_tune.end()) { *is_set = true; return it->second; }
     auto ie = g_env.find(name);
     if (ie == g_env.end()) {
         const std::string env = std::string("WSNARK_") + name;
         const char* e = getenv(env.c_str());
         ie = g_env.emplace(name, std::make_pair(e != nullptr, e ? atol(e) : 0L)).first;
     }
-    return ie->second.first ? ie->second.second : dflt;
+    *is_set = ie->second.first;
+    return ie->second.second;
+}
+long tuning_get(const char* name, long dflt) {
+    struct Slot { const char* name; uint64_t gen; long value; bool is_set; };
+    static thread_local Slot cache[64];
+    const uint64_t gen = g_tune_gen.load(std::memory_order_acquire);
+    Slot& sl = cache[((uintptr_t)name >> 2) & 63];
+    if (sl.name != name || sl.gen != gen) {
+        bool is_set = false;
+        const long v = tuning_lookup(name, &is_set);
+        sl = Slot{name, gen, v, is_set};
+    }
+    return sl.is_set ? sl.value : dflt;
 }
 void tuning_set(const char* name, long value) {
     std::lock_guard<std::mutex> lk(g_tune_mu);
     if (value == LONG_MIN) g_tune.erase(name);
     else g_tune[name] = value;
+    g_tune_gen.fetch_add(1, std::memory_order_release);
+}
+// WSNARK_<name> as a fraction-capable number (e.g. WSNARK_TABLE_MAX_GB=0.5): the environment value is parsed as a double once; an
+// override through wsnark_tuning_set (integers only) wins.  Negative values read as 0.
+double tuning_get_real(const char* name, double dflt) {
+    {
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        auto it = g_tune.find(name);
+        if (it != g_tune.end()) return it->second < 0 ? 0.0 : (double)it->second;
+    }
+    static std::mutex mu;
+    static std::map<std::string, std::pair<bool, double>> env;
+    std::lock_guard<std::mutex> lk(mu);
+    auto ie = env.find(name);
+    if (ie == env.end()) {
+        const std::string key = std::string("WSNARK_") + name;
+        const char* e = getenv(key.c_str());
+        ie = env.emplace(name, std::make_pair(e != nullptr, e ? atof(e) : 0.0)).first;
+    }
+    if (!ie->second.first) return dflt;
+    return ie->second.second < 0 ? 0.0 : ie->second.second;
 }
 
 static int ensure_ring(Context* C);
 // One context on one device: its queues, lanes and helper threads.  device < 0: LOCAL_RANK, else 0.
-int context_create(int device, Context** out) {
+static int context_create_impl(int device, bool wrap, Context* C);
+int context_create(int device, Context** out, bool wrap) {
+    Context* C = new Context();
+    const int rc = context_create_impl(device, wrap, C);
+    if (rc != WS_OK) {                 // (an error return used to delete the Context and leak the queues created so far)
+        const std::string why = get_last_error();
+        context_destroy(C);
+        set_last_error(why);
+        return rc;
+    }
+    *out = C;
+    return WS_OK;
+}
+// device < 0: LOCAL_RANK, else 0.  wrap (the default context only: torchrun-style launches on hosts that show each rank one GPU):
+// ordinals beyond the device count wrap around; a GROUP's ordinals must exist (two contexts on one GPU are asked for by repeating
+// the ordinal, never by naming a device that is not there).
+static int context_create_impl(int device, bool wrap, Context* C) {
     if (device < 0) {
         const char* lr = getenv("LOCAL_RANK");
         device = lr ? atoi(lr) : 0;
@@ -65,15 +119,17 @@ int context_create(int device, Context** out) {
     int count = 0;
     WS_HIP_CHECK(hipGetDeviceCount(&count));
     if (count <= 0) { set_last_error("no HIP device visible"); return WS_ERR_HIP; }
-    if (device >= count) device = device % count;
+    if (device >= count) {
+        if (!wrap) { set_last_error("device ordinal " + std::to_string(device) + " does not exist (" + std::to_string(count) + " visible)"); return WS_ERR_ARG; }
+        device = device % count;
+    }
     WS_HIP_CHECK(hipSetDevice(device));
-    std::unique_ptr<Context> C(new Context());
     C->device = device;
     C->owner_pid = (int)getpid();
     hipDeviceProp_t prop;
     WS_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     C->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    g_devinfo = std::string(prop.name) + " " + prop.gcnArchName + " CUs=" + std::to_string(C->num_cu);
+    C->devinfo = std::string(prop.name) + " " + prop.gcnArchName + " CUs=" + std::to_string(C->num_cu);
     WS_HIP_CHECK(hipStreamCreateWithFlags(&C->stream, hipStreamNonBlocking));
     {
         const long nl = tuning_get("LANES", 2);
@@ -108,7 +164,7 @@ int context_create(int device, Context** out) {
     // work done or in progress (the ring is created under its mutex, module loads are serialised by the runtime).
     // WSNARK_INIT_WARM=0: on first use.
     if (tuning_get("INIT_WARM", 1)) {
-        Context* P = C.get();
+        Context* P = C;
         C->warm_ring = new std::thread([P]() {
             if (hipSetDevice(P->device) != hipSuccess) return;
             std::lock_guard<std::mutex> lk(P->ring_mu);
@@ -122,7 +178,6 @@ int context_create(int device, Context** out) {
         });
     }
 #endif
-    *out = C.release();
     return WS_OK;
 }
 void context_join_warm(Context* C) {
@@ -178,7 +233,7 @@ int context_init(int device) {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     if (g_ctx) return WS_OK;
     Context* C = nullptr;
-    int rc = context_create(device, &C);
+    int rc = context_create(device, &C, /*wrap=*/true);
     if (rc) return rc;
     g_ctx = C;
     return WS_OK;
@@ -191,7 +246,11 @@ void context_shutdown() {
     context_destroy(C);
 }
 
-const std::string& device_info() { return g_devinfo; }
+const std::string& device_info() {       // of the calling thread's context (the default one unless a group call selected another)
+    static const std::string none;
+    Context* C = ctx();
+    return C ? C->devinfo : none;
+}
 
 LaneLock acquire_lane(Context* C) {
     LaneLock r;
@@ -319,7 +378,7 @@ int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s
 #ifdef WSNARK_EMUL
     direct = !tuning_get("STAGE_FORCE_RING", 0);    // (the emulator's "device" memory is host memory; tests force the ring to run its bookkeeping)
 #else
-    {
+    if (!direct || direct_out) {                    // (small copies go up directly whatever their source: no query -- ADVICE r5)
         hipPointerAttribute_t at;
         if (hipPointerGetAttributes(&at, h_src) == hipSuccess) pinned = at.type == hipMemoryTypeHost;
         else (void)hipGetLastError();               // pageable memory is "invalid value" to the runtime: not an error here
@@ -470,7 +529,7 @@ void KernelTimer::end(hipStream_t s) {
 void KernelTimer::collect() {
     std::lock_guard<std::mutex> lk(mu);
     // WSNARK_TIMELINE=1: start/end of every bracket relative to the first one (both queues share the device clock)
-    static const bool timeline = tuning_get("TIMELINE", 0) == 1;
+    const bool timeline = tuning_get("TIMELINE", 0) == 1;
     for (auto& r : recs) {
         float ms = 0.f;
         (void)hipEventSynchronize(r.b);

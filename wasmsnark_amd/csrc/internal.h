@@ -95,6 +95,7 @@ struct Context {
     int device = 0;
     hipStream_t stream = nullptr;               // utility queue: key ingestion, table builds, small host-pointer calls
     int num_cu = 256;
+    std::string devinfo;                        // "<name> <arch> CUs=<n>" of THIS context's device (wsnark_device_info)
     int n_lanes = 2;
     Lane lanes[kMaxLanes];
     std::mutex lane_mu;                         // waiting for a lane: released lanes are announced on lane_cv
@@ -128,7 +129,7 @@ struct CtxScope {
     CtxScope(const CtxScope&) = delete;
     CtxScope& operator=(const CtxScope&) = delete;
 };
-int context_create(int device, Context** out);  // a context of its own on that device (wsnark_group_create)
+int context_create(int device, Context** out, bool wrap = false);  // a context of its own on that device (wsnark_group_create)
 void context_destroy(Context* C);
 // One no-op kernel per translation unit: the runtime loads a TU's code object when the first of its kernels is launched (7-12 ms for
 // msm.hip under ROCm 7.2) -- wsnark_init's helper thread launches these so that the first key load and proof do not pay for it
@@ -177,6 +178,7 @@ int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s
 // WSNARK_<name>, else dflt.  Read per call, so that ONE process can time several settings on the same resident key
 // (a gpurun box is charged by the minute; a fresh process per setting pays the key setup every time).
 long tuning_get(const char* name, long dflt);
+double tuning_get_real(const char* name, double dflt);      // fraction-capable (WSNARK_TABLE_MAX_GB=0.5); negatives read as 0
 void tuning_set(const char* name, long value);     // value == LONG_MIN: forget the override
 
 // ---- NTT (ntt.hip) ----

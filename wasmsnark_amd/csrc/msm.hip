@@ -927,7 +927,7 @@ static int msm_finish_t(MsmPending& P, typename H::Pt* out_host) {
     const MsmPlanInfo& I = P.info;
     if (I.n == 0) { *out_host = H::infinity(); P.active = false; return WS_OK; }
     struct Done { MsmPending& p; ~Done() { p.active = false; } } done{P};   // the slot is free again whatever happens
-    static const bool trace = tuning_get("TRACE", 0) == 1;
+    const bool trace = tuning_get("TRACE", 0) == 1;
     const auto t_wait = std::chrono::steady_clock::now();
     WS_HIP_CHECK(hipEventSynchronize(P.ev));
     const auto t_tail = std::chrono::steady_clock::now();

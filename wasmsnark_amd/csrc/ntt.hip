@@ -37,6 +37,7 @@ struct PassArgs {
     uint32_t np, kdig[4];
     const Fe* tw_small; uint32_t log_lmax;    // w_Lmax^j, j < Lmax/2 (direction-specific)
     const struct TwLimbs* tw_small29;         // the same table as nine 29-bit limbs per entry (radix-2^29 path: no unpacking per butterfly)
+    uint32_t lds_tw;                          // round 6: the L/2 small twiddles of this pass are staged in LDS behind the tile (L <= 256)
     const Fe* tw_lo; const Fe* tw_hi; uint32_t h;   // two-level w_N^e = tw_hi[e>>h] * tw_lo[e & mask]
     uint32_t apply_twiddle;
     const Fe* cs_lo; const Fe* cs_hi; uint32_t hc; uint32_t prescale;   // coset factors w_2N^i
@@ -144,6 +145,38 @@ template <class P> struct LdsTile<Field29<P>> {
     }
 };
 
+// The pass's own small twiddles w_L^j, j < L/2, staged in LDS once per workgroup (round 6; VERDICT r5 "what's weak" 1: every butterfly
+// pulled its twiddle from global memory as three 16-byte loads -- ~500 cycles of latency inside the butterfly loop against ~64 from
+// LDS).  Same three planes as the tile; lanes of a wavefront read few distinct entries (LDS broadcasts equal addresses).
+template <class F> struct LdsTw;
+template <class P> struct LdsTw<Field<P>> {
+    static constexpr uint32_t kBytes = 0;
+    __device__ __forceinline__ LdsTw(unsigned char*, uint32_t) {}
+    __device__ __forceinline__ void fill(const PassArgs&, uint32_t, uint32_t, uint32_t, uint32_t) {}
+    __device__ __forceinline__ Fe get(uint32_t) const { return Fe{}; }
+};
+template <class P> struct LdsTw<Field29<P>> {
+    static constexpr uint32_t kBytes = 36;
+    U4 *p0, *p1; uint32_t* p2;
+    __device__ __forceinline__ LdsTw(unsigned char* base, uint32_t half) : p0((U4*)base), p1((U4*)base + half), p2((uint32_t*)((U4*)base + 2 * half)) {}
+    __device__ __forceinline__ void fill(const PassArgs& A, uint32_t half, uint32_t shift, uint32_t tid, uint32_t nthr) {
+        for (uint32_t j = tid; j < half; j += nthr) {
+            const TwLimbs t = A.tw_small29[j << shift];
+            p0[j] = U4{t.v[0], t.v[1], t.v[2], t.v[3]};
+            p1[j] = U4{t.v[4], t.v[5], t.v[6], t.v[7]};
+            p2[j] = t.v[8];
+        }
+    }
+    __device__ __forceinline__ F29 get(uint32_t j) const {
+        const U4 a = p0[j], b = p1[j];
+        return F29{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, p2[j]}};
+    }
+};
+
+// (Round 6, measured and dropped: the same kernel on the inlined-product field -- 33 product bodies, 8 898 VALU instructions, a code
+//  object beyond the instruction cache -- ran the 2^20 passes in 73.8 us per launch against 74.0 with the product as a call:
+//  profiles/r06_ntt_experiments.txt.)
+
 // F = Field<FrParams> (saturated 4x64, values canonical, tables in the reference Montgomery form) or
 // Field29<Fr29Params> (values in [0,2p), internal domain R' = 2^261; the host scales every table by
 // 2^5 so that table products land in the internal domain, and the conversions from / to the
@@ -157,6 +190,10 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
     const uint32_t L = 1u << log_L, T = 1u << log_T, LT = L << log_T;
     LdsTile<F> tile(sm, LT);
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+    const bool lds_tw = A.lds_tw != 0;
+    const uint32_t tw_shift = A.log_lmax - log_L;               // table index of w_L^j = j << tw_shift
+    LdsTw<F> ltw(sm + (size_t)LT * LdsTile<F>::kBytes, L >> 1);
+    if (lds_tw) ltw.fill(A, L >> 1, tw_shift, tid, nthr);       // (visible after the load phase's barrier)
     const uint32_t w = blockIdx.x;
     // batched form: blockIdx.y selects one of several independent transforms stored back to back
     const Fe* __restrict__ src = A.in + ((uint64_t)blockIdx.y << A.log_n);
@@ -178,34 +215,53 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
     }
 
     // ---- load tile into LDS (element (j,t) at j*T + t), optional coset pre-scale ----
-    for (uint32_t idx = tid; idx < LT; idx += nthr) {
-        uint32_t j, t;
-        uint64_t g;
-        if (!A.is_last) {
-            t = idx & (T - 1); j = idx >> log_T;
-            g = base + ((uint64_t)j << A.log_S) + t;
-        } else {
-            j = idx & (L - 1); t = idx >> log_L;
-            g = ((uint64_t)(a0 + t) << A.log_S0) + ((uint64_t)mid << log_L) + j;
+    // Round 6: a lane has FOUR elements' loads in flight before it touches the first (the per-element loop waited out one HBM round
+    // trip per element, and a 2^20 pass is exactly one resident set of workgroups that all sit in their load phase at once).
+    for (uint32_t idx0 = tid; idx0 < LT; idx0 += 4 * nthr) {
+        Fe raw[4], raw2[4];
+        uint32_t slot[4];
+        uint64_t gs[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t idx = idx0 + u * nthr;
+            if (idx >= LT) break;
+            uint32_t j, t;
+            uint64_t g;
+            if (!A.is_last) {
+                t = idx & (T - 1); j = idx >> log_T;
+                g = base + ((uint64_t)j << A.log_S) + t;
+            } else {
+                j = idx & (L - 1); t = idx >> log_L;
+                g = ((uint64_t)(a0 + t) << A.log_S0) + ((uint64_t)mid << log_L) + j;
+            }
+            const Fe* from = &src[g];
+            if (MODE == NTT_GATHER && A.first) {
+                const uint64_t vec = blockIdx.y >> A.post_lr2, c2 = blockIdx.y & ((1u << A.post_lr2) - 1);
+                const uint64_t q = g >> A.post_lr1, r = g & (((uint64_t)1 << A.post_lr1) - 1);
+                from = &A.gather_in[((((q * A.post_k + vec) << A.post_lr1) + r) << A.post_lr2) + c2];
+            }
+            raw[u] = *from;
+            if (A.in2) raw2[u] = A.in2[g];
+            slot[u] = (j << log_T) + t;
+            gs[u] = g;
         }
-        const Fe* from = &src[g];
-        if (MODE == NTT_GATHER && A.first) {
-            const uint64_t vec = blockIdx.y >> A.post_lr2, c2 = blockIdx.y & ((1u << A.post_lr2) - 1);
-            const uint64_t q = g >> A.post_lr1, r = g & (((uint64_t)1 << A.post_lr1) - 1);
-            from = &A.gather_in[((((q * A.post_k + vec) << A.post_lr1) + r) << A.post_lr2) + c2];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (idx0 + u * nthr >= LT) break;
+            const uint64_t g = gs[u];
+            El v = F::unpack(raw[u]);
+            if (A.in2) {        // pass 0 of a product transform: v = in[g] * in2[g] (Montgomery product of the reference format)
+                v = F::mul(v, F::unpack(raw2[u]));
+                if (F::kInternalDomain && A.fold_in != 2) v = F::mul(v, F::unpack(A.k271));
+            } else if (A.prescale) {   // only ever set for pass 0, where storage index == input index
+                const uint32_t e = A.prescale == 2 ? ((uint32_t)g << A.pre_shift) + A.pre_row0 + (blockIdx.y & A.pre_row_mask) : (uint32_t)g;
+                El f = F::mul(F::unpack(A.cs_hi[e >> A.hc]), F::unpack(A.cs_lo[e & ((1u << A.hc) - 1)]));
+                v = F::mul(v, f);          // (radix-2^29: cs_lo carries the extra 2^5 => also converts the domain)
+            } else if (F::kInternalDomain && A.first && !A.fold_in) {
+                v = F::to_internal(raw[u]);
+            }
+            tile.put(slot[u], v);
         }
-        El v = F::unpack(*from);
-        if (A.in2) {        // pass 0 of a product transform: v = in[g] * in2[g] (Montgomery product of the reference format)
-            v = F::mul(v, F::unpack(A.in2[g]));
-            if (F::kInternalDomain && A.fold_in != 2) v = F::mul(v, F::unpack(A.k271));
-        } else if (A.prescale) {   // only ever set for pass 0, where storage index == input index
-            const uint32_t e = A.prescale == 2 ? ((uint32_t)g << A.pre_shift) + A.pre_row0 + (blockIdx.y & A.pre_row_mask) : (uint32_t)g;
-            El f = F::mul(F::unpack(A.cs_hi[e >> A.hc]), F::unpack(A.cs_lo[e & ((1u << A.hc) - 1)]));
-            v = F::mul(v, f);          // (radix-2^29: cs_lo carries the extra 2^5 => also converts the domain)
-        } else if (F::kInternalDomain && A.first && !A.fold_in) {
-            v = F::to_internal(*from);
-        }
-        tile.put((j << log_T) + t, v);
     }
     __syncthreads();
 
@@ -227,12 +283,17 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
             // stage hs: (j0, j0+h) with w_{2h}^{jl}, (j0+h/2, j0+3h/2) with w_{2h}^{jl+h/2}
             // (radix-2^29 field: tile values live in [0, 4p); sums are not corrected, only y0 -- and y1 of the last pair
             // of stages -- are folded back from [0, 16p); differences go into products uncorrected: field29.h add_nr)
-            El s0 = F::add_nr(x0, x2), d0 = F::mul(F::sub_weak4(x0, x2), SmallTw<F>::get(A, jl << sh_hi));
-            El s1 = F::add_nr(x1, x3), d1 = F::mul(F::sub_weak4(x1, x3), SmallTw<F>::get(A, (jl + (1u << (hs - 1))) << sh_hi));
+            // w_{2h}^{jl}, w_{2h}^{jl + h/2}, w_h^{jl}: out of LDS (index j of w_L^j) or the global table (index j << tw_shift)
+            const uint32_t ia = jl << (sh_hi - tw_shift), ib = (jl + (1u << (hs - 1))) << (sh_hi - tw_shift);
+            const El wa = lds_tw ? ltw.get(ia) : SmallTw<F>::get(A, ia << tw_shift);
+            const El wb = lds_tw ? ltw.get(ib) : SmallTw<F>::get(A, ib << tw_shift);
+            El s0 = F::add_nr(x0, x2), d0 = F::mul(F::sub_weak4(x0, x2), wa);
+            El s1 = F::add_nr(x1, x3), d1 = F::mul(F::sub_weak4(x1, x3), wb);
             // stage hs-1: (j0, j0+h/2) and (j0+h, j0+3h/2), both with w_{h}^{jl}
             El y0 = F::fold16(F::add_nr(s0, s1)), y2 = F::add_nr(d0, d1), y1, y3;
             if (hs > 1) {
-                const El w = SmallTw<F>::get(A, jl << (sh_hi + 1));
+                const uint32_t ic = jl << (sh_hi + 1 - tw_shift);
+                const El w = lds_tw ? ltw.get(ic) : SmallTw<F>::get(A, ic << tw_shift);
                 y1 = F::mul(F::sub_weak8(s0, s1), w);
                 y3 = F::mul(F::sub_weak(d0, d1), w);
             } else {
@@ -260,18 +321,32 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(PassArgs A) {
     // ---- write out ----
     if (!A.is_last) {
         const uint32_t log_c = A.log_n - log_L - A.log_S;   // c = N / (L*S)
-        for (uint32_t idx = tid; idx < LT; idx += nthr) {
-            const uint32_t t = idx & (T - 1), kk = idx >> log_T;
-            const uint32_t r = __brev(kk) >> (32 - log_L);
-            El v = tile.get((r << log_T) + t);
-            if (A.tw_full) {
-                v = F::mul(v, F::unpack(A.tw_full[((uint64_t)kk << A.log_S) + lo0 + t]));
-            } else if (A.apply_twiddle) {
-                const uint32_t e = (kk * (lo0 + t)) << log_c;
-                El f = F::mul(F::unpack(A.tw_hi[e >> A.h]), F::unpack(A.tw_lo[e & ((1u << A.h) - 1)]));
-                v = F::mul(v, f);
+        for (uint32_t idx0 = tid; idx0 < LT; idx0 += 4 * nthr) {
+            Fe twf[4];
+            if (A.tw_full) {        // the four table entries' loads in flight before the first product (round 6)
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t idx = idx0 + u * nthr;
+                    if (idx >= LT) break;
+                    twf[u] = A.tw_full[((uint64_t)(idx >> log_T) << A.log_S) + lo0 + (idx & (T - 1))];
+                }
             }
-            dst[base + ((uint64_t)kk << A.log_S) + t] = F::pack(v);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t idx = idx0 + u * nthr;
+                if (idx >= LT) break;
+                const uint32_t t = idx & (T - 1), kk = idx >> log_T;
+                const uint32_t r = __brev(kk) >> (32 - log_L);
+                El v = tile.get((r << log_T) + t);
+                if (A.tw_full) {
+                    v = F::mul(v, F::unpack(twf[u]));
+                } else if (A.apply_twiddle) {
+                    const uint32_t e = (kk * (lo0 + t)) << log_c;
+                    El f = F::mul(F::unpack(A.tw_hi[e >> A.h]), F::unpack(A.tw_lo[e & ((1u << A.h) - 1)]));
+                    v = F::mul(v, f);
+                }
+                dst[base + ((uint64_t)kk << A.log_S) + t] = F::pack(v);
+            }
         }
     } else {
         // digit-reverse the middle digits k_1..k_{np-2} of this tile
@@ -621,7 +696,9 @@ int ntt_run(Lane& L, const Fe* d_src, const Fe* d_in2, Fe* d_data, const Fe* com
         const size_t elems = (size_t)1 << (A.log_L + log_T);
         C->timer.begin(last ? "ntt_pass_last" : "ntt_pass", s);
         if (P->field29) {
-            const size_t smem = elems * LdsTile<Fr29>::kBytes;
+            // round 6: the pass's L/2 small twiddles behind the tile (<= 128 entries = 4.5 KiB: four workgroups per CU still fit)
+            A.lds_tw = (A.log_L >= 2 && A.log_L <= 8 && elems % 4 == 0 && !tuning_get("NTT_GLOBAL_TW", 0)) ? 1 : 0;
+            const size_t smem = elems * LdsTile<Fr29>::kBytes + (A.lds_tw ? ((size_t)1 << (A.log_L - 1)) * LdsTw<Fr29>::kBytes : 0);
             if (!C->ntt_attr_set) {   // (per device; two lanes may both set it once: same value)  2048-element tiles would need 72 KiB of dynamic LDS (> the 64 KiB default cap)
                 WS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<Fr29, NTT_PLAIN>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * 36));

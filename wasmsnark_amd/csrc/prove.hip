@@ -149,7 +149,7 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
         if (which != 0) {
             const uint32_t cw = (which == 1 || which == 3) ? msm_table_window(nl ? nl : 1) : 0, ch = (which == 1 || which == 2) ? msm_table_window(hl ? hl : 1) : 0;
             const uint64_t bytes = (uint64_t)nl * 320 * msm_table_rows(cw) + (uint64_t)hl * 64 * msm_table_rows(ch);
-            const uint64_t cap = (uint64_t)tuning_get("TABLE_MAX_GB", 160) << 30;
+            const uint64_t cap = (uint64_t)(tuning_get_real("TABLE_MAX_GB", 160.0) * (double)((uint64_t)1 << 30));   // GB, fractions allowed (0.5 = 512 MiB)
             size_t free_b = 0, total_b = 0;
             WS_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
             if (bytes <= cap && bytes <= free_b / 2 && (uint64_t)msm_table_rows(cw) * nl < ((uint64_t)1 << 31) &&
