@@ -239,14 +239,16 @@ def _latest_profile(pattern):
 
 
 def ntt_issue_note():
-    """The transform passes' share of the VALU issue slots from the newest committed SQ-counter summary."""
-    f = _latest_profile("s*_pmc_sq_counters.json")
+    """The transform passes' issue floor by instruction class over their duration, from the newest committed SQ-counter summary."""
+    f = _latest_profile("*_pmc_sq_counters.json")
     try:
         d = json.load(open(f))
         k = d.get("kernels", d)["ntt_pass_kernel"]
-        return "%.2f of the VALU issue slots, profiles/%s" % (k["valu_issue_frac"], os.path.basename(f))
+        if "issue_floor_frac" in k:
+            return "issue floor by instruction class / duration = %.2f, profiles/%s" % (k["issue_floor_frac"], os.path.basename(f))
+        return "%.2f of the VALU slots under the flat 4-cycle model of rounds 3-5, profiles/%s" % (k["valu_issue_frac"], os.path.basename(f))
     except Exception:  # noqa: BLE001
-        return "0.80-0.83 of the VALU issue slots in the committed SQ-counter summaries under profiles/"
+        return "about 0.6-0.7 of their issue floor by instruction class (profiles/r06_ntt_experiments.txt)"
 
 
 def rocprof_kernel_mean(csv_path, must_contain, must_not_contain=()):
@@ -287,29 +289,48 @@ def rocprof_citation(alg_bytes):
     return out or None
 
 
-def proof_issue_roofline(ms_per_proof, clock_hz, n_simd=1024):
-    """Whole-proof VALU-issue roofline: the wave-instructions one proof executes (rocprofv3 --pmc SQ_INSTS_VALU over exactly P
-    proofs, committed summary) x 4 cycles each / 1024 SIMD16s = the cycles a chip that did nothing but issue them would need,
-    over the cycles one measured proof takes.  The instruction count is a property of the workload and the build (same circuit,
-    same kernels), the time is this run's."""
+def proof_issue_roofline(ms_per_proof, rates):
+    """Whole-proof VALU-issue roofline BY INSTRUCTION CLASS (round 6; tools/issue_model.py): for every kernel of a proof its DYNAMIC
+    wave-instruction count (rocprofv3 --pmc SQ_INSTS_VALU over exactly P proofs, committed summary) x its STATIC class mix
+    (profiles/rNN_isa_classes.json, tools/isa_histogram.py) / the class rates THIS run measured on THIS box (wsnark_peak_probe 6..,
+    `issue_classes`).  floor = the time a chip that did nothing but issue the proof's instruction stream would need, whatever the
+    schedule; frac = floor / one measured proof.  No clock and no "4 cycles per instruction" enter (rounds 3-5 priced every VALU
+    instruction at 4 cycles, under which mul_base_kernel read 1.34 of the chip: plain 32-bit instructions issue in 2)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import issue_model
     f = _latest_profile("*proof_issue_budget.json")
-    if not f:
+    classes = issue_model.load_classes()
+    if not f or not classes or not rates:
         return None
     try:
         b = json.load(open(f))
         insts = float(b["valu_insts_per_proof"])
     except Exception:  # noqa: BLE001
         return None
-    cycles = ms_per_proof / 1e3 * clock_hz
-    floor_ms = 4.0 * insts / n_simd / clock_hz * 1e3
-    top = sorted(((k, v["valu_insts_per_proof"]) for k, v in b.get("kernels", {}).items()), key=lambda kv: -kv[1])[:6]
-    return {"bound": "valu-issue", "achieved": round(4.0 * insts / n_simd / 1e6, 3), "peak": round(cycles / 1e6, 3), "unit": "Mcycles per proof",
-            "frac": round(4.0 * insts / n_simd / cycles, 4), "valu_wave_insts_per_proof": int(insts), "issue_floor_ms": round(floor_ms, 3),
-            "ms_per_proof": round(ms_per_proof, 3), "clock_GHz": round(clock_hz / 1e9, 3), "n_simd": n_simd,
-            "share_of_issue_by_kernel": {k: round(v / insts, 4) for k, v in top},
-            "source": "profiles/%s (%s)" % (os.path.basename(f), b.get("how", "")),
-            "note": "achieved = 4 x SQ_INSTS_VALU / 1024 SIMDs (the issue cycles of one proof's instruction stream); peak = cycles of one "
-                    "measured proof at the device's shader clock; frac = the share of the chip's VALU issue slots a whole proof uses"}
+    per_kernel, floor_s, unclassified = {}, 0.0, 0.0
+    for k, v in b.get("kernels", {}).items():
+        fs, how = issue_model.kernel_floor_s(k, float(v["valu_insts_per_proof"]), classes, rates)
+        floor_s += fs
+        per_kernel[k] = fs
+        if how.startswith("unclassified"):
+            unclassified += float(v["valu_insts_per_proof"])
+    top = sorted(per_kernel.items(), key=lambda kv: -kv[1])[:8]
+    cyc, clock = issue_model.equivalent_cycles(rates)
+    return {"bound": "valu-issue (by instruction class)", "achieved": round(floor_s * 1e3, 3), "peak": round(ms_per_proof, 3), "unit": "ms per proof",
+            "frac": round(floor_s * 1e3 / ms_per_proof, 4), "valu_wave_insts_per_proof": int(insts), "issue_floor_ms": round(floor_s * 1e3, 3),
+            "ms_per_proof": round(ms_per_proof, 3),
+            "issue_floor_ms_by_kernel": {k: round(v * 1e3, 4) for k, v in top},
+            "share_of_instructions_unclassified": round(unclassified / insts, 5) if insts else None,
+            "class_rates_G_lane_ops_per_s": {k: rates.get(v) for k, v in classes["probe_of_class"].items()},
+            "class_cycles_per_wave_instruction_if_v_add_u32_is_2": {k: cyc.get(v) for k, v in classes["probe_of_class"].items()},
+            "clock_GHz_implied": clock,
+            "flat_4_cycle_model_of_rounds_3_to_5": {"issue_floor_ms": round(4.0 * insts / 1024 / 2.4e9 * 1e3, 3),
+                                                     "frac": round(4.0 * insts / 1024 / 2.4e9 * 1e3 / ms_per_proof, 4),
+                                                     "note": "every VALU instruction at 4 cycles, 2.4 GHz: too high a floor (kept for comparison with BENCH_r03..r05)"},
+            "source": "instructions: profiles/%s (%s); class mix: profiles/%s; class rates: this run (issue_classes)" % (
+                os.path.basename(f), b.get("how", ""), os.path.basename(classes["_path"])),
+            "note": "achieved = sum over kernels of SQ_INSTS_VALU x 64 x sum(class share / class rate): the issue time of one proof's "
+                    "instruction stream; peak = one measured proof; frac = the share of the chip's VALU issue capacity a whole proof uses"}
 
 
 def measure_peaks(bn):
@@ -325,6 +346,12 @@ def measure_peaks(bn):
         except Exception as e:  # noqa: BLE001
             out[name] = None
             out["error"] = repr(e)
+    try:      # VALU issue rate per instruction class (wsnark_peak_probe 6..28, ~10 ms each): what prices roofline_proof
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import issue_probe
+        out["issue_classes"] = issue_probe.measure(bn, reps=2)
+    except Exception as e:  # noqa: BLE001
+        out["issue_classes_error"] = repr(e)
     return out
 
 
@@ -459,7 +486,7 @@ def bench_prove(ctx):
     kt_all = bn.lib.timing_report()
     # the dominant kernel ALONE, and a proof with nothing overlapped: a few more proofs on ONE queue (WSNARK_PROVE_OVERLAP=0 through the
     # library's A/B switch), HIP events around the accumulations only.  (single GPU: the N > 1 modes bring their own schedule)
-    alone_ms = serial_ms = None
+    alone_ms = serial_ms = kt_serial = None
     if world == 1 and not args.no_alone_pass:
         bn.lib.tune("PROVE_OVERLAP", 0)
         try:
@@ -476,6 +503,16 @@ def bench_prove(ctx):
             bn.lib.c.wsnark_timing_enable(0)
             ka = bn.lib.timing_report().get("msm_accumulate_g1")
             alone_ms = ka[0] / ka[1] if ka and ka[1] else None
+            # every kernel ALONE, by HIP events on the one queue: the per-kernel means the bench line quotes (they add up to at most
+            # one serialised proof; the rocprofv3 summary of WSNARK_PROVE_OVERLAP=0 must agree with them)
+            bn.lib.c.wsnark_timing_reset()
+            bn.lib.c.wsnark_timing_enable(1)
+            n_k = 4
+            for _ in range(n_k):
+                step()
+            torch.cuda.synchronize()
+            bn.lib.c.wsnark_timing_enable(0)
+            kt_serial = kernel_ms(bn.lib.timing_report(), n_k)
         finally:
             bn.lib.tune("PROVE_OVERLAP", None)
     # the drop-in call itself: genZKSnarkProof(witness, provingKey) hands over a HOST witness (32 B x nVars of H2D inside
@@ -513,10 +550,6 @@ def bench_prove(ctx):
         pairs = (3 * nv + dom) / 4.0                   # msm_accumulate_g1 launches per proof: A, B1, C (nVars pairs) and H (domain pairs)
         shard_info = None
     hbm, alu = rooflines(kt, "msm_accumulate_g1", pairs, W_own, 96, 10, peak, alone_ms=alone_ms, cite_rocprof=(world == 1 and logd == 20))
-    try:
-        clock_hz = float(torch.cuda.get_device_properties(dev).clock_rate) * 1e3
-    except Exception:  # noqa: BLE001
-        clock_hz = 2.4e9
     g2 = kt.get("msm_accumulate_g2")
     # algorithmic bytes of one proof
     alg_bytes = 32 * nv + 8 * nv + 36 * info["nnz_A_plus_B"] + 64 * nv * 2 + 128 * nv + 64 * (nv - circ.n_public - 1) + 64 * dom + 64 * 6 * dom
@@ -551,10 +584,15 @@ def bench_prove(ctx):
            "prove_algorithmic_bytes": int(alg_bytes), "prove_algorithmic_GBps": round(alg_bytes / (ms / 1e3) / 1e9, 1),
            "prove_hbm_frac": round(alg_bytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
            "roofline": hbm, "roofline_int_alu": alu,
-           "roofline_proof": proof_issue_roofline(ms, clock_hz) if (world == 1 and logd == 20 and args.circuit == "columns") else None,
+           "roofline_proof": proof_issue_roofline(ms, ((peak or {}).get("issue_classes") or {}).get("G_lane_ops_per_s")) if (world == 1 and logd == 20 and args.circuit == "columns") else None,
            "serialised_one_queue_ms_per_proof": round(serial_ms, 3) if serial_ms else None,
            "msm_accumulate_g2_avg_launch_ms": round(g2[0] / g2[1], 4) if g2 and g2[1] else None,
-           "kernel_ms_per_proof": kernel_ms(kt_all, 2),
+           "kernel_ms_per_proof": None if kt_serial is None else dict(kt_serial, _sum=round(sum(kt_serial.values()), 3),
+                                                                      _what="each kernel ALONE: HIP events on the one queue of WSNARK_PROVE_OVERLAP=0 proofs (4 proofs right "
+                                                                            "after the timed region); _sum <= serialised_one_queue_ms_per_proof + the events' own cost"),
+           "kernel_event_spans_two_queues_ms_per_proof": dict(kernel_ms(kt_all, 2), _what="event-bracket SPANS on the launching queue under the shipped two-queue "
+                                                              "schedule: a span contains whatever the other queue's kernels took from the chip meanwhile -- NOT kernel times, "
+                                                              "they add up to more than a proof"),
            "reference_wasm_8_workers_prove_2p20_s": {"value": REF_WASM_PROVE_2P20_S, "where": "BASELINE.md: survey container (8 vCPU), NOT this box: the reference may not travel"}}
     want_extras = set() if (args.no_extras or world > 1) else set(x for x in args.extras.split(",") if x)
     extras = {}

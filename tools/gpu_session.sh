@@ -11,6 +11,8 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
   nproc; free -g | head -2; node --version 2>&1; python --version; rocm-smi --showid 2>/dev/null | grep -c "GPU\[" 
 } > "$O/env.log" 2>&1
 skip() { [[ " $SKIP " == *" $1 "* ]]; }
+# VALU issue rate per instruction class on THIS box (wsnark_peak_probe 6..28): prices the issue floors of the PMC summaries below
+timeout 300 python tools/issue_probe.py 3 > "$O/issue_classes.json" 2>> "$O/env.log"
 if ! skip tests; then
   timeout 2400 python -m pytest tests -m gpu -q --timeout 1200 -p no:cacheprovider --durations=12 ${PYTEST_K:+-k "$PYTEST_K"} > "$O/pytest_gpu.txt" 2>&1
   echo "pytest rc=$?" >> "$O/env.log"
@@ -40,7 +42,7 @@ fi
 if ! skip issue; then
   ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/$O/issue/pmc_issue" -o pmc -- python "$GRAFT_REPO_ROOT/tools/proof_counters.py" 20 4 ) > "$O/issue.log" 2>&1
   echo "pmc issue rc=$?" >> "$O/env.log"
-  python tools/pmc_proof_budget.py "$O/issue" 4 > "$O/proof_issue_budget.json" 2>> "$O/env.log"
+  python tools/pmc_proof_budget.py "$O/issue" 4 --rates "$O/issue_classes.json" > "$O/proof_issue_budget.json" 2>> "$O/env.log"
   find "$O/issue" -name "*.csv" -size +2M -delete 2>/dev/null
 fi
 # HBM traffic counters: separate --pmc passes, kernel-trace only (never combined with sys/hip/hsa traces)
@@ -60,7 +62,7 @@ if ! skip sq; then
     ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --pmc $GROUP --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/$O/sq/pmc_sq$I" -o pmc -- python "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --extras msm,ntt ) > "$O/pmc_sq$I.log" 2>&1
     echo "pmc sq$I rc=$?" >> "$O/env.log"
   done
-  python tools/pmc_counters.py "$O/sq" > "$O/pmc_sq_counters.json" 2>> "$O/env.log"
+  python tools/pmc_counters.py "$O/sq" --rates "$O/issue_classes.json" > "$O/pmc_sq_counters.json" 2>> "$O/env.log"
   find "$O/sq" -name "*kernel_trace.csv" -size +2M -delete 2>/dev/null
 fi
 # FETCH_SIZE / WRITE_SIZE calibration on known byte counts (64-B gathers out of a 1 GiB table; a 16-B-per-lane stream)

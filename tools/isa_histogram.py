@@ -1,10 +1,25 @@
-"""Per-kernel VALU opcode histogram of the shipped device code, by ISSUE CLASS (no GPU needed).
+"""Per-kernel VALU instruction mix of the shipped device code, by ISSUE CLASS (no GPU needed).
 
-hipcc -O3 --offload-arch=gfx950 --cuda-device-only -S on every .hip source with the flags of wasmsnark_amd/csrc/Makefile, then
-the instructions between a kernel's label and its s_endpgm are counted.  The counts are STATIC (an instruction inside a loop counts
-once); the hot kernels of this library are straight-line bodies inside one loop, so the static mix of a kernel is the mix of what
-it issues -- bench.py / tools/pmc_proof_budget.py multiply that mix by the DYNAMIC total (SQ_INSTS_VALU) and by each class's
-measured cost (wsnark_peak_probe 6.., `issue_classes` in the bench line).
+hipcc -O3 --offload-arch=gfx950 --cuda-device-only -S on every .hip source with the flags of wasmsnark_amd/csrc/Makefile; the
+instructions between a function's label and its end are classified by what the issue-class probes (wsnark_peak_probe 6.., tools/
+issue_probe.py) showed to decide a wave64 VALU instruction's cost on gfx950 -- not its mnemonic alone but its OPERANDS:
+
+  mad64      v_mad_u64_u32 / v_mad_i64_i32                                   (~3.7 cycles per wave-instruction)
+  mul32      v_mul_lo / v_mul_hi                                             (~3.7)
+  wide64     64-bit shifts, adds and moves                                   (~3.7)
+  carry      v_add_co / v_addc_co / v_sub_co / ...  (carry in or out of an SGPR pair)   (~3.7 each)
+  compare    v_cmp* (writes vcc or an SGPR pair)                             (~3.7)
+  sgpr_src   any other VALU instruction with an SGPR source operand          (~3.7: v_and_b32 v, s, v is TWICE v_and_b32 v, v, v)
+  src3       any other VALU instruction with three VGPR sources (v_add3_u32, v_or3_b32, v_bfi_b32, v_alignbit_b32 ...)   (~3.7)
+  dpp        DPP / SDWA / lane-crossing forms                                (~3.7)
+  fast       everything else: one or two VGPR sources, inline constants or a 32-bit literal, VOP2 or VOP3 encoding alike   (2.0)
+  select_run v_cndmask_b32_e32 in runs of three or more (the members beyond the second): ~20 cycles each back to back on a standing
+             vcc, 2 when other instructions sit between them -- counted apart so that a kernel with long runs shows it
+
+The counts are STATIC (an instruction inside a loop counts once).  A kernel's non-inlined callees (the Montgomery products of the
+transform and tail kernels: `s_swappc_b64`) are added once per call site, so the mix is that of a stream in which every static
+instruction of the body runs equally often -- what the hot loops of this library are.  bench.py / tools/pmc_counters.py /
+tools/pmc_proof_budget.py multiply the mix by the DYNAMIC total (SQ_INSTS_VALU) and divide by each class's measured rate.
 
 Usage: python tools/isa_histogram.py [--json] > profiles/rNN_isa_classes.{md,json}"""
 import json
@@ -19,33 +34,43 @@ CSRC = os.path.join(ROOT, "wasmsnark_amd", "csrc")
 SRCS = ["ntt.hip", "msm.hip", "calch.hip", "dist.hip", "fixedbase.hip", "selftest.hip"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-Wno-unused-function", "-Wno-unused-command-line-argument", "-S"]
 
-# issue classes: each has a probe in selftest.hip (wsnark_peak_probe) that measures its wave-instruction rate on the box
-CLASSES = ["mad64", "mul32", "shift64", "add64c", "bit32", "mov", "cmp_sel", "dpp", "other"]
+CLASSES = ["mad64", "mul32", "wide64", "carry", "compare", "sgpr_src", "src3", "dpp", "fast", "select_run"]
+# class -> the probe of tools/issue_probe.py whose rate prices it
+PROBE_OF = {"mad64": "mad64", "mul32": "mul32", "wide64": "shift64", "carry": "add64c", "compare": "compare", "sgpr_src": "and_sgpr",
+            "src3": "vop3_3src", "dpp": "dpp", "fast": "bit32", "select_run": "select"}
+
+_WIDE = ("v_lshrrev_b64", "v_lshlrev_b64", "v_ashrrev_i64", "v_lshl_add_u64", "v_add_u64", "v_mov_b64", "v_and_b64", "v_or_b64", "v_xor_b64")
+_CARRY = ("v_add_co_u32", "v_addc_co_u32", "v_sub_co_u32", "v_subb_co_u32", "v_subrev_co_u32", "v_subbrev_co_u32")
+_MUL = ("v_mul_lo_u32", "v_mul_hi_u32", "v_mul_hi_i32", "v_mul_lo_i32", "v_mad_u32_u24", "v_mul_u32_u24", "v_mul_hi_u32_u24", "v_mad_u32_u16", "v_mul_f", "v_fma", "v_rcp", "v_trunc", "v_fmamk", "v_cvt")
+_LANE = ("v_readlane", "v_readfirstlane", "v_writelane", "v_permlane", "v_bpermute", "ds_bpermute", "ds_swizzle")
 
 
-def classify(op):
-    """VALU mnemonic -> issue class (the probe that prices it)."""
-    base = op.split("_e32")[0].split("_e64")[0]
-    if base.endswith("_dpp") or "_dpp" in op or base.startswith(("v_readlane", "v_readfirstlane", "v_writelane", "v_permlane", "v_bpermute")):
-        return "dpp"
-    if base.startswith(("v_mad_u64_u32", "v_mad_i64_i32")):
+def classify(line):
+    """one assembly line (mnemonic + operands) of a VALU instruction -> issue class"""
+    parts = line.strip().split(None, 1)
+    op = parts[0]
+    ops = (parts[1] if len(parts) > 1 else "").split(";")[0]
+    if op.startswith(("v_mad_u64_u32", "v_mad_i64_i32")):
         return "mad64"
-    if base.startswith(("v_mul_lo_u32", "v_mul_hi_u32", "v_mul_hi_i32", "v_mul_lo_i32", "v_mad_u32_u24", "v_mul_u32_u24", "v_mad_u32_u16", "v_mul_hi_u32_u24")):
+    if op.startswith(_MUL):
         return "mul32"
-    if base.startswith(("v_lshrrev_b64", "v_lshlrev_b64", "v_ashrrev_i64", "v_lshl_add_u64", "v_add_u64")):
-        return "shift64"
-    if base.startswith(("v_add_co_u32", "v_addc_co_u32", "v_sub_co_u32", "v_subb_co_u32", "v_subrev_co_u32", "v_subbrev_co_u32")):
-        return "add64c"
-    if base.startswith(("v_mov_b32", "v_mov_b64", "v_accvgpr", "v_swap")):
-        return "mov"
-    if base.startswith(("v_cmp", "v_cndmask", "v_cmpx")):
-        return "cmp_sel"
-    if base.startswith(("v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_lshrrev_b32", "v_lshlrev_b32",
-                        "v_ashrrev_i32", "v_and_or_b32", "v_lshl_or_b32", "v_lshl_add_u32", "v_add_lshl_u32", "v_add3_u32", "v_or3_b32", "v_alignbit_b32",
-                        "v_bfe_u32", "v_bfe_i32", "v_bfi_b32", "v_xad_u32", "v_min_u32", "v_max_u32", "v_min_i32", "v_max_i32", "v_bfm_b32", "v_alignbyte",
-                        "v_perm_b32", "v_mbcnt", "v_ffbh", "v_ffbl", "v_bcnt", "v_sub_i32", "v_add_i32", "v_cvt", "v_lshl_add", "v_add_nc", "v_xnor")):
-        return "bit32"
-    return "other"
+    if op.startswith(_WIDE):
+        return "wide64"
+    if op.startswith(_CARRY):
+        return "carry"
+    if op.startswith("v_cmp"):
+        return "compare"
+    if "_dpp" in op or "_sdwa" in op or "quad_perm" in ops or "row_" in ops or op.startswith(_LANE):
+        return "dpp"
+    toks = [t.strip() for t in ops.split(",")]
+    srcs = toks[1:]
+    n_v = sum(1 for t in srcs if re.match(r"^-?\|?v(\d+|\[)", t))
+    n_s = sum(1 for t in srcs if re.match(r"^s(\d+|\[)", t) or t in ("vcc_lo", "vcc_hi", "m0", "exec_lo", "exec_hi"))
+    if op.startswith("v_cndmask_b32_e64") or n_s:
+        return "sgpr_src"
+    if n_v >= 3:
+        return "src3"
+    return "fast"
 
 
 def demangle(names):
@@ -62,32 +87,59 @@ def short(name):
     return name
 
 
+def pmc_name(demangled):
+    """the name tools/pmc_counters.py / pmc_proof_budget.py give the kernel's dispatches"""
+    m = re.search(r"wsnark::([A-Za-z0-9_]+)", demangled)
+    s = m.group(1) if m else demangled.split("(")[0].replace("void ", "").strip()[:60]
+    head = demangled.split("(")[0]
+    if m and ("Fp2" in demangled or "Fe2T" in demangled):
+        s += "_g2"
+    del head
+    return s
+
+
 def one(src):
     out = "/tmp/isa_hist_%s.s" % src.replace(".", "_")
     subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + [src, "-o", out], cwd=CSRC, check=True, capture_output=True)
     txt = open(out).read()
     kernels = set(re.findall(r"^\s*\.amdhsa_kernel\s+(\S+)", txt, re.M))
-    rows = []
+    rows = {}
     for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)\n\.Lfunc_end", txt, re.S | re.M):
         name, body = m.group(1), m.group(2)
-        ins = [l.split()[0] for l in body.splitlines() if l.startswith("\t") and l.split() and not l.strip().startswith((".", ";"))]
+        lines = [l for l in body.splitlines() if l.startswith("\t") and l.split() and not l.strip().startswith((".", ";"))]
         h = dict.fromkeys(CLASSES, 0)
-        ops = {}
-        n_valu = 0
-        for i in ins:
-            if not i.startswith("v_"):
+        run = 0
+        for l in lines:
+            op = l.split()[0]
+            if not op.startswith("v_"):
+                if not op.startswith(("s_nop", "s_waitcnt")):
+                    run = 0 if not op.startswith("s_") else run      # (scalar instructions issue from another port: a run survives them)
                 continue
-            n_valu += 1
-            c = classify(i)
-            h[c] += 1
-            if c == "other":
-                ops[i] = ops.get(i, 0) + 1
-        rows.append({"src": src, "name": name, "kernel": name in kernels, "valu": n_valu, "all": len(ins),
-                     "salu": sum(1 for i in ins if i.startswith("s_") and not i.startswith(("s_waitcnt", "s_nop"))),
-                     "s_nop": sum(1 for i in ins if i.startswith("s_nop")),
-                     "mem": sum(1 for i in ins if i.startswith(("global_", "buffer_", "flat_", "scratch_"))),
-                     "lds": sum(1 for i in ins if i.startswith("ds_")), "classes": h, "other_ops": ops})
-    return rows
+            if op.startswith("v_cndmask_b32_e32"):
+                run += 1
+                h["select_run" if run >= 3 else "fast"] += 1
+                continue
+            run = 0
+            h[classify(l)] += 1
+        ops = [l.split()[0] for l in lines]
+        callees = re.findall(r"(_ZN6wsnark\w+)@rel32@lo", body)
+        rows[name] = {"src": src, "name": name, "kernel": name in kernels, "classes": h, "valu": sum(h.values()), "all": len(ops),
+                      "calls": sum(1 for o in ops if o.startswith("s_swappc")), "callees": callees,
+                      "salu": sum(1 for o in ops if o.startswith("s_") and not o.startswith(("s_waitcnt", "s_nop"))),
+                      "s_nop": sum(1 for o in ops if o.startswith("s_nop")),
+                      "mem": sum(1 for o in ops if o.startswith(("global_", "buffer_", "flat_", "scratch_"))),
+                      "lds": sum(1 for o in ops if o.startswith("ds_"))}
+    # a kernel's calls: dealt to the callees it references, in proportion to the references (one reference may serve several sites)
+    for r in rows.values():
+        r["with_callees"] = dict(r["classes"])
+        refs = [c for c in r["callees"] if c in rows and not rows[c]["kernel"]]
+        if r["calls"] and refs:
+            for c in set(refs):
+                share = r["calls"] * refs.count(c) / len(refs)
+                for k, v in rows[c]["classes"].items():
+                    r["with_callees"][k] += v * share
+        r["valu_with_callees"] = sum(r["with_callees"].values())
+    return list(rows.values())
 
 
 def histogram():
@@ -95,22 +147,40 @@ def histogram():
         rows = [r for rs in ex.map(one, SRCS) for r in rs]
     dm = demangle([r["name"] for r in rows])
     for r in rows:
-        r["short"] = short(dm.get(r["name"], r["name"]))
+        r["demangled"] = dm.get(r["name"], r["name"])
+        r["short"] = short(r["demangled"])
+        r["pmc_name"] = pmc_name(r["demangled"])
     return rows
+
+
+def as_json(rows):
+    """{pmc kernel name: {"mix": {class: share of the VALU stream}, ...}}: the first instantiation seen stands for a name"""
+    out = {}
+    for r in rows:
+        if not r["kernel"] or not r["valu_with_callees"]:
+            continue
+        tot = float(r["valu_with_callees"])
+        out.setdefault(r["pmc_name"], {"function": r["short"], "src": r["src"], "static_valu": r["valu"], "static_valu_with_callees": round(tot, 1),
+                                       "call_sites": r["calls"], "mix": {k: round(v / tot, 5) for k, v in r["with_callees"].items()},
+                                       "salu": r["salu"], "s_nop": r["s_nop"], "mem": r["mem"], "lds": r["lds"]})
+    return {"how": "tools/isa_histogram.py: static VALU mix per kernel by issue class, non-inlined callees added once per call site",
+            "classes": CLASSES, "probe_of_class": PROBE_OF, "kernels": out}
 
 
 def main():
     rows = histogram()
     if "--json" in sys.argv:
-        print(json.dumps({r["short"]: {k: r[k] for k in ("src", "kernel", "valu", "all", "salu", "s_nop", "mem", "lds", "classes", "other_ops")} for r in rows}, indent=1))
+        print(json.dumps(as_json(rows), indent=1))
         return
-    print("Static VALU opcode mix per device function, by issue class (tools/isa_histogram.py; functions that are not kernels are the")
-    print("non-inlined product bodies the kernels call).  `other` lists its opcodes.\n")
-    print("| source | function | kernel | VALU | " + " | ".join(CLASSES) + " | SALU | s_nop | mem | LDS | other opcodes |")
-    print("|---|---|---|---|" + "---|" * (len(CLASSES) + 5))
+    print("Static VALU instruction mix per device function, by issue class (tools/isa_histogram.py -- the classes and what decides them")
+    print("are in that file's header).  `calls` = non-inlined product calls in the body; the last columns add the callees once per call site.\n")
+    print("| source | function | kernel | VALU | " + " | ".join(CLASSES) + " | calls | VALU with callees | slow share with callees | SALU | s_nop | mem | LDS |")
+    print("|---|---|---|---|" + "---|" * (len(CLASSES) + 7))
     for r in rows:
+        tot = r["valu_with_callees"] or 1
+        slow = 1.0 - (r["with_callees"]["fast"]) / tot
         print("| %s | `%s` | %s | %d | " % (r["src"], r["short"], "yes" if r["kernel"] else "", r["valu"]) + " | ".join(str(r["classes"][c]) for c in CLASSES)
-              + " | %d | %d | %d | %d | %s |" % (r["salu"], r["s_nop"], r["mem"], r["lds"], " ".join("%s:%d" % kv for kv in sorted(r["other_ops"].items()))))
+              + " | %d | %d | %.3f | %d | %d | %d | %d |" % (r["calls"], round(r["valu_with_callees"]), slow, r["salu"], r["s_nop"], r["mem"], r["lds"]))
 
 
 if __name__ == "__main__":

@@ -3,11 +3,14 @@
   tools/pmc_proof_budget.py <dir with *counter_collection.csv> <proofs between the markers> [n_simd] [n_xcd]
 Only the dispatches BETWEEN the two groups of marker launches (probe_inverse_kernel) are counted.  Output (JSON):
   kernels[name] = {launches_per_proof, valu_insts_per_proof, waves_per_proof, busy_cycles_per_proof (GRBM_GUI_ACTIVE / n_xcd, summed
-                   over the kernel's launches: what the launches would take one after the other), valu_issue_frac (of that)}
+                   over the kernel's launches: what the launches would take one after the other), issue_floor_ms_per_proof, valu_slots_flat4}
   valu_insts_per_proof   sum over kernels of SQ_INSTS_VALU (wave-instructions)
-  issue_cycles_per_proof 4 x valu_insts_per_proof / n_simd: cycles of a chip that issues one wave64 VALU instruction per SIMD16 every
-                         4 cycles and does nothing else -- the floor of this instruction stream, whatever the schedule.
-bench.py divides that floor by the cycles of one measured proof: `roofline_proof.frac`."""
+  issue_floor_ms_per_proof   (round 6) sum over kernels of their issue floors BY INSTRUCTION CLASS (tools/issue_model.py: static class
+                         mix x class rates measured on the box, --rates <issue_classes.json>): what a chip that did nothing but issue
+                         this proof's instruction stream would need, whatever the schedule.
+  issue_cycles_flat4_per_proof   the round-3..5 figure: 4 x valu_insts_per_proof / n_simd (every instruction priced at 4 cycles: too high)
+bench.py re-prices the per-kernel counts with the rates of ITS run and divides by one measured proof: `roofline_proof.frac`.
+  tools/pmc_proof_budget.py <dir> <proofs> [n_simd [n_xcd]] [--rates issue_classes.json] [--classes isa_classes.json]"""
 import csv
 import glob
 import json
@@ -16,10 +19,28 @@ import re
 import sys
 from collections import defaultdict
 
-root = sys.argv[1]
-P = int(sys.argv[2])
-n_simd = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
-n_xcd = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import issue_model  # noqa: E402
+
+argv = list(sys.argv[1:])
+opt = {}
+for flag in ("--rates", "--classes"):
+    if flag in argv:
+        i = argv.index(flag)
+        opt[flag] = argv[i + 1]
+        del argv[i:i + 2]
+root = argv[0]
+P = int(argv[1])
+n_simd = int(argv[2]) if len(argv) > 2 else 1024
+n_xcd = int(argv[3]) if len(argv) > 3 else 8
+classes = issue_model.load_classes(opt.get("--classes"))
+rates, rates_src = dict(issue_model.DEFAULT_RATES), "tools/issue_model.py DEFAULT_RATES (gpurun call r06_c05)"
+if opt.get("--rates") and os.path.exists(opt["--rates"]):
+    try:
+        rates.update(json.load(open(opt["--rates"]))["G_lane_ops_per_s"])
+        rates_src = opt["--rates"]
+    except Exception:  # noqa: BLE001
+        pass
 rows = []
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     with open(f, newline="") as fh:
@@ -56,16 +77,21 @@ for d, ctr in by_dispatch.items():
     acc[k]["launches"] += 1
     for c, v in ctr.items():
         acc[k][c] += v
-out, total_insts, total_busy = {}, 0.0, 0.0
+out, total_insts, total_busy, total_floor = {}, 0.0, 0.0, 0.0
 for k, a in sorted(acc.items()):
     insts, busy = a.get("SQ_INSTS_VALU", 0.0), a.get("GRBM_GUI_ACTIVE", 0.0) / n_xcd
     total_insts += insts
     total_busy += busy
+    floor_s, how = issue_model.kernel_floor_s(k, insts / P, classes, rates)
+    total_floor += floor_s
     out[k] = {"launches_per_proof": round(a["launches"] / P, 2), "valu_insts_per_proof": round(insts / P, 1),
               "waves_per_proof": round(a.get("SQ_WAVES", 0.0) / P, 1), "busy_cycles_per_proof": round(busy / P, 1),
-              "valu_issue_frac": round(4 * insts / (busy * n_simd), 4) if busy else None}
+              "issue_floor_ms_per_proof": round(floor_s * 1e3, 4), "issue_floor_how": how,
+              "valu_slots_flat4": round(4 * insts / (busy * n_simd), 4) if busy else None}
 print(json.dumps({"how": "rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace around tools/proof_counters.py; dispatches between "
                          "the two marker groups only; kernels are serialised by the counter collection, so busy_cycles are each kernel ALONE",
                   "proofs": P, "n_simd": n_simd, "n_xcd": n_xcd, "dispatches_counted": sum(int(a["launches"]) for a in acc.values()),
-                  "valu_insts_per_proof": round(total_insts / P, 1), "issue_cycles_per_proof": round(4 * total_insts / P / n_simd, 1),
+                  "valu_insts_per_proof": round(total_insts / P, 1), "issue_floor_ms_per_proof": round(total_floor * 1e3, 4),
+                  "class_rates_G_lane_ops_per_s": rates, "class_rates_source": rates_src, "class_mix_source": os.path.basename(classes["_path"]) if classes else None,
+                  "issue_cycles_flat4_per_proof": round(4 * total_insts / P / n_simd, 1),
                   "serialised_busy_cycles_per_proof": round(total_busy / P, 1), "kernels": out}, indent=1))

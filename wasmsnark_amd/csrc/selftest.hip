@@ -351,6 +351,15 @@ __global__ __launch_bounds__(256) void probe_modmul_kernel(const Fe* __restrict_
     for (int i = 0; i < iters; i++) x = F::mul(x, y);
     out[t] = F::from_internal(x);
 }
+template <class F>
+__global__ __launch_bounds__(256) void probe_modmul2_kernel(const Fe* __restrict__ in, Fe* __restrict__ out, int iters) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    typename F::El x = F::to_internal(in[t]);
+    const typename F::El y = x;
+    typename F::El z = F::add(x, y);
+    for (int i = 0; i < iters; i++) { x = F::mul(x, y); z = F::mul(z, y); }
+    out[t] = F::from_internal(F::add(x, z));
+}
 __global__ __launch_bounds__(256) void probe_mad_kernel(uint64_t* __restrict__ out, uint32_t a, uint32_t b, int iters) {
     uint64_t c0 = threadIdx.x, c1 = c0 + 1, c2 = c0 + 2, c3 = c0 + 3, c4 = c0 + 4, c5 = c0 + 5, c6 = c0 + 6, c7 = c0 + 7;
     uint32_t x = a + threadIdx.x, y = b;
@@ -432,7 +441,8 @@ __global__ __launch_bounds__(256) void probe_inverse_kernel(const Fe* __restrict
 // sum over classes of (count / rate) instead of a flat "4 cycles per VALU instruction" -- the classes are those of
 // tools/isa_histogram.py.   6 v_add_u32 (bit32: add / and / or / 32-bit shifts)   7 v_lshrrev_b64 (shift64)   8 v_and_b32
 // 9 v_mul_lo_u32 (mul32)   10 v_mad_u64_u32 (mad64)   11 v_add_co_u32 + v_addc_co_u32 pairs (add64c: two instructions counted)
-// 12 v_mov_b32 (mov)   13 v_cndmask_b32 (cmp_sel)   14 v_mov_b32 quad_perm DPP (dpp)
+// 12 v_mov_b32 (mov)   13 v_cndmask_b32 on a standing mask   14 v_mov_b32 quad_perm DPP (dpp)   16 v_cmp_lt_u32 into SGPR pairs
+// 17 v_cmp + the v_cndmask that reads its mask, back to back (cmp_sel: how the conditional subtractions are written)
 #ifndef WSNARK_EMUL
 #define WS_ISSUE8(INS) INS(0) INS(1) INS(2) INS(3) INS(4) INS(5) INS(6) INS(7)
 template <int CLASS>
@@ -473,10 +483,72 @@ __global__ __launch_bounds__(256) void probe_issue_kernel(uint64_t* __restrict__
                              "v_mov_b32 %4, %0\n\tv_mov_b32 %5, %1\n\tv_mov_b32 %6, %2\n\tv_mov_b32 %7, %3\n\t"
                              : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
             } else if (CLASS == 13) {
+                // selects on a mask that is already there (vcc written once per trip): v_cndmask_b32 alone
 #define WS_I(k) "v_cndmask_b32 %" #k ", %" #k ", %8, vcc\n\t"
-                asm volatile("v_cmp_lt_u32 vcc, %0, %8\n\t" WS_I(1) WS_I(2) WS_I(3) WS_I(4) WS_I(5) WS_I(6) WS_I(7)
-                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(y) : "vcc");
+                asm volatile(WS_ISSUE8(WS_I) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(y) : "vcc");
 #undef WS_I
+            } else if (CLASS == 16) {
+                // compares alone: eight independent v_cmp into four SGPR pairs (no instruction reads a mask the one before wrote)
+                uint64_t m0, m1, m2, m3;
+                asm volatile("v_cmp_lt_u32 %0, %4, %12\n\tv_cmp_lt_u32 %1, %5, %12\n\tv_cmp_lt_u32 %2, %6, %12\n\tv_cmp_lt_u32 %3, %7, %12\n\t"
+                             "v_cmp_lt_u32 %0, %8, %12\n\tv_cmp_lt_u32 %1, %9, %12\n\tv_cmp_lt_u32 %2, %10, %12\n\tv_cmp_lt_u32 %3, %11, %12\n\t"
+                             : "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+                             : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7), "v"(y));
+                x0 += (uint32_t)__builtin_popcountll(m0 ^ m1 ^ m2 ^ m3) & (u == 9);      // (keeps the masks alive; never taken: u < 8)
+            } else if (CLASS == 18) {
+                // selects on a standing mask, each followed by an independent v_add_u32 (does other work hide the select's cost?)
+                asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n\tv_add_u32 %4, %4, %8\n\tv_cndmask_b32 %1, %1, %8, vcc\n\tv_add_u32 %5, %5, %8\n\t"
+                             "v_cndmask_b32 %2, %2, %8, vcc\n\tv_add_u32 %6, %6, %8\n\tv_cndmask_b32 %3, %3, %8, vcc\n\tv_add_u32 %7, %7, %8\n\t"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(y) : "vcc");
+            } else if (CLASS == 19) {
+                // the select in its three-operand encoding with the mask in an SGPR pair other than vcc
+                uint64_t m = 0x5555555555555555ull;
+                asm volatile("v_cndmask_b32_e64 %0, %0, %8, %9\n\tv_cndmask_b32_e64 %1, %1, %8, %9\n\tv_cndmask_b32_e64 %2, %2, %8, %9\n\tv_cndmask_b32_e64 %3, %3, %8, %9\n\t"
+                             "v_cndmask_b32_e64 %4, %4, %8, %9\n\tv_cndmask_b32_e64 %5, %5, %8, %9\n\tv_cndmask_b32_e64 %6, %6, %8, %9\n\tv_cndmask_b32_e64 %7, %7, %8, %9\n\t"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(y), "s"(m));
+            } else if (CLASS == 20) {
+                // the same choice by arithmetic: x ^= (x ^ y) & mask with a per-lane 0 / ~0 mask register (two instructions per select)
+                asm volatile("v_xor_b32 %4, %0, %8\n\tv_and_b32 %4, %4, %9\n\tv_xor_b32 %0, %0, %4\n\tv_xor_b32 %5, %1, %8\n\tv_and_b32 %5, %5, %9\n\tv_xor_b32 %1, %1, %5\n\t"
+                             "v_bfi_b32 %2, %9, %8, %2\n\tv_bfi_b32 %3, %9, %8, %3\n\t"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(y), "v"(x6));
+            } else if (CLASS == 21) {
+#define WS_I(k) "v_add3_u32 %" #k ", %" #k ", %8, %8\n\t"
+                asm volatile(WS_ISSUE8(WS_I) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(y));
+#undef WS_I
+            } else if (CLASS == 22) {
+#define WS_I(k) "v_bfi_b32 %" #k ", %8, %9, %" #k "\n\t"
+                asm volatile(WS_ISSUE8(WS_I) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(y), "v"((uint32_t)w0));
+#undef WS_I
+            } else if (CLASS == 23) {
+                // selects on a standing mask in runs of TWO between independent additions
+                asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n\tv_cndmask_b32 %1, %1, %8, vcc\n\tv_add_u32 %4, %4, %8\n\tv_add_u32 %5, %5, %8\n\t"
+                             "v_cndmask_b32 %2, %2, %8, vcc\n\tv_cndmask_b32 %3, %3, %8, vcc\n\tv_add_u32 %6, %6, %8\n\tv_add_u32 %7, %7, %8\n\t"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(y) : "vcc");
+            } else if (CLASS == 24) {
+#define WS_I(k) "v_alignbit_b32 %" #k ", %8, %" #k ", 29\n\t"
+                asm volatile(WS_ISSUE8(WS_I) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(y));
+#undef WS_I
+            } else if (CLASS == 25) {
+#define WS_I(k) "v_and_b32 %" #k ", 0x1fffffff, %" #k "\n\t"
+                asm volatile(WS_ISSUE8(WS_I) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+#undef WS_I
+            } else if (CLASS == 26) {
+#define WS_I(k) "v_add_u32_e64 %" #k ", %" #k ", %8\n\t"
+                asm volatile(WS_ISSUE8(WS_I) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(y));
+#undef WS_I
+            } else if (CLASS == 27) {
+#define WS_I(k) "v_and_b32 %" #k ", %8, %" #k "\n\t"
+                asm volatile(WS_ISSUE8(WS_I) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "s"(b | 0x10000001u));
+#undef WS_I
+            } else if (CLASS == 28) {
+#define WS_I(k) "v_lshrrev_b32 %" #k ", 29, %" #k "\n\t"
+                asm volatile(WS_ISSUE8(WS_I) : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+#undef WS_I
+            } else if (CLASS == 17) {
+                // a compare and the select that reads its mask, back to back (the pattern of a conditional subtraction), four pairs
+                asm volatile("v_cmp_lt_u32 vcc, %0, %8\n\tv_cndmask_b32 %1, %1, %8, vcc\n\tv_cmp_lt_u32 vcc, %2, %8\n\tv_cndmask_b32 %3, %3, %8, vcc\n\t"
+                             "v_cmp_lt_u32 vcc, %4, %8\n\tv_cndmask_b32 %5, %5, %8, vcc\n\tv_cmp_lt_u32 vcc, %6, %8\n\tv_cndmask_b32 %7, %7, %8, vcc\n\t"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(y) : "vcc");
             } else {
                 asm volatile("v_mov_b32_dpp %0, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
                              "v_mov_b32_dpp %2, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %3, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
@@ -488,52 +560,33 @@ __global__ __launch_bounds__(256) void probe_issue_kernel(uint64_t* __restrict__
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = (x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7) + (w0 ^ w1 ^ w2 ^ w3 ^ w4 ^ w5 ^ w6 ^ w7);
 }
-// probe 15: the shader clock UNDER THE MULTIPLY-ADD LOAD, in GHz: the class-10 loop with s_memtime stamps (tick = shader cycle,
-// MI355X_MICROARCH.md) taken by one wavefront that lives as long as the kernel (the grid is exactly one resident set), over the
-// kernel's duration by HIP events.  Only used to EXPRESS the class rates as cycles per wave-instruction; the roofline itself is
-// rate-based and needs no clock.
-__global__ __launch_bounds__(256) void probe_clock_kernel(uint64_t* __restrict__ out, uint64_t* __restrict__ ticks, uint32_t a, uint32_t b, int iters) {
-    uint32_t x0 = a + threadIdx.x;
-    uint64_t w0 = x0, w1 = x0 + 1, w2 = x0 + 2, w3 = x0 + 3, w4 = x0 + 4, w5 = x0 + 5, w6 = x0 + 6, w7 = x0 + 7;
-    uint32_t y = b | 1;
-    const uint64_t t0 = __builtin_amdgcn_s_memtime();
-    for (int i = 0; i < iters; i++) {
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-#define WS_I(k) "v_mad_u64_u32 %" #k ", vcc, %8, %9, %" #k "\n\t"
-            asm volatile(WS_ISSUE8(WS_I) : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5), "+v"(w6), "+v"(w7) : "v"(y), "v"(x0) : "vcc");
-#undef WS_I
-        }
-    }
-    const uint64_t t1 = __builtin_amdgcn_s_memtime();
-    out[blockIdx.x * blockDim.x + threadIdx.x] = w0 ^ w1 ^ w2 ^ w3 ^ w4 ^ w5 ^ w6 ^ w7;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { ticks[0] = t0; ticks[1] = t1; }
-}
 static void launch_issue_probe(int cls, uint32_t blocks, uint32_t threads, hipStream_t s, uint64_t* out, int iters) {
     switch (cls) {
 #define WS_CASE(c) case c: hipLaunchKernelGGL(probe_issue_kernel<c>, dim3(blocks), dim3(threads), 0, s, out, 12345u, 777u, iters); break;
-        WS_CASE(6) WS_CASE(7) WS_CASE(8) WS_CASE(9) WS_CASE(10) WS_CASE(11) WS_CASE(12) WS_CASE(13) WS_CASE(14)
+        WS_CASE(6) WS_CASE(7) WS_CASE(8) WS_CASE(9) WS_CASE(10) WS_CASE(11) WS_CASE(12) WS_CASE(13) WS_CASE(14) WS_CASE(16) WS_CASE(17) WS_CASE(18) WS_CASE(19) WS_CASE(20) WS_CASE(21) WS_CASE(22) WS_CASE(23) WS_CASE(24) WS_CASE(25) WS_CASE(26) WS_CASE(27) WS_CASE(28)
 #undef WS_CASE
     }
 }
-static void launch_clock_probe(uint32_t blocks, uint32_t threads, hipStream_t s, uint64_t* out, uint64_t* ticks, int iters) {
-    hipLaunchKernelGGL(probe_clock_kernel, dim3(blocks), dim3(threads), 0, s, out, ticks, 12345u, 777u, iters);
-}
 #else
 static void launch_issue_probe(int, uint32_t, uint32_t, hipStream_t, uint64_t*, int) {}       // (inline assembly: device only)
-static void launch_clock_probe(uint32_t, uint32_t, hipStream_t, uint64_t*, uint64_t*, int) {}
 #endif
 
 int peak_probe(int probe, double* gops) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
-    if (!gops || probe < 0 || probe > 15) return WS_ERR_ARG;
+    // probes 101..108: probe 1 (the inlined product chain, ONE dependent chain per lane) at 1..8 wavefronts per SIMD instead of 8: what
+    // the product's dependent multiply-add chain reaches at the occupancy of the accumulation kernels (G1: 3, G2: 2).
+    // probes 201..208: the same with TWO independent product chains per lane, interleaved by the compiler.
+    int waves = 8, chains = 1;
+    if (probe >= 101 && probe <= 108) { waves = probe - 100; probe = 1; }
+    else if (probe >= 201 && probe <= 208) { waves = probe - 200; probe = 1; chains = 2; }
+    if (!gops || probe < 0 || probe > 28 || probe == 15) return WS_ERR_ARG;
     if (probe == 3 || probe == 4) return traffic_probe(C, probe, gops);
     hipStream_t s = C->stream;
 #ifdef WSNARK_EMUL
     const uint32_t blocks = 2, threads = 256, total = blocks * threads;      // (CPU thread emulator: the control flow only, no rate)
 #else
-    const uint32_t blocks = (uint32_t)C->num_cu * 8, threads = 256, total = blocks * threads;
+    const uint32_t blocks = (uint32_t)C->num_cu * (uint32_t)waves, threads = 256, total = blocks * threads;
 #endif
     DevBuf in, out;
     WS_HIP_CHECK(in.alloc((size_t)total * 32));
@@ -551,22 +604,16 @@ int peak_probe(int probe, double* gops) {
     for (int rep = 0; rep < 4; rep++) {          // the first repetition warms the clocks; the best of the rest counts
         (void)hipEventRecord(a, s);
         if (probe == 0) hipLaunchKernelGGL(probe_modmul_kernel<Fq29>, dim3(blocks), dim3(threads), 0, s, in.as<Fe>(), out.as<Fe>(), iters);
+        else if (probe == 1 && chains == 2) hipLaunchKernelGGL(probe_modmul2_kernel<Fq29I>, dim3(blocks), dim3(threads), 0, s, in.as<Fe>(), out.as<Fe>(), iters);
         else if (probe == 1) hipLaunchKernelGGL(probe_modmul_kernel<Fq29I>, dim3(blocks), dim3(threads), 0, s, in.as<Fe>(), out.as<Fe>(), iters);
         else if (probe == 5) hipLaunchKernelGGL(probe_inverse_kernel, dim3(blocks), dim3(threads), 0, s, in.as<Fe>(), out.as<Fe>(), iters);
-        else if (probe == 15) launch_clock_probe(blocks, threads, s, out.as<uint64_t>(), in.as<uint64_t>(), iters);
         else if (probe >= 6) launch_issue_probe(probe, blocks, threads, s, out.as<uint64_t>(), iters);
         else hipLaunchKernelGGL(probe_mad_kernel, dim3(blocks), dim3(threads), 0, s, out.as<uint64_t>(), 12345u, 777u, iters);
         (void)hipEventRecord(b, s);
         if (hipEventSynchronize(b) != hipSuccess) break;
         float ms = 0;
         (void)hipEventElapsedTime(&ms, a, b);
-        const double ops = (probe == 2 ? 8.0 : probe >= 6 ? 64.0 : 1.0) * iters * (double)total;
-        if (probe == 15) {                          // GHz = ticks of the stamped wavefront / the kernel's duration
-            uint64_t tk[2] = {0, 0};
-            if (hipMemcpy(tk, in.p, sizeof tk, hipMemcpyDeviceToHost) != hipSuccess) break;
-            if (rep && ms > 0) best = (double)(tk[1] - tk[0]) / ms / 1e6;
-            continue;
-        }
+        const double ops = (probe == 2 ? 8.0 : probe >= 6 ? 64.0 : (double)chains) * iters * (double)total;
         if (rep && ms > 0 && ops / ms / 1e6 > best) best = ops / ms / 1e6;
     }
     (void)hipEventDestroy(a);
