@@ -191,6 +191,17 @@ int wsnark_pkey_load_sections(const wsnark_key_sections_t* sections, wsnark_pkey
  * wsnark_groth16_prove_finish works on any handle of the key (it only needs the five fixed points). */
 int wsnark_pkey_load_shard(const wsnark_key_sections_t* sections, uint32_t rank, uint32_t world, uint32_t h_interleave_log,
                            wsnark_pkey_t** out_handle);
+/* A key FILE (round 6): `path` names the reference's proving_key.bin (tools/buildpkey.js:124-186: u32
+ * section offsets, at most 4 GiB) or the WSNARK64 container -- the same sections in the same order behind 64-bit offsets, for keys the
+ * reference's format cannot hold (BASELINE config 5, 7.8 GB at 2^24); layout: wasmsnark_amd/csrc/keyfile.hip, written by
+ * wasmsnark_amd/formats.py / js/formats.js.  The file is mapped read-only and ONLY the pages of the share asked for are read:
+ * (rank, world, h_interleave_log) as in wsnark_pkey_load_shard -- (0, 1, 0) loads the whole key -- so eight ranks read the five point
+ * sections once between them (each the two matrices); every range goes back to the kernel as soon as it has been staged, so the
+ * load's resident set does not grow with the key.  Replaces the caller-side `fs.readFileSync` + `new Uint32Array(pkey)` of
+ * src/bn128.js:580-604 for keys that do not fit one ArrayBuffer.  Errors: WSNARK_ERR_ARG (cannot open), WSNARK_ERR_FORMAT. */
+int wsnark_pkey_load_file(const char* path, uint32_t rank, uint32_t world, uint32_t h_interleave_log, wsnark_pkey_t** out_handle);
+/* header of a key file without loading it (no GPU needed).  format: 1 = proving_key.bin, 2 = WSNARK64.  Out pointers may be NULL. */
+int wsnark_pkey_file_info(const char* path, uint32_t* n_vars, uint32_t* n_public, uint32_t* domain, uint64_t* file_bytes, int* format);
 /* which share a handle holds: (0, 1, 0, nVars, domain, 0) for a whole key.  Any out pointer may be NULL. */
 int wsnark_pkey_shard_info(const wsnark_pkey_t* handle, uint32_t* rank, uint32_t* world, uint64_t* first_signal,
                            uint64_t* n_signals, uint64_t* n_hexps, uint32_t* h_interleave_log);
@@ -332,6 +343,8 @@ void wsnark_group_free(wsnark_group_t* group);
 uint32_t wsnark_group_size(const wsnark_group_t* group);
 int wsnark_group_pkey_load(wsnark_group_t* group, const void* pkey, size_t len, wsnark_group_pkey_t** out_handle);
 int wsnark_group_pkey_load_sections(wsnark_group_t* group, const wsnark_key_sections_t* ks, wsnark_group_pkey_t** out_handle);
+/* the same from a key file (wsnark_pkey_load_file): ONE read-only mapping, every member reads its own shard's pages */
+int wsnark_group_pkey_load_file(wsnark_group_t* group, const char* path, wsnark_group_pkey_t** out_handle);
 void wsnark_group_pkey_free(wsnark_group_pkey_t* handle);
 int wsnark_group_pkey_info(const wsnark_group_pkey_t* handle, uint32_t* n_vars, uint32_t* n_public, uint32_t* domain, uint32_t* world,
                            int* distributed_calc_h);

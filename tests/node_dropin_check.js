@@ -223,6 +223,47 @@ const toAB = (b) => b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength);
         const still = await bn.groth16GenProof(wit, pkey, { r: Buffer.from(c3.r, "hex"), s: Buffer.from(c3.s, "hex") });
         if (JSON.stringify(still) !== JSON.stringify(c3.proof)) throw new Error("proof after a group's terminate()");
     }
+    // key FILES (round 6): the reference's proving_key.bin and the WSNARK64 container (64-bit offsets: keys beyond 4 GiB) by PATH --
+    // single context and a group of two; same proofs; header query; cache by path; a file that changed is loaded again
+    {
+        const os = require("os");
+        const dir = fs.mkdtempSync(path.join(os.tmpdir(), "wsnark-keyfile-"));
+        try {
+            const k6 = fs.readFileSync(path.join(gold, "keys", "t6.pkey.bin")), w6 = fs.readFileSync(path.join(gold, "keys", "t6.witness.bin"));
+            const pBin = path.join(dir, "t6.bin"), p64 = path.join(dir, "t6.wsnark64");
+            fs.writeFileSync(pBin, k6);
+            const total = ws.pkeyBinToContainer(k6, p64);
+            if (fs.statSync(p64).size !== total) throw new Error("container length");
+            const i1 = bn.keyFileInfo(pBin), i2 = bn.keyFileInfo(p64);
+            if (i1.format !== "proving_key.bin" || i2.format !== "WSNARK64" || i1.nVars !== i2.nVars || i2.domainSize !== 64 || i2.fileBytes !== total)
+                throw new Error("keyFileInfo: " + JSON.stringify([i1, i2]));
+            const grp = await ws.buildBn128({ devices: [0, 0] });
+            for (const c of proofs.t6) {
+                const o = { r: Buffer.from(c.r, "hex"), s: Buffer.from(c.s, "hex") };
+                for (const who of [bn, grp]) for (const p of [pBin, p64]) {
+                    const got = await who.groth16GenProof(w6, p, o);
+                    if (JSON.stringify(got) !== JSON.stringify(c.proof)) throw new Error("proof from the key file " + p);
+                    checked++;
+                }
+            }
+            if ((await bn.loadKey(p64)) !== (await bn.loadKey(p64))) throw new Error("key file handle not cached");
+            const ki = await grp.keyInfo(p64);
+            if (ki.world !== 2) throw new Error("group keyInfo of a key file");
+            // the file is replaced by another key: the cached handle must not be used for it
+            const k3 = fs.readFileSync(path.join(gold, "keys", "t3.pkey.bin")), w3 = fs.readFileSync(path.join(gold, "keys", "t3.witness.bin"));
+            const before = await bn.loadKey(p64);
+            ws.pkeyBinToContainer(k3, p64);
+            fs.utimesSync(p64, new Date(), new Date(Date.now() + 5000));
+            const c3 = proofs.t3[0];
+            const got3 = await bn.groth16GenProof(w3, p64, { r: Buffer.from(c3.r, "hex"), s: Buffer.from(c3.s, "hex") });
+            if (JSON.stringify(got3) !== JSON.stringify(c3.proof) || (await bn.loadKey(p64)) === before) throw new Error("a rewritten key file was served from the cache");
+            let bad = 0;
+            fs.writeFileSync(path.join(dir, "cut"), fs.readFileSync(p64).slice(0, 5000));
+            for (const p of [path.join(dir, "cut"), path.join(dir, "missing")]) { try { await bn.loadKey(p); } catch (e) { bad++; } }
+            if (bad !== 2) throw new Error("a truncated / missing key file did not reject");
+            grp.terminate();
+        } finally { fs.rmdirSync(dir, { recursive: true }); }
+    }
     // terminate() with calls queued and in flight on a group (ADVICE r5: the addon freed the library's group under them -- a
     // use-after-free, not a rejected Promise).  Every such call must SETTLE: the ones that had started finish with the right proof,
     // the ones still queued are rejected; nothing crashes, and terminate() itself returns at once.

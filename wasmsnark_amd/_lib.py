@@ -21,7 +21,7 @@ SYMBOLS = [
     "wsnark_fr_ntt", "wsnark_fr_ntt_dev", "wsnark_fr_ntt_batch_dev", "wsnark_fr_dist_scale_dev",
     "wsnark_pkey_eval_ab_dev", "wsnark_fr_mul_dev", "wsnark_fr_dist_combine_dev", "wsnark_fr_to_montgomery", "wsnark_fr_from_montgomery",
     "wsnark_calc_h", "wsnark_pkey_load", "wsnark_pkey_free", "wsnark_pkey_info", "wsnark_pkey_table_info",
-    "wsnark_groth16_prove", "wsnark_groth16_prove_dev", "wsnark_pkey_load_sections", "wsnark_pkey_load_shard", "wsnark_pkey_shard_info", "wsnark_pkey_load_stats", "wsnark_pkey_wait_tables", "wsnark_pkey_h_msm_dev", "wsnark_last_blinding", "wsnark_groth16_verify",
+    "wsnark_groth16_prove", "wsnark_groth16_prove_dev", "wsnark_pkey_load_sections", "wsnark_pkey_load_shard", "wsnark_pkey_load_file", "wsnark_pkey_file_info", "wsnark_pkey_shard_info", "wsnark_pkey_load_stats", "wsnark_pkey_wait_tables", "wsnark_pkey_h_msm_dev", "wsnark_last_blinding", "wsnark_groth16_verify",
     "wsnark_groth16_prove_partial", "wsnark_groth16_prove_partial_dev", "wsnark_groth16_prove_finish", "wsnark_groth16_prove_dist",
     "wsnark_g1_mul_base_batch", "wsnark_g2_mul_base_batch",
     "wsnark_synth_new", "wsnark_synth_free", "wsnark_synth_info", "wsnark_synth_witness", "wsnark_synth_pols",
@@ -29,7 +29,7 @@ SYMBOLS = [
     "wsnark_selftest_field", "wsnark_selftest_curve",
     "wsnark_timing_enable", "wsnark_timing_reset", "wsnark_timing_report", "wsnark_peak_probe", "wsnark_tuning_set", "wsnark_host_alloc", "wsnark_host_free",
     "wsnark_points_load", "wsnark_points_free", "wsnark_points_info", "wsnark_points_msm", "wsnark_points_msm_dev",
-    "wsnark_group_create", "wsnark_group_free", "wsnark_group_size", "wsnark_group_pkey_load", "wsnark_group_pkey_load_sections", "wsnark_group_pkey_free",
+    "wsnark_group_create", "wsnark_group_free", "wsnark_group_size", "wsnark_group_pkey_load", "wsnark_group_pkey_load_sections", "wsnark_group_pkey_load_file", "wsnark_group_pkey_free",
     "wsnark_group_pkey_info", "wsnark_group_pkey_wait_tables", "wsnark_group_prove", "wsnark_group_last_blinding", "wsnark_group_g1_msm", "wsnark_group_g2_msm",
 ]
 
@@ -97,6 +97,9 @@ class Lib:
         c.wsnark_groth16_prove_dev.argtypes = [vp, vp, sz, vp, vp, vp, vp]
         c.wsnark_pkey_load_sections.argtypes = [vp, C.POINTER(vp)]
         c.wsnark_pkey_load_shard.argtypes = [vp, u32, u32, u32, C.POINTER(vp)]
+        c.wsnark_pkey_load_file.argtypes = [C.c_char_p, u32, u32, u32, C.POINTER(vp)]
+        c.wsnark_pkey_file_info.argtypes = [C.c_char_p, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u64), C.POINTER(C.c_int)]
+        c.wsnark_group_pkey_load_file.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
         c.wsnark_pkey_shard_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
         c.wsnark_peak_probe.argtypes = [C.c_int, C.POINTER(C.c_double)]
         c.wsnark_tuning_set.argtypes = [C.c_char_p, C.c_int64]

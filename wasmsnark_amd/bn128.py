@@ -8,6 +8,7 @@ proofs).  The Node.js drop-in (wasmsnark_amd/js) binds the same C ABI through N-
 Python mirror exists so the parity tests read like the reference's own tests.
 """
 import ctypes as C
+import os
 import weakref
 
 from . import _lib
@@ -61,8 +62,10 @@ class _KeySections(C.Structure):   # wsnark_key_sections_t
 class ProvingKey:
     """Device-resident proving key (wsnark_pkey_load, or wsnark_pkey_load_sections for `sections`)."""
 
-    def __init__(self, lib, data=None, sections=None, shard=None, h_interleave_log=0, wait_tables=True):
-        """shard=(rank, world) with `sections`: only that rank's share of the points becomes resident
+    def __init__(self, lib, data=None, sections=None, shard=None, h_interleave_log=0, wait_tables=True, path=None):
+        """path: a key FILE -- proving_key.bin or the WSNARK64 container for keys beyond 4 GiB (wsnark_pkey_load_file: mapped,
+        only the share's pages are read); shard / h_interleave_log apply to it as to `sections`.
+        shard=(rank, world) with `sections`: only that rank's share of the points becomes resident
         (wsnark_pkey_load_shard; h_interleave_log: the layout of its hExps share, see include/wsnark.h).
         wait_tables: the library builds the fixed-base table rows in the background and serves proofs from the plain sections
         until they are there; this mirror waits for them by default (tests and timing tools want the steady state from the first
@@ -70,9 +73,12 @@ class ProvingKey:
         `wait_tables()` / `refresh_load_stats()` complete the picture later."""
         self._lib = lib
         self._h = C.c_void_p()
-        if shard is not None and sections is None:
-            raise ValueError("a points shard is loaded from sections")
-        if sections is not None:
+        if shard is not None and sections is None and path is None:
+            raise ValueError("a points shard is loaded from sections or from a key file")
+        if path is not None:
+            rank, world = shard if shard is not None else (0, 1)
+            lib.check(lib.c.wsnark_pkey_load_file(os.fsencode(path), rank, world, h_interleave_log, C.byref(self._h)))
+        elif sections is not None:
             # dict: n_vars, n_public, domain + byte strings alfa1, beta1, delta1, beta2, delta2, polsA, polsB,
             # pointsA, pointsB1, pointsB2, pointsC, pointsH (64-bit lengths: keys beyond the 4 GiB file format)
             ks = _KeySections(sections["n_vars"], sections["n_public"], sections["domain"])
@@ -188,11 +194,13 @@ def _key_sections(sections):
 class GroupKey:
     """One points shard of a proving key per device of a Group (wsnark_group_pkey_load[_sections])."""
 
-    def __init__(self, group, data=None, sections=None, wait_tables=True):
+    def __init__(self, group, data=None, sections=None, wait_tables=True, path=None):
         self._group, self._lib = group, group._lib
         lib = self._lib
         self._h = C.c_void_p()
-        if sections is not None:
+        if path is not None:
+            lib.check(lib.c.wsnark_group_pkey_load_file(group._h, os.fsencode(path), C.byref(self._h)))
+        elif sections is not None:
             ks, keep = _key_sections(sections)
             lib.check(lib.c.wsnark_group_pkey_load_sections(group._h, C.byref(ks), C.byref(self._h)))
         else:
@@ -232,8 +240,8 @@ class Group:
         self._keys = weakref.WeakSet()
         self._lib.check(self._lib.c.wsnark_group_create(arr, len(self.devices), C.byref(self._h)))
 
-    def load_key(self, pkey=None, sections=None, wait_tables=True):
-        return GroupKey(self, data=pkey, sections=sections, wait_tables=wait_tables)
+    def load_key(self, pkey=None, sections=None, wait_tables=True, path=None):
+        return GroupKey(self, data=pkey, sections=sections, wait_tables=wait_tables, path=path)
 
     def groth16GenProof(self, signals, key, r=None, s=None):
         """src/bn128.js:580-720 over the group: `signals` the witness bytes (host memory), `key` a GroupKey (or the key's bytes)."""
@@ -391,8 +399,15 @@ class Bn128:
         """Make a point set resident as fixed-base tables (no reference counterpart): see ResidentPoints."""
         return ResidentPoints(self.lib, g, points)
 
-    def load_key(self, pkey=None, sections=None, shard=None, h_interleave_log=0, wait_tables=True):
-        return ProvingKey(self.lib, pkey, sections, shard, h_interleave_log, wait_tables)
+    def load_key(self, pkey=None, sections=None, shard=None, h_interleave_log=0, wait_tables=True, path=None):
+        return ProvingKey(self.lib, pkey, sections, shard, h_interleave_log, wait_tables, path)
+
+    def key_file_info(self, path):
+        """Header of a key file (no GPU work): {n_vars, n_public, domain, file_bytes, format: 'proving_key.bin' | 'WSNARK64'}."""
+        nv, npub, dom, nb, fmt = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_int()
+        self.lib.check(self.lib.c.wsnark_pkey_file_info(os.fsencode(path), C.byref(nv), C.byref(npub), C.byref(dom), C.byref(nb), C.byref(fmt)))
+        return {"n_vars": nv.value, "n_public": npub.value, "domain": dom.value, "file_bytes": nb.value,
+                "format": {1: "proving_key.bin", 2: "WSNARK64"}.get(fmt.value, "?")}
 
     def h_multiexp_dev(self, key, d_h_slice, n, stream=None):
         """The H sum of one rank against the key handle's resident hExps share (wsnark_pkey_h_msm_dev)."""

@@ -317,6 +317,33 @@ int wsnark_pkey_load_shard(const wsnark_key_sections_t* ks, uint32_t rank, uint3
     if (!shard_ok(rank, world)) return WSNARK_ERR_ARG;
     return load_sections_entry(ks, KeyShard{rank, world, h_interleave_log}, out_handle);
 }
+// a key FILE: proving_key.bin or the WSNARK64 container (keyfile.hip); rank / world / h_interleave_log as wsnark_pkey_load_shard
+int wsnark_pkey_load_file(const char* path, uint32_t rank, uint32_t world, uint32_t h_interleave_log, wsnark_pkey_t** out_handle) {
+    REQUIRE_CTX();
+    if (!path || !out_handle || !shard_ok(rank, world)) return WSNARK_ERR_ARG;
+    KeyFile F;
+    KeySections S;
+    int rc = keyfile_open(path, &F, &S);
+    if (rc) return rc;
+    ProvingKey* K = nullptr;
+    rc = pkey_load_sections(S, &K, KeyShard{rank, world, h_interleave_log});      // (returns with every byte it needs copied: F may go)
+    if (rc) return rc;
+    *out_handle = reinterpret_cast<wsnark_pkey_t*>(K);
+    return WSNARK_OK;
+}
+int wsnark_pkey_file_info(const char* path, uint32_t* n_vars, uint32_t* n_public, uint32_t* domain, uint64_t* file_bytes, int* format) {
+    if (!path) return WSNARK_ERR_ARG;
+    KeyFile F;
+    KeySections S;
+    int rc = keyfile_open(path, &F, &S);
+    if (rc) return rc;
+    if (n_vars) *n_vars = S.n_vars;
+    if (n_public) *n_public = S.n_public;
+    if (domain) *domain = S.domain;
+    if (file_bytes) *file_bytes = F.len;
+    if (format) *format = F.format;
+    return WSNARK_OK;
+}
 int wsnark_pkey_shard_info(const wsnark_pkey_t* h, uint32_t* rank, uint32_t* world, uint64_t* first_signal, uint64_t* n_signals,
                            uint64_t* n_hexps, uint32_t* h_interleave_log) {
     if (!h) return WSNARK_ERR_ARG;

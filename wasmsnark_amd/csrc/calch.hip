@@ -250,7 +250,7 @@ struct SlabPiece {      // a part of one device allocation, with DevBuf's access
 };
 
 int pols_to_csr(const uint8_t* pols, size_t len, uint32_t n_signals, uint32_t domain, CsrMatrix* out,
-                size_t* consumed, hipStream_t s) {
+                size_t* consumed, hipStream_t s, void (*release)(const void* p, size_t n)) {
     const bool trace = tuning_get("TRACE", 0) == 1;
     const auto t_in = std::chrono::steady_clock::now();
     auto at = [&](const char* what) {
@@ -262,6 +262,14 @@ int pols_to_csr(const uint8_t* pols, size_t len, uint32_t n_signals, uint32_t do
     std::vector<uint32_t> rec_base((size_t)n_signals + 1);
     size_t pp = 0;
     uint64_t nnz = 0;
+    // Streaming form (a mapped key file, `release` set): the records go up in pieces of ~32 MiB AS the walk passes them and every
+    // piece's pages are handed back at once, so the walk and the upload together never hold more than one piece of the file --
+    // instead of all of it twice (walk, then upload).  The device copy of the records then needs its own allocation, sized by the
+    // section's length, before the walk knows the record count.
+    DevBuf d_blob_own;
+    size_t sent = 0;
+    const size_t piece = (size_t)tuning_get("POLS_PIECE_KB", 32768) << 10;       // (tests make the pieces small)
+    if (release) WS_HIP_CHECK(d_blob_own.alloc(len + 64));
     for (uint32_t i = 0; i < n_signals; i++) {
         start[i] = pp;
         rec_base[i] = (uint32_t)nnz;
@@ -271,6 +279,18 @@ int pols_to_csr(const uint8_t* pols, size_t len, uint32_t n_signals, uint32_t do
         pp += (size_t)nc * 36;
         nnz += nc;
         if (nnz >= ((uint64_t)1 << 32)) return WS_ERR_SIZE;
+        if (release && pp - sent >= piece) {
+            const int rc_up = upload_staged((uint8_t*)d_blob_own.p + sent, pols + sent, pp - sent, s);
+            if (rc_up) return rc_up;
+            release(pols + sent, pp - sent);
+            sent = pp;
+        }
+    }
+    if (release && pp > sent) {
+        const int rc_up = upload_staged((uint8_t*)d_blob_own.p + sent, pols + sent, pp - sent, s);
+        if (rc_up) return rc_up;
+        release(pols + sent, pp - sent);
+        sent = pp;
     }
     start[n_signals] = pp;
     rec_base[n_signals] = (uint32_t)nnz;
@@ -287,17 +307,18 @@ int pols_to_csr(const uint8_t* pols, size_t len, uint32_t n_signals, uint32_t do
     SlabPiece d_blob, d_start, d_base, d_sig, d_row, d_cnt, d_cursor, d_tiles, d_bad;
     DevBuf d_tmp;
     {
-        const size_t sizes[9] = {pp + 64, start.size() * 8, rec_base.size() * 4, nz * 4, nz * 4, ((size_t)domain + 1) * 4, ((size_t)domain + 1) * 4, (size_t)ntiles * 4, 4};
+        const size_t sizes[9] = {release ? 64 : pp + 64, start.size() * 8, rec_base.size() * 4, nz * 4, nz * 4, ((size_t)domain + 1) * 4, ((size_t)domain + 1) * 4, (size_t)ntiles * 4, 4};
         SlabPiece* const pieces[9] = {&d_blob, &d_start, &d_base, &d_sig, &d_row, &d_cnt, &d_cursor, &d_tiles, &d_bad};
         size_t total = 0;
         for (size_t b : sizes) total += (b + 255) & ~(size_t)255;
         WS_HIP_CHECK(d_tmp.alloc(total));
         size_t off = 0;
         for (int i = 0; i < 9; i++) { pieces[i]->p = (uint8_t*)d_tmp.p + off; off += (sizes[i] + 255) & ~(size_t)255; }
+        if (release) d_blob.p = d_blob_own.p;
     }
     at("header walk + allocations done");
     int rc;
-    if ((rc = upload_staged(d_blob.p, pols, pp, s))) return rc;
+    if (!release && (rc = upload_staged(d_blob.p, pols, pp, s))) return rc;
     if ((rc = upload_staged(d_start.p, start.data(), start.size() * 8, s))) return rc;
     if ((rc = upload_staged(d_base.p, rec_base.data(), rec_base.size() * 4, s))) return rc;
     WS_HIP_CHECK(hipMemsetAsync(d_cnt.p, 0, ((size_t)domain + 1) * 4, s));

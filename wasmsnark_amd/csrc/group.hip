@@ -315,6 +315,14 @@ int wsnark_group_pkey_load(wsnark_group_t* g, const void* pkey, size_t len, wsna
     if (rc) return rc;
     return group_load(reinterpret_cast<Group*>(g), S, out);
 }
+int wsnark_group_pkey_load_file(wsnark_group_t* g, const char* path, wsnark_group_pkey_t** out) {
+    if (!g || !out || !path) return WSNARK_ERR_ARG;
+    KeyFile F;                // ONE mapping for all members: each reads its own slices of it (and the two matrices)
+    KeySections S;
+    int rc = keyfile_open(path, &F, &S);
+    if (rc) return rc;
+    return group_load(reinterpret_cast<Group*>(g), S, out);
+}
 void wsnark_group_pkey_free(wsnark_group_pkey_t* h) {
     if (!h) return;
     GroupKey* K = reinterpret_cast<GroupKey*>(h);

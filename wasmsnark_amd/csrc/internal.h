@@ -268,8 +268,9 @@ struct CsrMatrix {            // row-major transpose of the reference's column-m
 };
 // parse `ncoefs, (idx, coef)*` records (src/build_pol.js:62-144) for n_signals columns;
 // returns bytes consumed via *consumed.
+// release: see KeySections::release (nullptr: the records are walked, then uploaded in one piece)
 int pols_to_csr(const uint8_t* pols, size_t len, uint32_t n_signals, uint32_t domain, CsrMatrix* out,
-                size_t* consumed, hipStream_t s);
+                size_t* consumed, hipStream_t s, void (*release)(const void* p, size_t n) = nullptr);
 // d_h_out[domain] (plain form) from a device-resident plain witness; work arrays of lane L
 int calc_h_dev(Lane& L, const Fe* d_signals_plain, uint32_t n_signals, const CsrMatrix& A, const CsrMatrix& B,
                uint32_t domain, Fe* d_h_out, hipStream_t s);
@@ -289,9 +290,24 @@ struct KeySections {      // everything wsnark_pkey_load reads from proving_key.
     const uint8_t* polsB; uint64_t lenB;
     const uint8_t *A, *B1, *B2, *Cpts, *H;     // nVars, nVars, nVars, nVars-nPublic-1, domain points
     uint64_t lenPA, lenPB1, lenPB2, lenPC, lenPH;   // bytes the caller vouches for behind each of those
+    // Optional (the file loader, keyfile.hip): called with every source range the load has finished reading -- a mapped file drops
+    // those pages again (madvise), so a load never holds more of the file than the ranges in flight.
+    void (*release)(const void* p, size_t n) = nullptr;
 };
 struct KeyShard { uint32_t rank = 0, world = 1, h_log_m = 0; };
 int pkey_parse(const uint8_t* buf, size_t len, KeySections* out);
+// a key FILE (keyfile.hip): proving_key.bin, or the u64-offset container for keys beyond its 4 GiB (include/wsnark.h: WSNARK64)
+struct KeyFile {
+    int fd = -1;
+    const uint8_t* base = nullptr;
+    size_t len = 0;
+    int format = 0;                     // 1 = proving_key.bin (u32 offsets), 2 = WSNARK64 container
+    KeyFile() = default;
+    KeyFile(const KeyFile&) = delete;
+    KeyFile& operator=(const KeyFile&) = delete;
+    ~KeyFile();
+};
+int keyfile_open(const char* path, KeyFile* F, KeySections* S);      // maps the file read-only, bounds-checks the header; S points into the map
 int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard);      // on the calling thread's context
 void pkey_free(ProvingKey* K);
 int pkey_wait_tables(ProvingKey* K);

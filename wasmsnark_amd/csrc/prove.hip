@@ -209,6 +209,7 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
             for (uint64_t j = 0; j < cols; j++)
                 memcpy(&h_gather[(size_t)(r * cols + j) * 64], S.H + ((uint64_t)shard.rank * per + r + m * j) * 64, 64);
         secs[4].src = h_gather.data();
+        if (S.release) S.release(S.H, (size_t)dom * 64);      // (the gather touched a 1 / world share of the section's pages)
     }
     for (auto& sc : secs) {
         size_t front = 0;
@@ -217,6 +218,7 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
             WS_HIP_CHECK(hipMemsetAsync(sc.d->p, 0, front, s));
         }
         if (sc.bytes && (rc = upload_staged((uint8_t*)sc.d->p + front, sc.src, (size_t)sc.bytes, s))) return rc;
+        if (S.release && sc.bytes && sc.src != h_gather.data()) S.release(sc.src, (size_t)sc.bytes);
         if (trace_load) fprintf(stderr, "[wsnark trace] key load: section of %llu bytes handed to the copy queue at %.2f ms\n", (unsigned long long)sc.bytes, since(t_begin));
     }
     K->load_ms[1] = lap(t_phase);
@@ -257,11 +259,11 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
         std::string err_b;                      // (the error text is per thread: carried back by hand)
         std::future<int> fb = std::async(std::launch::async, [&, device, sb]() {
             if (hipSetDevice(device) != hipSuccess) return (int)WS_ERR_HIP;
-            const int r = pols_to_csr(S.polsB, (size_t)S.lenB, nv, dom, &K->polsB, &used_b, sb);
+            const int r = pols_to_csr(S.polsB, (size_t)S.lenB, nv, dom, &K->polsB, &used_b, sb, S.release);
             if (r) err_b = get_last_error();
             return r;
         });
-        rc = pols_to_csr(S.polsA, (size_t)S.lenA, nv, dom, &K->polsA, &used, sa);
+        rc = pols_to_csr(S.polsA, (size_t)S.lenA, nv, dom, &K->polsA, &used, sa, S.release);
         const int rcb = fb.get();
         if (rc) return rc;                      // (~ProvingKey waits for the build queue)
         if (rcb) { set_last_error(err_b); return rcb; }

@@ -585,6 +585,7 @@ int peak_probe(int probe, double* gops) {
     hipStream_t s = C->stream;
 #ifdef WSNARK_EMUL
     const uint32_t blocks = 2, threads = 256, total = blocks * threads;      // (CPU thread emulator: the control flow only, no rate)
+    (void)waves;
 #else
     const uint32_t blocks = (uint32_t)C->num_cu * (uint32_t)waves, threads = 256, total = blocks * threads;
 #endif

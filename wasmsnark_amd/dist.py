@@ -360,22 +360,25 @@ _AG = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_uint64)
 
 class NativeDistProver:
     """One rank of the multi-GPU prover over wsnark_groth16_prove_dist.  `sections`: the key's sections (every rank passes
-    the whole key and keeps its share).  The transport callbacks run torch.distributed collectives: "nccl" (= RCCL over
+    the whole key and keeps its share) -- or `path`: a key FILE (proving_key.bin / the WSNARK64 container), of which the rank
+    maps and reads only its share (wsnark_pkey_load_file: N ranks do not each hold the whole key in host memory).  The transport callbacks run torch.distributed collectives: "nccl" (= RCCL over
     xGMI) enqueued on the library's own queue (torch.cuda.ExternalStream), so no host synchronisation separates kernels and
     exchanges; "gloo" (CPU tests, ranks sharing a GPU) staged through the host."""
 
-    def __init__(self, bn, sections, device=None, group=None):
+    def __init__(self, bn, sections=None, device=None, group=None, path=None):
         self.bn, self.group, self.device = bn, group, device
+        if (sections is None) == (path is None):
+            raise ValueError("NativeDistProver: pass the key's sections or the path of a key file")
         if dist.is_available() and dist.is_initialized():
             self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         else:
             self.world, self.rank = 1, 0
-        dom = sections["domain"]
+        dom = sections["domain"] if path is None else bn.key_file_info(path)["domain"]
         self.log_n = dom.bit_length() - 1
         self.l2 = self.log_n // 2
         if self.world & (self.world - 1) or (1 << self.l2) < self.world:
             raise ValueError("the distributed prover needs a power-of-two world size <= 2^%d" % self.l2)
-        self.key = bn.load_key(sections=sections, shard=(self.rank, self.world), h_interleave_log=self.l2)
+        self.key = bn.load_key(sections=sections, path=path, shard=(self.rank, self.world), h_interleave_log=self.l2)
         nbytes = 3 * (dom // self.world) * 32
         self.send = torch.empty(nbytes, dtype=torch.uint8, device=device if device is not None else "cpu")
         self.recv = torch.empty(nbytes, dtype=torch.uint8, device=self.send.device)

@@ -23,6 +23,7 @@ Command line (the reference's two tools under their own names):
     python -m wasmsnark_amd.formats buildpkey    -i proving_key.json -o proving_key.bin
     python -m wasmsnark_amd.formats buildwitness -i witness.json     -o witness.bin
     python -m wasmsnark_amd.formats dumppkey     -i proving_key.bin  -o proving_key.json
+    python -m wasmsnark_amd.formats pkey64       -i proving_key.bin  -o proving_key.wsnark64     (the u64-offset container, below)
 """
 from __future__ import annotations
 
@@ -223,6 +224,81 @@ def pkey_bin_to_sections(b: bytes) -> dict:
             "pointsC": b[pC:pC + (nv - npub - 1) * 64], "pointsH": b[pH:pH + dom * 64]}
 
 
+# ---- the u64-offset container for keys beyond proving_key.bin's 4 GiB (layout: csrc/keyfile.hip) ----
+KEY_CONTAINER_MAGIC = b"WSNARK64"
+_CONTAINER_HEADER = 608
+_CONTAINER_ALIGN = 4096
+_SECTION_ORDER = ("polsA", "polsB", "pointsA", "pointsB1", "pointsB2", "pointsC", "pointsH")      # tools/buildpkey.js:166-186
+
+
+def write_key_container(sections: dict, path) -> int:
+    """The sections of a key (the dict pkey_bin_to_sections returns / wsnark_pkey_load_sections takes; values may be bytes,
+    memoryviews or numpy arrays of any size) -> a WSNARK64 file at `path`: the layout of proving_key.bin
+    (tools/buildpkey.js:124-186, same section order, same bytes) behind 64-bit offsets.  Streams section by section; returns the
+    file's length.  wsnark_pkey_load_file / Bn128.load_key(path=...) / loadKey(path) read it."""
+    nv, npub, dom = int(sections["n_vars"]), int(sections["n_public"]), int(sections["domain"])
+    views = {k: memoryview(sections[k]).cast("B") for k in _SECTION_ORDER}
+    want = {"pointsA": nv * 64, "pointsB1": nv * 64, "pointsB2": nv * 128, "pointsC": (nv - npub - 1) * 64, "pointsH": dom * 64}
+    for k, n in want.items():
+        if len(views[k]) < n:
+            raise FormatError("key container: section %s is shorter than its header-implied %d bytes" % (k, n))
+        views[k] = views[k][:n]
+    off, offs = _CONTAINER_HEADER, {}
+    for k in _SECTION_ORDER:
+        off = (off + _CONTAINER_ALIGN - 1) // _CONTAINER_ALIGN * _CONTAINER_ALIGN
+        offs[k] = off
+        off += len(views[k])
+    total = off
+    hdr = bytearray(_CONTAINER_HEADER)
+    hdr[0:8] = KEY_CONTAINER_MAGIC
+    struct.pack_into("<6I", hdr, 8, 1, _CONTAINER_HEADER, nv, npub, dom, 0)
+    struct.pack_into("<10Q", hdr, 32, offs["polsA"], len(views["polsA"]), offs["polsB"], len(views["polsB"]), offs["pointsA"], offs["pointsB1"],
+                     offs["pointsB2"], offs["pointsC"], offs["pointsH"], total)
+    fixed = b"".join(bytes(memoryview(sections[k]).cast("B")) for k in ("alfa1", "beta1", "delta1", "beta2", "delta2"))
+    if len(fixed) != 448:
+        raise FormatError("key container: alfa1 / beta1 / delta1 are 64 bytes, beta2 / delta2 128 bytes")
+    hdr[160:608] = fixed
+    with open(path, "wb") as f:
+        f.write(hdr)
+        for k in _SECTION_ORDER:
+            f.seek(offs[k])
+            v = views[k]
+            for lo in range(0, len(v), 64 << 20):       # (pieces: a 2 GiB section in one write() is cut short by the kernel)
+                f.write(v[lo:lo + (64 << 20)])
+        f.truncate(total)
+    return total
+
+
+def pkey_bin_to_container(b, path) -> int:
+    """proving_key.bin bytes -> the same key as a WSNARK64 file (what one would do before sharding a key over ranks by file)."""
+    return write_key_container(pkey_bin_to_sections(b), path)
+
+
+def read_key_container(path) -> dict:
+    """A WSNARK64 file -> its sections as bytes (tests, tools; the loader maps the file instead: wsnark_pkey_load_file)."""
+    with open(path, "rb") as f:
+        hdr = f.read(_CONTAINER_HEADER)
+        if len(hdr) < _CONTAINER_HEADER or hdr[:8] != KEY_CONTAINER_MAGIC:
+            raise FormatError("not a WSNARK64 key container")
+        ver, hb, nv, npub, dom, _ = struct.unpack_from("<6I", hdr, 8)
+        pPA, lPA, pPB, lPB, pA, pB1, pB2, pC, pH, total = struct.unpack_from("<10Q", hdr, 32)
+        if ver != 1 or hb < _CONTAINER_HEADER:
+            raise FormatError("key container: unknown version")
+        f.seek(0, 2)
+        if f.tell() != total:
+            raise FormatError("key container: the file is not as long as its header says")
+
+        def rd(off, n):
+            f.seek(off)
+            b = f.read(n)
+            if len(b) != n:
+                raise FormatError("key container: section out of range")
+            return b
+        return {"n_vars": nv, "n_public": npub, "domain": dom, "alfa1": hdr[160:224], "beta1": hdr[224:288], "delta1": hdr[288:352],
+                "beta2": hdr[352:480], "delta2": hdr[480:608], "polsA": rd(pPA, lPA), "polsB": rd(pPB, lPB), "pointsA": rd(pA, nv * 64),
+                "pointsB1": rd(pB1, nv * 64), "pointsB2": rd(pB2, nv * 128), "pointsC": rd(pC, (nv - npub - 1) * 64), "pointsH": rd(pH, dom * 64)}
+
+
 def proof_from_bytes(p: bytes) -> dict:
     """The 384-byte proof record of wsnark_groth16_prove (12 plain LE 256-bit integers) -> the reference's
     proof object of decimal strings (src/bn128.js:714-718)."""
@@ -235,13 +311,18 @@ def proof_from_bytes(p: bytes) -> dict:
 def _main(argv) -> int:
     import argparse
     ap = argparse.ArgumentParser(prog="python -m wasmsnark_amd.formats")
-    ap.add_argument("tool", choices=["buildpkey", "buildwitness", "dumppkey", "dumpwitness"])
+    ap.add_argument("tool", choices=["buildpkey", "buildwitness", "dumppkey", "dumpwitness", "pkey64"])
     ap.add_argument("-i", "--input")
     ap.add_argument("-o", "--output")
     a = ap.parse_args(argv)
     defaults = {"buildpkey": ("proving_key.json", "proving_key.bin"), "buildwitness": ("witness.json", "witness.bin"),
-                "dumppkey": ("proving_key.bin", "proving_key.json"), "dumpwitness": ("witness.bin", "witness.json")}
+                "dumppkey": ("proving_key.bin", "proving_key.json"), "dumpwitness": ("witness.bin", "witness.json"),
+                "pkey64": ("proving_key.bin", "proving_key.wsnark64")}
     src, dst = a.input or defaults[a.tool][0], a.output or defaults[a.tool][1]
+    if a.tool == "pkey64":
+        with open(src, "rb") as f:
+            pkey_bin_to_container(f.read(), dst)
+        return 0
     if a.tool in ("buildpkey", "buildwitness"):
         with open(src, "r") as f:
             obj = json.load(f)

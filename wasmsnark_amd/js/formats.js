@@ -74,4 +74,73 @@ function witnessJsonToBin(w) {
     return buf;
 }
 
-module.exports = { pkeyJsonToBin, witnessJsonToBin };
+/* ---- the u64-offset container for keys beyond proving_key.bin's 4 GiB (SURVEY.md section 8(f)1; layout: csrc/keyfile.hip) ----
+ * pkeyBinSections(buf) -> {nVars, nPublic, domainSize, alfa1, ..., pointsH}: views into a proving_key.bin image (true section bounds)
+ * writeKeyContainer(path, sections) -> file length: the same sections behind 64-bit offsets, written synchronously section by section
+ *   (each of them a Buffer / TypedArray / ArrayBuffer of any size; a key too large for one Buffer is written from its own pieces)
+ * pkeyBinToContainer(buf, path): proving_key.bin bytes -> the container.  loadKey(path) / wsnark_pkey_load_file read it. */
+const fs = require("fs");
+const HEADER = 608, ALIGN = 4096;
+const ORDER = ["polsA", "polsB", "pointsA", "pointsB1", "pointsB2", "pointsC", "pointsH"];      // tools/buildpkey.js:166-186
+function bytesOf(v) {
+    if (Buffer.isBuffer(v)) return v;
+    if (v instanceof ArrayBuffer) return Buffer.from(v);
+    if (ArrayBuffer.isView(v)) return Buffer.from(v.buffer, v.byteOffset, v.byteLength);
+    throw new TypeError("expected a Buffer, TypedArray or ArrayBuffer");
+}
+function pkeyBinSections(key) {
+    const b = bytesOf(key);
+    if (b.length < 488) throw new RangeError("proving key shorter than its fixed header");
+    const h = []; for (let i = 0; i < 10; i++) h.push(b.readUInt32LE(4 * i));
+    const [nVars, nPublic, domainSize, pPA, pPB, pA, pB1, pB2, pC, pH] = h;
+    if (nPublic + 1 > nVars || !(488 <= pPA && pPA <= pPB && pPB <= pA) || pH + domainSize * 64 > b.length || pB2 + nVars * 128 > b.length)
+        throw new RangeError("proving key: section offsets out of range");
+    return { nVars, nPublic, domainSize, alfa1: b.slice(40, 104), beta1: b.slice(104, 168), delta1: b.slice(168, 232), beta2: b.slice(232, 360),
+        delta2: b.slice(360, 488), polsA: b.slice(pPA, pPB), polsB: b.slice(pPB, pA), pointsA: b.slice(pA, pA + nVars * 64),
+        pointsB1: b.slice(pB1, pB1 + nVars * 64), pointsB2: b.slice(pB2, pB2 + nVars * 128), pointsC: b.slice(pC, pC + (nVars - nPublic - 1) * 64),
+        pointsH: b.slice(pH, pH + domainSize * 64) };
+}
+function writeKeyContainer(path, sec) {
+    const nVars = sec.nVars, nPublic = sec.nPublic, dom = sec.domainSize;
+    const want = { pointsA: nVars * 64, pointsB1: nVars * 64, pointsB2: nVars * 128, pointsC: (nVars - nPublic - 1) * 64, pointsH: dom * 64 };
+    const views = {};
+    for (const k of ORDER) {
+        views[k] = bytesOf(sec[k]);
+        if (k in want) {
+            if (views[k].length < want[k]) throw new RangeError("key container: section " + k + " is shorter than its header-implied " + want[k] + " bytes");
+            views[k] = views[k].slice(0, want[k]);
+        }
+    }
+    let off = HEADER;
+    const offs = {};
+    for (const k of ORDER) { off = Math.ceil(off / ALIGN) * ALIGN; offs[k] = off; off += views[k].length; }
+    const total = off;
+    const hdr = Buffer.alloc(HEADER);
+    hdr.write("WSNARK64", 0, "latin1");
+    [1, HEADER, nVars, nPublic, dom, 0].forEach((v, i) => hdr.writeUInt32LE(v, 8 + 4 * i));
+    [offs.polsA, views.polsA.length, offs.polsB, views.polsB.length, offs.pointsA, offs.pointsB1, offs.pointsB2, offs.pointsC, offs.pointsH, total]
+        .forEach((v, i) => hdr.writeBigUInt64LE(BigInt(v), 32 + 8 * i));
+    let o = 160;
+    for (const [k, n] of [["alfa1", 64], ["beta1", 64], ["delta1", 64], ["beta2", 128], ["delta2", 128]]) {
+        const v = bytesOf(sec[k]);
+        if (v.length !== n) throw new RangeError("key container: " + k + " must be " + n + " bytes");
+        v.copy(hdr, o); o += n;
+    }
+    const fd = fs.openSync(path, "w");
+    try {
+        fs.writeSync(fd, hdr, 0, HEADER, 0);
+        for (const k of ORDER) {
+            const v = views[k];
+            for (let lo = 0; lo < v.length; lo += 64 << 20) {
+                const n = Math.min(64 << 20, v.length - lo);
+                let done = 0;
+                while (done < n) done += fs.writeSync(fd, v, lo + done, n - done, offs[k] + lo + done);
+            }
+        }
+        fs.ftruncateSync(fd, total);
+    } finally { fs.closeSync(fd); }
+    return total;
+}
+function pkeyBinToContainer(key, path) { return writeKeyContainer(path, pkeyBinSections(key)); }
+
+module.exports = { pkeyJsonToBin, witnessJsonToBin, pkeyBinSections, writeKeyContainer, pkeyBinToContainer };

@@ -71,6 +71,7 @@ class Bn128 {
         // A cached handle is reused while offset, length and the sampled fingerprint still match -- and, for callers that
         // ask ({trustCache: false}), the digest of the WHOLE buffer; see fingerprint() / digest() above.
         this._keys = new WeakMap();
+        this._files = new Map();    // key FILE path -> {size, mtimeMs, handle (a Promise)}
         this.fullDigests = 0;   // how many whole-buffer digests this object has computed (tests, tools/node_bench.js)
         this._pr = null;     // blinding values of the last proof, "for tests" like the reference (src/bn128.js:662-664)
         this._ps = null;
@@ -101,6 +102,7 @@ class Bn128 {
      * the sampled fingerprint does.  Concurrent callers with the same key object share ONE load: the entry is in the map before it is awaited. */
     async loadKey(pkey, opts) {
         if (!this._live) throw new Error("wsnark: this Bn128 object has been terminated");
+        if (typeof pkey === "string") return this._loadKeyFile(pkey);
         if (pkey !== null && typeof pkey === "object" && !(pkey instanceof ArrayBuffer) && !ArrayBuffer.isView(pkey)) return pkey;   // already a handle
         const u8 = asBytes(pkey);
         const hit = this._cached(pkey, u8);
@@ -127,8 +129,22 @@ class Bn128 {
             throw e;
         }
     }
+    /* A key FILE -- the reference's proving_key.bin or the WSNARK64 container for keys beyond its 4 GiB (js/formats.js:
+     * writeKeyContainer; 2^24 constraints = 7.8 GB, more than one Buffer holds).  The library maps the file and reads only what it makes
+     * resident; with a group every device reads its own shard.  Handles are cached per path while the file's size and mtime stand. */
+    async _loadKeyFile(path) {
+        const fs = require("fs");
+        const st = fs.statSync(path);
+        const hit = this._files.get(path);
+        if (hit && hit.size === st.size && hit.mtimeMs === st.mtimeMs) return hit.handle;
+        const entry = { size: st.size, mtimeMs: st.mtimeMs, handle: this._group ? addon.groupLoadKeyFile(this._group, path) : addon.loadKeyFile(path) };
+        this._files.set(path, entry);
+        try { return await entry.handle; } catch (e) { if (this._files.get(path) === entry) this._files.delete(path); throw e; }
+    }
+    /* {nVars, nPublic, domainSize, fileBytes, format} of a key file, from its header (nothing is loaded) */
+    keyFileInfo(path) { return addon.keyFileInfo(path); }
     /* forget the cached handle of a key object (its bytes were rewritten in place, or its HBM should go back) */
-    invalidateKey(pkey) { return this._keys.delete(pkey); }
+    invalidateKey(pkey) { return typeof pkey === "string" ? this._files.delete(pkey) : this._keys.delete(pkey); }
     /* {nVars, nPublic, domainSize, loadMs: {polsToCsr, pointsH2d, masksConvert, tableBuild, total}} of a key (bytes or handle) */
     async keyInfo(pkey) { const h = await this.loadKey(pkey); return this._group ? addon.groupKeyInfo(h) : addon.keyInfo(h); }
     /* loadKey() returns once the key's sections are resident: proofs may start at once and run on the plain sections while the rows
@@ -148,7 +164,7 @@ class Bn128 {
         // awaiting their key, and a group key must never reach the single-context prove()
         const proveFn = this._group ? addon.groupProve : addon.prove;
         const prove = (h) => proveFn(h, signals, opts && opts.r ? opts.r : null, opts && opts.s ? opts.s : null);
-        const isBytes = pkey instanceof ArrayBuffer || ArrayBuffer.isView(pkey);
+        const isBytes = pkey instanceof ArrayBuffer || ArrayBuffer.isView(pkey);      // (else: a handle, or the path of a key file)
         let t1, out;
         const hit = isBytes && !(opts && opts.trustCache === true) ? this._cached(pkey, asBytes(pkey)) : null;
         if (hit) {
@@ -206,6 +222,7 @@ class Bn128 {
     terminate() {
         if (!this._live) return;
         this._live = false;
+        this._files.clear();
         if (this._group) { addon.groupFree(this._group); this._group = null; }     // (a group's contexts belong to this object alone)
         if (--liveInstances === 0) addon.shutdown();
     }
@@ -261,4 +278,5 @@ function groth16Verify(verificationKey, input, proof, cb) {   // main_bn128.js:4
 
 const formats = require("./formats.js");     // snarkjs JSON -> proving_key.bin / witness.bin (reference tools/build*.js)
 module.exports = { buildBn128, groth16GenProof, genZKSnarkProof: groth16GenProof, groth16Verify, terminate, Bn128, proofFromBytes,
-    pkeyJsonToBin: formats.pkeyJsonToBin, witnessJsonToBin: formats.witnessJsonToBin };
+    pkeyJsonToBin: formats.pkeyJsonToBin, witnessJsonToBin: formats.witnessJsonToBin,
+    pkeyBinSections: formats.pkeyBinSections, writeKeyContainer: formats.writeKeyContainer, pkeyBinToContainer: formats.pkeyBinToContainer };

@@ -58,6 +58,10 @@ static struct {
     int (*group_last_blinding)(wsnark_group_t*, void*, void*);
     int (*group_g1_msm)(wsnark_group_t*, const void*, const void*, uint64_t, void*);
     int (*group_g2_msm)(wsnark_group_t*, const void*, const void*, uint64_t, void*);
+    /* key files: proving_key.bin or the WSNARK64 container (include/wsnark.h: wsnark_pkey_load_file) */
+    int (*pkey_load_file)(const char*, uint32_t, uint32_t, uint32_t, wsnark_pkey_t**);
+    int (*pkey_file_info)(const char*, uint32_t*, uint32_t*, uint32_t*, uint64_t*, int*);
+    int (*group_pkey_load_file)(wsnark_group_t*, const char*, wsnark_group_pkey_t**);
     char dir[4096];
 } L;
 
@@ -96,6 +100,7 @@ static int load_lib(char* err, size_t errlen) {
     SYM(group_pkey_free, "wsnark_group_pkey_free") SYM(group_pkey_info, "wsnark_group_pkey_info")
     SYM(group_pkey_wait_tables, "wsnark_group_pkey_wait_tables") SYM(group_prove, "wsnark_group_prove")
     SYM(group_last_blinding, "wsnark_group_last_blinding") SYM(group_g1_msm, "wsnark_group_g1_msm") SYM(group_g2_msm, "wsnark_group_g2_msm")
+    SYM(pkey_load_file, "wsnark_pkey_load_file") SYM(pkey_file_info, "wsnark_pkey_file_info") SYM(group_pkey_load_file, "wsnark_group_pkey_load_file")
 #undef SYM
     return 0;
 }
@@ -122,7 +127,8 @@ static int get_bytes(napi_env env, napi_value v, uint8_t** p, size_t* n) {
 }
 
 enum { OP_G1, OP_G2, OP_NTT, OP_CALCH, OP_PROVE, OP_LOADKEY, OP_VERIFY, OP_HASH, OP_WAIT_TABLES,
-       OP_GROUP_G1, OP_GROUP_G2, OP_GROUP_LOADKEY, OP_GROUP_PROVE, OP_GROUP_WAIT_TABLES, OP_POINTS_LOAD, OP_POINTS_MSM };
+       OP_GROUP_G1, OP_GROUP_G2, OP_GROUP_LOADKEY, OP_GROUP_PROVE, OP_GROUP_WAIT_TABLES, OP_POINTS_LOAD, OP_POINTS_MSM,
+       OP_LOADKEY_FILE, OP_GROUP_LOADKEY_FILE };
 /* A group and the keys loaded on it.  The JS side holds them as externals; a key's finalizer must not touch a group that
  * terminate() has already freed (wsnark_group_free frees the keys that are left), so every group handle carries a `live` flag
  * that outlives the group itself and every key handle points at its group's handle. */
@@ -174,6 +180,7 @@ typedef struct {
     wsnark_points_t* pts;
     uint8_t* out;
     size_t nout;
+    char* path;                 /* key file (OP_LOADKEY_FILE, OP_GROUP_LOADKEY_FILE): owned by the job */
     char err[512];
 } job_t;
 
@@ -257,6 +264,8 @@ static void job_execute(napi_env env, void* data) {
         if (!j->rc) j->rc = L.last_blinding(j->out + 384, j->out + 416);
         break;
     case OP_LOADKEY: j->rc = L.pkey_load(j->a, j->na, &j->key); break;
+    case OP_LOADKEY_FILE: j->rc = L.pkey_load_file(j->path, 0, 1, 0, &j->key); break;
+    case OP_GROUP_LOADKEY_FILE: j->rc = L.group_pkey_load_file(j->gr->g, j->path, &j->gk->k); break;
     case OP_VERIFY: j->rc = L.verify(j->a, j->na, j->b, j->nb / 32, j->c, &j->i0); break;
     case OP_WAIT_TABLES: j->rc = L.pkey_wait_tables(j->key); break;
     case OP_GROUP_G1: j->rc = L.group_g1_msm(j->gr->g, j->a, j->b, j->na / 32, j->out); break;
@@ -327,8 +336,8 @@ static void job_complete(napi_env env, napi_status status, void* data) {
         napi_create_string_utf8(env, j->rc ? j->err : "async work cancelled", NAPI_AUTO_LENGTH, &msg);
         napi_create_error(env, NULL, msg, &e);
         napi_reject_deferred(env, j->deferred, e);
-        if (j->op == OP_GROUP_LOADKEY && j->gk) { group_ref_drop(j->gk->gr); free(j->gk); }
-    } else if (j->op == OP_GROUP_LOADKEY) {
+        if ((j->op == OP_GROUP_LOADKEY || j->op == OP_GROUP_LOADKEY_FILE) && j->gk) { group_ref_drop(j->gk->gr); free(j->gk); }
+    } else if (j->op == OP_GROUP_LOADKEY || j->op == OP_GROUP_LOADKEY_FILE) {
         napi_create_external(env, j->gk, gkey_finalize, NULL, &res);
         napi_resolve_deferred(env, j->deferred, res);
     } else if (j->op == OP_POINTS_LOAD) {
@@ -337,7 +346,7 @@ static void job_complete(napi_env env, napi_status status, void* data) {
     } else if (j->op == OP_VERIFY) {
         napi_get_boolean(env, j->i0 != 0, &res);
         napi_resolve_deferred(env, j->deferred, res);
-    } else if (j->op == OP_LOADKEY) {
+    } else if (j->op == OP_LOADKEY || j->op == OP_LOADKEY_FILE) {
         napi_create_external(env, new_handle(TAG_KEY, j->key), key_finalize, NULL, &res);
         napi_resolve_deferred(env, j->deferred, res);
     } else {
@@ -349,18 +358,19 @@ static void job_complete(napi_env env, napi_status status, void* data) {
     for (int i = 0; i < j->nrefs; i++) napi_delete_reference(env, j->refs[i]);
     napi_delete_async_work(env, j->work);
     job_done_with_group(j);
+    free(j->path);
     free(j->out);
     free(j);
 }
 
 static napi_value start_job(napi_env env, job_t* j, const char* name) {
     napi_value promise, rname;
-    if (!L.h) { job_done_with_group(j); free(j->out); free(j); napi_throw_error(env, NULL, "wsnark_napi: init() has not been called (use buildBn128())"); return NULL; }
+    if (!L.h) { job_done_with_group(j); free(j->path); free(j->out); free(j); napi_throw_error(env, NULL, "wsnark_napi: init() has not been called (use buildBn128())"); return NULL; }
     if (napi_create_promise(env, &j->deferred, &promise) != napi_ok || napi_create_string_utf8(env, name, NAPI_AUTO_LENGTH, &rname) != napi_ok ||
         napi_create_async_work(env, NULL, rname, job_execute, job_complete, j, &j->work) != napi_ok || napi_queue_async_work(env, j->work) != napi_ok) {
         for (int i = 0; i < j->nrefs; i++) napi_delete_reference(env, j->refs[i]);
         job_done_with_group(j);           /* (never queued: nothing will complete it) */
-        free(j->out); free(j);
+        free(j->path); free(j->out); free(j);
         napi_throw_error(env, NULL, "wsnark_napi: cannot queue the call");
         return NULL;
     }
@@ -369,7 +379,15 @@ static napi_value start_job(napi_env env, job_t* j, const char* name) {
 static int keep(napi_env env, job_t* j, napi_value v) {   /* inputs stay referenced until completion */
     return napi_create_reference(env, v, 1, &j->refs[j->nrefs++]) == napi_ok;
 }
-#define FAIL(env, j, msg) do { free((j)->out); free(j); napi_throw_type_error((env), NULL, (msg)); return NULL; } while (0)
+#define FAIL(env, j, msg) do { free((j)->path); free((j)->out); free(j); napi_throw_type_error((env), NULL, (msg)); return NULL; } while (0)
+static char* get_path(napi_env env, napi_value v) {        /* a JS string -> malloc'ed UTF-8 (NULL if it is not a string) */
+    size_t n = 0;
+    napi_valuetype t;
+    if (napi_typeof(env, v, &t) != napi_ok || t != napi_string || napi_get_value_string_utf8(env, v, NULL, 0, &n) != napi_ok) return NULL;
+    char* p = (char*)malloc(n + 1);
+    if (p && napi_get_value_string_utf8(env, v, p, n + 1, &n) != napi_ok) { free(p); return NULL; }
+    return p;
+}
 
 /* g1Multiexp(scalars, points) / g2Multiexp(scalars, points) -> Promise<ArrayBuffer 96/192> */
 static napi_value msm_common(napi_env env, napi_callback_info info, int op) {
@@ -425,6 +443,41 @@ static napi_value js_loadkey(napi_env env, napi_callback_info info) {
     if (argc < 1 || !get_bytes(env, argv[0], &j->a, &j->na)) FAIL(env, j, "expected a proving_key.bin byte buffer");
     keep(env, j, argv[0]);
     return start_job(env, j, "wsnark_pkey_load");
+}
+
+/* loadKeyFile(path) -> Promise<key handle>: proving_key.bin or the WSNARK64 container, mapped by the library (wsnark_pkey_load_file):
+ * the key never exists as a JS buffer -- how keys beyond one ArrayBuffer (4 GiB file format, 2^24 constraints = 7.8 GB) are loaded */
+static napi_value js_loadkey_file(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1];
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    job_t* j = (job_t*)calloc(1, sizeof *j);
+    j->op = OP_LOADKEY_FILE;
+    if (argc < 1 || !(j->path = get_path(env, argv[0]))) FAIL(env, j, "expected the path of a key file");
+    return start_job(env, j, "wsnark_pkey_load_file");
+}
+/* keyFileInfo(path) -> {nVars, nPublic, domainSize, fileBytes, format: "proving_key.bin" | "WSNARK64"} (synchronous: reads the header) */
+static napi_value js_keyfile_info(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1], o, v;
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (!L.h) { napi_throw_error(env, NULL, "wsnark_napi: init() has not been called (use buildBn128())"); return NULL; }
+    char* path = argc >= 1 ? get_path(env, argv[0]) : NULL;
+    if (!path) { napi_throw_type_error(env, NULL, "expected the path of a key file"); return NULL; }
+    uint32_t nv = 0, np = 0, dom = 0; uint64_t nb = 0; int fmt = 0;
+    int rc = L.pkey_file_info(path, &nv, &np, &dom, &nb, &fmt);
+    free(path);
+    if (rc) {
+        char msg[600];
+        snprintf(msg, sizeof msg, "wsnark error %d: %s", rc, L.last_error());
+        napi_throw_error(env, NULL, msg);
+        return NULL;
+    }
+    napi_create_object(env, &o);
+    napi_create_uint32(env, nv, &v); napi_set_named_property(env, o, "nVars", v);
+    napi_create_uint32(env, np, &v); napi_set_named_property(env, o, "nPublic", v);
+    napi_create_uint32(env, dom, &v); napi_set_named_property(env, o, "domainSize", v);
+    napi_create_double(env, (double)nb, &v); napi_set_named_property(env, o, "fileBytes", v);
+    napi_create_string_utf8(env, fmt == 2 ? "WSNARK64" : "proving_key.bin", NAPI_AUTO_LENGTH, &v); napi_set_named_property(env, o, "format", v);
+    return o;
 }
 
 /* hashBytes(buf) -> Promise<ArrayBuffer 16>: digest of the WHOLE buffer, computed off the event loop */
@@ -643,6 +696,19 @@ static napi_value js_group_loadkey(napi_env env, napi_callback_info info) {
     job_use_group(j, j->gr);
     return start_job(env, j, "wsnark_group_pkey_load");
 }
+/* groupLoadKeyFile(group, path) -> Promise<group key handle>: every member reads its own shard's pages of ONE mapping */
+static napi_value js_group_loadkey_file(napi_env env, napi_callback_info info) {
+    size_t argc = 2; napi_value argv[2];
+    CHECK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    job_t* j = (job_t*)calloc(1, sizeof *j);
+    j->op = OP_GROUP_LOADKEY_FILE;
+    if (argc < 2 || !(j->gr = live_group(env, argv[0])) || !(j->path = get_path(env, argv[1]))) FAIL(env, j, "expected (group, path of a key file)");
+    j->gk = (gkey_ref_t*)calloc(1, sizeof *j->gk);
+    j->gk->tag = TAG_GKEY; j->gk->gr = j->gr; j->gr->refs++;
+    keep(env, j, argv[0]);
+    job_use_group(j, j->gr);
+    return start_job(env, j, "wsnark_group_pkey_load_file");
+}
 /* groupProve(groupKey, witness, r32|null, s32|null) -> Promise<ArrayBuffer 448>: proof | r | s used */
 static napi_value js_group_prove(napi_env env, napi_callback_info info) {
     size_t argc = 4; napi_value argv[4];
@@ -781,6 +847,9 @@ static napi_value module_init(napi_env env, napi_value exports) {
         {"fft", NULL, js_fft, NULL, NULL, NULL, napi_default, NULL},
         {"calcH", NULL, js_calch, NULL, NULL, NULL, napi_default, NULL},
         {"loadKey", NULL, js_loadkey, NULL, NULL, NULL, napi_default, NULL},
+        {"loadKeyFile", NULL, js_loadkey_file, NULL, NULL, NULL, napi_default, NULL},
+        {"keyFileInfo", NULL, js_keyfile_info, NULL, NULL, NULL, napi_default, NULL},
+        {"groupLoadKeyFile", NULL, js_group_loadkey_file, NULL, NULL, NULL, napi_default, NULL},
         {"hashBytes", NULL, js_hash, NULL, NULL, NULL, napi_default, NULL},
         {"keyInfo", NULL, js_keyinfo, NULL, NULL, NULL, napi_default, NULL},
         {"allocPinned", NULL, js_alloc_pinned, NULL, NULL, NULL, napi_default, NULL},
