@@ -620,6 +620,7 @@ def bench_prove(ctx):
     if "sparse" in want_extras and args.circuit == "columns" and logd <= 20:
         key.free()
         run_extra(extras, "prove_sparse_rows_circuit", lambda: extra_prove_sparse(ctx, logd))
+        run_extra(extras, "prove_boolean_circuit", lambda: extra_prove_sparse(ctx, logd, "boolean"))
     if "node" in want_extras and logd == 20:
         run_extra(extras, "node_drop_in", lambda: extra_node(ctx, circ, wit, sec))
         nd = extras.get("node_drop_in", {})
@@ -945,12 +946,14 @@ def extra_ntt(ctx):
     return res
 
 
-def extra_prove_sparse(ctx, logd):
-    """Key-dependent extra: round 1's generator (1-2 terms per ROW) leaves ~40 % of the variables out of A and of B;
-    their key points are infinity and the sums run on plan variants that skip them."""
+def extra_prove_sparse(ctx, logd, style="rows"):
+    """Key-dependent extras.  "rows": round 1's generator (1-2 terms per ROW) leaves ~40 % of the variables out of A and of B;
+    their key points are infinity and the sums run on plan variants that skip them.  "boolean" (round 6): a VALID bit-decomposition
+    circuit -- 87.5 % of the witness is 0 / 1 (csrc/synth.hip style 2): the digit-0 / digit-1 buckets of every window row are very
+    hot (msm_plan_emit_hot, the hot role of msm_combine_all), zero scalars drop out of the sums, one B column has 2^20 entries."""
     bn, torch, dev = ctx["bn"], ctx["torch"], ctx["dev"]
     from wasmsnark_amd import synth
-    circ, key, wit, info = build_prover(bn, logd, "rows")
+    circ, key, wit, info = build_prover(bn, logd, style)
     info.pop("_cold", None); info.pop("_sections", None)
     d_w = torch.frombuffer(bytearray(wit), dtype=torch.uint8).to(dev)
     r32, s32 = bytes(range(32)), bytes(range(32, 64))

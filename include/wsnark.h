@@ -364,7 +364,8 @@ int wsnark_g2_mul_base_batch(const void* base128, const void* scalars, uint64_t 
 
 /* A whole synthetic circuit + trusted setup from KNOWN toxic waste, on the host (csrc/synth.hip): the multiplication-chain
  * R1CS SURVEY.md section 8d C4 specifies (style 0 = 1-3 non-zeros per COLUMN of A and B, every variable present; style 1 =
- * 1-2 terms per ROW, ~40 % of the variables absent from A resp. B), its witness, its polsA / polsB record streams
+ * 1-2 terms per ROW, ~40 % of the variables absent from A resp. B; style 2 = bit decompositions: groups of 14 free bits with their
+ * booleanity rows b (b - 1) = 0, a recomposition row and a product row -- 87.5 % of the witness is 0 / 1), its witness, its polsA / polsB record streams
  * (tools/buildpkey.js:79-89), the discrete logarithm of every key point (feed them to wsnark_g{1,2}_mul_base_batch) and
  * the discrete logarithms of the proof for given r, s -- the closed form the full-size parity tests compare against.
  * key_scalars group 1: alfa1, beta1, delta1, A[nVars], B1[nVars], C[nVars-nPublic-1], hExps[domain], IC[nPublic+1];

@@ -12,6 +12,26 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "sanitizer: the emulator suite under ASan + UBSan / TSan (slow; select with -m sanitizer or WSNARK_SANITIZERS=1)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # the sanitizer runs take tens of minutes: only when asked for by name
+    if "sanitizer" in (config.getoption("-m") or "") and "not sanitizer" not in (config.getoption("-m") or ""):
+        return
+    if os.environ.get("WSNARK_SANITIZERS") == "1":
+        return
+    skip = pytest.mark.skip(reason="sanitizer runs are selected with -m sanitizer (or WSNARK_SANITIZERS=1)")
+    for it in items:
+        if "sanitizer" in it.keywords:
+            it.add_marker(skip)
+
+
+def hamming_ok(b32):
+    """The reference's own sanity check of drawn blinding (test/bn128_prover.js:65-71): the zeros among the significant bits
+    of the 256-bit value number 96..160 (a uniform draw has 128 +- 8)."""
+    z = bin(int.from_bytes(b32, "little"))[2:].count("0")
+    return 96 <= z <= 160
 
 
 def load_golden(name):

@@ -6,6 +6,23 @@
 #include <mutex>
 #include <vector>
 
+// Sanitizer builds (make -C wasmsnark_amd/csrc emul SAN=address,undefined | SAN=thread): every kernel thread is a ucontext coroutine
+// on a heap stack, so each switch is announced to the sanitizer's runtime -- ASan would otherwise take the new stack for a wild
+// stack pointer (false stack-buffer-overflow reports, broken unwinding), TSan would attribute a coroutine's accesses to whatever
+// ran on the host thread before.
+#if defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/common_interface_defs.h>
+#define EMUL_ASAN 1
+#else
+#define EMUL_ASAN 0
+#endif
+#if defined(__SANITIZE_THREAD__)
+#include <sanitizer/tsan_interface.h>
+#define EMUL_TSAN 1
+#else
+#define EMUL_TSAN 0
+#endif
+
 namespace hip_emul {
 
 thread_local uint3_emul t_threadIdx, t_blockIdx;
@@ -24,6 +41,8 @@ struct Thr {
     int shfl_src = 0;
     bool at_pair = false;      // waiting in pair_exchange for lane ^ 1
     uint32_t pair_val = 0;
+    void* asan_fake = nullptr; // ASan: this coroutine's fake-stack handle while it is switched out
+    void* tsan_fiber = nullptr;
 };
 
 thread_local std::vector<Thr>* g_thr = nullptr;
@@ -32,11 +51,46 @@ thread_local int g_cur = -1;
 thread_local const std::function<void()>* g_body = nullptr;
 thread_local std::vector<unsigned char> g_smem;
 thread_local std::vector<char*> g_stack_pool;
+thread_local const void* g_sched_stack = nullptr;      // ASan: the scheduler's (host thread's) stack, learnt on the first switch
+thread_local size_t g_sched_stack_size = 0;
+thread_local void* g_sched_fiber = nullptr;            // TSan: the host thread's own fiber
+
+// coroutine -> scheduler (from trampoline's end with `last`: the coroutine never runs again)
+void yield_to_scheduler(Thr& me, bool last = false) {
+#if EMUL_ASAN
+    __sanitizer_start_switch_fiber(last ? nullptr : &me.asan_fake, g_sched_stack, g_sched_stack_size);
+#endif
+#if EMUL_TSAN
+    __tsan_switch_to_fiber(g_sched_fiber, 0);
+#endif
+    swapcontext(&me.uc, &g_sched);
+#if EMUL_ASAN
+    __sanitizer_finish_switch_fiber(me.asan_fake, &g_sched_stack, &g_sched_stack_size);      // (back in the coroutine)
+#endif
+    (void)last;
+}
+// scheduler -> coroutine
+void resume(Thr& T) {
+#if EMUL_ASAN
+    void* fake = nullptr;
+    __sanitizer_start_switch_fiber(&fake, T.stack, STACK_BYTES);
+#endif
+#if EMUL_TSAN
+    __tsan_switch_to_fiber(T.tsan_fiber, 0);
+#endif
+    swapcontext(&g_sched, &T.uc);
+#if EMUL_ASAN
+    __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#endif
+}
 
 void trampoline() {
+#if EMUL_ASAN
+    __sanitizer_finish_switch_fiber(nullptr, &g_sched_stack, &g_sched_stack_size);      // first entry: nothing to restore
+#endif
     (*g_body)();
     (*g_thr)[g_cur].done = true;
-    swapcontext(&(*g_thr)[g_cur].uc, &g_sched);
+    yield_to_scheduler((*g_thr)[g_cur], true);
 }
 void set_ids(int t, dim3 block) {
     t_threadIdx.x = (unsigned)t % block.x;
@@ -50,7 +104,7 @@ void* dyn_smem() { return g_smem.data(); }
 void sync_threads() {
     Thr& me = (*g_thr)[g_cur];
     me.at_barrier = true;
-    swapcontext(&me.uc, &g_sched);
+    yield_to_scheduler(me);
 }
 
 uint32_t shfl_exchange(uint32_t v, int src_lane, int /*width*/) {
@@ -58,7 +112,7 @@ uint32_t shfl_exchange(uint32_t v, int src_lane, int /*width*/) {
     me.shfl_val = v;
     me.shfl_src = src_lane;
     me.at_shfl = true;
-    swapcontext(&me.uc, &g_sched);   // scheduler resumes us once the whole wave has posted
+    yield_to_scheduler(me);          // scheduler resumes us once the whole wave has posted
     return me.shfl_val;
 }
 
@@ -68,7 +122,7 @@ uint32_t pair_exchange(uint32_t v) {
     Thr& me = (*g_thr)[g_cur];
     me.pair_val = v;
     me.at_pair = true;
-    swapcontext(&me.uc, &g_sched);   // the scheduler resumes us once the partner has posted
+    yield_to_scheduler(me);          // the scheduler resumes us once the partner has posted
     return me.pair_val;
 }
 
@@ -97,6 +151,10 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
             T.uc.uc_stack.ss_size = STACK_BYTES;
             T.uc.uc_link = &g_sched;
             makecontext(&T.uc, trampoline, 0);
+#if EMUL_TSAN
+            if (!g_sched_fiber) g_sched_fiber = __tsan_get_current_fiber();
+            T.tsan_fiber = __tsan_create_fiber(0);
+#endif
         }
         int live = nthr;
         while (live > 0) {
@@ -106,8 +164,14 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
                 if (T.done || T.at_barrier || T.at_shfl || T.at_pair) continue;
                 g_cur = t;
                 set_ids(t, block);
-                swapcontext(&g_sched, &T.uc);
-                if (T.done) live--;
+                resume(T);
+                if (T.done) {
+                    live--;
+#if EMUL_TSAN
+                    __tsan_destroy_fiber(T.tsan_fiber);
+                    T.tsan_fiber = nullptr;
+#endif
+                }
             }
             bool progressed = false;
             // resolve pair exchanges: lanes 2k and 2k + 1 swap once both have posted

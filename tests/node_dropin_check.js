@@ -71,8 +71,15 @@ const toAB = (b) => b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength);
         res();
     }));
     // default blinding: the values drawn are kept like the reference's _pr / _ps and reproduce the proof when injected
+    // ... and pass the reference's own check of its draw (test/bn128_prover.js:65-71): 96..160 zeros among the significant bits
+    const hammingOk = (u8) => {
+        let v = 0n; for (let i = 31; i >= 0; i--) v = (v << 8n) | BigInt(u8[i]);
+        const zeros = v.toString(2).split("").filter((b) => b === "0").length;
+        return zeros >= 96 && zeros <= 160;
+    };
     const p1 = await bn.groth16GenProof(wit, pkey);
     const r1 = Buffer.from(bn._pr), s1 = Buffer.from(bn._ps);
+    if (!hammingOk(r1) || !hammingOk(s1)) throw new Error("invalid hamming weight of r / s");
     const p2 = await bn.groth16GenProof(wit, pkey, { r: r1, s: s1 });
     if (JSON.stringify(p1) !== JSON.stringify(p2)) throw new Error("proof with drawn r, s is not reproducible");
     const p3 = await bn.groth16GenProof(wit, pkey);
@@ -208,6 +215,7 @@ const toAB = (b) => b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength);
         }
         const pk3 = fs.readFileSync(path.join(gold, "keys", "t3.pkey.bin")), wt3 = fs.readFileSync(path.join(gold, "keys", "t3.witness.bin"));
         const g1 = await grp.groth16GenProof(wt3, pk3);                                   // drawn blinding: kept like _pr / _ps, reproducible
+        if (!hammingOk(grp._pr) || !hammingOk(grp._ps)) throw new Error("invalid hamming weight of the group's r / s");
         const g2 = await grp.groth16GenProof(wt3, pk3, { r: Buffer.from(grp._pr), s: Buffer.from(grp._ps) });
         if (JSON.stringify(g1) !== JSON.stringify(g2)) throw new Error("group proof with drawn r, s is not reproducible");
         for (const [list, fn] of [[msm.g1, grp.g1_multiexp], [msm.g2, grp.g2_multiexp]]) {

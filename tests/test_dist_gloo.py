@@ -58,6 +58,8 @@ dist.all_gather(both, mine)
 assert all(torch.equal(both[0], b) for b in both), "ranks disagree on the proof"
 r_used, s_used = bn.last_blinding()
 assert got == bn.groth16GenProof(wit, key, r=r_used, s=s_used)                 # == the single-process proof for those r, s
+for v in (r_used, s_used):          # the reference's check of its draw (test/bn128_prover.js:65-71); rank 0 drew for everybody
+    assert 96 <= bin(int.from_bytes(v, "little"))[2:].count("0") <= 160, "hamming weight of drawn blinding"
 dist.barrier()
 open(os.path.join(os.environ["WS_OUT"], "rank%d.ok" % rank), "w").write("ok")
 '''

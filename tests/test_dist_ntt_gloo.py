@@ -75,6 +75,8 @@ for name in ("t3", "t6"):
     got = dp.prove(w.data_ptr(), len(wit))                     # rank 0 draws r, s
     r_used, s_used = bn.last_blinding()
     assert got == bn.groth16GenProof(wit, key, r=r_used, s=s_used), ("DistProver default blinding", name, rank)
+    for v in (r_used, s_used):      # the reference's check of its draw (test/bn128_prover.js:65-71); here rank 0 drew for everybody
+        assert 96 <= bin(int.from_bytes(v, "little"))[2:].count("0") <= 160, ("hamming weight of drawn blinding", rank)
 # the same proofs from the NATIVE orchestration (wsnark_groth16_prove_dist, csrc/dist.hip): points shards of the key (1 / world
 # resident per rank), row-sharded sparse products, pack / unpack kernels instead of permute().contiguous(), the transport as
 # callbacks -- nothing in Python between the kernels.  Must equal the reference's proofs and DistProver's.

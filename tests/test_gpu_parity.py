@@ -328,6 +328,28 @@ def test_msm_full_size_adversarial_closed_forms(bn, orc, g):
     assert out[:esz] == expect(sum(ss[i] * ks[i] for i in range(0, n, 2)))
 
 
+@pytest.mark.parametrize("logd,style", [(12, "boolean"), (16, "boolean"), (20, "boolean")])
+def test_prove_boolean_heavy_valid_circuit_vs_closed_form(bn, logd, style):
+    """A VALID boolean-heavy circuit at full size (round 6; csrc/synth.hip style 2: bit decompositions with their booleanity rows
+    b (b - 1) = 0, 87.5 % of the witness 0 / 1 -- what circom circuits look like): every window row's digit-1 bucket takes ~45 % of
+    the pairs (very hot buckets: msm_plan_emit_hot, the hot role of msm_combine_all), the zero scalars drop out, one B column has an
+    entry in every booleanity row.  Expected value: the toxic-waste closed form of the library's generator, which
+    tests/test_synth_native.py pins against the ORACLE's prover and the verifier on the CPU."""
+    from wasmsnark_amd import synth
+    circ = synth.NativeCircuit(bn.lib, logd, n_public=5, seed=logd, style=style)
+    sec, _ = circ.build_sections()
+    wit = circ.witness_bin()
+    vals01 = sum(1 for i in range(0, len(wit), 32) if wit[i + 1:i + 32] == bytes(31) and wit[i] < 2)
+    assert vals01 >= 0.8 * circ.n_vars
+    key = bn.load_key(sections=sec)
+    for r, s in ((bytes(32), bytes(32)), (bytes(range(32)), bytes(range(32, 64)))):
+        assert bn.groth16GenProof(wit, key, r=r, s=s) == circ.expected_proof(r, s)
+    # ... and before the table rows exist (plain sections: the per-window plans, whose digit-0 / digit-1 buckets are hot in EVERY window)
+    k2 = bn.load_key(sections=sec, wait_tables=False)
+    assert bn.groth16GenProof(wit, k2, r=bytes(32), s=bytes(32)) == circ.expected_proof(bytes(32), bytes(32))
+    k2.free(); key.free(); circ.free()
+
+
 @pytest.mark.parametrize("logd,style", [(10, "columns"), (16, "columns"), (16, "rows"), (20, "columns")])
 def test_prove_vs_toxic_waste_closed_form(bn, logd, style):
     """(20, columns) is BASELINE config 4 at full size: the circuit SURVEY.md section 8d C4 specifies (1-3 non-zeros per
@@ -352,6 +374,8 @@ def test_prove_vs_toxic_waste_closed_form(bn, logd, style):
     assert got == synth.expected_proof(circ, S, r, s, bn.mul_base)
     got2 = bn.groth16GenProof(wit, key)
     assert bn.last_blinding() != (r, s) and got2 != got
+    from conftest import hamming_ok                      # the reference's own check of its draw: test/bn128_prover.js:65-71
+    assert all(hamming_ok(v) for v in (r, s) + bn.last_blinding())
     key.free()
 
 

@@ -10,7 +10,7 @@ import pytest
 
 import base64
 
-from conftest import GOLDEN, load_golden
+from conftest import GOLDEN, hamming_ok, load_golden
 from emul_util import emul_bn128
 from wasmsnark_amd import bn128
 
@@ -38,6 +38,9 @@ def test_group_prove_matches_reference(name, world):
         # drawn blinding: rank 0 draws, every rank assembles the same proof; it must be a well-formed proof object
         p = g.groth16GenProof(wit, key)
         assert p["pi_a"][2] == "1" and p["pi_b"][2] == ["1", "0"] and p["pi_c"][2] == "1"
+        r_used, s_used = g.last_blinding()                      # (wsnark_group_last_blinding: the reference's _pr / _ps)
+        assert hamming_ok(r_used) and hamming_ok(s_used)        # test/bn128_prover.js:65-71
+        assert g.groth16GenProof(wit, key, r=r_used, s=s_used) == p
         key.free()
     finally:
         g.terminate()

@@ -9,7 +9,7 @@ import os
 
 import pytest
 
-from conftest import GOLDEN, load_golden
+from conftest import GOLDEN, load_golden, hamming_ok
 from emul_util import emul_bn128
 from gen_golden_keys import oracle_mul_base
 from wasmsnark_amd import WsnarkError, synth
@@ -274,6 +274,8 @@ def test_default_blinding_is_exposed_and_consistent(orc):
     p2 = bn.groth16GenProof(wit, pkey)
     r2, s2 = bn.last_blinding()
     assert (r1, s1) != (r2, s2) and p1 != p2                       # fresh randomness per proof
+    # the reference's own check of what it drew (test/bn128_prover.js:65-71): 96..160 zeros among the significant bits
+    assert all(hamming_ok(v) for v in (r1, s1, r2, s2)), [v.hex() for v in (r1, s1, r2, s2)]
     assert bn.groth16GenProof(wit, pkey, r=r1, s=s1) == p1
     assert bn.groth16GenProof(wit, pkey, r=r2, s=s2) == p2
     assert orc.groth16_prove(wit, pkey, r1, s1) == p1              # and it is the proof the reference algorithm gives for them

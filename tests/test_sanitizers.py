@@ -1,0 +1,67 @@
+"""Sanitizer runs of the host code and the kernel sources (SURVEY.md section 5 "race detection / sanitizers"; VERDICT r5 "missing" 3):
+the CPU thread-emulator build of the library compiled with -fsanitize=address,undefined and with -fsanitize=thread
+(make -C wasmsnark_amd/csrc emul-san SAN=...), and the tests that exercise what a sanitizer is for -- several host threads on one key
+handle (lanes), groups (one worker thread per context, spin barriers, the in-library exchange), loads / frees / proofs interleaved with
+the background table build, the file loader's mapping and page release, the distributed prover on two gloo ranks -- run under it in
+a child pytest with the sanitizer's runtime preloaded.  Reports go to files (log_path): a passing child with a report is a failure.
+
+Slow (ASan ~4x, TSan ~10x the plain emulator runs): selected with `-m sanitizer` (or WSNARK_SANITIZERS=1), skipped otherwise;
+tools/run_sanitizers.sh runs both and writes profiles/rNN_sanitizers.txt."""
+import glob
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.sanitizer
+
+RUNS = {
+    # what runs under each sanitizer: (test file, -k expression or None)
+    "asan": [("tests/test_group_cpu.py", None),
+             ("tests/test_key_file.py", "not js_writer"),
+             ("tests/test_prove_cpu.py", "two_proofs_in_flight or proofs_before_the_table_rows or staging_ring or key_format_errors or partial_finish or key_falls_back"),
+             ("tests/test_emul_kernels.py", None),
+             ("tests/test_dist_ntt_gloo.py", "native")],
+    "tsan": [("tests/test_prove_cpu.py", "two_proofs_in_flight or proofs_before_the_table_rows"),
+             ("tests/test_group_cpu.py", "terminate_with_a_live_key or errors_are_agreed or (matches_reference and t3)")],
+}
+
+
+def _runtime(name):
+    p = subprocess.run(["gcc", "-print-file-name=lib%s.so" % name], capture_output=True, text=True).stdout.strip()
+    return p if os.path.isabs(p) and os.path.exists(p) else None
+
+
+def run_under(san, file, kexpr, logdir, timeout=5400):
+    os.makedirs(logdir, exist_ok=True)
+    rt = _runtime(san)
+    if rt is None:
+        pytest.skip("lib%s.so not found" % san)
+    env = dict(os.environ, WSNARK_EMUL_SAN=san, LD_PRELOAD=rt, PYTHONMALLOC="malloc")
+    log = os.path.join(logdir, "report")
+    if san == "asan":
+        # (leaks: the host interpreter's own allocations would drown the library's; the library's frees are covered by use-after-free)
+        env["ASAN_OPTIONS"] = "detect_leaks=0:log_path=%s.asan:halt_on_error=0:detect_stack_use_after_return=0" % log
+        env["UBSAN_OPTIONS"] = "log_path=%s.ubsan:print_stacktrace=1" % log
+    else:
+        env["TSAN_OPTIONS"] = "log_path=%s.tsan:halt_on_error=0:report_signal_unsafe=0:second_deadlock_stack=1" % log
+    cmd = [sys.executable, "-m", "pytest", file, "-x", "-q", "-p", "no:cacheprovider", "-m", "not gpu"] + (["-k", kexpr] if kexpr else [])
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    reports = sorted(glob.glob(log + ".*"))
+    return out, reports
+
+
+@pytest.mark.parametrize("san", ["asan", "tsan"])
+def test_emulator_suite_under_sanitizer(san, tmp_path):
+    total = []
+    for file, kexpr in RUNS[san]:
+        out, reports = run_under(san, file, kexpr, str(tmp_path / (san + "_" + os.path.basename(file))))
+        tail = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else ""
+        total.append("%s %s%s: %s; sanitizer reports: %d" % (san, file, " -k '%s'" % kexpr if kexpr else "", tail, len(reports)))
+        print(total[-1], flush=True)
+        detail = "\n".join(open(r).read()[:6000] for r in reports[:3])
+        assert out.returncode == 0, total[-1] + "\n" + out.stdout[-3000:] + out.stderr[-3000:]
+        assert not reports, total[-1] + "\n" + detail

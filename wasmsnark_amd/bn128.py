@@ -259,6 +259,12 @@ class Group:
             if own is not None:
                 own.free()
 
+    def last_blinding(self):
+        """(r, s) of the group's last proof -- the reference's this._pr / this._ps (src/bn128.js:662-664)."""
+        r, s = (C.c_uint8 * 32)(), (C.c_uint8 * 32)()
+        self._lib.check(self._lib.c.wsnark_group_last_blinding(self._h, r, s))
+        return bytes(r), bytes(s)
+
     def _multiexp(self, g, scalars, points):
         sb, sn = _ro(scalars)
         pb, pn = _ro(points)

@@ -5,8 +5,12 @@
 // src/bn128.js:441-453).  The five MSMs and CALC_H run on the GPU with the key resident in
 // HBM; the O(1) tail (5 scalar multiplications, 9 additions, 3 inversions, src/bn128.js:671-712)
 // runs on the host with the same field/curve headers.
+#include <errno.h>
+#include <fcntl.h>
 #include <stdio.h>
 #include <string.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
@@ -411,11 +415,31 @@ static void sum_jac(const uint8_t* pts, uint64_t count, uint8_t* out) {
 void g1_sum_host(const uint8_t* pts, uint64_t count, uint8_t* out96) { sum_jac<G1, Fq>(pts, count, out96); }
 void g2_sum_host(const uint8_t* pts, uint64_t count, uint8_t* out192) { sum_jac<G2, Fq2>(pts, count, out192); }
 
+// The blinding values' entropy: the reference draws crypto.randomBytes(32) twice (src/bn128.js:642-661).  getrandom(2) -- no file
+// descriptor, works in a chroot without /dev, blocks only until the kernel's pool has been seeded once -- with an UNBUFFERED read
+// of /dev/urandom for kernels without the system call (round 5 pulled 4 KiB through stdio for 64 bytes).
 static int os_random(uint8_t* out, size_t n) {
-    FILE* f = fopen("/dev/urandom", "rb");
-    if (!f) return -1;
-    size_t got = fread(out, 1, n, f);
-    fclose(f);
+    size_t got = 0;
+#if defined(__linux__) && defined(SYS_getrandom)
+    while (got < n) {
+        const long r = syscall(SYS_getrandom, out + got, n - got, 0);
+        if (r < 0) {
+            if (errno == EINTR) continue;
+            break;                                   // ENOSYS (kernel < 3.17) or a seccomp filter: the device file below
+        }
+        got += (size_t)r;
+    }
+    if (got == n) return 0;
+#endif
+    const int fd = open("/dev/urandom", O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return -1;
+    while (got < n) {
+        const ssize_t r = read(fd, out + got, n - got);
+        if (r < 0 && errno == EINTR) continue;
+        if (r <= 0) break;
+        got += (size_t)r;
+    }
+    close(fd);
     return got == n ? 0 : -1;
 }
 
@@ -669,7 +693,7 @@ bool last_blinding(uint8_t* r32, uint8_t* s32) {
 static int start_blinding(ProvingKey* K, const uint8_t* r32, const uint8_t* s32, Blinding* B) {
     uint8_t rnd[64];
     if (!r32 || !s32) {
-        if (os_random(rnd, 64)) { set_last_error("cannot read /dev/urandom"); return WS_ERR_ARG; }
+        if (os_random(rnd, 64)) { set_last_error("no entropy: getrandom(2) and /dev/urandom both failed"); return WS_ERR_ARG; }
         if (!r32) r32 = rnd;
         if (!s32) s32 = rnd + 32;
     }
@@ -892,7 +916,7 @@ int groth16_prove_dist(ProvingKey* K, const Fe* d_witness, size_t witness_len, c
     uint8_t hello[kDistHello];
     memset(hello, 0, sizeof hello);
     const uint32_t inj = (r32 ? 1u : 0u) | (s32 ? 2u : 0u);
-    if (!st && inj != 3u && cm.rank == 0 && os_random(hello + 16, 64)) { st = WS_ERR_ARG; st_msg = "cannot read /dev/urandom"; }
+    if (!st && inj != 3u && cm.rank == 0 && os_random(hello + 16, 64)) { st = WS_ERR_ARG; st_msg = "no entropy: getrandom(2) and /dev/urandom both failed"; }
     if (r32) memcpy(hello + 16, r32, 32);
     if (s32) memcpy(hello + 48, s32, 32);
     const uint32_t st_u = (uint32_t)st;

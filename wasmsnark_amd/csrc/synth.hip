@@ -13,6 +13,11 @@
 //             style 0 "columns" (SURVEY.md section 8d C4): every variable occurs in 1-3 rows of A and of B, rows left
 //             empty get one fill-in term; style 1 "rows": 1-2 terms per row among the earlier variables (~40 % of the
 //             variables then never occur in A resp. B: their key points are infinity).
+//             style 2 "boolean" (round 6; what circom's bit decompositions look like): groups of 14 FREE bit variables b_i with
+//             their booleanity rows b_i (b_i - 1) = 0 (A = b_i, B = b_i - w_0, C = 0), one recomposition row
+//             (sum 2^i b_i) * 1 = v and one product row (k v + 1) * p_prev = p per group: 87.5 % of the variables are 0 / 1 in the
+//             witness, 6 % are 14-bit values, 6 % full-size field elements; w_0's B polynomial has an entry in every booleanity
+//             row (one very long column), the v never occur in B (their B1 / B2 points are infinity).
 //   setup     tau, alpha, beta, gamma, delta; a_s = A_s(tau), b_s, c_s through the Lagrange basis over w_n.
 //   key       the discrete logarithm of every key point (the points themselves: wsnark_g{1,2}_mul_base_batch on the GPU).
 //   expected  the discrete logarithms (a, b, c) of the proof for given r, s: a size-independent closed form.
@@ -114,24 +119,63 @@ struct SynthCircuit {
     std::vector<Fe> w;                          // witness, Montgomery
     Fe tau, alpha, beta, gamma, delta, z;       // toxic waste and Z(tau) = tau^n - 1, Montgomery
     std::vector<Fe> a, b, c;                    // a_s(tau), b_s(tau), c_s(tau), Montgomery
+    std::vector<uint32_t> out_row;              // style 2: the row that DEFINES variable s (C holds 1 * s there), or NO_ROW
 };
+static const uint32_t NO_ROW = 0xffffffffu;
+static const uint32_t BOOL_BITS = 14;           // style 2: bits per group
 
 static Fe coef_of(Rng& g) { return Fr::to_mont((g.next() >> 63) ? g.fr_nonzero() : fe_small(1 + g.below(7))); }
 
 static int synth_build(uint32_t log_domain, uint32_t n_public, uint64_t cseed, uint64_t sseed, int style, SynthCircuit* S) {
-    if (log_domain < 2 || log_domain > 27 || (style != 0 && style != 1)) return WS_ERR_ARG;
+    if (log_domain < 2 || log_domain > 27 || style < 0 || style > 2) return WS_ERR_ARG;
     const uint32_t domain = 1u << log_domain;
     if ((uint64_t)n_public + 2 > domain) { set_last_error("synth: domain too small for nPublic"); return WS_ERR_SIZE; }
     S->log_domain = log_domain; S->n_public = n_public; S->domain = domain;
     const uint32_t n_cons = S->n_cons = domain - n_public - 1;
     const uint32_t n_free = S->n_free = n_public + 2;                     // public inputs + two private seeds
-    const uint32_t n_vars = S->n_vars = 1 + n_free + n_cons;
+    // style 2: groups of BOOL_BITS bits + v + p over BOOL_BITS + 2 rows each; rows left over repeat a booleanity row
+    const uint32_t n_groups = style == 2 ? n_cons / (BOOL_BITS + 2) : 0;
+    if (style == 2 && n_groups == 0) { set_last_error("synth: domain too small for the boolean style"); return WS_ERR_SIZE; }
+    const uint32_t n_vars = S->n_vars = style == 2 ? 1 + n_free + n_groups * (BOOL_BITS + 2) : 1 + n_free + n_cons;
     Rng g(cseed);
     S->w.assign(n_vars, Fr::zero());
     S->w[0] = Fr::one();
     for (uint32_t i = 1; i <= n_free; i++) S->w[i] = Fr::to_mont((i % 3) ? g.fr_nonzero() : fe_small(1 + g.below(0xffffffffull)));
     std::vector<Triplet> tA, tB;
-    if (style == 0) {
+    if (style == 2) {
+        S->out_row.assign(n_vars, NO_ROW);
+        const Fe one = Fr::one(), minus_one = Fr::neg(Fr::one());
+        tA.reserve((size_t)n_cons * 2); tB.reserve((size_t)n_cons * 2);
+        uint32_t row = 0, p_prev = n_free;                                // (the last private seed starts the product chain)
+        for (uint32_t gi = 0; gi < n_groups; gi++) {
+            const uint32_t b0 = 1 + n_free + gi * (BOOL_BITS + 2), v = b0 + BOOL_BITS, pv = v + 1;
+            uint64_t bits = g.next();
+            if (gi % 5 == 4) bits &= g.next() & g.next();                 // every fifth group sparse in ones: values of 0 dominate there
+            for (uint32_t i = 0; i < BOOL_BITS; i++) {
+                const uint32_t b = b0 + i;
+                S->w[b] = ((bits >> i) & 1) ? one : Fr::zero();
+                tA.push_back(Triplet{b, row, one});                       // b * (b - 1) = 0
+                tB.push_back(Triplet{b, row, one});
+                tB.push_back(Triplet{0, row, minus_one});
+                row++;
+            }
+            for (uint32_t i = 0; i < BOOL_BITS; i++) tA.push_back(Triplet{b0 + i, row, Fr::to_mont(fe_small((uint64_t)1 << i))});
+            tB.push_back(Triplet{0, row, one});                           // (sum 2^i b_i) * 1 = v
+            S->out_row[v] = row++;
+            tA.push_back(Triplet{v, row, coef_of(g)});                    // (k v + 1) * p_prev = p  (+ 1: a recomposed 0 must not end the chain)
+            tA.push_back(Triplet{0, row, one});
+            tB.push_back(Triplet{p_prev, row, one});
+            S->out_row[pv] = row++;
+            p_prev = pv;
+        }
+        while (row < n_cons) {                                            // left-over rows: one more booleanity row of some bit
+            const uint32_t b = 1 + n_free + (uint32_t)g.below(n_groups) * (BOOL_BITS + 2) + (uint32_t)g.below(BOOL_BITS);
+            tA.push_back(Triplet{b, row, one});
+            tB.push_back(Triplet{b, row, one});
+            tB.push_back(Triplet{0, row, minus_one});
+            row++;
+        }
+    } else if (style == 0) {
         for (int m = 0; m < 2; m++) {
             std::vector<Triplet>& t = m ? tB : tA;
             t.reserve((size_t)n_vars * 5 / 2);
@@ -183,7 +227,17 @@ static int synth_build(uint32_t log_domain, uint32_t n_public, uint64_t cseed, u
         }
         return acc;
     };
-    for (uint32_t c = 0; c < n_cons; c++) S->w[1 + n_free + c] = Fr::mul(row_dot(S->A, c), row_dot(S->B, c));
+    if (style == 2) {
+        std::vector<uint32_t> var_of_row((size_t)n_cons, NO_ROW);
+        for (uint32_t s = 0; s < n_vars; s++) if (S->out_row[s] != NO_ROW) var_of_row[S->out_row[s]] = s;
+        for (uint32_t c = 0; c < n_cons; c++) {
+            const Fe prod = Fr::mul(row_dot(S->A, c), row_dot(S->B, c));
+            if (var_of_row[c] != NO_ROW) S->w[var_of_row[c]] = prod;
+            else if (!Fr::is_zero(prod)) { set_last_error("synth: a booleanity row is not satisfied"); return WS_ERR_ARG; }
+        }
+    } else {
+        for (uint32_t c = 0; c < n_cons; c++) S->w[1 + n_free + c] = Fr::mul(row_dot(S->A, c), row_dot(S->B, c));
+    }
     // ---- setup ----
     Rng t(sseed);
     S->tau = Fr::to_mont(t.fr_nonzero()); S->alpha = Fr::to_mont(t.fr_nonzero()); S->beta = Fr::to_mont(t.fr_nonzero());
@@ -222,7 +276,8 @@ static int synth_build(uint32_t log_domain, uint32_t n_public, uint64_t cseed, u
                 for (uint64_t k = M.col_ptr[s]; k < M.col_ptr[s + 1]; k++) acc = Fr::add(acc, Fr::mul(M.coef[k], L[M.row[k]]));
                 (m ? S->b : S->a)[s] = acc;
             }
-            if (s >= (uint64_t)1 + n_free) S->c[s] = L[s - 1 - n_free];      // C: row c holds 1 * (its output variable)
+            if (style == 2) { if (S->out_row[s] != NO_ROW) S->c[s] = L[S->out_row[s]]; }
+            else if (s >= (uint64_t)1 + n_free) S->c[s] = L[s - 1 - n_free];      // C: row c holds 1 * (its output variable)
         }
     });
     return WS_OK;

@@ -293,7 +293,7 @@ class NativeCircuit:
     def __init__(self, lib, log_domain, n_public=2, seed=1, setup_seed=None, style="columns"):
         import ctypes as C
         self._lib, self._h = lib, C.c_void_p()
-        st = {"columns": 0, "rows": 1}[style]
+        st = {"columns": 0, "rows": 1, "boolean": 2}[style]      # "boolean": bit decompositions, 87.5 % of the witness 0 / 1 (csrc/synth.hip)
         lib.check(lib.c.wsnark_synth_new(log_domain, n_public, seed, seed + 1 if setup_seed is None else setup_seed, st, C.byref(self._h)))
         inf = _SynthInfo()
         lib.check(lib.c.wsnark_synth_info(self._h, C.byref(inf)))
