@@ -351,6 +351,20 @@ __global__ __launch_bounds__(256) void probe_modmul_kernel(const Fe* __restrict_
     for (int i = 0; i < iters; i++) x = F::mul(x, y);
     out[t] = F::from_internal(x);
 }
+// probes 301..308 (G1) / 401..408 (G2): the accumulation loop's own mixed addition (curve.h madd_wide, the inlined radix-2^29 field) on
+// points held in REGISTERS -- no gather, no task list -- at 1..8 wavefronts per SIMD: what msm_accumulate would reach if memory cost
+// nothing.  G lane-additions per second.
+template <class C>
+__global__ __launch_bounds__(256) void probe_madd_kernel(const typename C::AffP* __restrict__ in, typename C::PtP* __restrict__ out, int iters) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const typename C::Aff p0 = C::unpack_aff(in[0]), p1 = C::unpack_aff(in[1]);
+    typename C::Pt acc = C::infinity();
+    for (int i = 0; i < iters; i++) {
+        C::madd_wide(acc, (i + t) & 1 ? p0 : p1, (t & 4) != 0);
+    }
+    C::narrow_x(acc);
+    out[t] = C::pack_pt(acc);
+}
 template <class F>
 __global__ __launch_bounds__(256) void probe_modmul2_kernel(const Fe* __restrict__ in, Fe* __restrict__ out, int iters) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -571,6 +585,49 @@ static void launch_issue_probe(int cls, uint32_t blocks, uint32_t threads, hipSt
 static void launch_issue_probe(int, uint32_t, uint32_t, hipStream_t, uint64_t*, int) {}       // (inline assembly: device only)
 #endif
 
+template <class Cv>
+static int madd_probe_t(Context* C, int waves, double* gops) {
+    hipStream_t s = C->stream;
+#ifdef WSNARK_EMUL
+    const uint32_t blocks = 1, iters = 3;
+#else
+    const uint32_t blocks = (uint32_t)C->num_cu * (uint32_t)waves, iters = 400;
+#endif
+    const uint32_t total = blocks * 256;
+    // two "points": arbitrary reduced field elements as coordinates -- the mixed addition never tests curve membership, and a
+    // timing probe only needs the generic path (no operand ever equals the accumulator)
+    typename Cv::AffP hp[2];
+    memset(&hp[0], 0x11, sizeof hp[0]);
+    memset(&hp[1], 0x23, sizeof hp[1]);
+    DevBuf in, out;
+    WS_HIP_CHECK(in.alloc(sizeof hp));
+    WS_HIP_CHECK(out.alloc((size_t)total * sizeof(typename Cv::PtP)));
+    WS_HIP_CHECK(hipMemcpyAsync(in.p, hp, sizeof hp, hipMemcpyHostToDevice, s));
+    WS_HIP_CHECK(hipStreamSynchronize(s));
+    hipEvent_t a = nullptr, b = nullptr;
+    WS_HIP_CHECK(hipEventCreate(&a));
+    WS_HIP_CHECK(hipEventCreate(&b));
+    double best = 0;
+    for (int rep = 0; rep < 3; rep++) {
+        (void)hipEventRecord(a, s);
+        hipLaunchKernelGGL(probe_madd_kernel<Cv>, dim3(blocks), dim3(256), 0, s, in.as<typename Cv::AffP>(), out.as<typename Cv::PtP>(), (int)iters);
+        (void)hipEventRecord(b, s);
+        if (hipEventSynchronize(b) != hipSuccess) break;
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, a, b);
+        const double ops = (double)iters * total;
+        if (rep && ms > 0 && ops / ms / 1e6 > best) best = ops / ms / 1e6;
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    WS_HIP_CHECK(hipGetLastError());
+    *gops = best;
+    return WS_OK;
+}
+static int madd_probe(Context* C, int g, int waves, double* gops) {
+    return g == 2 ? madd_probe_t<G2R29>(C, waves, gops) : madd_probe_t<G1R29I>(C, waves, gops);
+}
+
 int peak_probe(int probe, double* gops) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
@@ -578,6 +635,7 @@ int peak_probe(int probe, double* gops) {
     // the product's dependent multiply-add chain reaches at the occupancy of the accumulation kernels (G1: 3, G2: 2).
     // probes 201..208: the same with TWO independent product chains per lane, interleaved by the compiler.
     int waves = 8, chains = 1;
+    if ((probe >= 301 && probe <= 308) || (probe >= 401 && probe <= 408)) return madd_probe(C, probe >= 401 ? 2 : 1, probe % 100, gops);
     if (probe >= 101 && probe <= 108) { waves = probe - 100; probe = 1; }
     else if (probe >= 201 && probe <= 208) { waves = probe - 200; probe = 1; chains = 2; }
     if (!gops || probe < 0 || probe > 28 || probe == 15) return WS_ERR_ARG;
