@@ -52,13 +52,18 @@ def kernel_ms(report, per=1):
     return {k: round(v[0] / max(per, 1), 4) for k, v in sorted(report.items())}
 
 
-def build_prover(bn, logd, style, seed=1, keep_h=False, container="auto", load=True, cold_probe=False):
+def build_prover(bn, logd, style, seed=1, keep_h=False, container="auto", load=True, cold_probe=False, sections=True):
     """Synthetic circuit + key (device-resident) + witness bytes.  Keys past the 4 GiB of proving_key.bin's u32 offsets
     (2^23 constraints and up) go through the sections loader.  The circuit comes from the library's host-side generator
     (csrc/synth.hip; same family as wasmsnark_amd/synth.py's Python generator, seconds instead of minutes)."""
     from wasmsnark_amd import synth
     t0 = time.perf_counter()
     circ = synth.NativeCircuit(bn.lib, logd, n_public=5, seed=seed, style=style)
+    if not sections:      # (--key-file, ranks > 0: the key comes from the file rank 0 writes; only the witness and the closed form are needed here)
+        info = {"log_domain": logd, "n_vars": circ.n_vars, "n_public": circ.n_public, "nnz_A_plus_B": int(circ.nnz), "style": style,
+                "vars_absent_from_A_B": [int(x) for x in circ.absent], "key_bytes": None, "key_container": "WSNARK64 file written by rank 0",
+                "generator": "csrc/synth.hip (wsnark_synth_*)", "setup_s": round(time.perf_counter() - t0, 1), "_cold": {}, "_sections": None}
+        return circ, None, circ.witness_bin(), info
     sec, _ = circ.build_sections()
     use_sections = container == "sections" or (container == "auto" and logd >= 23)
     t1 = time.perf_counter()
@@ -121,6 +126,10 @@ def main():
     ap.add_argument("--circuit", choices=["columns", "rows"], default="columns")
     ap.add_argument("--key-container", choices=["auto", "file", "sections"], default="auto",
                     help="proving_key.bin (u32 offsets: up to 4 GiB) or the section container (wsnark_pkey_load_sections); auto = sections from 2^23")
+    ap.add_argument("--key-file", default="", help="N>1 (per-process ranks): rank 0 writes the key ONCE as a WSNARK64 container file (the u64-offset "
+                                                     "form of proving_key.bin) and every rank maps it and reads only its shard (wsnark_pkey_load_file) -- instead "
+                                                     "of every rank generating and holding the whole key in host memory.  'auto' = a file under $WSNARK_BENCH_KEY_DIR "
+                                                     "or the temp directory; or a path on a file system all ranks see")
     ap.add_argument("--log-n", type=int, default=20, help="--workload msm / extras: pairs per MSM")
     ap.add_argument("--extras", default="msm,ntt,cold,inflight,sparse,node", help="comma list (N=1 only): msm, ntt, cold, inflight, sparse, node")
     ap.add_argument("--no-extras", action="store_true")
@@ -403,7 +412,9 @@ def bench_prove(ctx):
     args, bn, rank, world, dev, torch = ctx["args"], ctx["bn"], ctx["rank"], ctx["world"], ctx["dev"], ctx["torch"]
     from wasmsnark_amd import dist as wdist, synth
     logd = args.prove_log_domain
-    circ, key, wit, info = build_prover(bn, logd, args.circuit, container=args.key_container, load=(world == 1), cold_probe=(world == 1))
+    use_file = bool(args.key_file) and world > 1
+    circ, key, wit, info = build_prover(bn, logd, args.circuit, container=args.key_container, load=(world == 1), cold_probe=(world == 1),
+                                        sections=not (use_file and rank != 0))
     info.pop("h_points", None)
     cold = info.pop("_cold")
     sec = info.pop("_sections", None)
@@ -426,23 +437,42 @@ def bench_prove(ctx):
     # N > 1: a ladder of orchestrations, each checked against the closed form on EVERY rank before it is timed.  None of them
     # had run on RCCL when this was written (the build's boxes have one GPU; they are tested on gloo, with ranks sharing a
     # GPU, and with a world of one): a mode that fails or disagrees anywhere falls through to the next and the line says so.
-    holder = {"key": key, "npv": None, "dp": None}
+    holder = {"key": key, "npv": None, "dp": None, "sec": sec}
+    key_file = None
+    if use_file:
+        import tempfile
+        from wasmsnark_amd import formats
+        key_file = args.key_file if args.key_file != "auto" else os.path.join(os.environ.get("WSNARK_BENCH_KEY_DIR") or tempfile.gettempdir(),
+                                                                              "wsnark_bench_key_2p%d_%s.wsnark64" % (logd, args.circuit))
+        if rank == 0:
+            t_w = time.perf_counter()
+            nbytes = formats.write_key_container(sec, key_file)
+            info["key_file"] = {"path": key_file, "bytes": nbytes, "write_s": round(time.perf_counter() - t_w, 2),
+                                "what": "WSNARK64 container written once by rank 0; every rank maps it and reads only its shard (wsnark_pkey_load_file)"}
+            info["key_container"] = "WSNARK64 file, points-sharded per rank"
+        ctx["dist"].barrier()
+
+    def sections():      # (the fall-back orchestrations want the whole key: ranks that never generated it read the file)
+        if holder["sec"] is None:
+            from wasmsnark_amd import formats
+            holder["sec"] = formats.read_key_container(key_file)
+        return holder["sec"]
 
     def whole_key():
         if holder["key"] is None:
-            holder["key"] = bn.load_key(sections=sec)
+            holder["key"] = bn.load_key(sections=sections())
         return holder["key"]
 
     def mode_native():
         if "native" in os.environ.get("WSNARK_BENCH_FAIL", "").split(","):       # (tests: exercise the fall-through)
             raise RuntimeError("forced by WSNARK_BENCH_FAIL")
-        holder["npv"] = wdist.NativeDistProver(bn, sec, device=dev)
+        holder["npv"] = wdist.NativeDistProver(bn, device=dev, path=key_file) if key_file else wdist.NativeDistProver(bn, sec, device=dev)
         return lambda: holder["npv"].prove(d_w.data_ptr(), len(wit), r=r32, s=s32)
 
     def mode_dist():
         if "dist" in os.environ.get("WSNARK_BENCH_FAIL", "").split(","):
             raise RuntimeError("forced by WSNARK_BENCH_FAIL")
-        holder["dp"] = wdist.DistProver(bn, whole_key(), bytes(sec["pointsH"]), device=dev)
+        holder["dp"] = wdist.DistProver(bn, whole_key(), bytes(sections()["pointsH"]), device=dev)
         return lambda: holder["dp"].prove(d_w.data_ptr(), len(wit), r=r32, s=s32)
 
     def mode_replicated():

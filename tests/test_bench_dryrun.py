@@ -64,6 +64,22 @@ def test_bench_two_ranks_line():
     assert "modmul_G_per_s" in d["int_alu_peaks_this_run"]          # the N > 1 line keeps the integer peak of its own run
 
 
+def test_bench_two_ranks_from_a_key_file(tmp_path):
+    """--key-file: rank 0 writes the key once as a WSNARK64 container, every rank maps it and reads only its shard
+    (wsnark_pkey_load_file) -- the N > 1 launch that does not need the whole key in every rank's host memory."""
+    from emul_util import emul_bn128
+    emul_bn128()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29661", os.path.join(ROOT, "tools", "bench_dryrun.py"), "--gpus", "2", "--prove-log-domain", "6",
+                          "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--key-file", "auto"],
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1", WSNARK_BENCH_KEY_DIR=str(tmp_path)))
+    d = _line(out)
+    assert d["n_gpus"] == 2 and d["proofs_match_toxic_waste_closed_form"] is True
+    assert "wsnark_groth16_prove_dist" in d["config"]["parallelism"] and "fell through" not in d["config"]["parallelism"]
+    kf = d["config"]["circuit"]["key_file"]
+    assert os.path.getsize(kf["path"]) == kf["bytes"] and d["config"]["circuit"]["key_container"].startswith("WSNARK64 file")
+
+
 def test_bench_two_ranks_falls_through_when_an_orchestration_fails():
     """None of the N > 1 orchestrations has run on RCCL in the build container: bench.py checks each one against the closed form on
     every rank and falls through native -> Python (DistProver) -> replicated CALC_H.  Forced here: the native mode fails on every

@@ -1373,7 +1373,7 @@ static int msm_acc_sets(Lane& L, MsmPending* const* Ps, int nsets, int which, hi
     T.begin(which ? "msm_accumulate_g2" : "msm_accumulate_g1", s);
     // (Round 6, measured and dropped: capping the kernel at two workgroups per CU with unused dynamic LDS -- 2 wavefronts per SIMD, 240
     //  VGPRs per SIMD left for the other queue's tail / grouping kernels to move in beside it -- changed neither the kernel alone nor
-    //  the two-queue proof: profiles/r06_acc_occupancy_ab.txt.)
+    //  the two-queue proof; the G2 kernel at ONE wavefront per SIMD (280 registers left) was 0.1-0.4 ms slower: profiles/r06_acc_occupancy_ab.txt.)
     hipLaunchKernelGGL(msm_accumulate<C>, dim3(ceil_div_u64(ntasks, 256), ny), dim3(256), 0, s, as);
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
