@@ -28,6 +28,10 @@ def test_group_vectors(bn, orc, g, impl):
     pc.check_group(bn, orc, g, impl)
 
 
+def test_paired_g1_tail_curve(bn, orc):
+    pc.check_group_pair_g1(bn, orc)
+
+
 def test_unsupported_ops_are_errors(bn):
     with pytest.raises(Exception):
         pc.st_field(bn, 2, 0, pc.INVERSE, [bytes(64)], [bytes(64)])     # the extension field is inverted on the host only

@@ -35,3 +35,7 @@ def test_fq2_vectors_on_device(bn, impl):
 @pytest.mark.parametrize("g,impl", [(g, i) for g in (1, 2) for i in pc.CURVE_IMPLS[g]])
 def test_group_vectors_on_device(bn, orc, g, impl):
     pc.check_group(bn, orc, g, impl)
+
+
+def test_paired_g1_tail_curve_on_device(bn, orc):
+    pc.check_group_pair_g1(bn, orc)

@@ -16,9 +16,11 @@ issue_probe.py) showed to decide a wave64 VALU instruction's cost on gfx950 -- n
   select_run v_cndmask_b32_e32 in runs of three or more (the members beyond the second): ~20 cycles each back to back on a standing
              vcc, 2 when other instructions sit between them -- counted apart so that a kernel with long runs shows it
 
-The counts are STATIC (an instruction inside a loop counts once).  A kernel's non-inlined callees (the Montgomery products of the
-transform and tail kernels: `s_swappc_b64`) are added once per call site, so the mix is that of a stream in which every static
-instruction of the body runs equally often -- what the hot loops of this library are.  bench.py / tools/pmc_counters.py /
+The counts are STATIC, weighted by LOOP DEPTH: the compiler annotates every basic block with the depth of the loop it belongs to, and an
+instruction at depth d counts 16^d times -- so the mix of a kernel with a loop is the mix of its loop body (the accumulation's
+per-addition code, not its prologue; the fixed-base helper's double-and-add, not its setup).  A kernel's non-inlined callees (the
+Montgomery products of the transform and tail kernels: `s_swappc_b64`) are added per call site with the site's weight.  The columns
+of the table are the unweighted counts; `mix` in the JSON is the weighted share.  bench.py / tools/pmc_counters.py /
 tools/pmc_proof_budget.py multiply the mix by the DYNAMIC total (SQ_INSTS_VALU) and divide by each class's measured rate.
 
 Usage: python tools/isa_histogram.py [--json] > profiles/rNN_isa_classes.{md,json}"""
@@ -108,22 +110,36 @@ def one(src):
         name, body = m.group(1), m.group(2)
         lines = [l for l in body.splitlines() if l.startswith("\t") and l.split() and not l.strip().startswith((".", ";"))]
         h = dict.fromkeys(CLASSES, 0)
-        run = 0
-        for l in lines:
+        hw = dict.fromkeys(CLASSES, 0.0)          # the same, every instruction weighted 16^(loop depth of its block)
+        run, depth, calls_w = 0, 0, 0.0
+        for raw in body.splitlines():
+            mlab = re.match(r"^\.LBB\w+:\s*(;.*)?$", raw)
+            if mlab:                                # a block label: "; =>This Inner Loop Header: Depth=1" / ";   in Loop: Header=BB3_6 Depth=2" / none
+                md = re.findall(r"Depth=(\d+)", raw)
+                depth = max(int(x) for x in md) if md else 0
+                continue
+            if not raw.startswith("\t") or not raw.split() or raw.strip().startswith((".", ";")):
+                continue
+            l, w = raw, 16.0 ** depth
             op = l.split()[0]
+            if op.startswith("s_swappc"):
+                calls_w += w
             if not op.startswith("v_"):
                 if not op.startswith(("s_nop", "s_waitcnt")):
                     run = 0 if not op.startswith("s_") else run      # (scalar instructions issue from another port: a run survives them)
                 continue
             if op.startswith("v_cndmask_b32_e32"):
                 run += 1
-                h["select_run" if run >= 3 else "fast"] += 1
-                continue
-            run = 0
-            h[classify(l)] += 1
+                c = "select_run" if run >= 3 else "fast"
+            else:
+                run = 0
+                c = classify(l)
+            h[c] += 1
+            hw[c] += w
         ops = [l.split()[0] for l in lines]
         callees = re.findall(r"(_ZN6wsnark\w+)@rel32@lo", body)
-        rows[name] = {"src": src, "name": name, "kernel": name in kernels, "classes": h, "valu": sum(h.values()), "all": len(ops),
+        rows[name] = {"src": src, "name": name, "kernel": name in kernels, "classes": h, "weighted": hw, "calls_weight": calls_w,
+                      "valu": sum(h.values()), "all": len(ops),
                       "calls": sum(1 for o in ops if o.startswith("s_swappc")), "callees": callees,
                       "salu": sum(1 for o in ops if o.startswith("s_") and not o.startswith(("s_waitcnt", "s_nop"))),
                       "s_nop": sum(1 for o in ops if o.startswith("s_nop")),
@@ -131,12 +147,12 @@ def one(src):
                       "lds": sum(1 for o in ops if o.startswith("ds_"))}
     # a kernel's calls: dealt to the callees it references, in proportion to the references (one reference may serve several sites)
     for r in rows.values():
-        r["with_callees"] = dict(r["classes"])
+        r["with_callees"] = dict(r["weighted"])
         refs = [c for c in r["callees"] if c in rows and not rows[c]["kernel"]]
         if r["calls"] and refs:
             for c in set(refs):
-                share = r["calls"] * refs.count(c) / len(refs)
-                for k, v in rows[c]["classes"].items():
+                share = r["calls_weight"] * refs.count(c) / len(refs)
+                for k, v in rows[c]["classes"].items():      # (the callees are straight-line products: unweighted counts)
                     r["with_callees"][k] += v * share
         r["valu_with_callees"] = sum(r["with_callees"].values())
     return list(rows.values())
@@ -163,7 +179,7 @@ def as_json(rows):
         out.setdefault(r["pmc_name"], {"function": r["short"], "src": r["src"], "static_valu": r["valu"], "static_valu_with_callees": round(tot, 1),
                                        "call_sites": r["calls"], "mix": {k: round(v / tot, 5) for k, v in r["with_callees"].items()},
                                        "salu": r["salu"], "s_nop": r["s_nop"], "mem": r["mem"], "lds": r["lds"]})
-    return {"how": "tools/isa_histogram.py: static VALU mix per kernel by issue class, non-inlined callees added once per call site",
+    return {"how": "tools/isa_histogram.py: static VALU mix per kernel by issue class, instructions weighted 16^(loop depth), non-inlined callees added per call site with the site's weight",
             "classes": CLASSES, "probe_of_class": PROBE_OF, "kernels": out}
 
 
@@ -173,8 +189,9 @@ def main():
         print(json.dumps(as_json(rows), indent=1))
         return
     print("Static VALU instruction mix per device function, by issue class (tools/isa_histogram.py -- the classes and what decides them")
-    print("are in that file's header).  `calls` = non-inlined product calls in the body; the last columns add the callees once per call site.\n")
-    print("| source | function | kernel | VALU | " + " | ".join(CLASSES) + " | calls | VALU with callees | slow share with callees | SALU | s_nop | mem | LDS |")
+    print("are in that file's header).  `calls` = non-inlined product calls in the body.  `slow share` = the share of the LOOP-WEIGHTED stream (callees")
+    print("included) that is not in the 2-cycle class -- what the issue model prices.\n")
+    print("| source | function | kernel | VALU | " + " | ".join(CLASSES) + " | calls | weighted stream (relative) | slow share | SALU | s_nop | mem | LDS |")
     print("|---|---|---|---|" + "---|" * (len(CLASSES) + 7))
     for r in rows:
         tot = r["valu_with_callees"] or 1

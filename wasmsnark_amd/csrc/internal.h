@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "curve.h"
+#include "curve_pair.h"
 #include "rt.h"
 
 namespace wsnark {

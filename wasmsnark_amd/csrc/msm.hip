@@ -729,6 +729,7 @@ __global__ __launch_bounds__(256) void msm_chunks(TailSets<C> ts, uint32_t nchun
 // ---------------------------------------------------------------------------
 // (one lane per 256-byte G2 point: 256 threads at most, so that a wavefront may use the whole register file)
 template <class C> struct TreeBound { static constexpr int value = (PointIO<C>::LPP == 1 && sizeof(typename PointIO<C>::Stored) > 128) ? 256 : 512; };
+template <class B> struct TreeBound<CurvePairG1<B>> { static constexpr int value = 1024; };      // 512 slots of two lanes (115 VGPRs: two workgroups' worth of wavefronts per SIMD)
 template <class C>
 __global__ __launch_bounds__(TreeBound<C>::value) void msm_tree(TailSets<C> ts, uint32_t J, uint32_t logJ, uint32_t to_ref, uint32_t nsum) {
     typedef PointIO<C> IO;
@@ -1467,13 +1468,18 @@ static int msm_launch_acc(Lane& L, int which, const typename H::Aff* d_points_re
 
 // reduction tail (chunks, trees, [piece reduction,] copy of the rows, completion event) for up to 4 launches of one geometry.
 // G1 runs on the curve variant with inlined products, G2 on the lane-paired curve (fp2.h; same buffers, same results).
-template <class C> struct TailCurve { typedef C type; };
-template <> struct TailCurve<G1R29> { typedef G1R29I type; };
-template <> struct TailCurve<G2R29> { typedef G2P29 type; };
-template <class C>
+template <class C> struct TailCurve { typedef C type; typedef C paired; };
+template <> struct TailCurve<G1R29> { typedef G1R29I type; typedef G1P29 paired; };      // (round 6: one G1 point on two lanes, curve_pair.h)
+template <> struct TailCurve<G2R29> { typedef G2P29 type; typedef G2P29 paired; };
+// WSNARK_TAIL_PAIR_G1 (default 1): the G1 reduction tails on lane pairs -- seven product steps per addition instead of fourteen
+static bool tail_pair_g1() { return tuning_get("TAIL_PAIR_G1", 1) != 0; }
+// CC: the curve of msm_chunks (throughput-bound: 2 additions per bucket on every lane of the chip -- the one-lane form is the cheaper
+// one there), C: the curve of msm_tree / msm_rows (latency-bound LDS reductions: the lane-paired forms halve every step).  Same buffers.
+template <class C, class CC = C>
 static int msm_launch_tail(Lane& L, const int* slot_ids, int nslots, hipStream_t s) {
     typedef PointIO<C> IO;
     typedef typename IO::Stored St;
+    static_assert(sizeof(typename PointIO<CC>::Stored) == sizeof(St), "the chunk and tree kernels share their buffers");
     Context* X = ctx();
     if (!s) s = L.stream;
     MsmPending* slots = ws(L).slot;
@@ -1495,7 +1501,12 @@ static int msm_launch_tail(Lane& L, const int* slot_ids, int nslots, hipStream_t
     const uint32_t J = I.J, logJ = I.logJ, nsum = I.nsum, m = I.m, LPP = IO::LPP, W = I.tW;
     KernelTimer& T = X->timer;
     T.begin("msm_chunks", s);
-    hipLaunchKernelGGL(msm_chunks<C>, dim3(ceil_div_u64((uint64_t)W * J * LPP, 256), nslots), dim3(256), 0, s, ts, W * J, m);
+    {
+        TailSets<CC> tc;
+        static_assert(sizeof tc == sizeof ts, "same pointers");
+        memcpy(&tc, &ts, sizeof tc);
+        hipLaunchKernelGGL(msm_chunks<CC>, dim3(ceil_div_u64((uint64_t)W * J * PointIO<CC>::LPP, 256), nslots), dim3(256), 0, s, tc, W * J, m);
+    }
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
     // one slot per element of the longest strided sum (J/2 for the masked rows); 256 slots per workgroup (at 152 VGPRs a 512-thread
@@ -1504,7 +1515,7 @@ static int msm_launch_tail(Lane& L, const int* slot_ids, int nslots, hipStream_t
     // (512 slots where the whole launch is one round of workgroups anyway -- a single G1 set at full size: 16 rows x 16 pieces --:
     //  4 + 9 dependent additions per lane instead of 8 + 8)
     const uint32_t tree_wgs = (logJ + 2 * (nsum - logJ)) * W * (uint32_t)nslots;
-    const uint32_t smax = (LPP == 1 && tree_wgs <= 256) ? 512 : 256;
+    const uint32_t smax = ((LPP == 1 || TreeBound<C>::value >= 1024) && tree_wgs <= 256) ? 512 : 256;
     while (tslots < (J > 1 ? J / 2 : 1) && tslots < smax && tslots * LPP < (uint32_t)TreeBound<C>::value) tslots <<= 1;
     T.begin("msm_tree", s);
     hipLaunchKernelGGL(msm_tree<C>, dim3(logJ + 2 * (nsum - logJ), W, nslots), dim3(tslots * LPP), (size_t)tslots * sizeof(St), s, ts, J, logJ, I.reduce ? 0u : 1u,
@@ -1536,7 +1547,8 @@ static int msm_launch(Lane& L, int which, const typename H::Aff* d_points_ref, b
     if (!s) s = L.stream;
     int rc = msm_launch_acc<C, H>(L, which, d_points_ref, prepared, slot_out, s);
     if (rc) return rc;
-    rc = msm_launch_tail<typename TailCurve<C>::type>(L, slot_out, 1, s);
+    rc = tail_pair_g1() ? msm_launch_tail<typename TailCurve<C>::paired, typename TailCurve<C>::type>(L, slot_out, 1, s)
+                        : msm_launch_tail<typename TailCurve<C>::type>(L, slot_out, 1, s);
     if (rc) msm_abort_slots(L, slot_out, 1, s, nullptr);
     return rc;
 }
@@ -1568,7 +1580,8 @@ int msm_g1_launch_batch(Lane& L, const Affine<Fq>* const* d_points, int nsets, b
         for (int k = 0; k < nsets; k++) Ps[k] = &M.slot[slots[k]];
         rc = msm_acc_sets<G1R29>(L, Ps, nsets, 0, s);
     }
-    if (!rc) rc = msm_launch_tail<TailCurve<G1R29>::type>(L, slots, nsets, s);
+    if (!rc) rc = tail_pair_g1() ? msm_launch_tail<TailCurve<G1R29>::paired, TailCurve<G1R29>::type>(L, slots, nsets, s)
+                                 : msm_launch_tail<TailCurve<G1R29>::type>(L, slots, nsets, s);
     if (rc) msm_abort_slots(L, slots, nsets, s, nullptr);
     return rc;
 }

@@ -269,6 +269,43 @@ __global__ __launch_bounds__(64) void st_curve_pair_kernel(int op, const Fe* __r
     out[8 * i + h] = r.x; out[8 * i + 2 + h] = r.y; out[8 * i + 4 + h] = r.zz; out[8 * i + 6 + h] = r.zzz;
     if (!ok) *bad = 1;
 }
+// the paired G1 curve (curve_pair.h: CurvePairG1): two lanes per vector, lo = (X, ZZ), hi = (Y, ZZZ); ops 0 (add), 1 (double), 3 (copy)
+__global__ __launch_bounds__(64) void st_curve_pair_g1_kernel(int op, const Fe* __restrict__ p, const Fe* __restrict__ q, Fe* __restrict__ out,
+                                                                uint64_t n, int* __restrict__ bad) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = t >> 1;
+    const uint32_t h = (uint32_t)(t & 1);
+    if (i >= n) return;
+    typedef G1R29I C;
+    typedef C::Field F;
+    auto from_jac = [](const Fe* j) -> C::Pt {                    // both lanes build the whole point, then keep their half
+        const F::El z = F::to_internal(j[2]);
+        if (F::is_zero(z)) return C::infinity();
+        const F::El zz = F::sqr(z);
+        return C::Pt{F::to_internal(j[0]), F::to_internal(j[1]), zz, F::mul(zz, z)};
+    };
+    const G1P29::Pt a = G1P29::split(from_jac(p + 3 * i)), b = G1P29::split(from_jac(q + 3 * i));
+    G1P29::Pt r = G1P29::infinity();
+    if (op == 0) r = G1P29::add(a, b);
+    else if (op == 1) r = G1P29::dbl(a);
+    else if (op == 3) r = a;
+    else *bad = 1;
+    out[4 * i + h] = F::from_internal(r.a);                       // x | y
+    out[4 * i + 2 + h] = F::from_internal(r.b);                   // zz | zzz
+}
+static int st_curve_pair_g1_dev(int op, const uint8_t* p, const uint8_t* q, uint8_t* out, uint64_t n, hipStream_t s) {
+    StBufs B;
+    int rc = B.up(p, q, n * 96, n * 128, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(st_curve_pair_g1_kernel, dim3(ceil_div_u64(2 * n, 64)), dim3(64), 0, s, op, B.a.as<Fe>(), B.b.as<Fe>(), B.out.as<Fe>(), n, B.bad.as<int>());
+    std::vector<G1::Pt> host(n);
+    if ((rc = B.down(reinterpret_cast<uint8_t*>(host.data()), n * sizeof(G1::Pt), s))) return rc;
+    for (uint64_t i = 0; i < n; i++) {
+        auto j = G1::to_affine_jac(host[i]);
+        memcpy(out + i * sizeof j, &j, sizeof j);
+    }
+    return WS_OK;
+}
 static int st_curve_pair_dev(int op, const uint8_t* p, const uint8_t* q, uint8_t* out, uint64_t n, hipStream_t s) {
     StBufs B;
     int rc = B.up(p, q, n * 192, n * 256, s);
@@ -323,6 +360,7 @@ int selftest_curve(int g, int impl, int op, const uint8_t* p, const uint8_t* q, 
     if (!X) return WS_ERR_NOINIT;
     if (n == 0) return WS_OK;
     if (n > (1u << 20) || op < 0 || op > 8 || (op == 8 && impl == 4)) return WS_ERR_ARG;
+    if (g == 1 && impl == 5) return (op == 0 || op == 1 || op == 3) ? st_curve_pair_g1_dev(op, p, q, out, n, X->stream) : (int)WS_ERR_ARG;
     hipStream_t s = X->stream;
     if (g == 1) {
         if (impl == 0) return st_curve_dev<G1R29, G1>(op, p, q, out, n, s);
