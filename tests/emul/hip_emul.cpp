@@ -39,8 +39,9 @@ struct Thr {
     bool at_shfl = false;
     uint32_t shfl_val = 0;
     int shfl_src = 0;
-    bool at_pair = false;      // waiting in pair_exchange for lane ^ 1
+    bool at_pair = false;      // waiting in pair_exchange for lane ^ pair_dist
     uint32_t pair_val = 0;
+    int pair_dist = 1;
     void* asan_fake = nullptr; // ASan: this coroutine's fake-stack handle while it is switched out
     void* tsan_fiber = nullptr;
 };
@@ -118,9 +119,11 @@ uint32_t shfl_exchange(uint32_t v, int src_lane, int /*width*/) {
 
 // exchange with lane ^ 1 only (a DPP quad_perm swap on the device): unlike the wave shuffles above it may be called from code
 // that only SOME lane pairs of the wave execute -- both lanes of a pair always take the same branch
-uint32_t pair_exchange(uint32_t v) {
+uint32_t pair_exchange(uint32_t v) { return pair_exchange_dist(v, 1); }
+uint32_t pair_exchange_dist(uint32_t v, int dist) {
     Thr& me = (*g_thr)[g_cur];
     me.pair_val = v;
+    me.pair_dist = dist;
     me.at_pair = true;
     yield_to_scheduler(me);          // the scheduler resumes us once the partner has posted
     return me.pair_val;
@@ -175,9 +178,13 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
             }
             bool progressed = false;
             // resolve pair exchanges: lanes 2k and 2k + 1 swap once both have posted
-            for (int t = 0; t + 1 < nthr; t += 2) {
-                Thr &A = thr[(size_t)t], &B = thr[(size_t)t + 1];
-                if (A.at_pair && B.at_pair) {
+            for (int t = 0; t < nthr; t++) {
+                Thr& A = thr[(size_t)t];
+                if (!A.at_pair || (t & A.pair_dist)) continue;          // (the lower lane of a pair does the swap)
+                const int u = t ^ A.pair_dist;
+                if (u >= nthr) continue;
+                Thr& B = thr[(size_t)u];
+                if (B.at_pair && B.pair_dist == A.pair_dist) {
                     const uint32_t x = A.pair_val;
                     A.pair_val = B.pair_val; B.pair_val = x;
                     A.at_pair = B.at_pair = false;

@@ -35,7 +35,8 @@ extern thread_local dim3 t_blockDim, t_gridDim;
 void* dyn_smem();
 void sync_threads();
 uint32_t shfl_exchange(uint32_t v, int src_lane, int width);
-uint32_t pair_exchange(uint32_t v);
+uint32_t pair_exchange(uint32_t v);          // with lane ^ 1 (a DPP quad_perm [1,0,3,2] swap on the device)
+uint32_t pair_exchange_dist(uint32_t v, int dist);   // with lane ^ dist, dist = 1 or 2 (quad_perm [2,3,0,1])
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
 }  // namespace hip_emul
 

@@ -201,40 +201,41 @@ def check_group(bn, orc, g, impl):
     assert st_curve(bn, g, impl, 6, [orc.g_neg(g, y) for y in Qa], Qa) == Qa
 
 
-def check_group_pair_g1(bn, orc):
-    """The lane-paired G1 curve of the reduction tails (csrc/curve_pair.h, selftest impl 5: one XYZZ point on two lanes, seven product
-    steps per addition): the reference's g1m_add / g1m_double vectors -- generic, P + P (the doubling branch), the same point with
-    another z, P - P, infinity operands (src/build_curve_jacobian_a0.js:322-356) -- and seeded random Jacobian operands."""
-    G = load_golden("groups.json")["g1"]
+def check_group_pair_g1(bn, orc, g=1, impl=5):
+    """The lane-split curves of the reduction tails (csrc/curve_pair.h): g = 1, impl 5 -- one G1 point on two lanes; g = 2, impl 6 -- one
+    G2 point on four lanes; seven product steps per addition.  The reference's g{1,2}m_add / g{1,2}m_double vectors -- generic, P + P
+    (the doubling branch), the same point with another z, P - P, infinity operands (src/build_curve_jacobian_a0.js:322-356) -- and
+    seeded random Jacobian operands."""
+    G = load_golden("groups.json")["g%d" % g]
     cs = G["cases"]
     p, q = [H(c["p"]) for c in cs], [H(c["q"]) for c in cs]
     labels = [c["label"] for c in cs]
-    got = st_curve(bn, 1, 5, 0, p, q)
+    got = st_curve(bn, g, impl, 0, p, q)
     assert got == [H(c["add_affine"]) for c in cs], [l for l, x, c in zip(labels, got, cs) if x != H(c["add_affine"])]
-    assert st_curve(bn, 1, 5, 0, q, p) == [H(c["add_affine"]) for c in cs]
-    assert st_curve(bn, 1, 5, 1, p, p) == [H(c["double_affine"]) for c in cs]
-    assert st_curve(bn, 1, 5, 0, p, p) == [H(c["double_affine"]) for c in cs]            # P + P takes the doubling branch
-    assert st_curve(bn, 1, 5, 3, p, p) == [H(c["p_affine"]) for c in cs]
-    zero = orc.g_affine(1, orc.g_zero(1))
-    assert st_curve(bn, 1, 5, 0, p, [orc.g_neg(1, x) for x in p]) == [zero] * len(p)
+    assert st_curve(bn, g, impl, 0, q, p) == [H(c["add_affine"]) for c in cs]
+    assert st_curve(bn, g, impl, 1, p, p) == [H(c["double_affine"]) for c in cs]
+    assert st_curve(bn, g, impl, 0, p, p) == [H(c["double_affine"]) for c in cs]            # P + P takes the doubling branch
+    assert st_curve(bn, g, impl, 3, p, p) == [H(c["p_affine"]) for c in cs]
+    zero = orc.g_affine(g, orc.g_zero(g))
+    assert st_curve(bn, g, impl, 0, p, [orc.g_neg(g, x) for x in p]) == [zero] * len(p)
     gen = H(G["gen"])
     acc, multiples = gen, [gen]
     for _ in range(9):
-        acc = st_curve(bn, 1, 5, 0, [acc], [gen])[0]
+        acc = st_curve(bn, g, impl, 0, [acc], [gen])[0]
         multiples.append(acc)
     ten = [c for c in G["times_scalar"] if _int(H(c["scalar"])) == 10 and c["bytes"] == 32]
     assert ten and multiples[9] == H(ten[0]["affine"])
     rnd = random.Random(77)
-    P = [orc.g_times_scalar(1, gen, _le(rnd.randrange(1, orc.R))) for _ in range(33)]      # (an odd count: the last pair of lanes alone in its quad)
-    Q = [orc.g_times_scalar(1, gen, _le(rnd.randrange(1, orc.R))) for _ in range(33)]
-    assert st_curve(bn, 1, 5, 0, P, Q) == [orc.g_affine(1, orc.g_add(1, x, y)) for x, y in zip(P, Q)]
-    assert st_curve(bn, 1, 5, 1, P, P) == [orc.g_affine(1, orc.g_double(1, x)) for x in P]
+    P = [orc.g_times_scalar(g, gen, _le(rnd.randrange(1, orc.R))) for _ in range(33 if g == 1 else 9)]      # (an odd count: the last pair of lanes alone in its quad)
+    Q = [orc.g_times_scalar(g, gen, _le(rnd.randrange(1, orc.R))) for _ in range(33 if g == 1 else 9)]
+    assert st_curve(bn, g, impl, 0, P, Q) == [orc.g_affine(g, orc.g_add(g, x, y)) for x, y in zip(P, Q)]
+    assert st_curve(bn, g, impl, 1, P, P) == [orc.g_affine(g, orc.g_double(g, x)) for x in P]
     # mixed in one launch: generic, doubling, inverse and infinity operands in NEIGHBOURING lane pairs (the branches are per pair)
-    mixP = [P[0], P[1], P[2], orc.g_zero(1), P[4]]
-    mixQ = [Q[0], P[1], orc.g_neg(1, P[2]), Q[3], orc.g_zero(1)]
-    assert st_curve(bn, 1, 5, 0, mixP, mixQ) == [orc.g_affine(1, orc.g_add(1, x, y)) for x, y in zip(mixP, mixQ)]
+    mixP = [P[0], P[1], P[2], orc.g_zero(g), P[4]]
+    mixQ = [Q[0], P[1], orc.g_neg(g, P[2]), Q[3], orc.g_zero(g)]
+    assert st_curve(bn, g, impl, 0, mixP, mixQ) == [orc.g_affine(g, orc.g_add(g, x, y)) for x, y in zip(mixP, mixQ)]
     with pytest.raises(Exception):
-        st_curve(bn, 1, 5, 4, p, q)                                                       # (the tails need no mixed addition)
+        st_curve(bn, g, impl, 4, p, q)                                                       # (the tails need no mixed addition)
 
 
 def degenerate_key_and_witness(orc, pkey, wit):

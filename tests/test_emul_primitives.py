@@ -28,8 +28,9 @@ def test_group_vectors(bn, orc, g, impl):
     pc.check_group(bn, orc, g, impl)
 
 
-def test_paired_g1_tail_curve(bn, orc):
-    pc.check_group_pair_g1(bn, orc)
+@pytest.mark.parametrize("g,impl", [(1, 5), (2, 6)])
+def test_lane_split_tail_curves(bn, orc, g, impl):
+    pc.check_group_pair_g1(bn, orc, g, impl)
 
 
 def test_unsupported_ops_are_errors(bn):

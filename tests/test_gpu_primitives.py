@@ -37,5 +37,6 @@ def test_group_vectors_on_device(bn, orc, g, impl):
     pc.check_group(bn, orc, g, impl)
 
 
-def test_paired_g1_tail_curve_on_device(bn, orc):
-    pc.check_group_pair_g1(bn, orc)
+@pytest.mark.parametrize("g,impl", [(1, 5), (2, 6)])
+def test_lane_split_tail_curves_on_device(bn, orc, g, impl):
+    pc.check_group_pair_g1(bn, orc, g, impl)

@@ -26,7 +26,10 @@
 
 namespace wsnark {
 
-template <class B>
+// DIST = 1: the two halves on lanes 2k, 2k + 1 (G1: B = the base field).  DIST = 2: on lanes 4k + {0, 1} and 4k + {2, 3}, for a base
+// "field" that is itself spread over lane pairs -- B = Fp2PairT<Fq29>: a G2 point on FOUR lanes, lane (h2, h1) holding component h1 of
+// (X, ZZ) (h2 = 0) or of (Y, ZZZ) (h2 = 1); every step is then one extension product = one fused double product per lane.
+template <class B, int DIST = 1>
 struct CurvePairG1 {
     typedef B Field;
     typedef typename B::El El;
@@ -34,11 +37,12 @@ struct CurvePairG1 {
     struct Pt { El a, b; };                         // lo: (X, ZZ)   hi: (Y, ZZZ)
     typedef typename Full::PtP PtP;
 
-    WS_HD static bool hi() { return WS_PAIR_HI(); }
+    WS_HD static bool hi() { return DIST == 1 ? WS_PAIR_HI() : WS_PAIR2_HI(); }
+    WS_HD static uint32_t swap_u32(uint32_t v) { return DIST == 1 ? WS_PAIR_SWAP_U32(v) : WS_PAIR2_SWAP_U32(v); }
     WS_HD static El swap(const El& x) {
         El r;
 #pragma unroll
-        for (int i = 0; i < 9; i++) r.v[i] = WS_PAIR_SWAP_U32(x.v[i]);
+        for (int i = 0; i < 9; i++) r.v[i] = swap_u32(x.v[i]);
         return r;
     }
     // the lane's own choice between two values: x on lo, y on hi -- by arithmetic on a 0 / ~0 mask (a run of nine v_cndmask_b32 on one
@@ -50,11 +54,11 @@ struct CurvePairG1 {
         return r;
     }
     WS_HD static bool from_lo(bool mine) {          // the LO lane's flag, on both lanes (unconditional exchange)
-        const uint32_t other = WS_PAIR_SWAP_U32(mine ? 1u : 0u);
+        const uint32_t other = swap_u32(mine ? 1u : 0u);
         return hi() ? other != 0 : mine;
     }
     WS_HD static bool from_hi(bool mine) {
-        const uint32_t other = WS_PAIR_SWAP_U32(mine ? 1u : 0u);
+        const uint32_t other = swap_u32(mine ? 1u : 0u);
         return hi() ? mine : other != 0;
     }
 
@@ -86,7 +90,8 @@ struct CurvePairG1 {
         const El t5 = B::mul(pick(m, t1, t4), pick(m, sq, o4));          // Q | ZZZ3
         const El osq = swap(sq);                                         // (lo: RR)
         const El x3 = B::sub(B::sub(osq, t4), B::dbl(t5));               // lo: X3 = RR - PPP - 2 Q   (hi: unused)
-        const El w = B::sub_weak(t5, x3);                                // lo: Q - X3
+        const El w = B::sub(t5, x3);                                     // lo: Q - X3   (strict: it is a SECOND operand below, and the lane-paired
+                                                                         //  extension field negates its second operand's components)
         const El t6 = B::mul(pick(m, p.b, t1), pick(m, q.b, o4));        // ZZ1 ZZ2 | S1 PPP
         const El ow = swap(w);                                           // (hi: Q - X3)
         const El t7 = B::mul(pick(m, t6, d), pick(m, sq, ow));           // ZZ3 | R (Q - X3)
@@ -96,10 +101,11 @@ struct CurvePairG1 {
 };
 
 typedef CurvePairG1<Fq29I> G1P29;
+typedef CurvePairG1<Fp2PairT<Fq29>, 2> G2Q29;       // G2 on four lanes
 
 template <class B>
-struct PointIO<CurvePairG1<B>> {
-    typedef CurvePairG1<B> C;
+struct PointIO<CurvePairG1<B, 1>> {
+    typedef CurvePairG1<B, 1> C;
     static constexpr uint32_t LPP = 2;
     typedef XYZZP<B> Stored;                         // the full 128-byte point, as the one-lane kernels store it
     WS_HD static typename C::Pt load(const Stored* a, uint64_t i) {
@@ -113,6 +119,27 @@ struct PointIO<CurvePairG1<B>> {
     WS_HD static void store_ref(Stored* a, uint64_t i, const typename C::Pt& p) {
         typename B::Packed* f = reinterpret_cast<typename B::Packed*>(a + i) + (C::hi() ? 1 : 0);
         f[0] = B::from_internal(p.a); f[2] = B::from_internal(p.b);
+    }
+};
+
+// four lanes per 256-byte G2 point: lane (h2, h1) reads / writes component h1 of coordinates (x, zz) or (y, zzz)
+template <class BB>
+struct PointIO<CurvePairG1<Fp2PairT<BB>, 2>> {
+    typedef Fp2PairT<BB> F;
+    typedef CurvePairG1<F, 2> C;
+    static constexpr uint32_t LPP = 4;
+    typedef XYZZP<Fp2T<BB>> Stored;
+    WS_HD static typename C::Pt load(const Stored* a, uint64_t i) {
+        const typename BB::Packed* f = reinterpret_cast<const typename BB::Packed*>(a + i) + (F::hi() ? 1 : 0) + (C::hi() ? 2 : 0);
+        return typename C::Pt{F::unpack(f[0]), F::unpack(f[4])};
+    }
+    WS_HD static void store(Stored* a, uint64_t i, const typename C::Pt& p) {
+        typename BB::Packed* f = reinterpret_cast<typename BB::Packed*>(a + i) + (F::hi() ? 1 : 0) + (C::hi() ? 2 : 0);
+        f[0] = F::pack(p.a); f[4] = F::pack(p.b);
+    }
+    WS_HD static void store_ref(Stored* a, uint64_t i, const typename C::Pt& p) {
+        typename BB::Packed* f = reinterpret_cast<typename BB::Packed*>(a + i) + (F::hi() ? 1 : 0) + (C::hi() ? 2 : 0);
+        f[0] = F::from_internal(p.a); f[4] = F::from_internal(p.b);
     }
 };
 

@@ -137,13 +137,19 @@ typedef Fp2T<Fq> Fq2;
 // ---------------------------------------------------------------------------------------------------------------------
 #if defined(WSNARK_EMUL)
 #define WS_PAIR_SWAP_U32(v) (::hip_emul::pair_exchange(v))
+#define WS_PAIR2_SWAP_U32(v) (::hip_emul::pair_exchange_dist((v), 2))
 #define WS_PAIR_HI() ((threadIdx.x & 1u) != 0)
+#define WS_PAIR2_HI() ((threadIdx.x & 2u) != 0)
 #elif defined(__HIP_DEVICE_COMPILE__)
 #define WS_PAIR_SWAP_U32(v) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true))
+#define WS_PAIR2_SWAP_U32(v) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, true))
 #define WS_PAIR_HI() ((threadIdx.x & 1u) != 0)
+#define WS_PAIR2_HI() ((threadIdx.x & 2u) != 0)
 #else
 #define WS_PAIR_SWAP_U32(v) (v)        // (host pass of hipcc: these functions are device-only)
+#define WS_PAIR2_SWAP_U32(v) (v)
 #define WS_PAIR_HI() (false)
+#define WS_PAIR2_HI() (false)
 #endif
 
 template <class B>

@@ -729,7 +729,8 @@ __global__ __launch_bounds__(256) void msm_chunks(TailSets<C> ts, uint32_t nchun
 // ---------------------------------------------------------------------------
 // (one lane per 256-byte G2 point: 256 threads at most, so that a wavefront may use the whole register file)
 template <class C> struct TreeBound { static constexpr int value = (PointIO<C>::LPP == 1 && sizeof(typename PointIO<C>::Stored) > 128) ? 256 : 512; };
-template <class B> struct TreeBound<CurvePairG1<B>> { static constexpr int value = 1024; };      // 512 slots of two lanes (115 VGPRs: two workgroups' worth of wavefronts per SIMD)
+template <class B> struct TreeBound<CurvePairG1<B, 1>> { static constexpr int value = 1024; };      // G1: 512 slots of two lanes (115 VGPRs)
+template <class B> struct TreeBound<CurvePairG1<B, 2>> { static constexpr int value = 512; };       // G2: 128 slots of four lanes (1024 threads cap the kernel at 128 VGPRs: it spills)
 template <class C>
 __global__ __launch_bounds__(TreeBound<C>::value) void msm_tree(TailSets<C> ts, uint32_t J, uint32_t logJ, uint32_t to_ref, uint32_t nsum) {
     typedef PointIO<C> IO;
@@ -1470,9 +1471,11 @@ static int msm_launch_acc(Lane& L, int which, const typename H::Aff* d_points_re
 // G1 runs on the curve variant with inlined products, G2 on the lane-paired curve (fp2.h; same buffers, same results).
 template <class C> struct TailCurve { typedef C type; typedef C paired; };
 template <> struct TailCurve<G1R29> { typedef G1R29I type; typedef G1P29 paired; };      // (round 6: one G1 point on two lanes, curve_pair.h)
-template <> struct TailCurve<G2R29> { typedef G2P29 type; typedef G2P29 paired; };
+template <> struct TailCurve<G2R29> { typedef G2P29 type; typedef G2Q29 paired; };       // (round 6: one G2 point on FOUR lanes for msm_tree / msm_rows)
 // WSNARK_TAIL_PAIR_G1 (default 1): the G1 reduction tails on lane pairs -- seven product steps per addition instead of fourteen
 static bool tail_pair_g1() { return tuning_get("TAIL_PAIR_G1", 1) != 0; }
+static bool tail_quad_g2() { return tuning_get("TAIL_QUAD_G2", 1) != 0; }
+template <class C> static bool tail_split() { return sizeof(typename C::AffP) > 64 ? tail_quad_g2() : tail_pair_g1(); }
 // CC: the curve of msm_chunks (throughput-bound: 2 additions per bucket on every lane of the chip -- the one-lane form is the cheaper
 // one there), C: the curve of msm_tree / msm_rows (latency-bound LDS reductions: the lane-paired forms halve every step).  Same buffers.
 template <class C, class CC = C>
@@ -1547,8 +1550,8 @@ static int msm_launch(Lane& L, int which, const typename H::Aff* d_points_ref, b
     if (!s) s = L.stream;
     int rc = msm_launch_acc<C, H>(L, which, d_points_ref, prepared, slot_out, s);
     if (rc) return rc;
-    rc = tail_pair_g1() ? msm_launch_tail<typename TailCurve<C>::paired, typename TailCurve<C>::type>(L, slot_out, 1, s)
-                        : msm_launch_tail<typename TailCurve<C>::type>(L, slot_out, 1, s);
+    rc = tail_split<C>() ? msm_launch_tail<typename TailCurve<C>::paired, typename TailCurve<C>::type>(L, slot_out, 1, s)
+                         : msm_launch_tail<typename TailCurve<C>::type>(L, slot_out, 1, s);
     if (rc) msm_abort_slots(L, slot_out, 1, s, nullptr);
     return rc;
 }

@@ -306,6 +306,45 @@ static int st_curve_pair_g1_dev(int op, const uint8_t* p, const uint8_t* q, uint
     }
     return WS_OK;
 }
+// G2 on FOUR lanes (curve_pair.h: CurvePairG1<Fp2PairT, 2>): lane (h2, h1) holds component h1 of (X, ZZ) or of (Y, ZZZ); ops 0, 1, 3
+__global__ __launch_bounds__(64) void st_curve_quad_g2_kernel(int op, const Fe* __restrict__ p, const Fe* __restrict__ q, Fe* __restrict__ out,
+                                                                uint64_t n, int* __restrict__ bad) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = t >> 2;
+    const uint32_t h1 = (uint32_t)(t & 1), h2 = (uint32_t)((t >> 1) & 1);
+    if (i >= n) return;
+    typedef G2P29 C;
+    typedef C::Field F;
+    auto from_jac = [](const Fe* j) -> C::Pt {                    // (this lane's component of every coordinate)
+        const F::El z = F::to_internal(j[2]);
+        if (F::is_zero(z)) return C::infinity();
+        const F::El zz = F::sqr(z);
+        return C::Pt{F::to_internal(j[0]), F::to_internal(j[1]), zz, F::mul(zz, z)};
+    };
+    const Fe pj[3] = {p[6 * i + h1], p[6 * i + 2 + h1], p[6 * i + 4 + h1]};
+    const Fe qj[3] = {q[6 * i + h1], q[6 * i + 2 + h1], q[6 * i + 4 + h1]};
+    const G2Q29::Pt a = G2Q29::split(from_jac(pj)), b = G2Q29::split(from_jac(qj));
+    G2Q29::Pt r = G2Q29::infinity();
+    if (op == 0) r = G2Q29::add(a, b);
+    else if (op == 1) r = G2Q29::dbl(a);
+    else if (op == 3) r = a;
+    else *bad = 1;
+    out[8 * i + h1 + 2 * h2] = F::from_internal(r.a);             // x.c | y.c
+    out[8 * i + 4 + h1 + 2 * h2] = F::from_internal(r.b);         // zz.c | zzz.c
+}
+static int st_curve_quad_g2_dev(int op, const uint8_t* p, const uint8_t* q, uint8_t* out, uint64_t n, hipStream_t s) {
+    StBufs B;
+    int rc = B.up(p, q, n * 192, n * 256, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(st_curve_quad_g2_kernel, dim3(ceil_div_u64(4 * n, 64)), dim3(64), 0, s, op, B.a.as<Fe>(), B.b.as<Fe>(), B.out.as<Fe>(), n, B.bad.as<int>());
+    std::vector<G2::Pt> host(n);
+    if ((rc = B.down(reinterpret_cast<uint8_t*>(host.data()), n * sizeof(G2::Pt), s))) return rc;
+    for (uint64_t i = 0; i < n; i++) {
+        auto j = G2::to_affine_jac(host[i]);
+        memcpy(out + i * sizeof j, &j, sizeof j);
+    }
+    return WS_OK;
+}
 static int st_curve_pair_dev(int op, const uint8_t* p, const uint8_t* q, uint8_t* out, uint64_t n, hipStream_t s) {
     StBufs B;
     int rc = B.up(p, q, n * 192, n * 256, s);
@@ -361,6 +400,7 @@ int selftest_curve(int g, int impl, int op, const uint8_t* p, const uint8_t* q, 
     if (n == 0) return WS_OK;
     if (n > (1u << 20) || op < 0 || op > 8 || (op == 8 && impl == 4)) return WS_ERR_ARG;
     if (g == 1 && impl == 5) return (op == 0 || op == 1 || op == 3) ? st_curve_pair_g1_dev(op, p, q, out, n, X->stream) : (int)WS_ERR_ARG;
+    if (g == 2 && impl == 6) return (op == 0 || op == 1 || op == 3) ? st_curve_quad_g2_dev(op, p, q, out, n, X->stream) : (int)WS_ERR_ARG;
     hipStream_t s = X->stream;
     if (g == 1) {
         if (impl == 0) return st_curve_dev<G1R29, G1>(op, p, q, out, n, s);
