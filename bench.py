@@ -318,7 +318,7 @@ def proof_issue_roofline(ms_per_proof, rates):
         return None
     per_kernel, floor_s, unclassified = {}, 0.0, 0.0
     for k, v in b.get("kernels", {}).items():
-        fs, how = issue_model.kernel_floor_s(k, float(v["valu_insts_per_proof"]), classes, rates)
+        fs, how = issue_model.kernel_floor_s(k, float(v["valu_insts_per_proof"]), classes, rates, v.get("dynamic_int64_share"))
         floor_s += fs
         per_kernel[k] = fs
         if how.startswith("unclassified"):

@@ -25,8 +25,10 @@ RUNS = {
              ("tests/test_prove_cpu.py", "two_proofs_in_flight or proofs_before_the_table_rows or staging_ring or key_format_errors or partial_finish or key_falls_back"),
              ("tests/test_emul_kernels.py", None),
              ("tests/test_dist_ntt_gloo.py", "native")],
+    # (TSan with one fibre per kernel thread is ~50x the plain emulator: 15 min for the first file, 46 min for three more group tests
+    #  in round 6's first run -- the list keeps what has threads in it: lanes, the background build, a group's workers and its death)
     "tsan": [("tests/test_prove_cpu.py", "two_proofs_in_flight or proofs_before_the_table_rows"),
-             ("tests/test_group_cpu.py", "terminate_with_a_live_key or errors_are_agreed or (matches_reference and t3)")],
+             ("tests/test_group_cpu.py", "terminate_with_a_live_key or errors_are_agreed")],
 }
 
 
@@ -50,7 +52,13 @@ def run_under(san, file, kexpr, logdir, timeout=5400):
         env["TSAN_OPTIONS"] = "log_path=%s.tsan:halt_on_error=0:report_signal_unsafe=0:second_deadlock_stack=1" % log
     cmd = [sys.executable, "-m", "pytest", file, "-x", "-q", "-p", "no:cacheprovider", "-m", "not gpu"] + (["-k", kexpr] if kexpr else [])
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
-    reports = sorted(glob.glob(log + ".*"))
+    # a report file that holds nothing but ASan's one-line notice about makecontext / swapcontext (printed once per process whatever
+    # the fiber annotations say) is not a finding
+    reports = []
+    for f in sorted(glob.glob(log + ".*")):
+        lines = [l for l in open(f, errors="replace").read().splitlines() if l.strip()]
+        if lines and not all("doesn't fully support makecontext/swapcontext" in l for l in lines):
+            reports.append(f)
     return out, reports
 
 

@@ -40,7 +40,7 @@ if ! skip prof; then
 fi
 # whole-proof instruction budget: SQ_INSTS_VALU over exactly P proofs between two marker launches (tools/proof_counters.py)
 if ! skip issue; then
-  ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/$O/issue/pmc_issue" -o pmc -- python "$GRAFT_REPO_ROOT/tools/proof_counters.py" 20 4 ) > "$O/issue.log" 2>&1
+  ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/$O/issue/pmc_issue" -o pmc -- python "$GRAFT_REPO_ROOT/tools/proof_counters.py" 20 4 ) > "$O/issue.log" 2>&1
   echo "pmc issue rc=$?" >> "$O/env.log"
   python tools/pmc_proof_budget.py "$O/issue" 4 --rates "$O/issue_classes.json" > "$O/proof_issue_budget.json" 2>> "$O/env.log"
   find "$O/issue" -name "*.csv" -size +2M -delete 2>/dev/null
@@ -57,7 +57,7 @@ fi
 # SQ / GRBM counters behind the issue-bound claim: two passes, proofs only, kernel-trace only
 if ! skip sq; then
   I=0
-  for GROUP in "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU"; do
+  for GROUP in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_INT64 SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU"; do
     I=$((I+1))
     ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --pmc $GROUP --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/$O/sq/pmc_sq$I" -o pmc -- python "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --extras msm,ntt ) > "$O/pmc_sq$I.log" 2>&1
     echo "pmc sq$I rc=$?" >> "$O/env.log"

@@ -172,6 +172,9 @@ def histogram():
 def as_json(rows):
     """{pmc kernel name: {"mix": {class: share of the VALU stream}, ...}}: the first instantiation seen stands for a name"""
     out = {}
+    # several instantiations share a dispatch name (msm_tree on one lane / on lane pairs; 4- and 8-byte grouping entries): the one the
+    # default build LAUNCHES goes first
+    rows = sorted(rows, key=lambda r: 0 if "CurvePairG1" in r["demangled"] and ("msm_tree" in r["demangled"] or "msm_rows" in r["demangled"]) else 1)
     for r in rows:
         if not r["kernel"] or not r["valu_with_callees"]:
             continue

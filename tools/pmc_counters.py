@@ -92,7 +92,8 @@ for k, ctrs in sorted(acc.items()):
         d["valu_slots_flat4"] = round(4 * d["SQ_INSTS_VALU"] / (d["GRBM_GUI_ACTIVE"] / n_xcd * n_simd), 4)
     if g("SQ_INSTS_VALU") and dur.get(k):
         mean_s = sum(dur[k]) / len(dur[k]) / 1e9
-        floor_s, how = issue_model.kernel_floor_s(k, d["SQ_INSTS_VALU"], classes, rates)
+        dyn64 = d["SQ_INSTS_VALU_INT64"] / d["SQ_INSTS_VALU"] if g("SQ_INSTS_VALU_INT64") is not None else None
+        floor_s, how = issue_model.kernel_floor_s(k, d["SQ_INSTS_VALU"], classes, rates, dyn64)
         d["mean_launch_us"] = round(mean_s * 1e6, 2)
         d["issue_floor_us"] = round(floor_s * 1e6, 2)
         d["issue_floor_frac"] = round(floor_s / mean_s, 4) if mean_s > 0 else None

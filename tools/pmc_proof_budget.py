@@ -82,11 +82,18 @@ for k, a in sorted(acc.items()):
     insts, busy = a.get("SQ_INSTS_VALU", 0.0), a.get("GRBM_GUI_ACTIVE", 0.0) / n_xcd
     total_insts += insts
     total_busy += busy
-    floor_s, how = issue_model.kernel_floor_s(k, insts / P, classes, rates)
+    dyn64 = a["SQ_INSTS_VALU_INT64"] / insts if insts and "SQ_INSTS_VALU_INT64" in a else None
+    floor_s, how = issue_model.kernel_floor_s(k, insts / P, classes, rates, dyn64)
     total_floor += floor_s
     out[k] = {"launches_per_proof": round(a["launches"] / P, 2), "valu_insts_per_proof": round(insts / P, 1),
               "waves_per_proof": round(a.get("SQ_WAVES", 0.0) / P, 1), "busy_cycles_per_proof": round(busy / P, 1),
               "issue_floor_ms_per_proof": round(floor_s * 1e3, 4), "issue_floor_how": how,
+              # DYNAMIC check of the static class mix (when the pass collected them): the hardware's own split of the VALU instructions
+              # into 32-bit and 64-bit integer operations, beside the static mix's share of multiply-adds + 64-bit shifts / moves
+              "dynamic_int64_share": round(a["SQ_INSTS_VALU_INT64"] / insts, 4) if insts and "SQ_INSTS_VALU_INT64" in a else None,
+              "dynamic_int32_share": round(a["SQ_INSTS_VALU_INT32"] / insts, 4) if insts and "SQ_INSTS_VALU_INT32" in a else None,
+              "static_mad64_plus_wide64_share": (round(classes["kernels"][k]["mix"]["mad64"] + classes["kernels"][k]["mix"]["wide64"], 4)
+                                                 if classes and k in classes["kernels"] else None),
               "valu_slots_flat4": round(4 * insts / (busy * n_simd), 4) if busy else None}
 print(json.dumps({"how": "rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace around tools/proof_counters.py; dispatches between "
                          "the two marker groups only; kernels are serialised by the counter collection, so busy_cycles are each kernel ALONE",

@@ -10,4 +10,4 @@ OUT=profiles/${TAG}_sanitizers.txt
   echo "reports are written to files (log_path): a line below ends with the number of report files its run left."
   echo
 } > "$OUT"
-python -m pytest tests/test_sanitizers.py -m sanitizer -q -s -p no:cacheprovider 2>&1 | grep -E "^(asan|tsan) tests/|passed|failed|error" | tee -a "$OUT"
+python -u -m pytest tests/test_sanitizers.py -m sanitizer -q -s -p no:cacheprovider ${SAN_K:+-k "$SAN_K"} 2>&1 | grep --line-buffered -E "^(asan|tsan) tests/|passed|failed|error" | tee -a "$OUT"

@@ -362,6 +362,10 @@ int calc_h_dev(Lane& L, const Fe* d_signals_plain, uint32_t n_signals, const Csr
     // is exactly one resident set of workgroups, all in the same phase; twice the workgroups let loads overlap butterflies)
     WS_HIP_CHECK(L.calch_buf[1].reserve(2 * nb));
     WS_HIP_CHECK(L.calch_buf[3].reserve(nb));
+    // the transforms' ping-pong buffer at the size of the LARGEST batch below, before the first transform takes it at half that: a
+    // buffer that grows is freed first, and hipFree waits for the whole device -- in a key's first proof that is the background
+    // table build (first proof 156 ms instead of 17: profiles/r06_s1 against r06_s2)
+    if (tuning_get("CALCH_BATCH", 1)) WS_HIP_CHECK(L.ntt_scratch.reserve(2 * nb));
     Fe* a = L.calch_buf[1].as<Fe>();
     Fe* b = a + domain;
     Fe* e = L.calch_buf[3].as<Fe>();
