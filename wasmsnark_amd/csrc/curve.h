@@ -159,6 +159,45 @@ struct Curve {
         acc.zzz = F::mul(acc.zzz, PPP);
     }
     WS_HD static void narrow_x(Pt& acc) { acc.x = F::narrow(acc.x); }
+    // The accumulation loop's COMMON case as one straight path (round 6): a finite acc (x wide, as madd_wide keeps it) plus a finite
+    // affine point that is neither acc nor -acc.  Returns false WITHOUT touching acc when the pair may be one of the reference's corner
+    // cases (build_curve_jacobian_a0.js:322-356: the cheap necessary test of field29.h on x2 zz1 - x1), and the caller runs the pair
+    // through madd_wide.  Why a second form: with madd_wide's early returns inlined in a loop the compiler merges five definitions of
+    // the accumulator at the loop's end -- 70 register moves, 36 constant loads, two nine-limb zero tests and a branch tree per
+    // addition, ~6 % of the loop's issue cycles (ISA of msm_accumulate, round 6) -- for paths a proof never takes.
+    WS_HD static bool madd_fast(Pt& acc, const Aff& a, bool negate) {
+        El y2 = F::cneg(a.y, negate);
+        El U2 = F::mul(a.x, acc.zz);
+        El S2 = F::mul(y2, acc.zzz);
+        El P = F::sub_wide(U2, acc.x);
+        if (F::maybe_zero_wide(P)) return false;
+        El R = F::sub_weak(S2, acc.y);
+        El PP = F::sqr(P);
+        El PPP = F::mul(P, PP);
+        El Q = F::mul(acc.x, PP);
+        El X3 = F::x3_wide(F::sqr(R), PPP, Q);
+        El Y3 = F::mulsub2(R, F::sub_wide(Q, X3), acc.y, PPP);
+        acc.x = X3;
+        acc.y = Y3;
+        acc.zz = F::mul(acc.zz, PP);
+        acc.zzz = F::mul(acc.zzz, PPP);
+        return true;
+    }
+    // The SECOND entry of a task meets a sum that is still an affine point (zz = zzz = 1): mmadd-2008-s, the same formulas without the
+    // four products by zz / zzz (4M + 2S; ZZ3 = PP, ZZZ3 = PPP).  `p` is that point (x, y strict); same contract as madd_fast.
+    WS_HD static bool mmadd_fast(Pt& acc, const Aff& p, const Aff& a, bool negate) {
+        El y2 = F::cneg(a.y, negate);
+        El P = F::sub_wide(a.x, p.x);
+        if (F::maybe_zero_wide(P)) return false;
+        El R = F::sub_weak(y2, p.y);
+        El PP = F::sqr(P);
+        El PPP = F::mul(P, PP);
+        El Q = F::mul(p.x, PP);
+        El X3 = F::x3_wide(F::sqr(R), PPP, Q);
+        El Y3 = F::mulsub2(R, F::sub_wide(Q, X3), p.y, PPP);
+        acc = Pt{X3, Y3, PP, PPP};
+        return true;
+    }
 
     // full addition (add-2008-s, 12M+2S) with all corner cases
     WS_HD static Pt add(const Pt& a, const Pt& b) {

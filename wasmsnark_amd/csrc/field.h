@@ -187,6 +187,12 @@ struct Field {
     WS_HD static Fe sub_wide(const Fe& a, const Fe& b) { return sub(a, b); }
     WS_HD static bool is_zero_wide(const Fe& a) { return is_zero(a); }
     WS_HD static Fe narrow(const Fe& a) { return a; }
+    // the accumulation loop's cheap tests (curve.h: madd_fast; field29.h has the forms that matter): "may be zero" must hold for every
+    // zero, "packed_is_zero" is is_zero on the stored form
+    WS_HD static bool maybe_zero_wide(const Fe& a) { return is_zero(a); }
+    WS_HD static bool maybe_zero_weak(const Fe& a) { return is_zero(a); }
+    WS_HD static bool packed_is_zero(const Fe& a) { return is_zero(a); }
+    WS_HD static void keep(Fe&) {}
     WS_HD static Fe sub_weak4(const Fe& a, const Fe& b) { return sub(a, b); }
     // (the lazily reduced butterfly sums of field29.h: strict here)
     WS_HD static Fe add_nr(const Fe& a, const Fe& b) { return add(a, b); }

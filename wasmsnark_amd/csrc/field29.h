@@ -283,6 +283,39 @@ struct Field29 {
         }
         return false;
     }
+    // Cheap NECESSARY condition for "a is a multiple k p, 1 <= k <= kmax" (a difference that vanishes mod p): the lowest limb of k p is
+    // k p_0 mod 2^29 and p_0 is odd, so l_0 p_0^-1 mod 2^29 must be k (or 0).  Three instructions where the nine-way comparison of
+    // is_zero_wide compiles to a branch tree that every wavefront walks; a hit (2^-26 by chance) sends the lane to the exact test.
+    WS_HD static constexpr uint32_t p0_inv29() {
+        uint32_t x = 1;                                    // Newton: x <- x (2 - p_0 x), doubling the correct low bits
+        for (int i = 0; i < 6; i++) x = x * (2u - p_limb(0) * x);
+        return x & WS_M29;
+    }
+    WS_HD static bool maybe_kp(const F29& a, uint32_t kmax) { return ((a.v[0] * p0_inv29()) & WS_M29) <= kmax; }   // (k = 0 included: strict forms)
+    WS_HD static bool maybe_zero_wide(const F29& a) { return maybe_kp(a, 9); }      // sub_wide results: (0, 10p)
+    WS_HD static bool maybe_zero_weak(const F29& a) { return maybe_kp(a, 3); }      // sub_weak results: (0, 4p)
+    // is_zero on the STORED form (any representative below 2^256 of a value in [0, 2p)): all words zero -- what every writer of a
+    // point table stores for infinity -- or p itself (a non-canonical input), kept behind a real branch
+    WS_HD static bool packed_is_zero(const Fe& x) {
+        const uint32_t lo = (uint32_t)x.l[0];
+        if (((uint32_t)(x.l[0] >> 32) | lo | (uint32_t)x.l[1] | (uint32_t)(x.l[1] >> 32) | (uint32_t)x.l[2] | (uint32_t)(x.l[2] >> 32) |
+             (uint32_t)x.l[3] | (uint32_t)(x.l[3] >> 32)) == 0)
+            return true;
+        if (__builtin_expect(lo == (uint32_t)P::P0, 0)) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(WSNARK_EMUL)
+            asm volatile("");           // (not to be folded into the common path as a chain of selects)
+#endif
+            return x.l[0] == P::P0 && x.l[1] == P::P1 && x.l[2] == P::P2 && x.l[3] == P::P3;
+        }
+        return false;
+    }
+    // pin an element's limbs in registers HERE (the accumulation loop unpacks a prefetched point before the registers it arrived in are
+    // loaded again; without this the compiler sinks the unpacking below the loads and copies the sixteen words instead)
+    WS_HD static void keep(F29& a) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(WSNARK_EMUL)
+        asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3]), "+v"(a.v[4]), "+v"(a.v[5]), "+v"(a.v[6]), "+v"(a.v[7]), "+v"(a.v[8]));
+#endif
+    }
     // r = s - k*p if s >= k*p else s (tight limbs in and out)
     WS_HD static F29 cond_sub_kp(const F29& s, uint32_t k) {
         F29 d;

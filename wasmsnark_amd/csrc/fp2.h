@@ -66,6 +66,11 @@ struct Fp2T {
 #endif
     WS_HD static El sub_wide(const El& a, const El& b) { return sub_weak(a, b); }
     WS_HD static bool is_zero_wide(const El& a) { return is_zero_weak(a); }
+    // (necessary conditions / the stored form's test, as in the base field: one component decides the cheap test)
+    WS_HD static bool maybe_zero_weak(const El& a) { return B::maybe_zero_weak(a.c0); }
+    WS_HD static bool maybe_zero_wide(const El& a) { return B::maybe_zero_weak(a.c0); }
+    WS_HD static bool packed_is_zero(const Packed& a) { return B::packed_is_zero(a.c0) && B::packed_is_zero(a.c1); }
+    WS_HD static void keep(El& a) { B::keep(a.c0); B::keep(a.c1); }
     WS_HD static El narrow(const El& a) { return a; }
     WS_HD static El neg(const El& a) { return El{B::neg(a.c0), B::neg(a.c1)}; }
     WS_HD static El cneg(const El& a, bool s) { return s ? neg(a) : a; }

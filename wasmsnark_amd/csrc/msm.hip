@@ -413,42 +413,111 @@ __global__ __launch_bounds__(1024) void presort_bins(const E* __restrict__ entri
 // ---------------------------------------------------------------------------
 // 4/5. accumulation
 // ---------------------------------------------------------------------------
+// Round 6: the loop is split in two.  FAST loop: one straight path per addition (curve.h: madd_fast) for what a task is made of --
+// a finite point added to a finite sum that is neither it nor its opposite; the cases the reference branches on
+// (build_curve_jacobian_a0.js:322-356: infinity operands, P = +-Q) make the LANE leave that loop, and the GENERIC loop below (madd_wide,
+// every case) finishes its task.  On a proof no lane ever leaves (the plan's variants drop the key's infinity points; equal points
+// need a 2^-26 coincidence first); the vectors with planted infinities, duplicates and P / -P pairs run the generic loop.
+// The index of the entry after next is loaded one addition early, so that no gather waits for its own index load (the round-5
+// loop issued `global_load_dword; s_waitcnt vmcnt(0)` in front of every gather).
+#ifndef WS_ACC_FAST
+#define WS_ACC_FAST 1      // 0: the round-5 loop (madd_wide for every entry), for A/B builds
+#endif
+#ifndef WS_ACC_MMADD
+#define WS_ACC_MMADD 1     // the second entry of a task by the affine + affine formulas
+#endif
 template <class C>
 __device__ __forceinline__ typename C::Pt accumulate_range(const typename C::AffP* __restrict__ points,
                                                            const uint32_t* __restrict__ vals, uint32_t s, uint32_t len) {
+    typedef typename C::Field F;
     typename C::Pt acc = C::infinity();
     if (len == 0) return acc;
-    if (sizeof(typename C::AffP) > 64 ? !WS_G2_PREFETCH : !WS_G1_PREFETCH) {
-        // G2: the accumulator alone is 72 VGPRs; holding a prefetched 128-byte point as well costs a
-        // wavefront of occupancy, so the gather is issued just before use (touching only the next point's cache line one
-        // addition ahead was measured too: +4 %, profiles/r02_ab_g2_variants.txt -- the kernel is issue-bound, not latency-bound)
-        for (uint32_t k = 0; k < len; k++) {
-            const uint32_t v = vals[s + k];
-            const typename C::Aff cur = C::unpack_aff(points[v & 0x7FFFFFFFu]);
-#if WS_MADD_WIDE
-            C::madd_wide(acc, cur, (v >> 31) != 0);
-#else
-            C::madd(acc, cur, (v >> 31) != 0);
+    constexpr bool kPrefetch = sizeof(typename C::AffP) > 64 ? WS_G2_PREFETCH != 0 : WS_G1_PREFETCH != 0;
+    uint32_t k = 0;
+#if WS_ACC_FAST && WS_MADD_WIDE
+    {
+        uint32_t v = vals[s];
+        typename C::AffP cp = points[v & 0x7FFFFFFFu];
+        if (!F::packed_is_zero(cp.x)) {
+            // the first entry starts the sum
+            typename C::Aff a0 = C::unpack_aff(cp);
+            a0.y = F::cneg(a0.y, (v >> 31) != 0);
+            acc = typename C::Pt{a0.x, a0.y, F::one(), F::one()};
+            k = 1;
+            const uint32_t last = len - 1;
+#if WS_ACC_MMADD
+            // the second meets an affine sum: four products fewer (curve.h: mmadd_fast)
+            if (len > 1) {
+                v = vals[s + 1];
+                cp = points[v & 0x7FFFFFFFu];
+                if (!F::packed_is_zero(cp.x) && C::mmadd_fast(acc, a0, C::unpack_aff(cp), (v >> 31) != 0)) k = 2;
+            }
 #endif
+            if (kPrefetch) {
+                // G1: the next point's gather is in flight while the current one is added.  No branches around the loads: indices
+                // past the task's end are clamped to its last entry (the final addition gathers that point once more)
+                uint32_t v1 = vals[s + (k < last ? k : last)], v2 = vals[s + (k + 1 < last ? k + 1 : last)];
+                cp = points[v1 & 0x7FFFFFFFu];
+                while (k < len) {
+                    const bool inf = F::packed_is_zero(cp.x);
+                    typename C::Aff cur = C::unpack_aff(cp);
+                    const bool neg = (v1 >> 31) != 0;
+                    F::keep(cur.x);                                    // limbs taken before the registers are loaded again: no copies
+                    F::keep(cur.y);
+                    v1 = v2;
+                    cp = points[v1 & 0x7FFFFFFFu];
+                    v2 = vals[s + (k + 2 < last ? k + 2 : last)];
+                    if (inf) break;
+                    if (!C::madd_fast(acc, cur, neg)) break;
+                    k++;
+                }
+            } else {
+                // G2: the accumulator alone is 72 VGPRs; holding a prefetched 128-byte point as well costs a wavefront of
+                // occupancy, so the gather is issued just before use (touching only the next point's cache line one addition
+                // ahead was measured too: +4 %, profiles/r02_ab_g2_variants.txt) -- but its INDEX is one register and comes early
+                uint32_t vn = vals[s + (k < last ? k : last)];
+                while (k < len) {
+                    v = vn;
+                    cp = points[v & 0x7FFFFFFFu];
+                    vn = vals[s + (k + 1 < last ? k + 1 : last)];
+                    if (F::packed_is_zero(cp.x)) break;
+                    if (!C::madd_fast(acc, C::unpack_aff(cp), (v >> 31) != 0)) break;
+                    k++;
+                }
+            }
         }
-        C::narrow_x(acc);
-        return acc;
     }
-    // software pipeline: the next point's gather is in flight while the current one is added
-    uint32_t v = vals[s];
-    typename C::AffP nxt = points[v & 0x7FFFFFFFu];
-    for (uint32_t k = 0; k < len; k++) {
-        const typename C::Aff cur = C::unpack_aff(nxt);
-        const bool neg = (v >> 31) != 0;
-        if (k + 1 < len) {
-            v = vals[s + k + 1];
-            nxt = points[v & 0x7FFFFFFFu];
-        }
-#if WS_MADD_WIDE
-        C::madd_wide(acc, cur, neg);
-#else
-        C::madd(acc, cur, neg);
 #endif
+    // generic loop: every case of the reference's addition; entries from k on (all of them when the task's first point is infinity)
+    if (k < len) {
+        if (!kPrefetch) {
+            for (; k < len; k++) {
+                const uint32_t v = vals[s + k];
+                const typename C::Aff cur = C::unpack_aff(points[v & 0x7FFFFFFFu]);
+#if WS_MADD_WIDE
+                C::madd_wide(acc, cur, (v >> 31) != 0);
+#else
+                C::madd(acc, cur, (v >> 31) != 0);
+#endif
+            }
+        } else {
+            // software pipeline: the next point's gather is in flight while the current one is added
+            uint32_t v = vals[s + k];
+            typename C::AffP nxt = points[v & 0x7FFFFFFFu];
+            for (; k < len; k++) {
+                const typename C::Aff cur = C::unpack_aff(nxt);
+                const bool neg = (v >> 31) != 0;
+                if (k + 1 < len) {
+                    v = vals[s + k + 1];
+                    nxt = points[v & 0x7FFFFFFFu];
+                }
+#if WS_MADD_WIDE
+                C::madd_wide(acc, cur, neg);
+#else
+                C::madd(acc, cur, neg);
+#endif
+            }
+        }
     }
     C::narrow_x(acc);
     return acc;
