@@ -131,7 +131,7 @@ def main():
                                                      "of every rank generating and holding the whole key in host memory.  'auto' = a file under $WSNARK_BENCH_KEY_DIR "
                                                      "or the temp directory; or a path on a file system all ranks see")
     ap.add_argument("--log-n", type=int, default=20, help="--workload msm / extras: pairs per MSM")
-    ap.add_argument("--extras", default="msm,ntt,cold,inflight,sparse,node", help="comma list (N=1 only): msm, ntt, cold, inflight, sparse, node")
+    ap.add_argument("--extras", default="msm,ntt,cold,inflight,power,sparse,node", help="comma list (N=1 only): msm, ntt, cold, inflight, power, sparse, node")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alone-pass", action="store_true",
@@ -628,6 +628,8 @@ def bench_prove(ctx):
     extras = {}
     if "inflight" in want_extras:
         run_extra(extras, "two_proofs_in_flight", lambda: extra_prove_inflight(ctx, key, d_w, len(wit), r32, s32, want, ms))
+    if "power" in want_extras:
+        run_extra(extras, "clock_and_power", lambda: extra_power(ctx, key, d_w, len(wit), r32, s32))
     del d_w
     if "msm" in want_extras:
         run_extra(extras, "g1_msm_2p%d" % args.log_n, lambda: extra_msm(ctx, "cold" in want_extras))
@@ -830,6 +832,69 @@ def extra_prove_inflight(ctx, key, d_w, wlen, r32, s32, want, ms_single):
         res["prove_throughput_per_s" + key_] = round(nthreads * reps / dt, 2)
         res["ms_per_proof_amortised" + key_] = round(dt / (nthreads * reps) * 1e3, 3)
     res["all_proofs_identical_to_closed_form"] = not bad
+    return res
+
+
+def _gpu_power_sampler():
+    """-> a function that returns (sclk_MHz, socket_W) of GPU 0 now, or None: rocm-smi's own figures (the firmware's metrics table;
+    an ordinary-user read, no setting touched).  (The amdgpu hwmon node's freq1_input / power1_average read 1 034 MHz / 296 W under a
+    load that rocm-smi -- and the proof rate -- put at 2 230 MHz / 1 300 W: gpurun_out r06_s3; not used.)"""
+    import subprocess
+
+    def smi():
+        try:
+            t = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=5).stdout
+            mhz = [ln for ln in t.splitlines() if "sclk" in ln][0].split("(")[1].split("Mhz")[0]
+            w = [ln for ln in t.splitlines() if "ower" in ln and "(W)" in ln][0].split(":")[-1]
+            return float(mhz), float(w)
+        except Exception:  # noqa: BLE001
+            return None
+    return smi if smi() is not None else None
+
+
+def extra_power(ctx, key, d_w, wlen, r32, s32):
+    """What clock and socket power the chip runs proofs at, against the clock / power of the probes that define the integer peak
+    (wsnark_peak_probe 1: the product chain).  A power-managed part does not run every instruction mix at one clock: the peak
+    (G products/s) is measured at the probe's clock, the proof runs at its own."""
+    bn = ctx["bn"]
+    import ctypes as C
+    read = _gpu_power_sampler()
+    if read is None:
+        return {"error": "no readable clock / power source (sysfs hwmon, rocm-smi)"}
+
+    def sample_while(fn, seconds):
+        got, stop = [], threading.Event()
+
+        def sampler():
+            time.sleep(0.5)                                 # (the firmware's averaging window)
+            while not stop.is_set():
+                v = read()                                  # (~0.2 s per call)
+                if v:
+                    got.append(v)
+        th = threading.Thread(target=sampler); th.start()
+        t0 = time.perf_counter(); n = 0
+        while time.perf_counter() - t0 < seconds:
+            fn(); n += 1
+        dt = time.perf_counter() - t0
+        stop.set(); th.join()
+        if not got:
+            return None
+        return {"sclk_MHz": round(sum(g[0] for g in got) / len(got)), "socket_W": round(sum(g[1] for g in got) / len(got)),
+                "samples": len(got), "calls": n, "ms_per_call": round(dt / n * 1e3, 3)}
+
+    def probe(which):
+        v = C.c_double(0)
+        bn.lib.check(bn.lib.c.wsnark_peak_probe(which, C.byref(v)))
+    res = {"idle": dict(zip(("sclk_MHz", "socket_W"), [round(x) for x in read()])),
+           "proofs_back_to_back": sample_while(lambda: bn.groth16GenProof_dev(d_w.data_ptr(), wlen, key, r=r32, s=s32), 4.0),
+           "product_chain_probe": sample_while(lambda: probe(1), 3.0),
+           "multiply_add_probe": sample_while(lambda: probe(10), 3.0)}
+    a, b = res["proofs_back_to_back"], res["product_chain_probe"]
+    if a and b and b["sclk_MHz"]:
+        res["proof_clock_over_probe_clock"] = round(a["sclk_MHz"] / b["sclk_MHz"], 4)
+        res["note"] = ("the issue rates and the product peak of this line are measured by probes that run at product_chain_probe.sclk_MHz; whole "
+                       "proofs hold the socket at its power limit and run at proofs_back_to_back.sclk_MHz: every `frac` against those peaks "
+                       "contains that clock ratio (profiles/r06_clock_power_probe.txt)")
     return res
 
 

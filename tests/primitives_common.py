@@ -267,3 +267,32 @@ def degenerate_key_and_witness(orc, pkey, wit):
     for i in range(6, 20):
         w[i * 32:(i + 1) * 32] = w[5 * 32:6 * 32]
     return bytes(key), bytes(w)
+
+
+def check_msm_corner_case_buckets(bn, orc, g, cases=24, seed=5):
+    """Every pair of a sum carries the SAME scalar, so each window's bucket holds all the points, in whatever order the grouping pass
+    left them: tasks whose first entry is infinity, whose second entry equals or cancels the first (the affine + affine step of the
+    accumulation's fast loop must hand both to the generic loop: doubling, infinity), duplicates and P / -P pairs further on, sums
+    that pass through infinity and go on.  Against the oracle's restatement of the reference's multiexp (src/build_multiexp.js:498-744),
+    whose additions take the branches of src/build_curve_jacobian_a0.js:322-356."""
+    rnd = random.Random(seed + g)
+    gen = bytes.fromhex(load_golden("groups.json")["g%d" % g]["gen"])
+    sz = 64 if g == 1 else 128
+    aff = lambda p: orc.g_affine(g, p)[:sz]
+    base = []
+    for k in (3, 5, 11):
+        p = orc.g_times_scalar(g, gen, k.to_bytes(32, "little"))
+        base += [aff(p), aff(orc.g_neg(g, p))]
+    inf = bytes(sz)
+    # hand-made orders first (the grouping pass keeps short lists in input order often enough), then random multisets
+    fixed = [[inf, base[0], base[0]], [base[0], base[0], base[2]], [base[0], base[1], base[2]], [base[0], inf, base[1], inf, base[0]],
+             [inf, inf, base[4]], [base[2], base[2], base[2], base[3], base[3]], [base[0], base[1], base[0], base[1]], [inf]]
+    for i in range(cases):
+        pts = fixed[i] if i < len(fixed) else [rnd.choice(base + [inf]) for _ in range(rnd.randrange(2, 14))]
+        n = len(pts)
+        s = rnd.choice([1, 2, 0x10001, (1 << 255) + 12345, rnd.randrange(1 << 256)])
+        sc = s.to_bytes(32, "little") * n
+        p = b"".join(pts)
+        got = bn.g1_multiexp(sc, p) if g == 1 else bn.g2_multiexp(sc, p)
+        want = orc.g_affine(g, orc.multiexp(g, "multiexp2" if g == 1 else "multiexp", sc, p, n))
+        assert got == want, (g, i, n, hex(s))

@@ -167,6 +167,12 @@ def test_msm_same_point_many_times(bn, orc):
     assert out == want
 
 
+@pytest.mark.parametrize("g", [1, 2])
+def test_msm_corner_case_buckets(bn, orc, g):
+    from primitives_common import check_msm_corner_case_buckets
+    check_msm_corner_case_buckets(bn, orc, g)
+
+
 def test_calc_h_golden(bn):
     for c in load_golden("calch.json"):
         h = bn.calcH(B64(c["signals"]), B64(c["polsA"]), B64(c["polsB"]), c["nSignals"], c["domain"])

@@ -136,6 +136,13 @@ def test_msm_vs_oracle(bn, orc, g, n):
     assert got == want
 
 
+@pytest.mark.parametrize("g", [1, 2])
+def test_msm_corner_case_buckets(bn, orc, g):
+    """the accumulation's fast loop hands every corner case of the reference's addition to the generic loop"""
+    from primitives_common import check_msm_corner_case_buckets
+    check_msm_corner_case_buckets(bn, orc, g, cases=40)
+
+
 def test_msm_all_same_point(bn, orc):
     n = 3000
     pts = bn.mul_base(1, (7).to_bytes(32, "little")) * n
