@@ -39,10 +39,7 @@ __global__ __launch_bounds__(256) void lc_spmv2_kernel(SpmvPair M, const Fe* __r
     const uint32_t* __restrict__ row_ptr = M.row_ptr[blockIdx.y];
     const uint32_t* __restrict__ col = M.col[blockIdx.y];
     const Fe* __restrict__ coef = M.coef[blockIdx.y];
-    Fe acc = Fr::zero();
-    const uint32_t e = row_ptr[r + 1];
-    for (uint32_t k = row_ptr[r]; k < e; k++) acc = Fr::add(acc, Fr::mul(coef[k], sig[col[k]]));
-    M.res[blockIdx.y][r] = acc;
+    M.res[blockIdx.y][r] = lc_row_dot(coef, col, sig, row_ptr[r], row_ptr[r + 1]);
 }
 
 __global__ __launch_bounds__(256) void fr_mul_kernel(const Fe* __restrict__ a, const Fe* __restrict__ b, Fe* __restrict__ out, uint64_t n) {

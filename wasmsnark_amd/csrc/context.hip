@@ -414,8 +414,8 @@ int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s
     // a points shard's 8 MiB sections went up in 4 MiB chunks, the 16 MiB one behind them in 8 MiB chunks -- and overwrote the second
     // half of its predecessor before that had left the ring.)
     if (C->pin_chunk_last != chunk) {
-        for (auto& e : C->pin_ev)
-            if (hipEventSynchronize(e) != hipSuccess) { set_last_error("staged upload: a ring slot's DMA failed"); return WS_ERR_HIP; }
+        for (int i = 0; i < PIN_MAX_SLOTS; i++)
+            if (C->pin_ev_rec[i] && hipEventSynchronize(C->pin_ev[i]) != hipSuccess) { set_last_error("staged upload: a ring slot's DMA failed"); return WS_ERR_HIP; }
         C->pin_chunk_last = chunk;
     }
     const size_t G = (bytes + chunk - 1) / chunk;
@@ -453,6 +453,11 @@ int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s
     auto release_upto = [&](size_t limit, bool block) -> int {
         while (next < limit) {
             hipEvent_t ev = C->pin_ev[next % nslots];
+            if (!C->pin_ev_rec[next % nslots]) {           // a slot no DMA has left yet: free (and its event is not to be touched, internal.h)
+                released.store(++next, std::memory_order_release);
+                block = false;
+                continue;
+            }
             if (block) {
                 if (hipEventSynchronize(ev) != hipSuccess) { set_last_error("staged upload: a ring slot's DMA failed"); return WS_ERR_HIP; }
             } else {
@@ -479,6 +484,7 @@ int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s
         const size_t slot = g % nslots;
         if (hipMemcpyAsync((char*)d_dst + lo, ring + slot * chunk, hi - lo, hipMemcpyHostToDevice, s) != hipSuccess ||
             hipEventRecord(C->pin_ev[slot], s) != hipSuccess) { set_last_error("staged upload: DMA failed"); rc = WS_ERR_HIP; break; }
+        C->pin_ev_rec[slot] = true;
         if (on_chunk) rc = on_chunk(lo, hi, s);
     }
     if (rc) stop.store(1);                          // the workers leave at their next chunk boundary

@@ -41,10 +41,7 @@ __global__ __launch_bounds__(256) void lc_spmv_rows_kernel(const uint32_t* __res
     if (idx >= (cols << log_rows)) return;
     const uint64_t r = idx & (((uint64_t)1 << log_rows) - 1), j = idx >> log_rows;
     const uint64_t t = (row0 + r) + (j << log_n1);
-    Fe acc = Fr::zero();
-    const uint32_t e = row_ptr[t + 1];
-    for (uint32_t k = row_ptr[t]; k < e; k++) acc = Fr::add(acc, Fr::mul(coef[k], sig[col[k]]));
-    res[r * cols + j] = acc;
+    res[r * cols + j] = lc_row_dot(coef, col, sig, row_ptr[t], row_ptr[t + 1]);
 }
 
 // send[q][v][r][c2] = x[v][r][q r2 + c2] * w_n^(+-(row0 + r)(q r2 + c2)): twiddle + block order of the exchange in one pass.

@@ -109,6 +109,11 @@ struct Context {
     size_t pin_ring_bytes = 0;
     size_t pin_chunk_last = 0;                  // chunk size of the last upload through the ring (slot geometry of the events)
     hipEvent_t pin_ev[128] = {};                // one per ring slot: the slot's last DMA
+    bool pin_ev_rec[128] = {};                  // ... and whether it has EVER been recorded: an event that has not is never queried or
+                                                // waited for (ROCm 7.2: hipEventQuery / hipEventSynchronize on a never-recorded event read
+                                                // its capture state, which a fresh event does not always have -- "operation not permitted
+                                                // on an event last recorded in a capturing stream" once in three full GPU suites, always
+                                                // on the first upload through the ring of a context created after others were destroyed)
     hipStream_t load_q[2] = {nullptr, nullptr}; // key loads: the two matrices are transposed side by side on these
     hipStream_t build_q = nullptr;              // the keys' background table builds, one after the other: the LOWEST stream priority (prove.hip)
     DevBuf build_tmp;                           // ... and their scratch slab (the builds are serial on build_q: one slab serves them all); grow-only
@@ -332,5 +337,22 @@ int calc_h_dist(Lane& L, const DistComm& cm, const Fe* d_signals_plain, uint32_t
                 uint32_t domain, uint32_t l2_expected, Fe* d_h_local, hipStream_t s, int* exchanges = nullptr);
 // its checks and buffer reserves alone (what can fail on one rank before any collective)
 int calc_h_dist_reserve(Lane& L, const DistComm& cm, uint32_t n_signals, uint32_t domain, uint32_t l2_expected);
+
+// One row of pol_constructLC (src/build_pol.js:62-144): sum_k coef[k] * sig[col[k]] over the row's CSR range, on the radix-2^29 field
+// (round 6, session 3: the kernel was priced by the counters at 0.78 of its ISSUE floor -- not gather latency -- with the saturated
+// field's 584-instruction product; a wavefront runs as many terms as its longest row).  Terms go in PAIRS through the fused double
+// product (one Montgomery reduction for two terms), the rest through a single one; the sum is kept in [0, 2r).  coef is c R^2 in the
+// reference's Montgomery form (R = 2^256: calch.hip pols_to_csr), sig the plain signal -- any 256-bit value --, so a product here is
+// c w R 2^-5 on this field's radix (2^261); one closing product by 2^266 mod r (the field's to_internal constant) makes the row's sum
+// the Montgomery term sum c w R, canonical: bit for bit what the saturated field gave.
+__device__ __forceinline__ Fe lc_row_dot(const Fe* __restrict__ coef, const uint32_t* __restrict__ col, const Fe* __restrict__ sig,
+                                         uint32_t k, uint32_t e) {
+    typedef Fr29 F;
+    F29 acc = F::zero();
+    for (; k + 1 < e; k += 2)
+        acc = F::add(acc, F::mul2add_inl(F::unpack(coef[k]), F::unpack(sig[col[k]]), F::unpack(coef[k + 1]), F::unpack(sig[col[k + 1]])));
+    if (k < e) acc = F::add(acc, F::mul_inl(F::unpack(coef[k]), F::unpack(sig[col[k]])));
+    return F::pack(F::canonical(F::mul_inl(acc, F::from_words(Fr29Params::CIN0, Fr29Params::CIN1, Fr29Params::CIN2, Fr29Params::CIN3))));
+}
 
 }  // namespace wsnark
