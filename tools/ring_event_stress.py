@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""Stress for the staging ring's slot events (csrc/context.hip: upload_pipelined): contexts are created and destroyed over and over
-(groups of two on device 0), and the FIRST upload of every new context goes through a fresh ring -- slot events that have never been
-recorded.  Before round 6's fix those events were queried / waited for, and ROCm 7.2 answered, now and then, "operation not permitted
-on an event last recorded in a capturing stream" (one full GPU suite in three; internal.h: pin_ev_rec).
+"""Stress around the staging ring's slot events (csrc/context.hip: upload_pipelined): groups of two contexts on device 0 are created, load a
+key from host sections (the transposition of matrix B runs on a helper thread: prove.hip), prove and are destroyed, with loads on the
+default context in between.  Before round 6's fix the helper thread staged matrix B through the DEFAULT context's ring on the GROUP
+context's queue, which left default-ring events pointing at a queue that the group's end destroyed; ROCm 7.2's hipEventQuery reads the
+queue through the event ("operation not permitted on an event last recorded in a capturing stream", one GPU suite in five).  Whether the
+stale read trips depends on what the freed memory holds: this loop did NOT trip it in 240 rounds on the old library -- it is kept as the
+closest thing to a regression run; the deterministic guard is upload_pipelined's queue_of_context check.
     python tools/ring_event_stress.py [rounds, default 40] [path/to/other/libwsnark.so]     -> one JSON line"""
 import json, os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

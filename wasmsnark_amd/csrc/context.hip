@@ -360,10 +360,25 @@ static int ensure_ring(Context* C) {
     return WS_OK;
 }
 
+// The ring's slot events are recorded on the queue an upload names, and the runtime keeps that queue's address inside the event
+// (hipEventRecord stores it, hipEventQuery / hipEventSynchronize read the queue's capture state through it -- libamdhip64 7.2): an
+// event must never outlive the queue it was last recorded on.  Both belong to ONE context here, which holds as long as an upload runs
+// on the context whose queue it names -- checked, because a helper thread once did not (prove.hip, the transposition of matrix B).
+static bool queue_of_context(const Context* C, hipStream_t s) {
+    if (s == C->stream || s == C->build_q) return true;
+    for (const auto& q : C->load_q) if (s == q) return true;
+    for (int i = 0; i < C->n_lanes; i++) {
+        const Lane& L = C->lanes[i];
+        if (s == L.stream || s == L.stream2 || s == L.stream3 || s == L.stream_copy) return true;
+    }
+    return false;
+}
+
 int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s, const ChunkFn& on_chunk, bool* direct_out) {
     Context* C = ctx();
     if (!C) return WS_ERR_NOINIT;
     if (!s) s = C->stream;
+    if (!queue_of_context(C, s)) { set_last_error("staged upload: the queue belongs to another context than the one this thread has selected"); return WS_ERR_ARG; }
     if (direct_out) *direct_out = false;
     if (bytes == 0) return WS_OK;
     // chunk size: WSNARK_STAGE_CHUNK_KB (default 4 MiB; 64 KiB granules, 64 KiB .. 16 MiB).  Measured on the MI355X box with a
@@ -453,7 +468,7 @@ int upload_pipelined(void* d_dst, const void* h_src, size_t bytes, hipStream_t s
     auto release_upto = [&](size_t limit, bool block) -> int {
         while (next < limit) {
             hipEvent_t ev = C->pin_ev[next % nslots];
-            if (!C->pin_ev_rec[next % nslots]) {           // a slot no DMA has left yet: free (and its event is not to be touched, internal.h)
+            if (!C->pin_ev_rec[next % nslots]) {           // a slot no DMA has left yet: free
                 released.store(++next, std::memory_order_release);
                 block = false;
                 continue;

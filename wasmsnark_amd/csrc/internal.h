@@ -109,11 +109,9 @@ struct Context {
     size_t pin_ring_bytes = 0;
     size_t pin_chunk_last = 0;                  // chunk size of the last upload through the ring (slot geometry of the events)
     hipEvent_t pin_ev[128] = {};                // one per ring slot: the slot's last DMA
-    bool pin_ev_rec[128] = {};                  // ... and whether it has EVER been recorded: an event that has not is never queried or
-                                                // waited for (ROCm 7.2: hipEventQuery / hipEventSynchronize on a never-recorded event read
-                                                // its capture state, which a fresh event does not always have -- "operation not permitted
-                                                // on an event last recorded in a capturing stream" once in three full GPU suites, always
-                                                // on the first upload through the ring of a context created after others were destroyed)
+    bool pin_ev_rec[128] = {};                  // ... and whether it has ever been recorded: a slot no DMA has left is free without a
+                                                // call into the runtime (and an event is only ever looked at after a record on a queue
+                                                // of THIS context: context.hip, queue_of_context)
     hipStream_t load_q[2] = {nullptr, nullptr}; // key loads: the two matrices are transposed side by side on these
     hipStream_t build_q = nullptr;              // the keys' background table builds, one after the other: the LOWEST stream priority (prove.hip)
     DevBuf build_tmp;                           // ... and their scratch slab (the builds are serial on build_q: one slab serves them all); grow-only

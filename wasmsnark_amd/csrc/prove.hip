@@ -262,6 +262,13 @@ int pkey_load_sections(const KeySections& S, ProvingKey** out, KeyShard shard) {
         const int device = C->device;
         std::string err_b;                      // (the error text is per thread: carried back by hand)
         std::future<int> fb = std::async(std::launch::async, [&, device, sb]() {
+            // THIS context on the helper thread, not just its device (round 6): a new thread's selection is the process's DEFAULT
+            // context, so the records of matrix B went up through the default context's staging ring whatever context was loading --
+            // a group member's load left the default ring's slot events recorded on ITS queue, and once the group was gone the next
+            // upload through the default ring queried events whose queue had been destroyed (hipEventQuery dereferences the event's
+            // last queue: "operation not permitted on an event last recorded in a capturing stream", one GPU suite in five); on a
+            // real second GPU the record itself fails (an event of device 0 on a queue of device 1).
+            CtxScope helper_scope(C);
             if (hipSetDevice(device) != hipSuccess) return (int)WS_ERR_HIP;
             const int r = pols_to_csr(S.polsB, (size_t)S.lenB, nv, dom, &K->polsB, &used_b, sb, S.release);
             if (r) err_b = get_last_error();
