@@ -99,6 +99,7 @@ struct hipDeviceProp_t { int multiProcessorCount; char name[64]; char gcnArchNam
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "emulated failure"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     p->multiProcessorCount = 4; strcpy(p->name, "cpu-emulator"); strcpy(p->gcnArchName, "emul"); return hipSuccess;

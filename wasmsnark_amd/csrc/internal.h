@@ -128,8 +128,17 @@ Context* ctx();   // nullptr before wsnark_init
 Context* ctx_set_current(Context* c);          // returns the previous selection of this thread (nullptr = the default)
 struct CtxScope {
     Context* prev;
-    explicit CtxScope(Context* c) : prev(ctx_set_current(c)) { if (c) (void)hipSetDevice(c->device); }
-    ~CtxScope() { (void)ctx_set_current(prev); }
+    int prev_device = -1;          // the thread's device is the CALLER's too (torch reads hipGetDevice): put back what was there
+    explicit CtxScope(Context* c) : prev(ctx_set_current(c)) {
+        if (!c) return;
+        int d = -1;
+        if (hipGetDevice(&d) == hipSuccess && d != c->device) prev_device = d;
+        (void)hipSetDevice(c->device);
+    }
+    ~CtxScope() {
+        (void)ctx_set_current(prev);
+        if (prev_device >= 0) (void)hipSetDevice(prev_device);
+    }
     CtxScope(const CtxScope&) = delete;
     CtxScope& operator=(const CtxScope&) = delete;
 };
