@@ -181,6 +181,7 @@ extern "C" {
 
 int wsnark_group_create(const int* devices, uint32_t n, wsnark_group_t** out) {
     if (!out || !devices || n == 0 || n > 64) return WSNARK_ERR_ARG;
+    DeviceRestore caller_device;                  // (context_create selects every member's device in turn on this thread)
     std::unique_ptr<Group> G(new Group());
     G->n = n;
     G->bar.n = n;
@@ -237,6 +238,7 @@ static void group_key_release(GroupKey* K) {      // caller holds the group's mu
 }
 void wsnark_group_free(wsnark_group_t* h) {
     if (!h) return;
+    DeviceRestore caller_device;
     Group* G = reinterpret_cast<Group*>(h);
     {
         std::lock_guard<std::mutex> lk(G->mu);

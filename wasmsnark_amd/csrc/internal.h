@@ -142,6 +142,14 @@ struct CtxScope {
     CtxScope(const CtxScope&) = delete;
     CtxScope& operator=(const CtxScope&) = delete;
 };
+// the calling thread's device as it was (group create / free walk over devices on the CALLER's thread: torch reads hipGetDevice)
+struct DeviceRestore {
+    int prev = -1;
+    DeviceRestore() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceRestore() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceRestore(const DeviceRestore&) = delete;
+    DeviceRestore& operator=(const DeviceRestore&) = delete;
+};
 int context_create(int device, Context** out, bool wrap = false);  // a context of its own on that device (wsnark_group_create)
 void context_destroy(Context* C);
 // One no-op kernel per translation unit: the runtime loads a TU's code object when the first of its kernels is launched (7-12 ms for
