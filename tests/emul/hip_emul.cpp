@@ -3,6 +3,7 @@
 
 #include <ucontext.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -22,6 +23,12 @@
 #else
 #define EMUL_TSAN 0
 #endif
+
+// a queue handle of its own per hipStreamCreate* (hip_emul.h): distinct, non-null, never dereferenced
+hipStream_t emul_new_stream_handle() {
+    static std::atomic<uintptr_t> next{0};
+    return reinterpret_cast<hipStream_t>((next.fetch_add(1) + 1) << 6);
+}
 
 namespace hip_emul {
 

@@ -120,9 +120,12 @@ static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); 
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b) { *free_b = (size_t)8 << 30; *total_b = (size_t)8 << 30; return hipSuccess; }
 static inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = 0; return hipSuccess; }
-static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = nullptr; return hipSuccess; }
-static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
-static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+// Every queue gets a handle of its own (never dereferenced): code that compares queues -- context.hip's queue_of_context, which keeps
+// an upload on the context whose queue it names -- then means on the emulator what it means on the device.
+hipStream_t emul_new_stream_handle();
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = emul_new_stream_handle(); return hipSuccess; }
+static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = emul_new_stream_handle(); return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = emul_new_stream_handle(); return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
