@@ -24,10 +24,21 @@
 #define EMUL_TSAN 0
 #endif
 
-// a queue handle of its own per hipStreamCreate* (hip_emul.h): distinct, non-null, never dereferenced
+// queue / event handles (hip_emul.h): distinct, non-null, never dereferenced; the low six bits hold the device they were created on
+int emul_device_count() {
+    const char* e = getenv("WSNARK_EMUL_DEVICES");
+    const int n = e ? atoi(e) : 1;
+    return n < 1 ? 1 : n > 16 ? 16 : n;
+}
+int& emul_current_device() { static thread_local int d = 0; return d; }
+hipError_t& emul_last_error() { static thread_local hipError_t e = hipSuccess; return e; }
 hipStream_t emul_new_stream_handle() {
     static std::atomic<uintptr_t> next{0};
-    return reinterpret_cast<hipStream_t>((next.fetch_add(1) + 1) << 6);
+    return reinterpret_cast<hipStream_t>(((next.fetch_add(1) + 1) << 6) | (uintptr_t)emul_current_device());
+}
+hipEvent_t emul_new_event_handle() {
+    static std::atomic<uintptr_t> next{0};
+    return reinterpret_cast<hipEvent_t>(((next.fetch_add(1) + 1) << 6) | (uintptr_t)emul_current_device());
 }
 
 namespace hip_emul {

@@ -96,11 +96,27 @@ enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDevice
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 struct hipDeviceProp_t { int multiProcessorCount; char name[64]; char gcnArchName[64]; };
 
-static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "emulated failure"; }
-static inline hipError_t hipGetLastError() { return hipSuccess; }
-static inline hipError_t hipSetDevice(int) { return hipSuccess; }
-static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
-static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+// ---- devices (round 6, closing): WSNARK_EMUL_DEVICES = how many "devices" the emulator shows (default 1).  They share the host's
+// memory; what they do NOT share is what real devices do not share either: a thread's CURRENT device, and the device a queue or an
+// event belongs to.  Work queued on a queue of another device than the thread's current one, and an event of one device recorded on a
+// queue of another, fail the way the runtime makes them fail -- so that the CPU suite sees the device-selection mistakes of a
+// several-GPU process (a helper thread that never selected its device; a record across devices) that one-GPU boxes cannot show.
+enum { hipErrorInvalidDevice = 101, hipErrorInvalidHandle = 400 };
+int emul_device_count();
+int& emul_current_device();                     // this thread's
+hipError_t& emul_last_error();                  // this thread's sticky error (hipGetLastError reads and clears it)
+static inline int emul_handle_device(const void* h) { return (int)((uintptr_t)h & 63); }
+static inline hipError_t emul_fail(hipError_t e) { emul_last_error() = e; return e; }
+static inline const char* hipGetErrorString(hipError_t e) {
+    return e == hipSuccess ? "success" : e == hipErrorInvalidHandle ? "emulated: a queue / event of another device than the thread's current one"
+           : e == hipErrorInvalidDevice ? "emulated: no such device" : "emulated failure";
+}
+static inline hipError_t hipGetLastError() { hipError_t e = emul_last_error(); emul_last_error() = hipSuccess; return e; }
+static inline hipError_t hipSetDevice(int d) { if (d < 0 || d >= emul_device_count()) return emul_fail(hipErrorInvalidDevice); emul_current_device() = d; return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = emul_current_device(); return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = emul_device_count(); return hipSuccess; }
+// a queue of the thread's current device?  (nullptr = the current device's default queue)
+static inline bool emul_queue_ok(const void* s) { return s == nullptr || emul_handle_device(s) == emul_current_device(); }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     p->multiProcessorCount = 4; strcpy(p->name, "cpu-emulator"); strcpy(p->gcnArchName, "emul"); return hipSuccess;
 }
@@ -114,10 +130,10 @@ static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = aligned_alloc(64, (n + 63) & ~(size_t)63); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
-static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
-static inline hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t q) { if (!emul_queue_ok(q)) return emul_fail(hipErrorInvalidHandle); memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t q) { if (!emul_queue_ok(q)) return emul_fail(hipErrorInvalidHandle); memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
-static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t q) { if (!emul_queue_ok(q)) return emul_fail(hipErrorInvalidHandle); memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b) { *free_b = (size_t)8 << 30; *total_b = (size_t)8 << 30; return hipSuccess; }
 static inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = 0; return hipSuccess; }
 // Every queue gets a handle of its own (never dereferenced): code that compares queues -- context.hip's queue_of_context, which keeps
@@ -130,12 +146,18 @@ static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
-static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = reinterpret_cast<hipEvent_t>(1); return hipSuccess; }   // (non-null: code tests handles)
+hipEvent_t emul_new_event_handle();            // (non-null: code tests handles; carries the device it was created on)
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = emul_new_event_handle(); return hipSuccess; }
 static const unsigned hipEventDisableTiming = 2;
-static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = reinterpret_cast<hipEvent_t>(1); return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = emul_new_event_handle(); return hipSuccess; }
 static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
-static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+// (the runtime compares the event's device with the queue's: libamdhip64 7.2 returns hipErrorInvalidHandle on a mismatch)
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t q) {
+    const int qd = q ? emul_handle_device(q) : emul_current_device();
+    if (emul_handle_device(e) != qd) return emul_fail(hipErrorInvalidHandle);
+    return hipSuccess;
+}
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 template <class F> static inline hipError_t hipFuncSetAttribute(F, int, int) { return hipSuccess; }
@@ -147,5 +169,7 @@ static inline void emul_launch(K kernel, dim3 g, dim3 b, size_t sh, Args... args
     launch(g, b, sh, [=]() { kernel(args...); });
 }
 }  // namespace hip_emul
+// (a launch on a queue of another device than the thread's current one is not run: it leaves the sticky error the library's
+//  hipGetLastError() checks pick up)
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-    ::hip_emul::emul_launch(kernel, (grid), (block), (shmem), __VA_ARGS__)
+    (emul_queue_ok(stream) ? ::hip_emul::emul_launch(kernel, (grid), (block), (shmem), __VA_ARGS__) : (void)emul_fail(hipErrorInvalidHandle))

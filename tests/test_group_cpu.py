@@ -98,3 +98,34 @@ def test_terminate_with_a_live_key_then_free_is_a_no_op():
     k2 = g2.load_key(pkey)
     assert g2.groth16GenProof(wit, k2, r=bytes.fromhex(c["r"]), s=bytes.fromhex(c["s"])) == c["proof"]
     g2.terminate()
+
+
+@pytest.mark.parametrize("devices", [[0, 1], [1, 0, 1, 0], [1, 1]])
+def test_group_on_several_emulated_devices(monkeypatch, devices):
+    """The emulator shows WSNARK_EMUL_DEVICES devices (tests/emul/hip_emul.h): a thread has a current device, queues and events belong to
+    the device they were created on, and work on a queue of another device than the thread's current one -- or an event of one device
+    recorded on a queue of another -- fails as the runtime makes it fail.  A group over two devices must therefore get every thread it
+    uses onto the right device: the members' workers, the key load's helper thread (which round 6 found on the default context: on a
+    second GPU its staging ring's events are device 0's), the caller's own thread in create / load / prove / free."""
+    monkeypatch.setenv("WSNARK_EMUL_DEVICES", "2")
+    bn = emul_bn128()
+    pkey, wit, _ = _key("t6")
+    g = bn128.Group(lib=bn.lib, devices=devices)
+    try:
+        key = g.load_key(pkey)
+        assert key.world == len(devices)
+        for c in load_golden("proofs.json")["t6"]:
+            assert g.groth16GenProof(wit, key, r=bytes.fromhex(c["r"]), s=bytes.fromhex(c["s"])) == c["proof"]
+        c = load_golden("msm.json")["g1"][3]
+        sc, pt = base64.b64decode(c["scalars"]), base64.b64decode(c["points"])
+        assert g.g1_multiexp(sc, pt) == bn.g1_multiexp(sc, pt)
+        # the default context (device 0) still works from this thread afterwards: the group calls put the caller's device back
+        k0 = bn.load_key(pkey)
+        c0 = load_golden("proofs.json")["t6"][0]
+        assert bn.groth16GenProof(wit, k0, r=bytes.fromhex(c0["r"]), s=bytes.fromhex(c0["s"])) == c0["proof"]
+        k0.free()
+        key.free()
+    finally:
+        g.terminate()
+    with pytest.raises(Exception):
+        bn128.Group(lib=bn.lib, devices=[0, 2])                 # no such device: refused, not wrapped
