@@ -54,7 +54,7 @@ def test_bench_two_ranks_line():
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", "29657", os.path.join(ROOT, "tools", "bench_dryrun.py"), "--gpus", "2", "--prove-log-domain", "6",
                           "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
-                         capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1", WSNARK_EMUL_DEVICES="2"))
     d = _line(out)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["proofs_match_toxic_waste_closed_form"] is True
     assert "distributed four-step NTT" in d["config"]["parallelism"] and "extras" not in d
@@ -72,7 +72,7 @@ def test_bench_two_ranks_from_a_key_file(tmp_path):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", "29661", os.path.join(ROOT, "tools", "bench_dryrun.py"), "--gpus", "2", "--prove-log-domain", "6",
                           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--key-file", "auto"],
-                         capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1", WSNARK_BENCH_KEY_DIR=str(tmp_path)))
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1", WSNARK_EMUL_DEVICES="2", WSNARK_BENCH_KEY_DIR=str(tmp_path)))
     d = _line(out)
     assert d["n_gpus"] == 2 and d["proofs_match_toxic_waste_closed_form"] is True
     assert "wsnark_groth16_prove_dist" in d["config"]["parallelism"] and "fell through" not in d["config"]["parallelism"]
@@ -98,13 +98,19 @@ def test_bench_two_ranks_falls_through_when_an_orchestration_fails():
 
 
 def test_bench_single_process_group_line():
-    """python bench.py --gpus 2 --single-process: ONE process drives the devices through wsnark_group_* (here: two contexts on the
-    emulator's one device)"""
+    """python bench.py --gpus 2 --single-process: ONE process drives the devices through wsnark_group_* (two contexts on the
+    emulator's one device, then one context on each of two emulated devices: tests/emul/hip_emul.h)"""
     from emul_util import emul_bn128
     emul_bn128()
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_dryrun.py"), "--gpus", "2", "--single-process", "--group-devices", "0,0",
-                          "--prove-log-domain", "6", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900)
-    d = _line(out)
+    for devs, ndev in (("0,0", "1"), ("0,1", "2")):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_dryrun.py"), "--gpus", "2", "--single-process", "--group-devices", devs,
+                              "--prove-log-domain", "6", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900,
+                             env=dict(os.environ, WSNARK_EMUL_DEVICES=ndev))
+        d = _line(out)
+        check_group_line(d, shared=(devs == "0,0"))
+
+
+def check_group_line(d, shared):
     assert d["n_gpus"] == 2 and d["proofs_match_toxic_waste_closed_form"] is True and d["one_gpu_proof_matches"] is True
     assert "wsnark_group_prove" in d["config"]["parallelism"] and "four-step" in d["config"]["parallelism"]
-    assert "functional check" in d["note"]
+    assert ("functional check" in d["note"]) if shared else d["note"] is None      # (two contexts on ONE device is not a scaling figure)

@@ -18,6 +18,7 @@ from wasmsnark_amd import dist as wd
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 bn = emul_bn128()
+assert bn.device_info.endswith("device=%d" % (rank % 2)), bn.device_info     # (two emulated devices: rank 1 works on device 1)
 rnd = random.Random(42)
 for g, n in ((1, 45), (2, 21)):
     sz = 64 if g == 1 else 128
@@ -70,7 +71,7 @@ def test_sharded_msm_world2(tmp_path):
     emul_bn128()   # build the emulator library once, before the ranks race for it
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, WS_ROOT=ROOT, WS_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, WS_ROOT=ROOT, WS_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1", WSNARK_EMUL_DEVICES="2")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29611", str(script)],
                          env=env, capture_output=True, text=True, timeout=600)

@@ -19,6 +19,7 @@ from wasmsnark_amd import dist as wd
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 bn = emul_bn128()
+assert bn.device_info.endswith("device=%d" % (rank % 2)), bn.device_info     # (two emulated devices: rank 1 works on device 1)
 def gather(y):
     parts = [torch.empty_like(y) for _ in range(world)]
     dist.all_gather(parts, y)
@@ -124,7 +125,7 @@ def test_dist_ntt_world2(tmp_path):
     emul_bn128()
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, WS_ROOT=ROOT, WS_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, WS_ROOT=ROOT, WS_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1", WSNARK_EMUL_DEVICES="2")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29641", str(script)],
                          env=env, capture_output=True, text=True, timeout=900)
@@ -141,6 +142,7 @@ from wasmsnark_amd import dist as wd, formats
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 bn = emul_bn128()
+assert bn.device_info.endswith("device=%d" % (rank % 2)), bn.device_info     # (two emulated devices: rank 1 works on device 1)
 gold = os.path.join(os.environ["WS_ROOT"], "tests", "golden")
 pkey = open(os.path.join(gold, "keys", "t6.pkey.bin"), "rb").read()
 wit = open(os.path.join(gold, "keys", "t6.witness.bin"), "rb").read()
@@ -166,7 +168,7 @@ def test_native_dist_prover_world4_and_world8(tmp_path):
     for world, port in ((4, "29643"), (8, "29644")):
         out_dir = tmp_path / ("w%d" % world)
         out_dir.mkdir()
-        env = dict(os.environ, WS_ROOT=ROOT, WS_OUT=str(out_dir), MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+        env = dict(os.environ, WS_ROOT=ROOT, WS_OUT=str(out_dir), MASTER_ADDR="127.0.0.1", WSNARK_EMUL_DEVICES="2", OMP_NUM_THREADS="1")
         out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                               "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
                              env=env, capture_output=True, text=True, timeout=1200)

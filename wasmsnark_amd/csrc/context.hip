@@ -129,7 +129,7 @@ static int context_create_impl(int device, bool wrap, Context* C) {
     hipDeviceProp_t prop;
     WS_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     C->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    C->devinfo = std::string(prop.name) + " " + prop.gcnArchName + " CUs=" + std::to_string(C->num_cu);
+    C->devinfo = std::string(prop.name) + " " + prop.gcnArchName + " CUs=" + std::to_string(C->num_cu) + " device=" + std::to_string(device);
     WS_HIP_CHECK(hipStreamCreateWithFlags(&C->stream, hipStreamNonBlocking));
     {
         const long nl = tuning_get("LANES", 2);
