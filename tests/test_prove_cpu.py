@@ -344,7 +344,7 @@ def test_reduction_tail_geometries(orc):
     import random
     bn = emul_bn128()
     tune = bn.lib.tune
-    names = ("MSM_CHUNK", "TAIL_BITS")
+    names = ("MSM_CHUNK", "TAIL_BITS", "TAIL_L2")
     try:
         rnd = random.Random(5)
         for g, n in ((1, 1500), (2, 400)):
@@ -353,9 +353,10 @@ def test_reduction_tail_geometries(orc):
             sc = b"".join((rnd.randrange(orc.R) if i % 7 else i % 3).to_bytes(32, "little") for i in range(n))
             want = orc.g_affine(g, orc.multiexp(g, "multiexp2" if g == 1 else "multiexp", sc, pts, n))
             msm = bn.g1_multiexp if g == 1 else bn.g2_multiexp
-            for chunk, bits_w in ((2, 3), (4, None), (4, 4), (8, 3), (8, None)):
-                tune("MSM_CHUNK", chunk); tune("TAIL_BITS", bits_w)
-                assert msm(sc, pts) == want, (g, chunk, bits_w)
+            # (l2: the second chunk level, msm_chunks2 -- m2 chunk pairs folded into one before the trees)
+            for chunk, bits_w, l2 in ((2, 3, None), (4, None, None), (4, 4, None), (8, 3, None), (8, None, None), (2, 5, 2), (2, 6, 4), (2, 4, 2)):
+                tune("MSM_CHUNK", chunk); tune("TAIL_BITS", bits_w); tune("TAIL_L2", l2)
+                assert msm(sc, pts) == want, (g, chunk, bits_w, l2)
         for name in names:
             tune(name, None)
         circ = synth.NativeCircuit(bn.lib, 10, n_public=3, seed=8, style="columns")
@@ -365,9 +366,9 @@ def test_reduction_tail_geometries(orc):
         want = circ.expected_proof(r, s)
         key = bn.load_key(sections=sec)
         assert key.table["rows_w"] > 1                      # table plans: one bucket set of 2^(c-1) buckets per sum
-        for chunk, bits in ((2, 4), (4, None), (4, 6), (8, 4), (8, 6), (8, None)):
-            tune("MSM_CHUNK", chunk); tune("TAIL_BITS", bits)
-            assert bn.groth16GenProof(wit, key, r=r, s=s) == want, (chunk, bits)
+        for chunk, bits, l2 in ((2, 4, None), (4, None, None), (4, 6, None), (8, 4, None), (8, 6, None), (8, None, None), (2, None, 4), (2, 6, 4), (2, 6, 2), (4, 7, 2), (2, 7, 8)):
+            tune("MSM_CHUNK", chunk); tune("TAIL_BITS", bits); tune("TAIL_L2", l2)
+            assert bn.groth16GenProof(wit, key, r=r, s=s) == want, (chunk, bits, l2)
     finally:
         for name in names:
             tune(name, None)

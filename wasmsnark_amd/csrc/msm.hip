@@ -48,6 +48,9 @@ namespace wsnark {
 #define WS_MADD_WIDE 1     // accumulation loop keeps X wide between additions (curve.h: madd_wide); 0 = strict madd, for A/B builds
 #endif
 static const uint32_t CHUNK = 8;          // buckets per msm_chunks lane
+#ifndef WS_TAIL_L2_DEFAULT
+#define WS_TAIL_L2_DEFAULT 4      // second chunk level (msm_chunks2) of full-size table plans: chunk pairs folded per lane (1 = off)
+#endif
 
 struct MsmScratch {
     DevBuf vals_out, entries, hot, hot_sums;
@@ -760,13 +763,16 @@ template <class C>
 struct TailSets {
     typedef typename PointIO<C>::Stored St;
     const St* buckets[4];
-    St* chunkS[4];
+    St* chunkS[4];       // what the trees read: msm_chunks' pairs, or msm_chunks2's when there is a second level
     St* chunkA[4];
+    const St* l1S[4];    // msm_chunks2's input: msm_chunks' pairs
+    const St* l1A[4];
+    St* chunkW[4];       // msm_chunks2's third output (the W row's elements)
     St* rows[4];         // per piece: U_0 .. U_{logJ-1}, A [, T]; in the internal domain when a piece-reduction pass follows
     St* sums[4];         // what leaves for the host (reference format)
     const uint32_t* bstart[4];   // the plan's bucket bounds: an EMPTY bucket (no entry) is infinity whatever its slot still holds from the
     const uint32_t* bend[4];     // launch before -- msm_chunks checks the bounds, so no pass over the buckets has to clear them
-    St* half[4];                 // msm_tree: the two halves of the unmasked rows (per piece: [A half 0, A half 1, T half 0, T half 1])
+    St* half[4];                 // msm_tree: the two halves of the unmasked rows (per piece: [A half 0, A half 1, T half 0, T half 1, W half 0, W half 1])
     uint32_t* half_done[4];      // ... and their completion counters (per piece and row; zero between launches)
 };
 
@@ -788,6 +794,40 @@ __global__ __launch_bounds__(256) void msm_chunks(TailSets<C> ts, uint32_t nchun
     }
     IO::store(chunkS, j, run);
     IO::store(chunkA, j, acc);
+}
+
+// 6'. second chunk level (round 6, closing): the m2 chunk pairs (S_j, A_j), j = k m2 + i, of msm_chunks (m1 buckets each) become the
+//     pair of ONE chunk of m = m1 m2 buckets:   S'_k = sum_i S_j,   A'_k = sum_i A_j,   W_k = sum_i i S_j
+//     sum_b (b + 1) B_b over the m buckets, b = i m1 + u, is A'_k + m1 W_k: the chunk's own A_j carries (u + 1), the offset i m1 falls on
+//     S_j.  The factor m1 is not applied here: the W_k are summed like the A'_k (one more unmasked row of msm_tree, one more row of
+//     msm_rows), and the host's Horner chain, which doubles its way from the U rows (weight m 2^q) down to the A row (weight 1) anyway,
+//     adds R_W when it passes weight m1: no doubling anywhere on the GPU.
+//     Latency-bound like the trees, so it runs on their curve (one point on two / four lanes), and the two chains sit on different
+//     lanes: slots [0, npairs) run S' and W (2 m2 - 1 dependent additions), slots [npairs, 2 npairs) run A' (m2 - 1).
+template <class C>
+__global__ __launch_bounds__(256) void msm_chunks2(TailSets<C> ts, uint32_t npairs, uint32_t m2) {
+    typedef PointIO<C> IO;
+    const typename IO::Stored* __restrict__ S1 = ts.l1S[blockIdx.y];
+    const typename IO::Stored* __restrict__ A1 = ts.l1A[blockIdx.y];
+    uint32_t k = (blockIdx.x * blockDim.x + threadIdx.x) / IO::LPP;
+    if (k >= 2 * npairs) return;
+    if (k >= npairs) {
+        k -= npairs;
+        const uint64_t base = (uint64_t)k * m2;
+        typename C::Pt aa = IO::load(A1, base);
+        for (uint32_t i = 1; i < m2; i++) aa = C::add(aa, IO::load(A1, base + i));
+        IO::store(ts.chunkA[blockIdx.y], k, aa);
+        return;
+    }
+    const uint64_t base = (uint64_t)k * m2;
+    typename C::Pt run = C::infinity(), acc = C::infinity();
+    for (uint32_t i = m2 - 1; i >= 1; i--) {
+        run = C::add(run, IO::load(S1, base + i));
+        acc = C::add(acc, run);                      // -> sum_{i >= 1} i S_i
+    }
+    run = C::add(run, IO::load(S1, base));
+    IO::store(ts.chunkS[blockIdx.y], k, run);
+    IO::store(ts.chunkW[blockIdx.y], k, acc);
 }
 
 // ---------------------------------------------------------------------------
@@ -816,7 +856,7 @@ __global__ __launch_bounds__(TreeBound<C>::value) void msm_tree(TailSets<C> ts, 
     const bool masked = blockIdx.x < logJ;
     const uint32_t q = masked ? blockIdx.x : logJ + ((blockIdx.x - logJ) >> 1), half = masked ? 0 : (blockIdx.x - logJ) & 1u;
     const uint32_t slot = threadIdx.x / IO::LPP, nslots = blockDim.x / IO::LPP;
-    const St* src = (q == logJ ? chunkA : chunkS) + (uint64_t)w * J;
+    const St* src = (q == logJ ? chunkA : q == logJ + 2 ? (const St*)ts.chunkW[blockIdx.z] : chunkS) + (uint64_t)w * J;      // A; T = sum of S; W
     typename C::Pt acc = C::infinity();
     if (!masked) {
         const uint32_t Jh = (J + 1) >> 1, lo = half ? Jh : 0, hi = half ? J : Jh;
@@ -839,9 +879,9 @@ __global__ __launch_bounds__(TreeBound<C>::value) void msm_tree(TailSets<C> ts, 
     typename C::Pt r = IO::load(sh, 0);
     uint32_t finish = masked ? 1u : 0u;
     if (!masked) {
-        const uint32_t hrow = q - logJ;                              // 0: A, 1: T
-        St* hv = ts.half[blockIdx.z] + ((uint64_t)w * 2 + hrow) * 2;
-        uint32_t* done = ts.half_done[blockIdx.z] + (uint64_t)w * 2 + hrow;
+        const uint32_t hrow = q - logJ;                              // 0: A, 1: T, 2: W
+        St* hv = ts.half[blockIdx.z] + ((uint64_t)w * 3 + hrow) * 2;
+        uint32_t* done = ts.half_done[blockIdx.z] + (uint64_t)w * 3 + hrow;
         uint32_t second = 0;
         if (slot == 0) {
             IO::store(hv, half, r);
@@ -872,7 +912,7 @@ __global__ __launch_bounds__(TreeBound<C>::value) void msm_tree(TailSets<C> ts, 
 //     leaves in the reference format: logJ + 1 + log2 P rows per group for the host instead of P (logJ + 2).
 // ---------------------------------------------------------------------------
 template <class C>
-__global__ __launch_bounds__(TreeBound<C>::value) void msm_rows(TailSets<C> ts, uint32_t P, uint32_t logJ, uint32_t nsum_in, uint32_t nrows_out) {
+__global__ __launch_bounds__(TreeBound<C>::value) void msm_rows(TailSets<C> ts, uint32_t P, uint32_t logJ, uint32_t nsum_in, uint32_t nrows_out, uint32_t w_row) {
     typedef PointIO<C> IO;
     typedef typename IO::Stored St;
     const St* __restrict__ rows = ts.rows[blockIdx.z];
@@ -880,8 +920,9 @@ __global__ __launch_bounds__(TreeBound<C>::value) void msm_rows(TailSets<C> ts, 
     WS_DYN_SMEM(St, sh);
     const uint32_t r = blockIdx.x, g = blockIdx.y;
     const uint32_t slot = threadIdx.x / IO::LPP, nslots = blockDim.x / IO::LPP;
-    const uint32_t in_row = r <= logJ ? r : logJ + 1;
-    const uint32_t bit = r > logJ ? r - logJ - 1 : 0xFFFFFFFFu;
+    // (w_row: the output row of the second chunk level's W sums -- R_W = sum_v W_v, input row logJ + 2, unmasked -- or none)
+    const uint32_t in_row = r == w_row ? logJ + 2 : r <= logJ ? r : logJ + 1;
+    const uint32_t bit = (r > logJ && r != w_row) ? r - logJ - 1 : 0xFFFFFFFFu;
     typename C::Pt acc = C::infinity();
     for (uint32_t v = slot; v < P; v += nslots)
         if (bit == 0xFFFFFFFFu || ((v >> bit) & 1u)) acc = C::add(acc, IO::load(rows, ((uint64_t)g * P + v) * nsum_in + in_row));
@@ -928,6 +969,9 @@ struct MsmPlanInfo {
     // host, otherwise nsum rows per PIECE do (the round-2 / 3 arrangement, TAIL_REDUCE=0)
     uint32_t tP = 1, groups = 1, nrows = 0;
     bool reduce = false;
+    // round 6 (closing): a SECOND chunk level (msm_chunks2).  msm_chunks leaves J1 = tNB / m1 chunk pairs per piece; msm_chunks2 folds m2
+    // of them into one, so that the trees see J = J1 / m2 pairs of m = m1 m2 buckets.  m2 = 1: no second level (m = m1, J = J1).
+    uint32_t m1 = 0, m2 = 1, J1 = 0;
     uint32_t ntasks = 0, nmulti = 0;
     bool valid = false;
 };
@@ -1012,7 +1056,16 @@ static int msm_finish_t(MsmPending& P, typename H::Pt* out_host) {
         while ((1u << logP) < I.tP) logP++;
         HPt acc = H::infinity();
         for (int q = (int)I.logJ - 1; q >= 0; q--) acc = H::add(H::dbl(acc), sums[q]);
-        for (uint32_t k = 0; k < logm; k++) acc = H::dbl(acc);
+        if (I.m2 > 1) {
+            // second chunk level: R_A' + m1 R_W + m sum_q 2^q R_q -- the W row (the last one) joins the chain at weight m1
+            uint32_t logm1 = 0;
+            while ((1u << logm1) < I.m1) logm1++;
+            for (uint32_t k = logm1; k < logm; k++) acc = H::dbl(acc);
+            acc = H::add(acc, sums[I.logJ + 1 + logP]);
+            for (uint32_t k = 0; k < logm1; k++) acc = H::dbl(acc);
+        } else {
+            for (uint32_t k = 0; k < logm; k++) acc = H::dbl(acc);
+        }
         acc = H::add(acc, sums[I.logJ]);
         HPt tot = H::infinity();
         for (int pb = (int)logP - 1; pb >= 0; pb--) tot = H::add(H::dbl(tot), sums[I.logJ + 1 + (uint32_t)pb]);
@@ -1162,15 +1215,27 @@ int msm_plan_begin(Lane& L, uint64_t n, WindowShard sh, hipStream_t s, uint32_t 
         I.groups = I.flat ? 1 : I.W;
         I.tW = I.groups * I.tP;
     }
-    I.m = I.tNB < chunk ? I.tNB : chunk;
-    I.J = I.tNB / I.m;
+    I.m1 = I.tNB < chunk ? I.tNB : chunk;
+    I.J1 = I.tNB / I.m1;
+    I.m2 = 1;
+    {
+        // Second chunk level for the full-size bucket sets of table plans: the masked tree rows cost (logJ / 2 + 2) J additions per piece,
+        // i.e. half of what msm_chunks itself does at J = 4096, on workgroups that spend most of their time in a nine-step LDS tree; a
+        // second running sum over m2 chunk pairs costs 3 additions per pair and leaves the trees 1 / m2 of their elements.
+        // WSNARK_TAIL_L2 = 1 / 2 / 4 / 8 (1: off); A/B: profiles/r06_tail_l2_ab.txt
+        // (table plans whose pieces' rows are folded on the GPU: the host branch that knows the W row, msm_finish_t)
+        long v = tuning_get("TAIL_L2", (I.flat && big_set) ? WS_TAIL_L2_DEFAULT : 1);
+        if ((v == 2 || v == 4 || v == 8) && I.flat && I.tP > 1 && I.J1 >= 8u * (uint32_t)v) I.m2 = (uint32_t)v;      // (the trees keep at least eight pairs)
+    }
+    I.m = I.m1 * I.m2;
+    I.J = I.J1 / I.m2;
     while ((1u << I.logJ) < I.J) I.logJ++;
-    I.nsum = I.logJ + 1 + ((I.flat || I.tP > 1) ? 1 : 0);
+    I.nsum = I.logJ + 1 + ((I.flat || I.tP > 1) ? 1 : 0) + (I.m2 > 1 ? 1 : 0);      // U_0 .. U_{logJ-1}, A [, T [, W]]
     I.reduce = I.tP > 1;
     {
         uint32_t logP = 0;
         while ((1u << logP) < I.tP) logP++;
-        I.nrows = I.reduce ? I.logJ + 1 + logP : I.nsum;
+        I.nrows = I.reduce ? I.logJ + 1 + logP + (I.m2 > 1 ? 1 : 0) : I.nsum;      // (the W row of a second chunk level comes last)
     }
     // task length cap: twice the mean bucket load
     I.lmax = (uint32_t)(2 * (((I.flat ? total : n) + I.NB - 1) / I.NB));
@@ -1487,16 +1552,17 @@ static int msm_launch_acc(Lane& L, int which, const typename H::Aff* d_points_re
     // concurrent streams (cache thrash), and the reduction tail on another (or a high-priority) stream: docs/HISTORY.md, DESIGN.md section 5.
     WS_HIP_CHECK(S.buckets.reserve((size_t)nbuckets * sizeof(Pt)));
     WS_HIP_CHECK(S.partials.reserve((size_t)I.hot_cap * sizeof(Pt)));
-    WS_HIP_CHECK(S.chunkS.reserve((size_t)W * J * sizeof(Pt)));
-    WS_HIP_CHECK(S.chunkA.reserve((size_t)W * J * sizeof(Pt)));
+    // (level-1 chunk pairs first; with a second chunk level its W * J pairs follow them in the same buffers)
+    WS_HIP_CHECK(S.chunkS.reserve(((size_t)W * I.J1 + (I.m2 > 1 ? (size_t)2 * W * J : 0)) * sizeof(Pt)));      // S, then S' and W
+    WS_HIP_CHECK(S.chunkA.reserve(((size_t)W * I.J1 + (I.m2 > 1 ? (size_t)W * J : 0)) * sizeof(Pt)));          // A, then A'
     // rows that reach the host: nrows per group when the pieces are folded on the GPU (their nsum rows per piece then stay in
     // d_rows), nsum per piece otherwise
     const size_t sums_bytes = (I.reduce ? (size_t)I.groups * I.nrows : (size_t)W * nsum) * sizeof(Pt);
     WS_HIP_CHECK(P.d_sums.reserve(sums_bytes));
     if (I.reduce) WS_HIP_CHECK(P.d_rows.reserve((size_t)W * nsum * sizeof(Pt)));
-    WS_HIP_CHECK(S.tree_half.reserve((size_t)W * 4 * sizeof(Pt)));
+    WS_HIP_CHECK(S.tree_half.reserve((size_t)W * 6 * sizeof(Pt)));
     {
-        const size_t db = (size_t)W * 2 * sizeof(uint32_t);
+        const size_t db = (size_t)W * 3 * sizeof(uint32_t);
         if (!S.tree_done.p || S.tree_done.bytes < db) { WS_HIP_CHECK(S.tree_done.alloc(db)); WS_HIP_CHECK(hipMemsetAsync(S.tree_done.p, 0, db, s)); }
     }
     if (P.h_bytes < sums_bytes) {
@@ -1561,8 +1627,11 @@ static int msm_launch_tail(Lane& L, const int* slot_ids, int nslots, hipStream_t
     for (int k = 0; k < 4; k++) {
         MsmPending& P = slots[slot_ids[k < nslots ? k : 0]];
         ts.buckets[k] = P.S.buckets.template as<St>();
-        ts.chunkS[k] = P.S.chunkS.template as<St>();
-        ts.chunkA[k] = P.S.chunkA.template as<St>();
+        ts.l1S[k] = P.S.chunkS.template as<St>();
+        ts.l1A[k] = P.S.chunkA.template as<St>();
+        ts.chunkS[k] = P.S.chunkS.template as<St>() + (I.m2 > 1 ? (size_t)I.tW * I.J1 : 0);
+        ts.chunkA[k] = P.S.chunkA.template as<St>() + (I.m2 > 1 ? (size_t)I.tW * I.J1 : 0);
+        ts.chunkW[k] = P.S.chunkS.template as<St>() + (size_t)I.tW * I.J1 + (size_t)I.tW * I.J;
         ts.rows[k] = P.d_rows.template as<St>();
         ts.sums[k] = P.d_sums.template as<St>();
         ts.bstart[k] = ws(L).plan[P.plan_id].S.bstart.template as<uint32_t>();
@@ -1570,17 +1639,24 @@ static int msm_launch_tail(Lane& L, const int* slot_ids, int nslots, hipStream_t
         ts.half[k] = P.S.tree_half.template as<St>();
         ts.half_done[k] = P.S.tree_done.template as<uint32_t>();
     }
-    const uint32_t J = I.J, logJ = I.logJ, nsum = I.nsum, m = I.m, LPP = IO::LPP, W = I.tW;
+    const uint32_t J = I.J, logJ = I.logJ, nsum = I.nsum, LPP = IO::LPP, W = I.tW;
     KernelTimer& T = X->timer;
     T.begin("msm_chunks", s);
     {
         TailSets<CC> tc;
         static_assert(sizeof tc == sizeof ts, "same pointers");
         memcpy(&tc, &ts, sizeof tc);
-        hipLaunchKernelGGL(msm_chunks<CC>, dim3(ceil_div_u64((uint64_t)W * J * PointIO<CC>::LPP, 256), nslots), dim3(256), 0, s, tc, W * J, m);
+        for (int k = 0; k < 4; k++) { tc.chunkS[k] = const_cast<typename PointIO<CC>::Stored*>(tc.l1S[k]); tc.chunkA[k] = const_cast<typename PointIO<CC>::Stored*>(tc.l1A[k]); }
+        hipLaunchKernelGGL(msm_chunks<CC>, dim3(ceil_div_u64((uint64_t)W * I.J1 * PointIO<CC>::LPP, 256), nslots), dim3(256), 0, s, tc, W * I.J1, I.m1);
     }
     T.end(s);
     WS_HIP_CHECK(hipGetLastError());
+    if (I.m2 > 1) {
+        T.begin("msm_chunks2", s);
+        hipLaunchKernelGGL(msm_chunks2<C>, dim3(ceil_div_u64((uint64_t)2 * W * J * LPP, 256), nslots), dim3(256), 0, s, ts, W * J, I.m2);
+        T.end(s);
+        WS_HIP_CHECK(hipGetLastError());
+    }
     // one slot per element of the longest strided sum (J/2 for the masked rows); 256 slots per workgroup (at 152 VGPRs a 512-thread
     // workgroup is one per CU and a full-size tree launch takes three rounds of them; 256 threads fit three per CU: profiles/r04_s6_*)
     uint32_t tslots = 1;
@@ -1599,7 +1675,7 @@ static int msm_launch_tail(Lane& L, const int* slot_ids, int nslots, hipStream_t
         uint32_t rslots = 1;
         while (rslots < I.tP && rslots < smax && rslots * LPP < (uint32_t)TreeBound<C>::value) rslots <<= 1;
         T.begin("msm_rows", s);
-        hipLaunchKernelGGL(msm_rows<C>, dim3(I.nrows, I.groups, nslots), dim3(rslots * LPP), (size_t)rslots * sizeof(St), s, ts, I.tP, logJ, nsum, I.nrows);
+        hipLaunchKernelGGL(msm_rows<C>, dim3(I.nrows, I.groups, nslots), dim3(rslots * LPP), (size_t)rslots * sizeof(St), s, ts, I.tP, logJ, nsum, I.nrows, I.m2 > 1 ? I.nrows - 1 : 0xFFFFFFFFu);
         T.end(s);
         WS_HIP_CHECK(hipGetLastError());
         sums_bytes = (size_t)I.groups * I.nrows * sizeof(St);
