@@ -1219,12 +1219,12 @@ int msm_plan_begin(Lane& L, uint64_t n, WindowShard sh, hipStream_t s, uint32_t 
     I.J1 = I.tNB / I.m1;
     I.m2 = 1;
     {
-        // Second chunk level for the full-size bucket sets of table plans: the masked tree rows cost (logJ / 2 + 2) J additions per piece,
+        // Second chunk level for the bucket sets of table plans from 2^17 buckets on: the masked tree rows cost (logJ / 2 + 2) J additions per piece,
         // i.e. half of what msm_chunks itself does at J = 4096, on workgroups that spend most of their time in a nine-step LDS tree; a
         // second running sum over m2 chunk pairs costs 3 additions per pair and leaves the trees 1 / m2 of their elements.
         // WSNARK_TAIL_L2 = 1 / 2 / 4 / 8 (1: off); A/B: profiles/r06_tail_l2_ab.txt
         // (table plans whose pieces' rows are folded on the GPU: the host branch that knows the W row, msm_finish_t)
-        long v = tuning_get("TAIL_L2", (I.flat && big_set) ? WS_TAIL_L2_DEFAULT : 1);
+        long v = tuning_get("TAIL_L2", (I.flat && I.NB >= (1u << 17)) ? WS_TAIL_L2_DEFAULT : 1);      // (2^16 buckets and fewer: no gain measured, call c47 / c48)
         if ((v == 2 || v == 4 || v == 8) && I.flat && I.tP > 1 && I.J1 >= 8u * (uint32_t)v) I.m2 = (uint32_t)v;      // (the trees keep at least eight pairs)
     }
     I.m = I.m1 * I.m2;
