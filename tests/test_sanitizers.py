@@ -22,7 +22,7 @@ RUNS = {
     # what runs under each sanitizer: (test file, -k expression or None)
     "asan": [("tests/test_group_cpu.py", None),
              ("tests/test_key_file.py", "not js_writer"),
-             ("tests/test_prove_cpu.py", "two_proofs_in_flight or proofs_before_the_table_rows or staging_ring or key_format_errors or partial_finish or key_falls_back"),
+             ("tests/test_prove_cpu.py", "two_proofs_in_flight or proofs_before_the_table_rows or staging_ring or key_format_errors or partial_finish or key_falls_back or reduction_tail"),
              ("tests/test_emul_kernels.py", None),
              ("tests/test_dist_ntt_gloo.py", "native")],
     # (TSan with one fibre per kernel thread is ~50x the plain emulator: 15 min for the first file, 46 min for three more group tests
