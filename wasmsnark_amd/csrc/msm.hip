@@ -674,14 +674,16 @@ static const uint32_t WAVE_COMBINE_MIN = 17;
 //  leave every lane a chain of four buckets: +0.09 ms on the rank's four sums, profiles/r05_s1_shard_probe_2p20.json vs r05_s2)
 static const uint32_t CB_SMALL_MIN = 256, CB_SMALL_MAX = 4096, CB_WAVE = 256, CB_HOT = 256;
 template <class C>
-__device__ __forceinline__ typename C::PtP wave_tree_sum(typename C::PtP* sh, uint32_t lane, const typename C::Pt& mine) {
+__device__ __forceinline__ typename C::Pt wave_tree_sum(typename C::PtP* sh, uint32_t lane, const typename C::Pt& mine) {
     sh[lane] = C::pack_pt(mine);
     __syncthreads();
     for (uint32_t step = 32; step >= 1; step >>= 1) {
         if (lane < step) sh[lane] = C::pack_pt(C::add(C::unpack_pt(sh[lane]), C::unpack_pt(sh[lane + step])));
         __syncthreads();
     }
-    const typename C::PtP r = sh[0];
+    // (the sum leaves in REGISTERS: returned as the packed struct it stayed in private memory across the caller's `if (lane == 0)` --
+    //  272 / 528 bytes of scratch per lane, the only per-proof kernel with any.  Its time did not change: profiles/r06_tail_l2_ab.txt, c57)
+    const typename C::Pt r = C::unpack_pt(sh[0]);
     __syncthreads();
     return r;
 }
@@ -715,8 +717,8 @@ __global__ __launch_bounds__(64) void msm_combine_all(AccSets<C> as, uint32_t CB
             if (h.ntasks < WAVE_COMBINE_MIN) continue;
             typename C::Pt acc = C::infinity();
             for (uint32_t k = lane; k < h.ntasks; k += 64) acc = C::add(acc, C::unpack_pt(partials[h.first_partial + k]));
-            const typename C::PtP r = wave_tree_sum<C>(sh, lane, acc);
-            if (lane == 0) buckets[h.bucket] = r;
+            const typename C::Pt r = wave_tree_sum<C>(sh, lane, acc);
+            if (lane == 0) buckets[h.bucket] = C::pack_pt(r);
         }
         return;
     }
@@ -734,10 +736,10 @@ __global__ __launch_bounds__(64) void msm_combine_all(AccSets<C> as, uint32_t CB
             const uint32_t lo = sl * HOT_SLICE, hi = lo + HOT_SLICE < h.ntasks ? lo + HOT_SLICE : h.ntasks;
             typename C::Pt acc = C::infinity();
             for (uint32_t k = lo + lane; k < hi; k += 64) acc = C::add(acc, C::unpack_pt(partials[h.first_partial + k]));
-            const typename C::PtP r = wave_tree_sum<C>(sh, lane, acc);
+            const typename C::Pt r = wave_tree_sum<C>(sh, lane, acc);
             uint32_t last = 0;
             if (lane == 0) {
-                slice_sums[h.slice_base + sl] = r;
+                slice_sums[h.slice_base + sl] = C::pack_pt(r);
                 __threadfence();
                 last = atomicAdd(&done[hb], 1u) + 1 == nsl ? 1u : 0u;
             }
@@ -746,8 +748,8 @@ __global__ __launch_bounds__(64) void msm_combine_all(AccSets<C> as, uint32_t CB
             __threadfence();                                          // the other wavefronts' slice sums are visible from here on
             typename C::Pt tot = C::infinity();
             for (uint32_t k = lane; k < nsl; k += 64) tot = C::add(tot, C::unpack_pt(slice_sums[h.slice_base + k]));
-            const typename C::PtP rr = wave_tree_sum<C>(sh, lane, tot);
-            if (lane == 0) { buckets[h.bucket] = rr; done[hb] = 0; }
+            const typename C::Pt rr = wave_tree_sum<C>(sh, lane, tot);
+            if (lane == 0) { buckets[h.bucket] = C::pack_pt(rr); done[hb] = 0; }
         }
     }
 }
