@@ -401,10 +401,12 @@ def test_host_witness_paths_and_runtime_switches(bn):
     key = bn.load_key(sections=sec)
     pinned = C.c_void_p()
     bn.lib.check(bn.lib.c.wsnark_host_alloc(len(wit), C.byref(pinned)))
-    names = ("STAGE_CHUNK_KB", "STAGE_WORKERS", "MSM_CHUNK", "TAIL_BITS")
+    names = ("STAGE_CHUNK_KB", "STAGE_WORKERS", "MSM_CHUNK", "TAIL_BITS", "TAIL_L2")
     try:
         C.memmove(pinned, wit, len(wit))
-        for cfg in ({}, {"STAGE_CHUNK_KB": 64, "STAGE_WORKERS": 3}, {"STAGE_CHUNK_KB": 1024}, {"MSM_CHUNK": 8, "TAIL_BITS": 15}, {"MSM_CHUNK": 2, "TAIL_BITS": 10}):
+        # (TAIL_L2: the second chunk level of the tail, msm_chunks2 -- default 4 at this size; off, 2 and 8, and on other chunk / piece sizes)
+        for cfg in ({}, {"STAGE_CHUNK_KB": 64, "STAGE_WORKERS": 3}, {"STAGE_CHUNK_KB": 1024}, {"MSM_CHUNK": 8, "TAIL_BITS": 15}, {"MSM_CHUNK": 2, "TAIL_BITS": 10},
+                    {"TAIL_L2": 1}, {"TAIL_L2": 2}, {"TAIL_L2": 8}, {"TAIL_L2": 8, "MSM_CHUNK": 2, "TAIL_BITS": 9}, {"TAIL_L2": 2, "MSM_CHUNK": 16, "TAIL_BITS": 13}):
             for n in names:
                 bn.lib.tune(n, cfg.get(n))
             assert bn.groth16GenProof(wit, key, r=r, s=s) == want, cfg
