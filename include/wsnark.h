@@ -57,7 +57,7 @@ int wsnark_init(int device);
 /* Replaces Bn128.terminate() / worker TERMINATE (src/bn128.js:562-566, 167-169). */
 void wsnark_shutdown(void);
 const char* wsnark_last_error(void);
-/* "<device name> <gcn arch> CUs=<n>" of the device in use */
+/* "<device name> <gcn arch> CUs=<n> device=<ordinal>" of the device in use */
 const char* wsnark_device_info(void);
 
 /* Worker command G1_MULTIEXP + Bn128.g1_multiexp (src/bn128.js:102-113, 353-383;
